@@ -1,0 +1,222 @@
+/* mpn.h — C ABI of libmpn_hip.so: the MI355X (gfx950) per-image detection hot path of MultiPathNet.
+ *
+ * Drop-in boundary.  Every entry point mirrors ONE reference surface — an
+ * nn.Module:updateOutput, a utils.lua helper, or an nms.c export — and cites it.  Plain pointers and
+ * sizes only; no torch / TH types.  (The TH-struct-compatible `NMS` / `bbox_vote` pair that
+ * utils.lua:15-19 binds lives in include/mpn_libnms.h → libnms.so.)
+ *
+ * Conventions
+ *   - `d_` pointers are DEVICE (HBM) pointers on the current HIP device, fp32, contiguous, row-major,
+ *     Torch layout (NCHW images/features, [N,5] rois = {batch(1-based), x1,y1,x2,y2} 1-based pixels).
+ *   - `h_` pointers are host pointers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls enqueue work and
+ *     return; they never synchronise unless the name ends in `_host` / `_sync`.
+ *   - Return value: MPN_OK or a negative mpn_status; mpn_last_error() gives a thread-local message.
+ *     Nothing aborts, nothing allocates behind the caller's back except where a `ws` (workspace)
+ *     argument is documented.
+ *   - Integer results (argmax, keep indices, counts) are bit-exact vs the reference semantics; fp32
+ *     box arithmetic is evaluated without FMA contraction, in the reference's operation order.
+ */
+#ifndef MPN_H
+#define MPN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPN_VERSION 100
+
+typedef enum mpn_status {
+  MPN_OK = 0,
+  MPN_EINVAL = -1,   /* bad argument (null pointer, non-positive size, unsupported shape) */
+  MPN_EHIP = -2,     /* a HIP runtime call or kernel launch failed */
+  MPN_ENOMEM = -3,   /* workspace too small / allocation failed */
+  MPN_ENCCL = -4,    /* collective failure (reserved; collectives run in the host layer) */
+  MPN_ESTATE = -5    /* object used in the wrong state */
+} mpn_status;
+
+int mpn_version(void);
+const char *mpn_last_error(void);
+/* Fills name[] with the device's gcnArchName; returns MPN_EHIP when no HIP device is usable. */
+int mpn_device_info(char *name, int name_len, int *cu_count, size_t *hbm_bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * NMS family — replaces nms.c (the reference's only native code)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* nms.c:59-108 `NMS`, batched over classes (Tester_FRCNN.lua:106-125 calls it once per class).
+ *   d_scored [n_cls, m_stride, 5] {x1,y1,x2,y2,score}; class c has d_counts[c] valid rows
+ *   (d_counts == NULL -> every class has m_stride rows).
+ *   d_keep      [n_cls, m_stride, 5]  kept rows in SELECTION order (as nms.c:102-105 writes them)
+ *   d_keep_idx  [n_cls, m_stride]     original row index of each kept box (may be NULL)
+ *   d_n_keep    [n_cls]               number kept
+ * Greedy selection, IoU with the +1 convention (nms.c:14-41), suppression when IoU > thr,
+ * tie-breaking among bit-equal scores identical to nms.c:74-98 (swap + stable partition history).
+ * One 64-lane wavefront per class; boxes live in LDS.  m_stride <= MPN_NMS_MAX_BOXES. */
+#define MPN_NMS_MAX_BOXES 6144
+int mpn_nms_batched(const float *d_scored, const int *d_counts, int n_cls, int m_stride, float thr, float *d_keep,
+                    int *d_keep_idx, int *d_n_keep, void *stream);
+
+/* Single-class convenience (== utils.nms, utils.lua:29-33) on device buffers. */
+int mpn_nms(const float *d_scored, int m, float thr, float *d_keep, int *d_keep_idx, int *d_n_keep, void *stream);
+
+/* Host-buffer form used by the libnms.so drop-in: H2D, kernel, D2H, synchronous.  h_keep [m,5]. */
+int mpn_nms_host(const float *h_scored, int m, float thr, float *h_keep, int *h_keep_idx, int *n_keep);
+
+/* nms.c:110-142 `bbox_vote`: d_res[i] = score-weighted mean of all scored boxes with IoU(j,i) > thr
+ * (strict), accumulated sequentially in j order; d_res[i][4] = nms score.  d_nms [n_nms,5],
+ * d_scored [m,5], d_res [n_nms,5].  d_n_nms (device int, may be NULL) overrides n_nms at run time. */
+int mpn_bbox_vote(const float *d_nms, int n_nms, const int *d_n_nms, const float *d_scored, int m, float thr,
+                  float *d_res, void *stream);
+int mpn_bbox_vote_host(const float *h_nms, int n_nms, const float *h_scored, int m, float thr, float *h_res);
+
+/* nms.c:43-56 `boxoverlap`: IoU of n boxes [n,4] against one box (h_b[4], host). */
+int mpn_boxoverlap(const float *d_a, int n, const float *h_b, float *d_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Image / ROI preparation — ImageTransformer.lua, ImageDetect.lua
+ * ---------------------------------------------------------------------------------------------- */
+
+/* fbcoco.ImageTransformer:updateOutput (modules/ImageTransformer.lua:19-33):
+ * out[i] = (in[swap[i]]*scale - mean[i]) / std[i], f64 arithmetic rounded once to fp32
+ * (the reference transforms a DoubleTensor, ImageDetect.lua:29,44-50).  swap is 0-based;
+ * h_std == NULL skips the division.  d_in, d_out [3,H,W]. */
+int mpn_image_transform(const float *d_in, int H, int W, const int *h_swap, double scale, const double *h_mean,
+                        const double *h_std, float *d_out, void *stream);
+
+/* ImageDetect.lua:34-43: scale factor for one image (host arithmetic). */
+double mpn_pick_scale(int H, int W, double target, double max_size);
+
+/* project_im_rois (ImageDetect.lua:66-70): rois = {1, (boxes-1)*s+1}.  d_boxes [n,4] -> d_rois [n,5]. */
+int mpn_project_im_rois(const float *d_boxes, int n, double scale, float *d_rois, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * nn.Module:updateOutput mirrors
+ * ---------------------------------------------------------------------------------------------- */
+
+/* inn.ROIPooling(PW,PH,scale):updateOutput{feat, rois} (vgg.lua:28, alexnet.lua:23, resnet.lua:48,
+ * inceptionv3.lua:41, model_utils.lua:215).  d_feat [B,C,H,W], d_rois [N,5] -> d_out [N,C,PH,PW],
+ * d_argmax [N,C,PH,PW] int32 (h*W+w within the plane, -1 for an empty bin; may be NULL).
+ * start=round((x1-coord_offset)*scale), end=round((x2-coord_offset)*scale)+end_adjust, ROI forced
+ * >= 1x1, bins floor/ceil of fp32 bin size, clipped to the map, empty bin -> 0.
+ * Reference default ("v2" fix, README.md:202-203): coord_offset=1, end_adjust=0. */
+int mpn_roi_pool_forward(const float *d_feat, int B, int C, int H, int W, const float *d_rois, int N, int PH, int PW,
+                         float scale, float coord_offset, int end_adjust, float *d_out, int32_t *d_argmax,
+                         void *stream);
+
+/* nn.Foveal:updateOutput (modules/Foveal.lua:15-44): [N,5] -> [4N,5], f64 arithmetic rounded to fp32. */
+int mpn_foveal_forward(const float *d_rois, int N, float *d_out, void *stream);
+
+/* nn.ContextRegion(scale):updateOutput (modules/ContextRegion.lua:14-32): [N,5] -> [N,5]. */
+int mpn_context_region_forward(const float *d_rois, int N, double scale, float *d_out, void *stream);
+
+/* nn.BBoxNorm:updateOutput, evaluate mode (modules/BBoxNorm.lua:18-32): in place, view(-1,4)*std+mean. */
+int mpn_bbox_norm_forward(float *d_bbox, int N, int C4, const float *h_mean4, const float *h_std4, void *stream);
+
+/* nn.SelectBoxes:updateOutput (modules/SelectBoxes.lua:26-56): first arg-max class -> its 4 coords. */
+int mpn_select_boxes_forward(const float *d_scores, const float *d_bbox, int N, int C, float *d_out, void *stream);
+
+/* nn.SoftMax:updateOutput over dim 2 (ImageDetect.lua:19,189-191).  [M,C] -> [M,C]. */
+int mpn_softmax_forward(const float *d_x, int M, int C, float *d_y, void *stream);
+
+/* cudnn.SpatialConvolution(Cin,Cout,3,3,1,1,1,1):updateOutput (+ fused nn.ReLU) as in `features`
+ * (models/vgg.lua:15,25; multipathnet.lua:34-46).  NCHW in/out, d_w [Cout,Cin,3,3], d_b [Cout] or NULL.
+ * fp32 MFMA implicit GEMM.  The activations are converted to the library's channel-blocked HBM layout
+ * inside `ws`; mpn_conv3x3_workspace_bytes gives the size needed. */
+size_t mpn_conv3x3_workspace_bytes(int B, int Cin, int H, int W, int Cout);
+int mpn_conv3x3_forward(const float *d_in, int B, int Cin, int H, int W, const float *d_w, const float *d_b,
+                        int Cout, int relu, float *d_out, void *d_ws, size_t ws_bytes, void *stream);
+
+/* nn.SpatialMaxPooling(2,2,2,2):ceil():updateOutput.  [B*C,H,W] -> [B*C,ceil(H/2),ceil(W/2)]. */
+int mpn_maxpool2x2_ceil_forward(const float *d_in, int BC, int H, int W, float *d_out, void *stream);
+
+/* nn.Linear(K,N):updateOutput (+ fused nn.ReLU) (vgg.lua:16,30 `top`; model_utils.lua:105-119).
+ * y[M,N] = x[M,K] W[N,K]^T + b.  fp32 MFMA; per-output k-ascending fmaf chain, independent of M
+ * (so chunked == un-chunked exactly, test.lua:140-179). */
+int mpn_linear_forward(const float *d_x, int M, int K, const float *d_w, const float *d_b, int N, int relu,
+                       float *d_y, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * utils.lua / Tester_FRCNN.lua helpers
+ * ---------------------------------------------------------------------------------------------- */
+
+/* utils.convertFrom, 2-D path, for every 4-column class block (utils.lua:229-247,
+ * ImageDetect.lua:183-185).  d_boxes [N,4] original-image boxes, d_deltas [N,4C] -> d_out [N,4C]. */
+int mpn_bbox_decode(const float *d_boxes, const float *d_deltas, int N, int C, float *d_out, void *stream);
+
+/* Tester_FRCNN.lua:75-78: in place, x -> [1,im_w], y -> [1,im_h] on the (x,y) pairs of d_bbox. */
+int mpn_clamp_boxes(float *d_bbox, size_t n_pairs, float im_w, float im_h, void *stream);
+
+/* Tester_FRCNN.lua:106-116 for all classes j = first_cls .. C-1 at once: rows with score > thresh,
+ * in row order -> d_scored [C-first_cls, N, 5], d_counts [C-first_cls], d_src_idx (may be NULL). */
+int mpn_select_scored(const float *d_scores, const float *d_bbox, int N, int C, int first_cls, float thresh,
+                      float *d_scored, int *d_counts, int *d_src_idx, void *stream);
+
+/* utils.keep_top_k (utils.lua:75-96): threshold = k-th largest kept score over all classes (ties
+ * survive).  d_keep [n_cls, m_stride, 5] / d_n_keep [n_cls] as written by mpn_nms_batched.
+ * Writes *d_thresh (device float) and compacts survivors into d_out [max_out, 6] =
+ * {x1,y1,x2,y2,score,class(1-based, as float)} class-major, and *d_n_out (clipped to max_out). */
+int mpn_keep_top_k(const float *d_keep, const int *d_n_keep, int n_cls, int m_stride, int k, float *d_thresh,
+                   float *d_out, int max_out, int *d_n_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused per-image pipeline: Tester_FRCNN:testOne -> ImageDetect:detect -> model:forward -> NMS
+ * (Tester_FRCNN.lua:54-139, ImageDetect.lua:156-193, models/vgg.lua:23-31)
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct mpn_frcnn_config {
+  int n_conv;              /* number of 3x3 conv layers in the trunk (VGG-16: 13) */
+  const int *conv_cout;    /* [n_conv] output channels */
+  const int *pool_after;   /* [n_conv] 1 = ceil-mode 2x2 max-pool after this layer's ReLU */
+  int pooled_h, pooled_w;  /* ROIPooling bins (VGG: 7,7) */
+  float spatial_scale;     /* VGG: 1/16 */
+  int fc_dim;              /* 4096 */
+  int n_classes;           /* C incl. background (VOC: 21) */
+  int max_h, max_w;        /* largest input image (600 x 1000) */
+  int max_rois;            /* largest ROI batch (1000) */
+  double tf_scale;         /* ImageTransformer: scale, mean[3], std[3] (std[0]==0 -> none), swap[3] */
+  double tf_mean[3];
+  double tf_std[3];
+  int tf_swap[3];
+  float bbox_mean[4];      /* BBoxNorm (std[0]==0 -> module absent) */
+  float bbox_std[4];
+  float nms_thresh;        /* 0.3 */
+  float score_thresh;      /* -1.5 (Tester_FRCNN.lua:50) */
+  int top_k;               /* 100 (Tester_FRCNN.lua:163) */
+} mpn_frcnn_config;
+
+typedef struct mpn_frcnn mpn_frcnn; /* opaque */
+
+/* Builds the pipeline on the current device: allocates activations/workspace once, re-packs weights
+ * into MFMA-fragment order in HBM.  Weight pointers are DEVICE pointers in Torch layout
+ * (conv [Cout,Cin,3,3]; linear [out,in]); they are read during this call only.
+ * d_conv_w/d_conv_b: arrays (host) of n_conv device pointers. */
+int mpn_frcnn_create(const mpn_frcnn_config *cfg, const float *const *d_conv_w, const float *const *d_conv_b,
+                     const float *d_fc6_w, const float *d_fc6_b, const float *d_fc7_w, const float *d_fc7_b,
+                     const float *d_cls_w, const float *d_cls_b, const float *d_bbox_w, const float *d_bbox_b,
+                     mpn_frcnn **out);
+void mpn_frcnn_destroy(mpn_frcnn *p);
+
+/* ImageDetect:detect on a scale-1 image (getImages' resample is the identity):
+ * d_image [3,H,W] fp32 in [0,1]; d_boxes [N,4].  Outputs (all optional, device):
+ *   d_scores [N,C] softmax, d_bbox [N,4C] decoded + clamped boxes. */
+int mpn_frcnn_detect(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N, float *d_scores,
+                     float *d_bbox, void *stream);
+
+/* Tester:testOne + keep_top_k: detect, per-class NMS, global top-k.
+ *   d_dets [top_cap,6] {x1,y1,x2,y2,score,class}, *d_n_dets; raw per-class NMS results stay readable
+ *   through mpn_frcnn_nms_results until the next call. */
+int mpn_frcnn_test_one(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N, float *d_dets,
+                       int top_cap, int *d_n_dets, void *stream);
+int mpn_frcnn_nms_results(mpn_frcnn *p, const float **d_keep, const int **d_keep_idx, const int **d_n_keep,
+                          int *m_stride);
+/* Intermediate activations for parity tests: name in {"conv5","pooled","fc7","cls","bbox_raw"}. */
+int mpn_frcnn_debug_tensor(mpn_frcnn *p, const char *name, const float **d_ptr, size_t *n_elems);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPN_H */

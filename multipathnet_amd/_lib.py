@@ -1,0 +1,64 @@
+"""ctypes binding of libmpn_hip.so — the ONLY compute backend of this package.
+
+There is no CPU fallback: if the HIP library is missing, or no gfx950 device is usable, every op
+raises.  (The CPU restatement under oracle/ is test infrastructure and is never imported here.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmpn_hip.so")
+_lib = None
+
+f32p = C.POINTER(C.c_float)
+i32p = C.POINTER(C.c_int32)
+
+
+class MpnError(RuntimeError):
+    pass
+
+
+class FrcnnConfig(C.Structure):
+    """mirror of mpn_frcnn_config (include/mpn.h)"""
+    _fields_ = [
+        ("n_conv", C.c_int), ("conv_cout", C.POINTER(C.c_int)), ("pool_after", C.POINTER(C.c_int)),
+        ("pooled_h", C.c_int), ("pooled_w", C.c_int), ("spatial_scale", C.c_float), ("fc_dim", C.c_int),
+        ("n_classes", C.c_int), ("max_h", C.c_int), ("max_w", C.c_int), ("max_rois", C.c_int),
+        ("tf_scale", C.c_double), ("tf_mean", C.c_double * 3), ("tf_std", C.c_double * 3), ("tf_swap", C.c_int * 3),
+        ("bbox_mean", C.c_float * 4), ("bbox_std", C.c_float * 4), ("nms_thresh", C.c_float),
+        ("score_thresh", C.c_float), ("top_k", C.c_int),
+    ]
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load libmpn_hip.so (built in-tree by `make -C multipathnet_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise MpnError(
+            "libmpn_hip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). multipathnet_amd has no CPU fallback." % _LIB_PATH)
+    lib = C.CDLL(_LIB_PATH, mode=C.RTLD_GLOBAL)
+    lib.mpn_last_error.restype = C.c_char_p
+    lib.mpn_pick_scale.restype = C.c_double
+    lib.mpn_pick_scale.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double]
+    lib.mpn_conv3x3_workspace_bytes.restype = C.c_size_t
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise MpnError("%s failed (status %d): %s" % (what or "mpn call", rc, load().mpn_last_error().decode()))
+
+
+def require_gpu():
+    """Fail loudly unless a HIP device is usable (no silent fallback)."""
+    import torch
+    if not torch.cuda.is_available():
+        raise MpnError("multipathnet_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")

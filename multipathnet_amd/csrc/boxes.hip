@@ -1,0 +1,430 @@
+// boxes.hip — the small HBM/latency-bound kernels around the dense path: image transformer,
+// ROI projection, Foveal / ContextRegion / BBoxNorm / SelectBoxes modules, softmax, bbox decode,
+// clamp, per-class scored-box selection and the global top-k.  Each kernel cites the reference
+// lines it mirrors; fp32 arithmetic follows the reference's operation order (no FMA contraction).
+#include "mpn_internal.h"
+
+namespace mpn {
+
+// modules/ImageTransformer.lua:19-33 — f64 arithmetic, one rounding to fp32 (see mpn.h).
+__global__ void image_transform_kernel(const float *__restrict__ in, size_t plane, int s0, int s1, int s2, double scale,
+                                       double m0, double m1, double m2, double d0, double d1, double d2, int has_std,
+                                       float *__restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int c = blockIdx.y;
+  if (i >= plane) return;
+  int sc = c == 0 ? s0 : c == 1 ? s1 : s2;
+  double mean = c == 0 ? m0 : c == 1 ? m1 : m2;
+  double sd = c == 0 ? d0 : c == 1 ? d1 : d2;
+  double v = (double)in[(size_t)sc * plane + i];
+  if (scale != 1.0) v = v * scale;
+  v = v + (-mean);
+  if (has_std) v = v / sd;
+  out[(size_t)c * plane + i] = (float)v;
+}
+
+// ImageDetect.lua:66-70
+__global__ void project_rois_kernel(const float *__restrict__ boxes, int n, float s, float *__restrict__ rois) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  rois[5 * i] = 1.0f;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    float v = boxes[4 * i + f];
+    v = v + (-1.0f);
+    v = v * s;
+    v = v + 1.0f;
+    rois[5 * i + 1 + f] = v;
+  }
+}
+
+// modules/Foveal.lua:15-44 — Lua doubles, rounded to fp32 on store.
+__global__ void foveal_kernel(const float *__restrict__ rois, int n, float *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float *r = rois + 5 * (size_t)i;
+  float fid = r[0], fx = r[1], fy = r[2], fx2 = r[3], fy2 = r[4];
+  double id = fid, x = fx, y = fy, x2 = fx2, y2 = fy2;
+  double w = x2 - x, h = y2 - y;
+  float *o = out + 20 * (size_t)i;
+  o[0] = fid; o[1] = fx; o[2] = fy; o[3] = fx2; o[4] = fy2;
+  const double off[3] = {0.25, 0.5, 1.5};
+  const double mul[3] = {1.5, 2.0, 4.0};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    double xx = x - w * off[k], yy = y - h * off[k], ww = w * mul[k], hh = h * mul[k];
+    o[5 * (k + 1) + 0] = (float)id;
+    o[5 * (k + 1) + 1] = (float)xx;
+    o[5 * (k + 1) + 2] = (float)yy;
+    o[5 * (k + 1) + 3] = (float)(xx + ww);
+    o[5 * (k + 1) + 4] = (float)(yy + hh);
+  }
+}
+
+// modules/ContextRegion.lua:14-32
+__global__ void context_region_kernel(const float *__restrict__ rois, int n, float a, float b, float *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float *r = rois + 5 * (size_t)i;
+  float r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
+  float *o = out + 5 * (size_t)i;
+  o[0] = r0;
+  o[1] = a * r1 + b * r3;
+  o[2] = a * r2 + b * r4;
+  o[3] = b * r1 + a * r3;
+  o[4] = b * r2 + a * r4;
+}
+
+// modules/BBoxNorm.lua:28-29
+__global__ void bbox_norm_kernel(float *__restrict__ bbox, size_t total, float m0, float m1, float m2, float m3,
+                                 float s0, float s1, float s2, float s3) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int f = (int)(i & 3);
+  float sd = f == 0 ? s0 : f == 1 ? s1 : f == 2 ? s2 : s3;
+  float mn = f == 0 ? m0 : f == 1 ? m1 : f == 2 ? m2 : m3;
+  float v = bbox[i] * sd;
+  bbox[i] = v + mn;
+}
+
+// modules/SelectBoxes.lua:26-56 (torch.max over dim 2 returns the first maximum)
+__global__ void select_boxes_kernel(const float *__restrict__ scores, const float *__restrict__ bbox, int n, int C,
+                                    float *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float *s = scores + (size_t)i * C;
+  int best = 0;
+  float bs = s[0];
+  for (int c = 1; c < C; ++c) {
+    float v = s[c];
+    if (v > bs) { bs = v; best = c; }
+  }
+  const float *b = bbox + (size_t)i * 4 * C + 4 * best;
+  float *o = out + 4 * (size_t)i;
+  o[0] = b[0]; o[1] = b[1]; o[2] = b[2]; o[3] = b[3];
+}
+
+// nn.SoftMax over the class dim: one wave per row, shuffle reductions; exp(x-max)/sum.
+// The sum is accumulated across lanes (tree), so it matches a serial CPU softmax to ~1 ulp, not bit-exactly.
+__global__ __launch_bounds__(256) void softmax_kernel(const float *__restrict__ x, int M, int C, float *__restrict__ y) {
+  int row = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+  int lane = threadIdx.x & (kWave - 1);
+  if (row >= M) return;
+  const float *r = x + (size_t)row * C;
+  float mx = -INFINITY;
+  for (int c = lane; c < C; c += kWave) mx = fmaxf(mx, r[c]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  float sum = 0.f;
+  for (int c = lane; c < C; c += kWave) sum += expf(r[c] - mx);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+  for (int c = lane; c < C; c += kWave) y[(size_t)row * C + c] = expf(r[c] - mx) / sum;
+}
+
+// utils.lua:229-247 — one thread per (roi, class) 4-vector.
+__global__ void bbox_decode_kernel(const float *__restrict__ boxes, const float *__restrict__ deltas, int n, int C,
+                                   float *__restrict__ out, int clamp, float im_w, float im_h) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)n * C) return;
+  int i = (int)(t / C);
+  const float4 bx = *reinterpret_cast<const float4 *>(boxes + 4 * (size_t)i);
+  const float4 d = *reinterpret_cast<const float4 *>(deltas + 4 * t);
+  float xc = (bx.x + bx.z) * 0.5f, yc = (bx.y + bx.w) * 0.5f;
+  float w = bx.z - bx.x, h = bx.w - bx.y;
+  float p0 = d.x * w, p1 = d.y * h;
+  float xtc = xc + p0, ytc = yc + p1;
+  float wt = expf(d.z) * w, ht = expf(d.w) * h;
+  float hw = wt * 0.5f, hh = ht * 0.5f;
+  float4 o;
+  o.x = xtc - hw; o.y = ytc - hh; o.z = xtc + hw; o.w = ytc + hh;
+  if (clamp) {  // Tester_FRCNN.lua:75-78 fused
+    o.x = o.x < 1.0f ? 1.0f : (o.x > im_w ? im_w : o.x);
+    o.z = o.z < 1.0f ? 1.0f : (o.z > im_w ? im_w : o.z);
+    o.y = o.y < 1.0f ? 1.0f : (o.y > im_h ? im_h : o.y);
+    o.w = o.w < 1.0f ? 1.0f : (o.w > im_h ? im_h : o.w);
+  }
+  *reinterpret_cast<float4 *>(out + 4 * t) = o;
+}
+
+__global__ void clamp_kernel(float *__restrict__ bbox, size_t n_pairs, float im_w, float im_h) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pairs) return;
+  float2 v = *reinterpret_cast<float2 *>(bbox + 2 * i);
+  v.x = v.x < 1.0f ? 1.0f : (v.x > im_w ? im_w : v.x);
+  v.y = v.y < 1.0f ? 1.0f : (v.y > im_h ? im_h : v.y);
+  *reinterpret_cast<float2 *>(bbox + 2 * i) = v;
+}
+
+// Tester_FRCNN.lua:106-116 for every foreground class at once.  One block per class; rows are
+// compacted IN ROW ORDER (the order utils.nms then sees) with a ballot/popcount prefix per wave and
+// a running block offset, so the kept order is deterministic and equals the reference's.
+__global__ __launch_bounds__(256) void select_scored_kernel(const float *__restrict__ scores,
+                                                            const float *__restrict__ bbox, int n, int C,
+                                                            int first_cls, float thresh, float *__restrict__ scored,
+                                                            int *__restrict__ counts, int *__restrict__ src_idx) {
+  __shared__ int wave_cnt[4];
+  __shared__ int base_s;
+  const int cls = first_cls + blockIdx.x;
+  float *dst = scored + (size_t)blockIdx.x * n * 5;
+  int *didx = src_idx ? src_idx + (size_t)blockIdx.x * n : nullptr;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base_s = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    int i = i0 + threadIdx.x;
+    float s = 0.f;
+    bool take = false;
+    if (i < n) { s = scores[(size_t)i * C + cls]; take = s > thresh; }
+    unsigned long long mask = __ballot(take);
+    int before = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wid] = __popcll(mask);
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wid; ++w) off += wave_cnt[w];
+    if (take) {
+      int o = off + before;
+      const float4 b = *reinterpret_cast<const float4 *>(bbox + (size_t)i * 4 * C + 4 * cls);
+      float *p = dst + 5 * (size_t)o;
+      p[0] = b.x; p[1] = b.y; p[2] = b.z; p[3] = b.w; p[4] = s;
+      if (didx) didx[o] = i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) base_s += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) counts[blockIdx.x] = base_s;
+}
+
+// utils.lua:75-96.  Single block.  The k-th largest score is found by an MSB-first radix select over
+// the order-preserving integer image of the fp32 scores (4 passes x 8 bits, LDS histogram) — exact,
+// no sort, no host round trip.  Then survivors (score >= thresh) are compacted class-major, in NMS
+// selection order inside a class (= the order keep_top_k preserves).
+__device__ __forceinline__ unsigned f2key(float f) {
+  unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+  unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+
+__global__ __launch_bounds__(1024) void keep_top_k_kernel(const float *__restrict__ keep, const int *__restrict__ n_keep,
+                                                          int n_cls, int m_stride, int k, float *__restrict__ thresh_out,
+                                                          float *__restrict__ out, int max_out, int *__restrict__ n_out) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned sel_prefix, sel_rank;
+  __shared__ int total_s;
+  __shared__ int wave_cnt[16];
+  __shared__ int base_s;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    int t = 0;
+    for (int c = 0; c < n_cls; ++c) t += min(n_keep[c], m_stride);
+    total_s = t;
+    sel_prefix = 0;
+    sel_rank = (unsigned)max(min(t, k), 1);  // 1-based rank from the top
+    base_s = 0;
+  }
+  __syncthreads();
+  const int total = total_s;
+  if (total == 0) {
+    if (tid == 0) { *thresh_out = 0.0f; *n_out = 0; }  // utils.lua:77-79
+    return;
+  }
+  unsigned prefix_mask = 0;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    for (int b = tid; b < 256; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    const unsigned prefix = sel_prefix;
+    for (int c = 0; c < n_cls; ++c) {
+      int nk = min(n_keep[c], m_stride);
+      for (int j = tid; j < nk; j += blockDim.x) {
+        unsigned key = f2key(keep[((size_t)c * m_stride + j) * 5 + 4]);
+        if ((key & prefix_mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned rank = sel_rank, acc = 0;
+      int b = 255;
+      for (; b > 0; --b) {
+        if (acc + hist[b] >= rank) break;
+        acc += hist[b];
+      }
+      sel_rank = rank - acc;
+      sel_prefix = prefix | ((unsigned)b << shift);
+    }
+    prefix_mask |= 0xffu << shift;
+    __syncthreads();
+  }
+  const float thr = key2f(sel_prefix);
+  if (tid == 0) *thresh_out = thr;
+  // ordered compaction
+  const int lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
+  for (int c = 0; c < n_cls; ++c) {
+    int nk = min(n_keep[c], m_stride);
+    for (int j0 = 0; j0 < nk; j0 += blockDim.x) {
+      int j = j0 + tid;
+      bool take = false;
+      const float *row = keep + ((size_t)c * m_stride + j) * 5;
+      float s = 0.f;
+      if (j < nk) { s = row[4]; take = s >= thr; }
+      unsigned long long mask = __ballot(take);
+      int before = __popcll(mask & ((1ull << lane) - 1ull));
+      if (lane == 0) wave_cnt[wid] = __popcll(mask);
+      __syncthreads();
+      int off = base_s;
+      for (int w = 0; w < wid; ++w) off += wave_cnt[w];
+      if (take && off + before < max_out) {
+        float *o = out + 6 * (size_t)(off + before);
+        o[0] = row[0]; o[1] = row[1]; o[2] = row[2]; o[3] = row[3]; o[4] = s; o[5] = (float)(c + 1);
+      }
+      __syncthreads();
+      if (tid == 0) { int t = 0; for (int w = 0; w < nw; ++w) t += wave_cnt[w]; base_s += t; }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) *n_out = min(base_s, max_out);
+}
+
+}  // namespace mpn
+
+using namespace mpn;
+
+extern "C" int mpn_image_transform(const float *d_in, int H, int W, const int *h_swap, double scale,
+                                   const double *h_mean, const double *h_std, float *d_out, void *stream) {
+  MPN_CHECK_ARG(d_in && d_out && h_swap && h_mean && H > 0 && W > 0);
+  for (int c = 0; c < 3; ++c) MPN_CHECK_ARG(h_swap[c] >= 0 && h_swap[c] < 3);
+  MPN_CHECK_ARG(d_in != d_out);
+  size_t plane = (size_t)H * W;
+  dim3 grid((unsigned)cdiv_sz(plane, 256), 3);
+  hipLaunchKernelGGL(image_transform_kernel, grid, dim3(256), 0, as_stream(stream), d_in, plane, h_swap[0], h_swap[1],
+                     h_swap[2], scale, h_mean[0], h_mean[1], h_mean[2], h_std ? h_std[0] : 1.0, h_std ? h_std[1] : 1.0,
+                     h_std ? h_std[2] : 1.0, h_std ? 1 : 0, d_out);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+extern "C" double mpn_pick_scale(int H, int W, double target, double max_size) {
+  double mn = H < W ? H : W, mx = H < W ? W : H;
+  double s = target / mn;
+  if (round(s * mx) > max_size) s = max_size / mx;
+  return s;
+}
+
+extern "C" int mpn_project_im_rois(const float *d_boxes, int n, double scale, float *d_rois, void *stream) {
+  MPN_CHECK_ARG(n >= 0);
+  if (n == 0) return MPN_OK;
+  MPN_CHECK_ARG(d_boxes && d_rois);
+  hipLaunchKernelGGL(project_rois_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), d_boxes, n, (float)scale,
+                     d_rois);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+extern "C" int mpn_foveal_forward(const float *d_rois, int N, float *d_out, void *stream) {
+  MPN_CHECK_ARG(N >= 0);
+  if (N == 0) return MPN_OK;
+  MPN_CHECK_ARG(d_rois && d_out);
+  hipLaunchKernelGGL(foveal_kernel, dim3(cdiv(N, 256)), dim3(256), 0, as_stream(stream), d_rois, N, d_out);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+extern "C" int mpn_context_region_forward(const float *d_rois, int N, double scale, float *d_out, void *stream) {
+  MPN_CHECK_ARG(N >= 0);
+  if (N == 0) return MPN_OK;
+  MPN_CHECK_ARG(d_rois && d_out);
+  float a = (float)((1.0 + scale) / 2.0), b = (float)((1.0 - scale) / 2.0);
+  hipLaunchKernelGGL(context_region_kernel, dim3(cdiv(N, 256)), dim3(256), 0, as_stream(stream), d_rois, N, a, b, d_out);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+extern "C" int mpn_bbox_norm_forward(float *d_bbox, int N, int C4, const float *h_mean4, const float *h_std4,
+                                     void *stream) {
+  MPN_CHECK_ARG(N >= 0 && C4 >= 0 && (C4 % 4) == 0 && h_mean4 && h_std4);
+  size_t total = (size_t)N * C4;
+  if (total == 0) return MPN_OK;
+  MPN_CHECK_ARG(d_bbox);
+  hipLaunchKernelGGL(bbox_norm_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, as_stream(stream), d_bbox, total,
+                     h_mean4[0], h_mean4[1], h_mean4[2], h_mean4[3], h_std4[0], h_std4[1], h_std4[2], h_std4[3]);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+extern "C" int mpn_select_boxes_forward(const float *d_scores, const float *d_bbox, int N, int C, float *d_out,
+                                        void *stream) {
+  MPN_CHECK_ARG(N >= 0 && C > 0);
+  if (N == 0) return MPN_OK;
+  MPN_CHECK_ARG(d_scores && d_bbox && d_out);
+  hipLaunchKernelGGL(select_boxes_kernel, dim3(cdiv(N, 256)), dim3(256), 0, as_stream(stream), d_scores, d_bbox, N, C,
+                     d_out);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+extern "C" int mpn_softmax_forward(const float *d_x, int M, int C, float *d_y, void *stream) {
+  MPN_CHECK_ARG(M >= 0 && C > 0);
+  if (M == 0) return MPN_OK;
+  MPN_CHECK_ARG(d_x && d_y);
+  hipLaunchKernelGGL(softmax_kernel, dim3(cdiv(M, 4)), dim3(256), 0, as_stream(stream), d_x, M, C, d_y);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+namespace mpn {
+int launch_bbox_decode(const float *d_boxes, const float *d_deltas, int N, int C, float *d_out, int clamp, float im_w,
+                       float im_h, hipStream_t s) {
+  size_t total = (size_t)N * C;
+  hipLaunchKernelGGL(bbox_decode_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, d_boxes, d_deltas, N, C,
+                     d_out, clamp, im_w, im_h);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+}  // namespace mpn
+
+extern "C" int mpn_bbox_decode(const float *d_boxes, const float *d_deltas, int N, int C, float *d_out, void *stream) {
+  MPN_CHECK_ARG(N >= 0 && C > 0);
+  if (N == 0) return MPN_OK;
+  MPN_CHECK_ARG(d_boxes && d_deltas && d_out);
+  return launch_bbox_decode(d_boxes, d_deltas, N, C, d_out, 0, 0.f, 0.f, as_stream(stream));
+}
+
+extern "C" int mpn_clamp_boxes(float *d_bbox, size_t n_pairs, float im_w, float im_h, void *stream) {
+  if (n_pairs == 0) return MPN_OK;
+  MPN_CHECK_ARG(d_bbox);
+  hipLaunchKernelGGL(clamp_kernel, dim3((unsigned)cdiv_sz(n_pairs, 256)), dim3(256), 0, as_stream(stream), d_bbox, n_pairs,
+                     im_w, im_h);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+extern "C" int mpn_select_scored(const float *d_scores, const float *d_bbox, int N, int C, int first_cls, float thresh,
+                                 float *d_scored, int *d_counts, int *d_src_idx, void *stream) {
+  MPN_CHECK_ARG(N >= 0 && C > 0 && first_cls >= 0 && first_cls <= C && d_counts);
+  int n_cls = C - first_cls;
+  if (n_cls == 0) return MPN_OK;
+  if (N == 0) {
+    MPN_CHECK_HIP(hipMemsetAsync(d_counts, 0, sizeof(int) * n_cls, as_stream(stream)));
+    return MPN_OK;
+  }
+  MPN_CHECK_ARG(d_scores && d_bbox && d_scored);
+  hipLaunchKernelGGL(select_scored_kernel, dim3(n_cls), dim3(256), 0, as_stream(stream), d_scores, d_bbox, N, C, first_cls,
+                     thresh, d_scored, d_counts, d_src_idx);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+extern "C" int mpn_keep_top_k(const float *d_keep, const int *d_n_keep, int n_cls, int m_stride, int k, float *d_thresh,
+                              float *d_out, int max_out, int *d_n_out, void *stream) {
+  MPN_CHECK_ARG(n_cls >= 0 && m_stride >= 0 && k > 0 && max_out >= 0);
+  MPN_CHECK_ARG(d_thresh && d_n_out && (max_out == 0 || d_out));
+  MPN_CHECK_ARG(n_cls == 0 || (d_keep && d_n_keep));
+  hipLaunchKernelGGL(keep_top_k_kernel, dim3(1), dim3(1024), 0, as_stream(stream), d_keep, d_n_keep, n_cls, m_stride, k,
+                     d_thresh, d_out, max_out, d_n_out);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}

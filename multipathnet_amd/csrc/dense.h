@@ -1,0 +1,74 @@
+// dense.h — internal interface of the fp32-MFMA dense kernels (conv3x3 implicit GEMM, linear GEMM,
+// 2x2 ceil max-pool, layout converters, weight packers).  Used by the module-level C entry points
+// (dense.hip) and by the fused pipeline (pipeline.hip).
+//
+// HBM layouts (MI355X-first; chosen so that every LDS image is a linear copy of HBM and every MFMA
+// operand fetch is one conflict-free ds_read_b128):
+//
+//   C8P activation  [Cb][Hp][Wp][8] fp32, Cb = ceil(C/8).  Pixel (y,x) of channel c lives at
+//        ((c/8 * Hp + y + 1) * Wp + x + 1) * 8 + c%8.  Row 0, column 0 and everything at/after row
+//        H+1 / column W+1 is a ZERO halo: the 3x3 conv's padding and the ragged tile edges are read
+//        straight from HBM with no bounds checks.  Pad channels (c >= C) are zero.
+//   C8 matrix       [K/8][Mp][8] fp32 — the same thing for a [M,K] matrix (rows = "pixels").
+//   packed conv W   [Cin8/8][9][CoutP][8]  (tap = ky*3+kx; element j of the last dim = cin chunk*8+j)
+//   packed linear W [K8/8][NP][8]
+//   The k-pair of one v_mfma_f32_32x32x2_f32 is (cin j, cin j+4) of a chunk: lanes 0-31 fetch floats
+//   0-3 of the 32-byte pixel/row record, lanes 32-63 floats 4-7, identically for both operands.
+#pragma once
+#include "mpn_internal.h"
+
+namespace mpn {
+
+struct Act {      // C8P activation view
+  float *p;
+  int C, H, W;    // logical dims
+  int Hp, Wp;     // physical padded dims (rows, cols)
+  __host__ __device__ int Cb() const { return (C + 7) / 8; }
+  __host__ __device__ size_t plane() const { return (size_t)Hp * Wp * 8; }  // floats per channel block
+  __host__ __device__ size_t elems() const { return plane() * Cb(); }
+};
+
+// physical dims for a logical HxW map: 1 halo row/col in front, >= 1 behind, rounded so that whole
+// conv tiles (8 rows x 32 cols + halo) can be read without leaving the allocation.
+inline int act_hp(int H) { return ((H + 7) / 8) * 8 + 2; }
+inline int act_wp(int W) { return ((W + 31) / 32) * 32 + 2; }
+inline Act make_act(float *p, int C, int H, int W) { return Act{p, C, H, W, act_hp(H), act_wp(W)}; }
+inline size_t act_bytes(int C, int H, int W) { return (size_t)((C + 7) / 8) * act_hp(H) * act_wp(W) * 8 * sizeof(float); }
+
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+inline int conv_coutp(int Cout) { return round_up(Cout, 128); }
+inline size_t conv_wpk_elems(int Cin, int Cout) { return (size_t)((Cin + 7) / 8) * 9 * conv_coutp(Cout) * 8; }
+inline int lin_np(int N) { return round_up(N, 128); }
+inline int lin_mp(int M) { return round_up(M, 128); }
+inline size_t lin_wpk_elems(int K, int N) { return (size_t)((K + 7) / 8) * lin_np(N) * 8; }
+inline size_t mat_c8_elems(int M, int K) { return (size_t)((K + 7) / 8) * lin_mp(M) * 8; }
+
+// --- packers / converters (all enqueue on `s`) -------------------------------------------------
+int pack_conv_weights(const float *d_w, const float *d_b, int Cin, int Cout, float *d_wpk, float *d_bpk, hipStream_t s);
+// inner: K index permutation k_src = (q/inner*8 + j)*inner + q%inner for chunk q, element j
+// (inner=1: plain; inner=PH*PW: fc6 behind a channel-blocked ROI pool).
+int pack_linear_weights(const float *d_w, const float *d_b, int K, int N, int inner, float *d_wpk, float *d_bpk,
+                        hipStream_t s);
+int nchw_to_c8p(const float *d_in, int C, int H, int W, Act out, hipStream_t s);   // also zeroes pad channels
+int c8p_to_nchw(Act in, float *d_out, hipStream_t s);
+int rowmajor_to_c8(const float *d_x, int M, int K, float *d_c8, hipStream_t s);
+int c8_to_rowmajor(const float *d_c8, int M, int N, float *d_y, hipStream_t s);
+// image transformer fused with the NCHW->C8P conversion (channels 3..7 zero)
+int image_transform_c8p(const float *d_in, int H, int W, const int *swap, double scale, const double *mean,
+                        const double *std, int has_std, Act out, hipStream_t s);
+
+// --- compute ------------------------------------------------------------------------------------
+// out = relu?(conv3x3(in) + b); optional fused ceil-mode 2x2 max-pool writes `pooled` as well
+// (out.p may be null when only the pooled map is needed).
+int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int relu, Act out, Act pooled, hipStream_t s);
+int maxpool2x2_c8p(Act in, Act out, hipStream_t s);
+// y = relu?(x W^T + b).  x: C8 matrix [K8/8][Mp][8]; y: C8 matrix [NP/8][Mp][8] (y_c8) and/or
+// row-major [M,N] (y_rm); either may be null.
+int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float *d_bpk, int N, int relu, float *d_y_c8,
+              float *d_y_rm, hipStream_t s);
+// ROI max-pool reading a C8P feature map and writing the C8 matrix the fc6 GEMM consumes:
+// chunk q = cb*PH*PW + bin, row = roi.  argmax (optional) [N,C,PH,PW] int32 as the NCHW kernel.
+int roi_pool_c8(Act feat, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset, int end_adjust,
+                float *d_x_c8, int32_t *d_argmax, hipStream_t s);
+
+}  // namespace mpn

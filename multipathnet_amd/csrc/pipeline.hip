@@ -1,0 +1,387 @@
+// pipeline.hip — the fused per-image path: Tester_FRCNN:testOne -> ImageDetect:detect ->
+// model:forward (models/vgg.lua:23-31) -> per-class NMS -> keep_top_k, as ONE stream of kernels with
+// no host synchronisation between the image upload and the final detections.
+//
+// Memory plan (sized for 288 GB HBM, nothing is re-used to save bytes): every layer output has its
+// own C8P buffer whose halo is zeroed once; packed weights (fc6 alone 411 MB) stay resident; the
+// ROI-pooled matrix, fc activations, scored boxes and NMS outputs are fixed-capacity buffers
+// allocated at create time.  The reference's 500-ROI chunking (ImageDetect.lua:116-124) is not
+// needed: all ROIs go through each GEMM at once (rows are independent, results identical), so the
+// fc weights stream from HBM once per image instead of twice.
+#include <string>
+#include <vector>
+
+#include "dense.h"
+
+namespace mpn {
+int launch_bbox_decode(const float *d_boxes, const float *d_deltas, int N, int C, float *d_out, int clamp, float im_w,
+                       float im_h, hipStream_t s);
+
+// softmax over head[:, 0:C] (row stride ld) -> scores [M,C]; one wave per row
+__global__ __launch_bounds__(256) void head_softmax_kernel(const float *__restrict__ head, int ld, int M, int C,
+                                                           float *__restrict__ scores) {
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float *r = head + (size_t)row * ld;
+  float mx = -INFINITY;
+  for (int c = lane; c < C; c += 64) mx = fmaxf(mx, r[c]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  float sum = 0.f;
+  for (int c = lane; c < C; c += 64) sum += expf(r[c] - mx);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+  for (int c = lane; c < C; c += 64) scores[(size_t)row * C + c] = expf(r[c] - mx) / sum;
+}
+
+// BBoxNorm (modules/BBoxNorm.lua:28-29) + convertFrom (utils.lua:229-247) + clamp
+// (Tester_FRCNN.lua:75-78) on head[:, C:5C]; thread per (roi, class)
+__global__ void head_decode_kernel(const float *__restrict__ head, int ld, int M, int C, const float *__restrict__ boxes,
+                                   int has_norm, float m0, float m1, float m2, float m3, float s0, float s1, float s2,
+                                   float s3, float im_w, float im_h, float *__restrict__ raw, float *__restrict__ out) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)M * C) return;
+  int i = (int)(t / C), c = (int)(t - (size_t)i * C);
+  const float *d = head + (size_t)i * ld + C + 4 * c;
+  float d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];
+  if (has_norm) {
+    d0 = d0 * s0; d0 = d0 + m0;
+    d1 = d1 * s1; d1 = d1 + m1;
+    d2 = d2 * s2; d2 = d2 + m2;
+    d3 = d3 * s3; d3 = d3 + m3;
+  }
+  if (raw) { float *r = raw + 4 * t; r[0] = d0; r[1] = d1; r[2] = d2; r[3] = d3; }
+  const float *bx = boxes + 4 * (size_t)i;
+  float x1 = bx[0], y1 = bx[1], x2 = bx[2], y2 = bx[3];
+  float xc = (x1 + x2) * 0.5f, yc = (y1 + y2) * 0.5f;
+  float w = x2 - x1, h = y2 - y1;
+  float p0 = d0 * w, p1 = d1 * h;
+  float xtc = xc + p0, ytc = yc + p1;
+  float wt = expf(d2) * w, ht = expf(d3) * h;
+  float hw = wt * 0.5f, hh = ht * 0.5f;
+  float o0 = xtc - hw, o1 = ytc - hh, o2 = xtc + hw, o3 = ytc + hh;
+  o0 = o0 < 1.0f ? 1.0f : (o0 > im_w ? im_w : o0);
+  o2 = o2 < 1.0f ? 1.0f : (o2 > im_w ? im_w : o2);
+  o1 = o1 < 1.0f ? 1.0f : (o1 > im_h ? im_h : o1);
+  o3 = o3 < 1.0f ? 1.0f : (o3 > im_h ? im_h : o3);
+  float *o = out + 4 * t;
+  o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3;
+}
+
+// pooled C8 matrix [cb*PP+bin][Mp][8] -> reference order [N, C*PP] (debug / parity only)
+__global__ void unpack_pooled_kernel(const float *__restrict__ xc8, int N, int C, int PP, int Mp, float *__restrict__ out) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)N * C * PP;
+  if (t >= total) return;
+  int bin = (int)(t % PP); size_t r = t / PP;
+  int c = (int)(r % C); int n = (int)(r / C);
+  out[t] = xc8[(((size_t)(c >> 3) * PP + bin) * Mp + n) * 8 + (c & 7)];
+}
+
+__global__ void copy_cols_kernel(const float *__restrict__ src, int ld, int col0, int M, int ncols, float *__restrict__ dst) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)M * ncols) return;
+  int m = (int)(t / ncols), c = (int)(t - (size_t)m * ncols);
+  dst[t] = src[(size_t)m * ld + col0 + c];
+}
+}  // namespace mpn
+
+using namespace mpn;
+
+struct ConvLayer {
+  int Cin, Cout, pool;
+  float *wpk = nullptr, *bpk = nullptr;
+  float *out = nullptr;     // C8P buffer for the conv output (max image size)
+  float *pooled = nullptr;  // C8P buffer for the pooled output (when pool)
+};
+
+struct mpn_frcnn {
+  mpn_frcnn_config cfg;
+  std::vector<int> cout, pool_after;
+  std::vector<ConvLayer> conv;
+  float *img_c8p = nullptr;
+  size_t act_total_bytes = 0;
+  std::vector<std::pair<float *, size_t>> act_bufs;  // for re-zeroing when the image size changes
+  int last_h = -1, last_w = -1;
+  int feat_c = 0;
+  // head
+  int K6 = 0, Mp = 0, n_head = 0;
+  float *w6 = nullptr, *b6 = nullptr, *w7 = nullptr, *b7 = nullptr, *wh = nullptr, *bh = nullptr;
+  float *rois = nullptr, *x6 = nullptr, *y6 = nullptr, *y7 = nullptr, *head = nullptr;
+  float *scores = nullptr, *bbox = nullptr, *bbox_raw = nullptr;
+  float *scored = nullptr, *keep = nullptr, *thresh = nullptr;
+  int *counts = nullptr, *keep_idx = nullptr, *n_keep = nullptr;
+  float *dbg = nullptr;
+  size_t dbg_bytes = 0;
+  int last_n = 0;
+  int fuse_pool = 1;
+  std::vector<void *> allocs;
+};
+
+static int g_fuse_pool = 1;
+extern "C" void mpn_debug_set_fuse_pool(int v) { g_fuse_pool = v; }
+
+template <typename T>
+static int dev_alloc(mpn_frcnn *p, T **ptr, size_t bytes, bool zero) {
+  void *q = nullptr;
+  hipError_t e = hipMalloc(&q, bytes ? bytes : 16);
+  if (e != hipSuccess) { set_error("mpn_frcnn_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return MPN_ENOMEM; }
+  if (zero) {
+    e = hipMemset(q, 0, bytes ? bytes : 16);
+    if (e != hipSuccess) { set_error("mpn_frcnn_create: hipMemset failed: %s", hipGetErrorString(e)); return MPN_EHIP; }
+  }
+  p->allocs.push_back(q);
+  *ptr = static_cast<T *>(q);
+  return MPN_OK;
+}
+
+extern "C" void mpn_frcnn_destroy(mpn_frcnn *p) {
+  if (!p) return;
+  (void)hipDeviceSynchronize();
+  for (void *q : p->allocs) (void)hipFree(q);
+  if (p->dbg) (void)hipFree(p->dbg);
+  delete p;
+}
+
+extern "C" int mpn_frcnn_create(const mpn_frcnn_config *cfg, const float *const *d_conv_w, const float *const *d_conv_b,
+                                const float *d_fc6_w, const float *d_fc6_b, const float *d_fc7_w, const float *d_fc7_b,
+                                const float *d_cls_w, const float *d_cls_b, const float *d_bbox_w, const float *d_bbox_b,
+                                mpn_frcnn **out) {
+  MPN_CHECK_ARG(cfg && d_conv_w && d_conv_b && d_fc6_w && d_fc7_w && d_cls_w && d_bbox_w && out);
+  MPN_CHECK_ARG(cfg->n_conv > 0 && cfg->conv_cout && cfg->pool_after);
+  MPN_CHECK_ARG(cfg->pooled_h > 0 && cfg->pooled_w > 0 && cfg->fc_dim > 0 && cfg->n_classes > 1);
+  MPN_CHECK_ARG(cfg->max_h > 0 && cfg->max_w > 0 && cfg->max_rois > 0 && cfg->max_rois <= MPN_NMS_MAX_BOXES);
+  MPN_CHECK_ARG(cfg->top_k > 0);
+  mpn_frcnn *p = new mpn_frcnn();
+  p->cfg = *cfg;
+  p->cout.assign(cfg->conv_cout, cfg->conv_cout + cfg->n_conv);
+  p->pool_after.assign(cfg->pool_after, cfg->pool_after + cfg->n_conv);
+  p->cfg.conv_cout = p->cout.data();
+  p->cfg.pool_after = p->pool_after.data();
+  int rc = MPN_OK;
+#define TRY(x) do { rc = (x); if (rc != MPN_OK) { mpn_frcnn_destroy(p); return rc; } } while (0)
+  // ---- trunk buffers + packed weights
+  int h = cfg->max_h, w = cfg->max_w, cin = 3;
+  size_t b = act_bytes(3, h, w);
+  TRY(dev_alloc(p, &p->img_c8p, b, true));
+  p->act_bufs.push_back({p->img_c8p, b});
+  for (int l = 0; l < cfg->n_conv; ++l) {
+    MPN_CHECK_ARG(d_conv_w[l] != nullptr);
+    ConvLayer L;
+    L.Cin = cin; L.Cout = p->cout[l]; L.pool = p->pool_after[l];
+    TRY(dev_alloc(p, &L.wpk, conv_wpk_elems(L.Cin, L.Cout) * sizeof(float), false));
+    TRY(dev_alloc(p, &L.bpk, (size_t)conv_coutp(L.Cout) * sizeof(float), false));
+    TRY(pack_conv_weights(d_conv_w[l], d_conv_b[l], L.Cin, L.Cout, L.wpk, L.bpk, nullptr));
+    b = act_bytes(L.Cout, h, w);
+    TRY(dev_alloc(p, &L.out, b, true));
+    p->act_bufs.push_back({L.out, b});
+    if (L.pool) {
+      h = (h + 1) / 2; w = (w + 1) / 2;
+      b = act_bytes(L.Cout, h, w);
+      TRY(dev_alloc(p, &L.pooled, b, true));
+      p->act_bufs.push_back({L.pooled, b});
+    }
+    cin = L.Cout;
+    p->conv.push_back(L);
+  }
+  p->feat_c = cin;
+  // ---- head
+  const int PP = cfg->pooled_h * cfg->pooled_w, C = cfg->n_classes, F = cfg->fc_dim;
+  MPN_CHECK_ARG(p->feat_c % 8 == 0);
+  p->K6 = p->feat_c * PP;
+  p->Mp = lin_mp(cfg->max_rois);
+  p->n_head = 5 * C;
+  const int K6_32 = round_up(p->K6, 32), F32 = round_up(F, 32);
+  TRY(dev_alloc(p, &p->w6, lin_wpk_elems(K6_32, F) * sizeof(float), false));
+  TRY(dev_alloc(p, &p->b6, (size_t)lin_np(F) * sizeof(float), false));
+  TRY(pack_linear_weights(d_fc6_w, d_fc6_b, p->K6, F, PP, p->w6, p->b6, nullptr));
+  TRY(dev_alloc(p, &p->w7, lin_wpk_elems(F32, F) * sizeof(float), false));
+  TRY(dev_alloc(p, &p->b7, (size_t)lin_np(F) * sizeof(float), false));
+  TRY(pack_linear_weights(d_fc7_w, d_fc7_b, F, F, 1, p->w7, p->b7, nullptr));
+  {  // cls and bbox heads share their input -> one [5C, F] GEMM (model_utils.lua:105-119 ConcatTable)
+    float *tmp_w = nullptr, *tmp_b = nullptr;
+    TRY(dev_alloc(p, &tmp_w, (size_t)5 * C * F * sizeof(float), false));
+    TRY(dev_alloc(p, &tmp_b, (size_t)5 * C * sizeof(float), true));
+    hipError_t e = hipMemcpy(tmp_w, d_cls_w, (size_t)C * F * sizeof(float), hipMemcpyDeviceToDevice);
+    if (e == hipSuccess) e = hipMemcpy(tmp_w + (size_t)C * F, d_bbox_w, (size_t)4 * C * F * sizeof(float), hipMemcpyDeviceToDevice);
+    if (e == hipSuccess && d_cls_b) e = hipMemcpy(tmp_b, d_cls_b, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice);
+    if (e == hipSuccess && d_bbox_b) e = hipMemcpy(tmp_b + C, d_bbox_b, (size_t)4 * C * sizeof(float), hipMemcpyDeviceToDevice);
+    if (e != hipSuccess) { set_error("mpn_frcnn_create: head weight copy failed: %s", hipGetErrorString(e)); mpn_frcnn_destroy(p); return MPN_EHIP; }
+    TRY(dev_alloc(p, &p->wh, lin_wpk_elems(F32, 5 * C) * sizeof(float), false));
+    TRY(dev_alloc(p, &p->bh, (size_t)lin_np(5 * C) * sizeof(float), false));
+    TRY(pack_linear_weights(tmp_w, tmp_b, F, 5 * C, 1, p->wh, p->bh, nullptr));
+  }
+  const size_t M = cfg->max_rois;
+  TRY(dev_alloc(p, &p->rois, M * 5 * sizeof(float), true));
+  TRY(dev_alloc(p, &p->x6, (size_t)(K6_32 / 8) * p->Mp * 8 * sizeof(float), true));
+  TRY(dev_alloc(p, &p->y6, (size_t)(lin_np(F) / 8) * p->Mp * 8 * sizeof(float), true));
+  TRY(dev_alloc(p, &p->y7, (size_t)(lin_np(F) / 8) * p->Mp * 8 * sizeof(float), true));
+  TRY(dev_alloc(p, &p->head, M * 5 * C * sizeof(float), true));
+  TRY(dev_alloc(p, &p->scores, M * C * sizeof(float), true));
+  TRY(dev_alloc(p, &p->bbox, M * 4 * C * sizeof(float), true));
+  TRY(dev_alloc(p, &p->bbox_raw, M * 4 * C * sizeof(float), true));
+  TRY(dev_alloc(p, &p->scored, (size_t)(C - 1) * M * 5 * sizeof(float), true));
+  TRY(dev_alloc(p, &p->keep, (size_t)(C - 1) * M * 5 * sizeof(float), true));
+  TRY(dev_alloc(p, &p->keep_idx, (size_t)(C - 1) * M * sizeof(int), true));
+  TRY(dev_alloc(p, &p->counts, (size_t)(C - 1) * sizeof(int), true));
+  TRY(dev_alloc(p, &p->n_keep, (size_t)(C - 1) * sizeof(int), true));
+  TRY(dev_alloc(p, &p->thresh, 16, true));
+#undef TRY
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) { set_error("mpn_frcnn_create: %s", hipGetErrorString(e)); mpn_frcnn_destroy(p); return MPN_EHIP; }
+  *out = p;
+  return MPN_OK;
+}
+
+static int run_trunk(mpn_frcnn *p, const float *d_image, int H, int W, hipStream_t s, Act *feat_out) {
+  const mpn_frcnn_config &c = p->cfg;
+  if (H != p->last_h || W != p->last_w) {  // halo positions move with the image size: re-zero once
+    for (auto &b : p->act_bufs) MPN_CHECK_HIP(hipMemsetAsync(b.first, 0, b.second, s));
+    p->last_h = H; p->last_w = W;
+  }
+  Act cur = make_act(p->img_c8p, 3, H, W);
+  int rc = image_transform_c8p(d_image, H, W, c.tf_swap, c.tf_scale, c.tf_mean, c.tf_std, c.tf_std[0] != 0.0, cur, s);
+  if (rc) return rc;
+  int h = H, w = W;
+  for (auto &L : p->conv) {
+    Act out = make_act(L.out, L.Cout, h, w);
+    if (L.pool) {
+      Act pooled = make_act(L.pooled, L.Cout, (h + 1) / 2, (w + 1) / 2);
+      if (g_fuse_pool) {
+        rc = conv3x3_c8p(cur, L.wpk, L.bpk, L.Cout, 1, Act{}, pooled, s);
+        if (rc == MPN_EINVAL) {  // tile variant without a fused pool: fall back to two kernels
+          rc = conv3x3_c8p(cur, L.wpk, L.bpk, L.Cout, 1, out, Act{}, s);
+          if (rc == MPN_OK) rc = maxpool2x2_c8p(out, pooled, s);
+        }
+      } else {
+        rc = conv3x3_c8p(cur, L.wpk, L.bpk, L.Cout, 1, out, Act{}, s);
+        if (rc == MPN_OK) rc = maxpool2x2_c8p(out, pooled, s);
+      }
+      if (rc) return rc;
+      cur = pooled; h = pooled.H; w = pooled.W;
+    } else {
+      rc = conv3x3_c8p(cur, L.wpk, L.bpk, L.Cout, 1, out, Act{}, s);
+      if (rc) return rc;
+      cur = out;
+    }
+  }
+  *feat_out = cur;
+  return MPN_OK;
+}
+
+static int run_detect(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N, hipStream_t s) {
+  const mpn_frcnn_config &c = p->cfg;
+  MPN_CHECK_ARG(p && d_image && d_boxes);
+  MPN_CHECK_ARG(H > 0 && W > 0 && H <= c.max_h && W <= c.max_w && N > 0 && N <= c.max_rois);
+  // ImageDetect.lua:34-43 — only the scale==1 path exists on the device (no bilinear resample);
+  // the host layer resizes other images before calling.
+  if (mpn_pick_scale(H, W, 600.0, 1000.0) != 1.0 && !(H == c.max_h && W == c.max_w)) {
+    // non-canonical sizes are still processed at scale 1; the caller owns the resample.
+  }
+  Act feat;
+  int rc = run_trunk(p, d_image, H, W, s, &feat);
+  if (rc) return rc;
+  rc = mpn_project_im_rois(d_boxes, N, 1.0, p->rois, s);
+  if (rc) return rc;
+  const int C = c.n_classes, F = c.fc_dim;
+  rc = roi_pool_c8(feat, p->rois, N, c.pooled_h, c.pooled_w, c.spatial_scale, 1.0f, 0, p->x6, nullptr, s);
+  if (rc) return rc;
+  rc = linear_c8(p->x6, N, p->K6, p->w6, p->b6, F, 1, p->y6, nullptr, s);
+  if (rc) return rc;
+  rc = linear_c8(p->y6, N, F, p->w7, p->b7, F, 1, p->y7, nullptr, s);
+  if (rc) return rc;
+  rc = linear_c8(p->y7, N, F, p->wh, p->bh, 5 * C, 0, nullptr, p->head, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(head_softmax_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, p->head, 5 * C, N, C, p->scores);
+  MPN_CHECK_LAUNCH();
+  const bool norm = c.bbox_std[0] != 0.0f;
+  hipLaunchKernelGGL(head_decode_kernel, dim3((unsigned)cdiv_sz((size_t)N * C, 256)), dim3(256), 0, s, p->head, 5 * C, N, C, d_boxes,
+                     norm ? 1 : 0, c.bbox_mean[0], c.bbox_mean[1], c.bbox_mean[2], c.bbox_mean[3], c.bbox_std[0], c.bbox_std[1],
+                     c.bbox_std[2], c.bbox_std[3], (float)W, (float)H, p->bbox_raw, p->bbox);
+  MPN_CHECK_LAUNCH();
+  p->last_n = N;
+  return MPN_OK;
+}
+
+extern "C" int mpn_frcnn_detect(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N,
+                                float *d_scores, float *d_bbox, void *stream) {
+  MPN_CHECK_ARG(p != nullptr);
+  hipStream_t s = as_stream(stream);
+  int rc = run_detect(p, d_image, H, W, d_boxes, N, s);
+  if (rc) return rc;
+  const int C = p->cfg.n_classes;
+  if (d_scores) MPN_CHECK_HIP(hipMemcpyAsync(d_scores, p->scores, (size_t)N * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (d_bbox) MPN_CHECK_HIP(hipMemcpyAsync(d_bbox, p->bbox, (size_t)N * 4 * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return MPN_OK;
+}
+
+extern "C" int mpn_frcnn_test_one(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N,
+                                  float *d_dets, int top_cap, int *d_n_dets, void *stream) {
+  MPN_CHECK_ARG(p != nullptr && d_n_dets && (top_cap == 0 || d_dets) && top_cap >= 0);
+  hipStream_t s = as_stream(stream);
+  int rc = run_detect(p, d_image, H, W, d_boxes, N, s);
+  if (rc) return rc;
+  const mpn_frcnn_config &c = p->cfg;
+  const int C = c.n_classes;
+  // Tester_FRCNN.lua:106-125: per class j=1..C-1 select (score > thresh) -> NMS.  The class slabs
+  // have stride max_rois so that mpn_frcnn_nms_results stays valid across calls with different N.
+  rc = mpn_select_scored(p->scores, p->bbox, N, C, 1, c.score_thresh, p->scored, p->counts, nullptr, s);
+  if (rc) return rc;
+  rc = mpn_nms_batched(p->scored, p->counts, C - 1, N, c.nms_thresh, p->keep, p->keep_idx, p->n_keep, s);
+  if (rc) return rc;
+  return mpn_keep_top_k(p->keep, p->n_keep, C - 1, N, c.top_k, p->thresh, d_dets, top_cap, d_n_dets, s);
+}
+
+extern "C" int mpn_frcnn_nms_results(mpn_frcnn *p, const float **d_keep, const int **d_keep_idx, const int **d_n_keep,
+                                     int *m_stride) {
+  MPN_CHECK_ARG(p != nullptr);
+  if (d_keep) *d_keep = p->keep;
+  if (d_keep_idx) *d_keep_idx = p->keep_idx;
+  if (d_n_keep) *d_n_keep = p->n_keep;
+  if (m_stride) *m_stride = p->last_n;
+  return MPN_OK;
+}
+
+extern "C" int mpn_frcnn_debug_tensor(mpn_frcnn *p, const char *name, const float **d_ptr, size_t *n_elems) {
+  MPN_CHECK_ARG(p && name && d_ptr && n_elems);
+  if (p->last_h <= 0 || p->last_n <= 0) { set_error("mpn_frcnn_debug_tensor: run detect first"); return MPN_ESTATE; }
+  const mpn_frcnn_config &c = p->cfg;
+  const int N = p->last_n, C = c.n_classes, F = c.fc_dim, PP = c.pooled_h * c.pooled_w;
+  int h = p->last_h, w = p->last_w;
+  for (auto &L : p->conv) if (L.pool) { h = (h + 1) / 2; w = (w + 1) / 2; }
+  std::string nm(name);
+  size_t n = 0;
+  if (nm == "conv5") n = (size_t)p->feat_c * h * w;
+  else if (nm == "pooled") n = (size_t)N * p->feat_c * PP;
+  else if (nm == "fc7") n = (size_t)N * F;
+  else if (nm == "cls") n = (size_t)N * C;
+  else if (nm == "bbox_raw") n = (size_t)N * 4 * C;
+  else { set_error("mpn_frcnn_debug_tensor: unknown tensor '%s'", name); return MPN_EINVAL; }
+  MPN_CHECK_HIP(hipDeviceSynchronize());
+  if (n * sizeof(float) > p->dbg_bytes) {
+    if (p->dbg) (void)hipFree(p->dbg);
+    p->dbg = nullptr; p->dbg_bytes = 0;
+    MPN_CHECK_HIP(hipMalloc(&p->dbg, n * sizeof(float)));
+    p->dbg_bytes = n * sizeof(float);
+  }
+  int rc = MPN_OK;
+  if (nm == "conv5") {
+    const ConvLayer &L = p->conv.back();
+    rc = c8p_to_nchw(make_act(L.pool ? L.pooled : L.out, p->feat_c, h, w), p->dbg, nullptr);
+  } else if (nm == "pooled") {
+    hipLaunchKernelGGL(unpack_pooled_kernel, dim3((unsigned)cdiv_sz(n, 256)), dim3(256), 0, nullptr, p->x6, N, p->feat_c, PP, lin_mp(N), p->dbg);
+    MPN_CHECK_LAUNCH();
+  } else if (nm == "fc7") {
+    rc = c8_to_rowmajor(p->y7, N, F, p->dbg, nullptr);  // rows at stride lin_mp(N), as linear_c8 wrote them
+  } else if (nm == "cls") {
+    hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)cdiv_sz(n, 256)), dim3(256), 0, nullptr, p->head, 5 * C, 0, N, C, p->dbg);
+    MPN_CHECK_LAUNCH();
+  } else {
+    MPN_CHECK_HIP(hipMemcpy(p->dbg, p->bbox_raw, n * sizeof(float), hipMemcpyDeviceToDevice));
+  }
+  if (rc) return rc;
+  MPN_CHECK_HIP(hipDeviceSynchronize());
+  *d_ptr = p->dbg;
+  *n_elems = n;
+  return MPN_OK;
+}

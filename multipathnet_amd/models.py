@@ -1,0 +1,160 @@
+"""Model objects for the hot path (models/vgg.lua, models/alexnet.lua shape of graph).
+
+`FastRCNN` owns one fused device pipeline (mpn_frcnn_* in include/mpn.h): trunk -> ROIPooling ->
+fc6/fc7 -> {cls, bbox} (+BBoxNorm) -> softmax/decode/clamp -> per-class NMS -> top-k.  Weights are
+given in Torch layout (conv [Cout,Cin,3,3], linear [out,in]) and re-packed once into HBM-resident
+MFMA-fragment order.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import FrcnnConfig, check, f32p
+from .nn import _f, _i, _stream
+
+VGG16_CFG = [64, 64, "P", 128, 128, "P", 256, 256, 256, "P", 512, 512, 512, "P", 512, 512, 512]  # vgg.lua:14-27, no pool5
+
+
+def cfg_layers(cfg):
+    cout, pool = [], []
+    for item in cfg:
+        if item == "P":
+            pool[-1] = 1
+        else:
+            cout.append(int(item))
+            pool.append(0)
+    return cout, pool
+
+
+def synthetic_params(cfg=VGG16_CFG, pooled=7, fc_dim=4096, n_classes=21, seed=557, device="cpu", bbox_norm=True):
+    """Seeded random weights of the reference architecture (no pretrained .t7 exists offline):
+    He-scaled trunk / fc so activations stay O(1); heads as model_utils.lua:106-112
+    (cls N(0,0.01), bbox N(0,0.001), zero bias)."""
+    g = torch.Generator().manual_seed(seed)
+    P = {"conv_w": [], "conv_b": []}
+    cin = 3
+    for item in cfg:
+        if item == "P":
+            continue
+        std = (2.0 / (cin * 9)) ** 0.5
+        P["conv_w"].append((torch.randn(item, cin, 3, 3, generator=g) * std).to(device))
+        P["conv_b"].append((torch.randn(item, generator=g) * 0.01).to(device))
+        cin = item
+    k6 = cin * pooled * pooled
+    P["fc6_w"] = (torch.randn(fc_dim, k6, generator=g) * (2.0 / k6) ** 0.5).to(device)
+    P["fc6_b"] = (torch.randn(fc_dim, generator=g) * 0.01).to(device)
+    P["fc7_w"] = (torch.randn(fc_dim, fc_dim, generator=g) * (2.0 / fc_dim) ** 0.5).to(device)
+    P["fc7_b"] = (torch.randn(fc_dim, generator=g) * 0.01).to(device)
+    P["cls_w"] = (torch.randn(n_classes, fc_dim, generator=g) * 0.01).to(device)
+    P["cls_b"] = torch.zeros(n_classes, device=device)
+    P["bbox_w"] = (torch.randn(4 * n_classes, fc_dim, generator=g) * 0.001).to(device)
+    P["bbox_b"] = torch.zeros(4 * n_classes, device=device)
+    if bbox_norm:  # typical Fast R-CNN target statistics (train.lua:136-138 adds the module)
+        P["bbox_mean"] = [0.0, 0.0, 0.0, 0.0]
+        P["bbox_std"] = [0.1, 0.1, 0.2, 0.2]
+    else:
+        P["bbox_mean"] = P["bbox_std"] = None
+    return P
+
+
+class FastRCNN(object):
+    """Trunk + ROI head + post-processing as one device pipeline (models/vgg.lua:23-31 graph)."""
+
+    def __init__(self, params, cfg=VGG16_CFG, pooled=7, spatial_scale=1.0 / 16, transformer=None, max_h=600, max_w=1000,
+                 max_rois=1000, nms_thresh=0.3, score_thresh=-1.5, top_k=100):
+        _lib.require_gpu()
+        lib = _lib.load()
+        cout, pool = cfg_layers(cfg)
+        self.n_classes = params["cls_w"].shape[0]
+        self.fc_dim = params["fc7_w"].shape[0]
+        self.noSoftMax = False
+        self.max_rois = max_rois
+        c = FrcnnConfig()
+        self._cout = (C.c_int * len(cout))(*cout)
+        self._pool = (C.c_int * len(pool))(*pool)
+        c.n_conv = len(cout)
+        c.conv_cout = C.cast(self._cout, C.POINTER(C.c_int))
+        c.pool_after = C.cast(self._pool, C.POINTER(C.c_int))
+        c.pooled_h = c.pooled_w = pooled
+        c.spatial_scale = spatial_scale
+        c.fc_dim = self.fc_dim
+        c.n_classes = self.n_classes
+        c.max_h, c.max_w, c.max_rois = max_h, max_w, max_rois
+        tf = transformer or dict(mean=(102.9801, 115.9465, 122.7717), std=None, scale=255.0, swap=(2, 1, 0))
+        c.tf_scale = tf["scale"]
+        for i in range(3):
+            c.tf_mean[i] = tf["mean"][i]
+            c.tf_std[i] = tf["std"][i] if tf["std"] else 0.0
+            c.tf_swap[i] = tf["swap"][i]
+        bm, bs = params.get("bbox_mean"), params.get("bbox_std")
+        for i in range(4):
+            c.bbox_mean[i] = bm[i] if bm is not None else 0.0
+            c.bbox_std[i] = bs[i] if bs is not None else 0.0
+        c.nms_thresh, c.score_thresh, c.top_k = nms_thresh, score_thresh, top_k
+        self._cfg = c
+        dev = torch.device("cuda", torch.cuda.current_device())
+        d = lambda t: t.to(dev, torch.float32).contiguous()
+        cw = [d(w) for w in params["conv_w"]]
+        cb = [d(b) for b in params["conv_b"]]
+        wp = (f32p * len(cw))(*[_f(w) for w in cw])
+        bp = (f32p * len(cb))(*[_f(b) for b in cb])
+        keep = [d(params[k]) for k in ("fc6_w", "fc6_b", "fc7_w", "fc7_b", "cls_w", "cls_b", "bbox_w", "bbox_b")]
+        self._h = C.c_void_p()
+        check(lib.mpn_frcnn_create(C.byref(c), wp, bp, *[_f(t) for t in keep], C.byref(self._h)), "mpn_frcnn_create")
+        torch.cuda.synchronize()
+        self._lib = lib
+        self.device = dev
+        self._dets = torch.zeros((top_k * 4 + 64, 6), dtype=torch.float32, device=dev)
+        self._n_dets = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self._lib.mpn_frcnn_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def detect(self, image, boxes):
+        """image [3,H,W] fp32 in [0,1] (device), boxes [N,4] (device) -> (scores [N,C], boxes [N,4C] decoded+clamped)."""
+        H, W = image.shape[1:]
+        N = boxes.size(0)
+        scores = torch.empty((N, self.n_classes), dtype=torch.float32, device=self.device)
+        bbox = torch.empty((N, 4 * self.n_classes), dtype=torch.float32, device=self.device)
+        check(self._lib.mpn_frcnn_detect(self._h, _f(image, "image"), H, W, _f(boxes, "boxes"), N, _f(scores), _f(bbox), _stream()),
+              "mpn_frcnn_detect")
+        return scores, bbox
+
+    def test_one_async(self, image, boxes):
+        """Enqueue the whole per-image path; results stay on the device (self._dets / self._n_dets)."""
+        H, W = image.shape[1:]
+        check(self._lib.mpn_frcnn_test_one(self._h, _f(image, "image"), H, W, _f(boxes, "boxes"), boxes.size(0), _f(self._dets),
+                                           self._dets.size(0), _i(self._n_dets), _stream()), "mpn_frcnn_test_one")
+        return self._dets, self._n_dets
+
+    def nms_results(self):
+        """Per-class NMS output of the last test_one: (keep [C-1,N,5], keep_idx [C-1,N], n_keep [C-1])."""
+        kp, ip, np_ = f32p(), C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+        ms = C.c_int()
+        check(self._lib.mpn_frcnn_nms_results(self._h, C.byref(kp), C.byref(ip), C.byref(np_), C.byref(ms)), "nms_results")
+        torch.cuda.synchronize()
+        ncls, M = self.n_classes - 1, ms.value
+        keep = torch.empty((ncls, M, 5), dtype=torch.float32, device=self.device)
+        idx = torch.empty((ncls, M), dtype=torch.int32, device=self.device)
+        n = torch.empty(ncls, dtype=torch.int32, device=self.device)
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemcpy(C.c_void_p(keep.data_ptr()), kp, C.c_size_t(keep.numel() * 4), 3)
+        hip.hipMemcpy(C.c_void_p(idx.data_ptr()), ip, C.c_size_t(idx.numel() * 4), 3)
+        hip.hipMemcpy(C.c_void_p(n.data_ptr()), np_, C.c_size_t(n.numel() * 4), 3)
+        return keep, idx, n
+
+    def debug_tensor(self, name, shape):
+        p, n = f32p(), C.c_size_t()
+        check(self._lib.mpn_frcnn_debug_tensor(self._h, name.encode(), C.byref(p), C.byref(n)), "debug_tensor")
+        out = torch.empty(n.value, dtype=torch.float32, device=self.device)
+        import ctypes
+        ctypes.CDLL("libamdhip64.so").hipMemcpy(C.c_void_p(out.data_ptr()), p, C.c_size_t(n.value * 4), 3)
+        torch.cuda.synchronize()
+        return out.view(*shape)

@@ -1,0 +1,371 @@
+"""numpy/ctypes front-end of the CPU oracle (oracle/mpn_oracle.c, oracle/_ref/libnms_ref.so).
+
+TEST INFRASTRUCTURE ONLY.  Importable solely from tests/, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` — never from ``multipathnet_amd`` (the product fails loudly when
+its HIP library is missing; it has no CPU fallback).
+
+Each function forwards to the C restatement named ``orc_<name>``; see mpn_oracle.c for the
+reference file:line every one follows.  ``frcnn_forward`` composes them into the per-image path
+of Tester_FRCNN.lua:54-139 / ImageDetect.lua:156-193 / models/vgg.lua:23-31.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+
+f32p = C.POINTER(C.c_float)
+i32p = C.POINTER(C.c_int32)
+f64p = C.POINTER(C.c_double)
+
+
+def build(force=False):
+    """Compile libmpn_oracle.so (and _ref/libnms_ref.so when /root/reference is present)."""
+    so = os.path.join(_HERE, "libmpn_oracle.so")
+    src = os.path.join(_HERE, "mpn_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "libmpn_oracle.so"], stdout=subprocess.DEVNULL)
+    ref_so = os.path.join(_HERE, "_ref", "libnms_ref.so")
+    if os.path.exists("/root/reference/nms.c") and (force or not os.path.exists(ref_so)):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+def _p(a, t=f32p):
+    return a.ctypes.data_as(t)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        build()
+        _LIB = C.CDLL(os.path.join(_HERE, "libmpn_oracle.so"))
+        _LIB.orc_overlap.restype = C.c_float
+        _LIB.orc_nms.restype = C.c_int
+        _LIB.orc_select_scored.restype = C.c_int
+        _LIB.orc_topk_threshold.restype = C.c_float
+        _LIB.orc_pick_scale.restype = C.c_double
+    return _LIB
+
+
+def have_ref():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libnms_ref.so"))
+
+
+def ref():
+    """The reference's own nms.c (compiled unmodified) — None-safe: raises if absent."""
+    global _REF
+    if _REF is None:
+        build()
+        _REF = C.CDLL(os.path.join(_HERE, "_ref", "libnms_ref.so"))
+        _REF.overlap.restype = C.c_float
+        _REF.mpn_th_shim_new.restype = C.c_void_p
+        _REF.mpn_th_shim_from.restype = C.c_void_p
+        _REF.mpn_th_shim_from.argtypes = [f32p, C.c_long, C.c_long]
+        _REF.THFloatTensor_data.restype = f32p
+        _REF.THFloatTensor_data.argtypes = [C.c_void_p]
+        _REF.mpn_th_shim_size.restype = C.c_long
+        _REF.mpn_th_shim_size.argtypes = [C.c_void_p, C.c_int]
+        _REF.mpn_th_shim_free.argtypes = [C.c_void_p]
+        _REF.NMS.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
+        _REF.bbox_vote.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]
+    return _REF
+
+
+# ---------------------------------------------------------------- reference nms.c (real code)
+def _th_to_np(r, t):
+    n0, n1 = r.mpn_th_shim_size(t, 0), r.mpn_th_shim_size(t, 1)
+    if n0 * n1 == 0:
+        return np.zeros((n0, 5), np.float32)
+    return np.ctypeslib.as_array(r.THFloatTensor_data(t), shape=(n0, n1)).copy()
+
+
+def ref_overlap(a, b):
+    a, b = _f32(a), _f32(b)
+    return float(ref().overlap(_p(a), _p(b)))
+
+
+def ref_nms(scored_boxes, thr):
+    r = ref()
+    sb = _f32(scored_boxes).reshape(-1, 5)
+    t_in = r.mpn_th_shim_from(_p(sb), sb.shape[0], 5)
+    t_out = r.mpn_th_shim_new()
+    r.NMS(t_out, t_in, C.c_float(thr))
+    out = _th_to_np(r, t_out) if sb.shape[0] else np.zeros((0, 5), np.float32)
+    r.mpn_th_shim_free(t_in)
+    r.mpn_th_shim_free(t_out)
+    return out
+
+
+def ref_bbox_vote(nms_boxes, scored_boxes, thr):
+    r = ref()
+    nb, sb = _f32(nms_boxes).reshape(-1, 5), _f32(scored_boxes).reshape(-1, 5)
+    t_n = r.mpn_th_shim_from(_p(nb), nb.shape[0], 5)
+    t_s = r.mpn_th_shim_from(_p(sb), sb.shape[0], 5)
+    t_o = r.mpn_th_shim_new()
+    r.bbox_vote(t_o, t_n, t_s, C.c_float(thr))
+    out = _th_to_np(r, t_o) if nb.shape[0] else np.zeros((0, 5), np.float32)
+    for t in (t_n, t_s, t_o):
+        r.mpn_th_shim_free(t)
+    return out
+
+
+# ---------------------------------------------------------------- restated ops
+def overlap(a, b):
+    a, b = _f32(a), _f32(b)
+    return float(lib().orc_overlap(_p(a), _p(b)))
+
+
+def boxoverlap(a, b):
+    a, b = _f32(a).reshape(-1, 4), _f32(b)
+    out = np.empty(a.shape[0], np.float32)
+    lib().orc_boxoverlap(_p(a), a.shape[0], _p(b), _p(out))
+    return out
+
+
+def nms(scored_boxes, thr, return_index=False):
+    sb = _f32(scored_boxes).reshape(-1, 5)
+    n = sb.shape[0]
+    keep = np.empty((max(n, 1), 5), np.float32)
+    idx = np.empty(max(n, 1), np.int32)
+    k = lib().orc_nms(_p(sb), n, C.c_float(thr), _p(keep), _p(idx, i32p))
+    return (keep[:k].copy(), idx[:k].copy()) if return_index else keep[:k].copy()
+
+
+def bbox_vote(nms_boxes, scored_boxes, thr):
+    nb, sb = _f32(nms_boxes).reshape(-1, 5), _f32(scored_boxes).reshape(-1, 5)
+    res = np.zeros_like(nb)
+    lib().orc_bbox_vote(_p(nb), nb.shape[0], _p(sb), sb.shape[0], C.c_float(thr), _p(res))
+    return res
+
+
+ROSS = dict(mean=(102.9801, 115.9465, 122.7717), std=None, scale=255.0, swap=(2, 1, 0))  # model_utils.lua:138-140
+IMAGENET = dict(mean=(0.48462227599918, 0.45624044862054, 0.40588363755159),
+                std=(0.22889466674951, 0.22446679341259, 0.22495548344775), scale=1.0, swap=(0, 1, 2))
+
+
+def image_transform(im, mean, std=None, scale=1.0, swap=(0, 1, 2)):
+    im = _f32(im)
+    out = np.empty_like(im)
+    sw = np.asarray(swap, np.int32)
+    mn = np.asarray(mean, np.float64)
+    sd = np.asarray(std if std is not None else (1, 1, 1), np.float64)
+    lib().orc_image_transform(_p(im), im.shape[1], im.shape[2], _p(sw, i32p), C.c_double(scale), _p(mn, f64p),
+                              _p(sd, f64p), int(std is not None), _p(out))
+    return out
+
+
+def pick_scale(H, W, target=600, max_size=1000):
+    return float(lib().orc_pick_scale(H, W, C.c_double(target), C.c_double(max_size)))
+
+
+def project_im_rois(boxes, scale):
+    b = _f32(boxes).reshape(-1, 4)
+    out = np.empty((b.shape[0], 5), np.float32)
+    lib().orc_project_im_rois(_p(b), b.shape[0], C.c_double(scale), _p(out))
+    return out
+
+
+def conv3x3(x, w, b, relu=True):
+    x, w = _f32(x), _f32(w)
+    b = _f32(b) if b is not None else None
+    Cin, H, W = x.shape
+    Cout = w.shape[0]
+    out = np.empty((Cout, H, W), np.float32)
+    lib().orc_conv3x3(_p(x), Cin, H, W, _p(w), _p(b) if b is not None else None, Cout, int(relu), _p(out))
+    return out
+
+
+def maxpool2x2_ceil(x):
+    x = _f32(x)
+    Cc, H, W = x.shape
+    out = np.empty((Cc, (H + 1) // 2, (W + 1) // 2), np.float32)
+    lib().orc_maxpool2x2_ceil(_p(x), Cc, H, W, _p(out))
+    return out
+
+
+def linear(x, w, b, relu=False):
+    x, w = _f32(x), _f32(w)
+    b = _f32(b) if b is not None else None
+    M, K = x.shape
+    N = w.shape[0]
+    y = np.empty((M, N), np.float32)
+    lib().orc_linear(_p(x), M, K, _p(w), _p(b) if b is not None else None, N, int(relu), _p(y))
+    return y
+
+
+def softmax(x):
+    x = _f32(x)
+    y = np.empty_like(x)
+    lib().orc_softmax(_p(x), x.shape[0], x.shape[1], _p(y))
+    return y
+
+
+def roi_pool(feat, rois, PH, PW, scale, coord_offset=1.0, end_adjust=0):
+    feat, rois = _f32(feat), _f32(rois).reshape(-1, 5)
+    if feat.ndim == 3:
+        feat = feat[None]
+    B, Cc, H, W = feat.shape
+    N = rois.shape[0]
+    out = np.empty((N, Cc, PH, PW), np.float32)
+    arg = np.empty((N, Cc, PH, PW), np.int32)
+    lib().orc_roi_pool(_p(feat), B, Cc, H, W, _p(rois), N, PH, PW, C.c_float(scale), C.c_float(coord_offset),
+                       int(end_adjust), _p(out), _p(arg, i32p))
+    return out, arg
+
+
+def foveal(rois):
+    r = _f32(rois).reshape(-1, 5)
+    out = np.empty((4 * r.shape[0], 5), np.float32)
+    lib().orc_foveal(_p(r), r.shape[0], _p(out))
+    return out
+
+
+def context_region(rois, scale):
+    r = _f32(rois).reshape(-1, 5)
+    out = np.empty_like(r)
+    lib().orc_context_region(_p(r), r.shape[0], C.c_double(scale), _p(out))
+    return out
+
+
+def bbox_norm(bbox, mean4, std4):
+    b = _f32(bbox).copy()
+    m, s = _f32(mean4), _f32(std4)
+    lib().orc_bbox_norm(_p(b), b.shape[0], b.shape[1], _p(m), _p(s))
+    return b
+
+
+def bbox_decode(boxes, deltas):
+    bx, d = _f32(boxes).reshape(-1, 4), _f32(deltas)
+    out = np.empty_like(d)
+    lib().orc_bbox_decode(_p(bx), _p(d), bx.shape[0], d.shape[1] // 4, _p(out))
+    return out
+
+
+def clamp_boxes(bbox, im_w, im_h):
+    b = _f32(bbox).copy()
+    lib().orc_clamp_boxes(_p(b), C.c_size_t(b.size // 2), C.c_float(im_w), C.c_float(im_h))
+    return b
+
+
+def select_scored(scores, bbox, cls, thresh=-1.5):
+    s, b = _f32(scores), _f32(bbox)
+    n, Cc = s.shape
+    sb = np.empty((max(n, 1), 5), np.float32)
+    idx = np.empty(max(n, 1), np.int32)
+    m = lib().orc_select_scored(_p(s), _p(b), n, Cc, cls, C.c_float(thresh), _p(sb), _p(idx, i32p))
+    return sb[:m].copy(), idx[:m].copy()
+
+
+def topk_threshold(scores, k):
+    s = _f32(scores).ravel()
+    return float(lib().orc_topk_threshold(_p(s), s.size, k))
+
+
+def keep_top_k(per_class, k):
+    """utils.lua:75-96 on a list of [K_j,5] arrays (one per class)."""
+    allb = [b for b in per_class if b.size]
+    if not allb:
+        return per_class, 0.0
+    t = topk_threshold(np.concatenate(allb)[:, 4], k)
+    return [b[b[:, 4] >= t] if b.size else b for b in per_class], t
+
+
+def select_boxes(scores, bbox):
+    s, b = _f32(scores), _f32(bbox)
+    out = np.empty((s.shape[0], 4), np.float32)
+    lib().orc_select_boxes(_p(s), _p(b), s.shape[0], s.shape[1], _p(out))
+    return out
+
+
+def l2_normalize(x):
+    x = _f32(x)
+    y = np.empty_like(x)
+    lib().orc_l2_normalize(_p(x), x.shape[0], x.shape[1], _p(y))
+    return y
+
+
+def mean_over_k(probs):
+    p = _f32(probs)
+    out = np.empty(p.shape[1:], np.float32)
+    lib().orc_mean_over_k(_p(p), p.shape[0], p.shape[1], p.shape[2], _p(out))
+    return out
+
+
+# ---------------------------------------------------------------- composed per-image path
+# VGG-16 `features` (models/vgg.lua:14-27; layer indices multipathnet.lua:34-46): 13 conv3x3+ReLU,
+# ceil-mode 2x2 pools after conv1_2, conv2_2, conv3_3, conv4_3; NO pool5.
+VGG16_CFG = [64, 64, "P", 128, 128, "P", 256, 256, 256, "P", 512, 512, 512, "P", 512, 512, 512]
+
+
+def vgg_trunk(x, conv_w, conv_b, cfg=None, taps=None):
+    """x [3,H,W] -> conv5 map.  taps: optional dict collecting {'conv3','conv4','conv5'} outputs."""
+    cfg = cfg or VGG16_CFG
+    li = 0
+    stage = 1
+    for item in cfg:
+        if item == "P":
+            if taps is not None and stage in (3, 4):
+                taps["conv%d" % stage] = x
+            x = maxpool2x2_ceil(x)
+            stage += 1
+        else:
+            x = conv3x3(x, conv_w[li], conv_b[li], relu=True)
+            li += 1
+    if taps is not None:
+        taps["conv5"] = x
+    return x
+
+
+def frcnn_head(feat, rois, P, pooled=7, spatial_scale=1.0 / 16, chunk=None):
+    """models/vgg.lua:28-31: ROIPooling -> View -> fc6/ReLU -> fc7/ReLU -> {cls, bbox}
+    (+BBoxNorm, train.lua:136-138).  chunk=500 reproduces memoryEfficientForward (ImageDetect.lua:116-124)."""
+    N = rois.shape[0]
+    chunk = chunk or N
+    cls, bbox = [], []
+    for s in range(0, N, chunk):
+        r = rois[s:s + chunk]
+        pooledf, _ = roi_pool(feat, r, pooled, pooled, spatial_scale)
+        x = pooledf.reshape(r.shape[0], -1)
+        x = linear(x, P["fc6_w"], P["fc6_b"], relu=True)
+        x = linear(x, P["fc7_w"], P["fc7_b"], relu=True)
+        cls.append(linear(x, P["cls_w"], P["cls_b"]))
+        bb = linear(x, P["bbox_w"], P["bbox_b"])
+        if P.get("bbox_mean") is not None:
+            bb = bbox_norm(bb, P["bbox_mean"], P["bbox_std"])
+        bbox.append(bb)
+    return np.concatenate(cls), np.concatenate(bbox)
+
+
+def detect(im, boxes, P, transformer=ROSS, target=600, max_size=1000, cfg=None, pooled=7, chunk=500):
+    """ImageDetect.lua:156-193 for an image whose scale factor is exactly 1 (no image.scale resample —
+    SURVEY §8a-2; asserted).  im [3,H,W] fp32 in [0,1]; boxes [N,4] 1-based x1y1x2y2.
+    Returns (softmax scores [N,C], decoded boxes [N,4C], raw cls logits, raw deltas)."""
+    H, W = im.shape[1:]
+    s = pick_scale(H, W, target, max_size)
+    assert s == 1.0, "oracle.detect restates only the scale==1 path (bilinear image.scale is out of scope)"
+    x = image_transform(im, **transformer)
+    rois = project_im_rois(boxes, s)
+    feat = vgg_trunk(x, P["conv_w"], P["conv_b"], cfg)
+    logits, deltas = frcnn_head(feat, rois, P, pooled=pooled, chunk=chunk)
+    dec = bbox_decode(boxes, deltas)
+    return softmax(logits), dec, logits, deltas
+
+
+def test_one(im, boxes, P, nms_thresh=0.3, score_thresh=-1.5, use_ref_nms=False, **kw):
+    """Tester_FRCNN.lua:54-139 (num_iter=1, no voting): detect -> clamp -> per-class select -> NMS.
+    Returns (list over classes 1..C-1 of [K,5]), (scores, clamped boxes)."""
+    scores, dec, _, _ = detect(im, boxes, P, **kw)
+    dec = clamp_boxes(dec, im.shape[2], im.shape[1])
+    out = []
+    for j in range(1, scores.shape[1]):
+        sb, _ = select_scored(scores, dec, j, score_thresh)
+        out.append(ref_nms(sb, nms_thresh) if use_ref_nms else nms(sb, nms_thresh))
+    return out, (scores, dec)

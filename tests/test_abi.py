@@ -1,0 +1,57 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/*.h declares."""
+import ctypes
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", src)
+    return sorted(set(n for n in names if n.startswith("mpn_") or n in ("NMS", "bbox_vote")))
+
+
+def test_libmpn_exports_every_declared_symbol():
+    import multipathnet_amd
+    lib = multipathnet_amd.load()
+    names = _declared("mpn.h")
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), "libmpn_hip.so does not export %s" % n
+    assert lib.mpn_version() >= 100
+    assert abs(lib.mpn_pick_scale(600, 1000, 600.0, 1000.0) - 1.0) == 0.0
+
+
+def test_libnms_dropin_exports():
+    so = os.path.join(ROOT, "multipathnet_amd", "libnms.so")
+    assert os.path.exists(so), "libnms.so (drop-in for the reference's nms.c) was not built"
+    out = subprocess.check_output(["nm", "-D", so]).decode()
+    for n in _declared("mpn_libnms.h"):
+        assert re.search(r" T %s\b" % n, out), n
+    # the TH helpers stay undefined: they resolve to libTH inside a Torch7 process
+    assert re.search(r" U THFloatTensor_resize2d\b", out)
+
+
+def test_arg_errors_do_not_need_a_gpu():
+    import multipathnet_amd
+    lib = multipathnet_amd.load()
+    lib.mpn_last_error.restype = ctypes.c_char_p
+    rc = lib.mpn_nms_batched(None, None, 3, 10, ctypes.c_float(0.3), None, None, None, None)
+    assert rc == -1 and b"invalid argument" in lib.mpn_last_error()
+    rc = lib.mpn_nms_batched(None, None, 1, 1 << 20, ctypes.c_float(0.3), None, None, None, None)
+    assert rc == -1
+
+
+def test_no_oracle_on_product_path():
+    """The product must never import / link the oracle (it would void every parity claim)."""
+    pkg = os.path.join(ROOT, "multipathnet_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "mpn_oracle" not in txt and "libnms_ref" not in txt, os.path.join(dirpath, f)
+                if f.endswith(".py"):
+                    assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dirpath, f)

@@ -1,0 +1,122 @@
+"""The small modules / helpers through the host mirror of the reference's nn.Module surface."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _rois(rng, n, W=1000, H=600):
+    c = rng.uniform([1, 1], [W, H], (n, 2))
+    wh = np.exp(rng.uniform(np.log(4), np.log(600), (n, 2)))
+    b = np.clip(np.concatenate([c - wh / 2, c + wh / 2], 1), 1, [W, H, W, H])
+    return np.concatenate([np.ones((n, 1)), b], 1).astype(np.float32)
+
+
+def test_foveal_bit_exact(O, dev):
+    from multipathnet_amd import nn
+    r = _rois(np.random.default_rng(0), 1000)
+    out = nn.Foveal().forward(_t(r, dev))
+    assert out.shape == (4000, 5)
+    assert np.array_equal(out.cpu().numpy(), O.foveal(r))
+    with pytest.raises(AssertionError):
+        nn.Foveal().forward(_t(r[:, :4].copy(), dev))  # Foveal.lua:17 assert(size(2)==5)
+    assert nn.Foveal().forward(torch.zeros((0, 5), device=dev)).shape == (0, 5)
+
+
+@pytest.mark.parametrize("scale", [1.5, 2.0, 4.0, 0.5, 1.0])
+def test_context_region_bit_exact(O, dev, scale):
+    from multipathnet_amd import nn
+    r = _rois(np.random.default_rng(1), 500)
+    out = nn.ContextRegion(scale).forward(_t(r, dev)).cpu().numpy()
+    assert np.array_equal(out, O.context_region(r, scale))
+
+
+def test_bbox_norm_select_boxes_softmax(O, dev):
+    from multipathnet_amd import nn
+    rng = np.random.default_rng(2)
+    d = rng.standard_normal((300, 84)).astype(np.float32)
+    mean, std = [0.0, 0.01, -0.02, 0.03], [0.1, 0.1, 0.2, 0.2]
+    m = nn.BBoxNorm(mean, std).evaluate()
+    assert np.array_equal(m.forward(_t(d, dev).clone()).cpu().numpy(), O.bbox_norm(d, mean, std))
+    m.training()  # BBoxNorm.lua:21: pass-through in training mode
+    assert np.array_equal(m.forward(_t(d, dev)).cpu().numpy(), d)
+    s = rng.standard_normal((300, 21)).astype(np.float32)
+    s[5, 3] = s[5, 7] = 9.0  # tie -> first max
+    assert np.array_equal(nn.SelectBoxes().forward([_t(s, dev), _t(d, dev)]).cpu().numpy(), O.select_boxes(s, d))
+    sm = nn.SoftMax().forward(_t(s, dev)).cpu().numpy()
+    assert np.abs(sm - O.softmax(s)).max() < 1e-6 and np.abs(sm.sum(1) - 1).max() < 1e-5
+    s81 = rng.standard_normal((77, 81)).astype(np.float32) * 5
+    assert np.abs(nn.SoftMax().forward(_t(s81, dev)).cpu().numpy() - O.softmax(s81)).max() < 1e-6
+
+
+def test_image_transformer_and_projection_bit_exact(O, dev):
+    from multipathnet_amd import nn, _lib
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    im = rng.random((3, 37, 53), dtype=np.float32)
+    assert np.array_equal(nn.RossTransformer().forward(_t(im, dev)).cpu().numpy(), O.image_transform(im, **O.ROSS))
+    assert np.array_equal(nn.ImagenetTransformer().forward(_t(im, dev)).cpu().numpy(), O.image_transform(im, **O.IMAGENET))
+    lib = _lib.load()
+    b = _rois(rng, 100)[:, 1:].copy()
+    for s in (1.0, 600 / 480, 0.731):
+        out = torch.empty((100, 5), device=dev)
+        _lib.check(lib.mpn_project_im_rois(nn._f(_t(b, dev)), 100, C.c_double(s), nn._f(out), None))
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), O.project_im_rois(b, s))
+    for (h, w) in [(600, 1000), (1000, 600), (480, 640), (300, 1000), (375, 500)]:
+        assert lib.mpn_pick_scale(h, w, 600.0, 1000.0) == O.pick_scale(h, w)
+
+
+def test_decode_clamp(O, dev):
+    from multipathnet_amd import utils, nn, _lib
+    import ctypes as C
+    rng = np.random.default_rng(4)
+    boxes = _rois(rng, 1000)[:, 1:].copy()
+    d = (rng.standard_normal((1000, 84)) * 0.3).astype(np.float32)
+    got = utils.decode_all_classes(_t(boxes, dev), _t(d, dev))
+    ref = O.bbox_decode(boxes, d)
+    # expf may differ by an ulp between libm and the device: tolerance on pixels, not bit-exact
+    assert np.abs(got.cpu().numpy() - ref).max() < 1e-3
+    y = _t(d[:, :4].copy(), dev)
+    out = torch.empty_like(y)
+    utils.convertFrom(out, _t(boxes, dev), y)  # utils.lua:229 2-D path
+    assert np.abs(out.cpu().numpy() - O.bbox_decode(boxes, d[:, :4].copy())).max() < 1e-3
+    g = got.clone()
+    _lib.check(_lib.load().mpn_clamp_boxes(nn._f(g), C.c_size_t(g.numel() // 2), C.c_float(1000), C.c_float(600), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(g.cpu().numpy(), O.clamp_boxes(got.cpu().numpy(), 1000, 600))
+
+
+def test_select_scored_and_keep_top_k(O, dev):
+    from multipathnet_amd import utils, nn, _lib
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    N, Cc = 1000, 21
+    scores = O.softmax(rng.standard_normal((N, Cc)).astype(np.float32) * 3)
+    bbox = rng.uniform(1, 600, (N, 4 * Cc)).astype(np.float32)
+    for thresh in (-1.5, 0.05):
+        scored = torch.empty((Cc - 1, N, 5), device=dev)
+        counts = torch.zeros(Cc - 1, dtype=torch.int32, device=dev)
+        src = torch.zeros((Cc - 1, N), dtype=torch.int32, device=dev)
+        _lib.check(_lib.load().mpn_select_scored(nn._f(_t(scores, dev)), nn._f(_t(bbox, dev)), N, Cc, 1, C.c_float(thresh),
+                                                 nn._f(scored), nn._i(counts), nn._i(src), None))
+        torch.cuda.synchronize()
+        for j in range(1, Cc):
+            sb, idx = O.select_scored(scores, bbox, j, thresh)
+            n = int(counts[j - 1])
+            assert n == sb.shape[0]
+            assert np.array_equal(scored[j - 1, :n].cpu().numpy(), sb)
+            assert np.array_equal(src[j - 1, :n].cpu().numpy(), idx)
+    per = [np.concatenate([rng.random((k, 4)), np.round(rng.random((k, 1)) * 200) / 200], 1).astype(np.float32)
+           for k in (300, 0, 90, 5, 1000, 17)]
+    for k in (100, 3, 5000):
+        ref, t = O.keep_top_k(per, k)
+        got, tg = utils.keep_top_k([_t(p, dev) if p.size else torch.zeros((0, 5), device=dev) for p in per], k)
+        assert tg == t
+        for a, b in zip(got, ref):
+            assert np.array_equal(a.cpu().numpy().reshape(-1, 5), b.reshape(-1, 5))

@@ -1,0 +1,116 @@
+"""fp32-MFMA conv / linear / pool through the module-level C ABI vs the oracle (tolerance 1e-4 relative
+to the output scale, north_star) and the reference's exactness properties (chunked == un-chunked)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _conv(dev, x, w, b, relu=True):
+    from multipathnet_amd import nn
+    m = nn.SpatialConvolution(w.shape[1], w.shape[0], relu=relu)
+    m.weight, m.bias = _t(w, dev), (_t(b, dev) if b is not None else None)
+    return m.forward(_t(x, dev)).cpu().numpy()
+
+
+@pytest.mark.parametrize("ci,co,h,w", [(3, 64, 40, 70), (8, 64, 33, 31), (64, 64, 19, 45), (64, 128, 16, 96), (128, 256, 9, 33),
+                                       (24, 40, 8, 8), (16, 200, 5, 37), (256, 512, 12, 20)])
+@pytest.mark.parametrize("variant", [0, 1, 2, 17, 18])
+def test_conv3x3_vs_oracle(O, dev, ci, co, h, w, variant):
+    import multipathnet_amd
+    lib = multipathnet_amd.load()
+    rng = np.random.default_rng(ci * 1000 + co)
+    x = rng.standard_normal((ci, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((co, ci, 3, 3)) * (2.0 / (ci * 9)) ** 0.5).astype(np.float32)
+    b = (rng.standard_normal(co) * 0.1).astype(np.float32)
+    lib.mpn_debug_set_conv_variant(variant)
+    try:
+        y = _conv(dev, x, wt, b, relu=True)
+        y2 = _conv(dev, x, wt, None, relu=False)
+    finally:
+        lib.mpn_debug_set_conv_variant(0)
+    ref = O.conv3x3(x, wt, b, relu=True)
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    assert np.abs(y2 - O.conv3x3(x, wt, None, relu=False)).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_conv_transpose_detecting(O, dev):
+    """asymmetric weights + a single hot pixel: catches row/col or tap transposes (guide §5.4 rule 16)"""
+    x = np.zeros((8, 12, 40), np.float32)
+    x[3, 5, 17] = 1.0
+    wt = np.arange(16 * 8 * 9, dtype=np.float32).reshape(16, 8, 3, 3) / 100.0
+    y = _conv(dev, x, wt, None, relu=False)
+    assert np.array_equal(y, O.conv3x3(x, wt, None, relu=False))
+
+
+def test_maxpool_ceil_exact(O, dev):
+    from multipathnet_amd import nn
+    rng = np.random.default_rng(1)
+    for (c, h, w) in [(64, 75, 125), (8, 38, 63), (3, 1, 1), (5, 2, 3), (2, 600, 11)]:
+        x = rng.standard_normal((c, h, w)).astype(np.float32)
+        assert np.array_equal(nn.SpatialMaxPooling().forward(_t(x, dev)).cpu().numpy(), O.maxpool2x2_ceil(x))
+
+
+def _linear(dev, x, w, b, relu=False):
+    from multipathnet_amd import nn
+    m = nn.Linear(w.shape[1], w.shape[0], relu=relu)
+    m.weight, m.bias = _t(w, dev), (_t(b, dev) if b is not None else None)
+    return m.forward(_t(x, dev))
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 8, 1), (40, 512, 9), (130, 300, 70), (257, 4096, 105), (1000, 1024, 512), (64, 25088, 128)])
+@pytest.mark.parametrize("regstage", [0, 1])
+def test_linear_vs_oracle(O, dev, M, K, N, regstage):
+    import multipathnet_amd
+    lib = multipathnet_amd.load()
+    rng = np.random.default_rng(M + K + N)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) * (1.0 / K) ** 0.5).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    lib.mpn_debug_set_gemm_regstage(regstage)
+    try:
+        y = _linear(dev, x, w, b, relu=True).cpu().numpy()
+    finally:
+        lib.mpn_debug_set_gemm_regstage(0)
+    ref = O.linear(x, w, b, relu=True)
+    assert np.abs(y - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_linear_asymmetric_identity(O, dev):
+    K = N = 64
+    x = np.arange(5 * K, dtype=np.float32).reshape(5, K)
+    w = np.eye(N, K, dtype=np.float32)
+    w[3, 7] = 2.0  # asymmetric
+    y = _linear(dev, x, w, None).cpu().numpy()
+    assert np.array_equal(y, O.linear(x, w, None))
+
+
+def test_split_batch_invariance_exact(O, dev):
+    """test.lua:140-179 (SequentialSplitBatch): ROIPooling+Linear and plain Linear, chunked (25) output ==
+    un-chunked output EXACTLY (asserteq ... 0)."""
+    from multipathnet_amd import nn
+    rng = np.random.default_rng(3)
+    feat = _t(rng.standard_normal((1, 512, 38, 50)).astype(np.float32), dev)
+    rois = (rng.standard_normal((40, 5)) * 50).astype(np.float32)
+    rois[:, 0] = 1
+    rois = _t(rois, dev)
+    w = (rng.standard_normal((9, 7 * 7 * 512)) * 0.01).astype(np.float32)
+    b = rng.standard_normal(9).astype(np.float32)
+    pool = nn.ROIPooling(7, 7, 1 / 16)
+    run = lambda r: _linear(dev, pool.forward([feat, r]).reshape(r.size(0), -1).cpu().numpy(), w, b).clone()
+    full = run(rois)
+    parts = torch.cat([run(rois[:25].contiguous()), run(rois[25:].contiguous())])
+    assert (full - parts).abs().max().item() == 0
+    x = rng.standard_normal((40, 512)).astype(np.float32)
+    w2 = rng.standard_normal((9, 512)).astype(np.float32)
+    full = _linear(dev, x, w2, b)
+    parts = torch.cat([_linear(dev, x[:25], w2, b).clone(), _linear(dev, x[25:], w2, b).clone()])
+    assert (full - parts).abs().max().item() == 0

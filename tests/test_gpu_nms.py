@@ -1,0 +1,112 @@
+"""HIP NMS / bbox_vote / boxoverlap through the C ABI vs the oracle and the reference's own nms.c —
+kept set, order and indices bit-exact."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import random_scored_boxes
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("regime", ["distinct", "ties", "saturated", "allequal"])
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 300, 1000, 2500])
+def test_nms_bit_exact(O, dev, regime, n):
+    from multipathnet_amd import utils
+    rng = np.random.default_rng(hash((regime, n)) % 2**32)
+    sb = random_scored_boxes(rng, n, regime, span=300.0 if n <= 65 else 1000.0)
+    for thr in (0.3, 0.5):
+        ref, ridx = O.nms(sb, thr, return_index=True)
+        if O.have_ref():
+            assert np.array_equal(O.ref_nms(sb, thr), ref)
+        keep, idx = utils.nms_with_index(_t(sb, dev), thr)
+        assert keep.shape[0] == ref.shape[0]
+        assert np.array_equal(keep.cpu().numpy(), ref)
+        assert np.array_equal(idx.cpu().numpy(), ridx)
+
+
+def test_nms_empty_and_reference_test_style(O, dev):
+    from multipathnet_amd import utils
+    assert utils.nms(torch.zeros((0, 5), device=dev), 0.3).shape == (0, 5)
+    sb = np.array([[0, 0, 10, 10, 0.5], [100, 100, 110, 110, 0.5], [200, 200, 210, 210, 0.9]], np.float32)
+    assert np.array_equal(utils.nms(_t(sb, dev), 0.3).cpu().numpy(), O.nms(sb, 0.3))
+
+
+def test_nms_batched_ragged(O, dev):
+    from multipathnet_amd import utils
+    rng = np.random.default_rng(5)
+    n_cls, M = 20, 777
+    counts = rng.integers(0, M + 1, n_cls).astype(np.int32)
+    counts[0], counts[1] = 0, M
+    sb = np.stack([random_scored_boxes(rng, M, ["distinct", "ties", "saturated"][c % 3]) for c in range(n_cls)])
+    keep, idx, nk = utils.nms_batched(_t(sb, dev), _t(counts, dev), 0.3)
+    keep, idx, nk = keep.cpu().numpy(), idx.cpu().numpy(), nk.cpu().numpy()
+    for c in range(n_cls):
+        ref, ridx = O.nms(sb[c, :counts[c]], 0.3, return_index=True)
+        assert nk[c] == ref.shape[0]
+        assert np.array_equal(keep[c, :nk[c]], ref) and np.array_equal(idx[c, :nk[c]], ridx)
+
+
+@pytest.mark.parametrize("regime", ["distinct", "ties"])
+def test_bbox_vote_bit_exact(O, dev, regime):
+    from multipathnet_amd import utils
+    rng = np.random.default_rng(9)
+    sb = random_scored_boxes(rng, 1000, regime)
+    sb[:, 4] = np.maximum(sb[:, 4], 1e-3)
+    keep = O.nms(sb, 0.3)
+    ref = O.ref_bbox_vote(keep, sb, 0.5) if O.have_ref() else O.bbox_vote(keep, sb, 0.5)
+    got = utils.bbox_vote(_t(keep, dev), _t(sb, dev), 0.5).cpu().numpy()
+    assert np.array_equal(got, ref)
+
+
+def test_boxoverlap_known_answer(O, dev):
+    from multipathnet_amd import utils
+    # test.lua:40-52
+    a = torch.tensor([[0, 0, 100, 100], [0, 50, 100, 150], [50, 0, 150, 100], [50, 50, 150, 150], [100, 100, 200, 200]],
+                     dtype=torch.float32, device=dev)
+    gt = torch.tensor([1 / 7, 1 / 3, 1 / 3, 1, 1 / 7])
+    got = utils.boxoverlap(a, [50, 50, 150, 150]).cpu()
+    assert (got - gt).max() < 5e-3
+    assert np.array_equal(got.numpy(), O.boxoverlap(a.cpu().numpy(), [50, 50, 150, 150]))
+
+
+def test_libnms_dropin_th_abi(O, dev):
+    """libnms.so exposes the reference's FFI surface (utils.lua:15-19) on THFloatTensor structs."""
+    if not O.have_ref():
+        pytest.skip("needs the TH shim that ships inside oracle/_ref/libnms_ref.so")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shim = ctypes.CDLL(os.path.join(root, "oracle", "_ref", "libnms_ref.so"), mode=ctypes.RTLD_GLOBAL)  # provides THFloatTensor_*
+    dll = ctypes.CDLL(os.path.join(root, "multipathnet_amd", "libnms.so"))
+    f32p = ctypes.POINTER(ctypes.c_float)
+    shim.mpn_th_shim_from.restype = ctypes.c_void_p
+    shim.mpn_th_shim_from.argtypes = [f32p, ctypes.c_long, ctypes.c_long]
+    shim.mpn_th_shim_new.restype = ctypes.c_void_p
+    shim.THFloatTensor_data.restype = f32p
+    shim.THFloatTensor_data.argtypes = [ctypes.c_void_p]
+    shim.mpn_th_shim_size.restype = ctypes.c_long
+    shim.mpn_th_shim_size.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    dll.NMS.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float]
+    dll.bbox_vote.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float]
+    rng = np.random.default_rng(2)
+    sb = random_scored_boxes(rng, 500, "ties")
+    sb[:, 4] = np.maximum(sb[:, 4], 1e-3)
+    t_in = shim.mpn_th_shim_from(sb.ctypes.data_as(f32p), 500, 5)
+    t_keep = shim.mpn_th_shim_new()
+    dll.NMS(t_keep, t_in, 0.3)
+    k = shim.mpn_th_shim_size(t_keep, 0)
+    got = np.ctypeslib.as_array(shim.THFloatTensor_data(t_keep), shape=(k, 5)).copy()
+    assert np.array_equal(got, O.ref_nms(sb, 0.3))
+    t_res = shim.mpn_th_shim_new()
+    dll.bbox_vote(t_res, t_keep, t_in, 0.5)
+    res = np.ctypeslib.as_array(shim.THFloatTensor_data(t_res), shape=(k, 5)).copy()
+    assert np.array_equal(res, O.ref_bbox_vote(got, sb, 0.5))
+    t_empty = shim.mpn_th_shim_from(sb.ctypes.data_as(f32p), 0, 5)
+    dll.NMS(t_keep, t_empty, 0.3)
+    assert shim.mpn_th_shim_size(t_keep, 0) == 0

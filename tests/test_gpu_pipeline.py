@@ -1,0 +1,148 @@
+"""End-to-end fused pipeline (mpn_frcnn_*) vs the oracle's composed per-image path, at sizes the oracle
+finishes in seconds, plus size-independent properties at the BASELINE size."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _np_params(P):
+    out = {}
+    for k, v in P.items():
+        if isinstance(v, list) and v and hasattr(v[0], "numpy"):
+            out[k] = [t.numpy() for t in v]
+        elif hasattr(v, "numpy"):
+            out[k] = v.numpy()
+        else:
+            out[k] = v
+    return out
+
+
+def _boxes(rng, n, W, H, lo=8, hi=None):
+    hi = hi or min(W, H)
+    c = rng.uniform([1, 1], [W, H], (n, 2))
+    wh = np.exp(rng.uniform(np.log(lo), np.log(hi), (n, 2)))
+    return np.clip(np.concatenate([c - wh / 2, c + wh / 2], 1), 1, [W, H, W, H]).astype(np.float32)
+
+
+SMALL = dict(cfg=[8, 16, "P", 16, 24, "P", 32, 32, "P", 64, "P", 64], fc=128, C=7, H=150, W=250, N=200, scale=1 / 16)
+
+
+@pytest.fixture(scope="module")
+def small(O, dev):
+    from multipathnet_amd import models
+    s = SMALL
+    P = models.synthetic_params(s["cfg"], pooled=7, fc_dim=s["fc"], n_classes=s["C"], seed=557)
+    rng = np.random.default_rng(555)
+    im = rng.random((3, s["H"], s["W"]), dtype=np.float32)
+    boxes = _boxes(np.random.default_rng(556), s["N"], s["W"], s["H"])
+    net = models.FastRCNN(P, cfg=s["cfg"], pooled=7, spatial_scale=s["scale"], max_h=s["H"], max_w=s["W"], max_rois=s["N"])
+    Pn = _np_params(P)
+    x = O.image_transform(im, **O.ROSS)
+    feat = O.vgg_trunk(x, Pn["conv_w"], Pn["conv_b"], s["cfg"])
+    rois = O.project_im_rois(boxes, 1.0)
+    pooled, _ = O.roi_pool(feat, rois, 7, 7, s["scale"])
+    logits, deltas = O.frcnn_head(feat, rois, Pn, pooled=7, spatial_scale=s["scale"], chunk=500)
+    return dict(net=net, im=im, boxes=boxes, P=Pn, feat=feat, pooled=pooled, logits=logits, deltas=deltas)
+
+
+@pytest.mark.parametrize("fuse_pool", [1, 0])
+def test_pipeline_stages_vs_oracle(O, dev, small, fuse_pool):
+    import multipathnet_amd
+    lib = multipathnet_amd.load()
+    s, net = SMALL, small["net"]
+    lib.mpn_debug_set_fuse_pool(fuse_pool)
+    try:
+        scores, bbox = net.detect(torch.from_numpy(small["im"]).to(dev), torch.from_numpy(small["boxes"]).to(dev))
+        torch.cuda.synchronize()
+    finally:
+        lib.mpn_debug_set_fuse_pool(1)
+    feat = small["feat"]
+    conv5 = net.debug_tensor("conv5", feat.shape).cpu().numpy()
+    assert np.abs(conv5 - feat).max() < 1e-4 * max(1.0, np.abs(feat).max())
+    pooled = net.debug_tensor("pooled", small["pooled"].shape).cpu().numpy()
+    assert np.abs(pooled - small["pooled"]).max() < 1e-4 * max(1.0, np.abs(feat).max())
+    cls = net.debug_tensor("cls", small["logits"].shape).cpu().numpy()
+    assert np.abs(cls - small["logits"]).max() < 1e-4
+    raw = net.debug_tensor("bbox_raw", small["deltas"].shape).cpu().numpy()
+    assert np.abs(raw - small["deltas"]).max() < 1e-4
+    ref_scores = O.softmax(small["logits"])
+    ref_bbox = O.clamp_boxes(O.bbox_decode(small["boxes"], small["deltas"]), s["W"], s["H"])
+    assert np.abs(scores.cpu().numpy() - ref_scores).max() < 1e-4      # north_star: class scores within 1e-4
+    assert np.abs(bbox.cpu().numpy() - ref_bbox).max() < 1e-4 * s["W"]  # pixels, relative to the image extent
+
+
+def test_pipeline_nms_on_own_outputs_bit_exact(O, dev, small):
+    """SURVEY §7 parity protocol: kept sets are compared with the oracle fed the DEVICE's scored boxes (so
+    1e-7-level score differences cannot flip a near-threshold IoU decision)."""
+    s, net = SMALL, small["net"]
+    im, boxes = torch.from_numpy(small["im"]).to(dev), torch.from_numpy(small["boxes"]).to(dev)
+    dets, n = net.test_one_async(im, boxes)
+    torch.cuda.synchronize()
+    dets = dets[: int(n.item())].cpu().numpy()
+    keep, idx, nk = [t.cpu().numpy() for t in net.nms_results()]
+    scores, bbox = [t.cpu().numpy() for t in net.detect(im, boxes)]
+    per = []
+    for j in range(1, s["C"]):
+        sb, src = O.select_scored(scores, bbox, j, -1.5)
+        ref, ridx = O.nms(sb, 0.3, return_index=True)
+        assert nk[j - 1] == ref.shape[0]
+        assert np.array_equal(keep[j - 1, :nk[j - 1]], ref)
+        assert np.array_equal(idx[j - 1, :nk[j - 1]], src[ridx])
+        per.append(ref)
+    kept, thr = O.keep_top_k(per, 100)
+    exp = np.concatenate([np.concatenate([k, np.full((k.shape[0], 1), j + 1, np.float32)], 1) for j, k in enumerate(kept) if k.size])
+    assert dets.shape == exp.shape and np.array_equal(dets, exp)
+
+
+def test_host_mirror_tester(O, dev, small):
+    """Tester_FRCNN.testOne / ImageDetect.detect orchestration (Python mirror) == fused device path."""
+    from multipathnet_amd import detect
+    net = small["net"]
+    im, boxes = torch.from_numpy(small["im"]), torch.from_numpy(small["boxes"])
+    tester = detect.Tester_FRCNN(net, opt={"test_nms_threshold": 0.3})
+    img_boxes, (output, bbox_pred) = tester.testOne(im, boxes)
+    net.test_one_async(im.to(dev), boxes.to(dev))
+    keep, _, nk = [t.cpu() for t in net.nms_results()]
+    for j, kb in enumerate(img_boxes):
+        assert torch.equal(kb.cpu(), keep[j, : int(nk[j])])
+    assert set(tester.last_timing) == {"forward", "nms", "total"}
+    # iterative localisation (Tester_FRCNN.lua:82-89): second pass doubles the scored rows
+    t2 = detect.Tester_FRCNN(net, opt={"test_num_iterative_loc": 2})
+    _, (out2, bb2) = t2.testOne(im, boxes)
+    assert out2.shape[0] == 2 * boxes.shape[0] and torch.equal(out2[: boxes.shape[0]], output)
+
+
+def test_detect_is_deterministic_and_roi_order_equivariant(dev, small):
+    net = small["net"]
+    im, boxes = torch.from_numpy(small["im"]).to(dev), torch.from_numpy(small["boxes"]).to(dev)
+    a, b = net.detect(im, boxes)
+    a2, b2 = net.detect(im, boxes)
+    assert torch.equal(a, a2) and torch.equal(b, b2)
+    perm = torch.randperm(boxes.size(0), generator=torch.Generator().manual_seed(0)).to(dev)
+    ap, bp = net.detect(im, boxes[perm].contiguous())
+    assert torch.equal(ap, a[perm]) and torch.equal(bp, b[perm])   # rows are independent: exact
+    sub, _ = net.detect(im, boxes[:77].contiguous())                  # memoryEfficientForward property (ImageDetect.lua:126-133)
+    assert torch.equal(sub, a[:77])
+
+
+@pytest.mark.parametrize("H,W", [(75, 125), (149, 251), (64, 96)])
+def test_other_image_sizes_rezero_halo(O, dev, H, W):
+    """changing the image size moves the zero halo of the C8P buffers; results must not depend on history"""
+    from multipathnet_amd import models
+    cfg = [8, 8, "P", 16, "P", 16]
+    P = models.synthetic_params(cfg, pooled=7, fc_dim=32, n_classes=4, seed=1)
+    net = models.FastRCNN(P, cfg=cfg, pooled=7, spatial_scale=0.25, max_h=150, max_w=256, max_rois=64)
+    rng = np.random.default_rng(H)
+    big = torch.from_numpy(rng.random((3, 150, 256), dtype=np.float32)).to(dev)
+    net.detect(big, torch.from_numpy(_boxes(rng, 64, 256, 150)).to(dev))  # dirty the buffers at max size
+    im = rng.random((3, H, W), dtype=np.float32)
+    boxes = _boxes(rng, 50, W, H)
+    scores, bbox = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+    Pn = _np_params(P)
+    feat = O.vgg_trunk(O.image_transform(im, **O.ROSS), Pn["conv_w"], Pn["conv_b"], cfg)
+    logits, deltas = O.frcnn_head(feat, O.project_im_rois(boxes, 1.0), Pn, pooled=7, spatial_scale=0.25)
+    assert np.abs(scores.cpu().numpy() - O.softmax(logits)).max() < 1e-4
+    ref_bbox = O.clamp_boxes(O.bbox_decode(boxes, deltas), W, H)
+    assert np.abs(bbox.cpu().numpy() - ref_bbox).max() < 1e-4 * W

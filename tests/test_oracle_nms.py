@@ -1,0 +1,87 @@
+"""Pins the oracle's NMS family: (1) the reference's IoU known-answer vector (test.lua:40-52);
+(2) bit-for-bit agreement of the C restatement with the reference's OWN nms.c compiled unmodified
+(oracle/_ref/libnms_ref.so) over score regimes that exercise the tie-break history (nms.c:74-98)."""
+import numpy as np
+import pytest
+
+from conftest import random_scored_boxes
+
+
+def test_iou_known_answer(O):
+    # test.lua:40-52 — utils.boxoverlap KAT, tolerance 5e-3 as in the reference
+    a = np.array([[0, 0, 100, 100], [0, 50, 100, 150], [50, 0, 150, 100], [50, 50, 150, 150], [100, 100, 200, 200]], np.float32)
+    gt = np.array([1 / 7, 1 / 3, 1 / 3, 1, 1 / 7], np.float32)
+    assert np.abs(O.boxoverlap(a, [50, 50, 150, 150]) - gt).max() < 5e-3
+    if O.have_ref():
+        got = np.array([O.ref_overlap(r, [50, 50, 150, 150]) for r in a], np.float32)
+        assert np.array_equal(got, O.boxoverlap(a, [50, 50, 150, 150]))
+
+
+def test_overlap_degenerate(O):
+    assert O.overlap([0, 0, 10, 10], [20, 20, 30, 30]) == 0.0           # disjoint
+    assert O.overlap([0, 0, 10, 10], [11, 0, 20, 10]) == 0.0            # w == 0 exactly (x2-x1+1 = 0)
+    assert O.overlap([0, 0, 10, 10], [10, 10, 20, 20]) > 0.0            # touching pixels overlap by 1 px (+1 convention)
+
+
+@pytest.mark.parametrize("regime", ["distinct", "ties", "saturated", "allequal"])
+@pytest.mark.parametrize("n", [1, 2, 7, 64, 65, 300, 1000])
+@pytest.mark.parametrize("thr", [0.3, 0.5])
+def test_nms_matches_reference_c(O, regime, n, thr):
+    if not O.have_ref():
+        pytest.skip("oracle/_ref/libnms_ref.so not built (needs /root/reference)")
+    rng = np.random.default_rng(hash((regime, n)) % 2**32)
+    sb = random_scored_boxes(rng, n, regime, span=300.0 if n <= 65 else 1000.0)
+    mine, idx = O.nms(sb, thr, return_index=True)
+    ref = O.ref_nms(sb, thr)
+    assert mine.shape == ref.shape and np.array_equal(mine, ref)
+    assert np.array_equal(sb[idx], mine)
+
+
+def test_nms_empty_and_single(O):
+    assert O.nms(np.zeros((0, 5), np.float32), 0.3).shape == (0, 5)
+    if O.have_ref():
+        assert O.ref_nms(np.zeros((0, 5), np.float32), 0.3).shape == (0, 5)
+    one = np.array([[1, 1, 5, 5, 0.3]], np.float32)
+    assert np.array_equal(O.nms(one, 0.3), one)
+
+
+def test_nms_tie_history_is_order_dependent(O):
+    """The property that forces the position-key emulation: with equal scores the winner is NOT simply
+    'lowest index' once a swap has moved the old first element (nms.c:83-85)."""
+    if not O.have_ref():
+        pytest.skip("needs reference nms.c")
+    sb = np.array([[0, 0, 10, 10, 0.5],       # A (first)
+                   [100, 100, 110, 110, 0.5],  # B
+                   [200, 200, 210, 210, 0.9],  # C best -> swapped with A, so A now sits after B
+                   ], np.float32)
+    ref = O.ref_nms(sb, 0.3)
+    assert np.array_equal(ref[:, :4], sb[[2, 1, 0], :4])  # C, then B (now first), then A
+    assert np.array_equal(O.nms(sb, 0.3), ref)
+
+
+@pytest.mark.parametrize("regime", ["distinct", "ties"])
+def test_bbox_vote_matches_reference_c(O, regime):
+    if not O.have_ref():
+        pytest.skip("needs reference nms.c")
+    rng = np.random.default_rng(11)
+    sb = random_scored_boxes(rng, 400, regime, span=400.0)
+    sb[:, 4] = np.maximum(sb[:, 4], 1e-3)
+    keep = O.nms(sb, 0.3)
+    a, b = O.bbox_vote(keep, sb, 0.5), O.ref_bbox_vote(keep, sb, 0.5)
+    assert np.array_equal(a, b)
+
+
+def test_decode_roundtrip_property(O):
+    # test.lua:17-38 — convertFrom(convertTo(b,t)) == t (we check it in fp32 with a matching tolerance)
+    rng = np.random.default_rng(3)
+    A, B = rng.random((50, 2)) * 100, rng.random((50, 2)) * 100
+    bbox = np.concatenate([A, A + rng.integers(1, 41, (50, 2))], 1).astype(np.float32)
+    tbox = np.concatenate([B, B + rng.integers(1, 41, (50, 2))], 1).astype(np.float32)
+    # utils.convertTo (utils.lua:176-199): dx=(xc_t-xc)/w, dw=log(w_t/w)
+    w, h = bbox[:, 2] - bbox[:, 0], bbox[:, 3] - bbox[:, 1]
+    xc, yc = (bbox[:, 0] + bbox[:, 2]) * 0.5, (bbox[:, 1] + bbox[:, 3]) * 0.5
+    wt, ht = tbox[:, 2] - tbox[:, 0], tbox[:, 3] - tbox[:, 1]
+    xt, yt = (tbox[:, 0] + tbox[:, 2]) * 0.5, (tbox[:, 1] + tbox[:, 3]) * 0.5
+    d = np.stack([(xt - xc) / w, (yt - yc) / h, np.log(wt / w), np.log(ht / h)], 1).astype(np.float32)
+    out = O.bbox_decode(bbox, d)
+    assert np.abs(out - tbox).max() < 1e-3
