@@ -65,7 +65,8 @@ def test_image_transformer_and_projection_bit_exact(O, dev):
     b = _rois(rng, 100)[:, 1:].copy()
     for s in (1.0, 600 / 480, 0.731):
         out = torch.empty((100, 5), device=dev)
-        _lib.check(lib.mpn_project_im_rois(nn._f(_t(b, dev)), 100, C.c_double(s), nn._f(out), None))
+        d_b = _t(b, dev)
+        _lib.check(lib.mpn_project_im_rois(nn._f(d_b), 100, C.c_double(s), nn._f(out), None))
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy(), O.project_im_rois(b, s))
     for (h, w) in [(600, 1000), (1000, 600), (480, 640), (300, 1000), (375, 500)]:
@@ -103,7 +104,8 @@ def test_select_scored_and_keep_top_k(O, dev):
         scored = torch.empty((Cc - 1, N, 5), device=dev)
         counts = torch.zeros(Cc - 1, dtype=torch.int32, device=dev)
         src = torch.zeros((Cc - 1, N), dtype=torch.int32, device=dev)
-        _lib.check(_lib.load().mpn_select_scored(nn._f(_t(scores, dev)), nn._f(_t(bbox, dev)), N, Cc, 1, C.c_float(thresh),
+        d_scores, d_bbox = _t(scores, dev), _t(bbox, dev)  # keep the device buffers alive across the async call
+        _lib.check(_lib.load().mpn_select_scored(nn._f(d_scores), nn._f(d_bbox), N, Cc, 1, C.c_float(thresh),
                                                  nn._f(scored), nn._i(counts), nn._i(src), None))
         torch.cuda.synchronize()
         for j in range(1, Cc):

@@ -101,7 +101,7 @@ def test_host_mirror_tester(O, dev, small):
     from multipathnet_amd import detect
     net = small["net"]
     im, boxes = torch.from_numpy(small["im"]), torch.from_numpy(small["boxes"])
-    tester = detect.Tester_FRCNN(net, opt={"test_nms_threshold": 0.3})
+    tester = detect.Tester_FRCNN(net, scale=[SMALL["H"]], max_size=SMALL["W"], opt={"test_nms_threshold": 0.3})
     img_boxes, (output, bbox_pred) = tester.testOne(im, boxes)
     net.test_one_async(im.to(dev), boxes.to(dev))
     keep, _, nk = [t.cpu() for t in net.nms_results()]
@@ -109,7 +109,7 @@ def test_host_mirror_tester(O, dev, small):
         assert torch.equal(kb.cpu(), keep[j, : int(nk[j])])
     assert set(tester.last_timing) == {"forward", "nms", "total"}
     # iterative localisation (Tester_FRCNN.lua:82-89): second pass doubles the scored rows
-    t2 = detect.Tester_FRCNN(net, opt={"test_num_iterative_loc": 2})
+    t2 = detect.Tester_FRCNN(net, scale=[SMALL["H"]], max_size=SMALL["W"], opt={"test_num_iterative_loc": 2})
     _, (out2, bb2) = t2.testOne(im, boxes)
     assert out2.shape[0] == 2 * boxes.shape[0] and torch.equal(out2[: boxes.shape[0]], output)
 
