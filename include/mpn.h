@@ -213,6 +213,15 @@ int mpn_frcnn_test_one(mpn_frcnn *p, const float *d_image, int H, int W, const f
                        int top_cap, int *d_n_dets, void *stream);
 int mpn_frcnn_nms_results(mpn_frcnn *p, const float **d_keep, const int **d_keep_idx, const int **d_n_keep,
                           int *m_stride);
+/* Per-kernel-group timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+ * Tags index the arrays returned by mpn_frcnn_get_profile (accumulated ms and launch-group counts). */
+enum {
+  MPN_PROF_TRANSFORM = 0, MPN_PROF_CONV_128x4, MPN_PROF_CONV_64x8, MPN_PROF_POOL, MPN_PROF_ROIPOOL, MPN_PROF_FC6,
+  MPN_PROF_FC7, MPN_PROF_HEADS, MPN_PROF_POST, MPN_PROF_SELECT, MPN_PROF_NMS, MPN_PROF_TOPK, MPN_PROF_NTAGS
+};
+int mpn_frcnn_set_profiling(mpn_frcnn *p, int enable);
+int mpn_frcnn_get_profile(mpn_frcnn *p, double *ms, long *counts, int n_tags, int reset);
+
 /* Intermediate activations for parity tests: name in {"conv5","pooled","fc7","cls","bbox_raw"}. */
 int mpn_frcnn_debug_tensor(mpn_frcnn *p, const char *name, const float **d_ptr, size_t *n_elems);
 

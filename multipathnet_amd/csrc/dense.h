@@ -61,6 +61,7 @@ int image_transform_c8p(const float *d_in, int H, int W, const int *swap, double
 // out = relu?(conv3x3(in) + b); optional fused ceil-mode 2x2 max-pool writes `pooled` as well
 // (out.p may be null when only the pooled map is needed).
 int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int relu, Act out, Act pooled, hipStream_t s);
+int conv3x3_variant_for(int Cout);  // 1 = 128 couts x 4 rows x 32 cols tile, 2 = 64 x 8 x 32
 int maxpool2x2_c8p(Act in, Act out, hipStream_t s);
 // y = relu?(x W^T + b).  x: C8 matrix [K8/8][Mp][8]; y: C8 matrix [NP/8][Mp][8] (y_c8) and/or
 // row-major [M,N] (y_rm); either may be null.

@@ -217,6 +217,12 @@ static int launch_conv(const ConvArgs &a0, int tiles_y, hipStream_t s) {
 
 static int g_conv_variant = 0;  // 0 = auto; test/bench hook: 1 = force 128x4 tile, 2 = force 64x8, +16 = register staging
 
+int conv3x3_variant_for(int Cout) {
+  int variant = g_conv_variant & 15;
+  if (variant == 0) variant = (Cout <= 64) ? 2 : 1;
+  return variant;
+}
+
 int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int relu, Act out, Act pooled, hipStream_t s) {
   MPN_CHECK_ARG(in.p && d_wpk && d_bpk && (out.p || pooled.p));
   ConvArgs a{};
@@ -229,9 +235,8 @@ int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int re
   a.tiles_x = cdiv(in.W, 32);
   if (out.p) MPN_CHECK_ARG(out.H == in.H && out.W == in.W && out.C == Cout);
   if (pooled.p) MPN_CHECK_ARG(pooled.H == (in.H + 1) / 2 && pooled.W == (in.W + 1) / 2 && pooled.C == Cout);
-  int variant = g_conv_variant & 15;
-  bool regstage = (g_conv_variant & 16) != 0;
-  if (variant == 0) variant = (Cout <= 64) ? 2 : 1;
+  const int variant = conv3x3_variant_for(Cout);
+  const bool regstage = (g_conv_variant & 16) != 0;
   if (variant == 1) {
     a.n_ct = cdiv(Cout, 128);
     int tiles_y = cdiv(in.H, 4);

@@ -57,8 +57,9 @@ constexpr int kDead = 0x7fffffff;
 __global__ __launch_bounds__(64) void nms_wave_kernel(const float *__restrict__ scored, const int *__restrict__ counts,
                                                       int m_stride, float thr, float *__restrict__ keep,
                                                       int *__restrict__ keep_idx, int *__restrict__ n_keep,
-                                                      int m_cap) {
+                                                      int m_cap, const int *__restrict__ flags) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (flags && flags[blockIdx.x] != 2) return;  // this class took a sorted/bitmask path
   float *X1 = lds, *Y1 = lds + m_cap, *X2 = lds + 2 * m_cap, *Y2 = lds + 3 * m_cap, *S = lds + 4 * m_cap;
   int *POS = reinterpret_cast<int *>(lds + 5 * m_cap);
 
@@ -125,6 +126,368 @@ __global__ __launch_bounds__(64) void nms_wave_kernel(const float *__restrict__ 
   if (lane == 0) n_keep[cls] = kept;
 }
 
+
+// =================================================================================================
+// Fast path: classes whose scores are all distinct (the common case).  With no bit-equal scores the
+// reference's pick order is simply "descending score", so the greedy loop factors into three
+// data-parallel / latency-short phases (the exact wave kernel above stays the fallback for classes
+// with ties, NaNs, or more boxes than the sort's LDS budget):
+//   1. sort_kernel   one block per class: LDS bitonic sort of 64-bit keys (score desc, index asc);
+//                    writes boxes in rank order, detects ties -> flags[c] = 1 (fallback).
+//   2. mask_kernel   whole GPU: 64-bit suppression words  mask[c][i][w] bit j = IoU(rank i, rank 64w+j) > thr
+//                    for j > i (upper triangle only), IoU evaluated exactly as nms.c:14-41.
+//   3. scan_kernel   one wavefront per class walks ranks in 64-box chunks: the chunk's diagonal word is
+//                    resolved with scalar bit tricks (ctz / readlane), then the rows of the kept boxes —
+//                    speculatively loaded for the whole chunk, 64 independent loads in flight — are OR-ed
+//                    into the per-lane `removed` words.
+// =================================================================================================
+__device__ __forceinline__ unsigned nms_f2key(float f) {
+  unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+constexpr int kSortMax = 8192;  // 64 KiB of LDS keys
+constexpr int kTieMax = 4096;   // nms_tie_kernel: one 64-bit alive/occupancy word per lane
+constexpr int kTieLdsMask = 1024;  // full symmetric mask kept in LDS up to this many boxes (128 KiB)
+
+__global__ __launch_bounds__(1024) void nms_sort_kernel(const float *__restrict__ scored, const int *__restrict__ counts,
+                                                        int m_stride, float4 *__restrict__ sbox, float *__restrict__ sscore,
+                                                        int *__restrict__ sidx, int *__restrict__ n_sel,
+                                                        int *__restrict__ flags, int force_mode) {
+  // flags[c]: 0 = tie-free -> chunked scan; 1 = ties -> nms_tie_kernel (exact slot emulation on the
+  // bitmask); 2 = NaN scores or too many boxes -> nms_wave_kernel (exact IoU sweep)
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+  __shared__ int bad, nsel, hasnan;
+  const int cls = blockIdx.x, tid = threadIdx.x;
+  int m = counts ? counts[cls] : m_stride;
+  if (m > m_stride) m = m_stride;
+  int n_pad = 64;
+  while (n_pad < m) n_pad <<= 1;
+  if (tid == 0) { bad = 0; nsel = 0; hasnan = 0; }
+  __syncthreads();
+  if (m > kSortMax || force_mode == 1) { if (tid == 0) { flags[cls] = 2; n_sel[cls] = 0; } return; }
+  const float *src = scored + (size_t)cls * m_stride * 5;
+  for (int i = tid; i < n_pad; i += blockDim.x) {
+    unsigned long long k = ~0ull;
+    if (i < m) {
+      float s = src[5 * (size_t)i + 4];
+      if (s != s) hasnan = 1;  // NaN: let the exact sweep kernel reproduce the reference's behaviour
+      k = ((unsigned long long)(~nms_f2key(s)) << 32) | (unsigned)i;
+    }
+    keys[i] = k;
+  }
+  __syncthreads();
+  for (int k = 2; k <= n_pad; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < n_pad / 2; t += blockDim.x) {
+        int lo = (t / j) * 2 * j + (t % j), hi = lo + j;
+        bool up = ((lo & k) == 0);
+        unsigned long long a = keys[lo], b = keys[hi];
+        if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+      }
+      __syncthreads();
+    }
+  float4 *ob = sbox + (size_t)cls * m_stride;
+  float *os = sscore + (size_t)cls * m_stride;
+  int *oi = sidx + (size_t)cls * m_stride;
+  int local_sel = 0;
+  for (int p = tid; p < m; p += blockDim.x) {
+    unsigned long long k = keys[p];
+    int i = (int)(unsigned)k;
+    if (p + 1 < m && (unsigned)(keys[p + 1] >> 32) == (unsigned)(k >> 32)) bad = 1;  // bit-equal scores
+    const float *r = src + 5 * (size_t)i;
+    float s = r[4];
+    ob[p] = make_float4(r[0], r[1], r[2], r[3]);
+    os[p] = s;
+    oi[p] = i;
+    if (s > -10000000.0f) ++local_sel;  // nms.c:75: never picked otherwise; sorted => a prefix
+  }
+  atomicAdd(&nsel, local_sel);
+  __syncthreads();
+  if (tid == 0) {
+    int f = hasnan ? 2 : ((bad || force_mode == 2) ? 1 : 0);
+    if (f == 1 && m > kTieMax) f = 2;
+    flags[cls] = f;
+    n_sel[cls] = nsel;
+  }
+}
+
+__global__ __launch_bounds__(256) void nms_mask_kernel(const float4 *__restrict__ sbox, const int *__restrict__ n_sel,
+                                                       const int *__restrict__ flags, const int *__restrict__ counts,
+                                                       int m_stride, int w64, float thr,
+                                                       unsigned long long *__restrict__ mask) {
+  __shared__ float4 cols[64];
+  const int cls = blockIdx.z;
+  const int flag = flags[cls];
+  if (flag == 2) return;
+  const bool full = flag == 1;  // tie classes: full symmetric rows over ALL boxes (unpickable ones can still be suppressed)
+  const int n = n_sel[cls];     // rows: only pickable ranks ever suppress
+  int m = counts ? counts[cls] : m_stride;
+  if (m > m_stride) m = m_stride;
+  const int ncol = full ? m : n;
+  const int w = blockIdx.x, rb = blockIdx.y;
+  if (w * 64 >= ncol || rb * 256 >= n) return;
+  if (!full && rb * 256 > w * 64 + 63) return;  // strictly lower triangle: never read by the chunked scan
+  const float4 *b = sbox + (size_t)cls * m_stride;
+  if (threadIdx.x < 64) {
+    int j = w * 64 + threadIdx.x;
+    cols[threadIdx.x] = j < ncol ? b[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  const int i = rb * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 a = b[i];
+  unsigned long long bits = 0;
+  const int jn = min(64, ncol - w * 64);
+  for (int jj = 0; jj < jn; ++jj) {
+    const int j = w * 64 + jj;
+    if (full ? (j == i) : (j <= i)) continue;
+    const float4 c = cols[jj];
+    float iou = iou_plus1(a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w);  // overlap(best, other), nms.c:92
+    if (!(iou <= thr)) bits |= 1ull << jj;
+  }
+  mask[((size_t)cls * m_stride + i) * w64 + w] = bits;
+}
+
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
+  unsigned lo = __builtin_amdgcn_readlane((unsigned)v, l);
+  unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int WPL>  // 64-bit `removed` words per lane: covers m <= 4096 * WPL
+__global__ __launch_bounds__(64) void nms_scan_kernel(const float4 *__restrict__ sbox, const float *__restrict__ sscore,
+                                                      const int *__restrict__ sidx, const int *__restrict__ n_sel,
+                                                      const int *__restrict__ flags, int m_stride, int w64,
+                                                      const unsigned long long *__restrict__ mask, float *__restrict__ keep,
+                                                      int *__restrict__ keep_idx, int *__restrict__ n_keep) {
+  const int cls = blockIdx.x, lane = threadIdx.x;
+  if (flags[cls] != 0) return;
+  const int n = n_sel[cls];
+  const float4 *b = sbox + (size_t)cls * m_stride;
+  const float *sc = sscore + (size_t)cls * m_stride;
+  const int *si = sidx + (size_t)cls * m_stride;
+  const unsigned long long *mk = mask + (size_t)cls * m_stride * w64;
+  float *kout = keep + (size_t)cls * m_stride * 5;
+  int *kidx = keep_idx ? keep_idx + (size_t)cls * m_stride : nullptr;
+  unsigned long long removed[WPL];
+#pragma unroll
+  for (int h = 0; h < WPL; ++h) removed[h] = 0;
+  int kept = 0;
+  const int nchunks = (n + 63) >> 6;
+  unsigned long long diag = (lane < n) ? mk[(size_t)lane * w64] : 0ull;
+  for (int c = 0; c < nchunks; ++c) {
+    const int base = c << 6;
+    // speculative: every row of this chunk, this lane's word(s) — independent loads, all in flight
+    unsigned long long rows[64];
+    if (lane > c && lane < w64) {
+#pragma unroll
+      for (int r = 0; r < 64; ++r) rows[r] = (base + r < n) ? mk[(size_t)(base + r) * w64 + lane] : 0ull;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 64; ++r) rows[r] = 0ull;
+    }
+    unsigned long long diag_next = 0ull;
+    if (c + 1 < nchunks && base + 64 + lane < n) diag_next = mk[(size_t)(base + 64 + lane) * w64 + (c + 1)];
+    // resolve the chunk's own 64x64 block serially with wave-uniform bit arithmetic
+    unsigned long long rsel = removed[0];
+    if constexpr (WPL > 1) { if (c >= 64) rsel = removed[1]; }
+    const unsigned long long rem_c = readlane64(rsel, c & 63);
+    const int nv = min(64, n - base);
+    unsigned long long alive = ~rem_c & (nv == 64 ? ~0ull : ((1ull << nv) - 1ull));
+    unsigned long long keptmask = 0ull;
+    while (alive) {
+      const int bit = __builtin_ctzll(alive);
+      keptmask |= 1ull << bit;
+      alive &= ~readlane64(diag, bit);
+      alive &= ~(1ull << bit);
+    }
+    // emit kept boxes in rank order
+    const bool mine = (keptmask >> lane) & 1ull;
+    if (mine) {
+      const int o = kept + __popcll(keptmask & ((1ull << lane) - 1ull));
+      const float4 bx = b[base + lane];
+      float *q = kout + (size_t)o * 5;
+      q[0] = bx.x; q[1] = bx.y; q[2] = bx.z; q[3] = bx.w; q[4] = sc[base + lane];
+      if (kidx) kidx[o] = si[base + lane];
+    }
+    kept += __popcll(keptmask);
+    // fold the kept rows into `removed` (words after this chunk)
+    unsigned long long acc = 0ull;
+#pragma unroll
+    for (int r = 0; r < 64; ++r) acc |= ((keptmask >> r) & 1ull) ? rows[r] : 0ull;
+    removed[0] |= acc;
+    if constexpr (WPL > 1) {  // second word per lane (m > 4096): non-speculative, batched
+      const int wsec = lane + 64;
+      if (wsec < w64 && wsec > c) {
+        unsigned long long km = keptmask;
+        unsigned long long acc2 = 0ull;
+        while (km) {
+          const int r = __builtin_ctzll(km);
+          km &= km - 1;
+          acc2 |= mk[(size_t)(base + r) * w64 + wsec];
+        }
+        removed[1] |= acc2;
+      }
+    }
+    diag = diag_next;
+  }
+  if (lane == 0) n_keep[cls] = kept;
+}
+
+
+// Tier 2: classes with bit-equal scores.  The reference's winner among equal scores depends on where
+// its array swap (nms.c:83-85) has moved boxes, so the array is emulated exactly — but on the bitmask,
+// not by re-sweeping IoUs: ranks (sorted order) index `alive` and the suppression rows; SLOTS (positions
+// in the reference's array) index `occ`.  Per pick: first alive rank (ballot/ctz) -> among its alive
+// equal-score run take the smallest slot -> head = first occupied slot holding an alive box (lazy
+// deletion) -> the head inherits the pick's slot -> alive &= ~row[pick].  One wave per class does the
+// serial part; the block's other waves only help stage the mask into LDS.
+__device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int l) {
+  unsigned lo = __shfl((unsigned)v, l), hi = __shfl((unsigned)(v >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+template <bool LDSMASK>
+__global__ __launch_bounds__(256) void nms_tie_kernel(const float4 *__restrict__ sbox, const float *__restrict__ sscore,
+                                                      const int *__restrict__ sidx, const int *__restrict__ n_sel,
+                                                      const int *__restrict__ flags, const int *__restrict__ counts,
+                                                      int m_stride, int w64, const unsigned long long *__restrict__ mask,
+                                                      float *__restrict__ keep, int *__restrict__ keep_idx,
+                                                      int *__restrict__ n_keep, int m_cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long lds64[];
+  const int cls = blockIdx.x;
+  if (flags[cls] != 1) return;
+  int m = counts ? counts[cls] : m_stride;
+  if (m > m_stride) m = m_stride;
+  if (LDSMASK != (m <= kTieLdsMask)) return;  // the other instantiation handles this class
+  const int n = n_sel[cls];
+  const int W = (m + 63) >> 6;
+  unsigned long long *mlds = lds64;                                                    // [n][W] when LDSMASK
+  int *pos_r = reinterpret_cast<int *>(lds64 + (LDSMASK ? (size_t)kTieLdsMask * (kTieLdsMask / 64) : 0));
+  int *box_at = pos_r + m_cap;
+  int *gend = box_at + m_cap;
+  int *kept_list = gend + m_cap;
+  const float4 *b4 = sbox + (size_t)cls * m_stride;
+  const float *sc = sscore + (size_t)cls * m_stride;
+  const int *si = sidx + (size_t)cls * m_stride;
+  const unsigned long long *mk = mask + (size_t)cls * m_stride * w64;
+  const int tid = threadIdx.x;
+  float *sc_l = reinterpret_cast<float *>(kept_list + m_cap);                 // scores in rank order
+  unsigned long long *tiew = reinterpret_cast<unsigned long long *>(sc_l + m_cap);  // [64] tie-next words
+  if (LDSMASK) {  // stage the class's mask rows: 8 independent 8-byte loads in flight per thread
+    const int total = n * W;
+    for (int t0 = 0; t0 < total; t0 += 256 * 8) {
+      unsigned long long v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int t = t0 + j * 256 + tid;
+        const int r = t / W, w = t - r * W;
+        v[j] = t < total ? mk[(size_t)r * w64 + w] : 0ull;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int t = t0 + j * 256 + tid;
+        if (t < total) mlds[t] = v[j];
+      }
+    }
+  }
+  for (int r = tid; r < m; r += blockDim.x) {
+    const int x = si[r];
+    pos_r[r] = x;
+    box_at[x] = r;
+    sc_l[r] = sc[r];
+  }
+  if (tid < 64) tiew[tid] = 0ull;
+  __syncthreads();
+  for (int r0 = 0; r0 < m; r0 += blockDim.x) {
+    const int r = r0 + tid;
+    // bit r of the tie words: rank r+1 exists, both are pickable (< n) and carry the same score
+    const bool tie = (r + 1 < n) && (sc_l[r] == sc_l[r + 1]);
+    const unsigned long long bal = __ballot(tie);
+    if ((tid & 63) == 0 && r < m) tiew[r >> 6] = bal;
+    if (r < m) {
+      const bool start = (r == 0) || !(r < n && sc_l[r - 1] == sc_l[r]);
+      if (start) {  // the first element of each equal-score run fills in the run's last rank
+        int e = r;
+        while (e + 1 < n && sc_l[e + 1] == sc_l[r]) ++e;
+        for (int q = r; q <= e; ++q) gend[q] = e;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid >= 64) return;
+  const int lane = tid;
+  float *kout = keep + (size_t)cls * m_stride * 5;
+  int *kidx = keep_idx ? keep_idx + (size_t)cls * m_stride : nullptr;
+  unsigned long long alive = 0ull;
+  if (lane < W) { int nv = min(64, m - lane * 64); alive = nv == 64 ? ~0ull : ((1ull << nv) - 1ull); }
+  unsigned long long occ = alive;  // slots 0..m-1 all occupied
+  const unsigned long long tiebits = tiew[lane];
+  int kept = 0;
+  for (;;) {
+    const unsigned long long bal = __ballot(alive != 0ull);
+    if (!bal) break;
+    const int L = __builtin_ctzll(bal);
+    const int r0 = (L << 6) + __builtin_ctzll(readlane64(alive, L));
+    if (r0 >= n) break;  // only boxes with score <= -1e7 are left: the reference would never pick them
+    int b = r0;
+    int e = r0;
+    // r0 is the first alive rank of its run; the run continues past r0 iff r0's tie bit is set
+    if ((readlane64(tiebits, r0 >> 6) >> (r0 & 63)) & 1ull) e = __builtin_amdgcn_readfirstlane(gend[r0]);
+    if (e > r0) {  // equal-score run: the reference takes the one sitting first in its array
+      int bp = 0x7fffffff, br = -1;
+      for (int base = r0; base <= e; base += 64) {
+        const int r = base + lane;
+        bool ok = r <= e;
+        const unsigned long long aw = shfl64(alive, (ok ? r : r0) >> 6);
+        ok = ok && ((aw >> (r & 63)) & 1ull);
+        const int p = ok ? pos_r[r] : 0x7fffffff;
+        if (p < bp) { bp = p; br = r; }
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const int op = __shfl_xor(bp, off), orr = __shfl_xor(br, off);
+        if (op < bp) { bp = op; br = orr; }
+      }
+      b = __builtin_amdgcn_readfirstlane(br);
+    }
+    const int sb = __builtin_amdgcn_readfirstlane(pos_r[b]);
+    // head of the reference's array = first occupied slot whose box is still alive (lazy deletion)
+    int hs, f;
+    for (;;) {
+      const unsigned long long ob = __ballot(occ != 0ull);
+      const int L2 = __builtin_ctzll(ob);
+      const int bit = __builtin_ctzll(readlane64(occ, L2));
+      hs = (L2 << 6) + bit;
+      f = __builtin_amdgcn_readfirstlane(box_at[hs]);
+      if ((readlane64(alive, f >> 6) >> (f & 63)) & 1ull) break;
+      if (lane == L2) occ &= ~(1ull << bit);
+    }
+    if (f != b) {  // nms.c:83-85: boxes[0] <-> boxes[best]
+      if (lane == (hs >> 6)) occ &= ~(1ull << (hs & 63));
+      box_at[sb] = f;
+      pos_r[f] = sb;
+    } else {
+      if (lane == (sb >> 6)) occ &= ~(1ull << (sb & 63));
+    }
+    kept_list[kept] = b;  // emitted after the loop: no global-memory latency on the serial chain
+    ++kept;
+    if (lane == (b >> 6)) alive &= ~(1ull << (b & 63));
+    unsigned long long row = 0ull;
+    if (lane < W) row = LDSMASK ? mlds[(size_t)b * W + lane] : mk[(size_t)b * w64 + lane];
+    alive &= ~row;
+  }
+  for (int k = lane; k < kept; k += kWave) {
+    const int b = kept_list[k];
+    const float4 bx = b4[b];
+    float *q = kout + (size_t)k * 5;
+    q[0] = bx.x; q[1] = bx.y; q[2] = bx.z; q[3] = bx.w; q[4] = sc[b];
+    if (kidx) kidx[k] = si[b];
+  }
+  if (lane == 0) n_keep[cls] = kept;
+}
+
 // nms.c:110-142.  One wave per kept box would reorder the sequential fp32 sums, so each LANE owns one
 // kept box and walks the scored boxes (staged in LDS tiles) in j order: the accumulation order — and
 // hence every rounding — is the reference's.
@@ -171,6 +534,9 @@ __global__ void boxoverlap_kernel(const float *__restrict__ a, int n, float bx1,
 
 using namespace mpn;
 
+static int g_nms_force_exact = 0;  // test hook: 1 = always the exact IoU-sweep kernel, 2 = always the tie (slot-emulation) kernel
+extern "C" void mpn_debug_set_nms_force_exact(int v) { g_nms_force_exact = v; }
+
 extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n_cls, int m_stride, float thr,
                                float *d_keep, int *d_keep_idx, int *d_n_keep, void *stream) {
   MPN_CHECK_ARG(n_cls >= 0 && m_stride >= 0);
@@ -182,6 +548,73 @@ extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n
     return MPN_OK;
   }
   MPN_CHECK_ARG(d_scored != nullptr && d_keep != nullptr);
+  hipStream_t st = as_stream(stream);
+  // ---- scratch for the fast path (library-owned, grown on demand, one stream at a time)
+  const int w64 = (m_stride + 63) / 64;
+  const size_t n_rows = (size_t)n_cls * m_stride;
+  const size_t need = n_rows * (sizeof(float4) + sizeof(float) + sizeof(int)) + n_rows * w64 * sizeof(unsigned long long) +
+                      (size_t)n_cls * 2 * sizeof(int) + 256;
+  static char *scratch = nullptr;
+  static size_t scratch_bytes = 0;
+  if (need > scratch_bytes) {
+    MPN_CHECK_HIP(hipStreamSynchronize(st));
+    if (scratch) (void)hipFree(scratch);
+    scratch = nullptr; scratch_bytes = 0;
+    MPN_CHECK_HIP(hipMalloc(&scratch, need));
+    scratch_bytes = need;
+  }
+  unsigned long long *mask = reinterpret_cast<unsigned long long *>(scratch);
+  float4 *sbox = reinterpret_cast<float4 *>(scratch + n_rows * w64 * sizeof(unsigned long long));
+  float *sscore = reinterpret_cast<float *>(sbox + n_rows);
+  int *sidx = reinterpret_cast<int *>(sscore + n_rows);
+  int *n_sel = sidx + n_rows;
+  int *flags = n_sel + n_cls;
+  static bool sort_attr = false;
+  if (!sort_attr) {
+    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kSortMax * 8));
+    sort_attr = true;
+  }
+  int n_pad = 64;
+  while (n_pad < m_stride && n_pad < kSortMax) n_pad <<= 1;
+  const int sort_threads = n_pad / 2 < 64 ? 64 : (n_pad / 2 > 1024 ? 1024 : n_pad / 2);
+  {
+    hipLaunchKernelGGL(nms_sort_kernel, dim3(n_cls), dim3(sort_threads), (size_t)n_pad * 8, st, d_scored, d_counts, m_stride, sbox,
+                       sscore, sidx, n_sel, flags, g_nms_force_exact);
+    MPN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(w64, cdiv(m_stride, 256), n_cls), dim3(256), 0, st, sbox, n_sel, flags, d_counts,
+                       m_stride, w64, thr, mask);
+    MPN_CHECK_LAUNCH();
+    {  // tie classes (exact slot emulation on the bitmask); both instantiations exit at once when not needed
+      const int tcap = (m_stride + 3) & ~3;
+      static bool tie_attr = false;
+      const size_t lds_a = (size_t)kTieLdsMask * (kTieLdsMask / 64) * 8 + (size_t)5 * kTieLdsMask * 4 + 512;
+      const size_t lds_b = (size_t)5 * kTieMax * 4 + 512;
+      if (!tie_attr) {
+        MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_tie_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+        MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_tie_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+        tie_attr = true;
+      }
+      if (m_stride <= kTieMax) {
+        const int cap_a = tcap < kTieLdsMask ? tcap : kTieLdsMask;
+        hipLaunchKernelGGL(nms_tie_kernel<true>, dim3(n_cls), dim3(256), (size_t)kTieLdsMask * (kTieLdsMask / 64) * 8 + (size_t)5 * cap_a * 4 + 512, st,
+                           sbox, sscore, sidx, n_sel, flags, d_counts, m_stride, w64, mask, d_keep, d_keep_idx, d_n_keep, cap_a);
+        MPN_CHECK_LAUNCH();
+        if (m_stride > kTieLdsMask) {
+          hipLaunchKernelGGL(nms_tie_kernel<false>, dim3(n_cls), dim3(256), (size_t)5 * tcap * 4 + 512, st, sbox, sscore, sidx, n_sel, flags,
+                             d_counts, m_stride, w64, mask, d_keep, d_keep_idx, d_n_keep, tcap);
+          MPN_CHECK_LAUNCH();
+        }
+      }
+    }
+    if (w64 <= 64)
+      hipLaunchKernelGGL(nms_scan_kernel<1>, dim3(n_cls), dim3(kWave), 0, st, sbox, sscore, sidx, n_sel, flags, m_stride, w64, mask,
+                         d_keep, d_keep_idx, d_n_keep);
+    else
+      hipLaunchKernelGGL(nms_scan_kernel<2>, dim3(n_cls), dim3(kWave), 0, st, sbox, sscore, sidx, n_sel, flags, m_stride, w64, mask,
+                         d_keep, d_keep_idx, d_n_keep);
+    MPN_CHECK_LAUNCH();
+  }
   int m_cap = (m_stride + 3) & ~3;
   size_t lds = (size_t)m_cap * 6 * sizeof(float);
   static bool attr_set = false;
@@ -190,8 +623,8 @@ extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n
                                       hipFuncAttributeMaxDynamicSharedMemorySize, MPN_NMS_MAX_BOXES * 6 * 4));
     attr_set = true;
   }
-  hipLaunchKernelGGL(nms_wave_kernel, dim3(n_cls), dim3(kWave), lds, as_stream(stream), d_scored, d_counts, m_stride,
-                     thr, d_keep, d_keep_idx, d_n_keep, m_cap);
+  hipLaunchKernelGGL(nms_wave_kernel, dim3(n_cls), dim3(kWave), lds, st, d_scored, d_counts, m_stride,
+                     thr, d_keep, d_keep_idx, d_n_keep, m_cap, flags);
   MPN_CHECK_LAUNCH();
   return MPN_OK;
 }

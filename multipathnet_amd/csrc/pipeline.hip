@@ -116,6 +116,30 @@ struct mpn_frcnn {
   int last_n = 0;
   int fuse_pool = 1;
   std::vector<void *> allocs;
+  // optional per-kernel-group timing with HIP events recorded on the launch stream
+  bool prof = false;
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<int> ev_tag;   // one tag per (begin,end) pair
+  size_t ev_used = 0;
+  double prof_ms[MPN_PROF_NTAGS] = {0};
+  long prof_cnt[MPN_PROF_NTAGS] = {0};
+};
+
+struct ProfScope {
+  mpn_frcnn *p; hipStream_t s; bool on;
+  ProfScope(mpn_frcnn *p_, int tag, hipStream_t s_) : p(p_), s(s_), on(p_->prof) {
+    if (!on) return;
+    if (p->ev_used + 2 > p->ev_pool.size()) {
+      for (int i = 0; i < 64; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { on = false; return; } p->ev_pool.push_back(e); }
+    }
+    p->ev_tag.push_back(tag);
+    (void)hipEventRecord(p->ev_pool[p->ev_used], s);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(p->ev_pool[p->ev_used + 1], s);
+    p->ev_used += 2;
+  }
 };
 
 static int g_fuse_pool = 1;
@@ -138,6 +162,7 @@ static int dev_alloc(mpn_frcnn *p, T **ptr, size_t bytes, bool zero) {
 extern "C" void mpn_frcnn_destroy(mpn_frcnn *p) {
   if (!p) return;
   (void)hipDeviceSynchronize();
+  for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   for (void *q : p->allocs) (void)hipFree(q);
   if (p->dbg) (void)hipFree(p->dbg);
   delete p;
@@ -240,27 +265,27 @@ static int run_trunk(mpn_frcnn *p, const float *d_image, int H, int W, hipStream
     p->last_h = H; p->last_w = W;
   }
   Act cur = make_act(p->img_c8p, 3, H, W);
-  int rc = image_transform_c8p(d_image, H, W, c.tf_swap, c.tf_scale, c.tf_mean, c.tf_std, c.tf_std[0] != 0.0, cur, s);
+  int rc;
+  { ProfScope ps(p, MPN_PROF_TRANSFORM, s);
+    rc = image_transform_c8p(d_image, H, W, c.tf_swap, c.tf_scale, c.tf_mean, c.tf_std, c.tf_std[0] != 0.0, cur, s); }
   if (rc) return rc;
   int h = H, w = W;
   for (auto &L : p->conv) {
     Act out = make_act(L.out, L.Cout, h, w);
+    const int ctag = conv3x3_variant_for(L.Cout) == 1 ? MPN_PROF_CONV_128x4 : MPN_PROF_CONV_64x8;
     if (L.pool) {
       Act pooled = make_act(L.pooled, L.Cout, (h + 1) / 2, (w + 1) / 2);
       if (g_fuse_pool) {
+        ProfScope ps(p, ctag, s);
         rc = conv3x3_c8p(cur, L.wpk, L.bpk, L.Cout, 1, Act{}, pooled, s);
-        if (rc == MPN_EINVAL) {  // tile variant without a fused pool: fall back to two kernels
-          rc = conv3x3_c8p(cur, L.wpk, L.bpk, L.Cout, 1, out, Act{}, s);
-          if (rc == MPN_OK) rc = maxpool2x2_c8p(out, pooled, s);
-        }
       } else {
-        rc = conv3x3_c8p(cur, L.wpk, L.bpk, L.Cout, 1, out, Act{}, s);
-        if (rc == MPN_OK) rc = maxpool2x2_c8p(out, pooled, s);
+        { ProfScope ps(p, ctag, s); rc = conv3x3_c8p(cur, L.wpk, L.bpk, L.Cout, 1, out, Act{}, s); }
+        if (rc == MPN_OK) { ProfScope ps(p, MPN_PROF_POOL, s); rc = maxpool2x2_c8p(out, pooled, s); }
       }
       if (rc) return rc;
       cur = pooled; h = pooled.H; w = pooled.W;
     } else {
-      rc = conv3x3_c8p(cur, L.wpk, L.bpk, L.Cout, 1, out, Act{}, s);
+      { ProfScope ps(p, ctag, s); rc = conv3x3_c8p(cur, L.wpk, L.bpk, L.Cout, 1, out, Act{}, s); }
       if (rc) return rc;
       cur = out;
     }
@@ -284,14 +309,16 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H, int W, const fl
   rc = mpn_project_im_rois(d_boxes, N, 1.0, p->rois, s);
   if (rc) return rc;
   const int C = c.n_classes, F = c.fc_dim;
-  rc = roi_pool_c8(feat, p->rois, N, c.pooled_h, c.pooled_w, c.spatial_scale, 1.0f, 0, p->x6, nullptr, s);
+  { ProfScope ps(p, MPN_PROF_ROIPOOL, s);
+    rc = roi_pool_c8(feat, p->rois, N, c.pooled_h, c.pooled_w, c.spatial_scale, 1.0f, 0, p->x6, nullptr, s); }
   if (rc) return rc;
-  rc = linear_c8(p->x6, N, p->K6, p->w6, p->b6, F, 1, p->y6, nullptr, s);
+  { ProfScope ps(p, MPN_PROF_FC6, s); rc = linear_c8(p->x6, N, p->K6, p->w6, p->b6, F, 1, p->y6, nullptr, s); }
   if (rc) return rc;
-  rc = linear_c8(p->y6, N, F, p->w7, p->b7, F, 1, p->y7, nullptr, s);
+  { ProfScope ps(p, MPN_PROF_FC7, s); rc = linear_c8(p->y6, N, F, p->w7, p->b7, F, 1, p->y7, nullptr, s); }
   if (rc) return rc;
-  rc = linear_c8(p->y7, N, F, p->wh, p->bh, 5 * C, 0, nullptr, p->head, s);
+  { ProfScope ps(p, MPN_PROF_HEADS, s); rc = linear_c8(p->y7, N, F, p->wh, p->bh, 5 * C, 0, nullptr, p->head, s); }
   if (rc) return rc;
+  ProfScope ps_post(p, MPN_PROF_POST, s);
   hipLaunchKernelGGL(head_softmax_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, p->head, 5 * C, N, C, p->scores);
   MPN_CHECK_LAUNCH();
   const bool norm = c.bbox_std[0] != 0.0f;
@@ -325,11 +352,37 @@ extern "C" int mpn_frcnn_test_one(mpn_frcnn *p, const float *d_image, int H, int
   const int C = c.n_classes;
   // Tester_FRCNN.lua:106-125: per class j=1..C-1 select (score > thresh) -> NMS.  The class slabs
   // have stride max_rois so that mpn_frcnn_nms_results stays valid across calls with different N.
-  rc = mpn_select_scored(p->scores, p->bbox, N, C, 1, c.score_thresh, p->scored, p->counts, nullptr, s);
+  { ProfScope ps(p, MPN_PROF_SELECT, s);
+    rc = mpn_select_scored(p->scores, p->bbox, N, C, 1, c.score_thresh, p->scored, p->counts, nullptr, s); }
   if (rc) return rc;
-  rc = mpn_nms_batched(p->scored, p->counts, C - 1, N, c.nms_thresh, p->keep, p->keep_idx, p->n_keep, s);
+  { ProfScope ps(p, MPN_PROF_NMS, s);
+    rc = mpn_nms_batched(p->scored, p->counts, C - 1, N, c.nms_thresh, p->keep, p->keep_idx, p->n_keep, s); }
   if (rc) return rc;
+  ProfScope ps(p, MPN_PROF_TOPK, s);
   return mpn_keep_top_k(p->keep, p->n_keep, C - 1, N, c.top_k, p->thresh, d_dets, top_cap, d_n_dets, s);
+}
+
+extern "C" int mpn_frcnn_set_profiling(mpn_frcnn *p, int enable) {
+  MPN_CHECK_ARG(p != nullptr);
+  p->prof = enable != 0;
+  return MPN_OK;
+}
+
+extern "C" int mpn_frcnn_get_profile(mpn_frcnn *p, double *ms, long *counts, int n_tags, int reset) {
+  MPN_CHECK_ARG(p != nullptr && ms && counts && n_tags >= MPN_PROF_NTAGS);
+  MPN_CHECK_HIP(hipDeviceSynchronize());
+  for (size_t i = 0; i + 1 < p->ev_used + 1 && i / 2 < p->ev_tag.size(); i += 2) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, p->ev_pool[i], p->ev_pool[i + 1]) == hipSuccess) {
+      p->prof_ms[p->ev_tag[i / 2]] += t;
+      p->prof_cnt[p->ev_tag[i / 2]] += 1;
+    }
+  }
+  p->ev_used = 0;
+  p->ev_tag.clear();
+  for (int t = 0; t < MPN_PROF_NTAGS; ++t) { ms[t] = p->prof_ms[t]; counts[t] = p->prof_cnt[t]; }
+  if (reset) for (int t = 0; t < MPN_PROF_NTAGS; ++t) { p->prof_ms[t] = 0; p->prof_cnt[t] = 0; }
+  return MPN_OK;
 }
 
 extern "C" int mpn_frcnn_nms_results(mpn_frcnn *p, const float **d_keep, const int **d_keep_idx, const int **d_n_keep,

@@ -29,8 +29,9 @@ def cfg_layers(cfg):
 
 def synthetic_params(cfg=VGG16_CFG, pooled=7, fc_dim=4096, n_classes=21, seed=557, device="cpu", bbox_norm=True):
     """Seeded random weights of the reference architecture (no pretrained .t7 exists offline):
-    He-scaled trunk / fc so activations stay O(1); heads as model_utils.lua:106-112
-    (cls N(0,0.01), bbox N(0,0.001), zero bias)."""
+    He-scaled trunk / fc so activations stay O(1) — the first conv is additionally divided by 70, the
+    spread of the mean-subtracted 0..255 pixels it sees, like a trained Caffe VGG whose conv1_1 filters
+    are O(1e-2); heads as model_utils.lua:106-112 (cls N(0,0.01), bbox N(0,0.001), zero bias)."""
     g = torch.Generator().manual_seed(seed)
     P = {"conv_w": [], "conv_b": []}
     cin = 3
@@ -38,6 +39,8 @@ def synthetic_params(cfg=VGG16_CFG, pooled=7, fc_dim=4096, n_classes=21, seed=55
         if item == "P":
             continue
         std = (2.0 / (cin * 9)) ** 0.5
+        if cin == 3:
+            std /= 70.0
         P["conv_w"].append((torch.randn(item, cin, 3, 3, generator=g) * std).to(device))
         P["conv_b"].append((torch.randn(item, generator=g) * 0.01).to(device))
         cin = item
@@ -149,6 +152,18 @@ class FastRCNN(object):
         hip.hipMemcpy(C.c_void_p(idx.data_ptr()), ip, C.c_size_t(idx.numel() * 4), 3)
         hip.hipMemcpy(C.c_void_p(n.data_ptr()), np_, C.c_size_t(n.numel() * 4), 3)
         return keep, idx, n
+
+    PROF_TAGS = ["transform", "conv_128x4", "conv_64x8", "pool", "roi_pool", "fc6", "fc7", "heads", "post", "select", "nms", "topk"]
+
+    def set_profiling(self, on):
+        """HIP-event timing of every kernel group, recorded on the launch stream (include/mpn.h MPN_PROF_*)."""
+        check(self._lib.mpn_frcnn_set_profiling(self._h, int(bool(on))), "set_profiling")
+
+    def get_profile(self, reset=True):
+        n = len(self.PROF_TAGS)
+        ms, cnt = (C.c_double * n)(), (C.c_long * n)()
+        check(self._lib.mpn_frcnn_get_profile(self._h, ms, cnt, n, int(reset)), "get_profile")
+        return {t: (ms[i], cnt[i]) for i, t in enumerate(self.PROF_TAGS)}
 
     def debug_tensor(self, name, shape):
         p, n = f32p(), C.c_size_t()

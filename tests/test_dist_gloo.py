@@ -1,0 +1,69 @@
+"""world_size-2 `gloo` test (CPU) of the N>1 path: image sharding + all-gather of scored-box records."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_images, top_cap, q):
+    from multipathnet_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = parallel.shard_indices(n_images, rank, world)
+    steps = (n_images + world - 1) // world
+    per_step = []
+    for t in range(steps):
+        if t < len(mine):
+            i = mine[t]
+            g = torch.Generator().manual_seed(i)
+            n = int(torch.randint(0, top_cap + 1, (1,), generator=g))
+            dets = torch.zeros((top_cap, 6))
+            dets[:n] = torch.rand((n, 6), generator=g) + i  # image-identifiable payload
+        else:  # ragged tail: this rank has no image this step, it still takes part in the collective
+            n, dets = 0, torch.zeros((top_cap, 6))
+        rec = parallel.pack_record(dets, n, top_cap)
+        per_step.append(parallel.gather_detections(rec).clone())
+    merged = parallel.merge_by_image(per_step, world, n_images, top_cap)
+    if rank == 0:
+        q.put([m.clone() for m in merged])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_and_gather_world2():
+    from multipathnet_amd import parallel
+    n_images, top_cap, world = 5, 16, 2
+    assert parallel.shard_indices(5, 0, 2) == [0, 2, 4] and parallel.shard_indices(5, 1, 2) == [1, 3]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_images, top_cap, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    merged = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for i, m in enumerate(merged):
+        g = torch.Generator().manual_seed(i)
+        n = int(torch.randint(0, top_cap + 1, (1,), generator=g))
+        exp = torch.rand((n, 6), generator=g) + i
+        assert m.shape == (n, 6) and torch.equal(m, exp)
+
+
+def test_record_roundtrip_single_process():
+    from multipathnet_amd import parallel
+    dets = torch.arange(60, dtype=torch.float32).view(10, 6)
+    rec = parallel.pack_record(dets, torch.tensor([7], dtype=torch.int32), 10)
+    assert rec.numel() == 61 and torch.equal(parallel.unpack_record(rec, 10), dets[:7])

@@ -16,9 +16,20 @@ def _t(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
+@pytest.fixture(params=[0, 1, 2], ids=["auto", "sweepkernel", "tiekernel"])
+def nms_path(request):
+    """0 = default dispatch (chunked bitmask scan for tie-free classes, slot-emulating tie kernel for classes with
+    bit-equal scores, IoU-sweep kernel for NaN / oversize); 1 = IoU-sweep kernel only; 2 = tie kernel wherever it applies"""
+    import multipathnet_amd
+    lib = multipathnet_amd.load()
+    lib.mpn_debug_set_nms_force_exact(request.param)
+    yield request.param
+    lib.mpn_debug_set_nms_force_exact(0)
+
+
 @pytest.mark.parametrize("regime", ["distinct", "ties", "saturated", "allequal"])
-@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 300, 1000, 2500])
-def test_nms_bit_exact(O, dev, regime, n):
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 300, 1000, 2500, 5000])
+def test_nms_bit_exact(O, dev, regime, n, nms_path):
     from multipathnet_amd import utils
     rng = np.random.default_rng(hash((regime, n)) % 2**32)
     sb = random_scored_boxes(rng, n, regime, span=300.0 if n <= 65 else 1000.0)
@@ -39,7 +50,24 @@ def test_nms_empty_and_reference_test_style(O, dev):
     assert np.array_equal(utils.nms(_t(sb, dev), 0.3).cpu().numpy(), O.nms(sb, 0.3))
 
 
-def test_nms_batched_ragged(O, dev):
+def test_nms_low_scores_and_dense_overlap(O, dev, nms_path):
+    """scores <= -1e7 are never picked (nms.c:75); heavy overlap -> few survivors; sparse -> all survive"""
+    from multipathnet_amd import utils
+    rng = np.random.default_rng(77)
+    sb = random_scored_boxes(rng, 500, "distinct", span=200.0)
+    sb[::7, 4] = -2e7
+    ref, ridx = O.nms(sb, 0.3, return_index=True)
+    keep, idx = utils.nms_with_index(_t(sb, dev), 0.3)
+    assert np.array_equal(keep.cpu().numpy(), ref) and np.array_equal(idx.cpu().numpy(), ridx)
+    dense = random_scored_boxes(rng, 1000, "distinct", span=60.0, lo=100, hi=120)
+    sparse = random_scored_boxes(rng, 1000, "distinct", span=100000.0, lo=4, hi=8)
+    for sb in (dense, sparse):
+        for thr in (0.0, 0.3, 1.0):
+            ref = O.nms(sb, thr)
+            assert np.array_equal(utils.nms(_t(sb, dev), thr).cpu().numpy(), ref)
+
+
+def test_nms_batched_ragged(O, dev, nms_path):
     from multipathnet_amd import utils
     rng = np.random.default_rng(5)
     n_cls, M = 20, 777
