@@ -16,6 +16,9 @@
 //     (conflict-free) and feeds 4 MFMAs;
 //   * D[cout][pixel] leaves the accumulators as float4 stores that are 1 KiB-contiguous per wave
 //     instruction in the C8P layout — the next layer's LDS image.
+#include <cstdlib>
+#include <vector>
+
 #include "dense.h"
 
 namespace mpn {
@@ -40,21 +43,33 @@ struct ConvArgs {
   float *out; size_t out_plane; int out_Wp;
   float *pool; size_t pool_plane; int pool_Wp; int pool_H, pool_W;
   int H, W, nchunks, out_cb, relu, n_ct, tiles_x;
+  // split-K (blockIdx.y = split): raw partial sums go to part + split*part_slab in the OUTPUT's C8P
+  // geometry; conv_splitk_reduce_kernel adds them in split order and applies bias/ReLU/pool.
+  int splits, chunks_per_split;
+  float *part; size_t part_slab;
+  int ablate;  // timing experiments only (results wrong): 1 = no DMA in loop, 2 = no barrier, 4 = no ds_reads
 };
 
-template <int BM, int TH, int WM, int WN, bool GLDS>
+// TPS = taps per LDS stage: 9 -> one stage per 8-channel chunk (input tile + all 9 taps' weights);
+//                           3 -> three stages per chunk (one filter row each): the weight ring shrinks to
+//                                2 x 3 taps, LDS drops from 88 KB to ~39 KB per block and 3 blocks share a CU,
+//                                so one block's prologue / epilogue / barrier gaps hide behind the others' MFMAs.
+template <int BM, int TH, int WM, int WN, int TPS>
 __global__ __launch_bounds__(256) void conv3x3_c8p_kernel(ConvArgs a) {
   static_assert(WM * WN == 4, "4 waves");
+  static_assert(TPS == 9 || TPS == 3, "taps per stage");
   constexpr int MI = BM / WM / 32, NI = TH / WN;
   static_assert(MI >= 1 && NI >= 1, "tile");
-  constexpr int IN_PIECES = (TH + 2) * 68;         // 16-byte pieces of the (TH+2) x 34 px halo tile
-  constexpr int IN_LOADS = (IN_PIECES + 63) / 64;  // 1 KiB wave-loads
+  constexpr int G = 9 / TPS;                        // stages per chunk
+  constexpr int IN_PIECES = (TH + 2) * 68;          // 16-byte pieces of the (TH+2) x 34 px halo tile
+  constexpr int IN_LOADS = (IN_PIECES + 63) / 64;   // 1 KiB wave-loads
   constexpr int IN_FLOATS = IN_LOADS * 256;
-  constexpr int W_LOADS = 9 * BM / 32;
-  constexpr int W_FLOATS = 9 * BM * 8;
-  constexpr int STAGE = IN_FLOATS + W_FLOATS;
+  constexpr int W_LOADS = TPS * BM / 32;
+  constexpr int W_FLOATS = TPS * BM * 8;
   constexpr int IN_IT = (IN_LOADS + 3) / 4, W_IT = (W_LOADS + 3) / 4;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [IN x2][W x2]
+  float *const in_lds = lds;
+  float *const w_lds = lds + 2 * IN_FLOATS;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -79,42 +94,20 @@ __global__ __launch_bounds__(256) void conv3x3_c8p_kernel(ConvArgs a) {
   for (int i = 0; i < W_IT; ++i) {
     int t = i * 4 + wave, p = t * 64 + lane;
     w_ok[i] = t < W_LOADS;
-    int tap = p / (BM * 2), rem = p - tap * (BM * 2);
+    int tap = p / (BM * 2), rem = p - tap * (BM * 2);  // tap local to the stage
     w_off[i] = (tap * a.CoutP + cout0) * 8 + rem * 4;
   }
-  const size_t w_chunk = (size_t)9 * a.CoutP * 8;
+  const size_t w_stage = (size_t)TPS * a.CoutP * 8;  // packed weights advance by TPS taps per stage
 
-  f32x4 rin[GLDS ? 1 : IN_IT], rw[GLDS ? 1 : W_IT];
-  auto issue = [&](int c, int s) {
-    const float *ib = a.in + (size_t)c * a.in_plane;
-    const float *wb = a.wpk + (size_t)c * w_chunk;
-    float *st = lds + s * STAGE;
-#pragma unroll
-    for (int i = 0; i < IN_IT; ++i) {
-      if constexpr (GLDS) {
-        if (in_ok[i]) glds16(ib + in_off[i], st + (i * 4 + wave) * 256);
-      } else {
-        if (in_ok[i]) rin[i] = *reinterpret_cast<const f32x4 *>(ib + in_off[i]);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < W_IT; ++i) {
-      if constexpr (GLDS) {
-        if (w_ok[i]) glds16(wb + w_off[i], st + IN_FLOATS + (i * 4 + wave) * 256);
-      } else {
-        if (w_ok[i]) rw[i] = *reinterpret_cast<const f32x4 *>(wb + w_off[i]);
-      }
-    }
-  };
-  auto commit = [&](int s) {  // register-staged path only
-    if constexpr (!GLDS) {
-      float *st = lds + s * STAGE;
-#pragma unroll
-      for (int i = 0; i < IN_IT; ++i)
-        if (in_ok[i]) *reinterpret_cast<f32x4 *>(st + (i * 4 + wave) * 256 + lane * 4) = rin[i];
-#pragma unroll
-      for (int i = 0; i < W_IT; ++i)
-        if (w_ok[i]) *reinterpret_cast<f32x4 *>(st + IN_FLOATS + (i * 4 + wave) * 256 + lane * 4) = rw[i];
+  // one staging item = one 1 KiB wave-load: weight items first, then (first stage of a chunk only) input items
+  auto issue_item = [&](int q, int item) {
+    if (item < W_IT) {
+      const int i = item;
+      if (w_ok[i]) glds16(a.wpk + (size_t)q * w_stage + w_off[i], w_lds + (q & 1) * W_FLOATS + (i * 4 + wave) * 256);
+    } else if (item - W_IT < IN_IT) {
+      const int i = item - W_IT;
+      const int c = q / G;
+      if ((q - c * G) == 0 && in_ok[i]) glds16(a.in + (size_t)c * a.in_plane + in_off[i], in_lds + (c & 1) * IN_FLOATS + (i * 4 + wave) * 256);
     }
   };
 
@@ -127,38 +120,84 @@ __global__ __launch_bounds__(256) void conv3x3_c8p_kernel(ConvArgs a) {
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
   const int lane_off = l31 * 8 + half * 4;
-  issue(0, 0);
-  commit(0);
+  const int c0 = blockIdx.y * a.chunks_per_split;
+  const int c1 = min(a.nchunks, c0 + a.chunks_per_split);
+  const int q0 = c0 * G, q1 = c1 * G;  // stage index q = chunk * G + filter-row group
+  constexpr int ITEMS = W_IT + IN_IT;
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) issue_item(q0, it);
   __syncthreads();
 
-  for (int c = 0; c < a.nchunks; ++c) {
-    const int s = c & 1;
-    if (c + 1 < a.nchunks) issue(c + 1, s ^ 1);
-    const float *Il = lds + s * STAGE + lane_off;
-    const float *Wl = lds + s * STAGE + IN_FLOATS + lane_off;
+  constexpr int PER_TAP = (ITEMS + TPS - 1) / TPS;  // DMA items issued per tap: the next stage is fully in flight by the last tap
+  for (int q = q0; q < q1; ++q) {
+    const int c = q / G, g = q - c * G;
+    const bool more = (q + 1 < q1) && !(a.ablate & 1);
+    const float *Il = in_lds + (c & 1) * IN_FLOATS + lane_off + (TPS == 3 ? g * 34 * 8 : 0);
+    const float *Wl = w_lds + (q & 1) * W_FLOATS + lane_off;
+    // operand fragments are double-buffered in registers: tap t+1's ds_reads are issued before tap t's
+    // 16 MFMAs, so LDS latency never sits on the matrix pipe; the next stage's DMA is spread over the taps.
+    f32x4 af[2][MI], bf[2][NI];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dy = tap / 3, dx = tap % 3;
-      f32x4 af[MI], bf[NI];
+    for (int mi = 0; mi < MI; ++mi) af[0][mi] = *reinterpret_cast<const f32x4 *>(Wl + (mbase + mi * 32) * 8);
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) af[mi] = *reinterpret_cast<const f32x4 *>(Wl + (tap * BM + mbase + mi * 32) * 8);
+    for (int ni = 0; ni < NI; ++ni) bf[0][ni] = *reinterpret_cast<const f32x4 *>(Il + ((rbase + ni) * 34) * 8);
+    if (a.ablate & 4) {
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const f32x4 *>(Il + ((rbase + ni + dy) * 34 + dx) * 8);
+      for (int mi = 0; mi < MI; ++mi) af[1][mi] = af[0][mi];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bf[1][ni] = bf[0][ni];
+    }
+#pragma unroll
+    for (int t = 0; t < TPS; ++t) {
+      const int cur = t & 1;
+      if (t + 1 < TPS && !(a.ablate & 4)) {
+        const int nt = t + 1, dy = (TPS == 9) ? nt / 3 : 0, dx = nt % 3;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) af[cur ^ 1][mi] = *reinterpret_cast<const f32x4 *>(Wl + (nt * BM + mbase + mi * 32) * 8);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bf[cur ^ 1][ni] = *reinterpret_cast<const f32x4 *>(Il + ((rbase + ni + dy) * 34 + dx) * 8);
+      }
+      if (more) {
+#pragma unroll
+        for (int k = 0; k < PER_TAP; ++k) issue_item(q + 1, t * PER_TAP + k);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][mi][j], bf[cur][ni][j], acc[mi][ni], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (c + 1 < a.nchunks) commit(s ^ 1);
-    __syncthreads();
+    if (!(a.ablate & 2)) __syncthreads();
   }
 
-  // ---- epilogue: bias + ReLU, C8P float4 stores, optional fused ceil-mode 2x2 max-pool
   const int x = x0 + l31;
   const bool xok = x < a.W;
+  if (a.splits > 1) {  // raw partial sums; the reduce kernel finishes the layer
+    float *pb = a.part + (size_t)blockIdx.y * a.part_slab;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cb = (cout0 + mbase + mi * 32) / 8 + g;
+        if (cb >= a.out_cb) continue;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int y = y0 + rbase + ni;
+          if (xok && y < a.H) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][g * 4 + e];
+            *reinterpret_cast<f32x4 *>(pb + (size_t)cb * a.out_plane + ((size_t)(y + 1) * a.out_Wp + x + 1) * 8 + half * 4) = v;
+          }
+        }
+      }
+    return;
+  }
+  // ---- epilogue: bias + ReLU, C8P float4 stores, optional fused ceil-mode 2x2 max-pool
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -198,27 +237,84 @@ __global__ __launch_bounds__(256) void conv3x3_c8p_kernel(ConvArgs a) {
   }
 }
 
-template <int BM, int TH, int WM, int WN, bool GLDS>
+template <int BM, int TH, int WM, int WN, int TPS>
 static int launch_conv(const ConvArgs &a0, int tiles_y, hipStream_t s) {
   ConvArgs a = a0;
   constexpr int IN_LOADS = ((TH + 2) * 68 + 63) / 64;
-  constexpr size_t LDS = (size_t)2 * (IN_LOADS * 256 + 9 * BM * 8) * sizeof(float);
-  auto kern = conv3x3_c8p_kernel<BM, TH, WM, WN, GLDS>;
+  constexpr size_t LDS = (size_t)2 * (IN_LOADS * 256 + TPS * BM * 8) * sizeof(float);
+  auto kern = conv3x3_c8p_kernel<BM, TH, WM, WN, TPS>;
   static bool attr = false;
   if (!attr) {
     MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
     attr = true;
   }
-  dim3 grid((unsigned)(a.n_ct * tiles_y * a.tiles_x));
+  dim3 grid((unsigned)(a.n_ct * tiles_y * a.tiles_x), (unsigned)a.splits);
   hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, a);
   MPN_CHECK_LAUNCH();
   return MPN_OK;
 }
 
-static int g_conv_variant = 0;  // 0 = auto; test/bench hook: 1 = force 128x4 tile, 2 = force 64x8, +16 = register staging
+// split-K finish: sums S partial slabs in split order (deterministic), + bias, ReLU; writes the C8P
+// output and/or its ceil-mode 2x2 max-pool.  One thread per (channel block, pooled-or-full pixel, half).
+__global__ void conv_splitk_reduce_kernel(const float *__restrict__ part, size_t slab, int S, size_t plane, int Wp, int H, int W,
+                                          int out_cb, const float *__restrict__ bpk, int relu, float *__restrict__ out,
+                                          float *__restrict__ pool, size_t pool_plane, int pool_Wp, int pool_H, int pool_W) {
+  const bool pooling = pool != nullptr;
+  const int GH = pooling ? pool_H : H, GW = pooling ? pool_W : W;
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)out_cb * GH * GW * 2;
+  if (t >= total) return;
+  const int h = (int)(t & 1); size_t r = t >> 1;
+  const int gx = (int)(r % GW); r /= GW;
+  const int gy = (int)(r % GH); const int cb = (int)(r / GH);
+  const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bpk + cb * 8 + h * 4);
+  f32x4 m = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  const int ny = pooling ? 2 : 1, nx = pooling ? 2 : 1;
+  for (int dy = 0; dy < ny; ++dy)
+    for (int dx = 0; dx < nx; ++dx) {
+      const int y = pooling ? 2 * gy + dy : gy, x = pooling ? 2 * gx + dx : gx;
+      if (y >= H || x >= W) continue;
+      const size_t off = (size_t)cb * plane + ((size_t)(y + 1) * Wp + x + 1) * 8 + h * 4;
+      f32x4 v = *reinterpret_cast<const f32x4 *>(part + off);
+      for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4 *>(part + s * slab + off);
+      v += b4;
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.0f ? 0.0f : v[e];
+      }
+      if (out) *reinterpret_cast<f32x4 *>(out + off) = v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+    }
+  if (pooling) *reinterpret_cast<f32x4 *>(pool + (size_t)cb * pool_plane + ((size_t)(gy + 1) * pool_Wp + gx + 1) * 8 + h * 4) = m;
+}
+
+static int g_gemm_ablate = 0;         // timing-experiment switch shared by conv and gemm
+static int g_conv_split = 0;          // 0 = auto, >0 = force this many splits (test/bench hook)
+static float *g_conv_ws = nullptr;    // library-owned split-K scratch (grown on demand, single stream)
+static size_t g_conv_ws_bytes = 0;
+
+// Fill model: 256 CUs, one 128x4 (or two 64x8) blocks resident per CU -> a launch of b equal blocks takes
+// ceil(b/slots) rounds.  Split K when that lifts the fill by a margin that pays for the extra slab pass.
+static int conv_pick_splits(int blocks, int nchunks, int slots) {
+  if (g_conv_split > 0) return g_conv_split < nchunks ? g_conv_split : nchunks;
+  auto fill = [&](int b) { return (double)b / ((double)slots * ((b + slots - 1) / slots)); };
+  int best = 1;
+  double best_score = fill(blocks);
+  for (int S = 2; S <= 8; ++S) {
+    if (nchunks / S < 6) break;
+    double score = fill(blocks * S) * (1.0 - 0.04 - 0.01 * S);
+    if (score > best_score * 1.08) { best_score = score; best = S; }
+  }
+  return best;
+}
+
+static int g_conv_variant = 0;  // 0 = auto; test/bench hook: 1 = 128x4 tile / 9 taps per stage, 2 = 64x8 / 9, 3 = 128x4 / 3, 4 = 64x8 / 3
 
 int conv3x3_variant_for(int Cout) {
   int variant = g_conv_variant & 15;
+  // measured on MI355X (tools/bench_layers.py): one 4-wave block per CU (9 taps per stage) beats the
+  // 3-blocks-per-CU variants on every VGG layer — co-resident waves only time-share the SIMD's matrix pipe.
   if (variant == 0) variant = (Cout <= 64) ? 2 : 1;
   return variant;
 }
@@ -233,19 +329,46 @@ int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int re
   a.pool_H = pooled.p ? pooled.H : 0; a.pool_W = pooled.p ? pooled.W : 0;
   a.H = in.H; a.W = in.W; a.nchunks = in.Cb(); a.out_cb = (Cout + 7) / 8; a.relu = relu;
   a.tiles_x = cdiv(in.W, 32);
+  a.ablate = g_gemm_ablate;
   if (out.p) MPN_CHECK_ARG(out.H == in.H && out.W == in.W && out.C == Cout);
   if (pooled.p) MPN_CHECK_ARG(pooled.H == (in.H + 1) / 2 && pooled.W == (in.W + 1) / 2 && pooled.C == Cout);
   const int variant = conv3x3_variant_for(Cout);
-  const bool regstage = (g_conv_variant & 16) != 0;
-  if (variant == 1) {
-    a.n_ct = cdiv(Cout, 128);
-    int tiles_y = cdiv(in.H, 4);
-    return regstage ? launch_conv<128, 4, 2, 2, false>(a, tiles_y, s) : launch_conv<128, 4, 2, 2, true>(a, tiles_y, s);
-  } else {
-    a.n_ct = cdiv(Cout, 64);
-    int tiles_y = cdiv(in.H, 8);
-    return regstage ? launch_conv<64, 8, 1, 4, false>(a, tiles_y, s) : launch_conv<64, 8, 1, 4, true>(a, tiles_y, s);
+  const bool wide = (variant == 1 || variant == 3);  // 128 couts x 4 rows; else 64 couts x 8 rows
+  const int tiles_y = cdiv(in.H, wide ? 4 : 8);
+  a.n_ct = cdiv(Cout, wide ? 128 : 64);
+  const int blocks = a.n_ct * tiles_y * a.tiles_x;
+  const int slots = variant == 1 ? 256 : (variant == 2 ? 512 : 768);  // co-resident blocks on 256 CUs (LDS / VGPR bound)
+  a.splits = conv_pick_splits(blocks, a.nchunks, slots);
+  a.chunks_per_split = cdiv(a.nchunks, a.splits);
+  a.splits = cdiv(a.nchunks, a.chunks_per_split);
+  Act geo = out.p ? out : make_act(nullptr, Cout, in.H, in.W);  // partial slabs use the full-resolution output geometry
+  if (a.splits > 1) {
+    a.part_slab = geo.elems();
+    a.out_plane = geo.plane(); a.out_Wp = geo.Wp;
+    size_t need = a.part_slab * a.splits * sizeof(float);
+    if (need > g_conv_ws_bytes) {
+      MPN_CHECK_HIP(hipStreamSynchronize(s));
+      if (g_conv_ws) (void)hipFree(g_conv_ws);
+      g_conv_ws = nullptr; g_conv_ws_bytes = 0;
+      MPN_CHECK_HIP(hipMalloc(&g_conv_ws, need));
+      g_conv_ws_bytes = need;
+    }
+    a.part = g_conv_ws;
   }
+  int rc;
+  switch (variant) {
+    case 1: rc = launch_conv<128, 4, 2, 2, 9>(a, tiles_y, s); break;
+    case 2: rc = launch_conv<64, 8, 1, 4, 9>(a, tiles_y, s); break;
+    case 3: rc = launch_conv<128, 4, 2, 2, 3>(a, tiles_y, s); break;
+    default: rc = launch_conv<64, 8, 1, 4, 3>(a, tiles_y, s); break;
+  }
+  if (rc != MPN_OK || a.splits == 1) return rc;
+  const int GH = pooled.p ? pooled.H : in.H, GW = pooled.p ? pooled.W : in.W;
+  const size_t total = (size_t)a.out_cb * GH * GW * 2;
+  hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, a.part, a.part_slab, a.splits, geo.plane(),
+                     geo.Wp, in.H, in.W, a.out_cb, d_bpk, relu, out.p, pooled.p, a.pool_plane, a.pool_Wp, a.pool_H, a.pool_W);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
 }
 
 // =================================================================================================
@@ -257,6 +380,7 @@ struct GemmArgs {
   const float *bpk;
   float *y;                     // [NP/8][Mp][8]   (split: partial slabs [S][NP/8][Mp][8])
   int M, nstages, stages_per_split, relu, n_mt, n_nt, direct;
+  int ablate;  // timing experiments only (results wrong): 1 = no DMA in loop, 2 = no barrier in loop, 4 = no ds_reads in loop
 };
 
 constexpr int KCH = 4;  // 8-wide K chunks per LDS stage (32 k)
@@ -335,18 +459,20 @@ __global__ __launch_bounds__(256) void gemm_c8_kernel(GemmArgs a) {
     commit(0);
   }
   __syncthreads();
+  f32x4 af[2] = {f32x4{1, 2, 3, 4}, f32x4{1, 2, 3, 4}}, bf[2] = {f32x4{1, 2, 3, 4}, f32x4{1, 2, 3, 4}};
   for (int st = st0; st < st1; ++st) {
     const int s = (st - st0) & 1;
-    if (st + 1 < st1) issue(st + 1, s ^ 1);
+    if (st + 1 < st1 && !(a.ablate & 1)) issue(st + 1, s ^ 1);
     const float *Al = lds + s * STAGE + lane_off;
     const float *Bl = Al + OP_FLOATS;
 #pragma unroll
     for (int kk = 0; kk < KCH; ++kk) {
-      f32x4 af[2], bf[2];
+      if (!(a.ablate & 4)) {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) af[mi] = *reinterpret_cast<const f32x4 *>(Al + (kk * 128 + wm * 64 + mi * 32) * 8);
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) bf[ni] = *reinterpret_cast<const f32x4 *>(Bl + (kk * 128 + wn * 64 + ni * 32) * 8);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -356,7 +482,7 @@ __global__ __launch_bounds__(256) void gemm_c8_kernel(GemmArgs a) {
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
     }
     if (st + 1 < st1) commit(s ^ 1);
-    __syncthreads();
+    if (!(a.ablate & 2)) __syncthreads();
   }
 
   float *yb = a.y + (a.direct ? (size_t)0 : (size_t)split * (a.NP / 8) * a.Mp * 8);
@@ -417,6 +543,7 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ part, int S, int 
 }
 
 static int g_gemm_regstage = 0;
+static int g_gemm_split = 0;  // test/bench hook: force a split-K factor
 static float *g_splitk_ws = nullptr;
 static size_t g_splitk_ws_bytes = 0;
 
@@ -425,13 +552,14 @@ int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float
   MPN_CHECK_ARG(d_x_c8 && d_wpk && d_bpk && (d_y_c8 || d_y_rm) && M > 0 && K > 0 && N > 0);
   GemmArgs a{};
   a.x = d_x_c8; a.Mp = lin_mp(M); a.wpk = d_wpk; a.NP = lin_np(N); a.bpk = d_bpk;
-  a.M = M; a.relu = relu;
+  a.M = M; a.relu = relu; a.ablate = g_gemm_ablate;
   const int K32 = round_up(K, 32);
   a.nstages = K32 / 32;
   a.n_mt = a.Mp / 128; a.n_nt = a.NP / 128;
   const int tiles = a.n_mt * a.n_nt;
   int S = 1;
-  if (tiles < 128) {  // too few tiles to fill 256 CUs: split K (deterministic two-pass reduce)
+  if (g_gemm_split > 0) S = g_gemm_split;
+  else if (tiles < 128) {  // too few tiles to fill 256 CUs: split K (deterministic two-pass reduce)
     S = 256 / tiles;
     if (S > a.nstages / 2) S = a.nstages / 2;
     if (S < 1) S = 1;
@@ -743,6 +871,94 @@ using namespace mpn;
 // ---- test / bench hooks (not part of the reference surface) -------------------------------------
 extern "C" void mpn_debug_set_conv_variant(int v) { g_conv_variant = v; }
 extern "C" void mpn_debug_set_gemm_regstage(int v) { g_gemm_regstage = v; }
+extern "C" void mpn_debug_set_conv_split(int v) { g_conv_split = v; }
+extern "C" void mpn_debug_set_gemm_split(int v) { g_gemm_split = v; }
+extern "C" void mpn_debug_set_gemm_ablate(int v) { g_gemm_ablate = v; }
+
+// Kernel-only timing of one conv layer / one linear layer in the pipeline's own layouts (tools/bench_layers.py).
+extern "C" int mpn_debug_bench_conv(int Cin, int Cout, int H, int W, int pool, int iters, float *ms_out) {
+  MPN_CHECK_ARG(Cin > 0 && Cout > 0 && H > 0 && W > 0 && iters > 0 && ms_out);
+  float *in = nullptr, *out = nullptr, *pl = nullptr, *wpk = nullptr, *bpk = nullptr;
+  MPN_CHECK_HIP(hipMalloc(&in, act_bytes(Cin, H, W)));
+  MPN_CHECK_HIP(hipMalloc(&out, act_bytes(Cout, H, W)));
+  MPN_CHECK_HIP(hipMalloc(&pl, act_bytes(Cout, (H + 1) / 2, (W + 1) / 2)));
+  MPN_CHECK_HIP(hipMalloc(&wpk, conv_wpk_elems(Cin, Cout) * sizeof(float)));
+  MPN_CHECK_HIP(hipMalloc(&bpk, conv_coutp(Cout) * sizeof(float)));
+  MPN_CHECK_HIP(hipMemset(in, 0, act_bytes(Cin, H, W)));
+  MPN_CHECK_HIP(hipMemset(out, 0, act_bytes(Cout, H, W)));
+  MPN_CHECK_HIP(hipMemset(pl, 0, act_bytes(Cout, (H + 1) / 2, (W + 1) / 2)));
+  // non-trivial data (DVFS: zero operands clock higher, guide §5.4 rule 25)
+  {
+    size_t n = act_bytes(Cin, H, W) / 4, nw = conv_wpk_elems(Cin, Cout);
+    std::vector<float> h(n > nw ? n : nw);
+    unsigned x = 12345u;
+    const char *fill = getenv("MPN_BENCH_FILL");  // "zero" / "const": DVFS / power experiments
+    for (auto &v : h) { x = x * 1664525u + 1013904223u; v = ((x >> 8) * (1.0f / 8388608.0f) - 1.0f); }
+    if (fill && fill[0] == 'z') for (auto &v : h) v = 0.0f;
+    if (fill && fill[0] == 'c') for (auto &v : h) v = 0.5f;
+    Act ai = make_act(in, Cin, H, W);
+    std::vector<float> hi(n, 0.0f);
+    for (int cb = 0; cb < ai.Cb(); ++cb)
+      for (int y = 0; y < H; ++y)
+        for (int xx = 0; xx < W; ++xx)
+          for (int j = 0; j < 8; ++j)
+            if (cb * 8 + j < Cin) hi[(((size_t)cb * ai.Hp + y + 1) * ai.Wp + xx + 1) * 8 + j] = h[((size_t)(cb * 8 + j) * H + y) % n];
+    MPN_CHECK_HIP(hipMemcpy(in, hi.data(), n * 4, hipMemcpyHostToDevice));
+    for (size_t i = 0; i < nw; ++i) h[i] *= 0.05f;
+    MPN_CHECK_HIP(hipMemcpy(wpk, h.data(), nw * 4, hipMemcpyHostToDevice));
+    MPN_CHECK_HIP(hipMemset(bpk, 0, conv_coutp(Cout) * sizeof(float)));
+  }
+  Act ai = make_act(in, Cin, H, W), ao = make_act(out, Cout, H, W), ap = make_act(pl, Cout, (H + 1) / 2, (W + 1) / 2);
+  hipEvent_t e0, e1;
+  MPN_CHECK_HIP(hipEventCreate(&e0));
+  MPN_CHECK_HIP(hipEventCreate(&e1));
+  int rc = MPN_OK;
+  for (int i = 0; i < 2 && rc == MPN_OK; ++i) rc = pool ? conv3x3_c8p(ai, wpk, bpk, Cout, 1, Act{}, ap, nullptr) : conv3x3_c8p(ai, wpk, bpk, Cout, 1, ao, Act{}, nullptr);
+  MPN_CHECK_HIP(hipDeviceSynchronize());
+  MPN_CHECK_HIP(hipEventRecord(e0, nullptr));
+  for (int i = 0; i < iters && rc == MPN_OK; ++i) rc = pool ? conv3x3_c8p(ai, wpk, bpk, Cout, 1, Act{}, ap, nullptr) : conv3x3_c8p(ai, wpk, bpk, Cout, 1, ao, Act{}, nullptr);
+  MPN_CHECK_HIP(hipEventRecord(e1, nullptr));
+  MPN_CHECK_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  MPN_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = ms / iters;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(in); (void)hipFree(out); (void)hipFree(pl); (void)hipFree(wpk); (void)hipFree(bpk);
+  return rc;
+}
+
+extern "C" int mpn_debug_bench_linear(int M, int K, int N, int iters, float *ms_out) {
+  MPN_CHECK_ARG(M > 0 && K > 0 && N > 0 && iters > 0 && ms_out);
+  const int K32 = round_up(K, 32);
+  size_t xe = mat_c8_elems(M, K32), we = lin_wpk_elems(K32, N), ye = (size_t)(lin_np(N) / 8) * lin_mp(M) * 8;
+  float *x = nullptr, *w = nullptr, *b = nullptr, *y = nullptr;
+  MPN_CHECK_HIP(hipMalloc(&x, xe * 4)); MPN_CHECK_HIP(hipMalloc(&w, we * 4));
+  MPN_CHECK_HIP(hipMalloc(&b, lin_np(N) * 4)); MPN_CHECK_HIP(hipMalloc(&y, ye * 4));
+  {
+    std::vector<float> h(xe > we ? xe : we);
+    unsigned s = 777u;
+    for (auto &v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) * (1.0f / 8388608.0f) - 1.0f); }
+    MPN_CHECK_HIP(hipMemcpy(x, h.data(), xe * 4, hipMemcpyHostToDevice));
+    for (size_t i = 0; i < we; ++i) h[i] *= 0.02f;
+    MPN_CHECK_HIP(hipMemcpy(w, h.data(), we * 4, hipMemcpyHostToDevice));
+    MPN_CHECK_HIP(hipMemset(b, 0, lin_np(N) * 4));
+  }
+  hipEvent_t e0, e1;
+  MPN_CHECK_HIP(hipEventCreate(&e0)); MPN_CHECK_HIP(hipEventCreate(&e1));
+  int rc = MPN_OK;
+  for (int i = 0; i < 2 && rc == MPN_OK; ++i) rc = linear_c8(x, M, K, w, b, N, 1, y, nullptr, nullptr);
+  MPN_CHECK_HIP(hipDeviceSynchronize());
+  MPN_CHECK_HIP(hipEventRecord(e0, nullptr));
+  for (int i = 0; i < iters && rc == MPN_OK; ++i) rc = linear_c8(x, M, K, w, b, N, 1, y, nullptr, nullptr);
+  MPN_CHECK_HIP(hipEventRecord(e1, nullptr));
+  MPN_CHECK_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  MPN_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = ms / iters;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(x); (void)hipFree(w); (void)hipFree(b); (void)hipFree(y);
+  return rc;
+}
 
 // ---- module-level C entry points (NCHW / row-major Torch layouts) -------------------------------
 extern "C" size_t mpn_conv3x3_workspace_bytes(int B, int Cin, int H, int W, int Cout) {

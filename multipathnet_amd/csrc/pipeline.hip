@@ -272,7 +272,8 @@ static int run_trunk(mpn_frcnn *p, const float *d_image, int H, int W, hipStream
   int h = H, w = W;
   for (auto &L : p->conv) {
     Act out = make_act(L.out, L.Cout, h, w);
-    const int ctag = conv3x3_variant_for(L.Cout) == 1 ? MPN_PROF_CONV_128x4 : MPN_PROF_CONV_64x8;
+    const int cv = conv3x3_variant_for(L.Cout);
+    const int ctag = (cv == 1 || cv == 3) ? MPN_PROF_CONV_128x4 : MPN_PROF_CONV_64x8;
     if (L.pool) {
       Act pooled = make_act(L.pooled, L.Cout, (h + 1) / 2, (w + 1) / 2);
       if (g_fuse_pool) {

@@ -22,10 +22,11 @@ def _conv(dev, x, w, b, relu=True):
 
 @pytest.mark.parametrize("ci,co,h,w", [(3, 64, 40, 70), (8, 64, 33, 31), (64, 64, 19, 45), (64, 128, 16, 96), (128, 256, 9, 33),
                                        (24, 40, 8, 8), (16, 200, 5, 37), (256, 512, 12, 20)])
-@pytest.mark.parametrize("variant", [0, 1, 2, 17, 18])
-def test_conv3x3_vs_oracle(O, dev, ci, co, h, w, variant):
+@pytest.mark.parametrize("variant,split", [(0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (1, 2), (2, 3), (3, 2), (4, 3), (0, 4)])
+def test_conv3x3_vs_oracle(O, dev, ci, co, h, w, variant, split):
     import multipathnet_amd
     lib = multipathnet_amd.load()
+    lib.mpn_debug_set_conv_split(split)
     rng = np.random.default_rng(ci * 1000 + co)
     x = rng.standard_normal((ci, h, w)).astype(np.float32)
     wt = (rng.standard_normal((co, ci, 3, 3)) * (2.0 / (ci * 9)) ** 0.5).astype(np.float32)
@@ -36,6 +37,7 @@ def test_conv3x3_vs_oracle(O, dev, ci, co, h, w, variant):
         y2 = _conv(dev, x, wt, None, relu=False)
     finally:
         lib.mpn_debug_set_conv_variant(0)
+        lib.mpn_debug_set_conv_split(0)
     ref = O.conv3x3(x, wt, b, relu=True)
     assert y.shape == ref.shape
     assert np.abs(y - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())

@@ -1,0 +1,11 @@
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import multipathnet_amd
+lib = multipathnet_amd.load()
+lib.mpn_debug_set_conv_split(1)
+for (ci, co, h, w) in [(128, 128, 300, 500), (64, 64, 600, 1000)]:
+    for ab in (0, 1, 2, 4, 5, 7):
+        lib.mpn_debug_set_gemm_ablate(ab)
+        ms = C.c_float()
+        lib.mpn_debug_bench_conv(ci, co, h, w, 0, 5, C.byref(ms))
+        print("conv %d->%d %dx%d ablate=%d (noDMA=%d noBarrier=%d noLDSread=%d): %.1f us  %.1f TF/s" % (ci, co, h, w, ab, ab & 1, (ab >> 1) & 1, (ab >> 2) & 1, ms.value * 1e3, 2.0 * h * w * ci * 9 * co / ms.value / 1e9))

@@ -1,0 +1,30 @@
+"""summarise a rocprofv3 --pmc --kernel-trace run: per kernel name avg duration, effective clock, MFMA util, wait fractions"""
+import csv, sys, collections, glob, os
+d = sys.argv[1]
+ct = glob.glob(os.path.join(d, "*counter_collection.csv"))[0]
+kt = glob.glob(os.path.join(d, "*kernel_trace.csv"))
+dur = {}
+if kt:
+    for r in csv.DictReader(open(kt[0])):
+        dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.Counter()
+seen = set()
+for r in csv.DictReader(open(ct)):
+    name = r["Kernel_Name"].split("(")[0][-60:]
+    key = (name, r.get("Grid_Size", ""))
+    acc[key][r["Counter_Name"]] += float(r["Counter_Value"])
+    if (r["Dispatch_Id"]) not in seen:
+        seen.add(r["Dispatch_Id"]); cnt[key] += 1
+        acc[key]["_dur_us"] += dur.get(r["Dispatch_Id"], 0.0)
+for key, c in sorted(acc.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0)):
+    n = cnt[key]
+    g = c.get("GRBM_GUI_ACTIVE", 0) / n
+    line = "%-58s grid=%-8s n=%-3d" % (key[0], key[1], n)
+    if c["_dur_us"]: line += " dur=%8.1fus clk=%5.0fMHz" % (c["_dur_us"] / n, g / (c["_dur_us"] / n))
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and g: line += " mfma_util=%5.1f%%" % (100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / n / (g * 1024))
+    for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+        if k in c and c.get("SQ_WAVE_CYCLES"): line += " %s=%4.1f%%" % (k[3:], 100 * c[k] / c["SQ_WAVE_CYCLES"])
+    for k in ("SQ_LDS_BANK_CONFLICT", "FETCH_SIZE", "WRITE_SIZE"):
+        if k in c: line += " %s=%.3g" % (k, c[k] / n)
+    print(line)
