@@ -211,6 +211,13 @@ int mpn_frcnn_detect(mpn_frcnn *p, const float *d_image, int H, int W, const flo
  *   through mpn_frcnn_nms_results until the next call. */
 int mpn_frcnn_test_one(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N, float *d_dets,
                        int top_cap, int *d_n_dets, void *stream);
+/* Throughput form for a loop over images (Tester:test, Tester_FRCNN.lua:150-157): same work, but the
+ * latency-bound NMS + top-k tail of image i runs on an internal high-priority stream and overlaps image
+ * i+1's trunk.  d_dets / d_n_dets of call i are ordered on `stream` only after call i+1 (on the same
+ * handle) or mpn_frcnn_flush(); alternate two output buffers between consecutive calls. */
+int mpn_frcnn_test_one_pipelined(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N,
+                                 float *d_dets, int top_cap, int *d_n_dets, void *stream);
+int mpn_frcnn_flush(mpn_frcnn *p, void *stream);
 int mpn_frcnn_nms_results(mpn_frcnn *p, const float **d_keep, const int **d_keep_idx, const int **d_n_keep,
                           int *m_stride);
 /* Per-kernel-group timing with HIP events recorded on the launch stream (bench.py's roofline leg).

@@ -109,8 +109,15 @@ struct mpn_frcnn {
   float *w6 = nullptr, *b6 = nullptr, *w7 = nullptr, *b7 = nullptr, *wh = nullptr, *bh = nullptr;
   float *rois = nullptr, *x6 = nullptr, *y6 = nullptr, *y7 = nullptr, *head = nullptr;
   float *scores = nullptr, *bbox = nullptr, *bbox_raw = nullptr;
-  float *scored = nullptr, *keep = nullptr, *thresh = nullptr;
+  // NMS-stage buffers: two sets so that image i's NMS (side stream) overlaps image i+1's trunk
+  float *scored_b[2] = {nullptr, nullptr}, *keep_b[2] = {nullptr, nullptr}, *thresh_b[2] = {nullptr, nullptr};
+  int *counts_b[2] = {nullptr, nullptr}, *keep_idx_b[2] = {nullptr, nullptr}, *n_keep_b[2] = {nullptr, nullptr};
+  float *scored = nullptr, *keep = nullptr, *thresh = nullptr;   // set of the most recent call
   int *counts = nullptr, *keep_idx = nullptr, *n_keep = nullptr;
+  hipStream_t side = nullptr;           // high-priority stream for the latency-bound NMS / top-k tail
+  hipEvent_t ev_head[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
+  bool tail_pending[2] = {false, false};
+  unsigned long long seq = 0;
   float *dbg = nullptr;
   size_t dbg_bytes = 0;
   int last_n = 0;
@@ -163,6 +170,8 @@ extern "C" void mpn_frcnn_destroy(mpn_frcnn *p) {
   if (!p) return;
   (void)hipDeviceSynchronize();
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
+  for (int i = 0; i < 2; ++i) { if (p->ev_head[i]) (void)hipEventDestroy(p->ev_head[i]); if (p->ev_tail[i]) (void)hipEventDestroy(p->ev_tail[i]); }
+  if (p->side) (void)hipStreamDestroy(p->side);
   for (void *q : p->allocs) (void)hipFree(q);
   if (p->dbg) (void)hipFree(p->dbg);
   delete p;
@@ -245,12 +254,26 @@ extern "C" int mpn_frcnn_create(const mpn_frcnn_config *cfg, const float *const 
   TRY(dev_alloc(p, &p->scores, M * C * sizeof(float), true));
   TRY(dev_alloc(p, &p->bbox, M * 4 * C * sizeof(float), true));
   TRY(dev_alloc(p, &p->bbox_raw, M * 4 * C * sizeof(float), true));
-  TRY(dev_alloc(p, &p->scored, (size_t)(C - 1) * M * 5 * sizeof(float), true));
-  TRY(dev_alloc(p, &p->keep, (size_t)(C - 1) * M * 5 * sizeof(float), true));
-  TRY(dev_alloc(p, &p->keep_idx, (size_t)(C - 1) * M * sizeof(int), true));
-  TRY(dev_alloc(p, &p->counts, (size_t)(C - 1) * sizeof(int), true));
-  TRY(dev_alloc(p, &p->n_keep, (size_t)(C - 1) * sizeof(int), true));
-  TRY(dev_alloc(p, &p->thresh, 16, true));
+  for (int i = 0; i < 2; ++i) {
+    TRY(dev_alloc(p, &p->scored_b[i], (size_t)(C - 1) * M * 5 * sizeof(float), true));
+    TRY(dev_alloc(p, &p->keep_b[i], (size_t)(C - 1) * M * 5 * sizeof(float), true));
+    TRY(dev_alloc(p, &p->keep_idx_b[i], (size_t)(C - 1) * M * sizeof(int), true));
+    TRY(dev_alloc(p, &p->counts_b[i], (size_t)(C - 1) * sizeof(int), true));
+    TRY(dev_alloc(p, &p->n_keep_b[i], (size_t)(C - 1) * sizeof(int), true));
+    TRY(dev_alloc(p, &p->thresh_b[i], 16, true));
+  }
+  p->scored = p->scored_b[0]; p->keep = p->keep_b[0]; p->keep_idx = p->keep_idx_b[0];
+  p->counts = p->counts_b[0]; p->n_keep = p->n_keep_b[0]; p->thresh = p->thresh_b[0];
+  {
+    int lo = 0, hi = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, hi);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+      e = hipEventCreateWithFlags(&p->ev_head[i], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_tail[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) { set_error("mpn_frcnn_create: side stream/events: %s", hipGetErrorString(e)); mpn_frcnn_destroy(p); return MPN_EHIP; }
+  }
 #undef TRY
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) { set_error("mpn_frcnn_create: %s", hipGetErrorString(e)); mpn_frcnn_destroy(p); return MPN_EHIP; }
@@ -343,24 +366,80 @@ extern "C" int mpn_frcnn_detect(mpn_frcnn *p, const float *d_image, int H, int W
   return MPN_OK;
 }
 
+static void select_set(mpn_frcnn *p, int b) {
+  p->scored = p->scored_b[b]; p->keep = p->keep_b[b]; p->keep_idx = p->keep_idx_b[b];
+  p->counts = p->counts_b[b]; p->n_keep = p->n_keep_b[b]; p->thresh = p->thresh_b[b];
+}
+
+// Tester_FRCNN.lua:106-125 + keep_top_k: per class j=1..C-1 select (score > thresh) -> NMS -> top-k, on stream `t`
+static int run_tail(mpn_frcnn *p, int N, float *d_dets, int top_cap, int *d_n_dets, hipStream_t sel_stream, hipStream_t t,
+                    hipEvent_t after_select) {
+  const mpn_frcnn_config &c = p->cfg;
+  const int C = c.n_classes;
+  int rc;
+  { ProfScope ps(p, MPN_PROF_SELECT, sel_stream);
+    rc = mpn_select_scored(p->scores, p->bbox, N, C, 1, c.score_thresh, p->scored, p->counts, nullptr, sel_stream); }
+  if (rc) return rc;
+  if (after_select) {  // hand over to the side stream
+    MPN_CHECK_HIP(hipEventRecord(after_select, sel_stream));
+    MPN_CHECK_HIP(hipStreamWaitEvent(t, after_select, 0));
+  }
+  { ProfScope ps(p, MPN_PROF_NMS, t);
+    rc = mpn_nms_batched(p->scored, p->counts, C - 1, N, c.nms_thresh, p->keep, p->keep_idx, p->n_keep, t); }
+  if (rc) return rc;
+  ProfScope ps(p, MPN_PROF_TOPK, t);
+  return mpn_keep_top_k(p->keep, p->n_keep, C - 1, N, c.top_k, p->thresh, d_dets, top_cap, d_n_dets, t);
+}
+
+static int join_tail(mpn_frcnn *p, int b, hipStream_t s) {
+  if (p->tail_pending[b]) {
+    MPN_CHECK_HIP(hipStreamWaitEvent(s, p->ev_tail[b], 0));
+    p->tail_pending[b] = false;
+  }
+  return MPN_OK;
+}
+
+extern "C" int mpn_frcnn_flush(mpn_frcnn *p, void *stream) {
+  MPN_CHECK_ARG(p != nullptr);
+  hipStream_t s = as_stream(stream);
+  int rc = join_tail(p, 0, s);
+  if (rc) return rc;
+  return join_tail(p, 1, s);
+}
+
 extern "C" int mpn_frcnn_test_one(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N,
                                   float *d_dets, int top_cap, int *d_n_dets, void *stream) {
   MPN_CHECK_ARG(p != nullptr && d_n_dets && (top_cap == 0 || d_dets) && top_cap >= 0);
   hipStream_t s = as_stream(stream);
-  int rc = run_detect(p, d_image, H, W, d_boxes, N, s);
+  int rc = mpn_frcnn_flush(p, stream);  // a pipelined predecessor may still own a buffer set
   if (rc) return rc;
-  const mpn_frcnn_config &c = p->cfg;
-  const int C = c.n_classes;
-  // Tester_FRCNN.lua:106-125: per class j=1..C-1 select (score > thresh) -> NMS.  The class slabs
-  // have stride max_rois so that mpn_frcnn_nms_results stays valid across calls with different N.
-  { ProfScope ps(p, MPN_PROF_SELECT, s);
-    rc = mpn_select_scored(p->scores, p->bbox, N, C, 1, c.score_thresh, p->scored, p->counts, nullptr, s); }
+  rc = run_detect(p, d_image, H, W, d_boxes, N, s);
   if (rc) return rc;
-  { ProfScope ps(p, MPN_PROF_NMS, s);
-    rc = mpn_nms_batched(p->scored, p->counts, C - 1, N, c.nms_thresh, p->keep, p->keep_idx, p->n_keep, s); }
+  select_set(p, 0);
+  return run_tail(p, N, d_dets, top_cap, d_n_dets, s, s, nullptr);
+}
+
+// Throughput form for a loop over images (Tester:test, Tester_FRCNN.lua:150-157): trunk + heads + select of
+// image i on `stream`; NMS + top-k of image i on the pipeline's high-priority side stream, overlapping image
+// i+1's MFMA kernels (they are latency-bound on ~20 CUs).  d_dets / d_n_dets of call i are ordered on `stream`
+// only after call i+1 returns or after mpn_frcnn_flush(); the caller alternates two output buffers.
+extern "C" int mpn_frcnn_test_one_pipelined(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N,
+                                            float *d_dets, int top_cap, int *d_n_dets, void *stream) {
+  MPN_CHECK_ARG(p != nullptr && d_n_dets && (top_cap == 0 || d_dets) && top_cap >= 0);
+  hipStream_t s = as_stream(stream);
+  const int b = (int)(p->seq & 1);
+  int rc = join_tail(p, b, s);  // buffer set b was last used two calls ago
   if (rc) return rc;
-  ProfScope ps(p, MPN_PROF_TOPK, s);
-  return mpn_keep_top_k(p->keep, p->n_keep, C - 1, N, c.top_k, p->thresh, d_dets, top_cap, d_n_dets, s);
+  rc = run_detect(p, d_image, H, W, d_boxes, N, s);
+  if (rc) return rc;
+  select_set(p, b);
+  rc = run_tail(p, N, d_dets, top_cap, d_n_dets, s, p->side, p->ev_head[b]);
+  if (rc) return rc;
+  MPN_CHECK_HIP(hipEventRecord(p->ev_tail[b], p->side));
+  p->tail_pending[b] = true;
+  rc = join_tail(p, b ^ 1, s);  // the previous image's detections become visible to `stream` here
+  p->seq++;
+  return rc;
 }
 
 extern "C" int mpn_frcnn_set_profiling(mpn_frcnn *p, int enable) {
@@ -389,6 +468,7 @@ extern "C" int mpn_frcnn_get_profile(mpn_frcnn *p, double *ms, long *counts, int
 extern "C" int mpn_frcnn_nms_results(mpn_frcnn *p, const float **d_keep, const int **d_keep_idx, const int **d_n_keep,
                                      int *m_stride) {
   MPN_CHECK_ARG(p != nullptr);
+  MPN_CHECK_HIP(hipDeviceSynchronize());
   if (d_keep) *d_keep = p->keep;
   if (d_keep_idx) *d_keep_idx = p->keep_idx;
   if (d_n_keep) *d_n_keep = p->n_keep;

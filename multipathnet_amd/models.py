@@ -110,6 +110,9 @@ class FastRCNN(object):
         self.device = dev
         self._dets = torch.zeros((top_k * 4 + 64, 6), dtype=torch.float32, device=dev)
         self._n_dets = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._dets2 = [torch.zeros_like(self._dets) for _ in range(2)]
+        self._n_dets2 = [torch.zeros_like(self._n_dets) for _ in range(2)]
+        self._pipe_seq = 0
 
     def __del__(self):
         try:
@@ -135,6 +138,20 @@ class FastRCNN(object):
         check(self._lib.mpn_frcnn_test_one(self._h, _f(image, "image"), H, W, _f(boxes, "boxes"), boxes.size(0), _f(self._dets),
                                            self._dets.size(0), _i(self._n_dets), _stream()), "mpn_frcnn_test_one")
         return self._dets, self._n_dets
+
+    def test_one_pipelined(self, image, boxes):
+        """Throughput form (mpn_frcnn_test_one_pipelined): returns the (dets, n) buffers this call will fill; they are
+        valid after the NEXT call or flush().  Two buffer pairs alternate."""
+        H, W = image.shape[1:]
+        b = self._pipe_seq & 1
+        self._pipe_seq += 1
+        dets, n = self._dets2[b], self._n_dets2[b]
+        check(self._lib.mpn_frcnn_test_one_pipelined(self._h, _f(image, "image"), H, W, _f(boxes, "boxes"), boxes.size(0), _f(dets),
+                                                     dets.size(0), _i(n), _stream()), "mpn_frcnn_test_one_pipelined")
+        return dets, n
+
+    def flush(self):
+        check(self._lib.mpn_frcnn_flush(self._h, _stream()), "mpn_frcnn_flush")
 
     def nms_results(self):
         """Per-class NMS output of the last test_one: (keep [C-1,N,5], keep_idx [C-1,N], n_keep [C-1])."""

@@ -148,3 +148,36 @@ def test_other_image_sizes_rezero_halo(O, dev, H, W):
     assert np.abs(scores.cpu().numpy() - O.softmax(logits)).max() < 1e-4
     ref_bbox = O.clamp_boxes(O.bbox_decode(boxes, deltas), W, H)
     assert np.abs(bbox.cpu().numpy() - ref_bbox).max() < 1e-4 * W
+
+
+def test_pipelined_equals_serial(dev, small):
+    """mpn_frcnn_test_one_pipelined (NMS tail on the side stream, overlapping the next image) returns exactly what the
+    serial form returns, image after image, with results valid one call later / after flush."""
+    net = small["net"]
+    rng = np.random.default_rng(99)
+    ims = [torch.from_numpy(rng.random((3, SMALL["H"], SMALL["W"]), dtype=np.float32)).to(dev) for _ in range(5)]
+    bxs = [torch.from_numpy(_boxes(rng, SMALL["N"] - 7 * i, SMALL["W"], SMALL["H"])).to(dev) for i in range(5)]
+    serial = []
+    for im, bx in zip(ims, bxs):
+        d, n = net.test_one_async(im, bx)
+        torch.cuda.synchronize()
+        serial.append(d[: int(n.item())].clone())
+    got, pending = [], None
+    for im, bx in zip(ims, bxs):
+        cur = net.test_one_pipelined(im, bx)
+        if pending is not None:  # previous call's buffers are ordered on the stream now
+            d, n = pending
+            torch.cuda.current_stream().synchronize()
+            got.append(d[: int(n.item())].clone())
+        pending = cur
+    net.flush()
+    torch.cuda.current_stream().synchronize()
+    d, n = pending
+    got.append(d[: int(n.item())].clone())
+    assert len(got) == len(serial)
+    for a, b in zip(got, serial):
+        assert a.shape == b.shape and torch.equal(a, b)
+    # the serial entry point stays correct after pipelined use
+    d, n = net.test_one_async(ims[0], bxs[0])
+    torch.cuda.synchronize()
+    assert torch.equal(d[: int(n.item())], serial[0])
