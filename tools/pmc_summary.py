@@ -17,9 +17,9 @@ for r in csv.DictReader(open(ct)):
     if (r["Dispatch_Id"]) not in seen:
         seen.add(r["Dispatch_Id"]); cnt[key] += 1
         acc[key]["_dur_us"] += dur.get(r["Dispatch_Id"], 0.0)
-for key, c in sorted(acc.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0)):
+for key, c in sorted(acc.items(), key=lambda kv: -kv[1].get("_dur_us", 0)):
     n = cnt[key]
-    g = c.get("GRBM_GUI_ACTIVE", 0) / n
+    g = c.get("GRBM_GUI_ACTIVE", 0) / n / 8.0  # the counter is reported per XCD (8 rows per dispatch): average them
     line = "%-58s grid=%-8s n=%-3d" % (key[0], key[1], n)
     if c["_dur_us"]: line += " dur=%8.1fus clk=%5.0fMHz" % (c["_dur_us"] / n, g / (c["_dur_us"] / n))
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and g: line += " mfma_util=%5.1f%%" % (100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / n / (g * 1024))
