@@ -383,13 +383,15 @@ struct GemmArgs {
   int ablate;  // timing experiments only (results wrong): 1 = no DMA in loop, 2 = no barrier in loop, 4 = no ds_reads in loop
 };
 
-constexpr int KCH = 4;  // 8-wide K chunks per LDS stage (32 k)
-
-template <bool GLDS>
+// KCH = 8-wide K chunks per LDS stage (4 -> 32 k per stage, 32 KiB per stage);  NBUF = LDS ring depth:
+//   2: next stage's DMA issued at the top of the current stage, `vmcnt(0)` + barrier at its end;
+//   3: DMA runs TWO stages ahead; the end-of-stage wait is a counted `vmcnt(2*IT)` (only the older stage must
+//      have landed) followed by a raw s_barrier, so HBM / cross-XCD latency up to ~2 stage times stays hidden.
+template <int KCH, int NBUF>
 __global__ __launch_bounds__(256) void gemm_c8_kernel(GemmArgs a) {
-  constexpr int OP_FLOATS = KCH * 128 * 8;  // 16 KiB per operand per stage
+  constexpr int OP_FLOATS = KCH * 128 * 8;  // per operand per stage
   constexpr int STAGE = 2 * OP_FLOATS;
-  constexpr int LOADS = OP_FLOATS / 256;    // 16 wave-loads per operand
+  constexpr int LOADS = OP_FLOATS / 256;    // 1 KiB wave-loads per operand
   constexpr int IT = LOADS / 4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -418,30 +420,14 @@ __global__ __launch_bounds__(256) void gemm_c8_kernel(GemmArgs a) {
   }
   const size_t a_stage = (size_t)KCH * a.NP * 8, b_stage = (size_t)KCH * a.Mp * 8;
 
-  f32x4 ra[GLDS ? 1 : IT], rb[GLDS ? 1 : IT];
-  auto issue = [&](int st, int s) {
+  auto issue = [&](int st, int s) {  // 2*IT global_load_lds per wave
     const float *ab = a.wpk + (size_t)st * a_stage;
     const float *bb = a.x + (size_t)st * b_stage;
     float *l = lds + s * STAGE;
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-      if constexpr (GLDS) {
-        glds16(ab + a_off[i], l + (i * 4 + wave) * 256);
-        glds16(bb + b_off[i], l + OP_FLOATS + (i * 4 + wave) * 256);
-      } else {
-        ra[i] = *reinterpret_cast<const f32x4 *>(ab + a_off[i]);
-        rb[i] = *reinterpret_cast<const f32x4 *>(bb + b_off[i]);
-      }
-    }
-  };
-  auto commit = [&](int s) {
-    if constexpr (!GLDS) {
-      float *l = lds + s * STAGE;
-#pragma unroll
-      for (int i = 0; i < IT; ++i) {
-        *reinterpret_cast<f32x4 *>(l + (i * 4 + wave) * 256 + lane * 4) = ra[i];
-        *reinterpret_cast<f32x4 *>(l + OP_FLOATS + (i * 4 + wave) * 256 + lane * 4) = rb[i];
-      }
+      glds16(ab + a_off[i], l + (i * 4 + wave) * 256);
+      glds16(bb + b_off[i], l + OP_FLOATS + (i * 4 + wave) * 256);
     }
   };
 
@@ -454,25 +440,31 @@ __global__ __launch_bounds__(256) void gemm_c8_kernel(GemmArgs a) {
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
   const int lane_off = l31 * 8 + half * 4;
-  if (st0 < st1) {
-    issue(st0, 0);
-    commit(0);
+  if (st0 < st1) issue(st0, 0);
+  if constexpr (NBUF == 3) {
+    if (st0 + 1 < st1) issue(st0 + 1, 1);
+    if (st0 + 1 < st1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  } else {
+    __syncthreads();
   }
-  __syncthreads();
-  f32x4 af[2] = {f32x4{1, 2, 3, 4}, f32x4{1, 2, 3, 4}}, bf[2] = {f32x4{1, 2, 3, 4}, f32x4{1, 2, 3, 4}};
+  int s = 0;  // ring slot of the stage being computed
   for (int st = st0; st < st1; ++st) {
-    const int s = (st - st0) & 1;
-    if (st + 1 < st1 && !(a.ablate & 1)) issue(st + 1, s ^ 1);
+    if constexpr (NBUF == 3) {
+      if (st + 2 < st1 && !(a.ablate & 1)) issue(st + 2, s >= 1 ? s - 1 : 2);  // slot (s+2)%3
+    } else {
+      if (st + 1 < st1 && !(a.ablate & 1)) issue(st + 1, s ^ 1);
+    }
     const float *Al = lds + s * STAGE + lane_off;
     const float *Bl = Al + OP_FLOATS;
 #pragma unroll
     for (int kk = 0; kk < KCH; ++kk) {
-      if (!(a.ablate & 4)) {
+      f32x4 af[2], bf[2];
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) af[mi] = *reinterpret_cast<const f32x4 *>(Al + (kk * 128 + wm * 64 + mi * 32) * 8);
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) bf[ni] = *reinterpret_cast<const f32x4 *>(Bl + (kk * 128 + wn * 64 + ni * 32) * 8);
-      }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -481,8 +473,17 @@ __global__ __launch_bounds__(256) void gemm_c8_kernel(GemmArgs a) {
           for (int ni = 0; ni < 2; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
     }
-    if (st + 1 < st1) commit(s ^ 1);
-    if (!(a.ablate & 2)) __syncthreads();
+    if constexpr (NBUF == 3) {
+      // stage st+1 must have landed (all but the newest 2*IT DMAs of this wave), then every wave must agree
+      if (st + 2 < st1 && !(a.ablate & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      s = (s == 2) ? 0 : s + 1;
+    } else {
+      if (!(a.ablate & 2)) __syncthreads();
+      s ^= 1;
+    }
   }
 
   float *yb = a.y + (a.direct ? (size_t)0 : (size_t)split * (a.NP / 8) * a.Mp * 8);
@@ -542,7 +543,9 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ part, int S, int 
   }
 }
 
-static int g_gemm_regstage = 0;
+static int g_gemm_regstage = 0;  // (retired; kept so the debug hook stays a no-op)
+static int g_gemm_kch = 0;       // test/bench hook: force 4 or 8 K chunks per stage
+static int g_gemm_nbuf = 2;      // LDS ring depth for the 32-k kernel (2 or 3)
 static int g_gemm_split = 0;  // test/bench hook: force a split-K factor
 static float *g_splitk_ws = nullptr;
 static size_t g_splitk_ws_bytes = 0;
@@ -553,10 +556,12 @@ int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float
   GemmArgs a{};
   a.x = d_x_c8; a.Mp = lin_mp(M); a.wpk = d_wpk; a.NP = lin_np(N); a.bpk = d_bpk;
   a.M = M; a.relu = relu; a.ablate = g_gemm_ablate;
-  const int K32 = round_up(K, 32);
-  a.nstages = K32 / 32;
+  const int K64 = round_up(K, 64);
   a.n_mt = a.Mp / 128; a.n_nt = a.NP / 128;
   const int tiles = a.n_mt * a.n_nt;
+  // long-K, enough tiles to fill the chip: 64-k stages; otherwise 32-k stages (finer split-K granularity)
+  const int kch = g_gemm_kch ? g_gemm_kch : 4;  // 64-k stages measured no faster than 32-k (tools/bench_layers.py)
+  a.nstages = K64 / (8 * kch);
   int S = 1;
   if (g_gemm_split > 0) S = g_gemm_split;
   else if (tiles < 128) {  // too few tiles to fill 256 CUs: split K (deterministic two-pass reduce)
@@ -568,11 +573,11 @@ int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float
   S = cdiv(a.nstages, a.stages_per_split);
   const bool direct = (S == 1) && d_y_c8 && !d_y_rm;
   a.direct = direct ? 1 : 0;
-  constexpr size_t LDS = (size_t)2 * 2 * KCH * 128 * 8 * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_c8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_c8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_c8_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 4 * 128 * 8 * 4));
+    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_c8_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 8 * 128 * 8 * 4));
+    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_c8_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 4 * 128 * 8 * 4));
     attr = true;
   }
   if (direct) {
@@ -589,8 +594,9 @@ int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float
     a.y = g_splitk_ws;
   }
   dim3 grid((unsigned)tiles, (unsigned)S);
-  if (g_gemm_regstage) hipLaunchKernelGGL(gemm_c8_kernel<false>, grid, dim3(256), LDS, s, a);
-  else hipLaunchKernelGGL(gemm_c8_kernel<true>, grid, dim3(256), LDS, s, a);
+  if (kch == 8) hipLaunchKernelGGL((gemm_c8_kernel<8, 2>), grid, dim3(256), (size_t)2 * 2 * 8 * 128 * 8 * 4, s, a);
+  else if (g_gemm_nbuf == 3) hipLaunchKernelGGL((gemm_c8_kernel<4, 3>), grid, dim3(256), (size_t)3 * 2 * 4 * 128 * 8 * 4, s, a);
+  else hipLaunchKernelGGL((gemm_c8_kernel<4, 2>), grid, dim3(256), (size_t)2 * 2 * 4 * 128 * 8 * 4, s, a);
   MPN_CHECK_LAUNCH();
   if (!direct) {
     size_t total = (size_t)(a.NP / 8) * M;
@@ -644,7 +650,7 @@ __global__ void pack_lin_w_kernel(const float *__restrict__ w, const float *__re
 
 int pack_linear_weights(const float *d_w, const float *d_b, int K, int N, int inner, float *d_wpk, float *d_bpk, hipStream_t s) {
   MPN_CHECK_ARG(d_w && d_wpk && d_bpk && K > 0 && N > 0 && inner > 0);
-  int K32 = round_up(K, 32), nq = K32 / 8, NP = lin_np(N);
+  int K32 = round_up(K, 64), nq = K32 / 8, NP = lin_np(N);
   MPN_CHECK_ARG(inner == 1 || (K % (8 * inner)) == 0);
   size_t total = (size_t)nq * NP * 8;
   hipLaunchKernelGGL(pack_lin_w_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, d_w, d_b, K, N, NP, nq, inner, d_wpk, d_bpk);
@@ -873,6 +879,8 @@ extern "C" void mpn_debug_set_conv_variant(int v) { g_conv_variant = v; }
 extern "C" void mpn_debug_set_gemm_regstage(int v) { g_gemm_regstage = v; }
 extern "C" void mpn_debug_set_conv_split(int v) { g_conv_split = v; }
 extern "C" void mpn_debug_set_gemm_split(int v) { g_gemm_split = v; }
+extern "C" void mpn_debug_set_gemm_kch(int v) { g_gemm_kch = (v == 4 || v == 8) ? v : 0; }
+extern "C" void mpn_debug_set_gemm_nbuf(int v) { g_gemm_nbuf = (v == 3) ? 3 : 2; }
 extern "C" void mpn_debug_set_gemm_ablate(int v) { g_gemm_ablate = v; }
 
 // Kernel-only timing of one conv layer / one linear layer in the pipeline's own layouts (tools/bench_layers.py).
@@ -929,7 +937,7 @@ extern "C" int mpn_debug_bench_conv(int Cin, int Cout, int H, int W, int pool, i
 
 extern "C" int mpn_debug_bench_linear(int M, int K, int N, int iters, float *ms_out) {
   MPN_CHECK_ARG(M > 0 && K > 0 && N > 0 && iters > 0 && ms_out);
-  const int K32 = round_up(K, 32);
+  const int K32 = round_up(K, 64);
   size_t xe = mat_c8_elems(M, K32), we = lin_wpk_elems(K32, N), ye = (size_t)(lin_np(N) / 8) * lin_mp(M) * 8;
   float *x = nullptr, *w = nullptr, *b = nullptr, *y = nullptr;
   MPN_CHECK_HIP(hipMalloc(&x, xe * 4)); MPN_CHECK_HIP(hipMalloc(&w, we * 4));
@@ -1012,7 +1020,7 @@ extern "C" int mpn_linear_forward(const float *d_x, int M, int K, const float *d
   hipStream_t s = as_stream(stream);
   static float *scratch = nullptr;
   static size_t scratch_bytes = 0;
-  size_t xe = mat_c8_elems(M, round_up(K, 32)), we = lin_wpk_elems(round_up(K, 32), N), be = lin_np(N);
+  size_t xe = mat_c8_elems(M, round_up(K, 64)), we = lin_wpk_elems(round_up(K, 64), N), be = lin_np(N);
   size_t need = (xe + we + be) * sizeof(float);
   if (need > scratch_bytes) {
     MPN_CHECK_HIP(hipStreamSynchronize(s));

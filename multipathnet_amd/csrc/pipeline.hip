@@ -225,7 +225,7 @@ extern "C" int mpn_frcnn_create(const mpn_frcnn_config *cfg, const float *const 
   p->K6 = p->feat_c * PP;
   p->Mp = lin_mp(cfg->max_rois);
   p->n_head = 5 * C;
-  const int K6_32 = round_up(p->K6, 32), F32 = round_up(F, 32);
+  const int K6_32 = round_up(p->K6, 64), F32 = round_up(F, 64);
   TRY(dev_alloc(p, &p->w6, lin_wpk_elems(K6_32, F) * sizeof(float), false));
   TRY(dev_alloc(p, &p->b6, (size_t)lin_np(F) * sizeof(float), false));
   TRY(pack_linear_weights(d_fc6_w, d_fc6_b, p->K6, F, PP, p->w6, p->b6, nullptr));

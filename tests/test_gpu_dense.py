@@ -116,3 +116,23 @@ def test_split_batch_invariance_exact(O, dev):
     full = _linear(dev, x, w2, b)
     parts = torch.cat([_linear(dev, x[:25], w2, b).clone(), _linear(dev, x[25:], w2, b).clone()])
     assert (full - parts).abs().max().item() == 0
+
+
+@pytest.mark.parametrize("M,K,N", [(130, 300, 70), (1000, 1024, 512), (64, 25088, 128), (257, 4096, 105)])
+def test_linear_three_stage_ring(O, dev, M, K, N):
+    """the depth-2-prefetch GEMM (3 LDS buffers, counted vmcnt + raw s_barrier) gives bit-identical results to the
+    2-buffer kernel (same k order) — run several times to screen for DMA/read races"""
+    import multipathnet_amd
+    lib = multipathnet_amd.load()
+    rng = np.random.default_rng(M * 7 + N)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) * (1.0 / K) ** 0.5).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    base = _linear(dev, x, w, b, relu=True).clone()
+    lib.mpn_debug_set_gemm_nbuf(3)
+    try:
+        for _ in range(5):
+            assert torch.equal(_linear(dev, x, w, b, relu=True), base)
+    finally:
+        lib.mpn_debug_set_gemm_nbuf(2)
+    assert np.abs(base.cpu().numpy() - O.linear(x, w, b, relu=True)).max() < 1e-4 * max(1.0, float(base.abs().max()))
