@@ -200,6 +200,27 @@ int mpn_frcnn_create(const mpn_frcnn_config *cfg, const float *const *d_conv_w, 
                      mpn_frcnn **out);
 void mpn_frcnn_destroy(mpn_frcnn *p);
 
+/* MultiPathNet head (models/multipathnet.lua:64-120): nn.Foveal -> n_towers region towers, each
+ * {conv345Combine (model_utils.lua:209-251: ROI pools of conv5 @scale, conv4 @2*scale, conv3 @4*scale,
+ * per-map nn.Normalize(2), channel concat, *1000, 1x1 conv mix to conv5's width) -> fc6 -> fc7};
+ * the first n_towers-1 ("foveal") towers are concatenated for the K integral classifiers
+ * (model_utils.lua:275-317: eval = mean of the K softmaxes), the last ("het") tower feeds the box
+ * regressor.  This replaces nn.ModelParallelTable's broadcast/concat (ModelParallelTable.lua:195-242)
+ * with zero-copy concatenation on one GPU.  All pointers are device pointers in Torch layout:
+ * mix_w[t] [c5, total_feat_t] (the 1x1 conv), fc6_w[t] [fc, c5*PH*PW], fc7_w[t] [fc, fc];
+ * d_cls_w [n_integral*C, (n_towers-1)*fc] (the K classifiers stacked), d_bbox_w [4C, fc]. */
+typedef struct mpn_mpnet_weights {
+  int n_towers;              /* 5 in the reference: regions {0,1,2,3} + het on region 1 */
+  int region[8];             /* 0-based Foveal region of each tower (Foveal.lua:36-39 rows) */
+  int use_conv4[8], use_conv3[8];
+  int tap_conv3, tap_conv4;  /* 0-based conv-layer indices whose pre-pool outputs are "conv3"/"conv4" (VGG-16: 6, 9) */
+  int n_integral;            /* K (opt.nDonkeys in the reference, 6 in scripts/train_multipathnet_coco.sh:8) */
+  const float *mix_w[8], *mix_b[8], *fc6_w[8], *fc6_b[8], *fc7_w[8], *fc7_b[8];
+} mpn_mpnet_weights;
+int mpn_mpnet_create(const mpn_frcnn_config *cfg, const float *const *d_conv_w, const float *const *d_conv_b,
+                     const mpn_mpnet_weights *mw, const float *d_cls_w, const float *d_cls_b, const float *d_bbox_w,
+                     const float *d_bbox_b, mpn_frcnn **out);
+
 /* ImageDetect:detect on a scale-1 image (getImages' resample is the identity):
  * d_image [3,H,W] fp32 in [0,1]; d_boxes [N,4].  Outputs (all optional, device):
  *   d_scores [N,C] softmax, d_bbox [N,4C] decoded + clamped boxes. */

@@ -65,11 +65,16 @@ int conv3x3_variant_for(int Cout);  // 1 = 128 couts x 4 rows x 32 cols tile, 2 
 int maxpool2x2_c8p(Act in, Act out, hipStream_t s);
 // y = relu?(x W^T + b).  x: C8 matrix [K8/8][Mp][8]; y: C8 matrix [NP/8][Mp][8] (y_c8) and/or
 // row-major [M,N] (y_rm); either may be null.
+// Mp_override: row pitch of x / y when it is not lin_mp(M) (a ROI-pooled matrix viewed as (bin, roi) rows).
 int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float *d_bpk, int N, int relu, float *d_y_c8,
-              float *d_y_rm, hipStream_t s);
+              float *d_y_rm, hipStream_t s, int Mp_override = 0);
 // ROI max-pool reading a C8P feature map and writing the C8 matrix the fc6 GEMM consumes:
 // chunk q = cb*PH*PW + bin, row = roi.  argmax (optional) [N,C,PH,PW] int32 as the NCHW kernel.
+// roi_stride: floats between consecutive rois (5; 20 selects one Foveal region out of the [4N,5] table);
+// Mp: row pitch of the output matrix (0 = lin_mp(N)).
 int roi_pool_c8(Act feat, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset, int end_adjust,
-                float *d_x_c8, int32_t *d_argmax, hipStream_t s);
+                float *d_x_c8, int32_t *d_argmax, hipStream_t s, int roi_stride = 5, int Mp = 0);
+// in-place x * (mul / sqrt(sum x^2 + 1e-10)) per ROI over n_records 8-float records of a C8 matrix
+int l2norm_scale_c8(float *d_x_c8, int n_records, int Mp, int N, float mul, hipStream_t s);
 
 }  // namespace mpn

@@ -551,10 +551,11 @@ static float *g_splitk_ws = nullptr;
 static size_t g_splitk_ws_bytes = 0;
 
 int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float *d_bpk, int N, int relu, float *d_y_c8,
-              float *d_y_rm, hipStream_t s) {
+              float *d_y_rm, hipStream_t s, int Mp_override) {
   MPN_CHECK_ARG(d_x_c8 && d_wpk && d_bpk && (d_y_c8 || d_y_rm) && M > 0 && K > 0 && N > 0);
+  MPN_CHECK_ARG(Mp_override == 0 || (Mp_override >= M && Mp_override % 128 == 0));
   GemmArgs a{};
-  a.x = d_x_c8; a.Mp = lin_mp(M); a.wpk = d_wpk; a.NP = lin_np(N); a.bpk = d_bpk;
+  a.x = d_x_c8; a.Mp = Mp_override ? Mp_override : lin_mp(M); a.wpk = d_wpk; a.NP = lin_np(N); a.bpk = d_bpk;
   a.M = M; a.relu = relu; a.ablate = g_gemm_ablate;
   const int K64 = round_up(K, 64);
   a.n_mt = a.Mp / 128; a.n_nt = a.NP / 128;
@@ -817,9 +818,9 @@ __global__ void maxpool2x2_nchw_kernel(const float *__restrict__ in, size_t BC, 
 // ROI max-pool: C8P feature map -> C8 matrix [cb*PH*PW + bin][Mp][8].  One thread per
 // (cb, bin, roi) half-record; roi fastest so a wave writes 1 KiB contiguous.
 __global__ __launch_bounds__(256) void roi_pool_c8_kernel(const float *__restrict__ feat, int C, int H, int W, int Hp, int Wp,
-                                                          const float *__restrict__ rois, int N, int PH, int PW, float scale,
-                                                          float coord_offset, int end_adjust, float *__restrict__ xc8, int Mp,
-                                                          int32_t *__restrict__ argmax) {
+                                                          const float *__restrict__ rois, int roi_stride, int N, int PH, int PW,
+                                                          float scale, float coord_offset, int end_adjust, float *__restrict__ xc8,
+                                                          int Mp, int32_t *__restrict__ argmax) {
   const int Cb = (C + 7) / 8, PP = PH * PW;
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)Cb * PP * N * 2;
@@ -828,7 +829,7 @@ __global__ __launch_bounds__(256) void roi_pool_c8_kernel(const float *__restric
   int n = (int)(r % N); r /= N;
   int bin = (int)(r % PP); int cb = (int)(r / PP);
   int ph = bin / PW, pw = bin - ph * PW;
-  const float *ro = rois + 5 * (size_t)n;
+  const float *ro = rois + (size_t)roi_stride * n;
   int sw = (int)roundf((ro[1] - coord_offset) * scale);
   int sh = (int)roundf((ro[2] - coord_offset) * scale);
   int ew = (int)roundf((ro[3] - coord_offset) * scale) + end_adjust;
@@ -860,12 +861,45 @@ __global__ __launch_bounds__(256) void roi_pool_c8_kernel(const float *__restric
   }
 }
 
+// nn.Normalize(2) + MulConstant over one pooled map of the skip concat (model_utils.lua:216-223,236-241):
+// per ROI, x * (mul / sqrt(sum x^2 + 1e-10)) over all C*PH*PW values of the map.  The map occupies chunks
+// [0, Cb*PP) of a C8 matrix; thread n walks its ROI's records (consecutive threads touch consecutive 32 B).
+__global__ __launch_bounds__(256) void l2norm_scale_c8_kernel(float *__restrict__ x, int nrec, int Mp, int N, float mul) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float ss = 0.0f;
+  for (int r = 0; r < nrec; ++r) {
+    const float *q = x + ((size_t)r * Mp + n) * 8;
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(q), b = *reinterpret_cast<const f32x4 *>(q + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ss += a[e] * a[e]; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ss += b[e] * b[e]; }
+  }
+  const float nrm = sqrtf(ss + 1e-10f);
+  for (int r = 0; r < nrec; ++r) {
+    float *q = x + ((size_t)r * Mp + n) * 8;
+    f32x4 a = *reinterpret_cast<f32x4 *>(q), b = *reinterpret_cast<f32x4 *>(q + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e] = (a[e] / nrm) * mul; b[e] = (b[e] / nrm) * mul; }
+    *reinterpret_cast<f32x4 *>(q) = a;
+    *reinterpret_cast<f32x4 *>(q + 4) = b;
+  }
+}
+
+int l2norm_scale_c8(float *d_x_c8, int n_records, int Mp, int N, float mul, hipStream_t s) {
+  MPN_CHECK_ARG(d_x_c8 && n_records > 0 && N > 0 && Mp >= N);
+  hipLaunchKernelGGL(l2norm_scale_c8_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, d_x_c8, n_records, Mp, N, mul);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
 int roi_pool_c8(Act feat, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset, int end_adjust,
-                float *d_x_c8, int32_t *d_argmax, hipStream_t s) {
+                float *d_x_c8, int32_t *d_argmax, hipStream_t s, int roi_stride, int Mp) {
   MPN_CHECK_ARG(feat.p && d_rois && d_x_c8 && N > 0 && PH > 0 && PW > 0);
   size_t total = (size_t)feat.Cb() * PH * PW * N * 2;
   hipLaunchKernelGGL(roi_pool_c8_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, feat.p, feat.C, feat.H, feat.W, feat.Hp,
-                     feat.Wp, d_rois, N, PH, PW, scale, coord_offset, end_adjust, d_x_c8, lin_mp(N), d_argmax);
+                     feat.Wp, d_rois, roi_stride, N, PH, PW, scale, coord_offset, end_adjust, d_x_c8, Mp > 0 ? Mp : lin_mp(N), d_argmax);
   MPN_CHECK_LAUNCH();
   return MPN_OK;
 }

@@ -36,13 +36,13 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(const float *__restri
 
 // BBoxNorm (modules/BBoxNorm.lua:28-29) + convertFrom (utils.lua:229-247) + clamp
 // (Tester_FRCNN.lua:75-78) on head[:, C:5C]; thread per (roi, class)
-__global__ void head_decode_kernel(const float *__restrict__ head, int ld, int M, int C, const float *__restrict__ boxes,
+__global__ void head_decode_kernel(const float *__restrict__ head, int ld, int col0, int M, int C, const float *__restrict__ boxes,
                                    int has_norm, float m0, float m1, float m2, float m3, float s0, float s1, float s2,
                                    float s3, float im_w, float im_h, float *__restrict__ raw, float *__restrict__ out) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)M * C) return;
   int i = (int)(t / C), c = (int)(t - (size_t)i * C);
-  const float *d = head + (size_t)i * ld + C + 4 * c;
+  const float *d = head + (size_t)i * ld + col0 + 4 * c;
   float d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];
   if (has_norm) {
     d0 = d0 * s0; d0 = d0 + m0;
@@ -66,6 +66,32 @@ __global__ void head_decode_kernel(const float *__restrict__ head, int ld, int M
   o3 = o3 < 1.0f ? 1.0f : (o3 > im_h ? im_h : o3);
   float *o = out + 4 * t;
   o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3;
+}
+
+// integral eval head (model_utils.lua:296-313): K classifiers -> softmax each -> mean over K.
+// logits [M, K*C] row-major; one wave per row; sum over k in k order, then * (1/K) like nn.Mean.
+__global__ __launch_bounds__(256) void integral_softmax_mean_kernel(const float *__restrict__ logits, int M, int K, int C,
+                                                                    float *__restrict__ scores) {
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float inv = 1.0f / (float)K;
+  // per k: max and sum over all C columns (wave reductions), then accumulate this lane's columns
+  float accv[4] = {0.f, 0.f, 0.f, 0.f};  // supports C <= 256
+  for (int k = 0; k < K; ++k) {
+    const float *r = logits + ((size_t)row * K + k) * C;
+    float mx = -INFINITY;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, r[c]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float sum = 0.f;
+    for (int c = lane; c < C; c += 64) sum += expf(r[c] - mx);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    int q = 0;
+    for (int c = lane; c < C; c += 64, ++q) accv[q] += expf(r[c] - mx) / sum;
+  }
+  int q = 0;
+  for (int c = lane; c < C; c += 64, ++q) scores[(size_t)row * C + c] = accv[q] * inv;
 }
 
 // pooled C8 matrix [cb*PP+bin][Mp][8] -> reference order [N, C*PP] (debug / parity only)
@@ -122,6 +148,14 @@ struct mpn_frcnn {
   size_t dbg_bytes = 0;
   int last_n = 0;
   int fuse_pool = 1;
+  // ---- MultiPathNet head (models/multipathnet.lua:64-120); empty for plain Fast R-CNN
+  struct Tower { int region, use4, use3, total_feat; float *mix_w, *mix_b, *w6, *b6, *w7, *b7; };
+  bool is_mpnet = false;
+  int tap3 = -1, tap4 = -1, n_integral = 1;
+  std::vector<Tower> towers;
+  float *fov = nullptr, *tx = nullptr, *ty = nullptr, *tz6 = nullptr, *cat = nullptr, *cls_rm = nullptr, *bbox_rm = nullptr;
+  float *wcls = nullptr, *bcls = nullptr, *wbbox = nullptr, *bbbox = nullptr;
+  Act tap_act[3];  // conv5, conv4, conv3 of the last trunk run
   std::vector<void *> allocs;
   // optional per-kernel-group timing with HIP events recorded on the launch stream
   bool prof = false;
@@ -177,17 +211,19 @@ extern "C" void mpn_frcnn_destroy(mpn_frcnn *p) {
   delete p;
 }
 
-extern "C" int mpn_frcnn_create(const mpn_frcnn_config *cfg, const float *const *d_conv_w, const float *const *d_conv_b,
-                                const float *d_fc6_w, const float *d_fc6_b, const float *d_fc7_w, const float *d_fc7_b,
-                                const float *d_cls_w, const float *d_cls_b, const float *d_bbox_w, const float *d_bbox_b,
-                                mpn_frcnn **out) {
-  MPN_CHECK_ARG(cfg && d_conv_w && d_conv_b && d_fc6_w && d_fc7_w && d_cls_w && d_bbox_w && out);
+static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w, const float *const *d_conv_b,
+                       const float *d_fc6_w, const float *d_fc6_b, const float *d_fc7_w, const float *d_fc7_b,
+                       const float *d_cls_w, const float *d_cls_b, const float *d_bbox_w, const float *d_bbox_b,
+                       const mpn_mpnet_weights *mw, mpn_frcnn **out) {
+  MPN_CHECK_ARG(cfg && d_conv_w && d_conv_b && d_cls_w && d_bbox_w && out);
+  MPN_CHECK_ARG(mw || (d_fc6_w && d_fc7_w));
   MPN_CHECK_ARG(cfg->n_conv > 0 && cfg->conv_cout && cfg->pool_after);
   MPN_CHECK_ARG(cfg->pooled_h > 0 && cfg->pooled_w > 0 && cfg->fc_dim > 0 && cfg->n_classes > 1);
   MPN_CHECK_ARG(cfg->max_h > 0 && cfg->max_w > 0 && cfg->max_rois > 0 && cfg->max_rois <= MPN_NMS_MAX_BOXES);
   MPN_CHECK_ARG(cfg->top_k > 0);
   mpn_frcnn *p = new mpn_frcnn();
   p->cfg = *cfg;
+  if (mw) { p->is_mpnet = true; p->tap3 = mw->tap_conv3; p->tap4 = mw->tap_conv4; p->n_integral = mw->n_integral > 0 ? mw->n_integral : 1; }
   p->cout.assign(cfg->conv_cout, cfg->conv_cout + cfg->n_conv);
   p->pool_after.assign(cfg->pool_after, cfg->pool_after + cfg->n_conv);
   p->cfg.conv_cout = p->cout.data();
@@ -226,6 +262,48 @@ extern "C" int mpn_frcnn_create(const mpn_frcnn_config *cfg, const float *const 
   p->Mp = lin_mp(cfg->max_rois);
   p->n_head = 5 * C;
   const int K6_32 = round_up(p->K6, 64), F32 = round_up(F, 64);
+  const size_t M = cfg->max_rois;
+  if (mw) {
+    MPN_CHECK_ARG(mw->n_towers >= 2 && mw->n_towers <= 8 && p->tap3 >= 0 && p->tap4 > p->tap3 && p->tap4 < cfg->n_conv - 1);
+    MPN_CHECK_ARG(C <= 256 && F % 128 == 0);
+    const int c5 = p->feat_c, c4 = p->cout[p->tap4], c3 = p->cout[p->tap3];
+    MPN_CHECK_ARG(c4 % 8 == 0 && c3 % 8 == 0);
+    int max_feat = 0;
+    for (int t = 0; t < mw->n_towers; ++t) {
+      mpn_frcnn::Tower T{};
+      T.region = mw->region[t]; T.use4 = mw->use_conv4[t]; T.use3 = mw->use_conv3[t];
+      MPN_CHECK_ARG(T.region >= 0 && T.region < 4 && mw->mix_w[t] && mw->fc6_w[t] && mw->fc7_w[t]);
+      T.total_feat = c5 + (T.use4 ? c4 : 0) + (T.use3 ? c3 : 0);
+      if (T.total_feat > max_feat) max_feat = T.total_feat;
+      const int TF64 = round_up(T.total_feat, 64);
+      TRY(dev_alloc(p, &T.mix_w, lin_wpk_elems(TF64, c5) * sizeof(float), false));
+      TRY(dev_alloc(p, &T.mix_b, (size_t)lin_np(c5) * sizeof(float), false));
+      TRY(pack_linear_weights(mw->mix_w[t], mw->mix_b[t], T.total_feat, c5, 1, T.mix_w, T.mix_b, nullptr));
+      TRY(dev_alloc(p, &T.w6, lin_wpk_elems(K6_32, F) * sizeof(float), false));
+      TRY(dev_alloc(p, &T.b6, (size_t)lin_np(F) * sizeof(float), false));
+      TRY(pack_linear_weights(mw->fc6_w[t], mw->fc6_b[t], p->K6, F, PP, T.w6, T.b6, nullptr));
+      TRY(dev_alloc(p, &T.w7, lin_wpk_elems(F32, F) * sizeof(float), false));
+      TRY(dev_alloc(p, &T.b7, (size_t)lin_np(F) * sizeof(float), false));
+      TRY(pack_linear_weights(mw->fc7_w[t], mw->fc7_b[t], F, F, 1, T.w7, T.b7, nullptr));
+      p->towers.push_back(T);
+    }
+    const int n_fov = mw->n_towers - 1, K = p->n_integral;
+    const int KC64 = round_up(n_fov * F, 64);
+    TRY(dev_alloc(p, &p->wcls, lin_wpk_elems(KC64, K * C) * sizeof(float), false));
+    TRY(dev_alloc(p, &p->bcls, (size_t)lin_np(K * C) * sizeof(float), false));
+    TRY(pack_linear_weights(d_cls_w, d_cls_b, n_fov * F, K * C, 1, p->wcls, p->bcls, nullptr));
+    TRY(dev_alloc(p, &p->wbbox, lin_wpk_elems(F32, 4 * C) * sizeof(float), false));
+    TRY(dev_alloc(p, &p->bbbox, (size_t)lin_np(4 * C) * sizeof(float), false));
+    TRY(pack_linear_weights(d_bbox_w, d_bbox_b, F, 4 * C, 1, p->wbbox, p->bbbox, nullptr));
+    const size_t rows = (size_t)PP * p->Mp;
+    TRY(dev_alloc(p, &p->fov, M * 20 * sizeof(float), true));
+    TRY(dev_alloc(p, &p->tx, (size_t)(round_up(max_feat, 64) / 8) * rows * 8 * sizeof(float), true));
+    TRY(dev_alloc(p, &p->ty, (size_t)(lin_np(c5) / 8) * rows * 8 * sizeof(float), true));
+    TRY(dev_alloc(p, &p->tz6, (size_t)(lin_np(F) / 8) * p->Mp * 8 * sizeof(float), true));
+    TRY(dev_alloc(p, &p->cat, (size_t)mw->n_towers * (lin_np(F) / 8) * p->Mp * 8 * sizeof(float), true));
+    TRY(dev_alloc(p, &p->cls_rm, M * K * C * sizeof(float), true));
+    TRY(dev_alloc(p, &p->bbox_rm, M * 4 * C * sizeof(float), true));
+  } else {
   TRY(dev_alloc(p, &p->w6, lin_wpk_elems(K6_32, F) * sizeof(float), false));
   TRY(dev_alloc(p, &p->b6, (size_t)lin_np(F) * sizeof(float), false));
   TRY(pack_linear_weights(d_fc6_w, d_fc6_b, p->K6, F, PP, p->w6, p->b6, nullptr));
@@ -245,12 +323,12 @@ extern "C" int mpn_frcnn_create(const mpn_frcnn_config *cfg, const float *const 
     TRY(dev_alloc(p, &p->bh, (size_t)lin_np(5 * C) * sizeof(float), false));
     TRY(pack_linear_weights(tmp_w, tmp_b, F, 5 * C, 1, p->wh, p->bh, nullptr));
   }
-  const size_t M = cfg->max_rois;
-  TRY(dev_alloc(p, &p->rois, M * 5 * sizeof(float), true));
   TRY(dev_alloc(p, &p->x6, (size_t)(K6_32 / 8) * p->Mp * 8 * sizeof(float), true));
   TRY(dev_alloc(p, &p->y6, (size_t)(lin_np(F) / 8) * p->Mp * 8 * sizeof(float), true));
   TRY(dev_alloc(p, &p->y7, (size_t)(lin_np(F) / 8) * p->Mp * 8 * sizeof(float), true));
   TRY(dev_alloc(p, &p->head, M * 5 * C * sizeof(float), true));
+  }
+  TRY(dev_alloc(p, &p->rois, M * 5 * sizeof(float), true));
   TRY(dev_alloc(p, &p->scores, M * C * sizeof(float), true));
   TRY(dev_alloc(p, &p->bbox, M * 4 * C * sizeof(float), true));
   TRY(dev_alloc(p, &p->bbox_raw, M * 4 * C * sizeof(float), true));
@@ -293,15 +371,19 @@ static int run_trunk(mpn_frcnn *p, const float *d_image, int H, int W, hipStream
     rc = image_transform_c8p(d_image, H, W, c.tf_swap, c.tf_scale, c.tf_mean, c.tf_std, c.tf_std[0] != 0.0, cur, s); }
   if (rc) return rc;
   int h = H, w = W;
+  int li = 0;
   for (auto &L : p->conv) {
     Act out = make_act(L.out, L.Cout, h, w);
     const int cv = conv3x3_variant_for(L.Cout);
     const int ctag = (cv == 1 || cv == 3) ? MPN_PROF_CONV_128x4 : MPN_PROF_CONV_64x8;
+    const bool is_tap = p->is_mpnet && (li == p->tap3 || li == p->tap4);
+    if (is_tap) p->tap_act[li == p->tap4 ? 1 : 2] = out;
+    ++li;
     if (L.pool) {
       Act pooled = make_act(L.pooled, L.Cout, (h + 1) / 2, (w + 1) / 2);
       if (g_fuse_pool) {
         ProfScope ps(p, ctag, s);
-        rc = conv3x3_c8p(cur, L.wpk, L.bpk, L.Cout, 1, Act{}, pooled, s);
+        rc = conv3x3_c8p(cur, L.wpk, L.bpk, L.Cout, 1, is_tap ? out : Act{}, pooled, s);  // tap layers keep the pre-pool map too
       } else {
         { ProfScope ps(p, ctag, s); rc = conv3x3_c8p(cur, L.wpk, L.bpk, L.Cout, 1, out, Act{}, s); }
         if (rc == MPN_OK) { ProfScope ps(p, MPN_PROF_POOL, s); rc = maxpool2x2_c8p(out, pooled, s); }
@@ -315,6 +397,60 @@ static int run_trunk(mpn_frcnn *p, const float *d_image, int H, int W, hipStream
     }
   }
   *feat_out = cur;
+  p->tap_act[0] = cur;
+  return MPN_OK;
+}
+
+// models/multipathnet.lua:64-120 + model_utils.lua:209-251,296-313 on the C8 layouts: Foveal -> per tower
+// {ROI pools of conv5 / conv4 / conv3 written side by side = the channel concat, per-map L2 normalise * 1000,
+// 1x1 conv mix as a GEMM over (bin, roi) rows whose output IS the fc6 operand, fc6, fc7 into the tower concat}
+// -> K integral classifiers (mean of softmaxes) + bbox regressor on the "het" tower.
+static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int W, hipStream_t s) {
+  const mpn_frcnn_config &c = p->cfg;
+  const int C = c.n_classes, F = c.fc_dim, PP = c.pooled_h * c.pooled_w, Mp = lin_mp(N), K = p->n_integral;
+  int rc = mpn_foveal_forward(p->rois, N, p->fov, s);
+  if (rc) return rc;
+  const Act maps[3] = {p->tap_act[0], p->tap_act[1], p->tap_act[2]};
+  const float scales[3] = {c.spatial_scale, c.spatial_scale * 2.0f, c.spatial_scale * 4.0f};
+  const int Fcb = lin_np(F) / 8;
+  int ti = 0;
+  for (auto &T : p->towers) {
+    const float *reg = p->fov + 5 * T.region;  // rows 4n + region of the Foveal table
+    int cb_off = 0;
+    const int used[3] = {1, T.use4, T.use3};
+    for (int m = 0; m < 3; ++m) {
+      if (!used[m]) continue;
+      float *dst = p->tx + (size_t)cb_off * PP * Mp * 8;
+      { ProfScope ps(p, MPN_PROF_ROIPOOL, s);
+        rc = roi_pool_c8(maps[m], reg, N, c.pooled_h, c.pooled_w, scales[m], 1.0f, 0, dst, nullptr, s, 20, Mp);
+        if (rc == MPN_OK) rc = l2norm_scale_c8(dst, maps[m].Cb() * PP, Mp, N, 1000.0f, s); }
+      if (rc) return rc;
+      cb_off += maps[m].Cb();
+    }
+    // 1x1 conv mix: rows = (bin, roi), K = concat channels, N = feat_c; output layout == fc6 operand layout
+    { ProfScope ps(p, MPN_PROF_HEADS, s);
+      rc = linear_c8(p->tx, PP * Mp, T.total_feat, T.mix_w, T.mix_b, p->feat_c, 0, p->ty, nullptr, s, PP * Mp); }
+    if (rc) return rc;
+    { ProfScope ps(p, MPN_PROF_FC6, s); rc = linear_c8(p->ty, N, p->K6, T.w6, T.b6, F, 1, p->tz6, nullptr, s, Mp); }
+    if (rc) return rc;
+    { ProfScope ps(p, MPN_PROF_FC7, s);
+      rc = linear_c8(p->tz6, N, F, T.w7, T.b7, F, 1, p->cat + (size_t)ti * Fcb * Mp * 8, nullptr, s, Mp); }
+    if (rc) return rc;
+    ++ti;
+  }
+  const int n_fov = (int)p->towers.size() - 1;
+  { ProfScope ps(p, MPN_PROF_HEADS, s);
+    rc = linear_c8(p->cat, N, n_fov * F, p->wcls, p->bcls, K * C, 0, nullptr, p->cls_rm, s, Mp);
+    if (rc == MPN_OK) rc = linear_c8(p->cat + (size_t)n_fov * Fcb * Mp * 8, N, F, p->wbbox, p->bbbox, 4 * C, 0, nullptr, p->bbox_rm, s, Mp); }
+  if (rc) return rc;
+  ProfScope ps_post(p, MPN_PROF_POST, s);
+  hipLaunchKernelGGL(integral_softmax_mean_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, p->cls_rm, N, K, C, p->scores);
+  MPN_CHECK_LAUNCH();
+  const bool norm = c.bbox_std[0] != 0.0f;
+  hipLaunchKernelGGL(head_decode_kernel, dim3((unsigned)cdiv_sz((size_t)N * C, 256)), dim3(256), 0, s, p->bbox_rm, 4 * C, 0, N, C, d_boxes,
+                     norm ? 1 : 0, c.bbox_mean[0], c.bbox_mean[1], c.bbox_mean[2], c.bbox_mean[3], c.bbox_std[0], c.bbox_std[1],
+                     c.bbox_std[2], c.bbox_std[3], (float)W, (float)H, p->bbox_raw, p->bbox);
+  MPN_CHECK_LAUNCH();
   return MPN_OK;
 }
 
@@ -332,6 +468,11 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H, int W, const fl
   if (rc) return rc;
   rc = mpn_project_im_rois(d_boxes, N, 1.0, p->rois, s);
   if (rc) return rc;
+  if (p->is_mpnet) {
+    rc = run_mpnet_head(p, d_boxes, N, H, W, s);
+    p->last_n = N;
+    return rc;
+  }
   const int C = c.n_classes, F = c.fc_dim;
   { ProfScope ps(p, MPN_PROF_ROIPOOL, s);
     rc = roi_pool_c8(feat, p->rois, N, c.pooled_h, c.pooled_w, c.spatial_scale, 1.0f, 0, p->x6, nullptr, s); }
@@ -346,7 +487,7 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H, int W, const fl
   hipLaunchKernelGGL(head_softmax_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, p->head, 5 * C, N, C, p->scores);
   MPN_CHECK_LAUNCH();
   const bool norm = c.bbox_std[0] != 0.0f;
-  hipLaunchKernelGGL(head_decode_kernel, dim3((unsigned)cdiv_sz((size_t)N * C, 256)), dim3(256), 0, s, p->head, 5 * C, N, C, d_boxes,
+  hipLaunchKernelGGL(head_decode_kernel, dim3((unsigned)cdiv_sz((size_t)N * C, 256)), dim3(256), 0, s, p->head, 5 * C, C, N, C, d_boxes,
                      norm ? 1 : 0, c.bbox_mean[0], c.bbox_mean[1], c.bbox_mean[2], c.bbox_mean[3], c.bbox_std[0], c.bbox_std[1],
                      c.bbox_std[2], c.bbox_std[3], (float)W, (float)H, p->bbox_raw, p->bbox);
   MPN_CHECK_LAUNCH();
@@ -442,6 +583,20 @@ extern "C" int mpn_frcnn_test_one_pipelined(mpn_frcnn *p, const float *d_image, 
   return rc;
 }
 
+extern "C" int mpn_frcnn_create(const mpn_frcnn_config *cfg, const float *const *d_conv_w, const float *const *d_conv_b,
+                                const float *d_fc6_w, const float *d_fc6_b, const float *d_fc7_w, const float *d_fc7_b,
+                                const float *d_cls_w, const float *d_cls_b, const float *d_bbox_w, const float *d_bbox_b,
+                                mpn_frcnn **out) {
+  return create_impl(cfg, d_conv_w, d_conv_b, d_fc6_w, d_fc6_b, d_fc7_w, d_fc7_b, d_cls_w, d_cls_b, d_bbox_w, d_bbox_b, nullptr, out);
+}
+
+extern "C" int mpn_mpnet_create(const mpn_frcnn_config *cfg, const float *const *d_conv_w, const float *const *d_conv_b,
+                                const mpn_mpnet_weights *mw, const float *d_cls_w, const float *d_cls_b,
+                                const float *d_bbox_w, const float *d_bbox_b, mpn_frcnn **out) {
+  MPN_CHECK_ARG(mw != nullptr);
+  return create_impl(cfg, d_conv_w, d_conv_b, nullptr, nullptr, nullptr, nullptr, d_cls_w, d_cls_b, d_bbox_w, d_bbox_b, mw, out);
+}
+
 extern "C" int mpn_frcnn_set_profiling(mpn_frcnn *p, int enable) {
   MPN_CHECK_ARG(p != nullptr);
   p->prof = enable != 0;
@@ -491,6 +646,7 @@ extern "C" int mpn_frcnn_debug_tensor(mpn_frcnn *p, const char *name, const floa
   else if (nm == "cls") n = (size_t)N * C;
   else if (nm == "bbox_raw") n = (size_t)N * 4 * C;
   else { set_error("mpn_frcnn_debug_tensor: unknown tensor '%s'", name); return MPN_EINVAL; }
+  if (p->is_mpnet && nm != "conv5" && nm != "bbox_raw") { set_error("mpn_frcnn_debug_tensor: '%s' is not kept by the MultiPathNet head", name); return MPN_EINVAL; }
   MPN_CHECK_HIP(hipDeviceSynchronize());
   if (n * sizeof(float) > p->dbg_bytes) {
     if (p->dbg) (void)hipFree(p->dbg);

@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import FrcnnConfig, check, f32p
+from ._lib import FrcnnConfig, MpnetWeights, check, f32p
 from .nn import _f, _i, _stream
 
 VGG16_CFG = [64, 64, "P", 128, 128, "P", 256, 256, 256, "P", 512, 512, 512, "P", 512, 512, 512]  # vgg.lua:14-27, no pool5
@@ -61,6 +61,59 @@ def synthetic_params(cfg=VGG16_CFG, pooled=7, fc_dim=4096, n_classes=21, seed=55
     return P
 
 
+# models/multipathnet.lua:78-111: four foveal towers (region i; conv4 if i<=3, conv3 if i==1) + the "het" tower
+# (region 2, all three maps) whose output feeds the box regressor.  Regions are 0-based here.
+MPN_TOWERS = [dict(region=0, use4=1, use3=1), dict(region=1, use4=1, use3=0), dict(region=2, use4=1, use3=0),
+              dict(region=3, use4=0, use3=0), dict(region=1, use4=1, use3=1)]
+
+
+def conv_tap_indices(cfg):
+    """0-based conv-layer indices of the last conv before the 3rd and 4th pools (VGG-16: conv3_3 = 6, conv4_3 = 9)."""
+    convs, pools = -1, []
+    for item in cfg:
+        if item == "P":
+            pools.append(convs)
+        else:
+            convs += 1
+    return pools[2], pools[3]
+
+
+def synthetic_mpnet_params(cfg=VGG16_CFG, pooled=7, fc_dim=4096, n_classes=81, n_integral=6, seed=557, towers=MPN_TOWERS):
+    """Seeded weights for the MultiPathNet graph: shared trunk + per-tower {1x1 mix, fc6, fc7} + K integral
+    classifiers + one box regressor (multipathnet.lua:64-120, model_utils.lua:275-317)."""
+    P = synthetic_params(cfg, pooled, fc_dim, n_classes, seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    cout, _ = cfg_layers(cfg)
+    t3, t4 = conv_tap_indices(cfg)
+    c5, c4, c3 = cout[-1], cout[t4], cout[t3]
+    P["towers"] = []
+    for T in towers:
+        tf = c5 + (c4 if T["use4"] else 0) + (c3 if T["use3"] else 0)
+        k6 = c5 * pooled * pooled
+        P["towers"].append(dict(
+            T, total_feat=tf,
+            # after Normalize*1000 each map has RMS ~ 1000/sqrt(C*49); scale the mix so its output is O(1)
+            mix_w=torch.randn(c5, tf, generator=g) * (2.0 / tf) ** 0.5 * 0.15, mix_b=torch.randn(c5, generator=g) * 0.01,
+            fc6_w=torch.randn(fc_dim, k6, generator=g) * (2.0 / k6) ** 0.5, fc6_b=torch.randn(fc_dim, generator=g) * 0.01,
+            fc7_w=torch.randn(fc_dim, fc_dim, generator=g) * (2.0 / fc_dim) ** 0.5, fc7_b=torch.randn(fc_dim, generator=g) * 0.01))
+    nf = len(towers) - 1
+    P["cls_w"] = torch.randn(n_integral * n_classes, nf * fc_dim, generator=g) * 0.01  # K classifier clones stacked
+    P["cls_b"] = torch.zeros(n_integral * n_classes)
+    P["bbox_w"] = torch.randn(4 * n_classes, fc_dim, generator=g) * 0.001
+    P["bbox_b"] = torch.zeros(4 * n_classes)
+    P["n_integral"], P["n_classes"] = n_integral, n_classes
+    for k in ("fc6_w", "fc6_b", "fc7_w", "fc7_b"):
+        P.pop(k, None)
+    return P
+
+
+def MultiPathNet(params, **kw):
+    """models/multipathnet.lua graph as one device pipeline (same object type; noSoftMax like model_utils.lua:314)."""
+    net = FastRCNN(params, **kw)
+    net.noSoftMax = True
+    return net
+
+
 class FastRCNN(object):
     """Trunk + ROI head + post-processing as one device pipeline (models/vgg.lua:23-31 graph)."""
 
@@ -69,8 +122,9 @@ class FastRCNN(object):
         _lib.require_gpu()
         lib = _lib.load()
         cout, pool = cfg_layers(cfg)
-        self.n_classes = params["cls_w"].shape[0]
-        self.fc_dim = params["fc7_w"].shape[0]
+        self.is_mpnet = "towers" in params
+        self.n_classes = params["n_classes"] if self.is_mpnet else params["cls_w"].shape[0]
+        self.fc_dim = params["towers"][0]["fc7_w"].shape[0] if self.is_mpnet else params["fc7_w"].shape[0]
         self.noSoftMax = False
         self.max_rois = max_rois
         c = FrcnnConfig()
@@ -102,9 +156,25 @@ class FastRCNN(object):
         cb = [d(b) for b in params["conv_b"]]
         wp = (f32p * len(cw))(*[_f(w) for w in cw])
         bp = (f32p * len(cb))(*[_f(b) for b in cb])
-        keep = [d(params[k]) for k in ("fc6_w", "fc6_b", "fc7_w", "fc7_b", "cls_w", "cls_b", "bbox_w", "bbox_b")]
         self._h = C.c_void_p()
-        check(lib.mpn_frcnn_create(C.byref(c), wp, bp, *[_f(t) for t in keep], C.byref(self._h)), "mpn_frcnn_create")
+        if self.is_mpnet:
+            mw = MpnetWeights()
+            tow = params["towers"]
+            mw.n_towers = len(tow)
+            mw.tap_conv3, mw.tap_conv4 = conv_tap_indices(cfg)
+            mw.n_integral = params["n_integral"]
+            keep = []
+            for t, T in enumerate(tow):
+                mw.region[t], mw.use_conv4[t], mw.use_conv3[t] = T["region"], T["use4"], T["use3"]
+                for name in ("mix_w", "mix_b", "fc6_w", "fc6_b", "fc7_w", "fc7_b"):
+                    dt = d(T[name])
+                    keep.append(dt)
+                    getattr(mw, name)[t] = _f(dt)
+            heads = [d(params[k]) for k in ("cls_w", "cls_b", "bbox_w", "bbox_b")]
+            check(lib.mpn_mpnet_create(C.byref(c), wp, bp, C.byref(mw), *[_f(t) for t in heads], C.byref(self._h)), "mpn_mpnet_create")
+        else:
+            keep = [d(params[k]) for k in ("fc6_w", "fc6_b", "fc7_w", "fc7_b", "cls_w", "cls_b", "bbox_w", "bbox_b")]
+            check(lib.mpn_frcnn_create(C.byref(c), wp, bp, *[_f(t) for t in keep], C.byref(self._h)), "mpn_frcnn_create")
         torch.cuda.synchronize()
         self._lib = lib
         self.device = dev

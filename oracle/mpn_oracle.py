@@ -369,3 +369,40 @@ def test_one(im, boxes, P, nms_thresh=0.3, score_thresh=-1.5, use_ref_nms=False,
         sb, _ = select_scored(scores, dec, j, score_thresh)
         out.append(ref_nms(sb, nms_thresh) if use_ref_nms else nms(sb, nms_thresh))
     return out, (scores, dec)
+
+
+# ---------------------------------------------------------------- MultiPathNet head (models/multipathnet.lua:64-120)
+def conv345_combine(maps, region_rois, T, pooled=7, spatial_scale=1.0 / 16):
+    """model_utils.lua:209-251 with isNormalized=true: per map ROIPooling(7,7,scale_m) -> View(-1, C*49) -> nn.Normalize(2)
+    -> View(-1,C,7,7); JoinTable(2) [conv5, conv4, conv3]; MulConstant(1000); 1x1 conv mix; View(-1)."""
+    parts = []
+    for m, use in enumerate((1, T["use4"], T["use3"])):
+        if not use:
+            continue
+        pool, _ = roi_pool(maps[m], region_rois, pooled, pooled, spatial_scale * (2 ** m))
+        n = pool.shape[0]
+        parts.append(l2_normalize(pool.reshape(n, -1)).reshape(pool.shape))
+    x = np.concatenate(parts, 1) * np.float32(1000.0)                     # [N, totalFeat, 7, 7]
+    n, tf = x.shape[:2]
+    rows = np.ascontiguousarray(x.transpose(0, 2, 3, 1).reshape(-1, tf))  # one row per (roi, bin): the 1x1 conv is a linear over channels
+    y = linear(rows, T["mix_w"], T["mix_b"])                              # [N*49, c5]
+    return np.ascontiguousarray(y.reshape(n, pooled * pooled, -1).transpose(0, 2, 1)).reshape(n, -1)  # flatten as [c5,7,7]
+
+
+def mpnet_head(maps, rois, P, pooled=7, spatial_scale=1.0 / 16):
+    """maps = [conv5, conv4, conv3] ([C,h,w] each); rois [N,5].  Returns (scores [N,C] = mean of K softmaxes, bbox deltas [N,4C])."""
+    fov = foveal(rois).reshape(-1, 4, 5)
+    outs = []
+    for T in P["towers"]:
+        x = conv345_combine(maps, np.ascontiguousarray(fov[:, T["region"]]), T, pooled, spatial_scale)
+        x = linear(x, T["fc6_w"], T["fc6_b"], relu=True)
+        outs.append(linear(x, T["fc7_w"], T["fc7_b"], relu=True))
+    cat = np.concatenate(outs[:-1], 1)                                    # ModelParallelTable concat along dim 2 + Narrow
+    K, Cn = P["n_integral"], P["n_classes"]
+    logits = linear(cat, P["cls_w"], P["cls_b"]).reshape(-1, K, Cn)
+    probs = np.stack([softmax(np.ascontiguousarray(logits[:, k])) for k in range(K)])
+    scores = mean_over_k(probs)
+    deltas = linear(outs[-1], P["bbox_w"], P["bbox_b"])
+    if P.get("bbox_mean") is not None:
+        deltas = bbox_norm(deltas, P["bbox_mean"], P["bbox_std"])
+    return scores, deltas

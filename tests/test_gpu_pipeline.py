@@ -181,3 +181,38 @@ def test_pipelined_equals_serial(dev, small):
     d, n = net.test_one_async(ims[0], bxs[0])
     torch.cuda.synchronize()
     assert torch.equal(d[: int(n.item())], serial[0])
+
+
+def _np_tree(v):
+    if isinstance(v, dict):
+        return {k: _np_tree(x) for k, x in v.items()}
+    if isinstance(v, list):
+        return [_np_tree(x) for x in v]
+    return v.numpy() if hasattr(v, "numpy") else v
+
+
+def test_multipathnet_head_vs_oracle(O, dev):
+    """BASELINE configs[2] graph at an oracle-sized scale: Foveal -> 5 towers (conv345Combine skip pooling + per-map L2
+    normalise + 1x1 mix, fc6, fc7) -> K integral classifiers (mean of softmaxes) + het-tower box regressor
+    (multipathnet.lua:64-120, model_utils.lua:209-251,275-317)."""
+    from multipathnet_amd import models
+    cfg = [8, 16, "P", 16, 24, "P", 32, 32, "P", 64, "P", 64]
+    H, W, N, Cn, K = 150, 250, 120, 9, 3
+    P = models.synthetic_mpnet_params(cfg, pooled=7, fc_dim=128, n_classes=Cn, n_integral=K, seed=11)
+    rng = np.random.default_rng(21)
+    im = rng.random((3, H, W), dtype=np.float32)
+    boxes = _boxes(rng, N, W, H, lo=12)
+    net = models.MultiPathNet(P, cfg=cfg, pooled=7, spatial_scale=1 / 16, max_h=H, max_w=W, max_rois=N)
+    scores, bbox = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+    Pn = _np_tree(P)
+    taps = {}
+    O.vgg_trunk(O.image_transform(im, **O.ROSS), Pn["conv_w"], Pn["conv_b"], cfg, taps=taps)
+    ref_scores, deltas = O.mpnet_head([taps["conv5"], taps["conv4"], taps["conv3"]], O.project_im_rois(boxes, 1.0), Pn)
+    ref_bbox = O.clamp_boxes(O.bbox_decode(boxes, deltas), W, H)
+    assert np.abs(scores.cpu().numpy().sum(1) - 1).max() < 1e-5
+    assert np.abs(scores.cpu().numpy() - ref_scores).max() < 1e-4
+    assert np.abs(bbox.cpu().numpy() - ref_bbox).max() < 1e-4 * W
+    # the whole tail (select -> NMS -> top-k) runs on MultiPathNet outputs too
+    dets, n = net.test_one_async(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+    torch.cuda.synchronize()
+    assert 0 < int(n.item()) <= dets.shape[0]
