@@ -862,34 +862,72 @@ __global__ __launch_bounds__(256) void roi_pool_c8_kernel(const float *__restric
 }
 
 // nn.Normalize(2) + MulConstant over one pooled map of the skip concat (model_utils.lua:216-223,236-241):
-// per ROI, x * (mul / sqrt(sum x^2 + 1e-10)) over all C*PH*PW values of the map.  The map occupies chunks
-// [0, Cb*PP) of a C8 matrix; thread n walks its ROI's records (consecutive threads touch consecutive 32 B).
-__global__ __launch_bounds__(256) void l2norm_scale_c8_kernel(float *__restrict__ x, int nrec, int Mp, int N, float mul) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+// per ROI, (x / sqrt(sum x^2 + 1e-10)) * mul over all C*PH*PW values of the map, which occupies `nrec` 8-float
+// records (pitch Mp) of a C8 matrix.  Three HBM-streaming passes, all coalesced over the ROI index and
+// deterministic: (1) per (record group, roi) partial sums, (2) per roi: add the partials in group order -> norm,
+// (3) elementwise scale.
+__global__ __launch_bounds__(256) void l2norm_partial_kernel(const float *__restrict__ x, int nrec, int per, int Mp, int N,
+                                                             float *__restrict__ part) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
   if (n >= N) return;
+  const int r0 = g * per, r1 = min(nrec, r0 + per);
   float ss = 0.0f;
-  for (int r = 0; r < nrec; ++r) {
+  for (int r = r0; r < r1; ++r) {
     const float *q = x + ((size_t)r * Mp + n) * 8;
     const f32x4 a = *reinterpret_cast<const f32x4 *>(q), b = *reinterpret_cast<const f32x4 *>(q + 4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { ss += a[e] * a[e]; }
+    for (int e = 0; e < 4; ++e) ss += a[e] * a[e];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { ss += b[e] * b[e]; }
+    for (int e = 0; e < 4; ++e) ss += b[e] * b[e];
   }
-  const float nrm = sqrtf(ss + 1e-10f);
-  for (int r = 0; r < nrec; ++r) {
-    float *q = x + ((size_t)r * Mp + n) * 8;
-    f32x4 a = *reinterpret_cast<f32x4 *>(q), b = *reinterpret_cast<f32x4 *>(q + 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { a[e] = (a[e] / nrm) * mul; b[e] = (b[e] / nrm) * mul; }
-    *reinterpret_cast<f32x4 *>(q) = a;
-    *reinterpret_cast<f32x4 *>(q + 4) = b;
-  }
+  part[(size_t)g * N + n] = ss;
 }
+__global__ void l2norm_finish_kernel(const float *__restrict__ part, int G, int N, float *__restrict__ nrm) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float ss = 0.0f;
+  for (int g = 0; g < G; ++g) ss += part[(size_t)g * N + n];
+  nrm[n] = sqrtf(ss + 1e-10f);
+}
+__global__ __launch_bounds__(256) void l2norm_apply_kernel(float *__restrict__ x, size_t nrec, int Mp, int N,
+                                                           const float *__restrict__ nrm, float mul) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (record, roi, half)
+  const size_t total = nrec * (size_t)N * 2;
+  if (t >= total) return;
+  const int h = (int)(t & 1);
+  const size_t q = t >> 1;
+  const int n = (int)(q % N);
+  const size_t r = q / N;
+  float *p = x + (r * Mp + n) * 8 + h * 4;
+  f32x4 v = *reinterpret_cast<f32x4 *>(p);
+  const float d = nrm[n];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = (v[e] / d) * mul;
+  *reinterpret_cast<f32x4 *>(p) = v;
+}
+
+static float *g_l2_ws = nullptr;   // library-owned scratch for the partial sums (grown on demand, single stream)
+static size_t g_l2_ws_bytes = 0;
 
 int l2norm_scale_c8(float *d_x_c8, int n_records, int Mp, int N, float mul, hipStream_t s) {
   MPN_CHECK_ARG(d_x_c8 && n_records > 0 && N > 0 && Mp >= N);
-  hipLaunchKernelGGL(l2norm_scale_c8_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, d_x_c8, n_records, Mp, N, mul);
+  const int per = 49;  // one channel block's bins per partial sum
+  const int G = cdiv(n_records, per);
+  const size_t need = ((size_t)G + 1) * N * sizeof(float);
+  if (need > g_l2_ws_bytes) {
+    MPN_CHECK_HIP(hipStreamSynchronize(s));
+    if (g_l2_ws) (void)hipFree(g_l2_ws);
+    g_l2_ws = nullptr; g_l2_ws_bytes = 0;
+    MPN_CHECK_HIP(hipMalloc(&g_l2_ws, need));
+    g_l2_ws_bytes = need;
+  }
+  float *part = g_l2_ws, *nrm = g_l2_ws + (size_t)G * N;
+  hipLaunchKernelGGL(l2norm_partial_kernel, dim3(cdiv(N, 256), G), dim3(256), 0, s, d_x_c8, n_records, per, Mp, N, part);
+  MPN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(l2norm_finish_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, part, G, N, nrm);
+  MPN_CHECK_LAUNCH();
+  const size_t total = (size_t)n_records * N * 2;
+  hipLaunchKernelGGL(l2norm_apply_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, d_x_c8, (size_t)n_records, Mp, N, nrm, mul);
   MPN_CHECK_LAUNCH();
   return MPN_OK;
 }
