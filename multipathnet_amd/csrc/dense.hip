@@ -254,6 +254,309 @@ static int launch_conv(const ConvArgs &a0, int tiles_y, hipStream_t s) {
   return MPN_OK;
 }
 
+
+// =================================================================================================
+// Persistent stream-K conv3x3: ONE block per CU for the whole layer.
+//   * work = T tiles x nchunks K-chunks = U units; block p owns the contiguous unit range
+//     [u0(p), u0(p+1)) (sizes differ by at most one chunk) — no round quantisation, no idle tail;
+//   * the LDS staging pipeline is CONTINUOUS across tile boundaries: the first chunk of the next tile is in
+//     flight while the current tile's last chunk is on the matrix pipe, so no per-tile prologue latency;
+//   * a tile whose chunks all fall inside one block is finished in registers (bias / ReLU / pool / C8P store);
+//     a tile cut by a block boundary leaves raw partial sums in slab j (j = index of the block inside the tile)
+//     and conv_streamk_fixup_kernel adds the slabs in j order (deterministic) and applies the epilogue.
+// =================================================================================================
+struct PersistArgs {
+  ConvArgs c;
+  int T, U, P, base, rem, tiles_y;  // units per block = base (+1 for the first `rem` blocks)
+};
+
+__host__ __device__ inline int sk_u0(int p, int base, int rem) { return p * base + (p < rem ? p : rem); }
+__host__ __device__ inline int sk_block_of(int u, int base, int rem) {
+  const int cut = rem * (base + 1);
+  return u < cut ? u / (base + 1) : rem + (u - cut) / base;
+}
+
+template <int BM, int TH, int WM, int WN>
+__global__ __launch_bounds__(256) void conv3x3_c8p_persistent_kernel(PersistArgs pa) {
+  const ConvArgs &a = pa.c;
+  constexpr int MI = BM / WM / 32, NI = TH / WN;
+  static_assert(WM * WN == 4 && NI == 2, "4 waves, 2 rows per wave (fused pool)");
+  constexpr int IN_PIECES = (TH + 2) * 68;
+  constexpr int IN_LOADS = (IN_PIECES + 63) / 64;
+  constexpr int IN_FLOATS = IN_LOADS * 256;
+  constexpr int W_LOADS = 9 * BM / 32;
+  constexpr int W_FLOATS = 9 * BM * 8;
+  constexpr int STAGE = IN_FLOATS + W_FLOATS;
+  constexpr int IN_IT = (IN_LOADS + 3) / 4, W_IT = (W_LOADS + 3) / 4;
+  constexpr int ITEMS = IN_IT + W_IT, PER_TAP = (ITEMS + 8) / 9;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+  const int mbase = wm * (BM / WM), rbase = wn * NI;
+  const int lane_off = l31 * 8 + half * 4;
+
+  // staging offsets that do not depend on the tile: (row r, piece o) of the halo tile, (tap, cout, half) of the slab
+  int in_rel[IN_IT]; bool in_ok[IN_IT];
+#pragma unroll
+  for (int i = 0; i < IN_IT; ++i) {
+    int t = i * 4 + wave, p = t * 64 + lane;
+    in_ok[i] = (t < IN_LOADS) && (p < IN_PIECES);
+    int r = p / 68, o = p - r * 68;
+    in_rel[i] = (r * a.in_Wp) * 8 + o * 4;
+  }
+  int w_rel[W_IT]; bool w_ok[W_IT];
+#pragma unroll
+  for (int i = 0; i < W_IT; ++i) {
+    int t = i * 4 + wave, p = t * 64 + lane;
+    w_ok[i] = t < W_LOADS;
+    int tap = p / (BM * 2), rem = p - tap * (BM * 2);
+    w_rel[i] = (tap * a.CoutP) * 8 + rem * 4;
+  }
+  const size_t w_chunk = (size_t)9 * a.CoutP * 8;
+
+  const int p = blockIdx.x;
+  const int u_begin = sk_u0(p, pa.base, pa.rem), u_end = sk_u0(p + 1, pa.base, pa.rem);
+  if (u_begin >= u_end) return;
+
+  // tile decode: t -> (cout tile fastest, then x, then y)
+  auto tile_geo = [&](int t, int &y0, int &x0, int &cout0) {
+    const int ct = t % a.n_ct, sp = t / a.n_ct;
+    const int ty = sp / a.tiles_x, tx = sp - ty * a.tiles_x;
+    y0 = ty * TH; x0 = tx * 32; cout0 = ct * BM;
+  };
+  // the unit whose DMA is being issued, as two wave-uniform source pointers.  Advancing to the next unit is
+  // "next chunk of the same tile" (two pointer bumps) except at a tile boundary, where the tile is re-decoded.
+  const float *nx_in = nullptr, *nx_w = nullptr;
+  int nx_t = 0, nx_c = 0;
+  auto decode_tile = [&]() {
+    int y0, x0, cout0;
+    tile_geo(nx_t, y0, x0, cout0);
+    nx_in = a.in + (size_t)nx_c * a.in_plane + (size_t)(y0 * a.in_Wp + x0) * 8;
+    nx_w = a.wpk + (size_t)nx_c * w_chunk + (size_t)cout0 * 8;
+  };
+  auto advance_unit = [&]() {
+    if (++nx_c < a.nchunks) { nx_in += a.in_plane; nx_w += w_chunk; }
+    else { nx_c = 0; ++nx_t; decode_tile(); }
+  };
+  auto issue_item = [&](int s, int item) {  // decoded unit -> stage buffer s
+    float *st = lds + s * STAGE;
+    if (item < IN_IT) {
+      const int i = item;
+      if (in_ok[i]) glds16(nx_in + in_rel[i], st + (i * 4 + wave) * 256);
+    } else if (item - IN_IT < W_IT) {
+      const int i = item - IN_IT;
+      if (w_ok[i]) glds16(nx_w + w_rel[i], st + IN_FLOATS + (i * 4 + wave) * 256);
+    }
+  };
+
+  f32x16 acc[MI][NI];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+  };
+  zero_acc();
+
+  nx_t = u_begin / a.nchunks; nx_c = u_begin - nx_t * a.nchunks;
+  decode_tile();
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) issue_item(0, it);
+  __syncthreads();
+
+  int seg_first = u_begin;  // first unit of the tile segment being accumulated
+  int t = nx_t, c = nx_c;    // the unit on the matrix pipe
+
+  for (int u = u_begin; u < u_end; ++u) {
+    const int s = (u - u_begin) & 1;
+    const bool more = u + 1 < u_end;
+    if (more) advance_unit();
+    const float *Il = lds + s * STAGE + lane_off;
+    const float *Wl = lds + s * STAGE + IN_FLOATS + lane_off;
+    f32x4 af[2][MI], bf[2][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) af[0][mi] = *reinterpret_cast<const f32x4 *>(Wl + (mbase + mi * 32) * 8);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bf[0][ni] = *reinterpret_cast<const f32x4 *>(Il + ((rbase + ni) * 34) * 8);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int cur = tap & 1;
+      if (tap + 1 < 9) {
+        const int nt = tap + 1, dy = nt / 3, dx = nt % 3;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) af[cur ^ 1][mi] = *reinterpret_cast<const f32x4 *>(Wl + (nt * BM + mbase + mi * 32) * 8);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bf[cur ^ 1][ni] = *reinterpret_cast<const f32x4 *>(Il + ((rbase + ni + dy) * 34 + dx) * 8);
+      }
+      if (more) {
+#pragma unroll
+        for (int q = 0; q < PER_TAP; ++q) issue_item(s ^ 1, tap * PER_TAP + q);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][mi][j], bf[cur][ni][j], acc[mi][ni], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- end of a tile segment?  (last chunk of the tile, or last unit of this block)
+    if (c == a.nchunks - 1 || !more) {
+      int y0, x0, cout0;
+      tile_geo(t, y0, x0, cout0);
+      const int cs = seg_first - t * a.nchunks;
+      const bool whole = (cs == 0) && (c == a.nchunks - 1);
+      const int x = x0 + l31;
+      const bool xok = x < a.W;
+      if (!whole) {  // raw partial sums into slab j = position of this block among the blocks that cut the tile
+        const int j = p - sk_block_of(t * a.nchunks, pa.base, pa.rem);
+        float *pb = a.part + (size_t)j * a.part_slab;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int cb = (cout0 + mbase + mi * 32) / 8 + g;
+            if (cb >= a.out_cb) continue;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              const int y = y0 + rbase + ni;
+              if (xok && y < a.H) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][g * 4 + e];
+                *reinterpret_cast<f32x4 *>(pb + (size_t)cb * a.out_plane + ((size_t)(y + 1) * a.out_Wp + x + 1) * 8 + half * 4) = v;
+              }
+            }
+          }
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int cb = (cout0 + mbase + mi * 32) / 8 + g;
+            if (cb >= a.out_cb) continue;
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bpk + cb * 8 + half * 4);
+            f32x4 v[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              const int y = y0 + rbase + ni;
+              const bool ok = xok && (y < a.H);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float tv = acc[mi][ni][g * 4 + e] + b4[e];
+                if (a.relu) tv = tv < 0.0f ? 0.0f : tv;
+                v[ni][e] = tv;
+              }
+              if (ok && a.out)
+                *reinterpret_cast<f32x4 *>(a.out + (size_t)cb * a.out_plane + ((size_t)(y + 1) * a.out_Wp + x + 1) * 8 + half * 4) = v[ni];
+              if (!ok) v[ni] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            }
+            if (a.pool) {
+              f32x4 m;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float tv = fmaxf(v[0][e], v[1][e]);
+                m[e] = fmaxf(tv, __shfl_xor(tv, 1));
+              }
+              const int py = (y0 + rbase) >> 1, px = x >> 1;
+              if (!(l31 & 1) && py < a.pool_H && px < a.pool_W)
+                *reinterpret_cast<f32x4 *>(a.pool + (size_t)cb * a.pool_plane + ((size_t)(py + 1) * a.pool_Wp + px + 1) * 8 + half * 4) = m;
+            }
+          }
+        }
+      }
+      zero_acc();
+      seg_first = u + 1;
+    }
+    if (++c == a.nchunks) { c = 0; ++t; }
+    __syncthreads();
+  }
+}
+
+// Finishes the tiles that a block boundary cut: one block per tile; tiles owned by a single block exit at once.
+template <int BM, int TH>
+__global__ __launch_bounds__(256) void conv_streamk_fixup_kernel(PersistArgs pa) {
+  const ConvArgs &a = pa.c;
+  const int t = blockIdx.x;
+  const int pf = sk_block_of(t * a.nchunks, pa.base, pa.rem), pl = sk_block_of(t * a.nchunks + a.nchunks - 1, pa.base, pa.rem);
+  const int nseg = pl - pf + 1;
+  if (nseg == 1) return;
+  const int ct = t % a.n_ct, sp = t / a.n_ct;
+  const int ty = sp / a.tiles_x, tx = sp - ty * a.tiles_x;
+  const int y0 = ty * TH, x0 = tx * 32, cb0 = ct * BM / 8;
+  // items: (cb in tile, pooled-or-full row pair, column pair, half) — each thread finishes a 2x2 pixel quad of 4 channels
+  constexpr int QY = TH / 2, QX = 16;
+  const int items = (BM / 8) * QY * QX * 2;
+  for (int it = threadIdx.x; it < items; it += blockDim.x) {
+    const int h = it & 1; int r = it >> 1;
+    const int qx = r % QX; r /= QX;
+    const int qy = r % QY; const int cbl = r / QY;
+    const int cb = cb0 + cbl;
+    if (cb >= a.out_cb) continue;
+    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bpk + cb * 8 + h * 4);
+    f32x4 m = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    bool any = false;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int y = y0 + 2 * qy + dy, x = x0 + 2 * qx + dx;
+        if (y >= a.H || x >= a.W) continue;
+        const size_t off = (size_t)cb * a.out_plane + ((size_t)(y + 1) * a.out_Wp + x + 1) * 8 + h * 4;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(a.part + off);
+        for (int j = 1; j < nseg; ++j) v += *reinterpret_cast<const f32x4 *>(a.part + (size_t)j * a.part_slab + off);
+        v += b4;
+        if (a.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.0f ? 0.0f : v[e];
+        }
+        if (a.out) *reinterpret_cast<f32x4 *>(a.out + off) = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+        any = true;
+      }
+    if (a.pool && any) {
+      const int py = (y0 >> 1) + qy, px = (x0 >> 1) + qx;
+      if (py < a.pool_H && px < a.pool_W)
+        *reinterpret_cast<f32x4 *>(a.pool + (size_t)cb * a.pool_plane + ((size_t)(py + 1) * a.pool_Wp + px + 1) * 8 + h * 4) = m;
+    }
+  }
+}
+
+// Measured on MI355X (tools/bench_layers.py, tools/conv_shape_probe.py): the persistent stream-K kernel removes round
+// quantisation but its K loop runs 3-5 % slower than the plain kernel's (extra scalar state around the MFMA blocks), and a
+// deferred (interleaved) epilogue made it 15 % slower — so the VGG trunk is 3.69 ms with it vs 3.52 ms block-per-tile +
+// split-K.  It therefore stays an option (mode 1), fully parity-tested; the default is mode 0.
+static int g_conv_mode = 0;  // 0 = one block per tile (+ split-K, default), 1 = persistent stream-K
+static int g_num_cus = 0;
+
+template <int BM, int TH, int WM, int WN>
+static int launch_conv_persistent(PersistArgs &pa, hipStream_t s) {
+  constexpr int IN_LOADS = ((TH + 2) * 68 + 63) / 64;
+  constexpr size_t LDS = (size_t)2 * (IN_LOADS * 256 + 9 * BM * 8) * sizeof(float);
+  auto kern = conv3x3_c8p_persistent_kernel<BM, TH, WM, WN>;
+  static bool attr = false;
+  if (!attr) {
+    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(pa.P), dim3(256), LDS, s, pa);
+  MPN_CHECK_LAUNCH();
+  if (pa.U % pa.P != 0 || pa.base % pa.c.nchunks != 0) {  // some tile is cut by a block boundary
+    hipLaunchKernelGGL((conv_streamk_fixup_kernel<BM, TH>), dim3(pa.T), dim3(256), 0, s, pa);
+    MPN_CHECK_LAUNCH();
+  }
+  return MPN_OK;
+}
+
 // split-K finish: sums S partial slabs in split order (deterministic), + bias, ReLU; writes the C8P
 // output and/or its ceil-mode 2x2 max-pool.  One thread per (channel block, pooled-or-full pixel, half).
 __global__ void conv_splitk_reduce_kernel(const float *__restrict__ part, size_t slab, int S, size_t plane, int Wp, int H, int W,
@@ -337,6 +640,35 @@ int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int re
   const int tiles_y = cdiv(in.H, wide ? 4 : 8);
   a.n_ct = cdiv(Cout, wide ? 128 : 64);
   const int blocks = a.n_ct * tiles_y * a.tiles_x;
+  if (g_conv_mode == 1 && (variant == 1 || variant == 2) && g_conv_split == 0) {
+    if (g_num_cus == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      MPN_CHECK_HIP(hipGetDevice(&dev));
+      MPN_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+      g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    PersistArgs pa{};
+    pa.T = blocks; pa.U = blocks * a.nchunks; pa.tiles_y = tiles_y;
+    pa.P = pa.U < g_num_cus ? pa.U : g_num_cus;
+    pa.base = pa.U / pa.P; pa.rem = pa.U % pa.P;
+    Act geo = out.p ? out : make_act(nullptr, Cout, in.H, in.W);
+    a.out_plane = geo.plane(); a.out_Wp = geo.Wp;
+    a.part_slab = geo.elems();
+    const int nseg_max = (a.nchunks - 1) / pa.base + 2;  // blocks that can cut one tile
+    const size_t need = a.part_slab * (size_t)nseg_max * sizeof(float);
+    if (need > g_conv_ws_bytes) {
+      MPN_CHECK_HIP(hipStreamSynchronize(s));
+      if (g_conv_ws) (void)hipFree(g_conv_ws);
+      g_conv_ws = nullptr; g_conv_ws_bytes = 0;
+      MPN_CHECK_HIP(hipMalloc(&g_conv_ws, need));
+      g_conv_ws_bytes = need;
+    }
+    a.part = g_conv_ws;
+    a.splits = 1; a.chunks_per_split = a.nchunks;
+    pa.c = a;
+    return wide ? launch_conv_persistent<128, 4, 2, 2>(pa, s) : launch_conv_persistent<64, 8, 1, 4>(pa, s);
+  }
   const int slots = variant == 1 ? 256 : (variant == 2 ? 512 : 768);  // co-resident blocks on 256 CUs (LDS / VGPR bound)
   a.splits = conv_pick_splits(blocks, a.nchunks, slots);
   a.chunks_per_split = cdiv(a.nchunks, a.splits);
@@ -950,6 +1282,7 @@ using namespace mpn;
 extern "C" void mpn_debug_set_conv_variant(int v) { g_conv_variant = v; }
 extern "C" void mpn_debug_set_gemm_regstage(int v) { g_gemm_regstage = v; }
 extern "C" void mpn_debug_set_conv_split(int v) { g_conv_split = v; }
+extern "C" void mpn_debug_set_conv_mode(int v) { g_conv_mode = v; }  // 1 = persistent stream-K, 0 = block per tile
 extern "C" void mpn_debug_set_gemm_split(int v) { g_gemm_split = v; }
 extern "C" void mpn_debug_set_gemm_kch(int v) { g_gemm_kch = (v == 4 || v == 8) ? v : 0; }
 extern "C" void mpn_debug_set_gemm_nbuf(int v) { g_gemm_nbuf = (v == 3) ? 3 : 2; }

@@ -22,11 +22,14 @@ def _conv(dev, x, w, b, relu=True):
 
 @pytest.mark.parametrize("ci,co,h,w", [(3, 64, 40, 70), (8, 64, 33, 31), (64, 64, 19, 45), (64, 128, 16, 96), (128, 256, 9, 33),
                                        (24, 40, 8, 8), (16, 200, 5, 37), (256, 512, 12, 20)])
-@pytest.mark.parametrize("variant,split", [(0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (1, 2), (2, 3), (3, 2), (4, 3), (0, 4)])
-def test_conv3x3_vs_oracle(O, dev, ci, co, h, w, variant, split):
+@pytest.mark.parametrize("variant,split,mode", [(0, 0, 1), (1, 0, 1), (2, 0, 1), (0, 0, 0), (1, 0, 0), (2, 0, 0), (3, 0, 0), (4, 0, 0),
+                                                (1, 2, 0), (2, 3, 0), (3, 2, 0), (4, 3, 0), (0, 4, 0)])
+def test_conv3x3_vs_oracle(O, dev, ci, co, h, w, variant, split, mode):
+    """mode 0 = one block per tile (+ split-K; default), 1 = persistent stream-K kernel"""
     import multipathnet_amd
     lib = multipathnet_amd.load()
     lib.mpn_debug_set_conv_split(split)
+    lib.mpn_debug_set_conv_mode(mode)
     rng = np.random.default_rng(ci * 1000 + co)
     x = rng.standard_normal((ci, h, w)).astype(np.float32)
     wt = (rng.standard_normal((co, ci, 3, 3)) * (2.0 / (ci * 9)) ** 0.5).astype(np.float32)
@@ -38,6 +41,7 @@ def test_conv3x3_vs_oracle(O, dev, ci, co, h, w, variant, split):
     finally:
         lib.mpn_debug_set_conv_variant(0)
         lib.mpn_debug_set_conv_split(0)
+        lib.mpn_debug_set_conv_mode(0)
     ref = O.conv3x3(x, wt, b, relu=True)
     assert y.shape == ref.shape
     assert np.abs(y - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
@@ -136,3 +140,25 @@ def test_linear_three_stage_ring(O, dev, M, K, N):
     finally:
         lib.mpn_debug_set_gemm_nbuf(2)
     assert np.abs(base.cpu().numpy() - O.linear(x, w, b, relu=True)).max() < 1e-4 * max(1.0, float(base.abs().max()))
+
+
+def test_conv_streamk_cut_tiles_deterministic(O, dev):
+    """a layer whose tiles are cut by block boundaries (U not a multiple of the CU count): fixed-order slab sums give
+    bit-identical results run after run, and match the block-per-tile kernel within fp32 reassociation"""
+    import multipathnet_amd
+    lib = multipathnet_amd.load()
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((72, 75, 125)).astype(np.float32)
+    wt = (rng.standard_normal((200, 72, 3, 3)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(200).astype(np.float32)
+    lib.mpn_debug_set_conv_mode(1)  # persistent stream-K
+    try:
+        a = _conv(dev, x, wt, b)
+        for _ in range(3):
+            assert np.array_equal(_conv(dev, x, wt, b), a)
+    finally:
+        lib.mpn_debug_set_conv_mode(0)
+    c = _conv(dev, x, wt, b)  # block per tile (+ split-K)
+    ref = O.conv3x3(x, wt, b, relu=True)
+    assert np.abs(a - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    assert np.abs(a - c).max() < 1e-4 * max(1.0, np.abs(ref).max())

@@ -6,6 +6,7 @@ lib = multipathnet_amd.load()
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 split = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 lib.mpn_debug_set_conv_variant(variant); lib.mpn_debug_set_conv_split(split)
+lib.mpn_debug_set_conv_mode(int(sys.argv[3]) if len(sys.argv) > 3 else 0)
 cfg = [64, 64, "P", 128, 128, "P", 256, 256, 256, "P", 512, 512, 512, "P", 512, 512, 512]
 h, w, cin = 600, 1000, 3
 layers = []
