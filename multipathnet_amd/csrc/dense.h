@@ -30,7 +30,7 @@ struct Act {      // C8P activation view
 
 // physical dims for a logical HxW map: 1 halo row/col in front, >= 1 behind, rounded so that whole
 // conv tiles (8 rows x 32 cols + halo) can be read without leaving the allocation.
-inline int act_hp(int H) { return ((H + 7) / 8) * 8 + 2; }
+inline int act_hp(int H) { return ((H + 15) / 16) * 16 + 2; }
 inline int act_wp(int W) { return ((W + 31) / 32) * 32 + 2; }
 inline Act make_act(float *p, int C, int H, int W) { return Act{p, C, H, W, act_hp(H), act_wp(W)}; }
 inline size_t act_bytes(int C, int H, int W) { return (size_t)((C + 7) / 8) * act_hp(H) * act_wp(W) * 8 * sizeof(float); }

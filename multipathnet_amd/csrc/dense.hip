@@ -198,6 +198,15 @@ __global__ __launch_bounds__(256) void conv3x3_c8p_kernel(ConvArgs a) {
     return;
   }
   // ---- epilogue: bias + ReLU, C8P float4 stores, optional fused ceil-mode 2x2 max-pool
+  if (a.ablate & 8) {  // timing experiment: skip the output stores (the never-true store keeps the accumulators live)
+    if (a.H < 0) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) *reinterpret_cast<f32x16 *>(a.part + (size_t)(mi * NI + ni) * 16 + lane * 64) = acc[mi][ni];
+    }
+    return;
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -220,17 +229,20 @@ __global__ __launch_bounds__(256) void conv3x3_c8p_kernel(ConvArgs a) {
           *reinterpret_cast<f32x4 *>(a.out + (size_t)cb * a.out_plane + ((size_t)(y + 1) * a.out_Wp + x + 1) * 8 + half * 4) = v[ni];
         if (!ok) v[ni] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
       }
-      if constexpr (NI == 2) {
-        if (a.pool) {  // rows (y0+rbase, y0+rbase+1) are a vertical pooling pair; lanes (2j,2j+1) a horizontal one
-          f32x4 m;
+      if constexpr (NI % 2 == 0) {
+        if (a.pool) {  // rows (y0+rbase+2q, +1) are a vertical pooling pair; lanes (2j,2j+1) a horizontal one
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float t = fmaxf(v[0][e], v[1][e]);
-            m[e] = fmaxf(t, __shfl_xor(t, 1));
+          for (int q = 0; q < NI / 2; ++q) {
+            f32x4 m;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float t = fmaxf(v[2 * q][e], v[2 * q + 1][e]);
+              m[e] = fmaxf(t, __shfl_xor(t, 1));
+            }
+            const int py = ((y0 + rbase) >> 1) + q, px = x >> 1;
+            if (!(l31 & 1) && py < a.pool_H && px < a.pool_W)
+              *reinterpret_cast<f32x4 *>(a.pool + (size_t)cb * a.pool_plane + ((size_t)(py + 1) * a.pool_Wp + px + 1) * 8 + half * 4) = m;
           }
-          const int py = (y0 + rbase) >> 1, px = x >> 1;
-          if (!(l31 & 1) && py < a.pool_H && px < a.pool_W)
-            *reinterpret_cast<f32x4 *>(a.pool + (size_t)cb * a.pool_plane + ((size_t)(py + 1) * a.pool_Wp + px + 1) * 8 + half * 4) = m;
         }
       }
     }
@@ -612,7 +624,8 @@ static int conv_pick_splits(int blocks, int nchunks, int slots) {
   return best;
 }
 
-static int g_conv_variant = 0;  // 0 = auto; test/bench hook: 1 = 128x4 tile / 9 taps per stage, 2 = 64x8 / 9, 3 = 128x4 / 3, 4 = 64x8 / 3
+static int g_conv_variant = 0;  // 0 = auto; test/bench hook: 1 = 128x4 tile / 9 taps per stage, 2 = 64x8 / 9, 3 = 128x4 / 3, 4 = 64x8 / 3,
+                                 // 5 = 128 couts x 8 rows (64x128 per wave, 8 accumulators), 6 = 64 couts x 16 rows
 
 int conv3x3_variant_for(int Cout) {
   int variant = g_conv_variant & 15;
@@ -636,8 +649,9 @@ int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int re
   if (out.p) MPN_CHECK_ARG(out.H == in.H && out.W == in.W && out.C == Cout);
   if (pooled.p) MPN_CHECK_ARG(pooled.H == (in.H + 1) / 2 && pooled.W == (in.W + 1) / 2 && pooled.C == Cout);
   const int variant = conv3x3_variant_for(Cout);
-  const bool wide = (variant == 1 || variant == 3);  // 128 couts x 4 rows; else 64 couts x 8 rows
-  const int tiles_y = cdiv(in.H, wide ? 4 : 8);
+  const bool wide = (variant == 1 || variant == 3 || variant == 5);  // 128-cout tiles; else 64-cout tiles
+  const int th = variant == 5 ? 8 : (variant == 6 ? 16 : (wide ? 4 : 8));
+  const int tiles_y = cdiv(in.H, th);
   a.n_ct = cdiv(Cout, wide ? 128 : 64);
   const int blocks = a.n_ct * tiles_y * a.tiles_x;
   if (g_conv_mode == 1 && (variant == 1 || variant == 2) && g_conv_split == 0) {
@@ -669,7 +683,7 @@ int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int re
     pa.c = a;
     return wide ? launch_conv_persistent<128, 4, 2, 2>(pa, s) : launch_conv_persistent<64, 8, 1, 4>(pa, s);
   }
-  const int slots = variant == 1 ? 256 : (variant == 2 ? 512 : 768);  // co-resident blocks on 256 CUs (LDS / VGPR bound)
+  const int slots = (variant == 1 || variant >= 5) ? 256 : (variant == 2 ? 512 : 768);  // co-resident blocks on 256 CUs (LDS / VGPR bound)
   a.splits = conv_pick_splits(blocks, a.nchunks, slots);
   a.chunks_per_split = cdiv(a.nchunks, a.splits);
   a.splits = cdiv(a.nchunks, a.chunks_per_split);
@@ -692,6 +706,8 @@ int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int re
     case 1: rc = launch_conv<128, 4, 2, 2, 9>(a, tiles_y, s); break;
     case 2: rc = launch_conv<64, 8, 1, 4, 9>(a, tiles_y, s); break;
     case 3: rc = launch_conv<128, 4, 2, 2, 3>(a, tiles_y, s); break;
+    case 5: rc = launch_conv<128, 8, 2, 2, 9>(a, tiles_y, s); break;
+    case 6: rc = launch_conv<64, 16, 1, 4, 9>(a, tiles_y, s); break;
     default: rc = launch_conv<64, 8, 1, 4, 3>(a, tiles_y, s); break;
   }
   if (rc != MPN_OK || a.splits == 1) return rc;

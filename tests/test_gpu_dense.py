@@ -22,7 +22,7 @@ def _conv(dev, x, w, b, relu=True):
 
 @pytest.mark.parametrize("ci,co,h,w", [(3, 64, 40, 70), (8, 64, 33, 31), (64, 64, 19, 45), (64, 128, 16, 96), (128, 256, 9, 33),
                                        (24, 40, 8, 8), (16, 200, 5, 37), (256, 512, 12, 20)])
-@pytest.mark.parametrize("variant,split,mode", [(0, 0, 1), (1, 0, 1), (2, 0, 1), (0, 0, 0), (1, 0, 0), (2, 0, 0), (3, 0, 0), (4, 0, 0),
+@pytest.mark.parametrize("variant,split,mode", [(0, 0, 1), (1, 0, 1), (2, 0, 1), (0, 0, 0), (1, 0, 0), (2, 0, 0), (3, 0, 0), (4, 0, 0), (5, 0, 0), (6, 0, 0), (5, 2, 0), (6, 3, 0),
                                                 (1, 2, 0), (2, 3, 0), (3, 2, 0), (4, 3, 0), (0, 4, 0)])
 def test_conv3x3_vs_oracle(O, dev, ci, co, h, w, variant, split, mode):
     """mode 0 = one block per tile (+ split-K; default), 1 = persistent stream-K kernel"""

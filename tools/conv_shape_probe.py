@@ -3,6 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import multipathnet_amd
 lib = multipathnet_amd.load()
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+lib.mpn_debug_set_gemm_ablate(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 lib.mpn_debug_set_conv_mode(mode)
 if mode == 0: lib.mpn_debug_set_conv_split(1)
 for (ci, co, h, w, note) in [(128, 128, 300, 500, "VGG conv2_2: 1200 blocks, padded cols"), (128, 128, 256, 512, "exact tiles, 1024 blocks = 4.0 rounds"),
