@@ -223,7 +223,10 @@ int mpn_mpnet_create(const mpn_frcnn_config *cfg, const float *const *d_conv_w, 
 
 /* ImageDetect:detect on a scale-1 image (getImages' resample is the identity):
  * d_image [3,H,W] fp32 in [0,1]; d_boxes [N,4].  Outputs (all optional, device):
- *   d_scores [N,C] softmax, d_bbox [N,4C] decoded + clamped boxes. */
+ *   d_scores [N,C] softmax, d_bbox [N,4C] decoded + clamped boxes.
+ * d_image == NULL means recompute_features = false (ImageDetect.lua:107-111): the trunk output of the previous
+ * call on this handle is reused and only the ROI head runs on the new boxes (iterative localisation,
+ * Tester_FRCNN.lua:82-89); H, W must equal the cached image's size. */
 int mpn_frcnn_detect(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N, float *d_scores,
                      float *d_bbox, void *stream);
 

@@ -454,17 +454,22 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
   return MPN_OK;
 }
 
+// d_image == nullptr: recompute_features = false (ImageDetect.lua:107-111) — reuse the trunk output of the last
+// call on this handle (iterative localisation, Tester_FRCNN.lua:82-89) and run only the ROI head on new boxes.
 static int run_detect(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N, hipStream_t s) {
   const mpn_frcnn_config &c = p->cfg;
-  MPN_CHECK_ARG(p && d_image && d_boxes);
+  MPN_CHECK_ARG(p && d_boxes);
   MPN_CHECK_ARG(H > 0 && W > 0 && H <= c.max_h && W <= c.max_w && N > 0 && N <= c.max_rois);
   // ImageDetect.lua:34-43 — only the scale==1 path exists on the device (no bilinear resample);
   // the host layer resizes other images before calling.
-  if (mpn_pick_scale(H, W, 600.0, 1000.0) != 1.0 && !(H == c.max_h && W == c.max_w)) {
-    // non-canonical sizes are still processed at scale 1; the caller owns the resample.
-  }
   Act feat;
-  int rc = run_trunk(p, d_image, H, W, s, &feat);
+  int rc = MPN_OK;
+  if (d_image) {
+    rc = run_trunk(p, d_image, H, W, s, &feat);
+  } else {
+    if (p->last_h != H || p->last_w != W || !p->tap_act[0].p) { set_error("run_detect: no cached features for a %dx%d image", H, W); return MPN_ESTATE; }
+    feat = p->tap_act[0];
+  }
   if (rc) return rc;
   rc = mpn_project_im_rois(d_boxes, N, 1.0, p->rois, s);
   if (rc) return rc;
@@ -498,6 +503,7 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H, int W, const fl
 extern "C" int mpn_frcnn_detect(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N,
                                 float *d_scores, float *d_bbox, void *stream) {
   MPN_CHECK_ARG(p != nullptr);
+  if (d_image == nullptr) { int rcf = mpn_frcnn_flush(p, stream); if (rcf) return rcf; }
   hipStream_t s = as_stream(stream);
   int rc = run_detect(p, d_image, H, W, d_boxes, N, s);
   if (rc) return rc;

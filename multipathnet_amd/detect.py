@@ -37,7 +37,7 @@ class ImageDetect(object):
         im = im.to(self.model.device, torch.float32)
         boxes = boxes.to(self.model.device, torch.float32).contiguous()
         im_s, boxes_s, s = self._prepare(im, boxes)
-        scores, bbox = self.model.detect(im_s, boxes_s)
+        scores, bbox = self.model.detect(im_s, boxes_s, recompute_features=recompute_features)
         if s != 1.0:
             bbox = (bbox - 1) / s + 1
         return scores, bbox
@@ -66,7 +66,7 @@ class Tester_FRCNN(object):
         all_output, all_bbox = [output], [bbox_pred]
         for _ in range(2, self.num_iter + 1):  # Tester_FRCNN.lua:82-89 iterative localisation
             new_boxes = self.boxselect.forward([output, bbox_pred])
-            output, bbox_pred = self.detec.detect(im, new_boxes)
+            output, bbox_pred = self.detec.detect(im, new_boxes, None, False)  # recompute_features = false (:87)
             all_output.append(output)
             all_bbox.append(bbox_pred)
         output = utils.joinTable(all_output, 0)

@@ -192,13 +192,15 @@ class FastRCNN(object):
         except Exception:
             pass
 
-    def detect(self, image, boxes):
-        """image [3,H,W] fp32 in [0,1] (device), boxes [N,4] (device) -> (scores [N,C], boxes [N,4C] decoded+clamped)."""
+    def detect(self, image, boxes, recompute_features=True):
+        """image [3,H,W] fp32 in [0,1] (device), boxes [N,4] (device) -> (scores [N,C], boxes [N,4C] decoded+clamped).
+        recompute_features=False (ImageDetect.lua:107-111) reuses the cached trunk output of the previous call."""
         H, W = image.shape[1:]
         N = boxes.size(0)
         scores = torch.empty((N, self.n_classes), dtype=torch.float32, device=self.device)
         bbox = torch.empty((N, 4 * self.n_classes), dtype=torch.float32, device=self.device)
-        check(self._lib.mpn_frcnn_detect(self._h, _f(image, "image"), H, W, _f(boxes, "boxes"), N, _f(scores), _f(bbox), _stream()),
+        img_ptr = _f(image, "image") if recompute_features else None
+        check(self._lib.mpn_frcnn_detect(self._h, img_ptr, H, W, _f(boxes, "boxes"), N, _f(scores), _f(bbox), _stream()),
               "mpn_frcnn_detect")
         return scores, bbox
 

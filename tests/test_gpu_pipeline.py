@@ -116,6 +116,11 @@ def test_host_mirror_tester(O, dev, small):
     t2 = detect.Tester_FRCNN(net, scale=[SMALL["H"]], max_size=SMALL["W"], opt={"test_num_iterative_loc": 2})
     _, (out2, bb2) = t2.testOne(im, boxes)
     assert out2.shape[0] == 2 * boxes.shape[0] and torch.equal(out2[: boxes.shape[0]], output)
+    # the second pass ran on cached trunk features (recompute_features=false, ImageDetect.lua:107-111) and must equal
+    # a full forward on the refined boxes
+    new_boxes = t2.boxselect.forward([output, bbox_pred])
+    full, _ = net.detect(im.to(dev), new_boxes, recompute_features=True)
+    assert torch.equal(out2[boxes.shape[0]:], full)
 
 
 def test_detect_is_deterministic_and_roi_order_equivariant(dev, small):
@@ -218,3 +223,35 @@ def test_multipathnet_head_vs_oracle(O, dev):
     dets, n = net.test_one_async(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
     torch.cuda.synchronize()
     assert 0 < int(n.item()) <= dets.shape[0]
+
+
+def test_alexnet_shaped_head_vs_oracle(O, dev):
+    """BASELINE configs[0] head shape (models/alexnet.lua:23-27): ROIPooling(6,6,1/16) on a 256-channel map, fc6 9216->4096,
+    300 selective-search-like ROIs, 21 classes, through the module-level C ABI, then clamp/select/NMS/top-k vs the oracle.
+    (The AlexNet trunk itself — 11x11/4 and 5x5 grouped convs, LRN — is outside the 3x3 trunk this round builds.)"""
+    from multipathnet_amd import nn, utils
+    rng = np.random.default_rng(300)
+    feat = np.maximum(rng.standard_normal((1, 256, 37, 62)), 0).astype(np.float32)
+    boxes = _boxes(rng, 300, 1000, 600, lo=16, hi=500)
+    rois = O.project_im_rois(boxes, 1.0)
+    w6 = (rng.standard_normal((4096, 9216)) * (2.0 / 9216) ** 0.5).astype(np.float32); b6 = (rng.standard_normal(4096) * 0.01).astype(np.float32)
+    w7 = (rng.standard_normal((4096, 4096)) * (2.0 / 4096) ** 0.5).astype(np.float32); b7 = (rng.standard_normal(4096) * 0.01).astype(np.float32)
+    wc = (rng.standard_normal((21, 4096)) * 0.01).astype(np.float32); wb = (rng.standard_normal((84, 4096)) * 0.001).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    pool = nn.ROIPooling(6, 6, 1 / 16)
+    x = pool.forward([t(feat), t(rois)]).reshape(300, -1)
+    def lin(x, w, b, relu):
+        m = nn.Linear(w.shape[1], w.shape[0], relu=relu); m.weight = t(w); m.bias = t(b) if b is not None else None
+        return m.forward(x)
+    h7 = lin(lin(x, w6, b6, True), w7, b7, True)
+    scores = nn.SoftMax().forward(lin(h7, wc, None, False))
+    deltas = nn.BBoxNorm([0, 0, 0, 0], [0.1, 0.1, 0.2, 0.2]).evaluate().forward(lin(h7, wb, None, False))
+    dec = utils.decode_all_classes(t(boxes), deltas)
+    # oracle
+    px, _ = O.roi_pool(feat, rois, 6, 6, 1 / 16)
+    r7 = O.linear(O.linear(px.reshape(300, -1), w6, b6, True), w7, b7, True)
+    rs = O.softmax(O.linear(r7, wc, None))
+    rd = O.bbox_decode(boxes, O.bbox_norm(O.linear(r7, wb, None), [0, 0, 0, 0], [0.1, 0.1, 0.2, 0.2]))
+    assert np.array_equal(x.cpu().numpy(), px.reshape(300, -1))
+    assert np.abs(scores.cpu().numpy() - rs).max() < 1e-4
+    assert np.abs(dec.cpu().numpy() - rd).max() < 1e-4 * 1000
