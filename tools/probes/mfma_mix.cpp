@@ -23,7 +23,14 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ src, float* o
   const float* g = src + (size_t)blockIdx.x * 8192;
   for (int it = 0; it < iters; ++it) {
     const int s = it & 1;
-    if (MODE & 2) {
+    f32x4 stg[8];
+    if (MODE & 128) {  // register staging: plain 16-byte loads now, ds_write after the MFMAs
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        stg[i] = *(const f32x4*)((MODE & 16) ? (src + ((size_t)blockIdx.x * 1048576 + (size_t)(it & 127) * 8192 + ((i * 4 + wave) * 256 + lane * 4)))
+                                             : (g + ((size_t)(it & 63) * 8192 + ((i * 4 + wave) * 256 + lane * 4)) % (1 << 22)));
+    } else
+    if ((MODE & 2) && (!(MODE & 32) || (it & 1)) && (!(MODE & 64) || (it & 3) == 0)) {  // 32: half the DMA volume, 64: a quarter
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         __builtin_amdgcn_global_load_lds(GP((MODE & 16) ? (src + ((size_t)blockIdx.x * 1048576 + (size_t)(it & 127) * 8192 + ((i * 4 + wave) * 256 + lane * 4)))
@@ -45,6 +52,10 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ src, float* o
         acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][j], bf[1][j], acc[3], 0, 0, 0);
       }
     }
+    if (MODE & 128) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *(f32x4*)(lds + (s ^ 1) * 8192 + (i * 4 + wave) * 256 + lane * 4) = stg[i];
+    }
     if (MODE & 4) __syncthreads();
   }
   float sum = 0; for (int q = 0; q < 4; ++q) for (int r = 0; r < 16; ++r) sum += acc[q][r];
@@ -60,7 +71,7 @@ template <int MODE> void run(const float* src, float* out) {
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     double fl = 256.0 * 4 * iters * 64 * 2.0 * 32 * 32 * 2;
-    if (rep) printf("mode ldsread=%d dma=%d barrier=%d conflict=%d hbm=%d : %.2f ms  %.1f TFLOP/s\n", MODE & 1, (MODE >> 1) & 1, (MODE >> 2) & 1, (MODE >> 3) & 1, (MODE >> 4) & 1, ms, fl / ms / 1e9);
+    if (rep) printf("mode(%d) ldsread=%d dma=%d barrier=%d conflict=%d hbm=%d : %.2f ms  %.1f TFLOP/s\n", MODE, MODE & 1, (MODE >> 1) & 1, (MODE >> 2) & 1, (MODE >> 3) & 1, (MODE >> 4) & 1, ms, fl / ms / 1e9);
   }
 }
 int main() {
@@ -68,5 +79,5 @@ int main() {
   hipMalloc(&src, n * 4 + (256 * 8192 * 4)); hipMalloc(&out, 256 * 1024 * 4);
   std::vector<float> h(n + 256 * 8192); for (auto& v : h) v = rand() / (float)RAND_MAX * 2.f - 1.f;
   hipMemcpy(src, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-  run<0>(src, out); run<0>(src, out); run<1>(src, out); run<9>(src, out); run<7>(src, out); run<15>(src, out); run<23>(src, out); run<31>(src, out);
+  run<0>(src, out); run<0>(src, out); run<1>(src, out); run<9>(src, out); run<7>(src, out); run<15>(src, out); run<23>(src, out); run<31>(src, out); run<7 + 32>(src, out); run<7 + 64>(src, out); run<23 + 32>(src, out); run<23 + 64>(src, out); run<5 + 128>(src, out); run<21 + 128>(src, out);
 }
