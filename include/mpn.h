@@ -163,6 +163,21 @@ int mpn_keep_top_k(const float *d_keep, const int *d_n_keep, int n_cls, int m_st
                    float *d_out, int max_out, int *d_n_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Wire formats either side of the path
+ * ---------------------------------------------------------------------------------------------- */
+
+/* testCoco/init.lua:65-85: {x1,y1,x2,y2,score,class} rows (mpn_keep_top_k output) -> COCO result rows
+ * {image_id, x1-1, y1-1, x2-x1, y2-y1, score, category_id}; d_cat_ids [n_cat] maps class (1-based) to the
+ * dataset's category id (NULL: the class index itself).  d_n_dets (device int, may be NULL) bounds max_n. */
+int mpn_dets_to_coco_rows(const float *d_dets, const int *d_n_dets, int max_n, float image_id, const float *d_cat_ids,
+                          int n_cat, float *d_rows, void *stream);
+
+/* DataSetJSON.lua:157-239 (loadROIDB): proposal rows come as {y1,x1,y2,x2}; emits the {2,1,4,3}-permuted
+ * {x1,y1,x2,y2} rows and, in d_keep (may be NULL), 1 for rows whose area (x2-x1)*(y2-y1) > min_area
+ * (min_area == 0 keeps everything — filterArea, DataSetJSON.lua:172-186). */
+int mpn_proposals_permute_filter(const float *d_in, int n, float min_area, float *d_out, int *d_keep, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused per-image pipeline: Tester_FRCNN:testOne -> ImageDetect:detect -> model:forward -> NMS
  * (Tester_FRCNN.lua:54-139, ImageDetect.lua:156-193, models/vgg.lua:23-31)
  * ---------------------------------------------------------------------------------------------- */

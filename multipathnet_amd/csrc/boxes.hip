@@ -289,9 +289,61 @@ __global__ __launch_bounds__(1024) void keep_top_k_kernel(const float *__restric
   if (tid == 0) *n_out = min(base_s, max_out);
 }
 
+// testCoco/init.lua:65-85 — detection wire rows for COCO evaluation: {image_id, x1-1, y1-1, x2-x1, y2-y1, score, category_id}
+// from {x1,y1,x2,y2,score,class(1-based)} rows (mpn_keep_top_k's output); cat_ids maps class -> dataset category id.
+__global__ void dets_to_coco_kernel(const float *__restrict__ dets, const int *__restrict__ n_dets, int max_n, float image_id,
+                                    const float *__restrict__ cat_ids, int n_cat, float *__restrict__ rows) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int n = n_dets ? min(*n_dets, max_n) : max_n;
+  if (i >= n) return;
+  const float *d = dets + 6 * (size_t)i;
+  float *o = rows + 7 * (size_t)i;
+  int cls = (int)d[5];
+  o[0] = image_id;
+  o[1] = d[0] - 1.0f;
+  o[2] = d[1] - 1.0f;
+  o[3] = d[2] - d[0];
+  o[4] = d[3] - d[1];
+  o[5] = d[4];
+  o[6] = (cat_ids && cls >= 1 && cls <= n_cat) ? cat_ids[cls - 1] : (float)cls;
+}
+
+// DataSetJSON.lua:157-239 — proposal table rows are {y1,x1,y2,x2}; loadROIDB filters by area (w*h > min_area, no +1) and
+// emits {x1,y1,x2,y2} (the {2,1,4,3} column permute).  keep[i] = 1 when the row survives the area filter.
+__global__ void proposals_permute_filter_kernel(const float *__restrict__ in, int n, float min_area, float *__restrict__ out,
+                                                int *__restrict__ keep) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a = in[4 * i], b = in[4 * i + 1], c = in[4 * i + 2], d = in[4 * i + 3];
+  const float w0 = c - a, w1 = d - b;
+  const float s = w0 * w1;
+  out[4 * i] = b; out[4 * i + 1] = a; out[4 * i + 2] = d; out[4 * i + 3] = c;
+  if (keep) keep[i] = (min_area == 0.0f || s > min_area) ? 1 : 0;
+}
+
 }  // namespace mpn
 
 using namespace mpn;
+
+extern "C" int mpn_dets_to_coco_rows(const float *d_dets, const int *d_n_dets, int max_n, float image_id, const float *d_cat_ids,
+                                     int n_cat, float *d_rows, void *stream) {
+  MPN_CHECK_ARG(max_n >= 0);
+  if (max_n == 0) return MPN_OK;
+  MPN_CHECK_ARG(d_dets && d_rows);
+  hipLaunchKernelGGL(dets_to_coco_kernel, dim3(cdiv(max_n, 256)), dim3(256), 0, as_stream(stream), d_dets, d_n_dets, max_n, image_id,
+                     d_cat_ids, n_cat, d_rows);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+extern "C" int mpn_proposals_permute_filter(const float *d_in, int n, float min_area, float *d_out, int *d_keep, void *stream) {
+  MPN_CHECK_ARG(n >= 0);
+  if (n == 0) return MPN_OK;
+  MPN_CHECK_ARG(d_in && d_out);
+  hipLaunchKernelGGL(proposals_permute_filter_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), d_in, n, min_area, d_out, d_keep);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
 
 extern "C" int mpn_image_transform(const float *d_in, int H, int W, const int *h_swap, double scale,
                                    const double *h_mean, const double *h_std, float *d_out, void *stream) {
