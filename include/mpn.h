@@ -71,6 +71,10 @@ int mpn_nms_host(const float *h_scored, int m, float thr, float *h_keep, int *h_
  * d_scored [m,5], d_res [n_nms,5].  d_n_nms (device int, may be NULL) overrides n_nms at run time. */
 int mpn_bbox_vote(const float *d_nms, int n_nms, const int *d_n_nms, const float *d_scored, int m, float thr,
                   float *d_res, void *stream);
+/* The per-class voting loop of Tester_FRCNN.lua:118-124 in one launch: class c votes d_keep[c] (n_keep[c] rows) against
+ * d_scored[c] (counts[c] rows) with weights score^score_pow (opt.test_bbox_voting_score_pow; 1 = nms.c arithmetic exactly). */
+int mpn_bbox_vote_batched(const float *d_keep, const int *d_n_keep, const float *d_scored, const int *d_counts, int n_cls,
+                          int m_stride, float thr, float score_pow, float *d_res, void *stream);
 int mpn_bbox_vote_host(const float *h_nms, int n_nms, const float *h_scored, int m, float thr, float *h_res);
 
 /* nms.c:43-56 `boxoverlap`: IoU of n boxes [n,4] against one box (h_b[4], host). */
@@ -201,6 +205,12 @@ typedef struct mpn_frcnn_config {
   float nms_thresh;        /* 0.3 */
   float score_thresh;      /* -1.5 (Tester_FRCNN.lua:50) */
   int top_k;               /* 100 (Tester_FRCNN.lua:163) */
+  /* accuracy knobs of Tester_FRCNN (all off in the reference's default config): */
+  int num_iter;            /* opt.test_num_iterative_loc (1 = off; 2 = one SelectBoxes + head-only pass on cached features) */
+  int bbox_voting;         /* opt.test_bbox_voting */
+  float bbox_vote_thresh;  /* opt.test_bbox_voting_nms_threshold (0.5).  The reference passes an unset field here
+                              (Tester_FRCNN.lua:123 vs :29); we use the configured threshold. */
+  float bbox_vote_score_pow; /* opt.test_bbox_voting_score_pow (1) */
 } mpn_frcnn_config;
 
 typedef struct mpn_frcnn mpn_frcnn; /* opaque */

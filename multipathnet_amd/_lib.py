@@ -27,6 +27,7 @@ class FrcnnConfig(C.Structure):
         ("tf_scale", C.c_double), ("tf_mean", C.c_double * 3), ("tf_std", C.c_double * 3), ("tf_swap", C.c_int * 3),
         ("bbox_mean", C.c_float * 4), ("bbox_std", C.c_float * 4), ("nms_thresh", C.c_float),
         ("score_thresh", C.c_float), ("top_k", C.c_int),
+        ("num_iter", C.c_int), ("bbox_voting", C.c_int), ("bbox_vote_thresh", C.c_float), ("bbox_vote_score_pow", C.c_float),
     ]
 
 

@@ -524,6 +524,46 @@ __global__ __launch_bounds__(64) void bbox_vote_kernel(const float *__restrict__
   }
 }
 
+// bbox_vote for every class of an image at once (Tester_FRCNN.lua:118-124): class c votes its kept boxes against its
+// own scored boxes; the voting weights are score^pow (opt.test_bbox_voting_score_pow), pow == 1 skips powf so the
+// arithmetic stays bit-identical to nms.c.  Same one-lane-per-kept-box sequential accumulation as bbox_vote_kernel.
+__global__ __launch_bounds__(64) void bbox_vote_batched_kernel(const float *__restrict__ keep, const int *__restrict__ n_keep,
+                                                               const float *__restrict__ scored, const int *__restrict__ counts,
+                                                               int m_stride, float thr, float score_pow, float *__restrict__ res) {
+  constexpr int TILE = 256;
+  __shared__ float t[TILE * 5];
+  const int cls = blockIdx.y;
+  const int nk = min(n_keep[cls], m_stride), m = min(counts ? counts[cls] : m_stride, m_stride);
+  if (blockIdx.x * kWave >= nk) return;
+  const float *kb = keep + (size_t)cls * m_stride * 5;
+  const float *sb = scored + (size_t)cls * m_stride * 5;
+  float *rb = res + (size_t)cls * m_stride * 5;
+  const int i = blockIdx.x * kWave + threadIdx.x;
+  const bool act = i < nk;
+  float nx1 = 0, ny1 = 0, nx2 = 0, ny2 = 0, ns = 0;
+  if (act) { nx1 = kb[5 * i]; ny1 = kb[5 * i + 1]; nx2 = kb[5 * i + 2]; ny2 = kb[5 * i + 3]; ns = kb[5 * i + 4]; }
+  float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+  for (int j0 = 0; j0 < m; j0 += TILE) {
+    const int cnt = min(TILE, m - j0);
+    __syncthreads();
+    for (int q = threadIdx.x; q < cnt * 5; q += kWave) t[q] = sb[(size_t)j0 * 5 + q];
+    __syncthreads();
+    if (act) {
+      for (int j = 0; j < cnt; ++j) {
+        const float sx1 = t[5 * j], sy1 = t[5 * j + 1], sx2 = t[5 * j + 2], sy2 = t[5 * j + 3];
+        float ss = t[5 * j + 4];
+        if (score_pow != 1.0f) ss = powf(ss, score_pow);
+        const float ov = iou_plus1(sx1, sy1, sx2, sy2, nx1, ny1, nx2, ny2);
+        if (ov > thr) { a0 += sx1 * ss; a1 += sy1 * ss; a2 += sx2 * ss; a3 += sy2 * ss; a4 += ss; }
+      }
+    }
+  }
+  if (act) {
+    rb[5 * i] = a0 / a4; rb[5 * i + 1] = a1 / a4; rb[5 * i + 2] = a2 / a4; rb[5 * i + 3] = a3 / a4;
+    rb[5 * i + 4] = ns;
+  }
+}
+
 __global__ void boxoverlap_kernel(const float *__restrict__ a, int n, float bx1, float by1, float bx2, float by2,
                                   float *__restrict__ out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -669,6 +709,17 @@ extern "C" int mpn_bbox_vote(const float *d_nms, int n_nms, const int *d_n_nms, 
   MPN_CHECK_ARG(d_nms != nullptr && d_res != nullptr && (m == 0 || d_scored != nullptr));
   hipLaunchKernelGGL(bbox_vote_kernel, dim3(cdiv(n_nms, kWave)), dim3(kWave), 0, as_stream(stream), d_nms, n_nms,
                      d_n_nms, d_scored, m, thr, d_res);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+extern "C" int mpn_bbox_vote_batched(const float *d_keep, const int *d_n_keep, const float *d_scored, const int *d_counts, int n_cls,
+                                     int m_stride, float thr, float score_pow, float *d_res, void *stream) {
+  MPN_CHECK_ARG(n_cls >= 0 && m_stride >= 0);
+  if (n_cls == 0 || m_stride == 0) return MPN_OK;
+  MPN_CHECK_ARG(d_keep && d_n_keep && d_scored && d_res);
+  hipLaunchKernelGGL(bbox_vote_batched_kernel, dim3(cdiv(m_stride, kWave), n_cls), dim3(kWave), 0, as_stream(stream), d_keep, d_n_keep,
+                     d_scored, d_counts, m_stride, thr, score_pow, d_res);
   MPN_CHECK_LAUNCH();
   return MPN_OK;
 }

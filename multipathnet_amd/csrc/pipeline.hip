@@ -137,6 +137,8 @@ struct mpn_frcnn {
   float *scores = nullptr, *bbox = nullptr, *bbox_raw = nullptr;
   // NMS-stage buffers: two sets so that image i's NMS (side stream) overlaps image i+1's trunk
   float *scored_b[2] = {nullptr, nullptr}, *keep_b[2] = {nullptr, nullptr}, *thresh_b[2] = {nullptr, nullptr};
+  float *voted_b[2] = {nullptr, nullptr}, *voted = nullptr;      // bbox-voted tables (opt.test_bbox_voting)
+  float *it_scores = nullptr, *it_bbox = nullptr, *it_boxes = nullptr;  // iterative localisation: rows of both passes
   int *counts_b[2] = {nullptr, nullptr}, *keep_idx_b[2] = {nullptr, nullptr}, *n_keep_b[2] = {nullptr, nullptr};
   float *scored = nullptr, *keep = nullptr, *thresh = nullptr;   // set of the most recent call
   int *counts = nullptr, *keep_idx = nullptr, *n_keep = nullptr;
@@ -146,7 +148,7 @@ struct mpn_frcnn {
   unsigned long long seq = 0;
   float *dbg = nullptr;
   size_t dbg_bytes = 0;
-  int last_n = 0;
+  int last_n = 0, last_rows = 0;
   int fuse_pool = 1;
   // ---- MultiPathNet head (models/multipathnet.lua:64-120); empty for plain Fast R-CNN
   struct Tower { int region, use4, use3, total_feat; float *mix_w, *mix_b, *w6, *b6, *w7, *b7; };
@@ -332,10 +334,20 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
   TRY(dev_alloc(p, &p->scores, M * C * sizeof(float), true));
   TRY(dev_alloc(p, &p->bbox, M * 4 * C * sizeof(float), true));
   TRY(dev_alloc(p, &p->bbox_raw, M * 4 * C * sizeof(float), true));
+  const int n_it = cfg->num_iter > 1 ? cfg->num_iter : 1;
+  MPN_CHECK_ARG(n_it <= 2 && (size_t)n_it * M <= MPN_NMS_MAX_BOXES);
+  p->cfg.num_iter = n_it;
+  const size_t MR = M * n_it;  // rows that reach NMS per class
+  if (n_it > 1) {
+    TRY(dev_alloc(p, &p->it_scores, MR * C * sizeof(float), true));
+    TRY(dev_alloc(p, &p->it_bbox, MR * 4 * C * sizeof(float), true));
+    TRY(dev_alloc(p, &p->it_boxes, M * 4 * sizeof(float), true));
+  }
   for (int i = 0; i < 2; ++i) {
-    TRY(dev_alloc(p, &p->scored_b[i], (size_t)(C - 1) * M * 5 * sizeof(float), true));
-    TRY(dev_alloc(p, &p->keep_b[i], (size_t)(C - 1) * M * 5 * sizeof(float), true));
-    TRY(dev_alloc(p, &p->keep_idx_b[i], (size_t)(C - 1) * M * sizeof(int), true));
+    TRY(dev_alloc(p, &p->scored_b[i], (size_t)(C - 1) * MR * 5 * sizeof(float), true));
+    TRY(dev_alloc(p, &p->keep_b[i], (size_t)(C - 1) * MR * 5 * sizeof(float), true));
+    if (cfg->bbox_voting) TRY(dev_alloc(p, &p->voted_b[i], (size_t)(C - 1) * MR * 5 * sizeof(float), true));
+    TRY(dev_alloc(p, &p->keep_idx_b[i], (size_t)(C - 1) * MR * sizeof(int), true));
     TRY(dev_alloc(p, &p->counts_b[i], (size_t)(C - 1) * sizeof(int), true));
     TRY(dev_alloc(p, &p->n_keep_b[i], (size_t)(C - 1) * sizeof(int), true));
     TRY(dev_alloc(p, &p->thresh_b[i], 16, true));
@@ -516,6 +528,7 @@ extern "C" int mpn_frcnn_detect(mpn_frcnn *p, const float *d_image, int H, int W
 static void select_set(mpn_frcnn *p, int b) {
   p->scored = p->scored_b[b]; p->keep = p->keep_b[b]; p->keep_idx = p->keep_idx_b[b];
   p->counts = p->counts_b[b]; p->n_keep = p->n_keep_b[b]; p->thresh = p->thresh_b[b];
+  p->voted = p->voted_b[b];
 }
 
 // Tester_FRCNN.lua:106-125 + keep_top_k: per class j=1..C-1 select (score > thresh) -> NMS -> top-k, on stream `t`
@@ -524,8 +537,10 @@ static int run_tail(mpn_frcnn *p, int N, float *d_dets, int top_cap, int *d_n_de
   const mpn_frcnn_config &c = p->cfg;
   const int C = c.n_classes;
   int rc;
+  const float *sc = p->scores, *bb = p->bbox;
+  if (c.num_iter > 1) { sc = p->it_scores; bb = p->it_bbox; }  // rows of both localisation passes (utils.joinTable, Tester_FRCNN.lua:99-100)
   { ProfScope ps(p, MPN_PROF_SELECT, sel_stream);
-    rc = mpn_select_scored(p->scores, p->bbox, N, C, 1, c.score_thresh, p->scored, p->counts, nullptr, sel_stream); }
+    rc = mpn_select_scored(sc, bb, N, C, 1, c.score_thresh, p->scored, p->counts, nullptr, sel_stream); }
   if (rc) return rc;
   if (after_select) {  // hand over to the side stream
     MPN_CHECK_HIP(hipEventRecord(after_select, sel_stream));
@@ -534,8 +549,35 @@ static int run_tail(mpn_frcnn *p, int N, float *d_dets, int top_cap, int *d_n_de
   { ProfScope ps(p, MPN_PROF_NMS, t);
     rc = mpn_nms_batched(p->scored, p->counts, C - 1, N, c.nms_thresh, p->keep, p->keep_idx, p->n_keep, t); }
   if (rc) return rc;
+  const float *final_tables = p->keep;
+  if (c.bbox_voting) {  // Tester_FRCNN.lua:118-124
+    rc = mpn_bbox_vote_batched(p->keep, p->n_keep, p->scored, p->counts, C - 1, N, c.bbox_vote_thresh,
+                               c.bbox_vote_score_pow != 0.0f ? c.bbox_vote_score_pow : 1.0f, p->voted, t);
+    if (rc) return rc;
+    final_tables = p->voted;
+  }
   ProfScope ps(p, MPN_PROF_TOPK, t);
-  return mpn_keep_top_k(p->keep, p->n_keep, C - 1, N, c.top_k, p->thresh, d_dets, top_cap, d_n_dets, t);
+  return mpn_keep_top_k(final_tables, p->n_keep, C - 1, N, c.top_k, p->thresh, d_dets, top_cap, d_n_dets, t);
+}
+
+// Tester_FRCNN.lua:72-100: detect; for i = 2..num_iter: SelectBoxes -> detect on the refined boxes with
+// recompute_features = false; the rows of all passes are concatenated before the per-class NMS.
+static int run_detect_iter(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N, hipStream_t s, int *n_rows) {
+  int rc = run_detect(p, d_image, H, W, d_boxes, N, s);
+  *n_rows = N;
+  const mpn_frcnn_config &c = p->cfg;
+  if (rc || c.num_iter <= 1) return rc;
+  const int C = c.n_classes;
+  MPN_CHECK_HIP(hipMemcpyAsync(p->it_scores, p->scores, (size_t)N * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+  MPN_CHECK_HIP(hipMemcpyAsync(p->it_bbox, p->bbox, (size_t)N * 4 * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+  rc = mpn_select_boxes_forward(p->scores, p->bbox, N, C, p->it_boxes, s);
+  if (rc) return rc;
+  rc = run_detect(p, nullptr, H, W, p->it_boxes, N, s);
+  if (rc) return rc;
+  MPN_CHECK_HIP(hipMemcpyAsync(p->it_scores + (size_t)N * C, p->scores, (size_t)N * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+  MPN_CHECK_HIP(hipMemcpyAsync(p->it_bbox + (size_t)N * 4 * C, p->bbox, (size_t)N * 4 * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+  *n_rows = 2 * N;
+  return MPN_OK;
 }
 
 static int join_tail(mpn_frcnn *p, int b, hipStream_t s) {
@@ -560,10 +602,12 @@ extern "C" int mpn_frcnn_test_one(mpn_frcnn *p, const float *d_image, int H, int
   hipStream_t s = as_stream(stream);
   int rc = mpn_frcnn_flush(p, stream);  // a pipelined predecessor may still own a buffer set
   if (rc) return rc;
-  rc = run_detect(p, d_image, H, W, d_boxes, N, s);
+  int rows = N;
+  rc = run_detect_iter(p, d_image, H, W, d_boxes, N, s, &rows);
   if (rc) return rc;
   select_set(p, 0);
-  return run_tail(p, N, d_dets, top_cap, d_n_dets, s, s, nullptr);
+  p->last_rows = rows;
+  return run_tail(p, rows, d_dets, top_cap, d_n_dets, s, s, nullptr);
 }
 
 // Throughput form for a loop over images (Tester:test, Tester_FRCNN.lua:150-157): trunk + heads + select of
@@ -577,10 +621,12 @@ extern "C" int mpn_frcnn_test_one_pipelined(mpn_frcnn *p, const float *d_image, 
   const int b = (int)(p->seq & 1);
   int rc = join_tail(p, b, s);  // buffer set b was last used two calls ago
   if (rc) return rc;
-  rc = run_detect(p, d_image, H, W, d_boxes, N, s);
+  int rows = N;
+  rc = run_detect_iter(p, d_image, H, W, d_boxes, N, s, &rows);
   if (rc) return rc;
   select_set(p, b);
-  rc = run_tail(p, N, d_dets, top_cap, d_n_dets, s, p->side, p->ev_head[b]);
+  p->last_rows = rows;
+  rc = run_tail(p, rows, d_dets, top_cap, d_n_dets, s, p->side, p->ev_head[b]);
   if (rc) return rc;
   MPN_CHECK_HIP(hipEventRecord(p->ev_tail[b], p->side));
   p->tail_pending[b] = true;
@@ -630,10 +676,10 @@ extern "C" int mpn_frcnn_nms_results(mpn_frcnn *p, const float **d_keep, const i
                                      int *m_stride) {
   MPN_CHECK_ARG(p != nullptr);
   MPN_CHECK_HIP(hipDeviceSynchronize());
-  if (d_keep) *d_keep = p->keep;
+  if (d_keep) *d_keep = (p->cfg.bbox_voting && p->voted) ? p->voted : p->keep;  // what testOne returns as img_boxes[j]
   if (d_keep_idx) *d_keep_idx = p->keep_idx;
   if (d_n_keep) *d_n_keep = p->n_keep;
-  if (m_stride) *m_stride = p->last_n;
+  if (m_stride) *m_stride = p->last_rows ? p->last_rows : p->last_n;
   return MPN_OK;
 }
 

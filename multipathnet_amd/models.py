@@ -118,7 +118,8 @@ class FastRCNN(object):
     """Trunk + ROI head + post-processing as one device pipeline (models/vgg.lua:23-31 graph)."""
 
     def __init__(self, params, cfg=VGG16_CFG, pooled=7, spatial_scale=1.0 / 16, transformer=None, max_h=600, max_w=1000,
-                 max_rois=1000, nms_thresh=0.3, score_thresh=-1.5, top_k=100):
+                 max_rois=1000, nms_thresh=0.3, score_thresh=-1.5, top_k=100, num_iter=1, bbox_voting=False, bbox_vote_thresh=0.5,
+                 bbox_vote_score_pow=1.0):
         _lib.require_gpu()
         lib = _lib.load()
         cout, pool = cfg_layers(cfg)
@@ -149,6 +150,8 @@ class FastRCNN(object):
             c.bbox_mean[i] = bm[i] if bm is not None else 0.0
             c.bbox_std[i] = bs[i] if bs is not None else 0.0
         c.nms_thresh, c.score_thresh, c.top_k = nms_thresh, score_thresh, top_k
+        c.num_iter, c.bbox_voting, c.bbox_vote_thresh, c.bbox_vote_score_pow = num_iter, int(bbox_voting), bbox_vote_thresh, bbox_vote_score_pow
+        self.num_iter = num_iter
         self._cfg = c
         dev = torch.device("cuda", torch.cuda.current_device())
         d = lambda t: t.to(dev, torch.float32).contiguous()
@@ -231,7 +234,7 @@ class FastRCNN(object):
         ms = C.c_int()
         check(self._lib.mpn_frcnn_nms_results(self._h, C.byref(kp), C.byref(ip), C.byref(np_), C.byref(ms)), "nms_results")
         torch.cuda.synchronize()
-        ncls, M = self.n_classes - 1, ms.value
+        ncls, M = self.n_classes - 1, ms.value  # M = rows per class (N * num_iter)
         keep = torch.empty((ncls, M, 5), dtype=torch.float32, device=self.device)
         idx = torch.empty((ncls, M), dtype=torch.int32, device=self.device)
         n = torch.empty(ncls, dtype=torch.int32, device=self.device)

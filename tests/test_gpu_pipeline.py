@@ -255,3 +255,36 @@ def test_alexnet_shaped_head_vs_oracle(O, dev):
     assert np.array_equal(x.cpu().numpy(), px.reshape(300, -1))
     assert np.abs(scores.cpu().numpy() - rs).max() < 1e-4
     assert np.abs(dec.cpu().numpy() - rd).max() < 1e-4 * 1000
+
+
+def test_fused_iterative_loc_and_bbox_voting(O, dev, small):
+    """Tester_FRCNN.lua:82-99,118-124 fused on the device (num_iter = 2 on cached trunk features, per-class bbox voting)
+    == the host mirror driving the module-level entry points == the oracle's nms/bbox_vote on the device's rows."""
+    from multipathnet_amd import models, detect
+    s = SMALL
+    P = models.synthetic_params(s["cfg"], pooled=7, fc_dim=s["fc"], n_classes=s["C"], seed=557)
+    net2 = models.FastRCNN(P, cfg=s["cfg"], pooled=7, spatial_scale=s["scale"], max_h=s["H"], max_w=s["W"], max_rois=s["N"],
+                           num_iter=2, bbox_voting=True, bbox_vote_thresh=0.5)
+    im, boxes = torch.from_numpy(small["im"]).to(dev), torch.from_numpy(small["boxes"]).to(dev)
+    dets, n = net2.test_one_async(im, boxes)
+    torch.cuda.synchronize()
+    keep, idx, nk = [t.cpu().numpy() for t in net2.nms_results()]
+    assert keep.shape[1] == 2 * s["N"]
+    # host mirror on a plain pipeline with the same weights
+    tester = detect.Tester_FRCNN(small["net"], scale=[s["H"]], max_size=s["W"],
+                                 opt={"test_num_iterative_loc": 2, "test_bbox_voting": True, "test_bbox_voting_nms_threshold": 0.5})
+    img_boxes, (output, bbox_pred) = tester.testOne(im, boxes)
+    assert output.shape[0] == 2 * s["N"]
+    for j, kb in enumerate(img_boxes):
+        assert np.array_equal(keep[j, : nk[j]], kb.cpu().numpy()), j
+    # and against the oracle fed the device's rows
+    sc, bb = output.cpu().numpy(), bbox_pred.cpu().numpy()
+    per = []
+    for j in range(1, s["C"]):
+        sb, _ = O.select_scored(sc, bb, j, -1.5)
+        ref = O.bbox_vote(O.nms(sb, 0.3), sb, 0.5)
+        assert np.array_equal(keep[j - 1, : nk[j - 1]], ref, equal_nan=True)
+        per.append(ref)
+    kept, _ = O.keep_top_k(per, 100)
+    exp = np.concatenate([np.concatenate([k, np.full((k.shape[0], 1), j + 1, np.float32)], 1) for j, k in enumerate(kept) if k.size])
+    assert np.array_equal(dets[: int(n.item())].cpu().numpy(), exp)
