@@ -91,6 +91,13 @@ int mpn_boxoverlap(const float *d_a, int n, const float *h_b, float *d_out, void
 int mpn_image_transform(const float *d_in, int H, int W, const int *h_swap, double scale, const double *h_mean,
                         const double *h_std, float *d_out, void *stream);
 
+/* image.scale(src, W2, H2) in its default bilinear mode (external `image` rock; ImageDetect.lua:41).  PARITY
+ * UNPINNED: restated from torch/image's published separable algorithm — rows then columns through a float
+ * intermediate; upscaling interpolates with i+f = d*(src-1)/(dst-1) (last sample copied), downscaling is a
+ * fractional box average over [d*s,(d+1)*s), s = src/dst.  d_in [C,H,W] -> d_out [C,H2,W2]; d_tmp holds C*H*W2 floats.
+ * ImageDetect.lua:40 sizes the output as (long)(H*scale) x (long)(W*scale). */
+int mpn_image_scale(const float *d_in, int C, int H, int W, int H2, int W2, float *d_tmp, float *d_out, void *stream);
+
 /* ImageDetect.lua:34-43: scale factor for one image (host arithmetic). */
 double mpn_pick_scale(int H, int W, double target, double max_size);
 
@@ -211,6 +218,9 @@ typedef struct mpn_frcnn_config {
   float bbox_vote_thresh;  /* opt.test_bbox_voting_nms_threshold (0.5).  The reference passes an unset field here
                               (Tester_FRCNN.lua:123 vs :29); we use the configured threshold. */
   float bbox_vote_score_pow; /* opt.test_bbox_voting_score_pow (1) */
+  /* getImages (ImageDetect.lua:34-43): 0 = feed the image as it is; otherwise rescale so that the short side is
+   * scale_target (600), capped so that the long side stays <= scale_max (1000).  max_h / max_w bound the RESCALED image. */
+  double scale_target, scale_max;
 } mpn_frcnn_config;
 
 typedef struct mpn_frcnn mpn_frcnn; /* opaque */

@@ -289,6 +289,47 @@ __global__ __launch_bounds__(1024) void keep_top_k_kernel(const float *__restric
   if (tid == 0) *n_out = min(base_s, max_out);
 }
 
+// image.scale(src, W2, H2) 'bilinear' (external `image` rock, ImageDetect.lua:41; parity unpinned — see mpn.h):
+// one output sample of a 1-D resample; `sstride` walks the source line.
+__device__ __forceinline__ float scale_sample(const float *__restrict__ src, long sstride, long slen, long dlen, long d) {
+  if (dlen > slen) {
+    if (slen == 1) return src[0];
+    if (d == dlen - 1) return src[(slen - 1) * sstride];
+    const float scale = (float)(slen - 1) / (float)(dlen - 1);
+    float sf = (float)d * scale;
+    const long si = (long)sf;
+    sf -= (float)si;
+    return (1.0f - sf) * src[si * sstride] + sf * src[(si + 1) * sstride];
+  } else if (dlen < slen) {
+    const float scale = (float)slen / (float)dlen;
+    const float s0 = (float)d * scale, s1 = (float)(d + 1) * scale;
+    const long i0 = (long)s0, i1 = (long)s1;
+    const float f0 = s0 - (float)i0, f1 = s1 - (float)i1;
+    float acc = (1.0f - f0) * src[i0 * sstride], n = 1.0f - f0;
+    for (long i = i0 + 1; i < i1; ++i) { acc += src[i * sstride]; n += 1.0f; }
+    if (i1 < slen && i1 > i0) { acc += f1 * src[i1 * sstride]; n += f1; }
+    return acc / n;
+  }
+  return src[d * sstride];
+}
+// pass 0: rows  [C,H,W] -> tmp [C,H,W2];  pass 1: columns tmp -> out [C,H2,W2]
+__global__ void image_scale_kernel(const float *__restrict__ in, int C, int H, int W, int H2, int W2, int pass,
+                                   float *__restrict__ out) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pass == 0) {
+    size_t total = (size_t)C * H * W2;
+    if (t >= total) return;
+    long x = (long)(t % W2); size_t r = t / W2;  // r = c*H + y
+    out[t] = scale_sample(in + r * W, 1, W, W2, x);
+  } else {
+    size_t total = (size_t)C * H2 * W2;
+    if (t >= total) return;
+    long x = (long)(t % W2); size_t r = t / W2;
+    long y = (long)(r % H2); size_t c = r / H2;
+    out[t] = scale_sample(in + c * (size_t)H * W2 + x, W2, H, H2, y);
+  }
+}
+
 // testCoco/init.lua:65-85 — detection wire rows for COCO evaluation: {image_id, x1-1, y1-1, x2-x1, y2-y1, score, category_id}
 // from {x1,y1,x2,y2,score,class(1-based)} rows (mpn_keep_top_k's output); cat_ids maps class -> dataset category id.
 __global__ void dets_to_coco_kernel(const float *__restrict__ dets, const int *__restrict__ n_dets, int max_n, float image_id,
@@ -324,6 +365,16 @@ __global__ void proposals_permute_filter_kernel(const float *__restrict__ in, in
 }  // namespace mpn
 
 using namespace mpn;
+
+extern "C" int mpn_image_scale(const float *d_in, int C, int H, int W, int H2, int W2, float *d_tmp, float *d_out, void *stream) {
+  MPN_CHECK_ARG(d_in && d_tmp && d_out && C > 0 && H > 0 && W > 0 && H2 > 0 && W2 > 0);
+  size_t t0 = (size_t)C * H * W2, t1 = (size_t)C * H2 * W2;
+  hipLaunchKernelGGL(image_scale_kernel, dim3((unsigned)cdiv_sz(t0, 256)), dim3(256), 0, as_stream(stream), d_in, C, H, W, H2, W2, 0, d_tmp);
+  MPN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(image_scale_kernel, dim3((unsigned)cdiv_sz(t1, 256)), dim3(256), 0, as_stream(stream), d_tmp, C, H, W, H2, W2, 1, d_out);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
 
 extern "C" int mpn_dets_to_coco_rows(const float *d_dets, const int *d_n_dets, int max_n, float image_id, const float *d_cat_ids,
                                      int n_cat, float *d_rows, void *stream) {

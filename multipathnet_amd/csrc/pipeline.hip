@@ -139,6 +139,9 @@ struct mpn_frcnn {
   float *scored_b[2] = {nullptr, nullptr}, *keep_b[2] = {nullptr, nullptr}, *thresh_b[2] = {nullptr, nullptr};
   float *voted_b[2] = {nullptr, nullptr}, *voted = nullptr;      // bbox-voted tables (opt.test_bbox_voting)
   float *it_scores = nullptr, *it_bbox = nullptr, *it_boxes = nullptr;  // iterative localisation: rows of both passes
+  float *scaled = nullptr, *scale_tmp = nullptr;  // getImages' rescaled image (ImageDetect.lua:34-43), grown on demand
+  size_t scaled_bytes = 0, scale_tmp_bytes = 0;
+  int net_h = 0, net_w = 0;                       // size of the image the trunk last saw
   int *counts_b[2] = {nullptr, nullptr}, *keep_idx_b[2] = {nullptr, nullptr}, *n_keep_b[2] = {nullptr, nullptr};
   float *scored = nullptr, *keep = nullptr, *thresh = nullptr;   // set of the most recent call
   int *counts = nullptr, *keep_idx = nullptr, *n_keep = nullptr;
@@ -209,6 +212,8 @@ extern "C" void mpn_frcnn_destroy(mpn_frcnn *p) {
   for (int i = 0; i < 2; ++i) { if (p->ev_head[i]) (void)hipEventDestroy(p->ev_head[i]); if (p->ev_tail[i]) (void)hipEventDestroy(p->ev_tail[i]); }
   if (p->side) (void)hipStreamDestroy(p->side);
   for (void *q : p->allocs) (void)hipFree(q);
+  if (p->scaled) (void)hipFree(p->scaled);
+  if (p->scale_tmp) (void)hipFree(p->scale_tmp);
   if (p->dbg) (void)hipFree(p->dbg);
   delete p;
 }
@@ -468,23 +473,47 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
 
 // d_image == nullptr: recompute_features = false (ImageDetect.lua:107-111) — reuse the trunk output of the last
 // call on this handle (iterative localisation, Tester_FRCNN.lua:82-89) and run only the ROI head on new boxes.
-static int run_detect(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N, hipStream_t s) {
+static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const float *d_boxes, int N, hipStream_t s) {
   const mpn_frcnn_config &c = p->cfg;
   MPN_CHECK_ARG(p && d_boxes);
-  MPN_CHECK_ARG(H > 0 && W > 0 && H <= c.max_h && W <= c.max_w && N > 0 && N <= c.max_rois);
-  // ImageDetect.lua:34-43 — only the scale==1 path exists on the device (no bilinear resample);
-  // the host layer resizes other images before calling.
+  MPN_CHECK_ARG(H0 > 0 && W0 > 0 && N > 0 && N <= c.max_rois);
+  // getImages (ImageDetect.lua:34-43): s = target/min side, capped so that round(s*max side) <= max_size; the image is
+  // resampled to (long)(H*s) x (long)(W*s).  scale_target == 0 keeps the image as it is (s = 1).
+  double sc = 1.0;
+  int H = H0, W = W0;
+  if (c.scale_target > 0.0) {
+    sc = mpn_pick_scale(H0, W0, c.scale_target, c.scale_max > 0.0 ? c.scale_max : 1e30);
+    if (sc != 1.0) { H = (int)((double)H0 * sc); W = (int)((double)W0 * sc); }
+  }
+  if (H <= 0 || W <= 0 || H > c.max_h || W > c.max_w) {
+    set_error("run_detect: %dx%d image (scaled to %dx%d) exceeds the pipeline's %dx%d", H0, W0, H, W, c.max_h, c.max_w);
+    return MPN_EINVAL;
+  }
   Act feat;
   int rc = MPN_OK;
   if (d_image) {
-    rc = run_trunk(p, d_image, H, W, s, &feat);
+    const float *img = d_image;
+    if (sc != 1.0) {
+      const size_t need = (size_t)3 * H * W * sizeof(float), need_t = (size_t)3 * H0 * W * sizeof(float);
+      if (need > p->scaled_bytes || need_t > p->scale_tmp_bytes) {
+        MPN_CHECK_HIP(hipStreamSynchronize(s));
+        if (need > p->scaled_bytes) { if (p->scaled) (void)hipFree(p->scaled); p->scaled = nullptr; p->scaled_bytes = 0; MPN_CHECK_HIP(hipMalloc(&p->scaled, need)); p->scaled_bytes = need; }
+        if (need_t > p->scale_tmp_bytes) { if (p->scale_tmp) (void)hipFree(p->scale_tmp); p->scale_tmp = nullptr; p->scale_tmp_bytes = 0; MPN_CHECK_HIP(hipMalloc(&p->scale_tmp, need_t)); p->scale_tmp_bytes = need_t; }
+      }
+      rc = mpn_image_scale(d_image, 3, H0, W0, H, W, p->scale_tmp, p->scaled, s);
+      if (rc) return rc;
+      img = p->scaled;
+    }
+    rc = run_trunk(p, img, H, W, s, &feat);
   } else {
-    if (p->last_h != H || p->last_w != W || !p->tap_act[0].p) { set_error("run_detect: no cached features for a %dx%d image", H, W); return MPN_ESTATE; }
+    if (p->last_h != H || p->last_w != W || !p->tap_act[0].p) { set_error("run_detect: no cached features for a %dx%d image", H0, W0); return MPN_ESTATE; }
     feat = p->tap_act[0];
   }
   if (rc) return rc;
-  rc = mpn_project_im_rois(d_boxes, N, 1.0, p->rois, s);
+  rc = mpn_project_im_rois(d_boxes, N, sc, p->rois, s);
   if (rc) return rc;
+  // decode uses the ORIGINAL boxes and clamps to the ORIGINAL image (ImageDetect.lua:183-185, Tester_FRCNN.lua:75-78)
+  H = H0; W = W0;
   if (p->is_mpnet) {
     rc = run_mpnet_head(p, d_boxes, N, H, W, s);
     p->last_n = N;

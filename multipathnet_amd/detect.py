@@ -21,26 +21,12 @@ class ImageDetect(object):
         self.scale = scale or [600]
         self.max_size = max_size or 1000
 
-    def _prepare(self, im, boxes):
-        lib = _lib.load()
-        H, W = im.shape[1:]
-        s = lib.mpn_pick_scale(H, W, float(self.scale[0]), float(self.max_size))  # ImageDetect.lua:34-43
-        if s != 1.0:
-            # image.scale (bilinear) lives outside the parity scope; plumbing only.
-            im = torch.nn.functional.interpolate(im[None], size=(int(H * s), int(W * s)), mode="bilinear", align_corners=False)[0]
-            boxes_scaled = (boxes - 1) * s + 1
-        else:
-            boxes_scaled = boxes
-        return im.contiguous(), boxes_scaled.contiguous(), s
-
     def detect(self, im, boxes, min_images=None, recompute_features=True):
-        im = im.to(self.model.device, torch.float32)
+        """ImageDetect.lua:156-193.  Rescaling (getImages), ROI projection, decode on the original boxes all run inside the
+        device pipeline; the model must have been built with the same scale / max_size."""
+        im = im.to(self.model.device, torch.float32).contiguous()
         boxes = boxes.to(self.model.device, torch.float32).contiguous()
-        im_s, boxes_s, s = self._prepare(im, boxes)
-        scores, bbox = self.model.detect(im_s, boxes_s, recompute_features=recompute_features)
-        if s != 1.0:
-            bbox = (bbox - 1) / s + 1
-        return scores, bbox
+        return self.model.detect(im, boxes, recompute_features=recompute_features)
 
 
 class Tester_FRCNN(object):

@@ -119,7 +119,8 @@ class FastRCNN(object):
 
     def __init__(self, params, cfg=VGG16_CFG, pooled=7, spatial_scale=1.0 / 16, transformer=None, max_h=600, max_w=1000,
                  max_rois=1000, nms_thresh=0.3, score_thresh=-1.5, top_k=100, num_iter=1, bbox_voting=False, bbox_vote_thresh=0.5,
-                 bbox_vote_score_pow=1.0):
+                 bbox_vote_score_pow=1.0, scale=None, max_size=None):
+        """scale / max_size: getImages' rescaling (ImageDetect.lua:34-43) on the device; None feeds images as they are."""
         _lib.require_gpu()
         lib = _lib.load()
         cout, pool = cfg_layers(cfg)
@@ -152,6 +153,7 @@ class FastRCNN(object):
         c.nms_thresh, c.score_thresh, c.top_k = nms_thresh, score_thresh, top_k
         c.num_iter, c.bbox_voting, c.bbox_vote_thresh, c.bbox_vote_score_pow = num_iter, int(bbox_voting), bbox_vote_thresh, bbox_vote_score_pow
         self.num_iter = num_iter
+        c.scale_target, c.scale_max = float(scale or 0.0), float(max_size or 0.0)
         self._cfg = c
         dev = torch.device("cuda", torch.cuda.current_device())
         d = lambda t: t.to(dev, torch.float32).contiguous()

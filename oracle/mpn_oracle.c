@@ -476,3 +476,50 @@ void orc_mean_over_k(const float *probs, int K, int N, int C, float *out) {
     out[i] = s * inv;
   }
 }
+
+
+/* ------------------------------------------------------------------------------------------
+ * image.scale(src, width, height) in its default 'bilinear' mode — external `image` rock (ImageDetect.lua:41);
+ * PARITY UNPINNED (source not in the tree).  Restated from the published algorithm of torch/image's
+ * generic/image.c (scaleLinear_rowcol): separable, rows first then columns through a float intermediate;
+ *   upscale   : dst[d] = (1-f)*src[i] + f*src[i+1] with i+f = d*(src_len-1)/(dst_len-1), last sample copied;
+ *   downscale : fractional box average over [d*scale, (d+1)*scale), scale = src_len/dst_len;
+ *   equal     : copy.
+ * Output size as ImageDetect.lua:40 builds it: (long)(H*s) x (long)(W*s). */
+static void orc_scale_line(const float *src, long sstride, long slen, float *dst, long dstride, long dlen) {
+  if (dlen > slen) {
+    if (slen == 1) { for (long d = 0; d < dlen; ++d) dst[d * dstride] = src[0]; return; }
+    float scale = (float)(slen - 1) / (float)(dlen - 1);
+    for (long d = 0; d < dlen - 1; ++d) {
+      float sf = (float)d * scale;
+      long si = (long)sf;
+      sf -= (float)si;
+      dst[d * dstride] = (1.0f - sf) * src[si * sstride] + sf * src[(si + 1) * sstride];
+    }
+    dst[(dlen - 1) * dstride] = src[(slen - 1) * sstride];
+  } else if (dlen < slen) {
+    float scale = (float)slen / (float)dlen;
+    for (long d = 0; d < dlen; ++d) {
+      float s0 = (float)d * scale, s1 = (float)(d + 1) * scale;
+      long i0 = (long)s0, i1 = (long)s1;
+      float f0 = s0 - (float)i0, f1 = s1 - (float)i1;
+      float acc = (1.0f - f0) * src[i0 * sstride], n = 1.0f - f0;
+      for (long i = i0 + 1; i < i1; ++i) { acc += src[i * sstride]; n += 1.0f; }
+      if (i1 < slen && i1 > i0) { acc += f1 * src[i1 * sstride]; n += f1; }
+      dst[d * dstride] = acc / n;
+    }
+  } else {
+    for (long d = 0; d < dlen; ++d) dst[d * dstride] = src[d * sstride];
+  }
+}
+
+void orc_image_scale(const float *in, int C, int H, int W, int H2, int W2, float *out) {
+  float *tmp = (float *)malloc(sizeof(float) * (size_t)H * W2);
+  for (int c = 0; c < C; ++c) {
+    const float *ip = in + (size_t)c * H * W;
+    float *op = out + (size_t)c * H2 * W2;
+    for (int y = 0; y < H; ++y) orc_scale_line(ip + (size_t)y * W, 1, W, tmp + (size_t)y * W2, 1, W2);
+    for (int x = 0; x < W2; ++x) orc_scale_line(tmp + x, W2, H, op + x, W2, H2);
+  }
+  free(tmp);
+}

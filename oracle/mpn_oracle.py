@@ -162,6 +162,14 @@ def image_transform(im, mean, std=None, scale=1.0, swap=(0, 1, 2)):
     return out
 
 
+def image_scale(im, H2, W2):
+    """image.scale(im, W2, H2) bilinear (unpinned restatement, see mpn_oracle.c)"""
+    im = _f32(im)
+    out = np.empty((im.shape[0], H2, W2), np.float32)
+    lib().orc_image_scale(_p(im), im.shape[0], im.shape[1], im.shape[2], H2, W2, _p(out))
+    return out
+
+
 def pick_scale(H, W, target=600, max_size=1000):
     return float(lib().orc_pick_scale(H, W, C.c_double(target), C.c_double(max_size)))
 
@@ -345,13 +353,13 @@ def frcnn_head(feat, rois, P, pooled=7, spatial_scale=1.0 / 16, chunk=None):
 
 
 def detect(im, boxes, P, transformer=ROSS, target=600, max_size=1000, cfg=None, pooled=7, chunk=500):
-    """ImageDetect.lua:156-193 for an image whose scale factor is exactly 1 (no image.scale resample —
-    SURVEY §8a-2; asserted).  im [3,H,W] fp32 in [0,1]; boxes [N,4] 1-based x1y1x2y2.
+    """ImageDetect.lua:156-193.  im [3,H,W] fp32 in [0,1]; boxes [N,4] 1-based x1y1x2y2 in the ORIGINAL image.
     Returns (softmax scores [N,C], decoded boxes [N,4C], raw cls logits, raw deltas)."""
     H, W = im.shape[1:]
     s = pick_scale(H, W, target, max_size)
-    assert s == 1.0, "oracle.detect restates only the scale==1 path (bilinear image.scale is out of scope)"
     x = image_transform(im, **transformer)
+    if s != 1.0:  # ImageDetect.lua:40-41: image.scale(im, W*s, H*s) on the transformed image
+        x = image_scale(x, int(H * s), int(W * s))
     rois = project_im_rois(boxes, s)
     feat = vgg_trunk(x, P["conv_w"], P["conv_b"], cfg)
     logits, deltas = frcnn_head(feat, rois, P, pooled=pooled, chunk=chunk)

@@ -105,7 +105,7 @@ def test_host_mirror_tester(O, dev, small):
     from multipathnet_amd import detect
     net = small["net"]
     im, boxes = torch.from_numpy(small["im"]), torch.from_numpy(small["boxes"])
-    tester = detect.Tester_FRCNN(net, scale=[SMALL["H"]], max_size=SMALL["W"], opt={"test_nms_threshold": 0.3})
+    tester = detect.Tester_FRCNN(net, opt={"test_nms_threshold": 0.3})
     img_boxes, (output, bbox_pred) = tester.testOne(im, boxes)
     net.test_one_async(im.to(dev), boxes.to(dev))
     keep, _, nk = [t.cpu() for t in net.nms_results()]
@@ -113,7 +113,7 @@ def test_host_mirror_tester(O, dev, small):
         assert torch.equal(kb.cpu(), keep[j, : int(nk[j])])
     assert set(tester.last_timing) == {"forward", "nms", "total"}
     # iterative localisation (Tester_FRCNN.lua:82-89): second pass doubles the scored rows
-    t2 = detect.Tester_FRCNN(net, scale=[SMALL["H"]], max_size=SMALL["W"], opt={"test_num_iterative_loc": 2})
+    t2 = detect.Tester_FRCNN(net, opt={"test_num_iterative_loc": 2})
     _, (out2, bb2) = t2.testOne(im, boxes)
     assert out2.shape[0] == 2 * boxes.shape[0] and torch.equal(out2[: boxes.shape[0]], output)
     # the second pass ran on cached trunk features (recompute_features=false, ImageDetect.lua:107-111) and must equal
@@ -271,7 +271,7 @@ def test_fused_iterative_loc_and_bbox_voting(O, dev, small):
     keep, idx, nk = [t.cpu().numpy() for t in net2.nms_results()]
     assert keep.shape[1] == 2 * s["N"]
     # host mirror on a plain pipeline with the same weights
-    tester = detect.Tester_FRCNN(small["net"], scale=[s["H"]], max_size=s["W"],
+    tester = detect.Tester_FRCNN(small["net"],
                                  opt={"test_num_iterative_loc": 2, "test_bbox_voting": True, "test_bbox_voting_nms_threshold": 0.5})
     img_boxes, (output, bbox_pred) = tester.testOne(im, boxes)
     assert output.shape[0] == 2 * s["N"]
@@ -288,3 +288,42 @@ def test_fused_iterative_loc_and_bbox_voting(O, dev, small):
     kept, _ = O.keep_top_k(per, 100)
     exp = np.concatenate([np.concatenate([k, np.full((k.shape[0], 1), j + 1, np.float32)], 1) for j, k in enumerate(kept) if k.size])
     assert np.array_equal(dets[: int(n.item())].cpu().numpy(), exp)
+
+
+@pytest.mark.parametrize("H0,W0", [(60, 100), (120, 90), (200, 320), (150, 250)])
+def test_getimages_rescale_on_device(O, dev, H0, W0):
+    """getImages (ImageDetect.lua:34-43) inside the pipeline: short side -> 150, long side capped at 250; ROIs projected with
+    the scale, boxes decoded on the ORIGINAL boxes and clamped to the ORIGINAL image.  image.scale itself is parity-unpinned
+    (external rock); the check is device == oracle restatement."""
+    from multipathnet_amd import models
+    cfg = [8, 8, "P", 16, "P", 16]
+    P = models.synthetic_params(cfg, pooled=7, fc_dim=32, n_classes=4, seed=3)
+    net = models.FastRCNN(P, cfg=cfg, pooled=7, spatial_scale=0.25, max_h=256, max_w=256, max_rois=40, scale=150, max_size=250)
+    rng = np.random.default_rng(H0 * 7 + W0)
+    im = rng.random((3, H0, W0), dtype=np.float32)
+    boxes = _boxes(rng, 40, W0, H0, lo=6)
+    scores, bbox = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+    Pn = _np_params(P)
+    s = O.pick_scale(H0, W0, 150, 250)
+    x = O.image_transform(im, **O.ROSS)
+    if s != 1.0:
+        x = O.image_scale(x, int(H0 * s), int(W0 * s))
+    feat = O.vgg_trunk(x, Pn["conv_w"], Pn["conv_b"], cfg)
+    logits, deltas = O.frcnn_head(feat, O.project_im_rois(boxes, s), Pn, pooled=7, spatial_scale=0.25)
+    ref_bbox = O.clamp_boxes(O.bbox_decode(boxes, deltas), W0, H0)
+    assert np.abs(scores.cpu().numpy() - O.softmax(logits)).max() < 1e-4
+    assert np.abs(bbox.cpu().numpy() - ref_bbox).max() < 1e-4 * max(W0, H0)
+
+
+def test_image_scale_kernel_vs_oracle(O, dev):
+    import ctypes as C
+    from multipathnet_amd import nn, _lib
+    rng = np.random.default_rng(4)
+    for (h, w, h2, w2) in [(48, 64, 60, 80), (48, 64, 24, 32), (75, 125, 30, 100), (37, 53, 37, 90), (10, 10, 1, 1), (1, 7, 5, 7)]:
+        im = rng.random((3, h, w), dtype=np.float32)
+        d_in = torch.from_numpy(im).to(dev)
+        tmp = torch.empty((3, h, w2), device=dev)
+        out = torch.empty((3, h2, w2), device=dev)
+        _lib.check(_lib.load().mpn_image_scale(nn._f(d_in), 3, h, w, h2, w2, nn._f(tmp), nn._f(out), None))
+        torch.cuda.synchronize()
+        assert np.abs(out.cpu().numpy() - O.image_scale(im, h2, w2)).max() < 1e-6
