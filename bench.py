@@ -37,7 +37,7 @@ def conv_flops(cfg, h, w):
         if item == "P":
             h, w = (h + 1) // 2, (w + 1) // 2
         else:
-            out.append((2.0 * h * w * cin * 9 * item, "conv_64x8" if item <= 64 else "conv_128x4"))
+            out.append((2.0 * h * w * cin * 9 * item, "conv_wino" if cin >= 16 else "conv_direct"))
             cin = item
     return out
 
@@ -169,9 +169,9 @@ def main():
 
     if rank == 0:
         cf = conv_flops(models.VGG16_CFG, H, W)
-        flops = {"conv_128x4": sum(f for f, v in cf if v == "conv_128x4"), "conv_64x8": sum(f for f, v in cf if v == "conv_64x8"),
+        flops = {"conv_wino": sum(f for f, v in cf if v == "conv_wino"), "conv_direct": sum(f for f, v in cf if v == "conv_direct"),
                  "fc6": 2.0 * N_ROIS * 25088 * 4096, "fc7": 2.0 * N_ROIS * 4096 * 4096, "heads": 2.0 * N_ROIS * 4096 * 5 * N_CLASSES}
-        launches = {"conv_128x4": sum(1 for f, v in cf if v == "conv_128x4"), "conv_64x8": sum(1 for f, v in cf if v == "conv_64x8")}
+        launches = {"conv_wino": sum(1 for f, v in cf if v == "conv_wino"), "conv_direct": sum(1 for f, v in cf if v == "conv_direct")}
         kernels = {}
         for tag, (ms, cnt) in prof.items():
             if cnt:
@@ -200,6 +200,11 @@ def main():
                          "how": "HIP events on the launch stream around each kernel group, %d profiled steps after the timed region" % args.steps},
             "kernels": kernels,
         }
+        if dom == "conv_wino":  # the MFMA pipe executes 16 multiplies per 4 outputs instead of 36
+            out["roofline"]["algorithm"] = ("Winograd F(2x2,3x3) in fp32: 'achieved' counts the ALGORITHMIC flops (2*H*W*Cin*9*Cout); the matrix "
+                                            "pipe executes 1/2.25 of them, see executed_*")
+            out["roofline"]["executed_tflops"] = round(achieved / 2.25, 2)
+            out["roofline"]["executed_frac_of_peak"] = round(achieved / 2.25 * 1e12 / FP32_MFMA_PEAK, 4)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(P, im_np, boxes_np, args.cpu_rois)
         print(json.dumps(out))

@@ -282,7 +282,7 @@ int mpn_frcnn_nms_results(mpn_frcnn *p, const float **d_keep, const int **d_keep
 /* Per-kernel-group timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  * Tags index the arrays returned by mpn_frcnn_get_profile (accumulated ms and launch-group counts). */
 enum {
-  MPN_PROF_TRANSFORM = 0, MPN_PROF_CONV_128x4, MPN_PROF_CONV_64x8, MPN_PROF_POOL, MPN_PROF_ROIPOOL, MPN_PROF_FC6,
+  MPN_PROF_TRANSFORM = 0, MPN_PROF_CONV_WINO /* Winograd F(2x2,3x3) layers */, MPN_PROF_CONV_DIRECT /* direct implicit-GEMM layers */, MPN_PROF_POOL, MPN_PROF_ROIPOOL, MPN_PROF_FC6,
   MPN_PROF_FC7, MPN_PROF_HEADS, MPN_PROF_POST, MPN_PROF_SELECT, MPN_PROF_NMS, MPN_PROF_TOPK, MPN_PROF_NTAGS
 };
 int mpn_frcnn_set_profiling(mpn_frcnn *p, int enable);

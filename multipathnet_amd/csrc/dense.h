@@ -38,6 +38,7 @@ inline size_t act_bytes(int C, int H, int W) { return (size_t)((C + 7) / 8) * ac
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 inline int conv_coutp(int Cout) { return round_up(Cout, 128); }
 inline size_t conv_wpk_elems(int Cin, int Cout) { return (size_t)((Cin + 7) / 8) * 9 * conv_coutp(Cout) * 8; }
+inline size_t conv_wino_elems(int Cin, int Cout) { return (size_t)((Cin + 7) / 8) * 16 * conv_coutp(Cout) * 8; }
 inline int lin_np(int N) { return round_up(N, 128); }
 inline int lin_mp(int M) { return round_up(M, 128); }
 inline size_t lin_wpk_elems(int K, int N) { return (size_t)((K + 7) / 8) * lin_np(N) * 8; }
@@ -45,6 +46,8 @@ inline size_t mat_c8_elems(int M, int K) { return (size_t)((K + 7) / 8) * lin_mp
 
 // --- packers / converters (all enqueue on `s`) -------------------------------------------------
 int pack_conv_weights(const float *d_w, const float *d_b, int Cin, int Cout, float *d_wpk, float *d_bpk, hipStream_t s);
+// Winograd F(2x2,3x3) filter transform G g G^T -> [Cin8/8][16][CoutP][8]
+int pack_conv_weights_wino(const float *d_w, int Cin, int Cout, float *d_wino, hipStream_t s);
 // inner: K index permutation k_src = (q/inner*8 + j)*inner + q%inner for chunk q, element j
 // (inner=1: plain; inner=PH*PW: fc6 behind a channel-blocked ROI pool).
 int pack_linear_weights(const float *d_w, const float *d_b, int K, int N, int inner, float *d_wpk, float *d_bpk,
@@ -60,8 +63,10 @@ int image_transform_c8p(const float *d_in, int H, int W, const int *swap, double
 // --- compute ------------------------------------------------------------------------------------
 // out = relu?(conv3x3(in) + b); optional fused ceil-mode 2x2 max-pool writes `pooled` as well
 // (out.p may be null when only the pooled map is needed).
-int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int relu, Act out, Act pooled, hipStream_t s);
-int conv3x3_variant_for(int Cout);  // 1 = 128 couts x 4 rows x 32 cols tile, 2 = 64 x 8 x 32
+// d_wino (optional): Winograd-transformed weights; used when the variant selector picks the Winograd kernel.
+int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int relu, Act out, Act pooled, hipStream_t s,
+                const float *d_wino = nullptr);
+int conv3x3_variant_for(int Cout, bool has_wino = false);  // 7 = Winograd, 1 = direct 128 couts x 4 rows x 32 cols tile, 2 = direct 64 x 8 x 32
 int maxpool2x2_c8p(Act in, Act out, hipStream_t s);
 // y = relu?(x W^T + b).  x: C8 matrix [K8/8][Mp][8]; y: C8 matrix [NP/8][Mp][8] (y_c8) and/or
 // row-major [M,N] (y_rm); either may be null.

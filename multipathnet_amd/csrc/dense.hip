@@ -17,6 +17,7 @@
 //   * D[cout][pixel] leaves the accumulators as float4 stores that are 1 KiB-contiguous per wave
 //     instruction in the C8P layout — the next layer's LDS image.
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "dense.h"
@@ -266,6 +267,283 @@ static int launch_conv(const ConvArgs &a0, int tiles_y, hipStream_t s) {
   return MPN_OK;
 }
 
+
+// =================================================================================================
+// conv3x3 via Winograd F(2x2,3x3), fused: input transform, 16 component GEMMs on MFMA, output transform
+// =================================================================================================
+// Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A  per 2x2 output tile (Lavin & Gray 2015) — the algorithm cuDNN's
+// WINOGRAD conv algo runs for the reference's cudnn.SpatialConvolution; 16 multiplies per 4 outputs instead of 36,
+// i.e. 2.25x fewer MFMAs than the direct kernel, still all-fp32 (error ~1e-6 of the output scale).
+//   * block = 64 couts x (16 x 16 output px = 8 x 8 Winograd tiles); wave = 32 couts x 32 tiles x 16 components
+//     = 16 MFMA accumulators (256 AGPRs, one wave per SIMD);
+//   * per 8-channel chunk: the raw 18x18 halo tile and the 16 pre-transformed weight slices [comp][cout][8] are
+//     DMA'd (global_load_lds) one chunk ahead; the input transform B^T d B of chunk c+1 (thread = one tile x one
+//     channel pair: 16 ds_read_b64, 32 packed adds, 16 ds_write_b64) is interleaved between chunk c's MFMA groups
+//     and lands in the other V buffer [comp][tile][8];
+//   * the 16 components of one (cout, tile) sit at the same (lane, register) of the 16 accumulators, so the
+//     output transform A^T M A, bias, ReLU and the 2x2 max-pool (a Winograd tile IS a pooling window) are
+//     register-local; float4 stores go straight into the next layer's C8P layout.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int WG_RAW_PIECES = 18 * 36;                 // 18 rows x 18 px x two 16-byte pieces
+constexpr int WG_RAW_LOADS = 12;                      // 10.1 wave-loads of data; padded to 3 per wave so the DMA issue is branch-free
+constexpr int WG_RAW_FLOATS = WG_RAW_LOADS * 256;
+constexpr int WG_V_FLOATS = 16 * 64 * 8;
+constexpr int WG_U_FLOATS = 16 * 64 * 8;
+constexpr size_t WG_LDS_BYTES = (size_t)2 * (WG_RAW_FLOATS + WG_V_FLOATS + WG_U_FLOATS) * sizeof(float);
+
+template <int ABL>  // ABL: compile-time timing-experiment switches (0 in production; see tools/ablate_wino.py)
+__global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *const raw_lds = lds;
+  float *const v_lds = lds + 2 * WG_RAW_FLOATS;
+  float *const u_lds = v_lds + 2 * WG_V_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ct = blockIdx.x % a.n_ct, sp = blockIdx.x / a.n_ct;
+  const int tyb = sp / a.tiles_x, txb = sp - tyb * a.tiles_x;
+  const int y0 = tyb * 16, x0 = txb * 16, cout0 = ct * 64;
+  const int mbase = (wave >> 1) * 32, nbase = (wave & 1) * 32;
+
+  constexpr int RAW_IT = (WG_RAW_LOADS + 3) / 4;
+  int raw_off[RAW_IT];
+#pragma unroll
+  for (int i = 0; i < RAW_IT; ++i) {
+    int p = min((i * 4 + wave) * 64 + lane, WG_RAW_PIECES - 1);  // slots past the tile re-load its last piece (never read)
+    int r = p / 36, o = p - r * 36;
+    raw_off[i] = ((y0 + r) * a.in_Wp + x0) * 8 + o * 4;
+  }
+  int u_off[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int p = (i * 4 + wave) * 64 + lane;
+    int comp = p >> 7, rem = p & 127;
+    u_off[i] = (comp * a.CoutP + cout0) * 8 + rem * 4;
+  }
+  const size_t u_chunk = (size_t)16 * a.CoutP * 8;
+  auto issue_raw = [&](int c, int buf) {
+#pragma unroll
+    for (int i = 0; i < RAW_IT; ++i)
+      glds16(a.in + (size_t)c * a.in_plane + raw_off[i], raw_lds + buf * WG_RAW_FLOATS + (i * 4 + wave) * 256);
+  };
+  auto issue_u = [&](int c, int buf, int i) {
+    glds16(a.wpk + (size_t)c * u_chunk + u_off[i], u_lds + buf * WG_U_FLOATS + (i * 4 + wave) * 256);
+  };
+
+  // input transform: wave w owns tiles 16w..16w+15 (tile rows 2w, 2w+1); lane = tile_local * 4 + channel pair, so the
+  // 64 ds_write_b64 of one component cover 512 contiguous bytes and each half-wave's ds_read_b64 hits 32 distinct
+  // bank pairs (a tile-per-lane mapping was 8-way bank-conflicted and made the LDS pipe the bottleneck)
+  const int tf_tile = wave * 16 + (lane >> 2), tf_cp = lane & 3;
+  const int tf_rd = ((2 * (tf_tile >> 3)) * 18 + 2 * (tf_tile & 7)) * 8 + 2 * tf_cp;
+  const int tf_wr = tf_tile * 8 + 2 * tf_cp;
+  f32x2 d[16], t[16];
+  auto tf_load = [&](int buf) {
+    const float *R = raw_lds + buf * WG_RAW_FLOATS + tf_rd;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[r * 4 + q] = *reinterpret_cast<const f32x2 *>(R + (r * 18 + q) * 8);
+  };
+  auto tf_rows = [&]() {  // t = B^T d
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      t[0 + q] = d[0 + q] - d[8 + q];
+      t[4 + q] = d[4 + q] + d[8 + q];
+      t[8 + q] = d[8 + q] - d[4 + q];
+      t[12 + q] = d[4 + q] - d[12 + q];
+    }
+  };
+  auto tf_cols_store = [&](int xi, int buf) {  // V[xi][.] = t[xi][.] B  -> components xi*4 .. xi*4+3
+    float *Vw = v_lds + buf * WG_V_FLOATS + tf_wr + xi * 4 * 512;
+    *reinterpret_cast<f32x2 *>(Vw + 0 * 512) = t[xi * 4 + 0] - t[xi * 4 + 2];
+    *reinterpret_cast<f32x2 *>(Vw + 1 * 512) = t[xi * 4 + 1] + t[xi * 4 + 2];
+    *reinterpret_cast<f32x2 *>(Vw + 2 * 512) = t[xi * 4 + 2] - t[xi * 4 + 1];
+    *reinterpret_cast<f32x2 *>(Vw + 3 * 512) = t[xi * 4 + 1] - t[xi * 4 + 3];
+  };
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+
+  const int c0 = blockIdx.y * a.chunks_per_split;
+  const int c1 = min(a.nchunks, c0 + a.chunks_per_split);
+  issue_raw(c0, 0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) issue_u(c0, 0, i);
+  __syncthreads();
+  tf_load(0);
+  tf_rows();
+#pragma unroll
+  for (int xi = 0; xi < 4; ++xi) tf_cols_store(xi, 0);
+  if (c0 + 1 < c1) issue_raw(c0 + 1, 1);
+  __syncthreads();
+
+  const int frag_u = (mbase + l31) * 8 + half * 4, frag_v = (nbase + l31) * 8 + half * 4;
+  // Loop-body scheduling notes (from the ISA):
+  //  * branch-free: MORE is a compile-time tag (the last chunk runs the no-prefetch copy);
+  //  * the compiler forces every lgkmcnt wait that follows a global_load_lds to lgkmcnt(0) (LDS-DMA is a FLAT op
+  //    that may touch LDS), so a wait placed after the NEXT pair's fragment loads would expose their latency.
+  //    Each pair therefore issues its first MFMA before anything else — the forced wait lands there and only
+  //    covers LDS ops issued >= 6 MFMAs earlier — and the fragment loads / DMA issue / transform slices sit between
+  //    the remaining MFMAs, pinned by sched_barriers.
+  //  * the chunk barrier sits BEFORE the last pair's MFMAs: by then every LDS read of this chunk has been issued
+  //    and waited for (pair 7's fragments are in registers), so after the barrier the next chunk's first fragments
+  //    are fetched under pair 7's 8 MFMAs instead of exposing their latency; all DMA for the next chunk is issued
+  //    in pairs 0-1 so it has ~3000 cycles to land before that barrier's vmcnt(0).
+  f32x4 af[2][2], bf[2][2];
+  auto load_frags = [&](int buf, int pr, int slot) {
+    const float *Ul = u_lds + buf * WG_U_FLOATS + frag_u, *Vl = v_lds + buf * WG_V_FLOATS + frag_v;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      af[slot][k] = *reinterpret_cast<const f32x4 *>(Ul + (2 * pr + k) * 512);
+      bf[slot][k] = *reinterpret_cast<const f32x4 *>(Vl + (2 * pr + k) * 512);
+    }
+  };
+  load_frags(0, 0, 0);
+  auto body = [&](int c, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    const int s = (c - c0) & 1;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {  // component pair (2p, 2p+1): two independent accumulator chains
+      const int cur = p & 1;
+      if (p == 7 && MORE) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's last reads of U[s]/V[s] are done before others may overwrite them
+        if constexpr (!(ABL & 2)) __syncthreads();
+        if constexpr (!(ABL & 16)) load_frags(s ^ 1, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[2 * p] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0][0], bf[cur][0][0], acc[2 * p], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (p + 1 < 8 && !(ABL & 16)) load_frags(s, p + 1, cur ^ 1);
+      if constexpr (MORE) {
+        if (p == 0 && !(ABL & 4)) tf_load(s ^ 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][1][0], bf[cur][1][0], acc[2 * p + 1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (MORE) {
+        if constexpr (!(ABL & 1)) {
+          if (p == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) issue_u(c + 1, s ^ 1, i);
+            issue_raw(min(c + 2, c1 - 1), s);  // past the end: a harmless re-load of the last chunk
+          }
+          if (p == 1) {
+#pragma unroll
+            for (int i = 4; i < 8; ++i) issue_u(c + 1, s ^ 1, i);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[2 * p] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0][1], bf[cur][0][1], acc[2 * p], 0, 0, 0);
+      acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][1][1], bf[cur][1][1], acc[2 * p + 1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (MORE) {
+        if constexpr (!(ABL & 4)) {
+          if (p == 1) tf_rows();
+          if (p >= 2 && p <= 5) tf_cols_store(p - 2, s ^ 1);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 2; j < 4; ++j) {
+        acc[2 * p] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0][j], bf[cur][0][j], acc[2 * p], 0, 0, 0);
+        acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][1][j], bf[cur][1][j], acc[2 * p + 1], 0, 0, 0);
+      }
+    }
+  };
+  for (int c = c0; c < c1 - 1; ++c) body(c, std::true_type{});
+  body(c1 - 1, std::false_type{});
+
+  // ---- output transform A^T M A (register-local), bias, ReLU, stores, fused 2x2 max-pool
+  if constexpr ((ABL & 8) != 0) {  // timing experiment: no output transform / stores (the never-true store keeps the accumulators live)
+    if (a.H < 0) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x16 *>(a.part + (size_t)k * 16 + lane * 256) = acc[k];
+    }
+    return;
+  }
+  const int tau = nbase + l31;
+  const int y = y0 + 2 * (tau >> 3), x = x0 + 2 * (tau & 7);
+  float *const obase = (a.splits > 1) ? a.part + (size_t)blockIdx.y * a.part_slab : a.out;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int cb = (cout0 + mbase) / 8 + g;
+    if (cb >= a.out_cb) continue;
+    f32x4 Y[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int r = g * 4 + e;
+      const float s0 = acc[0][r] + acc[4][r] + acc[8][r], s1 = acc[1][r] + acc[5][r] + acc[9][r];
+      const float s2 = acc[2][r] + acc[6][r] + acc[10][r], s3 = acc[3][r] + acc[7][r] + acc[11][r];
+      const float u0 = acc[4][r] - acc[8][r] - acc[12][r], u1 = acc[5][r] - acc[9][r] - acc[13][r];
+      const float u2 = acc[6][r] - acc[10][r] - acc[14][r], u3 = acc[7][r] - acc[11][r] - acc[15][r];
+      Y[0][e] = s0 + s1 + s2; Y[1][e] = s1 - s2 - s3;
+      Y[2][e] = u0 + u1 + u2; Y[3][e] = u1 - u2 - u3;
+    }
+    if (a.splits > 1) {  // raw partial sums; conv_splitk_reduce_kernel finishes the layer
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int yy = y + (k >> 1), xx = x + (k & 1);
+        if (yy < a.H && xx < a.W)
+          *reinterpret_cast<f32x4 *>(obase + (size_t)cb * a.out_plane + ((size_t)(yy + 1) * a.out_Wp + xx + 1) * 8 + half * 4) = Y[k];
+      }
+      continue;
+    }
+    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bpk + cb * 8 + half * 4);
+    f32x4 m = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = y + (k >> 1), xx = x + (k & 1);
+      const bool ok = yy < a.H && xx < a.W;
+      f32x4 v = Y[k] + b4;
+      if (a.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.0f ? 0.0f : v[e];
+      }
+      if (ok && a.out)
+        *reinterpret_cast<f32x4 *>(a.out + (size_t)cb * a.out_plane + ((size_t)(yy + 1) * a.out_Wp + xx + 1) * 8 + half * 4) = v;
+      if (ok) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+      }
+    }
+    if (a.pool) {
+      const int py = y >> 1, px = x >> 1;
+      if (py < a.pool_H && px < a.pool_W)
+        *reinterpret_cast<f32x4 *>(a.pool + (size_t)cb * a.pool_plane + ((size_t)(py + 1) * a.pool_Wp + px + 1) * 8 + half * 4) = m;
+    }
+  }
+}
+
+template <int ABL>
+static int launch_conv_wino_t(const ConvArgs &a, int tiles_y, hipStream_t s) {
+  auto kern = conv3x3_wino_kernel<ABL>;
+  static bool attr = false;
+  if (!attr) {
+    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS_BYTES));
+    attr = true;
+  }
+  dim3 grid((unsigned)(a.n_ct * tiles_y * a.tiles_x), (unsigned)a.splits);
+  hipLaunchKernelGGL(kern, grid, dim3(256), WG_LDS_BYTES, s, a);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+static int launch_conv_wino(const ConvArgs &a, int tiles_y, hipStream_t s) {
+  switch (a.ablate) {  // timing experiments only (wrong results)
+    case 1: return launch_conv_wino_t<1>(a, tiles_y, s);
+    case 2: return launch_conv_wino_t<2>(a, tiles_y, s);
+    case 4: return launch_conv_wino_t<4>(a, tiles_y, s);
+    case 8: return launch_conv_wino_t<8>(a, tiles_y, s);
+    case 5: return launch_conv_wino_t<5>(a, tiles_y, s);
+    case 23: return launch_conv_wino_t<23>(a, tiles_y, s);
+    case 31: return launch_conv_wino_t<31>(a, tiles_y, s);
+    default: return launch_conv_wino_t<0>(a, tiles_y, s);
+  }
+}
 
 // =================================================================================================
 // Persistent stream-K conv3x3: ONE block per CU for the whole layer.
@@ -627,16 +905,18 @@ static int conv_pick_splits(int blocks, int nchunks, int slots) {
 static int g_conv_variant = 0;  // 0 = auto; test/bench hook: 1 = 128x4 tile / 9 taps per stage, 2 = 64x8 / 9, 3 = 128x4 / 3, 4 = 64x8 / 3,
                                  // 5 = 128 couts x 8 rows (64x128 per wave, 8 accumulators), 6 = 64 couts x 16 rows
 
-int conv3x3_variant_for(int Cout) {
+int conv3x3_variant_for(int Cout, bool has_wino) {
   int variant = g_conv_variant & 15;
-  // measured on MI355X (tools/bench_layers.py): one 4-wave block per CU (9 taps per stage) beats the
-  // 3-blocks-per-CU variants on every VGG layer — co-resident waves only time-share the SIMD's matrix pipe.
-  if (variant == 0) variant = (Cout <= 64) ? 2 : 1;
+  // measured on MI355X (tools/bench_layers.py): Winograd F(2x2,3x3) beats the direct kernels on every VGG layer with
+  // >= 16 input channels (2.33 vs 3.53 ms for the trunk); among the direct kernels one 4-wave block per CU (9 taps per
+  // stage) beats the 3-blocks-per-CU variants — co-resident waves only time-share the SIMD's matrix pipe.
+  if (variant == 7 && !has_wino) variant = 0;
+  if (variant == 0) variant = has_wino ? 7 : ((Cout <= 64) ? 2 : 1);
   return variant;
 }
 
-int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int relu, Act out, Act pooled, hipStream_t s) {
-  MPN_CHECK_ARG(in.p && d_wpk && d_bpk && (out.p || pooled.p));
+int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int relu, Act out, Act pooled, hipStream_t s, const float *d_wino) {
+  MPN_CHECK_ARG(in.p && (d_wpk || d_wino) && d_bpk && (out.p || pooled.p));
   ConvArgs a{};
   a.in = in.p; a.in_plane = in.plane(); a.in_Wp = in.Wp;
   a.wpk = d_wpk; a.CoutP = conv_coutp(Cout); a.bpk = d_bpk;
@@ -648,7 +928,40 @@ int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int re
   a.ablate = g_gemm_ablate;
   if (out.p) MPN_CHECK_ARG(out.H == in.H && out.W == in.W && out.C == Cout);
   if (pooled.p) MPN_CHECK_ARG(pooled.H == (in.H + 1) / 2 && pooled.W == (in.W + 1) / 2 && pooled.C == Cout);
-  const int variant = conv3x3_variant_for(Cout);
+  int variant = conv3x3_variant_for(Cout, d_wino != nullptr);
+  if (!d_wpk) variant = 7;
+  if (variant == 7) {  // Winograd F(2x2,3x3): 64 couts x 16x16 px per block
+    a.wpk = d_wino;
+    a.tiles_x = cdiv(in.W, 16);
+    const int tiles_y = cdiv(in.H, 16);
+    a.n_ct = cdiv(Cout, 64);
+    const int blocks = a.n_ct * tiles_y * a.tiles_x;
+    a.splits = conv_pick_splits(blocks, a.nchunks, 256);
+    a.chunks_per_split = cdiv(a.nchunks, a.splits);
+    a.splits = cdiv(a.nchunks, a.chunks_per_split);
+    Act geo = out.p ? out : make_act(nullptr, Cout, in.H, in.W);
+    if (a.splits > 1) {
+      a.part_slab = geo.elems();
+      a.out_plane = geo.plane(); a.out_Wp = geo.Wp;
+      size_t need = a.part_slab * a.splits * sizeof(float);
+      if (need > g_conv_ws_bytes) {
+        MPN_CHECK_HIP(hipStreamSynchronize(s));
+        if (g_conv_ws) (void)hipFree(g_conv_ws);
+        g_conv_ws = nullptr; g_conv_ws_bytes = 0;
+        MPN_CHECK_HIP(hipMalloc(&g_conv_ws, need));
+        g_conv_ws_bytes = need;
+      }
+      a.part = g_conv_ws;
+    }
+    int rc = launch_conv_wino(a, tiles_y, s);
+    if (rc != MPN_OK || a.splits == 1) return rc;
+    const int GH = pooled.p ? pooled.H : in.H, GW = pooled.p ? pooled.W : in.W;
+    const size_t total = (size_t)a.out_cb * GH * GW * 2;
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, a.part, a.part_slab, a.splits, geo.plane(),
+                       geo.Wp, in.H, in.W, a.out_cb, d_bpk, relu, out.p, pooled.p, a.pool_plane, a.pool_Wp, a.pool_H, a.pool_W);
+    MPN_CHECK_LAUNCH();
+    return MPN_OK;
+  }
   const bool wide = (variant == 1 || variant == 3 || variant == 5);  // 128-cout tiles; else 64-cout tiles
   const int th = variant == 5 ? 8 : (variant == 6 ? 16 : (wide ? 4 : 8));
   const int tiles_y = cdiv(in.H, th);
@@ -972,6 +1285,39 @@ __global__ void pack_conv_w_kernel(const float *__restrict__ w, const float *__r
   int ch = (int)(r / 9);
   int ci = ch * 8 + j;
   wpk[t] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * 9 + tap] : 0.0f;
+}
+
+// Winograd filter transform U = G g G^T (computed in double, rounded once) into [Cin8/8][16][CoutP][8]
+__global__ void pack_conv_w_wino_kernel(const float *__restrict__ w, int Cin, int Cout, int CoutP, int nchunks, float *__restrict__ wino) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)nchunks * 16 * CoutP * 8;
+  if (t >= total) return;
+  int j = (int)(t & 7);
+  size_t r = t >> 3;
+  int co = (int)(r % CoutP); r /= CoutP;
+  int comp = (int)(r % 16);
+  int ch = (int)(r / 16);
+  int ci = ch * 8 + j;
+  float v = 0.0f;
+  if (co < Cout && ci < Cin) {
+    const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+    const float *g = w + ((size_t)co * Cin + ci) * 9;
+    const int xi = comp >> 2, nu = comp & 3;
+    double acc = 0.0;
+    for (int ky = 0; ky < 3; ++ky)
+      for (int kx = 0; kx < 3; ++kx) acc += G[xi][ky] * (double)g[ky * 3 + kx] * G[nu][kx];
+    v = (float)acc;
+  }
+  wino[t] = v;
+}
+
+int pack_conv_weights_wino(const float *d_w, int Cin, int Cout, float *d_wino, hipStream_t s) {
+  MPN_CHECK_ARG(d_w && d_wino && Cin > 0 && Cout > 0);
+  const int nchunks = (Cin + 7) / 8, CoutP = conv_coutp(Cout);
+  size_t total = (size_t)nchunks * 16 * CoutP * 8;
+  hipLaunchKernelGGL(pack_conv_w_wino_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, d_w, Cin, Cout, CoutP, nchunks, d_wino);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
 }
 
 int pack_conv_weights(const float *d_w, const float *d_b, int Cin, int Cout, float *d_wpk, float *d_bpk, hipStream_t s) {
@@ -1313,6 +1659,8 @@ extern "C" int mpn_debug_bench_conv(int Cin, int Cout, int H, int W, int pool, i
   MPN_CHECK_HIP(hipMalloc(&pl, act_bytes(Cout, (H + 1) / 2, (W + 1) / 2)));
   MPN_CHECK_HIP(hipMalloc(&wpk, conv_wpk_elems(Cin, Cout) * sizeof(float)));
   MPN_CHECK_HIP(hipMalloc(&bpk, conv_coutp(Cout) * sizeof(float)));
+  float *wino = nullptr;
+  MPN_CHECK_HIP(hipMalloc(&wino, conv_wino_elems(Cin, Cout) * sizeof(float)));
   MPN_CHECK_HIP(hipMemset(in, 0, act_bytes(Cin, H, W)));
   MPN_CHECK_HIP(hipMemset(out, 0, act_bytes(Cout, H, W)));
   MPN_CHECK_HIP(hipMemset(pl, 0, act_bytes(Cout, (H + 1) / 2, (W + 1) / 2)));
@@ -1336,23 +1684,27 @@ extern "C" int mpn_debug_bench_conv(int Cin, int Cout, int H, int W, int pool, i
     for (size_t i = 0; i < nw; ++i) h[i] *= 0.05f;
     MPN_CHECK_HIP(hipMemcpy(wpk, h.data(), nw * 4, hipMemcpyHostToDevice));
     MPN_CHECK_HIP(hipMemset(bpk, 0, conv_coutp(Cout) * sizeof(float)));
+    std::vector<float> hw(conv_wino_elems(Cin, Cout));
+    for (auto &v : hw) { x = x * 1664525u + 1013904223u; v = ((x >> 8) * (1.0f / 8388608.0f) - 1.0f) * 0.05f; }
+    if (fill && fill[0] == 'z') for (auto &v : hw) v = 0.0f;
+    MPN_CHECK_HIP(hipMemcpy(wino, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
   }
   Act ai = make_act(in, Cin, H, W), ao = make_act(out, Cout, H, W), ap = make_act(pl, Cout, (H + 1) / 2, (W + 1) / 2);
   hipEvent_t e0, e1;
   MPN_CHECK_HIP(hipEventCreate(&e0));
   MPN_CHECK_HIP(hipEventCreate(&e1));
   int rc = MPN_OK;
-  for (int i = 0; i < 2 && rc == MPN_OK; ++i) rc = pool ? conv3x3_c8p(ai, wpk, bpk, Cout, 1, Act{}, ap, nullptr) : conv3x3_c8p(ai, wpk, bpk, Cout, 1, ao, Act{}, nullptr);
+  for (int i = 0; i < 2 && rc == MPN_OK; ++i) rc = pool ? conv3x3_c8p(ai, wpk, bpk, Cout, 1, Act{}, ap, nullptr, wino) : conv3x3_c8p(ai, wpk, bpk, Cout, 1, ao, Act{}, nullptr, wino);
   MPN_CHECK_HIP(hipDeviceSynchronize());
   MPN_CHECK_HIP(hipEventRecord(e0, nullptr));
-  for (int i = 0; i < iters && rc == MPN_OK; ++i) rc = pool ? conv3x3_c8p(ai, wpk, bpk, Cout, 1, Act{}, ap, nullptr) : conv3x3_c8p(ai, wpk, bpk, Cout, 1, ao, Act{}, nullptr);
+  for (int i = 0; i < iters && rc == MPN_OK; ++i) rc = pool ? conv3x3_c8p(ai, wpk, bpk, Cout, 1, Act{}, ap, nullptr, wino) : conv3x3_c8p(ai, wpk, bpk, Cout, 1, ao, Act{}, nullptr, wino);
   MPN_CHECK_HIP(hipEventRecord(e1, nullptr));
   MPN_CHECK_HIP(hipEventSynchronize(e1));
   float ms = 0.f;
   MPN_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
   *ms_out = ms / iters;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  (void)hipFree(in); (void)hipFree(out); (void)hipFree(pl); (void)hipFree(wpk); (void)hipFree(bpk);
+  (void)hipFree(in); (void)hipFree(out); (void)hipFree(pl); (void)hipFree(wpk); (void)hipFree(bpk); (void)hipFree(wino);
   return rc;
 }
 
@@ -1393,7 +1745,7 @@ extern "C" int mpn_debug_bench_linear(int M, int K, int N, int iters, float *ms_
 extern "C" size_t mpn_conv3x3_workspace_bytes(int B, int Cin, int H, int W, int Cout) {
   (void)B;
   size_t a = act_bytes(Cin, H, W), o = act_bytes(Cout, H, W);
-  size_t w = conv_wpk_elems(Cin, Cout) * sizeof(float) + (size_t)conv_coutp(Cout) * sizeof(float);
+  size_t w = (conv_wpk_elems(Cin, Cout) + conv_wino_elems(Cin, Cout) + (size_t)conv_coutp(Cout)) * sizeof(float);
   return a + o + w + 1024;
 }
 
@@ -1411,13 +1763,16 @@ extern "C" int mpn_conv3x3_forward(const float *d_in, int B, int Cin, int H, int
   Act aout = make_act(reinterpret_cast<float *>(ws + ab), Cout, H, W);
   float *wpk = reinterpret_cast<float *>(ws + ab + ob);
   float *bpk = wpk + conv_wpk_elems(Cin, Cout);
+  float *wino = bpk + conv_coutp(Cout);
   int rc = pack_conv_weights(d_w, d_b, Cin, Cout, wpk, bpk, s);
+  if (rc) return rc;
+  rc = pack_conv_weights_wino(d_w, Cin, Cout, wino, s);
   if (rc) return rc;
   for (int b = 0; b < B; ++b) {
     MPN_CHECK_HIP(hipMemsetAsync(ain.p, 0, ab, s));  // zero halo (+ pad channels)
     rc = nchw_to_c8p(d_in + (size_t)b * Cin * H * W, Cin, H, W, ain, s);
     if (rc) return rc;
-    rc = conv3x3_c8p(ain, wpk, bpk, Cout, relu, aout, Act{}, s);
+    rc = conv3x3_c8p(ain, wpk, bpk, Cout, relu, aout, Act{}, s, wino);
     if (rc) return rc;
     rc = c8p_to_nchw(aout, d_out + (size_t)b * Cout * H * W, s);
     if (rc) return rc;

@@ -116,7 +116,7 @@ using namespace mpn;
 
 struct ConvLayer {
   int Cin, Cout, pool;
-  float *wpk = nullptr, *bpk = nullptr;
+  float *wpk = nullptr, *bpk = nullptr, *wino = nullptr;  // direct-conv and Winograd-transformed weights
   float *out = nullptr;     // C8P buffer for the conv output (max image size)
   float *pooled = nullptr;  // C8P buffer for the pooled output (when pool)
 };
@@ -249,6 +249,10 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
     TRY(dev_alloc(p, &L.wpk, conv_wpk_elems(L.Cin, L.Cout) * sizeof(float), false));
     TRY(dev_alloc(p, &L.bpk, (size_t)conv_coutp(L.Cout) * sizeof(float), false));
     TRY(pack_conv_weights(d_conv_w[l], d_conv_b[l], L.Cin, L.Cout, L.wpk, L.bpk, nullptr));
+    if (L.Cin >= 16) {  // the first layer (3 channels) is HBM-bound either way: keep it on the direct kernel
+      TRY(dev_alloc(p, &L.wino, conv_wino_elems(L.Cin, L.Cout) * sizeof(float), false));
+      TRY(pack_conv_weights_wino(d_conv_w[l], L.Cin, L.Cout, L.wino, nullptr));
+    }
     b = act_bytes(L.Cout, h, w);
     TRY(dev_alloc(p, &L.out, b, true));
     p->act_bufs.push_back({L.out, b});
@@ -391,8 +395,7 @@ static int run_trunk(mpn_frcnn *p, const float *d_image, int H, int W, hipStream
   int li = 0;
   for (auto &L : p->conv) {
     Act out = make_act(L.out, L.Cout, h, w);
-    const int cv = conv3x3_variant_for(L.Cout);
-    const int ctag = (cv == 1 || cv == 3) ? MPN_PROF_CONV_128x4 : MPN_PROF_CONV_64x8;
+    const int ctag = conv3x3_variant_for(L.Cout, L.wino != nullptr) == 7 ? MPN_PROF_CONV_WINO : MPN_PROF_CONV_DIRECT;
     const bool is_tap = p->is_mpnet && (li == p->tap3 || li == p->tap4);
     if (is_tap) p->tap_act[li == p->tap4 ? 1 : 2] = out;
     ++li;
@@ -400,15 +403,15 @@ static int run_trunk(mpn_frcnn *p, const float *d_image, int H, int W, hipStream
       Act pooled = make_act(L.pooled, L.Cout, (h + 1) / 2, (w + 1) / 2);
       if (g_fuse_pool) {
         ProfScope ps(p, ctag, s);
-        rc = conv3x3_c8p(cur, L.wpk, L.bpk, L.Cout, 1, is_tap ? out : Act{}, pooled, s);  // tap layers keep the pre-pool map too
+        rc = conv3x3_c8p(cur, L.wpk, L.bpk, L.Cout, 1, is_tap ? out : Act{}, pooled, s, L.wino);  // tap layers keep the pre-pool map too
       } else {
-        { ProfScope ps(p, ctag, s); rc = conv3x3_c8p(cur, L.wpk, L.bpk, L.Cout, 1, out, Act{}, s); }
+        { ProfScope ps(p, ctag, s); rc = conv3x3_c8p(cur, L.wpk, L.bpk, L.Cout, 1, out, Act{}, s, L.wino); }
         if (rc == MPN_OK) { ProfScope ps(p, MPN_PROF_POOL, s); rc = maxpool2x2_c8p(out, pooled, s); }
       }
       if (rc) return rc;
       cur = pooled; h = pooled.H; w = pooled.W;
     } else {
-      { ProfScope ps(p, ctag, s); rc = conv3x3_c8p(cur, L.wpk, L.bpk, L.Cout, 1, out, Act{}, s); }
+      { ProfScope ps(p, ctag, s); rc = conv3x3_c8p(cur, L.wpk, L.bpk, L.Cout, 1, out, Act{}, s, L.wino); }
       if (rc) return rc;
       cur = out;
     }

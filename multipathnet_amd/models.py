@@ -247,7 +247,7 @@ class FastRCNN(object):
         hip.hipMemcpy(C.c_void_p(n.data_ptr()), np_, C.c_size_t(n.numel() * 4), 3)
         return keep, idx, n
 
-    PROF_TAGS = ["transform", "conv_128x4", "conv_64x8", "pool", "roi_pool", "fc6", "fc7", "heads", "post", "select", "nms", "topk"]
+    PROF_TAGS = ["transform", "conv_wino", "conv_direct", "pool", "roi_pool", "fc6", "fc7", "heads", "post", "select", "nms", "topk"]
 
     def set_profiling(self, on):
         """HIP-event timing of every kernel group, recorded on the launch stream (include/mpn.h MPN_PROF_*)."""
