@@ -361,23 +361,24 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
     *reinterpret_cast<f32x2 *>(Vw + 3 * 512) = t[xi * 4 + 1] - t[xi * 4 + 3];
   };
 
+  const int c0 = blockIdx.y * a.chunks_per_split;
+  const int c1 = min(a.nchunks, c0 + a.chunks_per_split);
+  // prologue: one DMA round trip for both raw tiles and the first weight slices (the accumulator zeroing
+  // overlaps it), then the first input transform
+  issue_raw(c0, 0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) issue_u(c0, 0, i);
+  issue_raw(min(c0 + 1, c1 - 1), 1);
   f32x16 acc[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
-
-  const int c0 = blockIdx.y * a.chunks_per_split;
-  const int c1 = min(a.nchunks, c0 + a.chunks_per_split);
-  issue_raw(c0, 0);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) issue_u(c0, 0, i);
   __syncthreads();
   tf_load(0);
   tf_rows();
 #pragma unroll
   for (int xi = 0; xi < 4; ++xi) tf_cols_store(xi, 0);
-  if (c0 + 1 < c1) issue_raw(c0 + 1, 1);
   __syncthreads();
 
   const int frag_u = (mbase + l31) * 8 + half * 4, frag_v = (nbase + l31) * 8 + half * 4;
@@ -1170,6 +1171,115 @@ __global__ __launch_bounds__(256) void gemm_c8_kernel(GemmArgs a) {
     }
 }
 
+// Same GEMM, software-pipelined by hand (see the scheduling notes in conv3x3_wino_kernel): branch-free stage body,
+// operand fragments double-buffered in registers one K chunk ahead, each chunk's first MFMA issued BEFORE the next
+// chunk's fragment loads (so the lgkmcnt(0) the compiler forces after LDS-DMA only covers loads issued 15 MFMAs
+// earlier), the next stage's DMA spread behind MFMAs 1-4 of the first chunk, and the stage barrier placed before the
+// LAST chunk's MFMAs so the next stage's first fragments are fetched under them.
+template <int KCH>
+__global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
+  constexpr int OP_FLOATS = KCH * 128 * 8;
+  constexpr int STAGE = 2 * OP_FLOATS;
+  constexpr int IT = OP_FLOATS / 256 / 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  int b = blockIdx.x;
+  const int nb = gridDim.x;
+  if ((nb & 7) == 0) b = (b & 7) * (nb >> 3) + (b >> 3);
+  const int nt = b / a.n_mt, mt = b - nt * a.n_mt;
+  const int n0 = nt * 128, m0 = mt * 128;
+  const int split = blockIdx.y;
+  const int st0 = split * a.stages_per_split;
+  const int st1 = min(a.nstages, st0 + a.stages_per_split);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  int a_off[IT], b_off[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    int p = (i * 4 + wave) * 64 + lane;
+    int kk = p >> 8, rem = p & 255;
+    a_off[i] = (kk * a.NP + n0) * 8 + rem * 4;
+    b_off[i] = (kk * a.Mp + m0) * 8 + rem * 4;
+  }
+  const size_t a_stage = (size_t)KCH * a.NP * 8, b_stage = (size_t)KCH * a.Mp * 8;
+  auto issue_a = [&](int st, int s, int i) { glds16(a.wpk + (size_t)st * a_stage + a_off[i], lds + s * STAGE + (i * 4 + wave) * 256); };
+  auto issue_b = [&](int st, int s, int i) { glds16(a.x + (size_t)st * b_stage + b_off[i], lds + s * STAGE + OP_FLOATS + (i * 4 + wave) * 256); };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+  const int lane_off = l31 * 8 + half * 4;
+  f32x4 af[2][2], bf[2][2];
+  auto load_frags = [&](int s, int kk, int slot) {
+    const float *Al = lds + s * STAGE + lane_off, *Bl = Al + OP_FLOATS;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) af[slot][mi] = *reinterpret_cast<const f32x4 *>(Al + (kk * 128 + wm * 64 + mi * 32) * 8);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) bf[slot][ni] = *reinterpret_cast<const f32x4 *>(Bl + (kk * 128 + wn * 64 + ni * 32) * 8);
+  };
+#pragma unroll
+  for (int i = 0; i < IT; ++i) { issue_a(st0, 0, i); issue_b(st0, 0, i); }
+  __syncthreads();
+  load_frags(0, 0, 0);
+
+  static_assert(KCH % 2 == 0, "fragment slot parity assumes an even chunk count per stage");
+  auto body = [&](int st, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    const int s = (st - st0) & 1;
+#pragma unroll
+    for (int kk = 0; kk < KCH; ++kk) {
+      const int cur = kk & 1;
+      if (kk == KCH - 1 && MORE) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's last reads of stage s are done
+        __syncthreads();
+        load_frags(s ^ 1, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int j = t >> 2, mi = (t >> 1) & 1, ni = t & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][mi][j], bf[cur][ni][j], acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t == 0 && kk + 1 < KCH) load_frags(s, kk + 1, cur ^ 1);
+        if constexpr (MORE) {
+          if (kk == 0 && t >= 1 && t <= IT) { issue_a(st + 1, s ^ 1, t - 1); issue_b(st + 1, s ^ 1, t - 1); }
+        }
+      }
+    }
+  };
+  for (int st = st0; st < st1 - 1; ++st) body(st, std::true_type{});
+  if (st0 < st1) body(st1 - 1, std::false_type{});
+
+  float *yb = a.y + (a.direct ? (size_t)0 : (size_t)split * (a.NP / 8) * a.Mp * 8);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nb8 = (n0 + wm * 64 + mi * 32) / 8 + g;
+      f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a.direct) b4 = *reinterpret_cast<const f32x4 *>(a.bpk + nb8 * 8 + half * 4);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int m = m0 + wn * 64 + ni * 32 + l31;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = acc[mi][ni][g * 4 + e] + b4[e];
+          if (a.direct && a.relu) t = t < 0.0f ? 0.0f : t;
+          v[e] = t;
+        }
+        if (m < a.M) *reinterpret_cast<f32x4 *>(yb + ((size_t)nb8 * a.Mp + m) * 8 + half * 4) = v;
+      }
+    }
+}
+
 // sums the split-K slabs in split order (deterministic), adds bias, ReLU; writes C8 and/or row-major
 __global__ void splitk_reduce_kernel(const float *__restrict__ part, int S, int NP, int Mp, int M, int N,
                                      const float *__restrict__ bpk, int relu, float *__restrict__ y_c8,
@@ -1206,7 +1316,7 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ part, int S, int 
 
 static int g_gemm_regstage = 0;  // (retired; kept so the debug hook stays a no-op)
 static int g_gemm_kch = 0;       // test/bench hook: force 4 or 8 K chunks per stage
-static int g_gemm_nbuf = 2;      // LDS ring depth for the 32-k kernel (2 or 3)
+static int g_gemm_nbuf = 4;      // 4 = hand-pipelined kernel (default, +5% on fc6/fc7); 2 / 3 = plain kernel with a 2- / 3-deep LDS ring
 static int g_gemm_split = 0;  // test/bench hook: force a split-K factor
 static float *g_splitk_ws = nullptr;
 static size_t g_splitk_ws_bytes = 0;
@@ -1240,6 +1350,8 @@ int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float
     MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_c8_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 4 * 128 * 8 * 4));
     MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_c8_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 8 * 128 * 8 * 4));
     MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_c8_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 4 * 128 * 8 * 4));
+    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_c8_pf_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 4 * 128 * 8 * 4));
+    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_c8_pf_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 8 * 128 * 8 * 4));
     attr = true;
   }
   if (direct) {
@@ -1256,7 +1368,9 @@ int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float
     a.y = g_splitk_ws;
   }
   dim3 grid((unsigned)tiles, (unsigned)S);
-  if (kch == 8) hipLaunchKernelGGL((gemm_c8_kernel<8, 2>), grid, dim3(256), (size_t)2 * 2 * 8 * 128 * 8 * 4, s, a);
+  if (g_gemm_nbuf == 4 && kch == 8) hipLaunchKernelGGL((gemm_c8_pf_kernel<8>), grid, dim3(256), (size_t)2 * 2 * 8 * 128 * 8 * 4, s, a);
+  else if (g_gemm_nbuf == 4) hipLaunchKernelGGL((gemm_c8_pf_kernel<4>), grid, dim3(256), (size_t)2 * 2 * 4 * 128 * 8 * 4, s, a);
+  else if (kch == 8) hipLaunchKernelGGL((gemm_c8_kernel<8, 2>), grid, dim3(256), (size_t)2 * 2 * 8 * 128 * 8 * 4, s, a);
   else if (g_gemm_nbuf == 3) hipLaunchKernelGGL((gemm_c8_kernel<4, 3>), grid, dim3(256), (size_t)3 * 2 * 4 * 128 * 8 * 4, s, a);
   else hipLaunchKernelGGL((gemm_c8_kernel<4, 2>), grid, dim3(256), (size_t)2 * 2 * 4 * 128 * 8 * 4, s, a);
   MPN_CHECK_LAUNCH();
@@ -1647,7 +1761,7 @@ extern "C" void mpn_debug_set_conv_split(int v) { g_conv_split = v; }
 extern "C" void mpn_debug_set_conv_mode(int v) { g_conv_mode = v; }  // 1 = persistent stream-K, 0 = block per tile
 extern "C" void mpn_debug_set_gemm_split(int v) { g_gemm_split = v; }
 extern "C" void mpn_debug_set_gemm_kch(int v) { g_gemm_kch = (v == 4 || v == 8) ? v : 0; }
-extern "C" void mpn_debug_set_gemm_nbuf(int v) { g_gemm_nbuf = (v == 3) ? 3 : 2; }
+extern "C" void mpn_debug_set_gemm_nbuf(int v) { g_gemm_nbuf = (v == 2 || v == 3) ? v : 4; }  // 0 / 4 = default hand-pipelined kernel
 extern "C" void mpn_debug_set_gemm_ablate(int v) { g_gemm_ablate = v; }
 
 // Kernel-only timing of one conv layer / one linear layer in the pipeline's own layouts (tools/bench_layers.py).

@@ -130,9 +130,11 @@ def test_split_batch_invariance_exact(O, dev):
     assert (full - parts).abs().max().item() == 0
 
 
-@pytest.mark.parametrize("M,K,N", [(130, 300, 70), (1000, 1024, 512), (64, 25088, 128), (257, 4096, 105)])
-def test_linear_three_stage_ring(O, dev, M, K, N):
-    """the depth-2-prefetch GEMM (3 LDS buffers, counted vmcnt + raw s_barrier) gives bit-identical results to the
+@pytest.mark.parametrize("nbuf", [3, 4])
+@pytest.mark.parametrize("M,K,N", [(130, 300, 70), (1000, 1024, 512), (64, 25088, 128), (257, 4096, 105), (5, 8, 3)])
+def test_linear_three_stage_ring(O, dev, M, K, N, nbuf):
+    """the depth-2-prefetch GEMM (nbuf 3: 3 LDS buffers, counted vmcnt + raw s_barrier) and the hand-pipelined GEMM
+    (nbuf 4: register-prefetched fragments, barrier before the last chunk) give bit-identical results to the plain
     2-buffer kernel (same k order) — run several times to screen for DMA/read races"""
     import multipathnet_amd
     lib = multipathnet_amd.load()
@@ -140,13 +142,14 @@ def test_linear_three_stage_ring(O, dev, M, K, N):
     x = rng.standard_normal((M, K)).astype(np.float32)
     w = (rng.standard_normal((N, K)) * (1.0 / K) ** 0.5).astype(np.float32)
     b = rng.standard_normal(N).astype(np.float32)
-    base = _linear(dev, x, w, b, relu=True).clone()
-    lib.mpn_debug_set_gemm_nbuf(3)
     try:
+        lib.mpn_debug_set_gemm_nbuf(2)
+        base = _linear(dev, x, w, b, relu=True).clone()
+        lib.mpn_debug_set_gemm_nbuf(nbuf)
         for _ in range(5):
             assert torch.equal(_linear(dev, x, w, b, relu=True), base)
     finally:
-        lib.mpn_debug_set_gemm_nbuf(2)
+        lib.mpn_debug_set_gemm_nbuf(0)
     assert np.abs(base.cpu().numpy() - O.linear(x, w, b, relu=True)).max() < 1e-4 * max(1.0, float(base.abs().max()))
 
 

@@ -23,7 +23,7 @@ for (ci, co, hh, ww, pool) in layers:
     tot_ms += ms.value; tot_fl += fl
     print("conv %3d->%3d %4dx%-4d pool=%d  %8.1f us  %6.1f TF/s (%4.1f%%) rc=%d" % (ci, co, hh, ww, pool, ms.value * 1e3, fl / ms.value / 1e9, fl / ms.value / 1e9 / 1.573, rc))
 print("trunk total %.3f ms  %.1f TF/s" % (tot_ms, tot_fl / tot_ms / 1e9))
-for (M, K, N, gs) in [(1000, 25088, 4096, 2), (1000, 25088, 4096, 3), (1000, 4096, 4096, 2), (1000, 4096, 4096, 3), (1000, 4096, 105, 2), (1000, 4096, 105, 3)]:
+for (M, K, N, gs) in [(1000, 25088, 4096, 2), (1000, 25088, 4096, 3), (1000, 25088, 4096, 4), (1000, 4096, 4096, 2), (1000, 4096, 4096, 4), (1000, 4096, 105, 2), (1000, 4096, 105, 4)]:
     ms = C.c_float()
     lib.mpn_debug_set_gemm_nbuf(gs)
     rc = lib.mpn_debug_bench_linear(M, K, N, 10, C.byref(ms))
