@@ -305,29 +305,30 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
   const int y0 = tyb * 16, x0 = txb * 16, cout0 = ct * 64;
   const int mbase = (wave >> 1) * 32, nbase = (wave & 1) * 32;
 
+  // DMA sources are (wave-uniform 64-bit base) + (32-bit per-lane byte offset): no 64-bit VALU address arithmetic in
+  // the loop and one offset VGPR per item instead of a 64-bit pair
   constexpr int RAW_IT = (WG_RAW_LOADS + 3) / 4;
-  int raw_off[RAW_IT];
+  unsigned raw_rel[RAW_IT];
 #pragma unroll
   for (int i = 0; i < RAW_IT; ++i) {
     int p = min((i * 4 + wave) * 64 + lane, WG_RAW_PIECES - 1);  // slots past the tile re-load its last piece (never read)
     int r = p / 36, o = p - r * 36;
-    raw_off[i] = ((y0 + r) * a.in_Wp + x0) * 8 + o * 4;
+    raw_rel[i] = (unsigned)(((r * a.in_Wp) * 8 + o * 4) * 4);
   }
-  int u_off[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    int p = (i * 4 + wave) * 64 + lane;
-    int comp = p >> 7, rem = p & 127;
-    u_off[i] = (comp * a.CoutP + cout0) * 8 + rem * 4;
-  }
+  // weight slice item i of this wave: component (i*4+wave)/2 (uniform), 16-byte piece (wave&1)*64 + lane of its 64 couts
+  const unsigned u_lane = (unsigned)((((wave & 1) * 64 + lane) * 4) * 4);
   const size_t u_chunk = (size_t)16 * a.CoutP * 8;
+  const float *const in_tile = a.in + (size_t)(y0 * a.in_Wp + x0) * 8;
+  const float *const w_tile = a.wpk + (size_t)cout0 * 8;
   auto issue_raw = [&](int c, int buf) {
+    const float *src = in_tile + (size_t)c * a.in_plane;
 #pragma unroll
     for (int i = 0; i < RAW_IT; ++i)
-      glds16(a.in + (size_t)c * a.in_plane + raw_off[i], raw_lds + buf * WG_RAW_FLOATS + (i * 4 + wave) * 256);
+      glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(src) + (size_t)raw_rel[i]), raw_lds + buf * WG_RAW_FLOATS + (i * 4 + wave) * 256);
   };
   auto issue_u = [&](int c, int buf, int i) {
-    glds16(a.wpk + (size_t)c * u_chunk + u_off[i], u_lds + buf * WG_U_FLOATS + (i * 4 + wave) * 256);
+    const float *slice = w_tile + (size_t)c * u_chunk + (size_t)(((i * 4 + wave) >> 1) * a.CoutP) * 8;  // wave-uniform
+    glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(slice) + (size_t)u_lane), u_lds + buf * WG_U_FLOATS + (i * 4 + wave) * 256);
   };
 
   // input transform: wave w owns tiles 16w..16w+15 (tile rows 2w, 2w+1); lane = tile_local * 4 + channel pair, so the
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(256) void conv3x3_c8p_persistent_kernel(PersistArgs
 }
 
 // Finishes the tiles that a block boundary cut: one block per tile; tiles owned by a single block exit at once.
-template <int BM, int TH>
+template <int BM, int TH, int TW = 32>
 __global__ __launch_bounds__(256) void conv_streamk_fixup_kernel(PersistArgs pa) {
   const ConvArgs &a = pa.c;
   const int t = blockIdx.x;
@@ -782,9 +783,9 @@ __global__ __launch_bounds__(256) void conv_streamk_fixup_kernel(PersistArgs pa)
   if (nseg == 1) return;
   const int ct = t % a.n_ct, sp = t / a.n_ct;
   const int ty = sp / a.tiles_x, tx = sp - ty * a.tiles_x;
-  const int y0 = ty * TH, x0 = tx * 32, cb0 = ct * BM / 8;
+  const int y0 = ty * TH, x0 = tx * TW, cb0 = ct * BM / 8;
   // items: (cb in tile, pooled-or-full row pair, column pair, half) — each thread finishes a 2x2 pixel quad of 4 channels
-  constexpr int QY = TH / 2, QX = 16;
+  constexpr int QY = TH / 2, QX = TW / 2;
   const int items = (BM / 8) * QY * QX * 2;
   for (int it = threadIdx.x; it < items; it += blockDim.x) {
     const int h = it & 1; int r = it >> 1;
@@ -822,10 +823,317 @@ __global__ __launch_bounds__(256) void conv_streamk_fixup_kernel(PersistArgs pa)
   }
 }
 
+// =================================================================================================
+// Winograd conv, persistent stream-K form: P = #CUs blocks, block p runs the contiguous unit range
+// [u0(p), u0(p+1)) of the (tile, 8-channel chunk) stream.  The DMA / transform / MFMA pipeline of
+// conv3x3_wino_kernel simply keeps running across tile boundaries (the next tile's raw tiles and weight slices
+// are already in flight while the finished tile's accumulators are transformed and stored), so the per-tile
+// prologue (a DMA round trip + the first transform, ~4 chunk times with one block per CU) and the round
+// quantisation of a one-block-per-tile grid disappear.  Tiles cut by a block boundary leave raw partial sums in
+// per-segment slabs; conv_streamk_fixup_kernel adds them in block order (deterministic).
+// =================================================================================================
+template <int ABL>
+__global__ __launch_bounds__(256) void conv3x3_wino_persistent_kernel(PersistArgs pa) {
+  const ConvArgs &a = pa.c;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *const raw_lds = lds;
+  float *const v_lds = lds + 2 * WG_RAW_FLOATS;
+  float *const u_lds = v_lds + 2 * WG_V_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int mbase = (wave >> 1) * 32, nbase = (wave & 1) * 32;
+  const int p = blockIdx.x;
+  const int u_begin = sk_u0(p, pa.base, pa.rem), u_end = sk_u0(p + 1, pa.base, pa.rem);
+  if (u_begin >= u_end) return;
+
+  // tile-independent staging offsets (see conv3x3_wino_kernel)
+  // DMA sources are (wave-uniform 64-bit base) + (32-bit per-lane byte offset): the saddr form of global_load_lds,
+  // no 64-bit VALU address arithmetic in the loop and one offset VGPR instead of a 64-bit pair per item
+  constexpr int RAW_IT = (WG_RAW_LOADS + 3) / 4;
+  unsigned raw_rel[RAW_IT];
+#pragma unroll
+  for (int i = 0; i < RAW_IT; ++i) {
+    int q = min((i * 4 + wave) * 64 + lane, WG_RAW_PIECES - 1);
+    int r = q / 36, o = q - r * 36;
+    raw_rel[i] = (unsigned)(((r * a.in_Wp) * 8 + o * 4) * 4);
+  }
+  // weight slice item i of this wave: component (i*4+wave)/2 (uniform), 16-byte piece (wave&1)*64 + lane of its 64 couts
+  const unsigned u_lane = (unsigned)((((wave & 1) * 64 + lane) * 4) * 4);
+  const size_t u_chunk = (size_t)16 * a.CoutP * 8;
+  auto tile_geo = [&](int t, int &y0, int &x0, int &cout0) {
+    const int ct = t % a.n_ct, sp = t / a.n_ct;
+    const int ty = sp / a.tiles_x, tx = sp - ty * a.tiles_x;
+    y0 = ty * 16; x0 = tx * 16; cout0 = ct * 64;
+  };
+  // stream cursors (wave-uniform): a unit's raw-tile source and weight-slice source
+  struct Cur { int t, c; const float *in, *w; };
+  auto decode = [&](Cur &k) {
+    int y0, x0, cout0;
+    tile_geo(k.t, y0, x0, cout0);
+    k.in = a.in + (size_t)k.c * a.in_plane + (size_t)(y0 * a.in_Wp + x0) * 8;
+    k.w = a.wpk + (size_t)k.c * u_chunk + (size_t)cout0 * 8;
+  };
+  auto advance = [&](Cur &k) {
+    if (++k.c < a.nchunks) { k.in += a.in_plane; k.w += u_chunk; }
+    else { k.c = 0; ++k.t; decode(k); }
+  };
+  auto issue_raw = [&](const float *src, int buf) {
+#pragma unroll
+    for (int i = 0; i < RAW_IT; ++i)
+      glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(src) + (size_t)raw_rel[i]), raw_lds + buf * WG_RAW_FLOATS + (i * 4 + wave) * 256);
+  };
+  auto issue_u = [&](const float *src, int buf, int i) {
+    const float *slice = src + (size_t)(((i * 4 + wave) >> 1) * a.CoutP) * 8;  // wave-uniform
+    glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(slice) + (size_t)u_lane), u_lds + buf * WG_U_FLOATS + (i * 4 + wave) * 256);
+  };
+
+  const int tf_tile = wave * 16 + (lane >> 2), tf_cp = lane & 3;
+  const int tf_rd = ((2 * (tf_tile >> 3)) * 18 + 2 * (tf_tile & 7)) * 8 + 2 * tf_cp;
+  const int tf_wr = tf_tile * 8 + 2 * tf_cp;
+  f32x2 d[16], t[16];
+  auto tf_load = [&](int buf) {
+    const float *R = raw_lds + buf * WG_RAW_FLOATS + tf_rd;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[r * 4 + q] = *reinterpret_cast<const f32x2 *>(R + (r * 18 + q) * 8);
+  };
+  auto tf_rows = [&]() {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      t[0 + q] = d[0 + q] - d[8 + q];
+      t[4 + q] = d[4 + q] + d[8 + q];
+      t[8 + q] = d[8 + q] - d[4 + q];
+      t[12 + q] = d[4 + q] - d[12 + q];
+    }
+  };
+  auto tf_cols_store = [&](int xi, int buf) {
+    float *Vw = v_lds + buf * WG_V_FLOATS + tf_wr + xi * 4 * 512;
+    *reinterpret_cast<f32x2 *>(Vw + 0 * 512) = t[xi * 4 + 0] - t[xi * 4 + 2];
+    *reinterpret_cast<f32x2 *>(Vw + 1 * 512) = t[xi * 4 + 1] + t[xi * 4 + 2];
+    *reinterpret_cast<f32x2 *>(Vw + 2 * 512) = t[xi * 4 + 2] - t[xi * 4 + 1];
+    *reinterpret_cast<f32x2 *>(Vw + 3 * 512) = t[xi * 4 + 1] - t[xi * 4 + 3];
+  };
+
+  Cur cu, cr;  // cu: the unit whose weight slices are DMA'd next (u+1); cr: the unit whose raw tile is DMA'd next (u+2)
+  cu.t = u_begin / a.nchunks; cu.c = u_begin - cu.t * a.nchunks;
+  decode(cu);
+  int tcur = cu.t;  // the tile on the matrix pipe
+  issue_raw(cu.in, 0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) issue_u(cu.w, 0, i);
+  if (u_begin + 1 < u_end) advance(cu);
+  issue_raw(cu.in, 1);
+  cr = cu;
+  if (u_begin + 2 < u_end) advance(cr);
+  f32x16 acc[16];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+  };
+  zero_acc();
+  __syncthreads();
+  tf_load(0);
+  tf_rows();
+#pragma unroll
+  for (int xi = 0; xi < 4; ++xi) tf_cols_store(xi, 0);
+  __syncthreads();
+
+  const int frag_u = (mbase + l31) * 8 + half * 4, frag_v = (nbase + l31) * 8 + half * 4;
+  f32x4 af[2][2], bf[2][2];
+  auto load_frags = [&](int buf, int pr, int slot) {
+    const float *Ul = u_lds + buf * WG_U_FLOATS + frag_u, *Vl = v_lds + buf * WG_V_FLOATS + frag_v;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      af[slot][k] = *reinterpret_cast<const f32x4 *>(Ul + (2 * pr + k) * 512);
+      bf[slot][k] = *reinterpret_cast<const f32x4 *>(Vl + (2 * pr + k) * 512);
+    }
+  };
+  load_frags(0, 0, 0);
+
+  // one unit on the matrix pipe (scheduling as in conv3x3_wino_kernel)
+  auto body = [&](int s, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
+#pragma unroll
+    for (int pp = 0; pp < 8; ++pp) {
+      const int cur = pp & 1;
+      if (pp == 7 && MORE) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if constexpr (!(ABL & 2)) __syncthreads();
+        if constexpr (!(ABL & 16)) load_frags(s ^ 1, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[2 * pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0][0], bf[cur][0][0], acc[2 * pp], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (pp + 1 < 8 && !(ABL & 16)) load_frags(s, pp + 1, cur ^ 1);
+      if constexpr (MORE) {
+        if (pp == 0 && !(ABL & 4)) tf_load(s ^ 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][1][0], bf[cur][1][0], acc[2 * pp + 1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (MORE) {
+        if constexpr (!(ABL & 1)) {
+          if (pp == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) issue_u(cu.w, s ^ 1, i);
+            issue_raw(cr.in, s);
+          }
+          if (pp == 1) {
+#pragma unroll
+            for (int i = 4; i < 8; ++i) issue_u(cu.w, s ^ 1, i);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[2 * pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0][1], bf[cur][0][1], acc[2 * pp], 0, 0, 0);
+      acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][1][1], bf[cur][1][1], acc[2 * pp + 1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (MORE) {
+        if constexpr (!(ABL & 4)) {
+          if (pp == 1) tf_rows();
+          if (pp >= 2 && pp <= 5) tf_cols_store(pp - 2, s ^ 1);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 2; j < 4; ++j) {
+        acc[2 * pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0][j], bf[cur][0][j], acc[2 * pp], 0, 0, 0);
+        acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][1][j], bf[cur][1][j], acc[2 * pp + 1], 0, 0, 0);
+      }
+    }
+  };
+
+  // end of a tile segment: output transform A^T M A (register-local), then either the finished layer output
+  // (bias, ReLU, fused 2x2 max-pool) or raw partial sums into this segment's slab
+  const int tau = nbase + l31;
+  auto finish_segment = [&](int tt, bool whole, int slab) {
+    if constexpr ((ABL & 8) != 0) {
+      if (a.H < 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x16 *>(a.part + (size_t)k * 16 + lane * 256) = acc[k];
+      }
+      return;
+    }
+    int y0, x0, cout0;
+    tile_geo(tt, y0, x0, cout0);
+    const int y = y0 + 2 * (tau >> 3), x = x0 + 2 * (tau & 7);
+    // wave-uniform 64-bit bases + one 32-bit per-lane offset (a channel-block plane is far below 4 GiB)
+    const int pix = ((y + 1) * a.out_Wp + x + 1) * 8 + half * 4;
+    float *const pb = a.part + (size_t)slab * a.part_slab;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cb = __builtin_amdgcn_readfirstlane((cout0 + mbase) / 8 + g);
+      if (cb >= a.out_cb) continue;
+      f32x4 Y[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = g * 4 + e;
+        const float s0 = acc[0][r] + acc[4][r] + acc[8][r], s1 = acc[1][r] + acc[5][r] + acc[9][r];
+        const float s2 = acc[2][r] + acc[6][r] + acc[10][r], s3 = acc[3][r] + acc[7][r] + acc[11][r];
+        const float q0 = acc[4][r] - acc[8][r] - acc[12][r], q1 = acc[5][r] - acc[9][r] - acc[13][r];
+        const float q2 = acc[6][r] - acc[10][r] - acc[14][r], q3 = acc[7][r] - acc[11][r] - acc[15][r];
+        Y[0][e] = s0 + s1 + s2; Y[1][e] = s1 - s2 - s3;
+        Y[2][e] = q0 + q1 + q2; Y[3][e] = q1 - q2 - q3;
+      }
+      if (!whole) {
+        float *const dst = pb + (size_t)cb * a.out_plane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int yy = y + (k >> 1), xx = x + (k & 1);
+          if (yy < a.H && xx < a.W) *reinterpret_cast<f32x4 *>(dst + pix + ((k >> 1) * a.out_Wp + (k & 1)) * 8) = Y[k];
+        }
+        continue;
+      }
+      const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bpk + cb * 8 + half * 4);
+      f32x4 m = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      float *const dst = a.out ? a.out + (size_t)cb * a.out_plane : nullptr;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int yy = y + (k >> 1), xx = x + (k & 1);
+        const bool ok = yy < a.H && xx < a.W;
+        f32x4 v = Y[k] + b4;
+        if (a.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.0f ? 0.0f : v[e];
+        }
+        if (ok && dst) *reinterpret_cast<f32x4 *>(dst + pix + ((k >> 1) * a.out_Wp + (k & 1)) * 8) = v;
+        if (ok) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+        }
+      }
+      if (a.pool) {
+        const int py = y >> 1, px = x >> 1;
+        if (py < a.pool_H && px < a.pool_W)
+          *reinterpret_cast<f32x4 *>(a.pool + (size_t)cb * a.pool_plane + ((py + 1) * a.pool_Wp + px + 1) * 8 + half * 4) = m;
+      }
+    }
+  };
+
+  // outer loop: tile segments; inner loop: the branch-free MFMA pipeline.  (The epilogue stays out of the inner
+  // loop so that its address arithmetic is not hoisted into — and spilled inside — the hot loop.)
+  int u = u_begin, seg_first = u_begin;
+  while (true) {
+    const int tile_end = (tcur + 1) * a.nchunks;
+    const bool last_seg = tile_end >= u_end;
+    const int seg_end = last_seg ? u_end : tile_end;
+    const int inner_end = last_seg ? seg_end - 1 : seg_end;
+    for (; u < inner_end; ++u) {
+      body((u - u_begin) & 1, std::true_type{});
+      if (u + 2 < u_end) advance(cu);
+      if (u + 3 < u_end) advance(cr);
+    }
+    if (last_seg) { body((u - u_begin) & 1, std::false_type{}); ++u; }
+    const bool whole = (seg_first == tcur * a.nchunks) && (seg_end == tile_end);
+    finish_segment(tcur, whole, p - sk_block_of(tcur * a.nchunks, pa.base, pa.rem));
+    if (last_seg) break;
+    zero_acc();
+    ++tcur;
+    seg_first = u;
+  }
+}
+
+template <int ABL>
+static int launch_conv_wino_persistent_t(PersistArgs &pa, hipStream_t s) {
+  auto kern = conv3x3_wino_persistent_kernel<ABL>;
+  static bool attr = false;
+  if (!attr) {
+    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS_BYTES));
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(pa.P), dim3(256), WG_LDS_BYTES, s, pa);
+  MPN_CHECK_LAUNCH();
+  if (pa.U % pa.P != 0 || pa.base % pa.c.nchunks != 0) {  // some tile is cut by a block boundary
+    hipLaunchKernelGGL((conv_streamk_fixup_kernel<64, 16, 16>), dim3(pa.T), dim3(256), 0, s, pa);
+    MPN_CHECK_LAUNCH();
+  }
+  return MPN_OK;
+}
+
+static int launch_conv_wino_persistent(PersistArgs &pa, hipStream_t s) {
+  switch (pa.c.ablate) {  // timing experiments only (wrong results)
+    case 1: return launch_conv_wino_persistent_t<1>(pa, s);
+    case 2: return launch_conv_wino_persistent_t<2>(pa, s);
+    case 4: return launch_conv_wino_persistent_t<4>(pa, s);
+    case 8: return launch_conv_wino_persistent_t<8>(pa, s);
+    case 7: return launch_conv_wino_persistent_t<7>(pa, s);
+    case 15: return launch_conv_wino_persistent_t<15>(pa, s);
+    case 31: return launch_conv_wino_persistent_t<31>(pa, s);
+    default: return launch_conv_wino_persistent_t<0>(pa, s);
+  }
+}
+
 // Measured on MI355X (tools/bench_layers.py, tools/conv_shape_probe.py): the persistent stream-K kernel removes round
 // quantisation but its K loop runs 3-5 % slower than the plain kernel's (extra scalar state around the MFMA blocks), and a
 // deferred (interleaved) epilogue made it 15 % slower — so the VGG trunk is 3.69 ms with it vs 3.52 ms block-per-tile +
 // split-K.  It therefore stays an option (mode 1), fully parity-tested; the default is mode 0.
+// The persistent Winograd kernel is 2-3 % faster than block-per-tile in isolation (trunk 2.22 vs 2.28 ms), but a grid that
+// pins one 155-KB-LDS block on every CU for the whole layer leaves the pipelined detector's NMS / top-k side stream
+// nowhere to run: end to end it is SLOWER (233.6k vs 241.7k proposals/s).  Default = block per tile.
 static int g_conv_mode = 0;  // 0 = one block per tile (+ split-K, default), 1 = persistent stream-K
 static int g_num_cus = 0;
 
@@ -937,10 +1245,38 @@ int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int re
     const int tiles_y = cdiv(in.H, 16);
     a.n_ct = cdiv(Cout, 64);
     const int blocks = a.n_ct * tiles_y * a.tiles_x;
+    Act geo = out.p ? out : make_act(nullptr, Cout, in.H, in.W);
+    if (g_conv_mode == 1 && g_conv_split == 0) {  // persistent stream-K (opt-in, see the note at g_conv_mode)
+      if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        MPN_CHECK_HIP(hipGetDevice(&dev));
+        MPN_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+        g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      }
+      PersistArgs pa{};
+      pa.T = blocks; pa.U = blocks * a.nchunks; pa.tiles_y = tiles_y;
+      pa.P = pa.U < g_num_cus ? pa.U : g_num_cus;
+      pa.base = pa.U / pa.P; pa.rem = pa.U % pa.P;
+      a.out_plane = geo.plane(); a.out_Wp = geo.Wp;
+      a.part_slab = geo.elems();
+      const int nseg_max = (a.nchunks - 1) / pa.base + 2;  // blocks that can cut one tile
+      const size_t need = a.part_slab * (size_t)nseg_max * sizeof(float);
+      if (need > g_conv_ws_bytes) {
+        MPN_CHECK_HIP(hipStreamSynchronize(s));
+        if (g_conv_ws) (void)hipFree(g_conv_ws);
+        g_conv_ws = nullptr; g_conv_ws_bytes = 0;
+        MPN_CHECK_HIP(hipMalloc(&g_conv_ws, need));
+        g_conv_ws_bytes = need;
+      }
+      a.part = g_conv_ws;
+      a.splits = 1; a.chunks_per_split = a.nchunks;
+      pa.c = a;
+      return launch_conv_wino_persistent(pa, s);
+    }
     a.splits = conv_pick_splits(blocks, a.nchunks, 256);
     a.chunks_per_split = cdiv(a.nchunks, a.splits);
     a.splits = cdiv(a.nchunks, a.chunks_per_split);
-    Act geo = out.p ? out : make_act(nullptr, Cout, in.H, in.W);
     if (a.splits > 1) {
       a.part_slab = geo.elems();
       a.out_plane = geo.plane(); a.out_Wp = geo.Wp;

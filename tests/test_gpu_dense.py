@@ -23,7 +23,7 @@ def _conv(dev, x, w, b, relu=True):
 @pytest.mark.parametrize("ci,co,h,w", [(3, 64, 40, 70), (8, 64, 33, 31), (64, 64, 19, 45), (64, 128, 16, 96), (128, 256, 9, 33),
                                        (24, 40, 8, 8), (16, 200, 5, 37), (256, 512, 12, 20)])
 @pytest.mark.parametrize("variant,split,mode", [(0, 0, 1), (1, 0, 1), (2, 0, 1), (0, 0, 0), (1, 0, 0), (2, 0, 0), (3, 0, 0), (4, 0, 0), (5, 0, 0), (6, 0, 0), (5, 2, 0), (6, 3, 0),
-                                                (1, 2, 0), (2, 3, 0), (3, 2, 0), (4, 3, 0), (0, 4, 0), (7, 0, 0), (7, 2, 0), (7, 3, 0)])
+                                                (1, 2, 0), (2, 3, 0), (3, 2, 0), (4, 3, 0), (0, 4, 0), (7, 0, 0), (7, 0, 1), (7, 2, 0), (7, 3, 0)])
 def test_conv3x3_vs_oracle(O, dev, ci, co, h, w, variant, split, mode):
     """mode 0 = one block per tile (+ split-K; default), 1 = persistent stream-K kernel; variant 7 = Winograd F(2x2,3x3)"""
     import multipathnet_amd
@@ -173,3 +173,31 @@ def test_conv_streamk_cut_tiles_deterministic(O, dev):
     ref = O.conv3x3(x, wt, b, relu=True)
     assert np.abs(a - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
     assert np.abs(a - c).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("ci,co,h,w", [(72, 200, 75, 125), (64, 64, 150, 200), (256, 96, 40, 333)])
+def test_conv_wino_streamk_deterministic(O, dev, ci, co, h, w):
+    """the persistent Winograd kernel on layers whose tiles are cut by block boundaries: bit-identical run after run
+    (fixed-order slab sums), equal to the block-per-tile Winograd kernel within fp32 reassociation, and within the
+    north_star tolerance of the oracle"""
+    import multipathnet_amd
+    lib = multipathnet_amd.load()
+    rng = np.random.default_rng(ci + co)
+    x = rng.standard_normal((ci, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((co, ci, 3, 3)) * (2.0 / (ci * 9)) ** 0.5).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32)
+    lib.mpn_debug_set_conv_variant(7)
+    lib.mpn_debug_set_conv_mode(1)
+    try:
+        a = _conv(dev, x, wt, b)
+        for _ in range(3):
+            assert np.array_equal(_conv(dev, x, wt, b), a)
+        lib.mpn_debug_set_conv_mode(0)
+        c = _conv(dev, x, wt, b)
+    finally:
+        lib.mpn_debug_set_conv_mode(0)
+        lib.mpn_debug_set_conv_variant(0)
+    ref = O.conv3x3(x, wt, b, relu=True)
+    tol = 1e-4 * max(1.0, np.abs(ref).max())
+    assert np.abs(a - ref).max() < tol
+    assert np.abs(a - c).max() < tol

@@ -27,4 +27,10 @@ for key, c in sorted(acc.items(), key=lambda kv: -kv[1].get("_dur_us", 0)):
         if k in c and c.get("SQ_WAVE_CYCLES"): line += " %s=%4.1f%%" % (k[3:], 100 * c[k] / c["SQ_WAVE_CYCLES"])
     for k in ("SQ_LDS_BANK_CONFLICT", "FETCH_SIZE", "WRITE_SIZE"):
         if k in c: line += " %s=%.3g" % (k, c[k] / n)
+    known = {"GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+             "SQ_LDS_BANK_CONFLICT", "FETCH_SIZE", "WRITE_SIZE", "_dur_us"}
+    for k in sorted(c):  # any other counter: per-dispatch average and its share of SQ_WAVE_CYCLES
+        if k not in known:
+            line += " %s=%.3g" % (k, c[k] / n)
+            if c.get("SQ_WAVE_CYCLES"): line += "(%.1f%%)" % (100 * c[k] / c["SQ_WAVE_CYCLES"])
     print(line)
