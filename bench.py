@@ -200,6 +200,13 @@ def main():
                          "how": "HIP events on the launch stream around each kernel group, %d profiled steps after the timed region" % args.steps},
             "kernels": kernels,
         }
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC passes cannot run inside the timed process: measured offline
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if dom in tj:
+                out["roofline"]["traffic"] = tj[dom]["bytes_per_launch"]
+                out["roofline"]["traffic_unit"] = "HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)"
+                out["roofline"]["traffic_source"] = tj.get("_source")
         if dom == "conv_wino":  # the MFMA pipe executes 16 multiplies per 4 outputs instead of 36
             out["roofline"]["algorithm"] = ("Winograd F(2x2,3x3) in fp32: 'achieved' counts the ALGORITHMIC flops (2*H*W*Cin*9*Cout); the matrix "
                                             "pipe executes 1/2.25 of them, see executed_*")

@@ -1,0 +1,18 @@
+# Collects the evidence set judged under profiles/ (run on the GPU box: gpurun -- bash tools/collect_profiles.sh r01)
+# $1 = round tag.  Output goes to gpurun_out/prof_<tag>/ ; copy the summaries into profiles/ afterwards.
+TAG=${1:-r01}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+rm -rf /tmp/kt && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt --output-format csv -- python $R/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2> /tmp/kt.err
+cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
+for set in "sq:GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT" "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
+  name=${set%%:*}; ctrs=${set#*:}
+  rm -rf /tmp/pmc_$name
+  timeout 600 rocprofv3 --kernel-trace --pmc $ctrs -d /tmp/pmc_$name -o p --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /tmp/pmc_$name.log 2>&1
+  D=$(dirname $(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1))
+  python $R/tools/pmc_summary.py $D > $OUT/${TAG}_pmc_$name.summary.txt 2>&1
+done
+ls -la $OUT
