@@ -35,6 +35,23 @@ __device__ __forceinline__ void glds16(const float *gsrc, float *lds_wave_base) 
   __builtin_amdgcn_global_load_lds(MPN_GPTR(gsrc), MPN_LPTR(lds_wave_base), 16, 0, 0);
 }
 
+// LDS-DMA with the address split the way the hardware takes it: wave-uniform 64-bit base in SGPRs + one 32-bit per-lane
+// byte offset (the SADDR form).  The builtin always materialises a 64-bit per-lane address with VALU instructions, and on
+// this chip VALU work from a wave does NOT overlap its MFMAs (tools/probes/mfma_shadow.cpp: every VALU instruction
+// between two MFMAs costs its issue time plus ~20 cycles for breaking the MFMA stream), so the inner loops issue their
+// DMA through this.  The compiler does not know these loads exist: callers wait with dma_wait_all() before the barrier
+// that publishes the data (and get counted lgkmcnt waits instead of the lgkmcnt(0) it forces after a builtin LDS-DMA).
+__device__ __forceinline__ void glds16_saddr(const float *base_uniform, unsigned lane_byte_off, unsigned lds_byte_addr_uniform) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               :
+               : "s"(lds_byte_addr_uniform), "v"(lane_byte_off), "s"(base_uniform)
+               : "memory");  // M0 is not in the clobber list (reserved): kernels that use this issue ALL their LDS-DMA through it
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_byte_addr(const float *p) {
+  return (unsigned)(size_t)((__attribute__((address_space(3))) const float *)p);
+}
+
 // =================================================================================================
 // conv3x3, stride 1, pad 1, C8P in/out
 // =================================================================================================
@@ -49,6 +66,7 @@ struct ConvArgs {
   int splits, chunks_per_split;
   float *part; size_t part_slab;
   int ablate;  // timing experiments only (results wrong): 1 = no DMA in loop, 2 = no barrier, 4 = no ds_reads
+  unsigned long long *trace;  // tools/wino_trace.py: per-chunk s_memtime stamps of wave 0 of blocks 0..3 (Winograd kernel, ABL 64)
 };
 
 // TPS = taps per LDS stage: 9 -> one stage per 8-channel chunk (input tile + all 9 taps' weights);
@@ -320,15 +338,18 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
   const size_t u_chunk = (size_t)16 * a.CoutP * 8;
   const float *const in_tile = a.in + (size_t)(y0 * a.in_Wp + x0) * 8;
   const float *const w_tile = a.wpk + (size_t)cout0 * 8;
+  const unsigned lds0 = lds_byte_addr(lds);  // LDS byte address of the dynamic segment (wave-uniform)
+  const unsigned raw_slot = lds0 + (unsigned)(wave * 256) * 4, u_slot = lds0 + (unsigned)(2 * WG_RAW_FLOATS + 2 * WG_V_FLOATS + wave * 256) * 4;
+  auto issue_raw_item = [&](int c, int buf, int i) {
+    glds16_saddr(in_tile + (size_t)c * a.in_plane, raw_rel[i], raw_slot + (unsigned)(buf * WG_RAW_FLOATS + i * 1024) * 4);
+  };
   auto issue_raw = [&](int c, int buf) {
-    const float *src = in_tile + (size_t)c * a.in_plane;
 #pragma unroll
-    for (int i = 0; i < RAW_IT; ++i)
-      glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(src) + (size_t)raw_rel[i]), raw_lds + buf * WG_RAW_FLOATS + (i * 4 + wave) * 256);
+    for (int i = 0; i < RAW_IT; ++i) issue_raw_item(c, buf, i);
   };
   auto issue_u = [&](int c, int buf, int i) {
     const float *slice = w_tile + (size_t)c * u_chunk + (size_t)(((i * 4 + wave) >> 1) * a.CoutP) * 8;  // wave-uniform
-    glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(slice) + (size_t)u_lane), u_lds + buf * WG_U_FLOATS + (i * 4 + wave) * 256);
+    glds16_saddr(slice, u_lane, u_slot + (unsigned)(buf * WG_U_FLOATS + i * 1024) * 4);
   };
 
   // input transform: wave w owns tiles 16w..16w+15 (tile rows 2w, 2w+1); lane = tile_local * 4 + channel pair, so the
@@ -362,6 +383,29 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
     *reinterpret_cast<f32x2 *>(Vw + 3 * 512) = t[xi * 4 + 1] - t[xi * 4 + 3];
   };
 
+  // the same work cut into single-shadow items for the loop schedule below
+  auto tf_load_item = [&](int buf, int i) {  // two adjacent pixels of one patch row: one ds_read2_b64
+    const float *R = raw_lds + buf * WG_RAW_FLOATS + tf_rd + ((i >> 1) * 18 + (i & 1) * 2) * 8;
+    d[2 * i] = *reinterpret_cast<const f32x2 *>(R);
+    d[2 * i + 1] = *reinterpret_cast<const f32x2 *>(R + 8);
+  };
+  auto tf_rows_item = [&](int q) {  // column q of t = B^T d: 4 packed adds
+    t[0 + q] = d[0 + q] - d[8 + q];
+    t[4 + q] = d[4 + q] + d[8 + q];
+    t[8 + q] = d[8 + q] - d[4 + q];
+    t[12 + q] = d[4 + q] - d[12 + q];
+  };
+  auto tf_cols_compute = [&](int xi) {  // V[xi][.] = t[xi][.] B, in place of t[xi][.]
+    const f32x2 v0 = t[xi * 4 + 0] - t[xi * 4 + 2], v1 = t[xi * 4 + 1] + t[xi * 4 + 2];
+    const f32x2 v2 = t[xi * 4 + 2] - t[xi * 4 + 1], v3 = t[xi * 4 + 1] - t[xi * 4 + 3];
+    t[xi * 4 + 0] = v0; t[xi * 4 + 1] = v1; t[xi * 4 + 2] = v2; t[xi * 4 + 3] = v3;
+  };
+  auto tf_store_item = [&](int i, int buf) {  // components 2i, 2i+1: one ds_write2st64_b64
+    float *Vw = v_lds + buf * WG_V_FLOATS + tf_wr + (2 * i) * 512;
+    *reinterpret_cast<f32x2 *>(Vw) = t[2 * i];
+    *reinterpret_cast<f32x2 *>(Vw + 512) = t[2 * i + 1];
+  };
+
   const int c0 = blockIdx.y * a.chunks_per_split;
   const int c1 = min(a.nchunks, c0 + a.chunks_per_split);
   // prologue: one DMA round trip for both raw tiles and the first weight slices (the accumulator zeroing
@@ -375,6 +419,7 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
   for (int k = 0; k < 16; ++k)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+  dma_wait_all();
   __syncthreads();
   tf_load(0);
   tf_rows();
@@ -383,17 +428,18 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
   __syncthreads();
 
   const int frag_u = (mbase + l31) * 8 + half * 4, frag_v = (nbase + l31) * 8 + half * 4;
-  // Loop-body scheduling notes (from the ISA):
+  // Loop-body scheduling (from the ISA and an s_memtime trace of the loop, tools/wino_trace.py):
+  //  * a wave issues in order: an instruction placed between two MFMAs runs in the first one's 64-cycle shadow, but
+  //    anything beyond ~60 cycles of issue time in one shadow delays the matrix pipe (a pair with 7 DMA issues + 8
+  //    ds_reads behind its first MFMAs measured 980 cycles instead of 512; one with 4 packed adds + 2 ds_writes in one
+  //    shadow 665).  So the per-chunk side work is cut into 31 single-shadow items (11 DMA issues, 8 ds_read2 of the
+  //    raw patch, 4 row-transform items, 8 column-transform + ds_write2 items) and dealt one per MFMA shadow;
+  //  * the compiler forces every lgkmcnt wait that follows a global_load_lds to lgkmcnt(0) (LDS-DMA is a FLAT op),
+  //    so each pair issues its first MFMA before the NEXT pair's fragment loads (the forced wait then only covers
+  //    loads issued 7 MFMAs earlier) and LDS items are kept out of a pair's last two shadows;
   //  * branch-free: MORE is a compile-time tag (the last chunk runs the no-prefetch copy);
-  //  * the compiler forces every lgkmcnt wait that follows a global_load_lds to lgkmcnt(0) (LDS-DMA is a FLAT op
-  //    that may touch LDS), so a wait placed after the NEXT pair's fragment loads would expose their latency.
-  //    Each pair therefore issues its first MFMA before anything else — the forced wait lands there and only
-  //    covers LDS ops issued >= 6 MFMAs earlier — and the fragment loads / DMA issue / transform slices sit between
-  //    the remaining MFMAs, pinned by sched_barriers.
-  //  * the chunk barrier sits BEFORE the last pair's MFMAs: by then every LDS read of this chunk has been issued
-  //    and waited for (pair 7's fragments are in registers), so after the barrier the next chunk's first fragments
-  //    are fetched under pair 7's 8 MFMAs instead of exposing their latency; all DMA for the next chunk is issued
-  //    in pairs 0-1 so it has ~3000 cycles to land before that barrier's vmcnt(0).
+  //  * the chunk barrier sits before the last pair's MFMAs: every LDS read of the chunk has been issued and waited
+  //    for by then, and the next chunk's first fragments are fetched under pair 7's 8 MFMAs.
   f32x4 af[2][2], bf[2][2];
   auto load_frags = [&](int buf, int pr, int slot) {
     const float *Ul = u_lds + buf * WG_U_FLOATS + frag_u, *Vl = v_lds + buf * WG_V_FLOATS + frag_v;
@@ -404,55 +450,57 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
     }
   };
   load_frags(0, 0, 0);
+  unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
   auto body = [&](int c, auto more_tag) {
     constexpr bool MORE = decltype(more_tag)::value;
     const int s = (c - c0) & 1;
 #pragma unroll
     for (int p = 0; p < 8; ++p) {  // component pair (2p, 2p+1): two independent accumulator chains
       const int cur = p & 1;
+      if constexpr ((ABL & 64) != 0) {
+        if (p == 0) tr0 = __builtin_amdgcn_s_memtime();
+        if (a.trace && blockIdx.x < 4 && blockIdx.y == 0 && tid == 0 && (c - c0) == 5) a.trace[4 * 64 * 4 + blockIdx.x * 8 + p] = __builtin_amdgcn_s_memtime();
+      }
       if (p == 7 && MORE) {
+        if constexpr ((ABL & 64) != 0) tr1 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's last reads of U[s]/V[s] are done before others may overwrite them
+        if constexpr ((ABL & 64) != 0) tr2 = __builtin_amdgcn_s_memtime();
+        dma_wait_all();  // the next chunk's weight slices / raw tile issued by this wave have landed
         if constexpr (!(ABL & 2)) __syncthreads();
+        if constexpr ((ABL & 64) != 0) {
+          const unsigned long long tr3 = __builtin_amdgcn_s_memtime();
+          if (a.trace && blockIdx.x < 4 && blockIdx.y == 0 && tid == 0) {
+            unsigned long long *o = a.trace + ((size_t)blockIdx.x * 64 + (c - c0)) * 4;
+            o[0] = tr0; o[1] = tr1 - tr0; o[2] = tr2 - tr1; o[3] = tr3 - tr2;
+          }
+        }
         if constexpr (!(ABL & 16)) load_frags(s ^ 1, 0, 0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      acc[2 * p] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0][0], bf[cur][0][0], acc[2 * p], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (p + 1 < 8 && !(ABL & 16)) load_frags(s, p + 1, cur ^ 1);
-      if constexpr (MORE) {
-        if (p == 0 && !(ABL & 4)) tf_load(s ^ 1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][1][0], bf[cur][1][0], acc[2 * p + 1], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (MORE) {
-        if constexpr (!(ABL & 1)) {
-          if (p == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) issue_u(c + 1, s ^ 1, i);
-            issue_raw(min(c + 2, c1 - 1), s);  // past the end: a harmless re-load of the last chunk
+      for (int i = 0; i < 8; ++i) {  // MFMA i of the pair: accumulator 2p + (i&1), k-pair i>>1
+        __builtin_amdgcn_sched_barrier(0);
+        acc[2 * p + (i & 1)] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i & 1][i >> 1], bf[cur][i & 1][i >> 1], acc[2 * p + (i & 1)], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i == 0 && p + 1 < 8 && !(ABL & 16)) load_frags(s, p + 1, cur ^ 1);
+        if constexpr (MORE) {
+          // side work: LDS / DMA instructions are free in an MFMA shadow (up to LDS bandwidth) and are dealt one per
+          // shadow; VALU instructions are NOT (they cost their issue time plus a ~20-cycle bubble each time the MFMA
+          // stream is broken), so the whole input transform's arithmetic sits in ONE cluster
+          const int m = p * 8 + i;
+          if constexpr (!(ABL & 1)) {
+            if (m >= 1 && m <= 8) issue_u(c + 1, s ^ 1, m - 1);
+            else if (m >= 9 && m <= 11) issue_raw_item(min(c + 2, c1 - 1), s, m - 9);  // past the end: a harmless re-load of the last chunk
           }
-          if (p == 1) {
+          if constexpr (!(ABL & 4)) {
+            if (m >= 12 && m <= 19) tf_load_item(s ^ 1, m - 12);
+            else if (m == 27) {
 #pragma unroll
-            for (int i = 4; i < 8; ++i) issue_u(c + 1, s ^ 1, i);
+              for (int q = 0; q < 4; ++q) tf_rows_item(q);
+#pragma unroll
+              for (int xi = 0; xi < 4; ++xi) tf_cols_compute(xi);
+            } else if (m >= 28 && m <= 35) tf_store_item(m - 28, s ^ 1);
           }
         }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      acc[2 * p] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0][1], bf[cur][0][1], acc[2 * p], 0, 0, 0);
-      acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][1][1], bf[cur][1][1], acc[2 * p + 1], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (MORE) {
-        if constexpr (!(ABL & 4)) {
-          if (p == 1) tf_rows();
-          if (p >= 2 && p <= 5) tf_cols_store(p - 2, s ^ 1);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 2; j < 4; ++j) {
-        acc[2 * p] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0][j], bf[cur][0][j], acc[2 * p], 0, 0, 0);
-        acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][1][j], bf[cur][1][j], acc[2 * p + 1], 0, 0, 0);
       }
     }
   };
@@ -543,9 +591,288 @@ static int launch_conv_wino(const ConvArgs &a, int tiles_y, hipStream_t s) {
     case 5: return launch_conv_wino_t<5>(a, tiles_y, s);
     case 23: return launch_conv_wino_t<23>(a, tiles_y, s);
     case 31: return launch_conv_wino_t<31>(a, tiles_y, s);
+    case 64: return launch_conv_wino_t<64>(a, tiles_y, s);
     default: return launch_conv_wino_t<0>(a, tiles_y, s);
   }
 }
+
+// -------------------------------------------------------------------------------------------------
+// Winograd conv, 8-wave form: the same block tile (64 couts x 16x16 px), LDS image and DMA schedule, but 512 threads.
+// With 256 accumulator registers per wave the 4-wave kernel runs ONE wave per SIMD, and a wave's own VALU / LDS /
+// DMA-issue work never overlaps its MFMAs (SQ_VALU_MFMA_COEXEC_CYCLES = 0): the matrix pipe idled ~45 % of the time.
+// Here the 16 Winograd components are split between two waves (wave>>2 = xi half: components xi in {0,1} / {2,3}), so
+// every SIMD holds two waves of 128 accumulator registers and one wave's transforms, waits and epilogue run under the
+// other's MFMAs.  The output transform is linear in the components: each wave forms the partial 2x2 outputs of its
+// half, the two halves swap what the other needs through LDS once per tile, and each finishes half of the channels.
+// -------------------------------------------------------------------------------------------------
+template <int ABL>
+__global__ __launch_bounds__(512) void conv3x3_wino8_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *const raw_lds = lds;
+  float *const v_lds = lds + 2 * WG_RAW_FLOATS;
+  float *const u_lds = v_lds + 2 * WG_V_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ch = wave >> 2;  // component half: xi in {2ch, 2ch+1}
+  const int ct = blockIdx.x % a.n_ct, sp = blockIdx.x / a.n_ct;
+  const int tyb = sp / a.tiles_x, txb = sp - tyb * a.tiles_x;
+  const int y0 = tyb * 16, x0 = txb * 16, cout0 = ct * 64;
+  const int mbase = ((wave >> 1) & 1) * 32, nbase = (wave & 1) * 32;
+
+  // DMA items: raw tile = 12 wave-loads (item A: t = wave; item B: t = 8 + wave for waves 0-3), weights = 32 (4 per wave)
+  unsigned raw_rel[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int p = min((i * 8 + wave) * 64 + lane, WG_RAW_PIECES - 1);
+    int r = p / 36, o = p - r * 36;
+    raw_rel[i] = (unsigned)(((r * a.in_Wp) * 8 + o * 4) * 4);
+  }
+  const unsigned u_lane = (unsigned)((((wave & 1) * 64 + lane) * 4) * 4);
+  const size_t u_chunk = (size_t)16 * a.CoutP * 8;
+  const float *const in_tile = a.in + (size_t)(y0 * a.in_Wp + x0) * 8;
+  const float *const w_tile = a.wpk + (size_t)cout0 * 8;
+  auto issue_raw = [&](int c, int buf) {
+    const float *src = in_tile + (size_t)c * a.in_plane;
+    glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(src) + (size_t)raw_rel[0]), raw_lds + buf * WG_RAW_FLOATS + wave * 256);
+    if (wave < 4)
+      glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(src) + (size_t)raw_rel[1]), raw_lds + buf * WG_RAW_FLOATS + (8 + wave) * 256);
+  };
+  auto issue_u = [&](int c, int buf, int i) {  // item t = i*8 + wave: component t>>1 = i*4 + (wave>>1), half-slice wave&1
+    const float *slice = w_tile + (size_t)c * u_chunk + (size_t)((i * 4 + (wave >> 1)) * a.CoutP) * 8;
+    glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(slice) + (size_t)u_lane), u_lds + buf * WG_U_FLOATS + (i * 8 + wave) * 256);
+  };
+
+  // input transform: this wave produces components xi in {2ch, 2ch+1} for tiles 16*(wave&3) .. +15; lane = tile*4 + channel pair
+  const int tf_tile = (wave & 3) * 16 + (lane >> 2), tf_cp = lane & 3;
+  const int tf_rd = ((2 * (tf_tile >> 3) + ch) * 18 + 2 * (tf_tile & 7)) * 8 + 2 * tf_cp;  // rows ch .. ch+2 of the 4x4 patch
+  const int tf_wr = (ch * 8 * 64 + tf_tile) * 8 + 2 * tf_cp;
+  f32x2 d[12], t[8];
+  auto tf_load = [&](int buf) {
+    const float *R = raw_lds + buf * WG_RAW_FLOATS + tf_rd;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[r * 4 + q] = *reinterpret_cast<const f32x2 *>(R + (r * 18 + q) * 8);
+  };
+  auto tf_rows = [&]() {  // ch 0: t0 = d0 - d2, t1 = d1 + d2 (patch rows 0,1,2);  ch 1: t2 = d2 - d1, t3 = d1 - d3 (patch rows 1,2,3)
+    if (ch == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { t[q] = d[q] - d[8 + q]; t[4 + q] = d[4 + q] + d[8 + q]; }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { t[q] = d[4 + q] - d[q]; t[4 + q] = d[q] - d[8 + q]; }
+    }
+  };
+  auto tf_cols_store = [&](int k, int buf) {  // component row xi = 2ch + k
+    float *Vw = v_lds + buf * WG_V_FLOATS + tf_wr + k * 4 * 512;
+    *reinterpret_cast<f32x2 *>(Vw + 0 * 512) = t[k * 4 + 0] - t[k * 4 + 2];
+    *reinterpret_cast<f32x2 *>(Vw + 1 * 512) = t[k * 4 + 1] + t[k * 4 + 2];
+    *reinterpret_cast<f32x2 *>(Vw + 2 * 512) = t[k * 4 + 2] - t[k * 4 + 1];
+    *reinterpret_cast<f32x2 *>(Vw + 3 * 512) = t[k * 4 + 1] - t[k * 4 + 3];
+  };
+
+  const int c0 = blockIdx.y * a.chunks_per_split;
+  const int c1 = min(a.nchunks, c0 + a.chunks_per_split);
+  issue_raw(c0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) issue_u(c0, 0, i);
+  issue_raw(min(c0 + 1, c1 - 1), 1);
+  f32x16 acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
+  __syncthreads();
+  tf_load(0);
+  tf_rows();
+  tf_cols_store(0, 0);
+  tf_cols_store(1, 0);
+  __syncthreads();
+
+  const int frag_u = (ch * 8 * 64 + mbase + l31) * 8 + half * 4, frag_v = (ch * 8 * 64 + nbase + l31) * 8 + half * 4;
+  f32x4 af[2][2], bf[2][2];
+  auto load_frags = [&](int buf, int pr, int slot) {  // pair pr of this wave's 4: components ch*8 + 2pr, +1
+    const float *Ul = u_lds + buf * WG_U_FLOATS + frag_u, *Vl = v_lds + buf * WG_V_FLOATS + frag_v;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      af[slot][k] = *reinterpret_cast<const f32x4 *>(Ul + (2 * pr + k) * 512);
+      bf[slot][k] = *reinterpret_cast<const f32x4 *>(Vl + (2 * pr + k) * 512);
+    }
+  };
+  load_frags(0, 0, 0);
+  auto body = [&](int c, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    const int s = (c - c0) & 1;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int cur = p & 1;
+      if (p == 3 && MORE) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's last reads of U[s]/V[s] are done before others may overwrite them
+        if constexpr (!(ABL & 2)) __syncthreads();
+        load_frags(s ^ 1, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[2 * p] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0][0], bf[cur][0][0], acc[2 * p], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (p + 1 < 4) load_frags(s, p + 1, cur ^ 1);
+      if constexpr (MORE) {
+        if (p == 0 && !(ABL & 4)) tf_load(s ^ 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][1][0], bf[cur][1][0], acc[2 * p + 1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (MORE) {
+        if constexpr (!(ABL & 1)) {
+          if (p == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) issue_u(c + 1, s ^ 1, i);
+            issue_raw(min(c + 2, c1 - 1), s);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[2 * p] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0][1], bf[cur][0][1], acc[2 * p], 0, 0, 0);
+      acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][1][1], bf[cur][1][1], acc[2 * p + 1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (MORE) {
+        if constexpr (!(ABL & 4)) {
+          if (p == 1) { tf_rows(); tf_cols_store(0, s ^ 1); }
+          if (p == 2) tf_cols_store(1, s ^ 1);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 2; j < 4; ++j) {
+        acc[2 * p] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0][j], bf[cur][0][j], acc[2 * p], 0, 0, 0);
+        acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][1][j], bf[cur][1][j], acc[2 * p + 1], 0, 0, 0);
+      }
+    }
+  };
+  for (int c = c0; c < c1 - 1; ++c) body(c, std::true_type{});
+  body(c1 - 1, std::false_type{});
+
+  if constexpr ((ABL & 8) != 0) {
+    if (a.H < 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) *reinterpret_cast<f32x16 *>(a.part + (size_t)k * 16 + lane * 256) = acc[k];
+    }
+    return;
+  }
+  // ---- epilogue.  Partial 2x2 outputs of this wave's component half for accumulator register r (acc[nu] = M[2ch][nu],
+  // acc[4+nu] = M[2ch+1][nu]):  ch 0: s = M0 + M1, u = M1;  ch 1: s = M2, u = -M2 - M3;  then
+  // Y00 = s0+s1+s2, Y01 = s1-s2-s3, Y10 = u0+u1+u2, Y11 = u1-u2-u3 (linear, so the halves just add).
+  auto partial = [&](int r, float (&Y)[4]) {
+    float sv[4], uv[4];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) {
+      if (ch == 0) { sv[nu] = acc[nu][r] + acc[4 + nu][r]; uv[nu] = acc[4 + nu][r]; }
+      else { sv[nu] = acc[nu][r]; uv[nu] = -acc[nu][r] - acc[4 + nu][r]; }
+    }
+    Y[0] = sv[0] + sv[1] + sv[2]; Y[1] = sv[1] - sv[2] - sv[3];
+    Y[2] = uv[0] + uv[1] + uv[2]; Y[3] = uv[1] - uv[2] - uv[3];
+  };
+  __syncthreads();  // every wave is done with the stage buffers: reuse them as the exchange area
+  float *const xbuf = lds;  // [wave 8][slot 32][lane 64]
+  // this wave finishes channel groups g in {2ch, 2ch+1} (accumulator registers 8ch .. 8ch+7); the partner (wave ^ 4) the others
+  {
+    float *xw = xbuf + (wave * 32) * 64 + lane;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      float Y[4];
+      partial((1 - ch) * 8 + rr, Y);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xw[(rr * 4 + k) * 64] = Y[k];
+    }
+  }
+  f32x4 Yk[2][4];  // [group in my half][pixel k] x 4 channels
+#pragma unroll
+  for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float Y[4];
+      partial(ch * 8 + gg * 4 + e, Y);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) Yk[gg][k][e] = Y[k];
+    }
+  __syncthreads();
+  {
+    const float *xr = xbuf + ((wave ^ 4) * 32) * 64 + lane;
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Yk[gg][k][e] += xr[((gg * 4 + e) * 4 + k) * 64];
+  }
+  const int tau = nbase + l31;
+  const int y = y0 + 2 * (tau >> 3), x = x0 + 2 * (tau & 7);
+  const int pix = ((y + 1) * a.out_Wp + x + 1) * 8 + half * 4;
+#pragma unroll
+  for (int gg = 0; gg < 2; ++gg) {
+    const int cb = __builtin_amdgcn_readfirstlane((cout0 + mbase) / 8 + ch * 2 + gg);
+    if (cb >= a.out_cb) continue;
+    if (a.splits > 1) {  // raw partial sums; conv_splitk_reduce_kernel finishes the layer
+      float *const dst = a.part + (size_t)blockIdx.y * a.part_slab + (size_t)cb * a.out_plane;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int yy = y + (k >> 1), xx = x + (k & 1);
+        if (yy < a.H && xx < a.W) *reinterpret_cast<f32x4 *>(dst + pix + ((k >> 1) * a.out_Wp + (k & 1)) * 8) = Yk[gg][k];
+      }
+      continue;
+    }
+    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bpk + cb * 8 + half * 4);
+    f32x4 m = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    float *const dst = a.out ? a.out + (size_t)cb * a.out_plane : nullptr;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = y + (k >> 1), xx = x + (k & 1);
+      const bool ok = yy < a.H && xx < a.W;
+      f32x4 v = Yk[gg][k] + b4;
+      if (a.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.0f ? 0.0f : v[e];
+      }
+      if (ok && dst) *reinterpret_cast<f32x4 *>(dst + pix + ((k >> 1) * a.out_Wp + (k & 1)) * 8) = v;
+      if (ok) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+      }
+    }
+    if (a.pool) {
+      const int py = y >> 1, px = x >> 1;
+      if (py < a.pool_H && px < a.pool_W)
+        *reinterpret_cast<f32x4 *>(a.pool + (size_t)cb * a.pool_plane + ((py + 1) * a.pool_Wp + px + 1) * 8 + half * 4) = m;
+    }
+  }
+}
+
+template <int ABL>
+static int launch_conv_wino8_t(const ConvArgs &a, int tiles_y, hipStream_t s) {
+  auto kern = conv3x3_wino8_kernel<ABL>;
+  static bool attr = false;
+  if (!attr) {
+    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS_BYTES));
+    attr = true;
+  }
+  dim3 grid((unsigned)(a.n_ct * tiles_y * a.tiles_x), (unsigned)a.splits);
+  hipLaunchKernelGGL(kern, grid, dim3(512), WG_LDS_BYTES, s, a);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+static int launch_conv_wino8(const ConvArgs &a, int tiles_y, hipStream_t s) {
+  switch (a.ablate) {  // timing experiments only (wrong results)
+    case 1: return launch_conv_wino8_t<1>(a, tiles_y, s);
+    case 2: return launch_conv_wino8_t<2>(a, tiles_y, s);
+    case 4: return launch_conv_wino8_t<4>(a, tiles_y, s);
+    case 8: return launch_conv_wino8_t<8>(a, tiles_y, s);
+    case 7: return launch_conv_wino8_t<7>(a, tiles_y, s);
+    case 15: return launch_conv_wino8_t<15>(a, tiles_y, s);
+    default: return launch_conv_wino8_t<0>(a, tiles_y, s);
+  }
+}
+
 
 // =================================================================================================
 // Persistent stream-K conv3x3: ONE block per CU for the whole layer.
@@ -1192,6 +1519,7 @@ __global__ void conv_splitk_reduce_kernel(const float *__restrict__ part, size_t
 }
 
 static int g_gemm_ablate = 0;         // timing-experiment switch shared by conv and gemm
+static unsigned long long *g_wino_trace = nullptr;  // tools/wino_trace.py
 static int g_conv_split = 0;          // 0 = auto, >0 = force this many splits (test/bench hook)
 static float *g_conv_ws = nullptr;    // library-owned split-K scratch (grown on demand, single stream)
 static size_t g_conv_ws_bytes = 0;
@@ -1219,7 +1547,7 @@ int conv3x3_variant_for(int Cout, bool has_wino) {
   // measured on MI355X (tools/bench_layers.py): Winograd F(2x2,3x3) beats the direct kernels on every VGG layer with
   // >= 16 input channels (2.33 vs 3.53 ms for the trunk); among the direct kernels one 4-wave block per CU (9 taps per
   // stage) beats the 3-blocks-per-CU variants — co-resident waves only time-share the SIMD's matrix pipe.
-  if (variant == 7 && !has_wino) variant = 0;
+  if ((variant == 7 || variant == 8) && !has_wino) variant = 0;
   if (variant == 0) variant = has_wino ? 7 : ((Cout <= 64) ? 2 : 1);
   return variant;
 }
@@ -1235,18 +1563,19 @@ int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int re
   a.H = in.H; a.W = in.W; a.nchunks = in.Cb(); a.out_cb = (Cout + 7) / 8; a.relu = relu;
   a.tiles_x = cdiv(in.W, 32);
   a.ablate = g_gemm_ablate;
+  a.trace = g_wino_trace;
   if (out.p) MPN_CHECK_ARG(out.H == in.H && out.W == in.W && out.C == Cout);
   if (pooled.p) MPN_CHECK_ARG(pooled.H == (in.H + 1) / 2 && pooled.W == (in.W + 1) / 2 && pooled.C == Cout);
   int variant = conv3x3_variant_for(Cout, d_wino != nullptr);
   if (!d_wpk) variant = 7;
-  if (variant == 7) {  // Winograd F(2x2,3x3): 64 couts x 16x16 px per block
+  if (variant == 7 || variant == 8) {  // Winograd F(2x2,3x3): 64 couts x 16x16 px per block (7 = 4-wave kernel, 8 = 8-wave kernel)
     a.wpk = d_wino;
     a.tiles_x = cdiv(in.W, 16);
     const int tiles_y = cdiv(in.H, 16);
     a.n_ct = cdiv(Cout, 64);
     const int blocks = a.n_ct * tiles_y * a.tiles_x;
     Act geo = out.p ? out : make_act(nullptr, Cout, in.H, in.W);
-    if (g_conv_mode == 1 && g_conv_split == 0) {  // persistent stream-K (opt-in, see the note at g_conv_mode)
+    if (g_conv_mode == 1 && g_conv_split == 0 && variant == 7) {  // persistent stream-K (opt-in, see the note at g_conv_mode)
       if (g_num_cus == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -1290,7 +1619,7 @@ int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int re
       }
       a.part = g_conv_ws;
     }
-    int rc = launch_conv_wino(a, tiles_y, s);
+    int rc = variant == 8 ? launch_conv_wino8(a, tiles_y, s) : launch_conv_wino(a, tiles_y, s);
     if (rc != MPN_OK || a.splits == 1) return rc;
     const int GH = pooled.p ? pooled.H : in.H, GW = pooled.p ? pooled.W : in.W;
     const size_t total = (size_t)a.out_cb * GH * GW * 2;
@@ -2091,6 +2420,7 @@ int roi_pool_c8(Act feat, const float *d_rois, int N, int PH, int PW, float scal
 using namespace mpn;
 
 // ---- test / bench hooks (not part of the reference surface) -------------------------------------
+extern "C" void mpn_debug_set_wino_trace(void *p) { g_wino_trace = static_cast<unsigned long long *>(p); }
 extern "C" void mpn_debug_set_conv_variant(int v) { g_conv_variant = v; }
 extern "C" void mpn_debug_set_gemm_regstage(int v) { g_gemm_regstage = v; }
 extern "C" void mpn_debug_set_conv_split(int v) { g_conv_split = v; }

@@ -23,9 +23,9 @@ def _conv(dev, x, w, b, relu=True):
 @pytest.mark.parametrize("ci,co,h,w", [(3, 64, 40, 70), (8, 64, 33, 31), (64, 64, 19, 45), (64, 128, 16, 96), (128, 256, 9, 33),
                                        (24, 40, 8, 8), (16, 200, 5, 37), (256, 512, 12, 20)])
 @pytest.mark.parametrize("variant,split,mode", [(0, 0, 1), (1, 0, 1), (2, 0, 1), (0, 0, 0), (1, 0, 0), (2, 0, 0), (3, 0, 0), (4, 0, 0), (5, 0, 0), (6, 0, 0), (5, 2, 0), (6, 3, 0),
-                                                (1, 2, 0), (2, 3, 0), (3, 2, 0), (4, 3, 0), (0, 4, 0), (7, 0, 0), (7, 0, 1), (7, 2, 0), (7, 3, 0)])
+                                                (1, 2, 0), (2, 3, 0), (3, 2, 0), (4, 3, 0), (0, 4, 0), (7, 0, 0), (7, 0, 1), (7, 2, 0), (7, 3, 0), (8, 0, 0), (8, 2, 0), (8, 3, 0)])
 def test_conv3x3_vs_oracle(O, dev, ci, co, h, w, variant, split, mode):
-    """mode 0 = one block per tile (+ split-K; default), 1 = persistent stream-K kernel; variant 7 = Winograd F(2x2,3x3)"""
+    """mode 0 = one block per tile (+ split-K; default), 1 = persistent stream-K kernel; variant 7 / 8 = Winograd F(2x2,3x3), 4-wave / 8-wave kernel"""
     import multipathnet_amd
     lib = multipathnet_amd.load()
     lib.mpn_debug_set_conv_split(split)

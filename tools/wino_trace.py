@@ -1,0 +1,31 @@
+"""s_memtime trace of the 4-wave Winograd kernel's chunk loop (wave 0 of blocks 0..3): cycles from chunk start to the
+pre-barrier point (MFMA pairs 0-6 + everything interleaved), the lgkmcnt(0) wait, and the vmcnt(0)+s_barrier wait.
+s_memtime ticks at 100 MHz on gfx9 (10 ns) — coarse, so look at sums over the chunks."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import multipathnet_amd
+lib = multipathnet_amd.load()
+lib.mpn_debug_set_conv_variant(7)
+buf = torch.zeros(4 * 64 * 4 + 32, dtype=torch.int64, device="cuda")
+lib.mpn_debug_set_wino_trace(C.c_void_p(buf.data_ptr()))
+for (ci, co, h, w) in [(128, 128, 300, 500), (512, 512, 75, 125)]:
+    for ab in (64,):
+        buf.zero_()
+        lib.mpn_debug_set_gemm_ablate(ab)
+        ms = C.c_float()
+        lib.mpn_debug_bench_conv(ci, co, h, w, 0, 3, C.byref(ms))
+        torch.cuda.synchronize()
+        pairs = buf.cpu()[4 * 64 * 4:].view(4, 8)
+        t = buf.cpu()[:4 * 64 * 4].view(4, 64, 4)
+        print("wino %d->%d %dx%d: %.1f us/launch" % (ci, co, h, w, ms.value * 1e3))
+        for b in range(4):
+            rows = [r for r in t[b].tolist() if r[0] != 0]
+            if not rows: continue
+            t0 = rows[0][0]
+            print(" block %d: chunks traced %d; per chunk [start-offset, pairs0-6, lgkm wait, vm+barrier wait] (memtime ticks):" % (b, len(rows)))
+            print("   " + " ".join("[%d %d %d %d]" % (r[0] - t0, r[1], r[2], r[3]) for r in rows[:8]))
+            pr = pairs[b].tolist()
+            print("   chunk 5 pair-start deltas: " + " ".join(str(pr[i + 1] - pr[i]) for i in range(7)))
+lib.mpn_debug_set_gemm_ablate(0)
+lib.mpn_debug_set_wino_trace(None)
