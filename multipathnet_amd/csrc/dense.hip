@@ -316,6 +316,8 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
   float *const v_lds = lds + 2 * WG_RAW_FLOATS;
   float *const u_lds = v_lds + 2 * WG_V_FLOATS;
   const int tid = threadIdx.x, lane = tid & 63;
+  unsigned long long tk0 = 0, tk1 = 0, tk2 = 0;
+  if constexpr ((ABL & 64) != 0) tk0 = __builtin_amdgcn_s_memtime();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int ct = blockIdx.x % a.n_ct, sp = blockIdx.x / a.n_ct;
@@ -504,8 +506,19 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
       }
     }
   };
+  if constexpr ((ABL & 64) != 0) tk1 = __builtin_amdgcn_s_memtime();
   for (int c = c0; c < c1 - 1; ++c) body(c, std::true_type{});
+  // the epilogue's bias vectors are fetched under the last chunk's MFMAs (the transform registers are free there): a
+  // global load inside the epilogue would sit behind an s_waitcnt vmcnt(0) that also waits for the previous channel
+  // group's STORES to be acknowledged (measured: 9.8k-cycle epilogue)
+  f32x4 bias4[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int cb = min((cout0 + mbase) / 8 + g, a.out_cb - 1);
+    bias4[g] = *reinterpret_cast<const f32x4 *>(a.bpk + cb * 8 + half * 4);
+  }
   body(c1 - 1, std::false_type{});
+  if constexpr ((ABL & 64) != 0) tk2 = __builtin_amdgcn_s_memtime();
 
   // ---- output transform A^T M A (register-local), bias, ReLU, stores, fused 2x2 max-pool
   if constexpr ((ABL & 8) != 0) {  // timing experiment: no output transform / stores (the never-true store keeps the accumulators live)
@@ -542,7 +555,7 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
       }
       continue;
     }
-    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bpk + cb * 8 + half * 4);
+    const f32x4 b4 = bias4[g];
     f32x4 m = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -564,6 +577,18 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
       const int py = y >> 1, px = x >> 1;
       if (py < a.pool_H && px < a.pool_W)
         *reinterpret_cast<f32x4 *>(a.pool + (size_t)cb * a.pool_plane + ((size_t)(py + 1) * a.pool_Wp + px + 1) * 8 + half * 4) = m;
+    }
+  }
+  if constexpr ((ABL & 64) != 0) {
+    const unsigned long long tk3 = __builtin_amdgcn_s_memtime();
+    if (a.trace && blockIdx.x < 4 && blockIdx.y == 0 && tid == 0) {
+      unsigned long long *o = a.trace + 4 * 64 * 4 + 32 + blockIdx.x * 4;
+      o[0] = tk1 - tk0; o[1] = tk2 - tk1; o[2] = tk3 - tk2; o[3] = tk0;
+    }
+    if (a.trace && blockIdx.y == 0 && tid == 0 && blockIdx.x < 4096) {  // every block: which CU, when it started / ended
+      unsigned long long *o = a.trace + 4 * 64 * 4 + 48 + (size_t)blockIdx.x * 3;
+      const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+      o[0] = ((unsigned long long)xcc << 32) | hw; o[1] = tk0; o[2] = tk3;
     }
   }
 }
@@ -1101,10 +1126,9 @@ __global__ __launch_bounds__(256) void conv3x3_c8p_persistent_kernel(PersistArgs
 }
 
 // Finishes the tiles that a block boundary cut: one block per tile; tiles owned by a single block exit at once.
-template <int BM, int TH, int TW = 32>
-__global__ __launch_bounds__(256) void conv_streamk_fixup_kernel(PersistArgs pa) {
+template <int BM, int TH, int TW>
+__device__ __forceinline__ void streamk_fixup_tile(const PersistArgs &pa, int t) {
   const ConvArgs &a = pa.c;
-  const int t = blockIdx.x;
   const int pf = sk_block_of(t * a.nchunks, pa.base, pa.rem), pl = sk_block_of(t * a.nchunks + a.nchunks - 1, pa.base, pa.rem);
   const int nseg = pl - pf + 1;
   if (nseg == 1) return;
@@ -1148,6 +1172,23 @@ __global__ __launch_bounds__(256) void conv_streamk_fixup_kernel(PersistArgs pa)
         *reinterpret_cast<f32x4 *>(a.pool + (size_t)cb * a.pool_plane + ((size_t)(py + 1) * a.pool_Wp + px + 1) * 8 + h * 4) = m;
     }
   }
+}
+
+template <int BM, int TH, int TW = 32>
+__global__ __launch_bounds__(256) void conv_streamk_fixup_kernel(PersistArgs pa) {  // one block per tile
+  streamk_fixup_tile<BM, TH, TW>(pa, blockIdx.x);
+}
+
+// one block per block BOUNDARY (P-1 blocks instead of T): boundary j sits at unit u0(j+1); it finishes the tile it cuts, unless
+// an earlier boundary lies strictly inside the same tile (that one's block does it)
+template <int BM, int TH, int TW>
+__global__ __launch_bounds__(256) void conv_streamk_fixup_cut_kernel(PersistArgs pa) {
+  const int nch = pa.c.nchunks;
+  const int ub = sk_u0(blockIdx.x + 1, pa.base, pa.rem);
+  const int t = ub / nch;
+  if (ub == t * nch) return;                                   // the boundary coincides with a tile boundary
+  if (sk_u0(blockIdx.x, pa.base, pa.rem) > t * nch) return;     // not the first boundary inside this tile
+  streamk_fixup_tile<BM, TH, TW>(pa, t);
 }
 
 // =================================================================================================
@@ -1205,14 +1246,15 @@ __global__ __launch_bounds__(256) void conv3x3_wino_persistent_kernel(PersistArg
     if (++k.c < a.nchunks) { k.in += a.in_plane; k.w += u_chunk; }
     else { k.c = 0; ++k.t; decode(k); }
   };
+  const unsigned lds0 = lds_byte_addr(lds);
+  const unsigned raw_slot = lds0 + (unsigned)(wave * 256) * 4, u_slot = lds0 + (unsigned)(2 * WG_RAW_FLOATS + 2 * WG_V_FLOATS + wave * 256) * 4;
+  auto issue_raw_item = [&](const float *src, int buf, int i) { glds16_saddr(src, raw_rel[i], raw_slot + (unsigned)(buf * WG_RAW_FLOATS + i * 1024) * 4); };
   auto issue_raw = [&](const float *src, int buf) {
 #pragma unroll
-    for (int i = 0; i < RAW_IT; ++i)
-      glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(src) + (size_t)raw_rel[i]), raw_lds + buf * WG_RAW_FLOATS + (i * 4 + wave) * 256);
+    for (int i = 0; i < RAW_IT; ++i) issue_raw_item(src, buf, i);
   };
   auto issue_u = [&](const float *src, int buf, int i) {
-    const float *slice = src + (size_t)(((i * 4 + wave) >> 1) * a.CoutP) * 8;  // wave-uniform
-    glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(slice) + (size_t)u_lane), u_lds + buf * WG_U_FLOATS + (i * 4 + wave) * 256);
+    glds16_saddr(src + (size_t)(((i * 4 + wave) >> 1) * a.CoutP) * 8, u_lane, u_slot + (unsigned)(buf * WG_U_FLOATS + i * 1024) * 4);
   };
 
   const int tf_tile = wave * 16 + (lane >> 2), tf_cp = lane & 3;
@@ -1243,6 +1285,22 @@ __global__ __launch_bounds__(256) void conv3x3_wino_persistent_kernel(PersistArg
     *reinterpret_cast<f32x2 *>(Vw + 3 * 512) = t[xi * 4 + 1] - t[xi * 4 + 3];
   };
 
+  auto tf_load_item = [&](int buf, int i) {
+    const float *R = raw_lds + buf * WG_RAW_FLOATS + tf_rd + ((i >> 1) * 18 + (i & 1) * 2) * 8;
+    d[2 * i] = *reinterpret_cast<const f32x2 *>(R);
+    d[2 * i + 1] = *reinterpret_cast<const f32x2 *>(R + 8);
+  };
+  auto tf_cols_compute = [&](int xi) {
+    const f32x2 v0 = t[xi * 4 + 0] - t[xi * 4 + 2], v1 = t[xi * 4 + 1] + t[xi * 4 + 2];
+    const f32x2 v2 = t[xi * 4 + 2] - t[xi * 4 + 1], v3 = t[xi * 4 + 1] - t[xi * 4 + 3];
+    t[xi * 4 + 0] = v0; t[xi * 4 + 1] = v1; t[xi * 4 + 2] = v2; t[xi * 4 + 3] = v3;
+  };
+  auto tf_store_item = [&](int i, int buf) {
+    float *Vw = v_lds + buf * WG_V_FLOATS + tf_wr + (2 * i) * 512;
+    *reinterpret_cast<f32x2 *>(Vw) = t[2 * i];
+    *reinterpret_cast<f32x2 *>(Vw + 512) = t[2 * i + 1];
+  };
+
   Cur cu, cr;  // cu: the unit whose weight slices are DMA'd next (u+1); cr: the unit whose raw tile is DMA'd next (u+2)
   cu.t = u_begin / a.nchunks; cu.c = u_begin - cu.t * a.nchunks;
   decode(cu);
@@ -1262,6 +1320,7 @@ __global__ __launch_bounds__(256) void conv3x3_wino_persistent_kernel(PersistArg
       for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
   };
   zero_acc();
+  dma_wait_all();
   __syncthreads();
   tf_load(0);
   tf_rows();
@@ -1281,7 +1340,7 @@ __global__ __launch_bounds__(256) void conv3x3_wino_persistent_kernel(PersistArg
   };
   load_frags(0, 0, 0);
 
-  // one unit on the matrix pipe (scheduling as in conv3x3_wino_kernel)
+  // one unit on the matrix pipe (schedule: see conv3x3_wino_kernel)
   auto body = [&](int s, auto more_tag) {
     constexpr bool MORE = decltype(more_tag)::value;
 #pragma unroll
@@ -1289,47 +1348,31 @@ __global__ __launch_bounds__(256) void conv3x3_wino_persistent_kernel(PersistArg
       const int cur = pp & 1;
       if (pp == 7 && MORE) {
         __builtin_amdgcn_s_waitcnt(0xc07f);
+        dma_wait_all();
         if constexpr (!(ABL & 2)) __syncthreads();
         if constexpr (!(ABL & 16)) load_frags(s ^ 1, 0, 0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      acc[2 * pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0][0], bf[cur][0][0], acc[2 * pp], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (pp + 1 < 8 && !(ABL & 16)) load_frags(s, pp + 1, cur ^ 1);
-      if constexpr (MORE) {
-        if (pp == 0 && !(ABL & 4)) tf_load(s ^ 1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][1][0], bf[cur][1][0], acc[2 * pp + 1], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (MORE) {
-        if constexpr (!(ABL & 1)) {
-          if (pp == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) issue_u(cu.w, s ^ 1, i);
-            issue_raw(cr.in, s);
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+        acc[2 * pp + (i & 1)] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i & 1][i >> 1], bf[cur][i & 1][i >> 1], acc[2 * pp + (i & 1)], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i == 0 && pp + 1 < 8 && !(ABL & 16)) load_frags(s, pp + 1, cur ^ 1);
+        if constexpr (MORE) {
+          const int m = pp * 8 + i;
+          if constexpr (!(ABL & 1)) {
+            if (m >= 1 && m <= 8) issue_u(cu.w, s ^ 1, m - 1);
+            else if (m >= 9 && m <= 11) issue_raw_item(cr.in, s, m - 9);
           }
-          if (pp == 1) {
+          if constexpr (!(ABL & 4)) {
+            if (m >= 12 && m <= 19) tf_load_item(s ^ 1, m - 12);
+            else if (m == 27) {
+              tf_rows();
 #pragma unroll
-            for (int i = 4; i < 8; ++i) issue_u(cu.w, s ^ 1, i);
+              for (int xi = 0; xi < 4; ++xi) tf_cols_compute(xi);
+            } else if (m >= 28 && m <= 35) tf_store_item(m - 28, s ^ 1);
           }
         }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      acc[2 * pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0][1], bf[cur][0][1], acc[2 * pp], 0, 0, 0);
-      acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][1][1], bf[cur][1][1], acc[2 * pp + 1], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (MORE) {
-        if constexpr (!(ABL & 4)) {
-          if (pp == 1) tf_rows();
-          if (pp >= 2 && pp <= 5) tf_cols_store(pp - 2, s ^ 1);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 2; j < 4; ++j) {
-        acc[2 * pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0][j], bf[cur][0][j], acc[2 * pp], 0, 0, 0);
-        acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][1][j], bf[cur][1][j], acc[2 * pp + 1], 0, 0, 0);
       }
     }
   };
@@ -1434,8 +1477,8 @@ static int launch_conv_wino_persistent_t(PersistArgs &pa, hipStream_t s) {
   }
   hipLaunchKernelGGL(kern, dim3(pa.P), dim3(256), WG_LDS_BYTES, s, pa);
   MPN_CHECK_LAUNCH();
-  if (pa.U % pa.P != 0 || pa.base % pa.c.nchunks != 0) {  // some tile is cut by a block boundary
-    hipLaunchKernelGGL((conv_streamk_fixup_kernel<64, 16, 16>), dim3(pa.T), dim3(256), 0, s, pa);
+  if (pa.P > 1 && (pa.U % pa.P != 0 || pa.base % pa.c.nchunks != 0)) {  // some tile is cut by a block boundary
+    hipLaunchKernelGGL((conv_streamk_fixup_cut_kernel<64, 16, 16>), dim3(pa.P - 1), dim3(256), 0, s, pa);
     MPN_CHECK_LAUNCH();
   }
   return MPN_OK;
@@ -1463,6 +1506,7 @@ static int launch_conv_wino_persistent(PersistArgs &pa, hipStream_t s) {
 // nowhere to run: end to end it is SLOWER (233.6k vs 241.7k proposals/s).  Default = block per tile.
 static int g_conv_mode = 0;  // 0 = one block per tile (+ split-K, default), 1 = persistent stream-K
 static int g_num_cus = 0;
+static int g_persist_blocks = 0;  // persistent kernels: blocks to launch (0 = one per CU); < #CUs leaves CUs to a concurrent stream
 
 template <int BM, int TH, int WM, int WN>
 static int launch_conv_persistent(PersistArgs &pa, hipStream_t s) {
@@ -1585,7 +1629,8 @@ int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int re
       }
       PersistArgs pa{};
       pa.T = blocks; pa.U = blocks * a.nchunks; pa.tiles_y = tiles_y;
-      pa.P = pa.U < g_num_cus ? pa.U : g_num_cus;
+      const int pmax = (g_persist_blocks > 0 && g_persist_blocks < g_num_cus) ? g_persist_blocks : g_num_cus;
+      pa.P = pa.U < pmax ? pa.U : pmax;
       pa.base = pa.U / pa.P; pa.rem = pa.U % pa.P;
       a.out_plane = geo.plane(); a.out_Wp = geo.Wp;
       a.part_slab = geo.elems();
@@ -1860,17 +1905,19 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
   const int st1 = min(a.nstages, st0 + a.stages_per_split);
   const int wm = wave >> 1, wn = wave & 1;
 
-  int a_off[IT], b_off[IT];
-#pragma unroll
-  for (int i = 0; i < IT; ++i) {
-    int p = (i * 4 + wave) * 64 + lane;
-    int kk = p >> 8, rem = p & 255;
-    a_off[i] = (kk * a.NP + n0) * 8 + rem * 4;
-    b_off[i] = (kk * a.Mp + m0) * 8 + rem * 4;
-  }
+  // DMA item i of this wave = K chunk i of the stage (uniform), 16-byte piece wave*64 + lane of its 128 rows: SADDR form,
+  // no VALU address arithmetic in the loop (see glds16_saddr)
+  static_assert(IT == KCH, "one 1-KiB wave-load per wave per K chunk per operand");
+  const unsigned dma_lane = (unsigned)((wave * 64 + lane) * 16);
   const size_t a_stage = (size_t)KCH * a.NP * 8, b_stage = (size_t)KCH * a.Mp * 8;
-  auto issue_a = [&](int st, int s, int i) { glds16(a.wpk + (size_t)st * a_stage + a_off[i], lds + s * STAGE + (i * 4 + wave) * 256); };
-  auto issue_b = [&](int st, int s, int i) { glds16(a.x + (size_t)st * b_stage + b_off[i], lds + s * STAGE + OP_FLOATS + (i * 4 + wave) * 256); };
+  const float *const a_tile = a.wpk + (size_t)n0 * 8, *const b_tile = a.x + (size_t)m0 * 8;
+  const unsigned lds0 = lds_byte_addr(lds) + (unsigned)(wave * 256) * 4;
+  auto issue_a = [&](int st, int s, int i) {
+    glds16_saddr(a_tile + (size_t)st * a_stage + (size_t)i * a.NP * 8, dma_lane, lds0 + (unsigned)(s * STAGE + i * 1024) * 4);
+  };
+  auto issue_b = [&](int st, int s, int i) {
+    glds16_saddr(b_tile + (size_t)st * b_stage + (size_t)i * a.Mp * 8, dma_lane, lds0 + (unsigned)(s * STAGE + OP_FLOATS + i * 1024) * 4);
+  };
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -1891,6 +1938,7 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
   };
 #pragma unroll
   for (int i = 0; i < IT; ++i) { issue_a(st0, 0, i); issue_b(st0, 0, i); }
+  dma_wait_all();
   __syncthreads();
   load_frags(0, 0, 0);
 
@@ -1903,6 +1951,7 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
       const int cur = kk & 1;
       if (kk == KCH - 1 && MORE) {
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's last reads of stage s are done
+        dma_wait_all();                      // and the next stage it issued has landed
         __syncthreads();
         load_frags(s ^ 1, 0, 0);
       }
@@ -2424,6 +2473,7 @@ extern "C" void mpn_debug_set_wino_trace(void *p) { g_wino_trace = static_cast<u
 extern "C" void mpn_debug_set_conv_variant(int v) { g_conv_variant = v; }
 extern "C" void mpn_debug_set_gemm_regstage(int v) { g_gemm_regstage = v; }
 extern "C" void mpn_debug_set_conv_split(int v) { g_conv_split = v; }
+extern "C" void mpn_debug_set_conv_persist_blocks(int v) { g_persist_blocks = v; }
 extern "C" void mpn_debug_set_conv_mode(int v) { g_conv_mode = v; }  // 1 = persistent stream-K, 0 = block per tile
 extern "C" void mpn_debug_set_gemm_split(int v) { g_gemm_split = v; }
 extern "C" void mpn_debug_set_gemm_kch(int v) { g_gemm_kch = (v == 4 || v == 8) ? v : 0; }
