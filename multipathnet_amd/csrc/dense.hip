@@ -412,10 +412,12 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
   const int c1 = min(a.nchunks, c0 + a.chunks_per_split);
   // prologue: one DMA round trip for both raw tiles and the first weight slices (the accumulator zeroing
   // overlaps it), then the first input transform
-  issue_raw(c0, 0);
+  const int n_more = c1 - 1 - c0;  // chunks that prefetch a successor
+  const int b0 = n_more & 1;       // chunk c lives in buffer (c - c0 + b0) & 1, so that the LAST chunk is always in buffer 0
+  issue_raw(c0, b0);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) issue_u(c0, 0, i);
-  issue_raw(min(c0 + 1, c1 - 1), 1);
+  for (int i = 0; i < 8; ++i) issue_u(c0, b0, i);
+  issue_raw(min(c0 + 1, c1 - 1), b0 ^ 1);
   f32x16 acc[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k)
@@ -423,10 +425,10 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
     for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
   dma_wait_all();
   __syncthreads();
-  tf_load(0);
+  tf_load(b0);
   tf_rows();
 #pragma unroll
-  for (int xi = 0; xi < 4; ++xi) tf_cols_store(xi, 0);
+  for (int xi = 0; xi < 4; ++xi) tf_cols_store(xi, b0);
   __syncthreads();
 
   const int frag_u = (mbase + l31) * 8 + half * 4, frag_v = (nbase + l31) * 8 + half * 4;
@@ -451,11 +453,11 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
       bf[slot][k] = *reinterpret_cast<const f32x4 *>(Vl + (2 * pr + k) * 512);
     }
   };
-  load_frags(0, 0, 0);
+  load_frags(b0, 0, 0);
   unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
-  auto body = [&](int c, auto more_tag) {
+  auto body = [&](int c, auto more_tag, auto parity_tag) {  // buffer parity s is a compile-time tag: LDS offsets become immediates
     constexpr bool MORE = decltype(more_tag)::value;
-    const int s = (c - c0) & 1;
+    constexpr int s = decltype(parity_tag)::value;
 #pragma unroll
     for (int p = 0; p < 8; ++p) {  // component pair (2p, 2p+1): two independent accumulator chains
       const int cur = p & 1;
@@ -507,7 +509,11 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
     }
   };
   if constexpr ((ABL & 64) != 0) tk1 = __builtin_amdgcn_s_memtime();
-  for (int c = c0; c < c1 - 1; ++c) body(c, std::true_type{});
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  int cc = c0;
+  if (n_more & 1) { body(cc, std::true_type{}, P1{}); ++cc; }   // the first chunk sits in buffer n_more & 1, the last in buffer 0
+  for (; cc < c1 - 1; cc += 2) { body(cc, std::true_type{}, P0{}); body(cc + 1, std::true_type{}, P1{}); }
   // the epilogue's bias vectors are fetched under the last chunk's MFMAs (the transform registers are free there): a
   // global load inside the epilogue would sit behind an s_waitcnt vmcnt(0) that also waits for the previous channel
   // group's STORES to be acknowledged (measured: 9.8k-cycle epilogue)
@@ -517,7 +523,7 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
     const int cb = min((cout0 + mbase) / 8 + g, a.out_cb - 1);
     bias4[g] = *reinterpret_cast<const f32x4 *>(a.bpk + cb * 8 + half * 4);
   }
-  body(c1 - 1, std::false_type{});
+  body(c1 - 1, std::false_type{}, P0{});
   if constexpr ((ABL & 64) != 0) tk2 = __builtin_amdgcn_s_memtime();
 
   // ---- output transform A^T M A (register-local), bias, ReLU, stores, fused 2x2 max-pool
