@@ -79,6 +79,12 @@ int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float
 // Mp: row pitch of the output matrix (0 = lin_mp(N)).
 int roi_pool_c8(Act feat, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset, int end_adjust,
                 float *d_x_c8, int32_t *d_argmax, hipStream_t s, int roi_stride = 5, int Mp = 0);
+// vertical range-max tables of a C8P map (levels 1..vmax_levels_for(H), each feat.elems() floats) and the ROI max-pool that
+// reads them: identical output to roi_pool_c8 (no argmax), cost 2 x bin-width reads per bin instead of bin-height x bin-width
+int vmax_levels_for(int H);
+int build_vmax_tables(Act feat, float *d_tables, hipStream_t s);
+int roi_pool_c8_rmq(Act feat, const float *d_tables, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset,
+                    int end_adjust, float *d_x_c8, hipStream_t s, int roi_stride = 5, int Mp = 0);
 // in-place x * (mul / sqrt(sum x^2 + 1e-10)) per ROI over n_records 8-float records of a C8 matrix
 int l2norm_scale_c8(float *d_x_c8, int n_records, int Mp, int N, float mul, hipStream_t s);
 

@@ -1942,16 +1942,19 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) bf[slot][ni] = *reinterpret_cast<const f32x4 *>(Bl + (kk * 128 + wn * 64 + ni * 32) * 8);
   };
+  if (st0 >= st1) return;  // (never: every split owns at least one stage)
+  const int n_more = st1 - 1 - st0;  // stages that prefetch a successor
+  const int b0 = n_more & 1;         // stage st lives in buffer (st - st0 + b0) & 1: the LAST stage is always in buffer 0
 #pragma unroll
-  for (int i = 0; i < IT; ++i) { issue_a(st0, 0, i); issue_b(st0, 0, i); }
+  for (int i = 0; i < IT; ++i) { issue_a(st0, b0, i); issue_b(st0, b0, i); }
   dma_wait_all();
   __syncthreads();
-  load_frags(0, 0, 0);
+  load_frags(b0, 0, 0);
 
   static_assert(KCH % 2 == 0, "fragment slot parity assumes an even chunk count per stage");
-  auto body = [&](int st, auto more_tag) {
+  auto body = [&](int st, auto more_tag, auto parity_tag) {  // buffer parity is a compile-time tag: LDS offsets become immediates
     constexpr bool MORE = decltype(more_tag)::value;
-    const int s = (st - st0) & 1;
+    constexpr int s = decltype(parity_tag)::value;
 #pragma unroll
     for (int kk = 0; kk < KCH; ++kk) {
       const int cur = kk & 1;
@@ -1974,8 +1977,12 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
       }
     }
   };
-  for (int st = st0; st < st1 - 1; ++st) body(st, std::true_type{});
-  if (st0 < st1) body(st1 - 1, std::false_type{});
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  int st = st0;
+  if (n_more & 1) { body(st, std::true_type{}, P1{}); ++st; }
+  for (; st < st1 - 1; st += 2) { body(st, std::true_type{}, P0{}); body(st + 1, std::true_type{}, P1{}); }
+  body(st1 - 1, std::false_type{}, P0{});
 
   float *yb = a.y + (a.direct ? (size_t)0 : (size_t)split * (a.NP / 8) * a.Mp * 8);
 #pragma unroll
@@ -2460,6 +2467,105 @@ int l2norm_scale_c8(float *d_x_c8, int n_records, int Mp, int N, float mul, hipS
   return MPN_OK;
 }
 
+// ---- ROI max-pool through vertical range-max tables (MultiPathNet head) ----------------------------------------
+// The skip-pool towers pool the stride-4 / stride-8 maps over Foveal regions up to 4x the ROI: a bin can cover hundreds
+// of pixels (a 21 x 36 window on conv3 for a full-image x4 region), and the direct kernel visits every one of them for
+// each of 11 (tower, map) pools.  Level k of the table holds T_k[y][x] = max(feat[y .. y + 2^k - 1][x]) (rows clipped at
+// H), built once per image by doubling; a bin [hs, he) x [ws, we) is then max over x of max(T_k[hs][x], T_k[he - 2^k][x])
+// with k = floor(log2(he - hs)): 2 (we - ws) reads instead of (he - hs)(we - ws).  max is exact, so the result is
+// identical to the direct kernel's (no argmax: the inference pipeline does not need it).
+__global__ void vmax_level_kernel(const float *__restrict__ prev, float *__restrict__ out, int Cb, int H, int W, int Hp, int Wp, int step) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)Cb * H * W * 2;
+  if (t >= total) return;
+  const int h = (int)(t & 1); size_t r = t >> 1;
+  const int x = (int)(r % W); r /= W;
+  const int y = (int)(r % H); const int cb = (int)(r / H);
+  const size_t base = (size_t)cb * Hp * Wp * 8 + h * 4;
+  const size_t o = base + ((size_t)(y + 1) * Wp + x + 1) * 8;
+  f32x4 a = *reinterpret_cast<const f32x4 *>(prev + o);
+  if (y + step < H) {
+    const f32x4 b = *reinterpret_cast<const f32x4 *>(prev + base + ((size_t)(y + step + 1) * Wp + x + 1) * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = b[e] > a[e] ? b[e] : a[e];
+  }
+  *reinterpret_cast<f32x4 *>(out + o) = a;
+}
+
+int vmax_levels_for(int H) {  // levels 1 .. L with 2^L <= H
+  int L = 0;
+  while ((2 << L) <= H) ++L;
+  return L;
+}
+
+int build_vmax_tables(Act feat, float *d_tables, hipStream_t s) {
+  MPN_CHECK_ARG(feat.p && d_tables);
+  const int L = vmax_levels_for(feat.H);
+  const size_t total = (size_t)feat.Cb() * feat.H * feat.W * 2;
+  const float *prev = feat.p;
+  for (int k = 1; k <= L; ++k) {
+    float *out = d_tables + (size_t)(k - 1) * feat.elems();
+    hipLaunchKernelGGL(vmax_level_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, prev, out, feat.Cb(), feat.H, feat.W, feat.Hp,
+                       feat.Wp, 1 << (k - 1));
+    MPN_CHECK_LAUNCH();
+    prev = out;
+  }
+  return MPN_OK;
+}
+
+__global__ __launch_bounds__(256) void roi_pool_c8_rmq_kernel(const float *__restrict__ feat, const float *__restrict__ tables, size_t level_elems,
+                                                              int C, int H, int W, int Hp, int Wp, const float *__restrict__ rois,
+                                                              int roi_stride, int N, int PH, int PW, float scale, float coord_offset,
+                                                              int end_adjust, float *__restrict__ xc8, int Mp) {
+  const int Cb = (C + 7) / 8, PP = PH * PW;
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)Cb * PP * N * 2;
+  if (t >= total) return;
+  int h = (int)(t & 1); size_t r = t >> 1;
+  int n = (int)(r % N); r /= N;
+  int bin = (int)(r % PP); int cb = (int)(r / PP);
+  int ph = bin / PW, pw = bin - ph * PW;
+  const float *ro = rois + (size_t)roi_stride * n;
+  int sw = (int)roundf((ro[1] - coord_offset) * scale);
+  int sh = (int)roundf((ro[2] - coord_offset) * scale);
+  int ew = (int)roundf((ro[3] - coord_offset) * scale) + end_adjust;
+  int eh = (int)roundf((ro[4] - coord_offset) * scale) + end_adjust;
+  int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
+  float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+  int hs = (int)floorf((float)ph * bh) + sh, he = (int)ceilf((float)(ph + 1) * bh) + sh;
+  int ws = (int)floorf((float)pw * bw) + sw, we = (int)ceilf((float)(pw + 1) * bw) + sw;
+  hs = min(max(hs, 0), H); he = min(max(he, 0), H);
+  ws = min(max(ws, 0), W); we = min(max(we, 0), W);
+  const bool empty = (he <= hs) || (we <= ws);
+  f32x4 m = empty ? f32x4{0, 0, 0, 0} : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  if (!empty) {
+    const int k = 31 - __clz(he - hs);  // 2^k <= he - hs < 2^(k+1)
+    const float *lvl = (k == 0) ? feat : tables + (size_t)(k - 1) * level_elems;
+    const float *r0 = lvl + (size_t)cb * Hp * Wp * 8 + h * 4 + ((size_t)(hs + 1) * Wp + 1) * 8;
+    const float *r1 = lvl + (size_t)cb * Hp * Wp * 8 + h * 4 + ((size_t)(he - (1 << k) + 1) * Wp + 1) * 8;
+    for (int x = ws; x < we; ++x) {
+      const f32x4 a = *reinterpret_cast<const f32x4 *>(r0 + (size_t)x * 8);
+      const f32x4 b = *reinterpret_cast<const f32x4 *>(r1 + (size_t)x * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = b[e] > a[e] ? b[e] : a[e];
+        if (v > m[e]) m[e] = v;
+      }
+    }
+  }
+  *reinterpret_cast<f32x4 *>(xc8 + (((size_t)cb * PP + bin) * Mp + n) * 8 + h * 4) = m;
+}
+
+int roi_pool_c8_rmq(Act feat, const float *d_tables, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset,
+                    int end_adjust, float *d_x_c8, hipStream_t s, int roi_stride, int Mp) {
+  MPN_CHECK_ARG(feat.p && d_tables && d_rois && d_x_c8 && N > 0 && PH > 0 && PW > 0);
+  size_t total = (size_t)feat.Cb() * PH * PW * N * 2;
+  hipLaunchKernelGGL(roi_pool_c8_rmq_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, feat.p, d_tables, feat.elems(), feat.C, feat.H,
+                     feat.W, feat.Hp, feat.Wp, d_rois, roi_stride, N, PH, PW, scale, coord_offset, end_adjust, d_x_c8, Mp > 0 ? Mp : lin_mp(N));
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
 int roi_pool_c8(Act feat, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset, int end_adjust,
                 float *d_x_c8, int32_t *d_argmax, hipStream_t s, int roi_stride, int Mp) {
   MPN_CHECK_ARG(feat.p && d_rois && d_x_c8 && N > 0 && PH > 0 && PW > 0);
@@ -2574,6 +2680,38 @@ extern "C" int mpn_debug_bench_linear(int M, int K, int N, int iters, float *ms_
   *ms_out = ms / iters;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(x); (void)hipFree(w); (void)hipFree(b); (void)hipFree(y);
+  return rc;
+}
+
+// test hook: direct vs range-max-table ROI pooling of the same NCHW map; returns the number of output words that differ
+__global__ void count_diff_kernel(const float *a, const float *b, size_t n, int *cnt) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n && !(a[t] == b[t])) atomicAdd(cnt, 1);
+}
+extern "C" int mpn_debug_roi_pool_rmq_mismatches(const float *d_feat_nchw, int C, int H, int W, const float *d_rois, int roi_stride, int N,
+                                                 int PH, int PW, float scale, int *n_mismatch) {
+  MPN_CHECK_ARG(d_feat_nchw && d_rois && n_mismatch && C > 0 && H > 0 && W > 0 && N > 0);
+  float *act = nullptr, *tab = nullptr, *o1 = nullptr, *o2 = nullptr;
+  int *cnt = nullptr;
+  const size_t ab = act_bytes(C, H, W);
+  const int L = vmax_levels_for(H);
+  const size_t oe = (size_t)((C + 7) / 8) * PH * PW * lin_mp(N) * 8;
+  MPN_CHECK_HIP(hipMalloc(&act, ab));
+  MPN_CHECK_HIP(hipMalloc(&tab, ab * (L > 0 ? L : 1)));
+  MPN_CHECK_HIP(hipMalloc(&o1, oe * 4)); MPN_CHECK_HIP(hipMalloc(&o2, oe * 4));
+  MPN_CHECK_HIP(hipMalloc(&cnt, 4));
+  MPN_CHECK_HIP(hipMemset(act, 0, ab)); MPN_CHECK_HIP(hipMemset(o1, 0, oe * 4)); MPN_CHECK_HIP(hipMemset(o2, 0, oe * 4));
+  MPN_CHECK_HIP(hipMemset(cnt, 0, 4));
+  Act a = make_act(act, C, H, W);
+  int rc = nchw_to_c8p(d_feat_nchw, C, H, W, a, nullptr);
+  if (rc == MPN_OK) rc = build_vmax_tables(a, tab, nullptr);
+  if (rc == MPN_OK) rc = roi_pool_c8(a, d_rois, N, PH, PW, scale, 1.0f, 0, o1, nullptr, nullptr, roi_stride, 0);
+  if (rc == MPN_OK) rc = roi_pool_c8_rmq(a, tab, d_rois, N, PH, PW, scale, 1.0f, 0, o2, nullptr, roi_stride, 0);
+  if (rc == MPN_OK) {
+    hipLaunchKernelGGL(count_diff_kernel, dim3((unsigned)cdiv_sz(oe, 256)), dim3(256), 0, nullptr, o1, o2, oe, cnt);
+    MPN_CHECK_HIP(hipMemcpy(n_mismatch, cnt, 4, hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(act); (void)hipFree(tab); (void)hipFree(o1); (void)hipFree(o2); (void)hipFree(cnt);
   return rc;
 }
 

@@ -161,6 +161,8 @@ struct mpn_frcnn {
   float *fov = nullptr, *tx = nullptr, *ty = nullptr, *tz6 = nullptr, *cat = nullptr, *cls_rm = nullptr, *bbox_rm = nullptr;
   float *wcls = nullptr, *bcls = nullptr, *wbbox = nullptr, *bbbox = nullptr;
   Act tap_act[3];  // conv5, conv4, conv3 of the last trunk run
+  float *vmax_tab[3] = {nullptr, nullptr, nullptr};  // vertical range-max tables of the three maps (MultiPathNet ROI pools)
+  bool vmax_valid = false;                            // built for the current tap_act maps
   std::vector<void *> allocs;
   // optional per-kernel-group timing with HIP events recorded on the launch stream
   bool prof = false;
@@ -256,6 +258,10 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
     b = act_bytes(L.Cout, h, w);
     TRY(dev_alloc(p, &L.out, b, true));
     p->act_bufs.push_back({L.out, b});
+    if (mw && (l == mw->tap_conv3 || l == mw->tap_conv4 || l == cfg->n_conv - 1)) {  // range-max tables of the maps the towers pool
+      const int slot = l == cfg->n_conv - 1 ? 0 : (l == mw->tap_conv4 ? 1 : 2);
+      TRY(dev_alloc(p, &p->vmax_tab[slot], (size_t)(vmax_levels_for(h) > 0 ? vmax_levels_for(h) : 1) * b, false));
+    }
     if (L.pool) {
       h = (h + 1) / 2; w = (w + 1) / 2;
       b = act_bytes(L.Cout, h, w);
@@ -387,6 +393,7 @@ static int run_trunk(mpn_frcnn *p, const float *d_image, int H, int W, hipStream
     p->last_h = H; p->last_w = W;
   }
   Act cur = make_act(p->img_c8p, 3, H, W);
+  p->vmax_valid = false;
   int rc;
   { ProfScope ps(p, MPN_PROF_TRANSFORM, s);
     rc = image_transform_c8p(d_image, H, W, c.tf_swap, c.tf_scale, c.tf_mean, c.tf_std, c.tf_std[0] != 0.0, cur, s); }
@@ -433,6 +440,12 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
   const Act maps[3] = {p->tap_act[0], p->tap_act[1], p->tap_act[2]};
   const float scales[3] = {c.spatial_scale, c.spatial_scale * 2.0f, c.spatial_scale * 4.0f};
   const int Fcb = lin_np(F) / 8;
+  if (!p->vmax_valid) {  // once per trunk run; iterative localisation on the cached maps reuses them
+    ProfScope ps(p, MPN_PROF_ROIPOOL, s);
+    for (int m = 0; m < 3 && rc == MPN_OK; ++m) rc = build_vmax_tables(maps[m], p->vmax_tab[m], s);
+    if (rc) return rc;
+    p->vmax_valid = true;
+  }
   int ti = 0;
   for (auto &T : p->towers) {
     const float *reg = p->fov + 5 * T.region;  // rows 4n + region of the Foveal table
@@ -442,7 +455,7 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
       if (!used[m]) continue;
       float *dst = p->tx + (size_t)cb_off * PP * Mp * 8;
       { ProfScope ps(p, MPN_PROF_ROIPOOL, s);
-        rc = roi_pool_c8(maps[m], reg, N, c.pooled_h, c.pooled_w, scales[m], 1.0f, 0, dst, nullptr, s, 20, Mp);
+        rc = roi_pool_c8_rmq(maps[m], p->vmax_tab[m], reg, N, c.pooled_h, c.pooled_w, scales[m], 1.0f, 0, dst, s, 20, Mp);
         if (rc == MPN_OK) rc = l2norm_scale_c8(dst, maps[m].Cb() * PP, Mp, N, 1000.0f, s); }
       if (rc) return rc;
       cb_off += maps[m].Cb();

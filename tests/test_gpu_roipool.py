@@ -53,3 +53,27 @@ def test_roi_pool_convention_is_parameterised(O, dev):
         ref, arg = O.roi_pool(feat, rois, 7, 7, 1 / 16, coord_offset=off, end_adjust=adj)
         assert np.array_equal(m.forward([_t(feat, dev), _t(rois, dev)]).cpu().numpy(), ref)
         assert np.array_equal(m.indices.cpu().numpy(), arg)
+
+
+@pytest.mark.parametrize("C,H,W,N,scale", [(16, 150, 250, 300, 0.25), (24, 75, 125, 200, 0.125), (8, 38, 63, 128, 0.0625), (8, 1, 1, 5, 1.0),
+                                           (8, 2, 37, 40, 0.5), (40, 9, 3, 33, 0.1)])
+def test_roi_pool_range_max_tables_equal_direct(dev, C, H, W, N, scale):
+    """the MultiPathNet head's ROI pool reads vertical range-max tables (2 x bin-width reads per bin): its output must be
+    identical to the direct kernel's — signed features, regions up to 4x the image (Foveal), degenerate and outside boxes"""
+    import ctypes
+    import multipathnet_amd
+    lib = multipathnet_amd.load()
+    rng = np.random.default_rng(C * 100 + H)
+    feat = rng.standard_normal((C, H, W)).astype(np.float32)
+    img_w, img_h = W / scale, H / scale
+    cx, cy = rng.uniform(-0.2, 1.2, N) * img_w, rng.uniform(-0.2, 1.2, N) * img_h
+    bw, bh = np.exp(rng.uniform(np.log(1.0), np.log(4 * img_w), N)), np.exp(rng.uniform(np.log(1.0), np.log(4 * img_h), N))
+    rois = np.stack([np.ones(N), cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2], 1).astype(np.float32)
+    rois[0, 1:] = [5, 5, 5, 5]                      # 1-pixel box
+    rois[1 % N, 1:] = [-500, -500, -400, -400]      # entirely outside -> empty bins -> 0
+    f = torch.from_numpy(feat).to(dev)
+    r = torch.from_numpy(rois).to(dev)
+    n = ctypes.c_int(-1)
+    rc = lib.mpn_debug_roi_pool_rmq_mismatches(ctypes.c_void_p(f.data_ptr()), C, H, W, ctypes.c_void_p(r.data_ptr()), 5, N, 7, 7,
+                                               ctypes.c_float(scale), ctypes.byref(n))
+    assert rc == 0 and n.value == 0
