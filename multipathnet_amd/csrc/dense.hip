@@ -1589,6 +1589,27 @@ static int conv_pick_splits(int blocks, int nchunks, int slots) {
   return best;
 }
 
+// Split-K choice for the Winograd kernel from its measured cost model (tools/wino_trace.py): one block = 4.74 k cycles per
+// 8-channel chunk + 14 k cycles of prologue / epilogue, 256 blocks per round; a split layer pays the slab pass
+// ((S + 1) x output bytes at ~8 TB/s — the slabs are still in the 256-MB Infinity Cache — + ~3 us for the extra launch;
+// calibrated against tools/wino_split_sweep.py).
+static int wino_pick_splits(int blocks, int nchunks, size_t out_bytes) {
+  if (g_conv_split > 0) return g_conv_split < nchunks ? g_conv_split : nchunks;
+  const double t_chunk = 4740.0, t_ovh = 14000.0, hz = 2.35e9;
+  int best = 1;
+  double best_t = 1e30;
+  for (int S = 1; S <= 8 && S <= nchunks; ++S) {
+    const int cps = (nchunks + S - 1) / S;
+    const int Se = (nchunks + cps - 1) / cps;
+    if (Se != S) continue;
+    const long long rounds = ((long long)blocks * S + 255) / 256;
+    double t = rounds * (cps * t_chunk + t_ovh);
+    if (S > 1) t += ((S + 1) * (double)out_bytes / 8.0e12 + 3e-6) * hz;
+    if (t < best_t * 0.995) { best_t = t; best = S; }
+  }
+  return best;
+}
+
 static int g_conv_variant = 0;  // 0 = auto; test/bench hook: 1 = 128x4 tile / 9 taps per stage, 2 = 64x8 / 9, 3 = 128x4 / 3, 4 = 64x8 / 3,
                                  // 5 = 128 couts x 8 rows (64x128 per wave, 8 accumulators), 6 = 64 couts x 16 rows
 
@@ -1654,7 +1675,7 @@ int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int re
       pa.c = a;
       return launch_conv_wino_persistent(pa, s);
     }
-    a.splits = conv_pick_splits(blocks, a.nchunks, 256);
+    a.splits = wino_pick_splits(blocks, a.nchunks, geo.elems() * sizeof(float));
     a.chunks_per_split = cdiv(a.nchunks, a.splits);
     a.splits = cdiv(a.nchunks, a.chunks_per_split);
     if (a.splits > 1) {
