@@ -2564,14 +2564,21 @@ __global__ __launch_bounds__(256) void roi_pool_c8_rmq_kernel(const float *__res
     const float *lvl = (k == 0) ? feat : tables + (size_t)(k - 1) * level_elems;
     const float *r0 = lvl + (size_t)cb * Hp * Wp * 8 + h * 4 + ((size_t)(hs + 1) * Wp + 1) * 8;
     const float *r1 = lvl + (size_t)cb * Hp * Wp * 8 + h * 4 + ((size_t)(he - (1 << k) + 1) * Wp + 1) * 8;
-    for (int x = ws; x < we; ++x) {
-      const f32x4 a = *reinterpret_cast<const f32x4 *>(r0 + (size_t)x * 8);
-      const f32x4 b = *reinterpret_cast<const f32x4 *>(r1 + (size_t)x * 8);
+    for (int xb = ws; xb < we; xb += 4) {  // 8 independent loads in flight; positions past the window re-read its last column
+      f32x4 a[4], b[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float v = b[e] > a[e] ? b[e] : a[e];
-        if (v > m[e]) m[e] = v;
+      for (int j = 0; j < 4; ++j) {
+        const int x = min(xb + j, we - 1);
+        a[j] = *reinterpret_cast<const f32x4 *>(r0 + (size_t)x * 8);
+        b[j] = *reinterpret_cast<const f32x4 *>(r1 + (size_t)x * 8);
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = b[j][e] > a[j][e] ? b[j][e] : a[j][e];
+          if (v > m[e]) m[e] = v;
+        }
     }
   }
   *reinterpret_cast<f32x4 *>(xc8 + (((size_t)cb * PP + bin) * Mp + n) * 8 + h * 4) = m;
