@@ -256,6 +256,27 @@ int mpn_mpnet_create(const mpn_frcnn_config *cfg, const float *const *d_conv_w, 
                      const mpn_mpnet_weights *mw, const float *d_cls_w, const float *d_cls_b, const float *d_bbox_w,
                      const float *d_bbox_b, mpn_frcnn **out);
 
+/* ResNet Fast R-CNN (models/resnet.lua:24-50): net:get(1..7) = conv1 7x7/2, BN, ReLU, max-pool 3x3/2 pad 1,
+ * layer1-3 run on the image; inn.ROIPooling(14,14,1/16); net:get(8..10) = layer4 + 7x7 average pool + View run per ROI;
+ * classAndBBoxLinear on the pooled vector.  The fb.resnet.torch `.t7` is not in the tree: the caller describes the graph —
+ * every convolution in execution order (conv1, then per residual block its convolutions followed by its shortcut
+ * convolution if it has one), BatchNorm already folded into w / b (inn.utils.BNtoFixed, resnet.lua:34-36).  A block is
+ * relu(conv_n(... relu(conv_1(x)) ...) + shortcut(x)).  Uses cfg->{max_h,max_w,max_rois,n_classes,pooled_h,spatial_scale,
+ * tf_*,bbox_*,nms_*,score_thresh,top_k,num_iter,bbox_voting,...}; cfg->n_conv / conv_cout / pool_after / fc_dim are ignored.
+ * All pointers are device pointers; fp32. */
+typedef struct mpn_resnet_weights {
+  int n_convs;
+  const float *const *w;       /* [n_convs] -> [cout, cin, k, k] */
+  const float *const *b;       /* [n_convs] -> [cout] (may be NULL = no biases) */
+  const int *cin, *cout, *ksize, *stride, *pad;   /* [n_convs] */
+  int n_blocks;
+  const int *block_n_convs;       /* [n_blocks] convolutions on the residual path */
+  const int *block_has_shortcut;  /* [n_blocks] 1 = a shortcut convolution follows the block's convolutions in the list */
+  int n_trunk_blocks;             /* blocks [0, n_trunk_blocks) = layer1-3 (image trunk); the rest = layer4 (per-ROI head) */
+} mpn_resnet_weights;
+int mpn_resnet_create(const mpn_frcnn_config *cfg, const mpn_resnet_weights *rw, const float *d_cls_w, const float *d_cls_b,
+                      const float *d_bbox_w, const float *d_bbox_b, mpn_frcnn **out);
+
 /* ImageDetect:detect on a scale-1 image (getImages' resample is the identity):
  * d_image [3,H,W] fp32 in [0,1]; d_boxes [N,4].  Outputs (all optional, device):
  *   d_scores [N,C] softmax, d_bbox [N,4C] decoded + clamped boxes.

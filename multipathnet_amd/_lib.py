@@ -41,6 +41,17 @@ class MpnetWeights(C.Structure):
     ]
 
 
+class ResnetWeights(C.Structure):
+    """mirror of mpn_resnet_weights (include/mpn.h)"""
+    _fields_ = [
+        ("n_convs", C.c_int), ("w", C.POINTER(f32p)), ("b", C.POINTER(f32p)),
+        ("cin", C.POINTER(C.c_int)), ("cout", C.POINTER(C.c_int)), ("ksize", C.POINTER(C.c_int)), ("stride", C.POINTER(C.c_int)),
+        ("pad", C.POINTER(C.c_int)),
+        ("n_blocks", C.c_int), ("block_n_convs", C.POINTER(C.c_int)), ("block_has_shortcut", C.POINTER(C.c_int)),
+        ("n_trunk_blocks", C.c_int),
+    ]
+
+
 def lib_path():
     return _LIB_PATH
 

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "dense.h"
+#include "resnet.h"
 
 namespace mpn {
 int launch_bbox_decode(const float *d_boxes, const float *d_deltas, int N, int C, float *d_out, int clamp, float im_w,
@@ -156,6 +157,7 @@ struct mpn_frcnn {
   // ---- MultiPathNet head (models/multipathnet.lua:64-120); empty for plain Fast R-CNN
   struct Tower { int region, use4, use3, total_feat; float *mix_w, *mix_b, *w6, *b6, *w7, *b7; };
   bool is_mpnet = false;
+  ResNetGraph *rn = nullptr;  // ResNet Fast R-CNN (mpn_resnet_create): trunk + per-ROI layer4 replace the VGG convs / fc6 / fc7
   int tap3 = -1, tap4 = -1, n_integral = 1;
   std::vector<Tower> towers;
   float *fov = nullptr, *tx = nullptr, *ty = nullptr, *tz6 = nullptr, *cat = nullptr, *cls_rm = nullptr, *bbox_rm = nullptr;
@@ -214,6 +216,7 @@ extern "C" void mpn_frcnn_destroy(mpn_frcnn *p) {
   for (int i = 0; i < 2; ++i) { if (p->ev_head[i]) (void)hipEventDestroy(p->ev_head[i]); if (p->ev_tail[i]) (void)hipEventDestroy(p->ev_tail[i]); }
   if (p->side) (void)hipStreamDestroy(p->side);
   for (void *q : p->allocs) (void)hipFree(q);
+  resnet_free(p->rn);
   if (p->scaled) (void)hipFree(p->scaled);
   if (p->scale_tmp) (void)hipFree(p->scale_tmp);
   if (p->dbg) (void)hipFree(p->dbg);
@@ -223,18 +226,20 @@ extern "C" void mpn_frcnn_destroy(mpn_frcnn *p) {
 static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w, const float *const *d_conv_b,
                        const float *d_fc6_w, const float *d_fc6_b, const float *d_fc7_w, const float *d_fc7_b,
                        const float *d_cls_w, const float *d_cls_b, const float *d_bbox_w, const float *d_bbox_b,
-                       const mpn_mpnet_weights *mw, mpn_frcnn **out) {
-  MPN_CHECK_ARG(cfg && d_conv_w && d_conv_b && d_cls_w && d_bbox_w && out);
-  MPN_CHECK_ARG(mw || (d_fc6_w && d_fc7_w));
-  MPN_CHECK_ARG(cfg->n_conv > 0 && cfg->conv_cout && cfg->pool_after);
-  MPN_CHECK_ARG(cfg->pooled_h > 0 && cfg->pooled_w > 0 && cfg->fc_dim > 0 && cfg->n_classes > 1);
+                       const mpn_mpnet_weights *mw, mpn_frcnn **out, const mpn_resnet_weights *rw = nullptr) {
+  MPN_CHECK_ARG(cfg && d_cls_w && d_bbox_w && out);
+  MPN_CHECK_ARG(rw || (d_conv_w && d_conv_b));
+  MPN_CHECK_ARG(rw || mw || (d_fc6_w && d_fc7_w));
+  MPN_CHECK_ARG(rw || (cfg->n_conv > 0 && cfg->conv_cout && cfg->pool_after && cfg->fc_dim > 0));
+  MPN_CHECK_ARG(cfg->pooled_h > 0 && cfg->pooled_w > 0 && cfg->n_classes > 1);
   MPN_CHECK_ARG(cfg->max_h > 0 && cfg->max_w > 0 && cfg->max_rois > 0 && cfg->max_rois <= MPN_NMS_MAX_BOXES);
   MPN_CHECK_ARG(cfg->top_k > 0);
   mpn_frcnn *p = new mpn_frcnn();
   p->cfg = *cfg;
   if (mw) { p->is_mpnet = true; p->tap3 = mw->tap_conv3; p->tap4 = mw->tap_conv4; p->n_integral = mw->n_integral > 0 ? mw->n_integral : 1; }
-  p->cout.assign(cfg->conv_cout, cfg->conv_cout + cfg->n_conv);
-  p->pool_after.assign(cfg->pool_after, cfg->pool_after + cfg->n_conv);
+  const int n_conv = rw ? 0 : cfg->n_conv;
+  p->cfg.n_conv = n_conv;
+  if (n_conv) { p->cout.assign(cfg->conv_cout, cfg->conv_cout + n_conv); p->pool_after.assign(cfg->pool_after, cfg->pool_after + n_conv); }
   p->cfg.conv_cout = p->cout.data();
   p->cfg.pool_after = p->pool_after.data();
   int rc = MPN_OK;
@@ -244,7 +249,7 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
   size_t b = act_bytes(3, h, w);
   TRY(dev_alloc(p, &p->img_c8p, b, true));
   p->act_bufs.push_back({p->img_c8p, b});
-  for (int l = 0; l < cfg->n_conv; ++l) {
+  for (int l = 0; l < n_conv; ++l) {
     MPN_CHECK_ARG(d_conv_w[l] != nullptr);
     ConvLayer L;
     L.Cin = cin; L.Cout = p->cout[l]; L.pool = p->pool_after[l];
@@ -258,8 +263,8 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
     b = act_bytes(L.Cout, h, w);
     TRY(dev_alloc(p, &L.out, b, true));
     p->act_bufs.push_back({L.out, b});
-    if (mw && (l == mw->tap_conv3 || l == mw->tap_conv4 || l == cfg->n_conv - 1)) {  // range-max tables of the maps the towers pool
-      const int slot = l == cfg->n_conv - 1 ? 0 : (l == mw->tap_conv4 ? 1 : 2);
+    if (mw && (l == mw->tap_conv3 || l == mw->tap_conv4 || l == n_conv - 1)) {  // range-max tables of the maps the towers pool
+      const int slot = l == n_conv - 1 ? 0 : (l == mw->tap_conv4 ? 1 : 2);
       TRY(dev_alloc(p, &p->vmax_tab[slot], (size_t)(vmax_levels_for(h) > 0 ? vmax_levels_for(h) : 1) * b, false));
     }
     if (L.pool) {
@@ -272,8 +277,13 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
     p->conv.push_back(L);
   }
   p->feat_c = cin;
+  if (rw) {  // ResNet: the graph object owns the trunk / layer4 weights and activations; the cls + bbox heads read its pooled vector
+    TRY(resnet_build(rw, cfg->max_h, cfg->max_w, cfg->max_rois, cfg->pooled_h, &p->rn));
+    p->feat_c = resnet_feat_channels(p->rn);
+  }
   // ---- head
-  const int PP = cfg->pooled_h * cfg->pooled_w, C = cfg->n_classes, F = cfg->fc_dim;
+  const int PP = cfg->pooled_h * cfg->pooled_w, C = cfg->n_classes, F = rw ? resnet_out_channels(p->rn) : cfg->fc_dim;
+  p->cfg.fc_dim = F;
   MPN_CHECK_ARG(p->feat_c % 8 == 0);
   p->K6 = p->feat_c * PP;
   p->Mp = lin_mp(cfg->max_rois);
@@ -321,12 +331,14 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
     TRY(dev_alloc(p, &p->cls_rm, M * K * C * sizeof(float), true));
     TRY(dev_alloc(p, &p->bbox_rm, M * 4 * C * sizeof(float), true));
   } else {
+  if (!rw) {
   TRY(dev_alloc(p, &p->w6, lin_wpk_elems(K6_32, F) * sizeof(float), false));
   TRY(dev_alloc(p, &p->b6, (size_t)lin_np(F) * sizeof(float), false));
   TRY(pack_linear_weights(d_fc6_w, d_fc6_b, p->K6, F, PP, p->w6, p->b6, nullptr));
   TRY(dev_alloc(p, &p->w7, lin_wpk_elems(F32, F) * sizeof(float), false));
   TRY(dev_alloc(p, &p->b7, (size_t)lin_np(F) * sizeof(float), false));
   TRY(pack_linear_weights(d_fc7_w, d_fc7_b, F, F, 1, p->w7, p->b7, nullptr));
+  }
   {  // cls and bbox heads share their input -> one [5C, F] GEMM (model_utils.lua:105-119 ConcatTable)
     float *tmp_w = nullptr, *tmp_b = nullptr;
     TRY(dev_alloc(p, &tmp_w, (size_t)5 * C * F * sizeof(float), false));
@@ -340,8 +352,10 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
     TRY(dev_alloc(p, &p->bh, (size_t)lin_np(5 * C) * sizeof(float), false));
     TRY(pack_linear_weights(tmp_w, tmp_b, F, 5 * C, 1, p->wh, p->bh, nullptr));
   }
+  if (!rw) {
   TRY(dev_alloc(p, &p->x6, (size_t)(K6_32 / 8) * p->Mp * 8 * sizeof(float), true));
   TRY(dev_alloc(p, &p->y6, (size_t)(lin_np(F) / 8) * p->Mp * 8 * sizeof(float), true));
+  }
   TRY(dev_alloc(p, &p->y7, (size_t)(lin_np(F) / 8) * p->Mp * 8 * sizeof(float), true));
   TRY(dev_alloc(p, &p->head, M * 5 * C * sizeof(float), true));
   }
@@ -520,7 +534,14 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const 
       if (rc) return rc;
       img = p->scaled;
     }
-    rc = run_trunk(p, img, H, W, s, &feat);
+    if (p->rn) {
+      ProfScope ps(p, MPN_PROF_CONV_DIRECT, s);
+      rc = resnet_trunk_forward(p->rn, img, H, W, c.tf_swap, c.tf_scale, c.tf_mean, c.tf_std, c.tf_std[0] != 0.0, s);
+    } else {
+      rc = run_trunk(p, img, H, W, s, &feat);
+    }
+  } else if (p->rn) {
+    if (!resnet_has_features(p->rn, H, W)) { set_error("run_detect: no cached features for a %dx%d image", H0, W0); return MPN_ESTATE; }
   } else {
     if (p->last_h != H || p->last_w != W || !p->tap_act[0].p) { set_error("run_detect: no cached features for a %dx%d image", H0, W0); return MPN_ESTATE; }
     feat = p->tap_act[0];
@@ -536,6 +557,11 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const 
     return rc;
   }
   const int C = c.n_classes, F = c.fc_dim;
+  if (p->rn) {  // resnet.lua:40-48: ROIPooling(14,14) -> layer4 -> average pool -> View; lands in y7 as the heads' operand
+    ProfScope ps(p, MPN_PROF_FC6, s);
+    rc = resnet_head_forward(p->rn, p->rois, N, c.spatial_scale, p->y7, lin_mp(N), s);
+    if (rc) return rc;
+  } else {
   { ProfScope ps(p, MPN_PROF_ROIPOOL, s);
     rc = roi_pool_c8(feat, p->rois, N, c.pooled_h, c.pooled_w, c.spatial_scale, 1.0f, 0, p->x6, nullptr, s); }
   if (rc) return rc;
@@ -543,6 +569,7 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const 
   if (rc) return rc;
   { ProfScope ps(p, MPN_PROF_FC7, s); rc = linear_c8(p->y6, N, F, p->w7, p->b7, F, 1, p->y7, nullptr, s); }
   if (rc) return rc;
+  }
   { ProfScope ps(p, MPN_PROF_HEADS, s); rc = linear_c8(p->y7, N, F, p->wh, p->bh, 5 * C, 0, nullptr, p->head, s); }
   if (rc) return rc;
   ProfScope ps_post(p, MPN_PROF_POST, s);
@@ -692,6 +719,12 @@ extern "C" int mpn_mpnet_create(const mpn_frcnn_config *cfg, const float *const 
                                 const float *d_bbox_w, const float *d_bbox_b, mpn_frcnn **out) {
   MPN_CHECK_ARG(mw != nullptr);
   return create_impl(cfg, d_conv_w, d_conv_b, nullptr, nullptr, nullptr, nullptr, d_cls_w, d_cls_b, d_bbox_w, d_bbox_b, mw, out);
+}
+
+extern "C" int mpn_resnet_create(const mpn_frcnn_config *cfg, const mpn_resnet_weights *rw, const float *d_cls_w, const float *d_cls_b,
+                                 const float *d_bbox_w, const float *d_bbox_b, mpn_frcnn **out) {
+  MPN_CHECK_ARG(rw != nullptr);
+  return create_impl(cfg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_cls_w, d_cls_b, d_bbox_w, d_bbox_b, nullptr, out, rw);
 }
 
 extern "C" int mpn_frcnn_set_profiling(mpn_frcnn *p, int enable) {

@@ -1,0 +1,28 @@
+// resnet.h — ResNet Fast R-CNN graph (models/resnet.lua:24-50): trunk conv1 / max-pool / layer1-3 on the
+// image, ROIPooling(14,14,1/16), per-ROI layer4 + global average pool.  fp32 MFMA, BN folded into the convolutions by the
+// caller.  Used by pipeline.hip (mpn_resnet_create); kernels in resnet.hip.
+//
+// Layout "C8I": [B][C/8][H][W][8] fp32 — a batch of channel-blocked maps WITHOUT halos: the generic convolution gathers
+// its input pixels with explicit bounds checks (7x7 pad 3, strides 1/2, 14x14 and 7x7 per-ROI maps), so a halo would only
+// inflate the thousand small per-ROI maps.  A pixel's 8 channels are one 32-byte record, as in C8P.
+#pragma once
+#include "dense.h"
+
+struct mpn_resnet_weights;
+
+namespace mpn {
+
+struct ResNetGraph;
+
+int resnet_build(const mpn_resnet_weights *rw, int max_h, int max_w, int max_rois, int pooled, ResNetGraph **out);
+void resnet_free(ResNetGraph *g);
+int resnet_feat_channels(const ResNetGraph *g);   // layer3 output channels (what the ROI pool reads)
+int resnet_out_channels(const ResNetGraph *g);    // layer4 output channels (what the cls / bbox heads read)
+// image [3,H,W] fp32 -> transformed -> conv1 -> pool -> layer1..3; the feature map is cached in the graph
+int resnet_trunk_forward(ResNetGraph *g, const float *d_image, int H, int W, const int *swap, double scale, const double *mean,
+                         const double *std, int has_std, hipStream_t s);
+bool resnet_has_features(const ResNetGraph *g, int H, int W);
+// rois [N,5] (projected) -> ROI pool -> layer4 -> average pool -> C8 matrix [out_c/8][Mp][8] (row = roi)
+int resnet_head_forward(ResNetGraph *g, const float *d_rois, int N, float spatial_scale, float *d_feat_c8, int Mp, hipStream_t s);
+
+}  // namespace mpn

@@ -1,0 +1,455 @@
+// resnet.hip — ResNet Fast R-CNN trunk and per-ROI head (models/resnet.lua:24-50) in fp32 on the matrix cores.
+//
+// One generic implicit-GEMM convolution (any kernel size / stride / pad, batched over maps, fused bias + residual add +
+// ReLU) covers conv1 7x7/2, the 1x1 / 3x3 convolutions of the residual blocks, the strided shortcuts and — with the
+// batch = the ROIs — the whole per-ROI layer4.  M side = 128 output channels, N side = 128 output pixels of the flattened
+// (map, y, x) index space, K step = 8 input channels of one filter tap.  Per step the 4-KiB weight slice is a linear copy of
+// the packed weights and the 4-KiB activation slice is GATHERED (one 16-byte load per thread, zero outside the map), both
+// staged through registers into double-buffered LDS; every MFMA operand fetch is then the same conflict-free ds_read_b128
+// as in dense.hip's kernels.  16 KiB of LDS per block lets several blocks share a CU, which hides the gather latency.
+#include <algorithm>
+#include <vector>
+
+#include "../../include/mpn.h"
+#include "resnet.h"
+
+namespace mpn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ActI {  // C8I batch of maps
+  float *p;
+  int B, C, H, W;
+  int Cb() const { return (C + 7) / 8; }
+  size_t elems() const { return (size_t)B * Cb() * H * W * 8; }
+};
+
+// ------------------------------------------------------------------------------------------------------------------------
+// packed weights: [tap = ky*KW + kx][Cin8/8][CoutP][8], CoutP = round_up(Cout, 128); bias [CoutP]
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ void pack_conv_generic_kernel(const float *__restrict__ w, const float *__restrict__ b, int Cin, int Cout, int KK, int nch, int CoutP,
+                                         float *__restrict__ wpk, float *__restrict__ bpk) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < (size_t)CoutP) bpk[t] = (t < (size_t)Cout && b) ? b[t] : 0.0f;
+  size_t total = (size_t)KK * nch * CoutP * 8;
+  if (t >= total) return;
+  const int j = (int)(t & 7);
+  size_t r = t >> 3;
+  const int co = (int)(r % CoutP); r /= CoutP;
+  const int ch = (int)(r % nch);
+  const int tap = (int)(r / nch);
+  const int ci = ch * 8 + j;
+  wpk[t] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * KK + tap] : 0.0f;
+}
+
+struct GConvArgs {
+  const float *in, *wpk, *bpk, *res;
+  float *out;
+  int B, Cb_in, H, W, nch;
+  int CoutP, Cb_out, KH, KW, stride, pad, OH, OW, relu;
+  long long P;  // B * OH * OW output pixels
+};
+
+__global__ __launch_bounds__(256) void conv2d_c8i_kernel(GConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[2][2][128 * 8];  // [buffer][A | B][row][8]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long long p0 = (long long)blockIdx.x * 128;
+  const int cout0 = blockIdx.y * 128;
+  const int OHW = a.OH * a.OW;
+
+  // staging roles: thread = (row tid>>1, 16-byte half tid&1) of both 128 x 8 slices
+  const int srow = tid >> 1, sh = tid & 1;
+  const long long gpix = p0 + srow;
+  const bool gvalid = gpix < a.P;
+  const int gb = gvalid ? (int)(gpix / OHW) : 0;
+  const int grem = gvalid ? (int)(gpix - (long long)gb * OHW) : 0;
+  const int goy = grem / a.OW, gox = grem - goy * a.OW;
+  const int iy0 = goy * a.stride - a.pad, ix0 = gox * a.stride - a.pad;
+  const size_t plane = (size_t)a.H * a.W * 8;
+  const float *in_b = a.in + (size_t)gb * a.Cb_in * plane + sh * 4;
+  const float *w_t = a.wpk + ((size_t)cout0 + srow) * 8 + sh * 4;
+  const size_t w_step = (size_t)a.CoutP * 8;
+
+  const int nsteps = a.KH * a.KW * a.nch;
+  f32x4 ra, rb;
+  auto fetch = [&](int step) {  // step = tap * nch + chunk
+    const int tap = step / a.nch, ch = step - tap * a.nch;
+    const int ky = tap / a.KW, kx = tap - ky * a.KW;
+    ra = *reinterpret_cast<const f32x4 *>(w_t + (size_t)step * w_step);
+    const int iy = iy0 + ky, ix = ix0 + kx;
+    const bool ok = gvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    rb = ok ? *reinterpret_cast<const f32x4 *>(in_b + (size_t)ch * plane + ((size_t)iy * a.W + ix) * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto stash = [&](int buf) {
+    *reinterpret_cast<f32x4 *>(&lds[buf][0][srow * 8 + sh * 4]) = ra;
+    *reinterpret_cast<f32x4 *>(&lds[buf][1][srow * 8 + sh * 4]) = rb;
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  const int frag = l31 * 8 + half * 4;
+  for (int step = 0; step < nsteps; ++step) {
+    const int buf = step & 1;
+    if (step + 1 < nsteps) fetch(step + 1);  // global loads in flight under this step's MFMAs
+    f32x4 af[2], bf[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) af[mi] = *reinterpret_cast<const f32x4 *>(&lds[buf][0][(wm * 64 + mi * 32) * 8 + frag]);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) bf[ni] = *reinterpret_cast<const f32x4 *>(&lds[buf][1][(wn * 64 + ni * 32) * 8 + frag]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
+    if (step + 1 < nsteps) stash(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: + bias (+ residual) -> ReLU -> C8I float4 stores
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const long long pix = p0 + wn * 64 + ni * 32 + l31;
+    if (pix >= a.P) continue;
+    const int b = (int)(pix / OHW);
+    const int rem = (int)(pix - (long long)b * OHW);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cb = (cout0 + wm * 64 + mi * 32) / 8 + g;
+        if (cb >= a.Cb_out) continue;
+        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bpk + cb * 8 + half * 4);
+        const size_t off = (((size_t)b * a.Cb_out + cb) * OHW + rem) * 8 + half * 4;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][g * 4 + e] + b4[e];
+        if (a.res) v += *reinterpret_cast<const f32x4 *>(a.res + off);
+        if (a.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.0f ? 0.0f : v[e];
+        }
+        *reinterpret_cast<f32x4 *>(a.out + off) = v;
+      }
+  }
+}
+
+// nn.SpatialMaxPooling(k,k,s,s,p,p), floor mode, on C8I
+__global__ void maxpool2d_c8i_kernel(const float *__restrict__ in, int BCb, int H, int W, int k, int stride, int pad, int OH, int OW,
+                                     float *__restrict__ out) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)BCb * OH * OW * 2;
+  if (t >= total) return;
+  const int h = (int)(t & 1); size_t r = t >> 1;
+  const int ox = (int)(r % OW); r /= OW;
+  const int oy = (int)(r % OH); const size_t bc = r / OH;
+  f32x4 m = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  for (int ky = 0; ky < k; ++ky)
+    for (int kx = 0; kx < k; ++kx) {
+      const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(in + ((bc * H + iy) * W + ix) * 8 + h * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+    }
+  *reinterpret_cast<f32x4 *>(out + ((bc * OH + oy) * OW + ox) * 8 + h * 4) = m;
+}
+
+// image transformer (modules/ImageTransformer.lua:19-33, f64 arithmetic) into a one-map C8I image (channels 3..7 zero)
+__global__ void image_transform_c8i_kernel(const float *__restrict__ in, int H, int W, int s0, int s1, int s2, double scale, double m0,
+                                           double m1, double m2, double d0, double d1, double d2, int has_std, float *__restrict__ out) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t plane = (size_t)H * W;
+  if (t >= plane) return;
+  double v0 = (double)in[(size_t)s0 * plane + t], v1 = (double)in[(size_t)s1 * plane + t], v2 = (double)in[(size_t)s2 * plane + t];
+  if (scale != 1.0) { v0 = v0 * scale; v1 = v1 * scale; v2 = v2 * scale; }
+  v0 = v0 + (-m0); v1 = v1 + (-m1); v2 = v2 + (-m2);
+  if (has_std) { v0 = v0 / d0; v1 = v1 / d1; v2 = v2 / d2; }
+  *reinterpret_cast<f32x4 *>(out + t * 8) = f32x4{(float)v0, (float)v1, (float)v2, 0.0f};
+  *reinterpret_cast<f32x4 *>(out + t * 8 + 4) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+}
+
+// inn.ROIPooling on a one-map C8I feature -> [N][Cb][PH][PW][8] (the batch the per-ROI head convolves); the bin arithmetic
+// is the same as roi_pool_c8_kernel / the oracle's orc_roi_pool (coord_offset 1, end_adjust 0)
+__global__ void roi_pool_c8i_kernel(const float *__restrict__ feat, int Cb, int H, int W, const float *__restrict__ rois, int N, int PH, int PW,
+                                    float scale, float *__restrict__ out) {
+  const int PP = PH * PW;
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)N * Cb * PP * 2;
+  if (t >= total) return;
+  const int h = (int)(t & 1); size_t r = t >> 1;
+  const int bin = (int)(r % PP); r /= PP;
+  const int cb = (int)(r % Cb); const int n = (int)(r / Cb);
+  const int ph = bin / PW, pw = bin - ph * PW;
+  const float *ro = rois + (size_t)5 * n;
+  const int sw = (int)roundf((ro[1] - 1.0f) * scale), sh = (int)roundf((ro[2] - 1.0f) * scale);
+  const int ew = (int)roundf((ro[3] - 1.0f) * scale), eh = (int)roundf((ro[4] - 1.0f) * scale);
+  const int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
+  const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+  int hs = (int)floorf((float)ph * bh) + sh, he = (int)ceilf((float)(ph + 1) * bh) + sh;
+  int ws = (int)floorf((float)pw * bw) + sw, we = (int)ceilf((float)(pw + 1) * bw) + sw;
+  hs = min(max(hs, 0), H); he = min(max(he, 0), H);
+  ws = min(max(ws, 0), W); we = min(max(we, 0), W);
+  const bool empty = (he <= hs) || (we <= ws);
+  f32x4 m = empty ? f32x4{0, 0, 0, 0} : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  const float *fp = feat + (size_t)cb * H * W * 8 + h * 4;
+  for (int y = hs; y < he; ++y)
+    for (int x = ws; x < we; ++x) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(fp + ((size_t)y * W + x) * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+    }
+  *reinterpret_cast<f32x4 *>(out + ((((size_t)n * Cb + cb) * PH + ph) * PW + pw) * 8 + h * 4) = m;
+}
+
+// 7x7 global average pool of [N][Cb][H][W][8] into the C8 matrix [Cb][Mp][8] the head GEMM reads (row = roi); the sum
+// runs in row-major order like the oracle's, then * 1/(H*W)
+__global__ void avgpool_c8i_to_c8_kernel(const float *__restrict__ in, int N, int Cb, int HW, float inv, float *__restrict__ out, int Mp) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)N * Cb * 2;
+  if (t >= total) return;
+  const int h = (int)(t & 1); size_t r = t >> 1;
+  const int n = (int)(r % N); const int cb = (int)(r / N);
+  const float *ip = in + (((size_t)n * Cb + cb) * HW) * 8 + h * 4;
+  f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < HW; ++i) sacc += *reinterpret_cast<const f32x4 *>(ip + (size_t)i * 8);
+  *reinterpret_cast<f32x4 *>(out + ((size_t)cb * Mp + n) * 8 + h * 4) = sacc * inv;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// graph
+// ------------------------------------------------------------------------------------------------------------------------
+struct RnConv {
+  int Cin = 0, Cout = 0, K = 0, stride = 1, pad = 0;
+  float *wpk = nullptr, *bpk = nullptr;
+};
+struct RnBlock {
+  std::vector<RnConv> convs;
+  bool has_sc = false;
+  RnConv sc;
+};
+struct ResNetGraph {
+  RnConv conv1;
+  std::vector<RnBlock> trunk, head;
+  int feat_c = 0, out_c = 0, pooled = 14, max_rois = 0;
+  float *img = nullptr;          // C8I image
+  float *tb[4] = {nullptr, nullptr, nullptr, nullptr};  // trunk activations (rotating)
+  float *hb[4] = {nullptr, nullptr, nullptr, nullptr};  // per-ROI head activations (rotating)
+  size_t tb_elems = 0, hb_elems = 0;
+  float *feat = nullptr;         // points into tb[]: layer3 output of the last trunk run
+  int feat_h = 0, feat_w = 0, last_h = -1, last_w = -1;
+  std::vector<void *> allocs;
+};
+
+static int rn_alloc(ResNetGraph *g, float **p, size_t bytes) {
+  void *q = nullptr;
+  MPN_CHECK_HIP(hipMalloc(&q, bytes ? bytes : 4));
+  g->allocs.push_back(q);
+  *p = static_cast<float *>(q);
+  return MPN_OK;
+}
+
+static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b) {
+  const int nch = (c.Cin + 7) / 8, CoutP = round_up(c.Cout, 128), KK = c.K * c.K;
+  const size_t total = (size_t)KK * nch * CoutP * 8;
+  int rc = rn_alloc(g, &c.wpk, total * sizeof(float));
+  if (rc) return rc;
+  rc = rn_alloc(g, &c.bpk, (size_t)CoutP * sizeof(float));
+  if (rc) return rc;
+  const size_t threads = total > (size_t)CoutP ? total : (size_t)CoutP;
+  hipLaunchKernelGGL(pack_conv_generic_kernel, dim3((unsigned)cdiv_sz(threads, 256)), dim3(256), 0, nullptr, d_w, d_b, c.Cin, c.Cout, KK, nch, CoutP,
+                     c.wpk, c.bpk);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int relu, hipStream_t s, ActI *o) {
+  GConvArgs a{};
+  a.in = in.p; a.wpk = c.wpk; a.bpk = c.bpk; a.res = res; a.out = out;
+  a.B = in.B; a.Cb_in = in.Cb(); a.H = in.H; a.W = in.W; a.nch = (c.Cin + 7) / 8;
+  a.CoutP = round_up(c.Cout, 128); a.Cb_out = (c.Cout + 7) / 8;
+  a.KH = a.KW = c.K; a.stride = c.stride; a.pad = c.pad;
+  a.OH = (in.H + 2 * c.pad - c.K) / c.stride + 1; a.OW = (in.W + 2 * c.pad - c.K) / c.stride + 1;
+  a.relu = relu;
+  MPN_CHECK_ARG(in.C == c.Cin && a.OH > 0 && a.OW > 0);
+  a.P = (long long)in.B * a.OH * a.OW;
+  dim3 grid((unsigned)((a.P + 127) / 128), (unsigned)(a.CoutP / 128));
+  hipLaunchKernelGGL(conv2d_c8i_kernel, grid, dim3(256), 0, s, a);
+  MPN_CHECK_LAUNCH();
+  *o = ActI{out, in.B, c.Cout, a.OH, a.OW};
+  return MPN_OK;
+}
+
+// one residual block: y = relu(conv_n(... relu(conv_1(x))) + shortcut(x)); buffers b[0..3] rotate, x may live in any of them
+static int rn_block(const RnBlock &blk, ActI x, float *const bufs[4], hipStream_t s, ActI *out) {
+  // pick three scratch buffers different from x.p
+  float *free_b[3];
+  int nf = 0;
+  for (int i = 0; i < 4 && nf < 3; ++i)
+    if (bufs[i] != x.p) free_b[nf++] = bufs[i];
+  MPN_CHECK_ARG(nf == 3);
+  ActI sc = x;
+  int rc;
+  if (blk.has_sc) {
+    rc = rn_conv(blk.sc, x, free_b[2], nullptr, 0, s, &sc);
+    if (rc) return rc;
+  }
+  ActI y = x;
+  const int n = (int)blk.convs.size();
+  for (int i = 0; i < n; ++i) {
+    const bool last = i == n - 1;
+    float *dst = free_b[i & 1];
+    if (dst == y.p) dst = free_b[(i & 1) ^ 1];
+    ActI o;
+    rc = rn_conv(blk.convs[i], y, dst, last ? sc.p : nullptr, 1, s, &o);
+    if (rc) return rc;
+    if (last) MPN_CHECK_ARG(o.C == sc.C && o.H == sc.H && o.W == sc.W);
+    y = o;
+  }
+  *out = y;
+  return MPN_OK;
+}
+
+static void rn_shape(const RnConv &c, int &h, int &w) {
+  h = (h + 2 * c.pad - c.K) / c.stride + 1;
+  w = (w + 2 * c.pad - c.K) / c.stride + 1;
+}
+
+int resnet_build(const mpn_resnet_weights *rw, int max_h, int max_w, int max_rois, int pooled, ResNetGraph **out) {
+  MPN_CHECK_ARG(rw && out && rw->n_convs > 0 && rw->n_blocks > 0 && rw->n_trunk_blocks > 0 && rw->n_trunk_blocks < rw->n_blocks);
+  MPN_CHECK_ARG(rw->w && rw->cin && rw->cout && rw->ksize && rw->stride && rw->pad && rw->block_n_convs && rw->block_has_shortcut);
+  ResNetGraph *g = new ResNetGraph();
+  g->pooled = pooled; g->max_rois = max_rois;
+  int rc = MPN_OK;
+#define RTRY(x) do { rc = (x); if (rc != MPN_OK) { resnet_free(g); return rc; } } while (0)
+  int ci = 0;
+  auto take = [&](RnConv &c) -> int {
+    if (ci >= rw->n_convs) { set_error("mpn_resnet_create: block table needs more than %d convolutions", rw->n_convs); return MPN_EINVAL; }
+    c.Cin = rw->cin[ci]; c.Cout = rw->cout[ci]; c.K = rw->ksize[ci]; c.stride = rw->stride[ci]; c.pad = rw->pad[ci];
+    if (!(c.Cin > 0 && c.Cout > 0 && c.K > 0 && c.stride > 0 && c.pad >= 0 && rw->w[ci])) { set_error("mpn_resnet_create: bad convolution %d", ci); return MPN_EINVAL; }
+    int r = rn_pack(g, c, rw->w[ci], rw->b ? rw->b[ci] : nullptr);
+    ++ci;
+    return r;
+  };
+  RTRY(take(g->conv1));
+  for (int b = 0; b < rw->n_blocks; ++b) {
+    RnBlock blk;
+    for (int k = 0; k < rw->block_n_convs[b]; ++k) { RnConv c; RTRY(take(c)); blk.convs.push_back(c); }
+    blk.has_sc = rw->block_has_shortcut[b] != 0;
+    if (blk.has_sc) RTRY(take(blk.sc));
+    (b < rw->n_trunk_blocks ? g->trunk : g->head).push_back(blk);
+  }
+  if (ci != rw->n_convs) { set_error("mpn_resnet_create: %d convolutions given, the block table uses %d", rw->n_convs, ci); resnet_free(g); return MPN_EINVAL; }
+  // shapes at the largest image -> buffer sizes
+  int h = max_h, w = max_w;
+  size_t te = (size_t)h * w * 8;
+  rn_shape(g->conv1, h, w);
+  te = std::max(te, (size_t)((g->conv1.Cout + 7) / 8) * h * w * 8);
+  h = (h + 2 - 3) / 2 + 1; w = (w + 2 - 3) / 2 + 1;  // max-pool 3x3/2 pad 1
+  int c = g->conv1.Cout;
+  for (auto &blk : g->trunk) {
+    int bh = h, bw = w;
+    for (auto &cv : blk.convs) {
+      if (cv.Cin != c && &cv == &blk.convs[0]) { set_error("mpn_resnet_create: channel mismatch in the trunk"); resnet_free(g); return MPN_EINVAL; }
+      rn_shape(cv, bh, bw);
+      te = std::max(te, (size_t)((cv.Cout + 7) / 8) * bh * bw * 8);
+      c = cv.Cout;
+    }
+    h = bh; w = bw;
+  }
+  g->feat_c = c;
+  h = w = pooled;
+  size_t he = (size_t)max_rois * ((c + 7) / 8) * h * w * 8;
+  for (auto &blk : g->head) {
+    int bh = h, bw = w;
+    for (auto &cv : blk.convs) {
+      rn_shape(cv, bh, bw);
+      he = std::max(he, (size_t)max_rois * ((cv.Cout + 7) / 8) * bh * bw * 8);
+      c = cv.Cout;
+    }
+    h = bh; w = bw;
+  }
+  g->out_c = c;
+  g->tb_elems = te; g->hb_elems = he;
+  RTRY(rn_alloc(g, &g->img, (size_t)max_h * max_w * 8 * sizeof(float)));
+  for (int i = 0; i < 4; ++i) RTRY(rn_alloc(g, &g->tb[i], te * sizeof(float)));
+  for (int i = 0; i < 4; ++i) RTRY(rn_alloc(g, &g->hb[i], he * sizeof(float)));
+#undef RTRY
+  MPN_CHECK_HIP(hipDeviceSynchronize());
+  *out = g;
+  return MPN_OK;
+}
+
+void resnet_free(ResNetGraph *g) {
+  if (!g) return;
+  for (void *q : g->allocs) (void)hipFree(q);
+  delete g;
+}
+
+int resnet_feat_channels(const ResNetGraph *g) { return g->feat_c; }
+int resnet_out_channels(const ResNetGraph *g) { return g->out_c; }
+bool resnet_has_features(const ResNetGraph *g, int H, int W) { return g->feat && g->last_h == H && g->last_w == W; }
+
+int resnet_trunk_forward(ResNetGraph *g, const float *d_image, int H, int W, const int *swap, double scale, const double *mean,
+                         const double *std, int has_std, hipStream_t s) {
+  MPN_CHECK_ARG(g && d_image && H > 0 && W > 0);
+  const size_t plane = (size_t)H * W;
+  hipLaunchKernelGGL(image_transform_c8i_kernel, dim3((unsigned)cdiv_sz(plane, 256)), dim3(256), 0, s, d_image, H, W, swap[0], swap[1], swap[2], scale,
+                     mean[0], mean[1], mean[2], has_std ? std[0] : 1.0, has_std ? std[1] : 1.0, has_std ? std[2] : 1.0, has_std, g->img);
+  MPN_CHECK_LAUNCH();
+  ActI x{g->img, 1, 3, H, W}, y;
+  int rc = rn_conv(g->conv1, x, g->tb[0], nullptr, 1, s, &y);
+  if (rc) return rc;
+  const int OH = (y.H + 2 - 3) / 2 + 1, OW = (y.W + 2 - 3) / 2 + 1;
+  {
+    const size_t total = (size_t)y.Cb() * OH * OW * 2;
+    hipLaunchKernelGGL(maxpool2d_c8i_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, y.p, y.Cb(), y.H, y.W, 3, 2, 1, OH, OW, g->tb[1]);
+    MPN_CHECK_LAUNCH();
+  }
+  ActI cur{g->tb[1], 1, y.C, OH, OW};
+  for (auto &blk : g->trunk) {
+    rc = rn_block(blk, cur, g->tb, s, &y);
+    if (rc) return rc;
+    cur = y;
+  }
+  g->feat = cur.p; g->feat_h = cur.H; g->feat_w = cur.W; g->last_h = H; g->last_w = W;
+  return MPN_OK;
+}
+
+int resnet_head_forward(ResNetGraph *g, const float *d_rois, int N, float spatial_scale, float *d_feat_c8, int Mp, hipStream_t s) {
+  MPN_CHECK_ARG(g && g->feat && d_rois && d_feat_c8 && N > 0 && N <= g->max_rois);
+  const int Cb = (g->feat_c + 7) / 8, PH = g->pooled;
+  {
+    const size_t total = (size_t)N * Cb * PH * PH * 2;
+    hipLaunchKernelGGL(roi_pool_c8i_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, g->feat, Cb, g->feat_h, g->feat_w, d_rois, N, PH, PH,
+                       spatial_scale, g->hb[0]);
+    MPN_CHECK_LAUNCH();
+  }
+  ActI cur{g->hb[0], N, g->feat_c, PH, PH}, y;
+  for (auto &blk : g->head) {
+    int rc = rn_block(blk, cur, g->hb, s, &y);
+    if (rc) return rc;
+    cur = y;
+  }
+  const size_t total = (size_t)N * cur.Cb() * 2;
+  hipLaunchKernelGGL(avgpool_c8i_to_c8_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, cur.p, N, cur.Cb(), cur.H * cur.W,
+                     1.0f / (float)(cur.H * cur.W), d_feat_c8, Mp);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+}  // namespace mpn

@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import FrcnnConfig, MpnetWeights, check, f32p
+from ._lib import FrcnnConfig, MpnetWeights, ResnetWeights, check, f32p
 from .nn import _f, _i, _stream
 
 VGG16_CFG = [64, 64, "P", 128, 128, "P", 256, 256, 256, "P", 512, 512, 512, "P", 512, 512, 512]  # vgg.lua:14-27, no pool5
@@ -59,6 +59,87 @@ def synthetic_params(cfg=VGG16_CFG, pooled=7, fc_dim=4096, n_classes=21, seed=55
     else:
         P["bbox_mean"] = P["bbox_std"] = None
     return P
+
+
+# fb.resnet.torch topologies (the `.t7` models/resnet.lua:17,25 loads): blocks per layer and block type
+RESNET_DEFS = {18: ("basic", [2, 2, 2, 2]), 34: ("basic", [3, 4, 6, 3]), 50: ("bottleneck", [3, 4, 6, 3]), 101: ("bottleneck", [3, 4, 23, 3])}
+IMAGENET_TRANSFORMER = dict(mean=(0.48462227599918, 0.45624044862054, 0.40588363755159),
+                            std=(0.22889466674951, 0.22446679341259, 0.22495548344775), scale=1.0, swap=(0, 1, 2))  # model_utils.lua:143-155
+
+
+def synthetic_resnet_params(depth=50, n_classes=21, seed=557, base_width=64, blocks=None, block_type=None, bbox_norm=True):
+    """Seeded random ResNet Fast R-CNN weights with BatchNorm already folded into (w, b) per convolution
+    (inn.utils.BNtoFixed, resnet.lua:34-36): conv1 7x7/2 -> [max-pool] -> layer1..3 (trunk) | layer4 (per-ROI head).
+    basic block: 3x3(stride) , 3x3; bottleneck: 1x1, 3x3(stride), 1x1 x4; shortcut type B (strided 1x1 convolution where
+    the shape changes).  He-scaled; the last convolution of every block is damped so the residual sums stay O(1).
+    `blocks` / `block_type` / `base_width` override the depth table (small test networks)."""
+    g = torch.Generator().manual_seed(seed)
+    bt, nb = RESNET_DEFS[depth] if depth in RESNET_DEFS else (block_type, blocks)
+    if blocks is not None:
+        nb = blocks
+    if block_type is not None:
+        bt = block_type
+    exp = 4 if bt == "bottleneck" else 1
+
+    def conv(cout, cin, k, damp=1.0):
+        w = torch.randn(cout, cin, k, k, generator=g) * ((2.0 / (cin * k * k)) ** 0.5 * damp)
+        b = torch.randn(cout, generator=g) * 0.01
+        return w, b
+
+    R = {"block_type": bt}
+    R["conv1_w"], R["conv1_b"] = conv(base_width, 3, 7)
+    layers = []
+    cin = base_width
+    for li, n in enumerate(nb):
+        width = base_width * (2 ** li)
+        stride = 1 if li == 0 else 2
+        layer = []
+        for bi in range(n):
+            st = stride if bi == 0 else 1
+            cout = width * exp
+            if bt == "bottleneck":
+                w1, b1 = conv(width, cin, 1)
+                w2, b2 = conv(width, width, 3)
+                w3, b3 = conv(cout, width, 1, damp=0.3)
+                convs = [(w1, b1, 1, 0), (w2, b2, st, 1), (w3, b3, 1, 0)]
+            else:
+                w1, b1 = conv(width, cin, 3)
+                w2, b2 = conv(cout, width, 3, damp=0.3)
+                convs = [(w1, b1, st, 1), (w2, b2, 1, 1)]
+            sc = None
+            if st != 1 or cin != cout:
+                ws, bs = conv(cout, cin, 1, damp=0.7)
+                sc = (ws, bs, st)
+            layer.append(dict(convs=convs, shortcut=sc))
+            cin = cout
+        layers.append(layer)
+    R["trunk_blocks"] = [b for layer in layers[:3] for b in layer]
+    R["head_blocks"] = list(layers[3])
+    R["cls_w"] = torch.randn(n_classes, cin, generator=g) * 0.01
+    R["cls_b"] = torch.zeros(n_classes)
+    R["bbox_w"] = torch.randn(4 * n_classes, cin, generator=g) * 0.001
+    R["bbox_b"] = torch.zeros(4 * n_classes)
+    R["bbox_mean"], R["bbox_std"] = ([0.0, 0.0, 0.0, 0.0], [0.1, 0.1, 0.2, 0.2]) if bbox_norm else (None, None)
+    return R
+
+
+def resnet_params_numpy(R):
+    """the same parameters in the oracle's (numpy) form"""
+    n = lambda t: t.detach().cpu().numpy()
+    blk = lambda b: dict(convs=[(n(w), n(bb), st, pd) for (w, bb, st, pd) in b["convs"]],
+                         shortcut=None if b["shortcut"] is None else (n(b["shortcut"][0]), n(b["shortcut"][1]), b["shortcut"][2]))
+    out = {k: n(R[k]) for k in ("conv1_w", "conv1_b", "cls_w", "cls_b", "bbox_w", "bbox_b")}
+    out["trunk_blocks"] = [blk(b) for b in R["trunk_blocks"]]
+    out["head_blocks"] = [blk(b) for b in R["head_blocks"]]
+    out["bbox_mean"], out["bbox_std"] = R["bbox_mean"], R["bbox_std"]
+    return out
+
+
+def ResNetFRCNN(params, **kw):
+    """models/resnet.lua graph as one device pipeline: pooled 14x14, ImagenetTransformer (resnet.lua:46,52)"""
+    kw.setdefault("pooled", 14)
+    kw.setdefault("transformer", IMAGENET_TRANSFORMER)
+    return FastRCNN(params, **kw)
 
 
 # models/multipathnet.lua:78-111: four foveal towers (region i; conv4 if i<=3, conv3 if i==1) + the "het" tower
@@ -123,10 +204,14 @@ class FastRCNN(object):
         """scale / max_size: getImages' rescaling (ImageDetect.lua:34-43) on the device; None feeds images as they are."""
         _lib.require_gpu()
         lib = _lib.load()
-        cout, pool = cfg_layers(cfg)
+        self.is_resnet = "trunk_blocks" in params
+        cout, pool = ([], []) if self.is_resnet else cfg_layers(cfg)
         self.is_mpnet = "towers" in params
         self.n_classes = params["n_classes"] if self.is_mpnet else params["cls_w"].shape[0]
-        self.fc_dim = params["towers"][0]["fc7_w"].shape[0] if self.is_mpnet else params["fc7_w"].shape[0]
+        if self.is_resnet:
+            self.fc_dim = params["cls_w"].shape[1]
+        else:
+            self.fc_dim = params["towers"][0]["fc7_w"].shape[0] if self.is_mpnet else params["fc7_w"].shape[0]
         self.noSoftMax = False
         self.max_rois = max_rois
         c = FrcnnConfig()
@@ -157,11 +242,39 @@ class FastRCNN(object):
         self._cfg = c
         dev = torch.device("cuda", torch.cuda.current_device())
         d = lambda t: t.to(dev, torch.float32).contiguous()
+        self._h = C.c_void_p()
+        if self.is_resnet:
+            convs, nconv, hassc = [], [], []  # execution order: conv1, then per block its convolutions (+ shortcut)
+            convs.append((params["conv1_w"], params["conv1_b"], 2, 3))
+            blocks = list(params["trunk_blocks"]) + list(params["head_blocks"])
+            for b in blocks:
+                convs += list(b["convs"])
+                nconv.append(len(b["convs"]))
+                hassc.append(0 if b["shortcut"] is None else 1)
+                if b["shortcut"] is not None:
+                    convs.append((b["shortcut"][0], b["shortcut"][1], b["shortcut"][2], 0))
+            keep = [(d(w), d(bb)) for (w, bb, _, _) in convs]
+            ia = lambda vals: (C.c_int * len(vals))(*[int(v) for v in vals])
+            rw = ResnetWeights()
+            rw.n_convs = len(convs)
+            self._rw_arrays = [(f32p * len(keep))(*[_f(w) for w, _ in keep]), (f32p * len(keep))(*[_f(bb) for _, bb in keep]),
+                               ia([w.shape[1] for w, _ in keep]), ia([w.shape[0] for w, _ in keep]), ia([w.shape[2] for w, _ in keep]),
+                               ia([c_[2] for c_ in convs]), ia([c_[3] for c_ in convs]), ia(nconv), ia(hassc)]
+            a = self._rw_arrays
+            rw.w, rw.b = C.cast(a[0], C.POINTER(f32p)), C.cast(a[1], C.POINTER(f32p))
+            rw.cin, rw.cout, rw.ksize, rw.stride, rw.pad = [C.cast(x, C.POINTER(C.c_int)) for x in a[2:7]]
+            rw.n_blocks = len(blocks)
+            rw.block_n_convs, rw.block_has_shortcut = C.cast(a[7], C.POINTER(C.c_int)), C.cast(a[8], C.POINTER(C.c_int))
+            rw.n_trunk_blocks = len(params["trunk_blocks"])
+            heads = [d(params[k]) for k in ("cls_w", "cls_b", "bbox_w", "bbox_b")]
+            check(lib.mpn_resnet_create(C.byref(c), C.byref(rw), *[_f(t) for t in heads], C.byref(self._h)), "mpn_resnet_create")
+            torch.cuda.synchronize()
+            self._finish_init(lib, dev, top_k)
+            return
         cw = [d(w) for w in params["conv_w"]]
         cb = [d(b) for b in params["conv_b"]]
         wp = (f32p * len(cw))(*[_f(w) for w in cw])
         bp = (f32p * len(cb))(*[_f(b) for b in cb])
-        self._h = C.c_void_p()
         if self.is_mpnet:
             mw = MpnetWeights()
             tow = params["towers"]
@@ -181,6 +294,9 @@ class FastRCNN(object):
             keep = [d(params[k]) for k in ("fc6_w", "fc6_b", "fc7_w", "fc7_b", "cls_w", "cls_b", "bbox_w", "bbox_b")]
             check(lib.mpn_frcnn_create(C.byref(c), wp, bp, *[_f(t) for t in keep], C.byref(self._h)), "mpn_frcnn_create")
         torch.cuda.synchronize()
+        self._finish_init(lib, dev, top_k)
+
+    def _finish_init(self, lib, dev, top_k):
         self._lib = lib
         self.device = dev
         self._dets = torch.zeros((top_k * 4 + 64, 6), dtype=torch.float32, device=dev)

@@ -523,3 +523,81 @@ void orc_image_scale(const float *in, int C, int H, int W, int H2, int W2, float
   }
   free(tmp);
 }
+
+/* ---- ResNet Fast R-CNN (models/resnet.lua:24-50) -------------------------------------------------
+ * The network itself comes from a fb.resnet.torch `.t7` that is not in the tree (resnet.lua:17,25): layers 1-7 =
+ * conv1 7x7/2 pad 3, BN, ReLU, SpatialMaxPooling(3,3,2,2,1,1), layer1-3; layers 8-10 = layer4, 7x7 average pool, View.
+ * BN is folded to a fixed per-channel scale/shift at load (inn.utils.BNtoFixed, resnet.lua:34-36) and, here, further
+ * into the preceding convolution's weights and bias by the caller.  PARITY UNPINNED: restated from the public
+ * fb.resnet.torch definition (bottleneck: 1x1, 3x3 carrying the stride, 1x1 x4; shortcut type B = strided 1x1 conv). */
+
+/* generic cross-correlation: in [B,Cin,H,W], w [Cout,Cin,KH,KW], stride s, zero pad p -> out [B,Cout,OH,OW],
+ * OH = (H + 2p - KH)/s + 1 (floor).  Sum in ascending (cin,ky,kx) order, then + bias, + residual (same shape as out,
+ * may be NULL), then optional ReLU. */
+void orc_conv2d(const float *in, int B, int Cin, int H, int W, const float *w, const float *bias, int Cout, int KH, int KW,
+                int stride, int pad, const float *residual, int relu, float *out) {
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  const size_t oplane = (size_t)OH * OW, iplane = (size_t)H * W;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+  for (int b = 0; b < B; ++b)
+    for (int co = 0; co < Cout; ++co) {
+      float *o = out + ((size_t)b * Cout + co) * oplane;
+      memset(o, 0, sizeof(float) * oplane);
+      for (int ci = 0; ci < Cin; ++ci) {
+        const float *ip = in + ((size_t)b * Cin + ci) * iplane;
+        for (int ky = 0; ky < KH; ++ky)
+          for (int kx = 0; kx < KW; ++kx) {
+            const float wv = w[(((size_t)co * Cin + ci) * KH + ky) * KW + kx];
+            for (int oy = 0; oy < OH; ++oy) {
+              const int iy = oy * stride + ky - pad;
+              if (iy < 0 || iy >= H) continue;
+              const float *irow = ip + (size_t)iy * W;
+              float *orow = o + (size_t)oy * OW;
+              for (int ox = 0; ox < OW; ++ox) {
+                const int ix = ox * stride + kx - pad;
+                if (ix >= 0 && ix < W) orow[ox] += wv * irow[ix];
+              }
+            }
+          }
+      }
+      const float bv = bias ? bias[co] : 0.0f;
+      const float *r = residual ? residual + ((size_t)b * Cout + co) * oplane : NULL;
+      for (size_t i = 0; i < oplane; ++i) {
+        float v = o[i] + bv;
+        if (r) v += r[i];
+        o[i] = (relu && v < 0.0f) ? 0.0f : v;
+      }
+    }
+}
+
+/* nn.SpatialMaxPooling(k,k,s,s,p,p), floor mode (fb.resnet.torch's 3x3/2 pad 1): padded positions never win. */
+void orc_maxpool2d(const float *in, int BC, int H, int W, int k, int stride, int pad, float *out) {
+  const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+#pragma omp parallel for
+  for (int c = 0; c < BC; ++c) {
+    const float *ip = in + (size_t)c * H * W;
+    float *op = out + (size_t)c * OH * OW;
+    for (int oy = 0; oy < OH; ++oy)
+      for (int ox = 0; ox < OW; ++ox) {
+        float m = -INFINITY;
+        for (int ky = 0; ky < k; ++ky)
+          for (int kx = 0; kx < k; ++kx) {
+            const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) { const float v = ip[(size_t)iy * W + ix]; if (v > m) m = v; }
+          }
+        op[(size_t)oy * OW + ox] = m;
+      }
+  }
+}
+
+/* nn.SpatialAveragePooling over the whole map (7x7 after layer4): sum in row-major order, then * 1/(H*W). */
+void orc_avgpool_global(const float *in, int BC, int H, int W, float *out) {
+  const float inv = 1.0f / (float)(H * W);
+#pragma omp parallel for
+  for (int c = 0; c < BC; ++c) {
+    const float *ip = in + (size_t)c * H * W;
+    float sacc = 0.0f;
+    for (int i = 0; i < H * W; ++i) sacc += ip[i];
+    out[c] = sacc * inv;
+  }
+}

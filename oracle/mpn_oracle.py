@@ -414,3 +414,92 @@ def mpnet_head(maps, rois, P, pooled=7, spatial_scale=1.0 / 16):
     if P.get("bbox_mean") is not None:
         deltas = bbox_norm(deltas, P["bbox_mean"], P["bbox_std"])
     return scores, deltas
+
+
+# ---- ResNet Fast R-CNN (models/resnet.lua; fb.resnet.torch topology, BN folded into the convolutions) -----------------
+def conv2d(x, w, b, stride=1, pad=0, relu=False, residual=None):
+    """x [B,Cin,H,W], w [Cout,Cin,KH,KW] -> [B,Cout,OH,OW] (+ bias, + residual, ReLU)"""
+    x, w = _f32(x), _f32(w)
+    b = _f32(b) if b is not None else None
+    B, Cin, H, W = x.shape
+    Cout, _, KH, KW = w.shape
+    OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    out = np.empty((B, Cout, OH, OW), np.float32)
+    res = _f32(residual) if residual is not None else None
+    lib().orc_conv2d(_p(x), B, Cin, H, W, _p(w), _p(b) if b is not None else None, Cout, KH, KW, stride, pad,
+                     _p(res) if res is not None else None, int(relu), _p(out))
+    return out
+
+
+def maxpool2d(x, k=3, stride=2, pad=1):
+    x = _f32(x)
+    B, Cc, H, W = x.shape
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = np.empty((B, Cc, OH, OW), np.float32)
+    lib().orc_maxpool2d(_p(x), B * Cc, H, W, k, stride, pad, _p(out))
+    return out
+
+
+def avgpool_global(x):
+    x = _f32(x)
+    B, Cc, H, W = x.shape
+    out = np.empty((B, Cc), np.float32)
+    lib().orc_avgpool_global(_p(x), B * Cc, H, W, _p(out))
+    return out
+
+
+def resnet_block(x, blk):
+    """one residual block; blk = dict(convs=[(w,b,stride,pad), ...], shortcut=(w,b,stride) or None).  ReLU after every
+    conv but the last; the last conv adds the shortcut, then ReLU (fb.resnet.torch basicblock / bottleneck)."""
+    sc = x
+    if blk["shortcut"] is not None:
+        w, b, st = blk["shortcut"]
+        sc = conv2d(x, w, b, stride=st, pad=0, relu=False)
+    y = x
+    n = len(blk["convs"])
+    for i, (w, b, st, pd) in enumerate(blk["convs"]):
+        last = i == n - 1
+        y = conv2d(y, w, b, stride=st, pad=pd, relu=True, residual=sc if last else None)
+    return y
+
+
+def resnet_trunk(x, R):
+    """net:get(1..7): conv1 7x7/2 (+BN folded) -> ReLU -> maxpool 3x3/2 pad 1 -> layer1..3.  x [3,H,W] -> [C3,H/16,W/16]"""
+    y = conv2d(x[None], R["conv1_w"], R["conv1_b"], stride=2, pad=3, relu=True)
+    y = maxpool2d(y, 3, 2, 1)
+    for blk in R["trunk_blocks"]:
+        y = resnet_block(y, blk)
+    return y[0]
+
+
+def resnet_head(feat, rois, R, pooled=14, spatial_scale=1.0 / 16, chunk=None):
+    """resnet.lua:40-48: ROIPooling(14,14,1/16) -> layer4 -> 7x7 average pool -> View -> {cls, bbox}"""
+    N = rois.shape[0]
+    chunk = chunk or N
+    cls, bbox = [], []
+    for s0 in range(0, N, chunk):
+        r = rois[s0:s0 + chunk]
+        y, _ = roi_pool(feat, r, pooled, pooled, spatial_scale)  # [n,C3,14,14]
+        for blk in R["head_blocks"]:
+            y = resnet_block(y, blk)
+        f = avgpool_global(y)
+        cls.append(linear(f, R["cls_w"], R["cls_b"]))
+        bb = linear(f, R["bbox_w"], R["bbox_b"])
+        if R.get("bbox_mean") is not None:
+            bb = bbox_norm(bb, R["bbox_mean"], R["bbox_std"])
+        bbox.append(bb)
+    return np.concatenate(cls), np.concatenate(bbox)
+
+
+def resnet_detect(im, boxes, R, transformer=IMAGENET, target=600, max_size=1000, pooled=14, chunk=None):
+    """ImageDetect.lua:156-193 on the ResNet model (ImagenetTransformer, resnet.lua:52)"""
+    H, W = im.shape[1:]
+    s = pick_scale(H, W, target, max_size)
+    x = image_transform(im, **transformer)
+    if s != 1.0:
+        x = image_scale(x, int(H * s), int(W * s))
+    rois = project_im_rois(boxes, s)
+    feat = resnet_trunk(x, R)
+    logits, deltas = resnet_head(feat, rois, R, pooled=pooled, chunk=chunk)
+    dec = bbox_decode(boxes, deltas)
+    return softmax(logits), dec, logits, deltas

@@ -1,0 +1,60 @@
+"""ResNet Fast R-CNN (models/resnet.lua graph) through the C ABI vs the oracle: small networks with the
+reference's topology (basic and bottleneck blocks, strided shortcuts, 7x7/2 stem, 3x3/2 max-pool, ROIPooling on the
+stride-16 map, per-ROI layer4, average pool, cls/bbox heads).  Tolerance 1e-4 on scores (north_star), NMS results equal."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(H, W, N, seed):
+    rng = np.random.default_rng(seed)
+    im = rng.uniform(0, 1, (3, H, W)).astype(np.float32)
+    c = rng.uniform([1, 1], [W, H], (N, 2))
+    wh = np.exp(rng.uniform(np.log(8), np.log(min(H, W)), (N, 2)))
+    b = np.concatenate([c - wh / 2, c + wh / 2], 1)
+    b[:, [0, 2]] = np.clip(b[:, [0, 2]], 1, W)
+    b[:, [1, 3]] = np.clip(b[:, [1, 3]], 1, H)
+    return im, b.astype(np.float32)
+
+
+@pytest.mark.parametrize("bt,blocks,width,pooled", [("bottleneck", [1, 1, 1, 1], 8, 14), ("basic", [1, 2, 1, 2], 8, 14), ("bottleneck", [2, 1, 2, 1], 16, 6)])
+def test_resnet_frcnn_vs_oracle(O, dev, bt, blocks, width, pooled):
+    from multipathnet_amd import models
+    H, W, N, C = 97, 131, 37, 6
+    R = models.synthetic_resnet_params(depth=0, n_classes=C, base_width=width, blocks=blocks, block_type=bt, seed=21)
+    Rn = models.resnet_params_numpy(R)
+    im, boxes = _inputs(H, W, N, 4)
+    net = models.ResNetFRCNN(R, pooled=pooled, max_h=H, max_w=W, max_rois=64, top_k=20)
+    s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+    so, bo, logits, deltas = O.resnet_detect(im, boxes, Rn, target=min(H, W), max_size=max(H, W), pooled=pooled)  # s = 1, as the pipeline (no rescale configured)
+    s, b = s.cpu().numpy(), b.cpu().numpy()
+    assert np.abs(s - so).max() < 1e-4
+    bo = O.clamp_boxes(bo.copy(), W, H)
+    assert np.abs(b - bo).max() < 1e-2  # pixels; deltas are O(1e-3) * box size
+    # cached features: the head alone on new boxes == a full run on them
+    im2, boxes2 = _inputs(H, W, N, 5)
+    s2, _ = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes2).to(dev), recompute_features=False)
+    s2f, _ = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes2).to(dev))
+    assert torch.equal(s2, s2f)
+
+
+def test_resnet_test_one_pipeline(O, dev):
+    """the whole Tester:testOne path (NMS, top-k, pipelined form) on the ResNet model: serial == pipelined exactly"""
+    from multipathnet_amd import models
+    H, W, N, C = 120, 160, 50, 5
+    R = models.synthetic_resnet_params(depth=0, n_classes=C, base_width=8, blocks=[1, 1, 1, 1], block_type="bottleneck", seed=3)
+    net = models.ResNetFRCNN(R, max_h=H, max_w=W, max_rois=64, top_k=10)
+    im, boxes = _inputs(H, W, N, 9)
+    imd, bd = torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev)
+    net.test_one_async(imd, bd)
+    torch.cuda.synchronize()
+    n = int(net._n_dets.item())
+    ref = net._dets[:n].clone()
+    assert n > 0
+    outs = [net.test_one_pipelined(imd, bd) for _ in range(3)]
+    net.flush()
+    torch.cuda.synchronize()
+    for d, nd in outs:
+        assert int(nd.item()) == n and torch.equal(d[:n], ref)

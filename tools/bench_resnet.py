@@ -1,0 +1,51 @@
+"""BASELINE configs[3] shape on ONE GPU: ResNet-50 Fast R-CNN (models/resnet.lua graph, fp32), 1000 ROIs, 600x1000 image —
+timing of the full per-image path (not a bench.py line; parity is tests/test_gpu_resnet.py)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from multipathnet_amd import models
+depth = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+R = models.synthetic_resnet_params(depth=depth, n_classes=21, seed=557)
+net = models.ResNetFRCNN(R, max_h=600, max_w=1000, max_rois=N)
+im, boxes = bench.synthetic_inputs()
+dev = torch.device("cuda", 0)
+im, boxes = torch.from_numpy(im).to(dev), torch.from_numpy(boxes[:N]).to(dev)
+for _ in range(2):
+    net.test_one_pipelined(im, boxes)
+net.flush(); torch.cuda.synchronize()
+K = 3
+t0 = time.perf_counter()
+for _ in range(K):
+    net.test_one_pipelined(im, boxes)
+net.flush(); torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / K
+# algorithmic FLOPs: every convolution 2*Cout*Cin*k*k*OH*OW (trunk on the image, head per ROI)
+def conv_flops(blocks, h, w, cin0):
+    f, cin = 0.0, cin0
+    for b in blocks:
+        bh, bw = h, w
+        if b["shortcut"] is not None:
+            ws, _, st = b["shortcut"]
+            f += 2.0 * ws.shape[0] * ws.shape[1] * ((h - 1) // st + 1) * ((w - 1) // st + 1)
+        for (wt, _, st, pd) in b["convs"]:
+            k = wt.shape[2]
+            bh, bw = (bh + 2 * pd - k) // st + 1, (bw + 2 * pd - k) // st + 1
+            f += 2.0 * wt.shape[0] * wt.shape[1] * k * k * bh * bw
+        h, w = bh, bw
+    return f, h, w
+h1, w1 = (600 + 6 - 7) // 2 + 1, (1000 + 6 - 7) // 2 + 1
+f_trunk = 2.0 * 64 * 3 * 49 * h1 * w1
+h2, w2 = (h1 + 2 - 3) // 2 + 1, (w1 + 2 - 3) // 2 + 1
+ft, fh_, fw_ = conv_flops(R["trunk_blocks"], h2, w2, 64)
+fhead, _, _ = conv_flops(R["head_blocks"], 14, 14, 0)
+flops = f_trunk + ft + N * fhead
+net.set_profiling(True); net.get_profile(True)
+net.test_one_async(im, boxes); torch.cuda.synchronize()
+prof = net.get_profile(True)
+print("ResNet-%d Fast R-CNN, %d ROIs: %.2f ms/image  %.0f proposals/s  %.2f TFLOP/image  %.1f TFLOP/s (%.1f%% of fp32 MFMA peak); feature map %dx%d" % (
+    depth, N, dt * 1e3, N / dt, flops / 1e12, flops / dt / 1e12, flops / dt / 157.3e12 * 100, fh_, fw_))
+for k, (ms, n) in prof.items():
+    if n: print("  %-12s %8.3f ms (%d launch groups)%s" % (k, ms, n, {"conv_direct": "  = ResNet trunk", "fc6": "  = ROI pool + per-ROI layer4 + avgpool"}.get(k, "")))
+print("n dets", int(net._n_dets.item()))
