@@ -51,8 +51,11 @@ struct GConvArgs {
   long long P;  // B * OH * OW output pixels
 };
 
+// KC = 8-channel chunks per LDS stage (all of the same filter tap): 16 * KC MFMAs per wave between two barriers.  KC = 4
+// when the channel count allows it (every layer but the 3-channel stem), KC = 1 otherwise.
+template <int KC>
 __global__ __launch_bounds__(256) void conv2d_c8i_kernel(GConvArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[2][2][128 * 8];  // [buffer][A | B][row][8]
+  __shared__ __attribute__((aligned(16))) float lds[2][2][KC * 128 * 8];  // [buffer][A | B][chunk][row][8]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(256) void conv2d_c8i_kernel(GConvArgs a) {
   const int cout0 = blockIdx.y * 128;
   const int OHW = a.OH * a.OW;
 
-  // staging roles: thread = (row tid>>1, 16-byte half tid&1) of both 128 x 8 slices
+  // staging roles: thread = (row tid>>1, 16-byte half tid&1) of both 128 x 8 slices of every chunk of the stage
   const int srow = tid >> 1, sh = tid & 1;
   const long long gpix = p0 + srow;
   const bool gvalid = gpix < a.P;
@@ -74,19 +77,28 @@ __global__ __launch_bounds__(256) void conv2d_c8i_kernel(GConvArgs a) {
   const float *w_t = a.wpk + ((size_t)cout0 + srow) * 8 + sh * 4;
   const size_t w_step = (size_t)a.CoutP * 8;
 
-  const int nsteps = a.KH * a.KW * a.nch;
-  f32x4 ra, rb;
-  auto fetch = [&](int step) {  // step = tap * nch + chunk
-    const int tap = step / a.nch, ch = step - tap * a.nch;
+  const int spt = a.nch / KC;             // stages per tap
+  const int nstages = a.KH * a.KW * spt;
+  f32x4 ra[KC], rb[KC];
+  auto fetch = [&](int st) {  // stage = tap * spt + chunk group
+    const int tap = st / spt, cg = st - tap * spt;
     const int ky = tap / a.KW, kx = tap - ky * a.KW;
-    ra = *reinterpret_cast<const f32x4 *>(w_t + (size_t)step * w_step);
     const int iy = iy0 + ky, ix = ix0 + kx;
     const bool ok = gvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-    rb = ok ? *reinterpret_cast<const f32x4 *>(in_b + (size_t)ch * plane + ((size_t)iy * a.W + ix) * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *wp = w_t + ((size_t)tap * a.nch + (size_t)cg * KC) * w_step;
+    const float *ip = in_b + (size_t)cg * KC * plane + ((size_t)iy * a.W + ix) * 8;
+#pragma unroll
+    for (int q = 0; q < KC; ++q) {
+      ra[q] = *reinterpret_cast<const f32x4 *>(wp + (size_t)q * w_step);
+      rb[q] = ok ? *reinterpret_cast<const f32x4 *>(ip + (size_t)q * plane) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   };
   auto stash = [&](int buf) {
-    *reinterpret_cast<f32x4 *>(&lds[buf][0][srow * 8 + sh * 4]) = ra;
-    *reinterpret_cast<f32x4 *>(&lds[buf][1][srow * 8 + sh * 4]) = rb;
+#pragma unroll
+    for (int q = 0; q < KC; ++q) {
+      *reinterpret_cast<f32x4 *>(&lds[buf][0][(q * 128 + srow) * 8 + sh * 4]) = ra[q];
+      *reinterpret_cast<f32x4 *>(&lds[buf][1][(q * 128 + srow) * 8 + sh * 4]) = rb[q];
+    }
   };
 
   f32x16 acc[2][2];
@@ -101,22 +113,25 @@ __global__ __launch_bounds__(256) void conv2d_c8i_kernel(GConvArgs a) {
   stash(0);
   __syncthreads();
   const int frag = l31 * 8 + half * 4;
-  for (int step = 0; step < nsteps; ++step) {
-    const int buf = step & 1;
-    if (step + 1 < nsteps) fetch(step + 1);  // global loads in flight under this step's MFMAs
-    f32x4 af[2], bf[2];
+  for (int st = 0; st < nstages; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nstages) fetch(st + 1);  // global loads in flight under this stage's MFMAs
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) af[mi] = *reinterpret_cast<const f32x4 *>(&lds[buf][0][(wm * 64 + mi * 32) * 8 + frag]);
+    for (int q = 0; q < KC; ++q) {
+      f32x4 af[2], bf[2];
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) bf[ni] = *reinterpret_cast<const f32x4 *>(&lds[buf][1][(wn * 64 + ni * 32) * 8 + frag]);
+      for (int mi = 0; mi < 2; ++mi) af[mi] = *reinterpret_cast<const f32x4 *>(&lds[buf][0][(q * 128 + wm * 64 + mi * 32) * 8 + frag]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int ni = 0; ni < 2; ++ni) bf[ni] = *reinterpret_cast<const f32x4 *>(&lds[buf][1][(q * 128 + wn * 64 + ni * 32) * 8 + frag]);
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
-    if (step + 1 < nsteps) stash(buf ^ 1);
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
+    }
+    if (st + 1 < nstages) stash(buf ^ 1);
     __syncthreads();
   }
 
@@ -288,7 +303,8 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
   MPN_CHECK_ARG(in.C == c.Cin && a.OH > 0 && a.OW > 0);
   a.P = (long long)in.B * a.OH * a.OW;
   dim3 grid((unsigned)((a.P + 127) / 128), (unsigned)(a.CoutP / 128));
-  hipLaunchKernelGGL(conv2d_c8i_kernel, grid, dim3(256), 0, s, a);
+  if (a.nch % 4 == 0) hipLaunchKernelGGL((conv2d_c8i_kernel<4>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((conv2d_c8i_kernel<1>), grid, dim3(256), 0, s, a);
   MPN_CHECK_LAUNCH();
   *o = ActI{out, in.B, c.Cout, a.OH, a.OW};
   return MPN_OK;
