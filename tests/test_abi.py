@@ -43,6 +43,12 @@ def test_arg_errors_do_not_need_a_gpu():
     assert rc == -1 and b"invalid argument" in lib.mpn_last_error()
     rc = lib.mpn_nms_batched(None, None, 1, 1 << 20, ctypes.c_float(0.3), None, None, None, None)
     assert rc == -1
+    # the three pipeline constructors reject missing descriptors before touching the device
+    h = ctypes.c_void_p()
+    assert lib.mpn_frcnn_create(None, None, None, None, None, None, None, None, None, None, None, ctypes.byref(h)) == -1
+    assert lib.mpn_mpnet_create(None, None, None, None, None, None, None, None, ctypes.byref(h)) == -1
+    assert lib.mpn_resnet_create(None, None, None, None, None, None, ctypes.byref(h)) == -1
+    assert not h.value
 
 
 def test_no_oracle_on_product_path():
