@@ -1,0 +1,77 @@
+"""BASELINE configs[1] at FULL size (VGG-16 Fast R-CNN, 600x1000 image, 1000 ROIs, 21 classes, the bench's own synthetic
+inputs and weights): (1) parity against the oracle on a ROI sample — the oracle runs the whole trunk (a few seconds on the GPU
+box's host cores) and the head for 24 of the 1000 ROIs; (2) the size-independent properties of the path on all 1000 ROIs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full(dev):
+    import bench
+    from multipathnet_amd import models
+    P = models.synthetic_params(models.VGG16_CFG, pooled=7, fc_dim=4096, n_classes=bench.N_CLASSES, seed=557)
+    net = models.FastRCNN(P, max_h=bench.H, max_w=bench.W, max_rois=bench.N_ROIS)
+    im, boxes = bench.synthetic_inputs()
+    return dict(P=P, net=net, im=im, boxes=boxes, imd=torch.from_numpy(im).to(dev), bd=torch.from_numpy(boxes).to(dev))
+
+
+def test_fullsize_scores_vs_oracle_on_roi_sample(O, dev, full):
+    net, im, boxes, P = full["net"], full["im"], full["boxes"], full["P"]
+    s, b = net.detect(full["imd"], full["bd"])
+    s, b = s.cpu().numpy(), b.cpu().numpy()
+    Pn = {k: ([t.numpy() for t in v] if isinstance(v, list) and v and hasattr(v[0], "numpy") else (v.numpy() if hasattr(v, "numpy") else v))
+          for k, v in P.items()}
+    x = O.image_transform(im, **O.ROSS)
+    feat = O.vgg_trunk(x, Pn["conv_w"], Pn["conv_b"])  # full 600x1000 trunk on the host cores
+    conv5 = net.debug_tensor("conv5", (512, feat.shape[1], feat.shape[2])).cpu().numpy()
+    assert feat.shape == conv5.shape == (512, 38, 63)
+    assert np.abs(conv5 - feat).max() < 1e-4 * max(1.0, np.abs(feat).max())
+    idx = np.random.default_rng(7).choice(boxes.shape[0], 24, replace=False)
+    rois = O.project_im_rois(boxes[idx], 1.0)
+    logits, deltas = O.frcnn_head(feat, rois, Pn)
+    so = O.softmax(logits)
+    assert np.abs(s[idx] - so).max() < 1e-4  # north_star tolerance on class scores
+    bo = O.clamp_boxes(O.bbox_decode(boxes[idx], deltas), im.shape[2], im.shape[1])
+    assert np.abs(b[idx] - bo).max() < 5e-3  # pixels
+
+
+def test_fullsize_properties(O, dev, full):
+    net, imd, bd, boxes = full["net"], full["imd"], full["bd"], full["boxes"]
+    N, C = boxes.shape[0], net.n_classes
+    s, b = net.detect(imd, bd)
+    # softmax rows, clamping (Tester_FRCNN.lua:75-78)
+    assert float((s.sum(1) - 1).abs().max()) < 1e-5
+    bb = b.view(N, C, 4)
+    assert float(bb[..., 0::2].min()) >= 1 and float(bb[..., 0::2].max()) <= imd.shape[2]
+    assert float(bb[..., 1::2].min()) >= 1 and float(bb[..., 1::2].max()) <= imd.shape[1]
+    # determinism and ROI-order equivariance (rows are independent: memoryEfficientForward's chunk invariance, ImageDetect.lua:126-133)
+    s2, b2 = net.detect(imd, bd)
+    assert torch.equal(s, s2) and torch.equal(b, b2)
+    perm = torch.from_numpy(np.random.default_rng(1).permutation(N)).to(dev)
+    sp, bp = net.detect(imd, bd[perm].contiguous())
+    assert torch.equal(sp, s[perm]) and torch.equal(bp, b[perm])
+    # cached trunk features (recompute_features = false) == full run
+    sc, bc = net.detect(imd, bd, recompute_features=False)
+    assert torch.equal(sc, s) and torch.equal(bc, b)
+    # Tester:testOne: per-class NMS on the device == the reference's own nms.c on the same scored boxes, class by class
+    net.test_one_async(imd, bd)
+    torch.cuda.synchronize()
+    keep, kidx, nk = net.nms_results()
+    keep, nk = keep.cpu().numpy(), nk.cpu().numpy()
+    sn, bn = s.cpu().numpy(), b.cpu().numpy()
+    for cls in (1, 7, 20):
+        sb = np.concatenate([bn[:, 4 * cls:4 * cls + 4], sn[:, cls:cls + 1]], 1).astype(np.float32)
+        ref = O.ref_nms(sb, 0.3)
+        k = int(nk[cls - 1])
+        assert k == ref.shape[0] and np.array_equal(keep[cls - 1, :k], ref)
+        # idempotence: NMS of the kept set keeps everything, in the same order
+        assert np.array_equal(O.ref_nms(ref, 0.3), ref)
+    # keep_top_k(100): at most top_k rows unless ties at the threshold, scores >= the k-th largest kept score
+    n = int(net._n_dets.item())
+    dets = net._dets[:n].cpu().numpy()
+    allk = np.concatenate([keep[c, :int(nk[c]), 4] for c in range(C - 1)])
+    thr = np.sort(allk)[::-1][min(100, allk.size) - 1]
+    assert n == int((allk >= thr).sum()) and dets[:, 4].min() >= thr
