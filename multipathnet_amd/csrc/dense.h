@@ -71,8 +71,10 @@ int maxpool2x2_c8p(Act in, Act out, hipStream_t s);
 // y = relu?(x W^T + b).  x: C8 matrix [K8/8][Mp][8]; y: C8 matrix [NP/8][Mp][8] (y_c8) and/or
 // row-major [M,N] (y_rm); either may be null.
 // Mp_override: row pitch of x / y when it is not lin_mp(M) (a ROI-pooled matrix viewed as (bin, roi) rows).
+// d_res_c8 (optional, y_c8's layout): added before the ReLU; only with the direct form (>= 128 output tiles, C8 output only).
 int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float *d_bpk, int N, int relu, float *d_y_c8,
-              float *d_y_rm, hipStream_t s, int Mp_override = 0);
+              float *d_y_rm, hipStream_t s, int Mp_override = 0, const float *d_res_c8 = nullptr);
+bool linear_c8_is_direct(int M, int N, int Mp_override = 0);  // would linear_c8 run un-split for this shape?
 // ROI max-pool reading a C8P feature map and writing the C8 matrix the fc6 GEMM consumes:
 // chunk q = cb*PH*PW + bin, row = roi.  argmax (optional) [N,C,PH,PW] int32 as the NCHW kernel.
 // roi_stride: floats between consecutive rois (5; 20 selects one Foveal region out of the [4N,5] table);

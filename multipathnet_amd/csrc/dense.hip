@@ -1780,6 +1780,7 @@ struct GemmArgs {
   float *y;                     // [NP/8][Mp][8]   (split: partial slabs [S][NP/8][Mp][8])
   int M, nstages, stages_per_split, relu, n_mt, n_nt, direct;
   int ablate;  // timing experiments only (results wrong): 1 = no DMA in loop, 2 = no barrier in loop, 4 = no ds_reads in loop
+  const float *res;  // optional residual in y's layout, added before the ReLU (direct mode only; ResNet 1x1 convolutions)
 };
 
 // KCH = 8-wide K chunks per LDS stage (4 -> 32 k per stage, 32 KiB per stage);  NBUF = LDS ring depth:
@@ -1900,6 +1901,7 @@ __global__ __launch_bounds__(256) void gemm_c8_kernel(GemmArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float t = acc[mi][ni][g * 4 + e] + b4[e];
+          if (a.res && m < a.M) t += a.res[((size_t)nb8 * a.Mp + m) * 8 + half * 4 + e];
           if (a.direct && a.relu) t = t < 0.0f ? 0.0f : t;
           v[e] = t;
         }
@@ -2020,6 +2022,7 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float t = acc[mi][ni][g * 4 + e] + b4[e];
+          if (a.res && m < a.M) t += a.res[((size_t)nb8 * a.Mp + m) * 8 + half * 4 + e];
           if (a.direct && a.relu) t = t < 0.0f ? 0.0f : t;
           v[e] = t;
         }
@@ -2069,8 +2072,13 @@ static int g_gemm_split = 0;  // test/bench hook: force a split-K factor
 static float *g_splitk_ws = nullptr;
 static size_t g_splitk_ws_bytes = 0;
 
+bool linear_c8_is_direct(int M, int N, int Mp_override) {
+  const int Mp = Mp_override ? Mp_override : lin_mp(M);
+  return g_gemm_split == 0 && (Mp / 128) * (lin_np(N) / 128) >= 128;
+}
+
 int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float *d_bpk, int N, int relu, float *d_y_c8,
-              float *d_y_rm, hipStream_t s, int Mp_override) {
+              float *d_y_rm, hipStream_t s, int Mp_override, const float *d_res_c8) {
   MPN_CHECK_ARG(d_x_c8 && d_wpk && d_bpk && (d_y_c8 || d_y_rm) && M > 0 && K > 0 && N > 0);
   MPN_CHECK_ARG(Mp_override == 0 || (Mp_override >= M && Mp_override % 128 == 0));
   GemmArgs a{};
@@ -2093,6 +2101,8 @@ int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float
   S = cdiv(a.nstages, a.stages_per_split);
   const bool direct = (S == 1) && d_y_c8 && !d_y_rm;
   a.direct = direct ? 1 : 0;
+  if (d_res_c8 && !direct) { set_error("linear_c8: a residual needs the direct (un-split, C8 output) form"); return MPN_EINVAL; }
+  a.res = d_res_c8;
   static bool attr = false;
   if (!attr) {
     MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_c8_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 4 * 128 * 8 * 4));

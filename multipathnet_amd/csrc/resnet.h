@@ -2,9 +2,11 @@
 // image, ROIPooling(14,14,1/16), per-ROI layer4 + global average pool.  fp32 MFMA, BN folded into the convolutions by the
 // caller.  Used by pipeline.hip (mpn_resnet_create); kernels in resnet.hip.
 //
-// Layout "C8I": [B][C/8][H][W][8] fp32 — a batch of channel-blocked maps WITHOUT halos: the generic convolution gathers
-// its input pixels with explicit bounds checks (7x7 pad 3, strides 1/2, 14x14 and 7x7 per-ROI maps), so a halo would only
-// inflate the thousand small per-ROI maps.  A pixel's 8 channels are one 32-byte record, as in C8P.
+// Layout "C8I": [C/8][B*H*W rows, pitch rounded up to 128][8] fp32 — a batch of channel-blocked maps WITHOUT halos: the generic
+// convolution gathers its input pixels with explicit bounds checks (7x7 pad 3, strides 1/2, 14x14 and 7x7 per-ROI maps), so a
+// halo would only inflate the thousand small per-ROI maps.  A pixel's 8 channels are one 32-byte record, as in C8P, and one
+// channel-block plane holds ALL maps' pixels: the whole batch is a C8 matrix (dense.h) whose rows are the pixels, so a 1x1 /
+// stride-1 convolution is exactly dense.h's linear_c8 GEMM on it (residual add + ReLU fused in its epilogue).
 #pragma once
 #include "dense.h"
 

@@ -18,12 +18,16 @@ namespace mpn {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct ActI {  // C8I batch of maps
+struct ActI {  // C8I batch of maps: element (b, c, y, x) at ((c/8) * pitch + (b*H + y)*W + x) * 8 + c%8
   float *p;
   int B, C, H, W;
   int Cb() const { return (C + 7) / 8; }
-  size_t elems() const { return (size_t)B * Cb() * H * W * 8; }
+  size_t rows() const { return (size_t)B * H * W; }
+  size_t pitch() const { return (rows() + 127) / 128 * 128; }  // rows per channel-block plane (a C8 matrix of `rows` rows)
 };
+static size_t c8i_elems(int B, int C, int H, int W) {  // allocation size: planes rounded up to the GEMM's 128-column tiles
+  return (size_t)(round_up(C, 128) / 8) * (((size_t)B * H * W + 127) / 128 * 128) * 8;
+}
 
 // ------------------------------------------------------------------------------------------------------------------------
 // packed weights: [tap = ky*KW + kx][Cin8/8][CoutP][8], CoutP = round_up(Cout, 128); bias [CoutP]
@@ -47,6 +51,7 @@ struct GConvArgs {
   const float *in, *wpk, *bpk, *res;
   float *out;
   int B, Cb_in, H, W, nch;
+  size_t pitch_in, pitch_out;  // rows per channel-block plane
   int CoutP, Cb_out, KH, KW, stride, pad, OH, OW, relu;
   long long P;  // B * OH * OW output pixels
 };
@@ -72,8 +77,8 @@ __global__ __launch_bounds__(256) void conv2d_c8i_kernel(GConvArgs a) {
   const int grem = gvalid ? (int)(gpix - (long long)gb * OHW) : 0;
   const int goy = grem / a.OW, gox = grem - goy * a.OW;
   const int iy0 = goy * a.stride - a.pad, ix0 = gox * a.stride - a.pad;
-  const size_t plane = (size_t)a.H * a.W * 8;
-  const float *in_b = a.in + (size_t)gb * a.Cb_in * plane + sh * 4;
+  const size_t plane = a.pitch_in * 8;
+  const float *in_b = a.in + (size_t)gb * a.H * a.W * 8 + sh * 4;
   const float *w_t = a.wpk + ((size_t)cout0 + srow) * 8 + sh * 4;
   const size_t w_step = (size_t)a.CoutP * 8;
 
@@ -140,8 +145,6 @@ __global__ __launch_bounds__(256) void conv2d_c8i_kernel(GConvArgs a) {
   for (int ni = 0; ni < 2; ++ni) {
     const long long pix = p0 + wn * 64 + ni * 32 + l31;
     if (pix >= a.P) continue;
-    const int b = (int)(pix / OHW);
-    const int rem = (int)(pix - (long long)b * OHW);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void conv2d_c8i_kernel(GConvArgs a) {
         const int cb = (cout0 + wm * 64 + mi * 32) / 8 + g;
         if (cb >= a.Cb_out) continue;
         const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bpk + cb * 8 + half * 4);
-        const size_t off = (((size_t)b * a.Cb_out + cb) * OHW + rem) * 8 + half * 4;
+        const size_t off = ((size_t)cb * a.pitch_out + (size_t)pix) * 8 + half * 4;
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][g * 4 + e] + b4[e];
@@ -164,24 +167,25 @@ __global__ __launch_bounds__(256) void conv2d_c8i_kernel(GConvArgs a) {
 }
 
 // nn.SpatialMaxPooling(k,k,s,s,p,p), floor mode, on C8I
-__global__ void maxpool2d_c8i_kernel(const float *__restrict__ in, int BCb, int H, int W, int k, int stride, int pad, int OH, int OW,
-                                     float *__restrict__ out) {
+__global__ void maxpool2d_c8i_kernel(const float *__restrict__ in, int Cb, int B, int H, int W, size_t pitch_in, int k, int stride, int pad, int OH,
+                                     int OW, size_t pitch_out, float *__restrict__ out) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t total = (size_t)BCb * OH * OW * 2;
+  size_t total = (size_t)Cb * B * OH * OW * 2;
   if (t >= total) return;
   const int h = (int)(t & 1); size_t r = t >> 1;
   const int ox = (int)(r % OW); r /= OW;
-  const int oy = (int)(r % OH); const size_t bc = r / OH;
+  const int oy = (int)(r % OH); r /= OH;
+  const int b = (int)(r % B); const size_t cb = r / B;
   f32x4 m = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
   for (int ky = 0; ky < k; ++ky)
     for (int kx = 0; kx < k; ++kx) {
       const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
       if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-      const f32x4 v = *reinterpret_cast<const f32x4 *>(in + ((bc * H + iy) * W + ix) * 8 + h * 4);
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(in + (cb * pitch_in + ((size_t)b * H + iy) * W + ix) * 8 + h * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
     }
-  *reinterpret_cast<f32x4 *>(out + ((bc * OH + oy) * OW + ox) * 8 + h * 4) = m;
+  *reinterpret_cast<f32x4 *>(out + (cb * pitch_out + ((size_t)b * OH + oy) * OW + ox) * 8 + h * 4) = m;
 }
 
 // image transformer (modules/ImageTransformer.lua:19-33, f64 arithmetic) into a one-map C8I image (channels 3..7 zero)
@@ -200,8 +204,8 @@ __global__ void image_transform_c8i_kernel(const float *__restrict__ in, int H, 
 
 // inn.ROIPooling on a one-map C8I feature -> [N][Cb][PH][PW][8] (the batch the per-ROI head convolves); the bin arithmetic
 // is the same as roi_pool_c8_kernel / the oracle's orc_roi_pool (coord_offset 1, end_adjust 0)
-__global__ void roi_pool_c8i_kernel(const float *__restrict__ feat, int Cb, int H, int W, const float *__restrict__ rois, int N, int PH, int PW,
-                                    float scale, float *__restrict__ out) {
+__global__ void roi_pool_c8i_kernel(const float *__restrict__ feat, int Cb, int H, int W, size_t pitch_f, const float *__restrict__ rois, int N, int PH,
+                                    int PW, float scale, float *__restrict__ out, size_t pitch_o) {
   const int PP = PH * PW;
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)N * Cb * PP * 2;
@@ -221,25 +225,26 @@ __global__ void roi_pool_c8i_kernel(const float *__restrict__ feat, int Cb, int 
   ws = min(max(ws, 0), W); we = min(max(we, 0), W);
   const bool empty = (he <= hs) || (we <= ws);
   f32x4 m = empty ? f32x4{0, 0, 0, 0} : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-  const float *fp = feat + (size_t)cb * H * W * 8 + h * 4;
+  const float *fp = feat + (size_t)cb * pitch_f * 8 + h * 4;
   for (int y = hs; y < he; ++y)
     for (int x = ws; x < we; ++x) {
       const f32x4 v = *reinterpret_cast<const f32x4 *>(fp + ((size_t)y * W + x) * 8);
 #pragma unroll
       for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
     }
-  *reinterpret_cast<f32x4 *>(out + ((((size_t)n * Cb + cb) * PH + ph) * PW + pw) * 8 + h * 4) = m;
+  *reinterpret_cast<f32x4 *>(out + ((size_t)cb * pitch_o + ((size_t)n * PH + ph) * PW + pw) * 8 + h * 4) = m;
 }
 
 // 7x7 global average pool of [N][Cb][H][W][8] into the C8 matrix [Cb][Mp][8] the head GEMM reads (row = roi); the sum
 // runs in row-major order like the oracle's, then * 1/(H*W)
-__global__ void avgpool_c8i_to_c8_kernel(const float *__restrict__ in, int N, int Cb, int HW, float inv, float *__restrict__ out, int Mp) {
+__global__ void avgpool_c8i_to_c8_kernel(const float *__restrict__ in, int N, int Cb, int HW, size_t pitch, float inv, float *__restrict__ out,
+                                         int Mp) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)N * Cb * 2;
   if (t >= total) return;
   const int h = (int)(t & 1); size_t r = t >> 1;
   const int n = (int)(r % N); const int cb = (int)(r / N);
-  const float *ip = in + (((size_t)n * Cb + cb) * HW) * 8 + h * 4;
+  const float *ip = in + ((size_t)cb * pitch + (size_t)n * HW) * 8 + h * 4;
   f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int i = 0; i < HW; ++i) sacc += *reinterpret_cast<const f32x4 *>(ip + (size_t)i * 8);
   *reinterpret_cast<f32x4 *>(out + ((size_t)cb * Mp + n) * 8 + h * 4) = sacc * inv;
@@ -251,6 +256,7 @@ __global__ void avgpool_c8i_to_c8_kernel(const float *__restrict__ in, int N, in
 struct RnConv {
   int Cin = 0, Cout = 0, K = 0, stride = 1, pad = 0;
   float *wpk = nullptr, *bpk = nullptr;
+  float *lin_w = nullptr, *lin_b = nullptr;  // 1x1 / stride 1 with Cin % 64 == 0: also packed for the tuned GEMM (linear_c8)
 };
 struct RnBlock {
   std::vector<RnConv> convs;
@@ -289,6 +295,14 @@ static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b
   hipLaunchKernelGGL(pack_conv_generic_kernel, dim3((unsigned)cdiv_sz(threads, 256)), dim3(256), 0, nullptr, d_w, d_b, c.Cin, c.Cout, KK, nch, CoutP,
                      c.wpk, c.bpk);
   MPN_CHECK_LAUNCH();
+  if (c.K == 1 && c.stride == 1 && c.pad == 0 && c.Cin % 64 == 0) {  // a pointwise convolution IS a GEMM over the C8I rows
+    rc = rn_alloc(g, &c.lin_w, lin_wpk_elems(c.Cin, c.Cout) * sizeof(float));
+    if (rc) return rc;
+    rc = rn_alloc(g, &c.lin_b, (size_t)lin_np(c.Cout) * sizeof(float));
+    if (rc) return rc;
+    rc = pack_linear_weights(d_w, d_b, c.Cin, c.Cout, 1, c.lin_w, c.lin_b, nullptr);
+    if (rc) return rc;
+  }
   return MPN_OK;
 }
 
@@ -302,11 +316,14 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
   a.relu = relu;
   MPN_CHECK_ARG(in.C == c.Cin && a.OH > 0 && a.OW > 0);
   a.P = (long long)in.B * a.OH * a.OW;
+  *o = ActI{out, in.B, c.Cout, a.OH, a.OW};
+  a.pitch_in = in.pitch(); a.pitch_out = o->pitch();
+  if (c.lin_w && linear_c8_is_direct((int)in.rows(), c.Cout, (int)in.pitch()))  // same rows in and out: the tuned GEMM, residual + ReLU fused
+    return linear_c8(in.p, (int)in.rows(), c.Cin, c.lin_w, c.lin_b, c.Cout, relu, out, nullptr, s, (int)in.pitch(), res);
   dim3 grid((unsigned)((a.P + 127) / 128), (unsigned)(a.CoutP / 128));
   if (a.nch % 4 == 0) hipLaunchKernelGGL((conv2d_c8i_kernel<4>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((conv2d_c8i_kernel<1>), grid, dim3(256), 0, s, a);
   MPN_CHECK_LAUNCH();
-  *o = ActI{out, in.B, c.Cout, a.OH, a.OW};
   return MPN_OK;
 }
 
@@ -372,9 +389,9 @@ int resnet_build(const mpn_resnet_weights *rw, int max_h, int max_w, int max_roi
   if (ci != rw->n_convs) { set_error("mpn_resnet_create: %d convolutions given, the block table uses %d", rw->n_convs, ci); resnet_free(g); return MPN_EINVAL; }
   // shapes at the largest image -> buffer sizes
   int h = max_h, w = max_w;
-  size_t te = (size_t)h * w * 8;
+  size_t te = c8i_elems(1, 8, h, w);
   rn_shape(g->conv1, h, w);
-  te = std::max(te, (size_t)((g->conv1.Cout + 7) / 8) * h * w * 8);
+  te = std::max(te, c8i_elems(1, g->conv1.Cout, h, w));
   h = (h + 2 - 3) / 2 + 1; w = (w + 2 - 3) / 2 + 1;  // max-pool 3x3/2 pad 1
   int c = g->conv1.Cout;
   for (auto &blk : g->trunk) {
@@ -382,26 +399,26 @@ int resnet_build(const mpn_resnet_weights *rw, int max_h, int max_w, int max_roi
     for (auto &cv : blk.convs) {
       if (cv.Cin != c && &cv == &blk.convs[0]) { set_error("mpn_resnet_create: channel mismatch in the trunk"); resnet_free(g); return MPN_EINVAL; }
       rn_shape(cv, bh, bw);
-      te = std::max(te, (size_t)((cv.Cout + 7) / 8) * bh * bw * 8);
+      te = std::max(te, c8i_elems(1, cv.Cout, bh, bw));
       c = cv.Cout;
     }
     h = bh; w = bw;
   }
   g->feat_c = c;
   h = w = pooled;
-  size_t he = (size_t)max_rois * ((c + 7) / 8) * h * w * 8;
+  size_t he = c8i_elems(max_rois, c, h, w);
   for (auto &blk : g->head) {
     int bh = h, bw = w;
     for (auto &cv : blk.convs) {
       rn_shape(cv, bh, bw);
-      he = std::max(he, (size_t)max_rois * ((cv.Cout + 7) / 8) * bh * bw * 8);
+      he = std::max(he, c8i_elems(max_rois, cv.Cout, bh, bw));
       c = cv.Cout;
     }
     h = bh; w = bw;
   }
   g->out_c = c;
   g->tb_elems = te; g->hb_elems = he;
-  RTRY(rn_alloc(g, &g->img, (size_t)max_h * max_w * 8 * sizeof(float)));
+  RTRY(rn_alloc(g, &g->img, c8i_elems(1, 8, max_h, max_w) * sizeof(float)));
   for (int i = 0; i < 4; ++i) RTRY(rn_alloc(g, &g->tb[i], te * sizeof(float)));
   for (int i = 0; i < 4; ++i) RTRY(rn_alloc(g, &g->hb[i], he * sizeof(float)));
 #undef RTRY
@@ -433,7 +450,9 @@ int resnet_trunk_forward(ResNetGraph *g, const float *d_image, int H, int W, con
   const int OH = (y.H + 2 - 3) / 2 + 1, OW = (y.W + 2 - 3) / 2 + 1;
   {
     const size_t total = (size_t)y.Cb() * OH * OW * 2;
-    hipLaunchKernelGGL(maxpool2d_c8i_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, y.p, y.Cb(), y.H, y.W, 3, 2, 1, OH, OW, g->tb[1]);
+    const ActI po{g->tb[1], 1, y.C, OH, OW};
+    hipLaunchKernelGGL(maxpool2d_c8i_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, y.p, y.Cb(), 1, y.H, y.W, y.pitch(), 3, 2, 1, OH, OW,
+                       po.pitch(), g->tb[1]);
     MPN_CHECK_LAUNCH();
   }
   ActI cur{g->tb[1], 1, y.C, OH, OW};
@@ -451,8 +470,9 @@ int resnet_head_forward(ResNetGraph *g, const float *d_rois, int N, float spatia
   const int Cb = (g->feat_c + 7) / 8, PH = g->pooled;
   {
     const size_t total = (size_t)N * Cb * PH * PH * 2;
-    hipLaunchKernelGGL(roi_pool_c8i_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, g->feat, Cb, g->feat_h, g->feat_w, d_rois, N, PH, PH,
-                       spatial_scale, g->hb[0]);
+    const ActI fa{g->feat, 1, g->feat_c, g->feat_h, g->feat_w}, pa{g->hb[0], N, g->feat_c, PH, PH};
+    hipLaunchKernelGGL(roi_pool_c8i_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, g->feat, Cb, g->feat_h, g->feat_w, fa.pitch(), d_rois, N,
+                       PH, PH, spatial_scale, g->hb[0], pa.pitch());
     MPN_CHECK_LAUNCH();
   }
   ActI cur{g->hb[0], N, g->feat_c, PH, PH}, y;
@@ -462,7 +482,7 @@ int resnet_head_forward(ResNetGraph *g, const float *d_rois, int N, float spatia
     cur = y;
   }
   const size_t total = (size_t)N * cur.Cb() * 2;
-  hipLaunchKernelGGL(avgpool_c8i_to_c8_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, cur.p, N, cur.Cb(), cur.H * cur.W,
+  hipLaunchKernelGGL(avgpool_c8i_to_c8_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, cur.p, N, cur.Cb(), cur.H * cur.W, cur.pitch(),
                      1.0f / (float)(cur.H * cur.W), d_feat_c8, Mp);
   MPN_CHECK_LAUNCH();
   return MPN_OK;

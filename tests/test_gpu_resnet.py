@@ -19,14 +19,15 @@ def _inputs(H, W, N, seed):
     return im, b.astype(np.float32)
 
 
-@pytest.mark.parametrize("bt,blocks,width,pooled", [("bottleneck", [1, 1, 1, 1], 8, 14), ("basic", [1, 2, 1, 2], 8, 14), ("bottleneck", [2, 1, 2, 1], 16, 6)])
-def test_resnet_frcnn_vs_oracle(O, dev, bt, blocks, width, pooled):
+@pytest.mark.parametrize("bt,blocks,width,pooled,N", [("bottleneck", [1, 1, 1, 1], 8, 14, 37), ("basic", [1, 2, 1, 2], 8, 14, 37), ("bottleneck", [2, 1, 2, 1], 16, 6, 37),
+                                                   ("bottleneck", [1, 1, 1, 2], 16, 14, 150)])  # the last one is large enough for the 1x1 convolutions to take the GEMM path
+def test_resnet_frcnn_vs_oracle(O, dev, bt, blocks, width, pooled, N):
     from multipathnet_amd import models
-    H, W, N, C = 97, 131, 37, 6
+    H, W, C = 97, 131, 6
     R = models.synthetic_resnet_params(depth=0, n_classes=C, base_width=width, blocks=blocks, block_type=bt, seed=21)
     Rn = models.resnet_params_numpy(R)
     im, boxes = _inputs(H, W, N, 4)
-    net = models.ResNetFRCNN(R, pooled=pooled, max_h=H, max_w=W, max_rois=64, top_k=20)
+    net = models.ResNetFRCNN(R, pooled=pooled, max_h=H, max_w=W, max_rois=max(64, N), top_k=20)
     s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
     so, bo, logits, deltas = O.resnet_detect(im, boxes, Rn, target=min(H, W), max_size=max(H, W), pooled=pooled)  # s = 1, as the pipeline (no rescale configured)
     s, b = s.cpu().numpy(), b.cpu().numpy()
