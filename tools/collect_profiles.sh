@@ -16,3 +16,11 @@ for set in "sq:GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_A
   python $R/tools/pmc_summary.py $D > $OUT/${TAG}_pmc_$name.summary.txt 2>&1
 done
 ls -la $OUT
+# the two widened configurations (not bench.py lines): per-kernel stats + the tools' own timing lines
+for cfg in "mpn:bench_mpn.py" "resnet50:bench_resnet.py"; do
+  name=${cfg%%:*}; tool=${cfg#*:}
+  rm -rf /tmp/kt_$name
+  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt_$name -o kt --output-format csv -- python $R/tools/$tool > $OUT/${TAG}_${name}_timing.txt 2> /tmp/kt_$name.err
+  cp $(find /tmp/kt_$name -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${name}_kernel_stats.csv
+done
+ls -la $OUT
