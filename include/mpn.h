@@ -12,8 +12,13 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls enqueue work and
  *     return; they never synchronise unless the name ends in `_host` / `_sync`.
  *   - Return value: MPN_OK or a negative mpn_status; mpn_last_error() gives a thread-local message.
- *     Nothing aborts, nothing allocates behind the caller's back except where a `ws` (workspace)
- *     argument is documented.
+ *     Nothing aborts.  Module-level calls allocate only what a `ws` (workspace) argument documents, plus the shared
+ *     scratch named under Concurrency; pipeline handles allocate everything at creation.
+ *   - Concurrency: one GPU per process, one calling thread per device (the reference's own test-time design,
+ *     test_runner.lua:55-66).  The dense entry points (conv / linear / the mpn_frcnn pipelines) share library-owned
+ *     split-K and NMS scratch that grows on demand: calls on ONE stream at a time are ordered and safe; driving two
+ *     pipeline handles concurrently from different streams of the same process is not supported.  (A pipeline's
+ *     internal side stream for the NMS / top-k tail uses handle-owned buffers only.)
  *   - Integer results (argmax, keep indices, counts) are bit-exact vs the reference semantics; fp32
  *     box arithmetic is evaluated without FMA contraction, in the reference's operation order.
  */
