@@ -278,6 +278,15 @@ typedef struct mpn_resnet_weights {
   const int *block_n_convs;       /* [n_blocks] convolutions on the residual path */
   const int *block_has_shortcut;  /* [n_blocks] 1 = a shortcut convolution follows the block's convolutions in the list */
   int n_trunk_blocks;             /* blocks [0, n_trunk_blocks) = layer1-3 (image trunk); the rest = layer4 (per-ROI head) */
+  /* MultiPathNet on a ResNet backbone (BASELINE configs[3]).  The reference tree has NO such model: this is
+   * this library's extension, shaped like models/multipathnet.lua:64-120 — nn.Foveal regions over the single stride-16 map, one
+   * layer4 copy ("tower") per region, the classification towers' pooled vectors concatenated for n_integral classifier clones
+   * (mean of their softmaxes, model_utils.lua:296-315), the LAST tower feeding the box regressor.  n_heads <= 1: plain
+   * resnet.lua.  n_heads >= 2: the blocks after the trunk are n_heads equal groups in tower order; d_cls_w is
+   * [n_integral*C, (n_heads-1)*out_c], d_bbox_w [4C, out_c]. */
+  int n_heads;
+  int head_region[8];             /* 0-based Foveal region of each tower */
+  int n_integral;
 } mpn_resnet_weights;
 int mpn_resnet_create(const mpn_frcnn_config *cfg, const mpn_resnet_weights *rw, const float *d_cls_w, const float *d_cls_b,
                       const float *d_bbox_w, const float *d_bbox_b, mpn_frcnn **out);

@@ -157,6 +157,7 @@ struct mpn_frcnn {
   // ---- MultiPathNet head (models/multipathnet.lua:64-120); empty for plain Fast R-CNN
   struct Tower { int region, use4, use3, total_feat; float *mix_w, *mix_b, *w6, *b6, *w7, *b7; };
   bool is_mpnet = false;
+  std::vector<int> rn_region;   // ResNet towers: Foveal region per tower (empty = plain resnet.lua)
   ResNetGraph *rn = nullptr;  // ResNet Fast R-CNN (mpn_resnet_create): trunk + per-ROI layer4 replace the VGG convs / fc6 / fc7
   int tap3 = -1, tap4 = -1, n_integral = 1;
   std::vector<Tower> towers;
@@ -236,6 +237,7 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
   MPN_CHECK_ARG(cfg->top_k > 0);
   mpn_frcnn *p = new mpn_frcnn();
   p->cfg = *cfg;
+  if (rw && rw->n_heads > 1) p->n_integral = rw->n_integral > 0 ? rw->n_integral : 1;
   if (mw) { p->is_mpnet = true; p->tap3 = mw->tap_conv3; p->tap4 = mw->tap_conv4; p->n_integral = mw->n_integral > 0 ? mw->n_integral : 1; }
   const int n_conv = rw ? 0 : cfg->n_conv;
   p->cfg.n_conv = n_conv;
@@ -330,6 +332,21 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
     TRY(dev_alloc(p, &p->cat, (size_t)mw->n_towers * (lin_np(F) / 8) * p->Mp * 8 * sizeof(float), true));
     TRY(dev_alloc(p, &p->cls_rm, M * K * C * sizeof(float), true));
     TRY(dev_alloc(p, &p->bbox_rm, M * 4 * C * sizeof(float), true));
+  } else if (rw && rw->n_heads > 1) {  // ResNet towers (this library's extension, see mpn_resnet_weights): same classifier stage as MultiPathNet
+    const int n_fov = rw->n_heads - 1, K = p->n_integral;
+    MPN_CHECK_ARG(C <= 256);
+    const int KC64 = round_up(n_fov * F, 64);
+    TRY(dev_alloc(p, &p->wcls, lin_wpk_elems(KC64, K * C) * sizeof(float), false));
+    TRY(dev_alloc(p, &p->bcls, (size_t)lin_np(K * C) * sizeof(float), false));
+    TRY(pack_linear_weights(d_cls_w, d_cls_b, n_fov * F, K * C, 1, p->wcls, p->bcls, nullptr));
+    TRY(dev_alloc(p, &p->wbbox, lin_wpk_elems(F32, 4 * C) * sizeof(float), false));
+    TRY(dev_alloc(p, &p->bbbox, (size_t)lin_np(4 * C) * sizeof(float), false));
+    TRY(pack_linear_weights(d_bbox_w, d_bbox_b, F, 4 * C, 1, p->wbbox, p->bbbox, nullptr));
+    TRY(dev_alloc(p, &p->fov, M * 20 * sizeof(float), true));
+    TRY(dev_alloc(p, &p->cat, (size_t)rw->n_heads * (lin_np(F) / 8) * p->Mp * 8 * sizeof(float), true));
+    TRY(dev_alloc(p, &p->cls_rm, M * K * C * sizeof(float), true));
+    TRY(dev_alloc(p, &p->bbox_rm, M * 4 * C * sizeof(float), true));
+    for (int t = 0; t < rw->n_heads; ++t) { MPN_CHECK_ARG(rw->head_region[t] >= 0 && rw->head_region[t] < 4); p->rn_region.push_back(rw->head_region[t]); }
   } else {
   if (!rw) {
   TRY(dev_alloc(p, &p->w6, lin_wpk_elems(K6_32, F) * sizeof(float), false));
@@ -446,9 +463,11 @@ static int run_trunk(mpn_frcnn *p, const float *d_image, int H, int W, hipStream
 // {ROI pools of conv5 / conv4 / conv3 written side by side = the channel concat, per-map L2 normalise * 1000,
 // 1x1 conv mix as a GEMM over (bin, roi) rows whose output IS the fc6 operand, fc6, fc7 into the tower concat}
 // -> K integral classifiers (mean of softmaxes) + bbox regressor on the "het" tower.
+static int run_integral_heads(mpn_frcnn *p, const float *d_boxes, int N, int H, int W, int n_fov, hipStream_t s);
+
 static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int W, hipStream_t s) {
   const mpn_frcnn_config &c = p->cfg;
-  const int C = c.n_classes, F = c.fc_dim, PP = c.pooled_h * c.pooled_w, Mp = lin_mp(N), K = p->n_integral;
+  const int F = c.fc_dim, PP = c.pooled_h * c.pooled_w, Mp = lin_mp(N);
   int rc = mpn_foveal_forward(p->rois, N, p->fov, s);
   if (rc) return rc;
   const Act maps[3] = {p->tap_act[0], p->tap_act[1], p->tap_act[2]};
@@ -485,7 +504,16 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
     if (rc) return rc;
     ++ti;
   }
-  const int n_fov = (int)p->towers.size() - 1;
+  return run_integral_heads(p, d_boxes, N, H, W, (int)p->towers.size() - 1, s);
+}
+
+// the stage after the towers (model_utils.lua:296-315, multipathnet.lua:112-120): K classifier clones on the concatenated
+// classification towers -> mean of their softmaxes; box regressor on the last tower; decode + clamp
+static int run_integral_heads(mpn_frcnn *p, const float *d_boxes, int N, int H, int W, int n_fov, hipStream_t s) {
+  const mpn_frcnn_config &c = p->cfg;
+  const int C = c.n_classes, F = c.fc_dim, Mp = lin_mp(N), K = p->n_integral;
+  const int Fcb = lin_np(F) / 8;
+  int rc;
   { ProfScope ps(p, MPN_PROF_HEADS, s);
     rc = linear_c8(p->cat, N, n_fov * F, p->wcls, p->bcls, K * C, 0, nullptr, p->cls_rm, s, Mp);
     if (rc == MPN_OK) rc = linear_c8(p->cat + (size_t)n_fov * Fcb * Mp * 8, N, F, p->wbbox, p->bbbox, 4 * C, 0, nullptr, p->bbox_rm, s, Mp); }
@@ -557,9 +585,22 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const 
     return rc;
   }
   const int C = c.n_classes, F = c.fc_dim;
+  if (p->rn && !p->rn_region.empty()) {  // ResNet towers: Foveal region t -> ROI pool -> layer4 copy t -> average pool -> its slice of `cat`
+    rc = mpn_foveal_forward(p->rois, N, p->fov, s);
+    if (rc) return rc;
+    const int Fcb = lin_np(F) / 8, Mp = lin_mp(N);
+    for (size_t t = 0; t < p->rn_region.size(); ++t) {
+      ProfScope ps(p, MPN_PROF_FC6, s);
+      rc = resnet_head_forward(p->rn, (int)t, p->fov + 5 * p->rn_region[t], 20, N, c.spatial_scale, p->cat + t * (size_t)Fcb * Mp * 8, Mp, s);
+      if (rc) return rc;
+    }
+    rc = run_integral_heads(p, d_boxes, N, H, W, (int)p->rn_region.size() - 1, s);
+    p->last_n = N;
+    return rc;
+  }
   if (p->rn) {  // resnet.lua:40-48: ROIPooling(14,14) -> layer4 -> average pool -> View; lands in y7 as the heads' operand
     ProfScope ps(p, MPN_PROF_FC6, s);
-    rc = resnet_head_forward(p->rn, p->rois, N, c.spatial_scale, p->y7, lin_mp(N), s);
+    rc = resnet_head_forward(p->rn, 0, p->rois, 5, N, c.spatial_scale, p->y7, lin_mp(N), s);
     if (rc) return rc;
   } else {
   { ProfScope ps(p, MPN_PROF_ROIPOOL, s);

@@ -24,7 +24,10 @@ int resnet_out_channels(const ResNetGraph *g);    // layer4 output channels (wha
 int resnet_trunk_forward(ResNetGraph *g, const float *d_image, int H, int W, const int *swap, double scale, const double *mean,
                          const double *std, int has_std, hipStream_t s);
 bool resnet_has_features(const ResNetGraph *g, int H, int W);
-// rois [N,5] (projected) -> ROI pool -> layer4 -> average pool -> C8 matrix [out_c/8][Mp][8] (row = roi)
-int resnet_head_forward(ResNetGraph *g, const float *d_rois, int N, float spatial_scale, float *d_feat_c8, int Mp, hipStream_t s);
+int resnet_n_heads(const ResNetGraph *g);
+// rois (roi_stride floats apart; 5 = a plain [N,5] table, 20 = one region of a Foveal [4N,5] table) -> ROI pool -> tower `head`'s
+// layer4 -> average pool -> C8 matrix [out_c/8][Mp][8] (row = roi)
+int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_stride, int N, float spatial_scale, float *d_feat_c8, int Mp,
+                        hipStream_t s);
 
 }  // namespace mpn

@@ -204,8 +204,8 @@ __global__ void image_transform_c8i_kernel(const float *__restrict__ in, int H, 
 
 // inn.ROIPooling on a one-map C8I feature -> [N][Cb][PH][PW][8] (the batch the per-ROI head convolves); the bin arithmetic
 // is the same as roi_pool_c8_kernel / the oracle's orc_roi_pool (coord_offset 1, end_adjust 0)
-__global__ void roi_pool_c8i_kernel(const float *__restrict__ feat, int Cb, int H, int W, size_t pitch_f, const float *__restrict__ rois, int N, int PH,
-                                    int PW, float scale, float *__restrict__ out, size_t pitch_o) {
+__global__ void roi_pool_c8i_kernel(const float *__restrict__ feat, int Cb, int H, int W, size_t pitch_f, const float *__restrict__ rois, int roi_stride,
+                                    int N, int PH, int PW, float scale, float *__restrict__ out, size_t pitch_o) {
   const int PP = PH * PW;
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)N * Cb * PP * 2;
@@ -214,7 +214,7 @@ __global__ void roi_pool_c8i_kernel(const float *__restrict__ feat, int Cb, int 
   const int bin = (int)(r % PP); r /= PP;
   const int cb = (int)(r % Cb); const int n = (int)(r / Cb);
   const int ph = bin / PW, pw = bin - ph * PW;
-  const float *ro = rois + (size_t)5 * n;
+  const float *ro = rois + (size_t)roi_stride * n;
   const int sw = (int)roundf((ro[1] - 1.0f) * scale), sh = (int)roundf((ro[2] - 1.0f) * scale);
   const int ew = (int)roundf((ro[3] - 1.0f) * scale), eh = (int)roundf((ro[4] - 1.0f) * scale);
   const int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
@@ -265,7 +265,8 @@ struct RnBlock {
 };
 struct ResNetGraph {
   RnConv conv1;
-  std::vector<RnBlock> trunk, head;
+  std::vector<RnBlock> trunk;
+  std::vector<std::vector<RnBlock>> heads;  // one layer4 copy per tower (1 for plain resnet.lua)
   int feat_c = 0, out_c = 0, pooled = 14, max_rois = 0;
   float *img = nullptr;          // C8I image
   float *tb[4] = {nullptr, nullptr, nullptr, nullptr};  // trunk activations (rotating)
@@ -369,6 +370,11 @@ int resnet_build(const mpn_resnet_weights *rw, int max_h, int max_w, int max_roi
   g->pooled = pooled; g->max_rois = max_rois;
   int rc = MPN_OK;
 #define RTRY(x) do { rc = (x); if (rc != MPN_OK) { resnet_free(g); return rc; } } while (0)
+  const int n_heads = rw->n_heads > 1 ? rw->n_heads : 1;
+  const int n_head_blocks = rw->n_blocks - rw->n_trunk_blocks;
+  if (n_heads > 8 || n_head_blocks % n_heads != 0) { set_error("mpn_resnet_create: %d head blocks do not split into %d towers", n_head_blocks, n_heads); resnet_free(g); return MPN_EINVAL; }
+  const int per_head = n_head_blocks / n_heads;
+  g->heads.resize(n_heads);
   int ci = 0;
   auto take = [&](RnConv &c) -> int {
     if (ci >= rw->n_convs) { set_error("mpn_resnet_create: block table needs more than %d convolutions", rw->n_convs); return MPN_EINVAL; }
@@ -384,7 +390,8 @@ int resnet_build(const mpn_resnet_weights *rw, int max_h, int max_w, int max_roi
     for (int k = 0; k < rw->block_n_convs[b]; ++k) { RnConv c; RTRY(take(c)); blk.convs.push_back(c); }
     blk.has_sc = rw->block_has_shortcut[b] != 0;
     if (blk.has_sc) RTRY(take(blk.sc));
-    (b < rw->n_trunk_blocks ? g->trunk : g->head).push_back(blk);
+    if (b < rw->n_trunk_blocks) g->trunk.push_back(blk);
+    else g->heads[(size_t)(b - rw->n_trunk_blocks) / per_head].push_back(blk);
   }
   if (ci != rw->n_convs) { set_error("mpn_resnet_create: %d convolutions given, the block table uses %d", rw->n_convs, ci); resnet_free(g); return MPN_EINVAL; }
   // shapes at the largest image -> buffer sizes
@@ -407,16 +414,20 @@ int resnet_build(const mpn_resnet_weights *rw, int max_h, int max_w, int max_roi
   g->feat_c = c;
   h = w = pooled;
   size_t he = c8i_elems(max_rois, c, h, w);
-  for (auto &blk : g->head) {
-    int bh = h, bw = w;
-    for (auto &cv : blk.convs) {
-      rn_shape(cv, bh, bw);
-      he = std::max(he, c8i_elems(max_rois, cv.Cout, bh, bw));
-      c = cv.Cout;
+  for (auto &hd : g->heads) {
+    int hh = h, hw = w, hc = g->feat_c;
+    for (auto &blk : hd) {
+      int bh = hh, bw = hw;
+      for (auto &cv : blk.convs) {
+        rn_shape(cv, bh, bw);
+        he = std::max(he, c8i_elems(max_rois, cv.Cout, bh, bw));
+        hc = cv.Cout;
+      }
+      hh = bh; hw = bw;
     }
-    h = bh; w = bw;
+    if (g->out_c && g->out_c != hc) { set_error("mpn_resnet_create: towers end in different channel counts"); resnet_free(g); return MPN_EINVAL; }
+    g->out_c = hc;
   }
-  g->out_c = c;
   g->tb_elems = te; g->hb_elems = he;
   RTRY(rn_alloc(g, &g->img, c8i_elems(1, 8, max_h, max_w) * sizeof(float)));
   for (int i = 0; i < 4; ++i) RTRY(rn_alloc(g, &g->tb[i], te * sizeof(float)));
@@ -435,6 +446,7 @@ void resnet_free(ResNetGraph *g) {
 
 int resnet_feat_channels(const ResNetGraph *g) { return g->feat_c; }
 int resnet_out_channels(const ResNetGraph *g) { return g->out_c; }
+int resnet_n_heads(const ResNetGraph *g) { return (int)g->heads.size(); }
 bool resnet_has_features(const ResNetGraph *g, int H, int W) { return g->feat && g->last_h == H && g->last_w == W; }
 
 int resnet_trunk_forward(ResNetGraph *g, const float *d_image, int H, int W, const int *swap, double scale, const double *mean,
@@ -465,18 +477,19 @@ int resnet_trunk_forward(ResNetGraph *g, const float *d_image, int H, int W, con
   return MPN_OK;
 }
 
-int resnet_head_forward(ResNetGraph *g, const float *d_rois, int N, float spatial_scale, float *d_feat_c8, int Mp, hipStream_t s) {
-  MPN_CHECK_ARG(g && g->feat && d_rois && d_feat_c8 && N > 0 && N <= g->max_rois);
+int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_stride, int N, float spatial_scale, float *d_feat_c8, int Mp,
+                        hipStream_t s) {
+  MPN_CHECK_ARG(g && g->feat && d_rois && d_feat_c8 && N > 0 && N <= g->max_rois && head >= 0 && head < (int)g->heads.size());
   const int Cb = (g->feat_c + 7) / 8, PH = g->pooled;
   {
     const size_t total = (size_t)N * Cb * PH * PH * 2;
     const ActI fa{g->feat, 1, g->feat_c, g->feat_h, g->feat_w}, pa{g->hb[0], N, g->feat_c, PH, PH};
-    hipLaunchKernelGGL(roi_pool_c8i_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, g->feat, Cb, g->feat_h, g->feat_w, fa.pitch(), d_rois, N,
-                       PH, PH, spatial_scale, g->hb[0], pa.pitch());
+    hipLaunchKernelGGL(roi_pool_c8i_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, g->feat, Cb, g->feat_h, g->feat_w, fa.pitch(), d_rois, roi_stride,
+                       N, PH, PH, spatial_scale, g->hb[0], pa.pitch());
     MPN_CHECK_LAUNCH();
   }
   ActI cur{g->hb[0], N, g->feat_c, PH, PH}, y;
-  for (auto &blk : g->head) {
+  for (auto &blk : g->heads[head]) {
     int rc = rn_block(blk, cur, g->hb, s, &y);
     if (rc) return rc;
     cur = y;

@@ -123,6 +123,39 @@ def synthetic_resnet_params(depth=50, n_classes=21, seed=557, base_width=64, blo
     return R
 
 
+RESNET_MPN_REGIONS = [0, 1, 2, 3, 1]  # four Foveal classification towers + the box tower (as multipathnet.lua:78-111's five towers)
+
+
+def synthetic_resnet_mpn_params(depth=50, n_classes=81, n_integral=6, seed=557, regions=RESNET_MPN_REGIONS, **kw):
+    """MultiPathNet on a ResNet backbone (BASELINE configs[3]; this library's extension — the reference has no such model):
+    shared trunk, one layer4 copy per Foveal tower, K integral classifiers on the concatenated classification towers, the
+    last tower feeding the box regressor."""
+    R = synthetic_resnet_params(depth=depth, n_classes=n_classes, seed=seed, **kw)
+    g = torch.Generator().manual_seed(seed + 7)
+    base = R["head_blocks"]
+    towers = []
+    for t, _ in enumerate(regions):
+        if t == 0:
+            towers.append(base)
+            continue
+        tw = []
+        for b in base:  # same shapes, fresh weights
+            convs = [(torch.randn(w.shape, generator=g) * w.std(), torch.randn(bb.shape, generator=g) * 0.01, st, pd) for (w, bb, st, pd) in b["convs"]]
+            sc = None if b["shortcut"] is None else (torch.randn(b["shortcut"][0].shape, generator=g) * b["shortcut"][0].std(),
+                                                     torch.randn(b["shortcut"][1].shape, generator=g) * 0.01, b["shortcut"][2])
+            tw.append(dict(convs=convs, shortcut=sc))
+        towers.append(tw)
+    out_c = R["cls_w"].shape[1]
+    R["head_towers"], R["head_regions"] = towers, list(regions)
+    nf = len(regions) - 1
+    R["cls_w"] = torch.randn(n_integral * n_classes, nf * out_c, generator=g) * 0.01
+    R["cls_b"] = torch.zeros(n_integral * n_classes)
+    R["bbox_w"] = torch.randn(4 * n_classes, out_c, generator=g) * 0.001
+    R["bbox_b"] = torch.zeros(4 * n_classes)
+    R["n_integral"], R["n_classes"] = n_integral, n_classes
+    return R
+
+
 def resnet_params_numpy(R):
     """the same parameters in the oracle's (numpy) form"""
     n = lambda t: t.detach().cpu().numpy()
@@ -131,6 +164,9 @@ def resnet_params_numpy(R):
     out = {k: n(R[k]) for k in ("conv1_w", "conv1_b", "cls_w", "cls_b", "bbox_w", "bbox_b")}
     out["trunk_blocks"] = [blk(b) for b in R["trunk_blocks"]]
     out["head_blocks"] = [blk(b) for b in R["head_blocks"]]
+    if "head_towers" in R:
+        out["head_towers"] = [[blk(b) for b in tw] for tw in R["head_towers"]]
+        out["head_regions"], out["n_integral"], out["n_classes"] = R["head_regions"], R["n_integral"], R["n_classes"]
     out["bbox_mean"], out["bbox_std"] = R["bbox_mean"], R["bbox_std"]
     return out
 
@@ -207,9 +243,9 @@ class FastRCNN(object):
         self.is_resnet = "trunk_blocks" in params
         cout, pool = ([], []) if self.is_resnet else cfg_layers(cfg)
         self.is_mpnet = "towers" in params
-        self.n_classes = params["n_classes"] if self.is_mpnet else params["cls_w"].shape[0]
+        self.n_classes = params["n_classes"] if (self.is_mpnet or "head_towers" in params) else params["cls_w"].shape[0]
         if self.is_resnet:
-            self.fc_dim = params["cls_w"].shape[1]
+            self.fc_dim = params["bbox_w"].shape[1]
         else:
             self.fc_dim = params["towers"][0]["fc7_w"].shape[0] if self.is_mpnet else params["fc7_w"].shape[0]
         self.noSoftMax = False
@@ -246,7 +282,8 @@ class FastRCNN(object):
         if self.is_resnet:
             convs, nconv, hassc = [], [], []  # execution order: conv1, then per block its convolutions (+ shortcut)
             convs.append((params["conv1_w"], params["conv1_b"], 2, 3))
-            blocks = list(params["trunk_blocks"]) + list(params["head_blocks"])
+            towers = params.get("head_towers") or [params["head_blocks"]]
+            blocks = list(params["trunk_blocks"]) + [b for tw in towers for b in tw]
             for b in blocks:
                 convs += list(b["convs"])
                 nconv.append(len(b["convs"]))
@@ -266,6 +303,11 @@ class FastRCNN(object):
             rw.n_blocks = len(blocks)
             rw.block_n_convs, rw.block_has_shortcut = C.cast(a[7], C.POINTER(C.c_int)), C.cast(a[8], C.POINTER(C.c_int))
             rw.n_trunk_blocks = len(params["trunk_blocks"])
+            if "head_towers" in params:
+                rw.n_heads, rw.n_integral = len(towers), params["n_integral"]
+                for t, rg in enumerate(params["head_regions"]):
+                    rw.head_region[t] = rg
+                self.noSoftMax = True
             heads = [d(params[k]) for k in ("cls_w", "cls_b", "bbox_w", "bbox_b")]
             check(lib.mpn_resnet_create(C.byref(c), C.byref(rw), *[_f(t) for t in heads], C.byref(self._h)), "mpn_resnet_create")
             torch.cuda.synchronize()

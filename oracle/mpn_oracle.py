@@ -503,3 +503,32 @@ def resnet_detect(im, boxes, R, transformer=IMAGENET, target=600, max_size=1000,
     logits, deltas = resnet_head(feat, rois, R, pooled=pooled, chunk=chunk)
     dec = bbox_decode(boxes, deltas)
     return softmax(logits), dec, logits, deltas
+
+
+def resnet_mpn_detect(im, boxes, R, transformer=IMAGENET, target=600, max_size=1000, pooled=14):
+    """MultiPathNet on a ResNet backbone (this library's extension of multipathnet.lua:64-120 to resnet.lua's graph):
+    Foveal regions -> per-tower ROIPooling + layer4 copy + average pool -> concat of the classification towers ->
+    K classifier clones, mean of softmaxes; the last tower feeds the box regressor.  Returns (scores, decoded boxes)."""
+    H, W = im.shape[1:]
+    s = pick_scale(H, W, target, max_size)
+    x = image_transform(im, **transformer)
+    if s != 1.0:
+        x = image_scale(x, int(H * s), int(W * s))
+    rois = project_im_rois(boxes, s)
+    feat = resnet_trunk(x, R)
+    fov = foveal(rois).reshape(-1, 4, 5)
+    outs = []
+    for tw, rg in zip(R["head_towers"], R["head_regions"]):
+        y, _ = roi_pool(feat, np.ascontiguousarray(fov[:, rg]), pooled, pooled, 1.0 / 16)
+        for blk in tw:
+            y = resnet_block(y, blk)
+        outs.append(avgpool_global(y))
+    cat = np.concatenate(outs[:-1], 1)
+    K, Cn = R["n_integral"], R["n_classes"]
+    logits = linear(cat, R["cls_w"], R["cls_b"]).reshape(-1, K, Cn)
+    probs = np.stack([softmax(np.ascontiguousarray(logits[:, k])) for k in range(K)])
+    scores = mean_over_k(probs)
+    deltas = linear(outs[-1], R["bbox_w"], R["bbox_b"])
+    if R.get("bbox_mean") is not None:
+        deltas = bbox_norm(deltas, R["bbox_mean"], R["bbox_std"])
+    return scores, bbox_decode(boxes, deltas)

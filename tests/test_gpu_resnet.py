@@ -59,3 +59,21 @@ def test_resnet_test_one_pipeline(O, dev):
     torch.cuda.synchronize()
     for d, nd in outs:
         assert int(nd.item()) == n and torch.equal(d[:n], ref)
+
+
+def test_resnet_multipathnet_extension_vs_oracle(O, dev):
+    """BASELINE configs[3] shape (MultiPathNet on a ResNet backbone — defined by this library, the reference has no such model):
+    Foveal towers over the stride-16 map, each with its own layer4 copy, K integral classifiers, box tower"""
+    from multipathnet_amd import models
+    H, W, N, C, K = 97, 131, 40, 5, 3
+    R = models.synthetic_resnet_mpn_params(depth=0, n_classes=C, n_integral=K, base_width=8, blocks=[1, 1, 1, 1], block_type="bottleneck", seed=31)
+    Rn = models.resnet_params_numpy(R)
+    im, boxes = _inputs(H, W, N, 14)
+    net = models.ResNetFRCNN(R, max_h=H, max_w=W, max_rois=64, top_k=20)
+    s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+    so, bo = O.resnet_mpn_detect(im, boxes, Rn, target=min(H, W), max_size=max(H, W))
+    assert np.abs(s.cpu().numpy() - so).max() < 1e-4
+    assert np.abs(b.cpu().numpy() - O.clamp_boxes(bo, W, H)).max() < 1e-2
+    net.test_one_async(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+    torch.cuda.synchronize()
+    assert int(net._n_dets.item()) > 0
