@@ -77,3 +77,27 @@ def test_resnet_multipathnet_extension_vs_oracle(O, dev):
     net.test_one_async(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
     torch.cuda.synchronize()
     assert int(net._n_dets.item()) > 0
+
+
+def test_resnet_iterative_localisation_and_voting_run(dev):
+    """Tester_FRCNN.lua:82-99,118-124 on the ResNet model: the second localisation pass re-runs only the per-ROI head on the
+    cached stride-16 map; deterministic run after run, and a later image of another size is handled"""
+    from multipathnet_amd import models
+    H, W, N, C = 120, 160, 48, 5
+    R = models.synthetic_resnet_params(depth=0, n_classes=C, base_width=8, blocks=[1, 1, 1, 1], block_type="bottleneck", seed=5)
+    im, boxes = _inputs(H, W, N, 2)
+    imd, bd = torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev)
+    net = models.ResNetFRCNN(R, max_h=H, max_w=W, max_rois=64, top_k=10, num_iter=2, bbox_voting=True)
+    net.test_one_async(imd, bd)
+    torch.cuda.synchronize()
+    n = int(net._n_dets.item())
+    assert n > 0
+    d1 = net._dets[:n].clone()
+    net.test_one_async(imd, bd)
+    torch.cuda.synchronize()
+    assert int(net._n_dets.item()) == n and torch.equal(net._dets[:n], d1)
+    # a different image size afterwards (buffers are sized for the maximum; the cached-feature check must see the new size)
+    im2, boxes2 = _inputs(100, 140, N, 3)
+    net.test_one_async(torch.from_numpy(im2).to(dev), torch.from_numpy(boxes2).to(dev))
+    torch.cuda.synchronize()
+    assert int(net._n_dets.item()) > 0
