@@ -287,6 +287,8 @@ typedef struct mpn_resnet_weights {
   int n_heads;
   int head_region[8];             /* 0-based Foveal region of each tower */
   int n_integral;
+  int bf16;                       /* 1: trunk and per-ROI convolutions in bf16 (bf16 activations and weights, fp32 accumulate; bias, residual,
+                                     ReLU in fp32; the cls / bbox head stays fp32) — the dtype SURVEY §8f rank 3 asks for.  0: fp32 */
 } mpn_resnet_weights;
 int mpn_resnet_create(const mpn_frcnn_config *cfg, const mpn_resnet_weights *rw, const float *d_cls_w, const float *d_cls_b,
                       const float *d_bbox_w, const float *d_bbox_b, mpn_frcnn **out);

@@ -49,7 +49,7 @@ class ResnetWeights(C.Structure):
         ("pad", C.POINTER(C.c_int)),
         ("n_blocks", C.c_int), ("block_n_convs", C.POINTER(C.c_int)), ("block_has_shortcut", C.POINTER(C.c_int)),
         ("n_trunk_blocks", C.c_int),
-        ("n_heads", C.c_int), ("head_region", C.c_int * 8), ("n_integral", C.c_int),
+        ("n_heads", C.c_int), ("head_region", C.c_int * 8), ("n_integral", C.c_int), ("bf16", C.c_int),
     ]
 
 

@@ -251,12 +251,257 @@ __global__ void avgpool_c8i_to_c8_kernel(const float *__restrict__ in, int N, in
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// bf16 variant (SURVEY §8f rank 3 asks for the ResNet / Inception trunks in bf16): activations and weights stored as bf16
+// (round-to-nearest-even), products accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (K = 16 per instruction = two 8-channel
+// records: lanes 0-31 fetch the record of chunk 2q, lanes 32-63 that of chunk 2q+1 — the same split for both operands, so
+// the k order inside the instruction cannot matter), bias / residual / ReLU in fp32, one rounding to bf16 at the store.
+// Layout: C8I with 16-byte records [C/8][rows, pitch][8 x bf16]; channel-block count padded to even (zero planes).
+// ------------------------------------------------------------------------------------------------------------------------
+typedef unsigned short bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round to nearest even (finite inputs)
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
+
+// packed bf16 weights: [tap][nch2][CoutP][8], nch2 = Cin chunks rounded up to even
+__global__ void pack_conv_bf16_kernel(const float *__restrict__ w, int Cin, int Cout, int KK, int nch2, int CoutP, bf16_t *__restrict__ wpk) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)KK * nch2 * CoutP * 8;
+  if (t >= total) return;
+  const int j = (int)(t & 7);
+  size_t r = t >> 3;
+  const int co = (int)(r % CoutP); r /= CoutP;
+  const int ch = (int)(r % nch2);
+  const int tap = (int)(r / nch2);
+  const int ci = ch * 8 + j;
+  wpk[t] = f2bf((co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * KK + tap] : 0.0f);
+}
+
+struct GConvArgsB {
+  const bf16_t *in, *wpk, *res;
+  const float *bpk;
+  bf16_t *out;
+  int B, H, W, nch2;
+  size_t pitch_in, pitch_out;
+  int CoutP, Cb_out, KH, KW, stride, pad, OH, OW, relu;
+  long long P;
+};
+
+// KP = chunk PAIRS (16 input channels) per LDS stage: 4 * KP MFMAs per wave between two barriers
+template <int KP>
+__global__ __launch_bounds__(256) void conv2d_c8i_bf16_kernel(GConvArgsB a) {
+  constexpr int NCH = 2 * KP;                       // 8-channel chunks per stage
+  constexpr int NREC = NCH * 128 / 256;             // 16-byte records per thread per operand per stage
+  __shared__ __attribute__((aligned(16))) u32x4 lds[2][2][NCH * 128];  // [buffer][A | B][chunk][row] records
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long long p0 = (long long)blockIdx.x * 128;
+  const int cout0 = blockIdx.y * 128;
+  const int OHW = a.OH * a.OW;
+
+  // staging roles: thread = row tid & 127, chunks (tid >> 7) + 2 i
+  const int srow = tid & 127, sc0 = tid >> 7;
+  const long long gpix = p0 + srow;
+  const bool gvalid = gpix < a.P;
+  const int gb = gvalid ? (int)(gpix / OHW) : 0;
+  const int grem = gvalid ? (int)(gpix - (long long)gb * OHW) : 0;
+  const int goy = grem / a.OW, gox = grem - goy * a.OW;
+  const int iy0 = goy * a.stride - a.pad, ix0 = gox * a.stride - a.pad;
+  const u32x4 *in_r = reinterpret_cast<const u32x4 *>(a.in) + (size_t)gb * a.H * a.W;   // record units
+  const u32x4 *w_r = reinterpret_cast<const u32x4 *>(a.wpk) + (size_t)cout0 + srow;
+
+  const int spt = a.nch2 / NCH;
+  const int nstages = a.KH * a.KW * spt;
+  u32x4 ra[NREC], rb[NREC];
+  auto fetch = [&](int st) {
+    const int tap = st / spt, cg = st - tap * spt;
+    const int ky = tap / a.KW, kx = tap - ky * a.KW;
+    const int iy = iy0 + ky, ix = ix0 + kx;
+    const bool ok = gvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+#pragma unroll
+    for (int i = 0; i < NREC; ++i) {
+      const int ch = cg * NCH + sc0 + 2 * i;
+      ra[i] = w_r[((size_t)tap * a.nch2 + ch) * a.CoutP];
+      rb[i] = ok ? in_r[(size_t)ch * a.pitch_in + (size_t)iy * a.W + ix] : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NREC; ++i) {
+      lds[buf][0][(sc0 + 2 * i) * 128 + srow] = ra[i];
+      lds[buf][1][(sc0 + 2 * i) * 128 + srow] = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int st = 0; st < nstages; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nstages) fetch(st + 1);
+#pragma unroll
+    for (int q = 0; q < KP; ++q) {
+      bf16x8 af[2], bf[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) af[mi] = *reinterpret_cast<const bf16x8 *>(&lds[buf][0][(2 * q + half) * 128 + wm * 64 + mi * 32 + l31]);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) bf[ni] = *reinterpret_cast<const bf16x8 *>(&lds[buf][1][(2 * q + half) * 128 + wn * 64 + ni * 32 + l31]);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+    }
+    if (st + 1 < nstages) stash(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const long long pix = p0 + wn * 64 + ni * 32 + l31;
+    if (pix >= a.P) continue;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cb = (cout0 + wm * 64 + mi * 32) / 8 + g;
+        if (cb >= a.Cb_out) continue;
+        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bpk + cb * 8 + half * 4);
+        const size_t off = ((size_t)cb * a.pitch_out + (size_t)pix) * 8 + half * 4;  // bf16 elements
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][g * 4 + e] + b4[e];
+        if (a.res) {
+          const u16x4 r4 = *reinterpret_cast<const u16x4 *>(a.res + off);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bf2f(r4[e]);
+        }
+        u16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf((a.relu && v[e] < 0.0f) ? 0.0f : v[e]);
+        *reinterpret_cast<u16x4 *>(a.out + off) = o;
+      }
+  }
+}
+
+__global__ void maxpool2d_c8i_bf16_kernel(const bf16_t *__restrict__ in, int Cb, int B, int H, int W, size_t pitch_in, int k, int stride, int pad,
+                                          int OH, int OW, size_t pitch_out, bf16_t *__restrict__ out) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)Cb * B * OH * OW * 2;
+  if (t >= total) return;
+  const int h = (int)(t & 1); size_t r = t >> 1;
+  const int ox = (int)(r % OW); r /= OW;
+  const int oy = (int)(r % OH); r /= OH;
+  const int b = (int)(r % B); const size_t cb = r / B;
+  f32x4 m = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  for (int ky = 0; ky < k; ++ky)
+    for (int kx = 0; kx < k; ++kx) {
+      const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+      const u16x4 v = *reinterpret_cast<const u16x4 *>(in + (cb * pitch_in + ((size_t)b * H + iy) * W + ix) * 8 + h * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float f = bf2f(v[e]); m[e] = f > m[e] ? f : m[e]; }
+    }
+  u16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = f2bf(m[e]);
+  *reinterpret_cast<u16x4 *>(out + (cb * pitch_out + ((size_t)b * OH + oy) * OW + ox) * 8 + h * 4) = o;
+}
+
+// transformed image as bf16 C8I with TWO channel-block planes (channels 3..15 zero: the MFMA consumes chunk pairs)
+__global__ void image_transform_c8i_bf16_kernel(const float *__restrict__ in, int H, int W, int s0, int s1, int s2, double scale, double m0,
+                                                double m1, double m2, double d0, double d1, double d2, int has_std, bf16_t *__restrict__ out,
+                                                size_t pitch) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t plane = (size_t)H * W;
+  if (t >= plane) return;
+  double v0 = (double)in[(size_t)s0 * plane + t], v1 = (double)in[(size_t)s1 * plane + t], v2 = (double)in[(size_t)s2 * plane + t];
+  if (scale != 1.0) { v0 = v0 * scale; v1 = v1 * scale; v2 = v2 * scale; }
+  v0 = v0 + (-m0); v1 = v1 + (-m1); v2 = v2 + (-m2);
+  if (has_std) { v0 = v0 / d0; v1 = v1 / d1; v2 = v2 / d2; }
+  u16x4 lo = {f2bf((float)v0), f2bf((float)v1), f2bf((float)v2), 0}, z = {0, 0, 0, 0};
+  *reinterpret_cast<u16x4 *>(out + t * 8) = lo;
+  *reinterpret_cast<u16x4 *>(out + t * 8 + 4) = z;
+  *reinterpret_cast<u16x4 *>(out + (pitch + t) * 8) = z;
+  *reinterpret_cast<u16x4 *>(out + (pitch + t) * 8 + 4) = z;
+}
+
+__global__ void roi_pool_c8i_bf16_kernel(const bf16_t *__restrict__ feat, int Cb, int H, int W, size_t pitch_f, const float *__restrict__ rois,
+                                         int roi_stride, int N, int PH, int PW, float scale, bf16_t *__restrict__ out, size_t pitch_o) {
+  const int PP = PH * PW;
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)N * Cb * PP * 2;
+  if (t >= total) return;
+  const int h = (int)(t & 1); size_t r = t >> 1;
+  const int bin = (int)(r % PP); r /= PP;
+  const int cb = (int)(r % Cb); const int n = (int)(r / Cb);
+  const int ph = bin / PW, pw = bin - ph * PW;
+  const float *ro = rois + (size_t)roi_stride * n;
+  const int sw = (int)roundf((ro[1] - 1.0f) * scale), sh = (int)roundf((ro[2] - 1.0f) * scale);
+  const int ew = (int)roundf((ro[3] - 1.0f) * scale), eh = (int)roundf((ro[4] - 1.0f) * scale);
+  const int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
+  const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+  int hs = (int)floorf((float)ph * bh) + sh, he = (int)ceilf((float)(ph + 1) * bh) + sh;
+  int ws = (int)floorf((float)pw * bw) + sw, we = (int)ceilf((float)(pw + 1) * bw) + sw;
+  hs = min(max(hs, 0), H); he = min(max(he, 0), H);
+  ws = min(max(ws, 0), W); we = min(max(we, 0), W);
+  const bool empty = (he <= hs) || (we <= ws);
+  f32x4 m = empty ? f32x4{0, 0, 0, 0} : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  const bf16_t *fp = feat + (size_t)cb * pitch_f * 8 + h * 4;
+  for (int y = hs; y < he; ++y)
+    for (int x = ws; x < we; ++x) {
+      const u16x4 v = *reinterpret_cast<const u16x4 *>(fp + ((size_t)y * W + x) * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float f = bf2f(v[e]); m[e] = f > m[e] ? f : m[e]; }
+    }
+  u16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = f2bf(m[e]);
+  *reinterpret_cast<u16x4 *>(out + ((size_t)cb * pitch_o + ((size_t)n * PH + ph) * PW + pw) * 8 + h * 4) = o;
+}
+
+// average pool of the bf16 maps into the fp32 C8 matrix the (fp32) head GEMM reads
+__global__ void avgpool_c8i_bf16_to_c8_kernel(const bf16_t *__restrict__ in, int N, int Cb, int HW, size_t pitch, float inv, float *__restrict__ out,
+                                              int Mp) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)N * Cb * 2;
+  if (t >= total) return;
+  const int h = (int)(t & 1); size_t r = t >> 1;
+  const int n = (int)(r % N); const int cb = (int)(r / N);
+  const bf16_t *ip = in + ((size_t)cb * pitch + (size_t)n * HW) * 8 + h * 4;
+  f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < HW; ++i) {
+    const u16x4 v = *reinterpret_cast<const u16x4 *>(ip + (size_t)i * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sacc[e] += bf2f(v[e]);
+  }
+  *reinterpret_cast<f32x4 *>(out + ((size_t)cb * Mp + n) * 8 + h * 4) = sacc * inv;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // graph
 // ------------------------------------------------------------------------------------------------------------------------
 struct RnConv {
   int Cin = 0, Cout = 0, K = 0, stride = 1, pad = 0;
   float *wpk = nullptr, *bpk = nullptr;
   float *lin_w = nullptr, *lin_b = nullptr;  // 1x1 / stride 1 with Cin % 64 == 0: also packed for the tuned GEMM (linear_c8)
+  bf16_t *wpk16 = nullptr;                   // bf16 graph: [tap][nch2][CoutP][8]
 };
 struct RnBlock {
   std::vector<RnConv> convs;
@@ -268,6 +513,7 @@ struct ResNetGraph {
   std::vector<RnBlock> trunk;
   std::vector<std::vector<RnBlock>> heads;  // one layer4 copy per tower (1 for plain resnet.lua)
   int feat_c = 0, out_c = 0, pooled = 14, max_rois = 0;
+  bool bf16 = false;             // activations / conv weights in bf16 (fp32 accumulate); the cls / bbox head GEMM stays fp32
   float *img = nullptr;          // C8I image
   float *tb[4] = {nullptr, nullptr, nullptr, nullptr};  // trunk activations (rotating)
   float *hb[4] = {nullptr, nullptr, nullptr, nullptr};  // per-ROI head activations (rotating)
@@ -286,6 +532,21 @@ static int rn_alloc(ResNetGraph *g, float **p, size_t bytes) {
 }
 
 static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b) {
+  if (g->bf16) {
+    const int nch2 = round_up((c.Cin + 7) / 8, 2), CoutP = round_up(c.Cout, 128), KK = c.K * c.K;
+    const size_t total = (size_t)KK * nch2 * CoutP * 8;
+    float *w16 = nullptr;
+    int rc = rn_alloc(g, &w16, total * sizeof(bf16_t));
+    if (rc) return rc;
+    c.wpk16 = reinterpret_cast<bf16_t *>(w16);
+    rc = rn_alloc(g, &c.bpk, (size_t)CoutP * sizeof(float));
+    if (rc) return rc;
+    MPN_CHECK_HIP(hipMemset(c.bpk, 0, (size_t)CoutP * sizeof(float)));
+    if (d_b) MPN_CHECK_HIP(hipMemcpy(c.bpk, d_b, (size_t)c.Cout * sizeof(float), hipMemcpyDeviceToDevice));
+    hipLaunchKernelGGL(pack_conv_bf16_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, nullptr, d_w, c.Cin, c.Cout, KK, nch2, CoutP, c.wpk16);
+    MPN_CHECK_LAUNCH();
+    return MPN_OK;
+  }
   const int nch = (c.Cin + 7) / 8, CoutP = round_up(c.Cout, 128), KK = c.K * c.K;
   const size_t total = (size_t)KK * nch * CoutP * 8;
   int rc = rn_alloc(g, &c.wpk, total * sizeof(float));
@@ -308,6 +569,25 @@ static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b
 }
 
 static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int relu, hipStream_t s, ActI *o) {
+  if (c.wpk16) {  // bf16 graph
+    GConvArgsB b{};
+    b.in = reinterpret_cast<const bf16_t *>(in.p); b.wpk = c.wpk16; b.res = reinterpret_cast<const bf16_t *>(res); b.bpk = c.bpk;
+    b.out = reinterpret_cast<bf16_t *>(out);
+    b.B = in.B; b.H = in.H; b.W = in.W; b.nch2 = round_up((c.Cin + 7) / 8, 2);
+    b.CoutP = round_up(c.Cout, 128); b.Cb_out = (c.Cout + 7) / 8;
+    b.KH = b.KW = c.K; b.stride = c.stride; b.pad = c.pad;
+    b.OH = (in.H + 2 * c.pad - c.K) / c.stride + 1; b.OW = (in.W + 2 * c.pad - c.K) / c.stride + 1;
+    b.relu = relu;
+    MPN_CHECK_ARG(in.C == c.Cin && b.OH > 0 && b.OW > 0);
+    b.P = (long long)in.B * b.OH * b.OW;
+    *o = ActI{out, in.B, c.Cout, b.OH, b.OW};
+    b.pitch_in = in.pitch(); b.pitch_out = o->pitch();
+    dim3 grid((unsigned)((b.P + 127) / 128), (unsigned)(b.CoutP / 128));
+    if (b.nch2 % 8 == 0) hipLaunchKernelGGL((conv2d_c8i_bf16_kernel<4>), grid, dim3(256), 0, s, b);
+    else hipLaunchKernelGGL((conv2d_c8i_bf16_kernel<1>), grid, dim3(256), 0, s, b);
+    MPN_CHECK_LAUNCH();
+    return MPN_OK;
+  }
   GConvArgs a{};
   a.in = in.p; a.wpk = c.wpk; a.bpk = c.bpk; a.res = res; a.out = out;
   a.B = in.B; a.Cb_in = in.Cb(); a.H = in.H; a.W = in.W; a.nch = (c.Cin + 7) / 8;
@@ -368,6 +648,7 @@ int resnet_build(const mpn_resnet_weights *rw, int max_h, int max_w, int max_roi
   MPN_CHECK_ARG(rw->w && rw->cin && rw->cout && rw->ksize && rw->stride && rw->pad && rw->block_n_convs && rw->block_has_shortcut);
   ResNetGraph *g = new ResNetGraph();
   g->pooled = pooled; g->max_rois = max_rois;
+  g->bf16 = rw->bf16 != 0;
   int rc = MPN_OK;
 #define RTRY(x) do { rc = (x); if (rc != MPN_OK) { resnet_free(g); return rc; } } while (0)
   const int n_heads = rw->n_heads > 1 ? rw->n_heads : 1;
@@ -429,9 +710,10 @@ int resnet_build(const mpn_resnet_weights *rw, int max_h, int max_w, int max_roi
     g->out_c = hc;
   }
   g->tb_elems = te; g->hb_elems = he;
-  RTRY(rn_alloc(g, &g->img, c8i_elems(1, 8, max_h, max_w) * sizeof(float)));
-  for (int i = 0; i < 4; ++i) RTRY(rn_alloc(g, &g->tb[i], te * sizeof(float)));
-  for (int i = 0; i < 4; ++i) RTRY(rn_alloc(g, &g->hb[i], he * sizeof(float)));
+  const size_t esz = g->bf16 ? sizeof(bf16_t) : sizeof(float);
+  RTRY(rn_alloc(g, &g->img, c8i_elems(1, 16, max_h, max_w) * esz));
+  for (int i = 0; i < 4; ++i) { RTRY(rn_alloc(g, &g->tb[i], te * esz)); MPN_CHECK_HIP(hipMemset(g->tb[i], 0, te * esz)); }
+  for (int i = 0; i < 4; ++i) { RTRY(rn_alloc(g, &g->hb[i], he * esz)); MPN_CHECK_HIP(hipMemset(g->hb[i], 0, he * esz)); }  // pad planes must hold finite values
 #undef RTRY
   MPN_CHECK_HIP(hipDeviceSynchronize());
   *out = g;
@@ -453,8 +735,13 @@ int resnet_trunk_forward(ResNetGraph *g, const float *d_image, int H, int W, con
                          const double *std, int has_std, hipStream_t s) {
   MPN_CHECK_ARG(g && d_image && H > 0 && W > 0);
   const size_t plane = (size_t)H * W;
-  hipLaunchKernelGGL(image_transform_c8i_kernel, dim3((unsigned)cdiv_sz(plane, 256)), dim3(256), 0, s, d_image, H, W, swap[0], swap[1], swap[2], scale,
-                     mean[0], mean[1], mean[2], has_std ? std[0] : 1.0, has_std ? std[1] : 1.0, has_std ? std[2] : 1.0, has_std, g->img);
+  if (g->bf16)
+    hipLaunchKernelGGL(image_transform_c8i_bf16_kernel, dim3((unsigned)cdiv_sz(plane, 256)), dim3(256), 0, s, d_image, H, W, swap[0], swap[1], swap[2],
+                       scale, mean[0], mean[1], mean[2], has_std ? std[0] : 1.0, has_std ? std[1] : 1.0, has_std ? std[2] : 1.0, has_std,
+                       reinterpret_cast<bf16_t *>(g->img), (ActI{g->img, 1, 3, H, W}).pitch());
+  else
+    hipLaunchKernelGGL(image_transform_c8i_kernel, dim3((unsigned)cdiv_sz(plane, 256)), dim3(256), 0, s, d_image, H, W, swap[0], swap[1], swap[2], scale,
+                       mean[0], mean[1], mean[2], has_std ? std[0] : 1.0, has_std ? std[1] : 1.0, has_std ? std[2] : 1.0, has_std, g->img);
   MPN_CHECK_LAUNCH();
   ActI x{g->img, 1, 3, H, W}, y;
   int rc = rn_conv(g->conv1, x, g->tb[0], nullptr, 1, s, &y);
@@ -463,6 +750,10 @@ int resnet_trunk_forward(ResNetGraph *g, const float *d_image, int H, int W, con
   {
     const size_t total = (size_t)y.Cb() * OH * OW * 2;
     const ActI po{g->tb[1], 1, y.C, OH, OW};
+    if (g->bf16)
+      hipLaunchKernelGGL(maxpool2d_c8i_bf16_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, reinterpret_cast<const bf16_t *>(y.p), y.Cb(), 1,
+                         y.H, y.W, y.pitch(), 3, 2, 1, OH, OW, po.pitch(), reinterpret_cast<bf16_t *>(g->tb[1]));
+    else
     hipLaunchKernelGGL(maxpool2d_c8i_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, y.p, y.Cb(), 1, y.H, y.W, y.pitch(), 3, 2, 1, OH, OW,
                        po.pitch(), g->tb[1]);
     MPN_CHECK_LAUNCH();
@@ -484,6 +775,10 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
   {
     const size_t total = (size_t)N * Cb * PH * PH * 2;
     const ActI fa{g->feat, 1, g->feat_c, g->feat_h, g->feat_w}, pa{g->hb[0], N, g->feat_c, PH, PH};
+    if (g->bf16)
+      hipLaunchKernelGGL(roi_pool_c8i_bf16_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, reinterpret_cast<const bf16_t *>(g->feat), Cb, g->feat_h,
+                         g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale, reinterpret_cast<bf16_t *>(g->hb[0]), pa.pitch());
+    else
     hipLaunchKernelGGL(roi_pool_c8i_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, g->feat, Cb, g->feat_h, g->feat_w, fa.pitch(), d_rois, roi_stride,
                        N, PH, PH, spatial_scale, g->hb[0], pa.pitch());
     MPN_CHECK_LAUNCH();
@@ -495,6 +790,10 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
     cur = y;
   }
   const size_t total = (size_t)N * cur.Cb() * 2;
+  if (g->bf16)
+    hipLaunchKernelGGL(avgpool_c8i_bf16_to_c8_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, reinterpret_cast<const bf16_t *>(cur.p), N, cur.Cb(),
+                       cur.H * cur.W, cur.pitch(), 1.0f / (float)(cur.H * cur.W), d_feat_c8, Mp);
+  else
   hipLaunchKernelGGL(avgpool_c8i_to_c8_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, cur.p, N, cur.Cb(), cur.H * cur.W, cur.pitch(),
                      1.0f / (float)(cur.H * cur.W), d_feat_c8, Mp);
   MPN_CHECK_LAUNCH();

@@ -236,7 +236,7 @@ class FastRCNN(object):
 
     def __init__(self, params, cfg=VGG16_CFG, pooled=7, spatial_scale=1.0 / 16, transformer=None, max_h=600, max_w=1000,
                  max_rois=1000, nms_thresh=0.3, score_thresh=-1.5, top_k=100, num_iter=1, bbox_voting=False, bbox_vote_thresh=0.5,
-                 bbox_vote_score_pow=1.0, scale=None, max_size=None):
+                 bbox_vote_score_pow=1.0, scale=None, max_size=None, bf16=False):
         """scale / max_size: getImages' rescaling (ImageDetect.lua:34-43) on the device; None feeds images as they are."""
         _lib.require_gpu()
         lib = _lib.load()
@@ -303,6 +303,7 @@ class FastRCNN(object):
             rw.n_blocks = len(blocks)
             rw.block_n_convs, rw.block_has_shortcut = C.cast(a[7], C.POINTER(C.c_int)), C.cast(a[8], C.POINTER(C.c_int))
             rw.n_trunk_blocks = len(params["trunk_blocks"])
+            rw.bf16 = int(bool(bf16))
             if "head_towers" in params:
                 rw.n_heads, rw.n_integral = len(towers), params["n_integral"]
                 for t, rg in enumerate(params["head_regions"]):

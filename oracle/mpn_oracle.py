@@ -417,9 +417,18 @@ def mpnet_head(maps, rois, P, pooled=7, spatial_scale=1.0 / 16):
 
 
 # ---- ResNet Fast R-CNN (models/resnet.lua; fb.resnet.torch topology, BN folded into the convolutions) -----------------
-def conv2d(x, w, b, stride=1, pad=0, relu=False, residual=None):
-    """x [B,Cin,H,W], w [Cout,Cin,KH,KW] -> [B,Cout,OH,OW] (+ bias, + residual, ReLU)"""
+def bf16_round(x):
+    """fp32 -> nearest-even bf16 -> fp32 (what the bf16 ResNet graph stores; finite inputs)"""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    return ((u + np.uint32(0x7fff) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xffff0000)).view(np.float32)
+
+
+def conv2d(x, w, b, stride=1, pad=0, relu=False, residual=None, bf16=False):
+    """x [B,Cin,H,W], w [Cout,Cin,KH,KW] -> [B,Cout,OH,OW] (+ bias, + residual, ReLU).  bf16: weights rounded to bf16, fp32
+    accumulation / bias / residual / ReLU, output rounded to bf16 (inputs are expected to be bf16-representable already)."""
     x, w = _f32(x), _f32(w)
+    if bf16:
+        w = bf16_round(w)
     b = _f32(b) if b is not None else None
     B, Cin, H, W = x.shape
     Cout, _, KH, KW = w.shape
@@ -428,7 +437,7 @@ def conv2d(x, w, b, stride=1, pad=0, relu=False, residual=None):
     res = _f32(residual) if residual is not None else None
     lib().orc_conv2d(_p(x), B, Cin, H, W, _p(w), _p(b) if b is not None else None, Cout, KH, KW, stride, pad,
                      _p(res) if res is not None else None, int(relu), _p(out))
-    return out
+    return bf16_round(out) if bf16 else out
 
 
 def maxpool2d(x, k=3, stride=2, pad=1):
@@ -448,27 +457,30 @@ def avgpool_global(x):
     return out
 
 
-def resnet_block(x, blk):
+def resnet_block(x, blk, bf16=False):
     """one residual block; blk = dict(convs=[(w,b,stride,pad), ...], shortcut=(w,b,stride) or None).  ReLU after every
     conv but the last; the last conv adds the shortcut, then ReLU (fb.resnet.torch basicblock / bottleneck)."""
     sc = x
     if blk["shortcut"] is not None:
         w, b, st = blk["shortcut"]
-        sc = conv2d(x, w, b, stride=st, pad=0, relu=False)
+        sc = conv2d(x, w, b, stride=st, pad=0, relu=False, bf16=bf16)
     y = x
     n = len(blk["convs"])
     for i, (w, b, st, pd) in enumerate(blk["convs"]):
         last = i == n - 1
-        y = conv2d(y, w, b, stride=st, pad=pd, relu=True, residual=sc if last else None)
+        y = conv2d(y, w, b, stride=st, pad=pd, relu=True, residual=sc if last else None, bf16=bf16)
     return y
 
 
 def resnet_trunk(x, R):
     """net:get(1..7): conv1 7x7/2 (+BN folded) -> ReLU -> maxpool 3x3/2 pad 1 -> layer1..3.  x [3,H,W] -> [C3,H/16,W/16]"""
-    y = conv2d(x[None], R["conv1_w"], R["conv1_b"], stride=2, pad=3, relu=True)
+    bf = bool(R.get("bf16"))
+    if bf:
+        x = bf16_round(x)
+    y = conv2d(x[None], R["conv1_w"], R["conv1_b"], stride=2, pad=3, relu=True, bf16=bf)
     y = maxpool2d(y, 3, 2, 1)
     for blk in R["trunk_blocks"]:
-        y = resnet_block(y, blk)
+        y = resnet_block(y, blk, bf)
     return y[0]
 
 
@@ -481,7 +493,7 @@ def resnet_head(feat, rois, R, pooled=14, spatial_scale=1.0 / 16, chunk=None):
         r = rois[s0:s0 + chunk]
         y, _ = roi_pool(feat, r, pooled, pooled, spatial_scale)  # [n,C3,14,14]
         for blk in R["head_blocks"]:
-            y = resnet_block(y, blk)
+            y = resnet_block(y, blk, bool(R.get("bf16")))
         f = avgpool_global(y)
         cls.append(linear(f, R["cls_w"], R["cls_b"]))
         bb = linear(f, R["bbox_w"], R["bbox_b"])
@@ -521,7 +533,7 @@ def resnet_mpn_detect(im, boxes, R, transformer=IMAGENET, target=600, max_size=1
     for tw, rg in zip(R["head_towers"], R["head_regions"]):
         y, _ = roi_pool(feat, np.ascontiguousarray(fov[:, rg]), pooled, pooled, 1.0 / 16)
         for blk in tw:
-            y = resnet_block(y, blk)
+            y = resnet_block(y, blk, bool(R.get("bf16")))
         outs.append(avgpool_global(y))
     cat = np.concatenate(outs[:-1], 1)
     K, Cn = R["n_integral"], R["n_classes"]

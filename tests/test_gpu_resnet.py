@@ -101,3 +101,24 @@ def test_resnet_iterative_localisation_and_voting_run(dev):
     net.test_one_async(torch.from_numpy(im2).to(dev), torch.from_numpy(boxes2).to(dev))
     torch.cuda.synchronize()
     assert int(net._n_dets.item()) > 0
+
+
+@pytest.mark.parametrize("bt,blocks,width", [("bottleneck", [1, 1, 1, 1], 16), ("basic", [1, 1, 1, 2], 16), ("bottleneck", [1, 1, 1, 1], 64)])
+def test_resnet_bf16_vs_bf16_oracle_and_fp32(O, dev, bt, blocks, width):
+    """bf16 graph (bf16 activations / weights, fp32 accumulate): against the oracle run with the same roundings (weights, the
+    transformed image and every layer output rounded to bf16) the scores agree to bf16 accumulation-order noise; against
+    the fp32 oracle they agree to bf16 precision.  width 64 exercises the 64-channel-per-stage kernel variant."""
+    from multipathnet_amd import models
+    H, W, N, C = 97, 131, 37, 6
+    R = models.synthetic_resnet_params(depth=0, n_classes=C, base_width=width, blocks=blocks, block_type=bt, seed=23)
+    Rn = models.resnet_params_numpy(R)
+    im, boxes = _inputs(H, W, N, 6)
+    net = models.ResNetFRCNN(R, max_h=H, max_w=W, max_rois=64, top_k=20, bf16=True)
+    s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+    s = s.cpu().numpy()
+    Rb = dict(Rn, bf16=True)
+    sb, _, _, _ = O.resnet_detect(im, boxes, Rb, target=min(H, W), max_size=max(H, W))
+    sf, _, _, _ = O.resnet_detect(im, boxes, Rn, target=min(H, W), max_size=max(H, W))
+    assert np.abs(s - sb).max() < 3e-3          # same roundings: only fp32 summation order + rare 1-ulp bf16 flips differ
+    assert np.abs(s - sf).max() < 3e-2          # bf16 vs fp32 arithmetic
+    assert np.abs(s.sum(1) - 1).max() < 1e-5

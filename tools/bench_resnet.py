@@ -7,9 +7,10 @@ import bench
 from multipathnet_amd import models
 depth = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-mpn = len(sys.argv) > 3 and sys.argv[3] == "mpn"  # BASELINE configs[3]: MultiPathNet on the ResNet backbone (this library's extension)
+mpn = "mpn" in sys.argv[3:]
+bf16 = "bf16" in sys.argv[3:]  # BASELINE configs[3]: MultiPathNet on the ResNet backbone (this library's extension)
 R = models.synthetic_resnet_mpn_params(depth=depth, n_classes=81, n_integral=6, seed=557) if mpn else models.synthetic_resnet_params(depth=depth, n_classes=21, seed=557)
-net = models.ResNetFRCNN(R, max_h=600, max_w=1000, max_rois=N)
+net = models.ResNetFRCNN(R, max_h=600, max_w=1000, max_rois=N, bf16=bf16)
 im, boxes = bench.synthetic_inputs()
 dev = torch.device("cuda", 0)
 im, boxes = torch.from_numpy(im).to(dev), torch.from_numpy(boxes[:N]).to(dev)
@@ -45,8 +46,9 @@ flops = f_trunk + ft + N * fhead * (len(R["head_towers"]) if mpn else 1)
 net.set_profiling(True); net.get_profile(True)
 net.test_one_async(im, boxes); torch.cuda.synchronize()
 prof = net.get_profile(True)
-print(("ResNet-%d MultiPathNet (5 towers, K=6, 81 classes)" if mpn else "ResNet-%d Fast R-CNN") % depth + ", %d ROIs: %.2f ms/image  %.0f proposals/s  %.2f TFLOP/image  %.1f TFLOP/s (%.1f%% of fp32 MFMA peak); feature map %dx%d" % (
-    N, dt * 1e3, N / dt, flops / 1e12, flops / dt / 1e12, flops / dt / 157.3e12 * 100, fh_, fw_))
+peak = 2500e12 if bf16 else 157.3e12
+print(("ResNet-%d MultiPathNet (5 towers, K=6, 81 classes)" if mpn else "ResNet-%d Fast R-CNN") % depth + (" bf16" if bf16 else " fp32") + ", %d ROIs: %.2f ms/image  %.0f proposals/s  %.2f TFLOP/image  %.1f TFLOP/s (%.1f%% of the dtype's dense MFMA peak); feature map %dx%d" % (
+    N, dt * 1e3, N / dt, flops / 1e12, flops / dt / 1e12, flops / dt / peak * 100, fh_, fw_))
 for k, (ms, n) in prof.items():
     if n: print("  %-12s %8.3f ms (%d launch groups)%s" % (k, ms, n, {"conv_direct": "  = ResNet trunk", "fc6": "  = ROI pool + per-ROI layer4 + avgpool"}.get(k, "")))
 print("n dets", int(net._n_dets.item()))
