@@ -52,7 +52,7 @@ struct GConvArgs {
   float *out;
   int B, Cb_in, H, W, nch;
   size_t pitch_in, pitch_out;  // rows per channel-block plane
-  int CoutP, Cb_out, KH, KW, stride, pad, OH, OW, relu;
+  int CoutP, Cb_out, KH, KW, sh, sw, ph, pw, OH, OW, relu;
   long long P;  // B * OH * OW output pixels
 };
 
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void conv2d_c8i_kernel(GConvArgs a) {
   const int gb = gvalid ? (int)(gpix / OHW) : 0;
   const int grem = gvalid ? (int)(gpix - (long long)gb * OHW) : 0;
   const int goy = grem / a.OW, gox = grem - goy * a.OW;
-  const int iy0 = goy * a.stride - a.pad, ix0 = gox * a.stride - a.pad;
+  const int iy0 = goy * a.sh - a.ph, ix0 = gox * a.sw - a.pw;
   const size_t plane = a.pitch_in * 8;
   const float *in_b = a.in + (size_t)gb * a.H * a.W * 8 + sh * 4;
   const float *w_t = a.wpk + ((size_t)cout0 + srow) * 8 + sh * 4;
@@ -289,7 +289,7 @@ struct GConvArgsB {
   bf16_t *out;
   int B, H, W, nch2;
   size_t pitch_in, pitch_out;
-  int CoutP, Cb_out, KH, KW, stride, pad, OH, OW, relu;
+  int CoutP, Cb_out, KH, KW, sh, sw, ph, pw, OH, OW, relu;
   long long P;
 };
 
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void conv2d_c8i_bf16_kernel(GConvArgsB a) {
   const int gb = gvalid ? (int)(gpix / OHW) : 0;
   const int grem = gvalid ? (int)(gpix - (long long)gb * OHW) : 0;
   const int goy = grem / a.OW, gox = grem - goy * a.OW;
-  const int iy0 = goy * a.stride - a.pad, ix0 = gox * a.stride - a.pad;
+  const int iy0 = goy * a.sh - a.ph, ix0 = gox * a.sw - a.pw;
   const u32x4 *in_r = reinterpret_cast<const u32x4 *>(a.in) + (size_t)gb * a.H * a.W;   // record units
   const u32x4 *w_r = reinterpret_cast<const u32x4 *>(a.wpk) + (size_t)cout0 + srow;
 
@@ -498,7 +498,8 @@ __global__ void avgpool_c8i_bf16_to_c8_kernel(const bf16_t *__restrict__ in, int
 // graph
 // ------------------------------------------------------------------------------------------------------------------------
 struct RnConv {
-  int Cin = 0, Cout = 0, K = 0, stride = 1, pad = 0;
+  int Cin = 0, Cout = 0, K = 0, stride = 1, pad = 0;  // square form (ResNet); KH/KW/sh/sw/ph/pw below are what the kernels use
+  int KH = 0, KW = 0, sh = 1, sw = 1, ph = 0, pw = 0;
   float *wpk = nullptr, *bpk = nullptr;
   float *lin_w = nullptr, *lin_b = nullptr;  // 1x1 / stride 1 with Cin % 64 == 0: also packed for the tuned GEMM (linear_c8)
   bf16_t *wpk16 = nullptr;                   // bf16 graph: [tap][nch2][CoutP][8]
@@ -533,7 +534,7 @@ static int rn_alloc(ResNetGraph *g, float **p, size_t bytes) {
 
 static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b) {
   if (g->bf16) {
-    const int nch2 = round_up((c.Cin + 7) / 8, 2), CoutP = round_up(c.Cout, 128), KK = c.K * c.K;
+    const int nch2 = round_up((c.Cin + 7) / 8, 2), CoutP = round_up(c.Cout, 128), KK = c.KH * c.KW;
     const size_t total = (size_t)KK * nch2 * CoutP * 8;
     float *w16 = nullptr;
     int rc = rn_alloc(g, &w16, total * sizeof(bf16_t));
@@ -547,7 +548,7 @@ static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b
     MPN_CHECK_LAUNCH();
     return MPN_OK;
   }
-  const int nch = (c.Cin + 7) / 8, CoutP = round_up(c.Cout, 128), KK = c.K * c.K;
+  const int nch = (c.Cin + 7) / 8, CoutP = round_up(c.Cout, 128), KK = c.KH * c.KW;
   const size_t total = (size_t)KK * nch * CoutP * 8;
   int rc = rn_alloc(g, &c.wpk, total * sizeof(float));
   if (rc) return rc;
@@ -557,7 +558,7 @@ static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b
   hipLaunchKernelGGL(pack_conv_generic_kernel, dim3((unsigned)cdiv_sz(threads, 256)), dim3(256), 0, nullptr, d_w, d_b, c.Cin, c.Cout, KK, nch, CoutP,
                      c.wpk, c.bpk);
   MPN_CHECK_LAUNCH();
-  if (c.K == 1 && c.stride == 1 && c.pad == 0 && c.Cin % 64 == 0) {  // a pointwise convolution IS a GEMM over the C8I rows
+  if (c.KH == 1 && c.KW == 1 && c.sh == 1 && c.sw == 1 && c.ph == 0 && c.pw == 0 && c.Cin % 64 == 0) {  // a pointwise convolution IS a GEMM over the C8I rows
     rc = rn_alloc(g, &c.lin_w, lin_wpk_elems(c.Cin, c.Cout) * sizeof(float));
     if (rc) return rc;
     rc = rn_alloc(g, &c.lin_b, (size_t)lin_np(c.Cout) * sizeof(float));
@@ -575,8 +576,8 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
     b.out = reinterpret_cast<bf16_t *>(out);
     b.B = in.B; b.H = in.H; b.W = in.W; b.nch2 = round_up((c.Cin + 7) / 8, 2);
     b.CoutP = round_up(c.Cout, 128); b.Cb_out = (c.Cout + 7) / 8;
-    b.KH = b.KW = c.K; b.stride = c.stride; b.pad = c.pad;
-    b.OH = (in.H + 2 * c.pad - c.K) / c.stride + 1; b.OW = (in.W + 2 * c.pad - c.K) / c.stride + 1;
+    b.KH = c.KH; b.KW = c.KW; b.sh = c.sh; b.sw = c.sw; b.ph = c.ph; b.pw = c.pw;
+    b.OH = (in.H + 2 * c.ph - c.KH) / c.sh + 1; b.OW = (in.W + 2 * c.pw - c.KW) / c.sw + 1;
     b.relu = relu;
     MPN_CHECK_ARG(in.C == c.Cin && b.OH > 0 && b.OW > 0);
     b.P = (long long)in.B * b.OH * b.OW;
@@ -592,8 +593,8 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
   a.in = in.p; a.wpk = c.wpk; a.bpk = c.bpk; a.res = res; a.out = out;
   a.B = in.B; a.Cb_in = in.Cb(); a.H = in.H; a.W = in.W; a.nch = (c.Cin + 7) / 8;
   a.CoutP = round_up(c.Cout, 128); a.Cb_out = (c.Cout + 7) / 8;
-  a.KH = a.KW = c.K; a.stride = c.stride; a.pad = c.pad;
-  a.OH = (in.H + 2 * c.pad - c.K) / c.stride + 1; a.OW = (in.W + 2 * c.pad - c.K) / c.stride + 1;
+  a.KH = c.KH; a.KW = c.KW; a.sh = c.sh; a.sw = c.sw; a.ph = c.ph; a.pw = c.pw;
+  a.OH = (in.H + 2 * c.ph - c.KH) / c.sh + 1; a.OW = (in.W + 2 * c.pw - c.KW) / c.sw + 1;
   a.relu = relu;
   MPN_CHECK_ARG(in.C == c.Cin && a.OH > 0 && a.OW > 0);
   a.P = (long long)in.B * a.OH * a.OW;
@@ -639,8 +640,8 @@ static int rn_block(const RnBlock &blk, ActI x, float *const bufs[4], hipStream_
 }
 
 static void rn_shape(const RnConv &c, int &h, int &w) {
-  h = (h + 2 * c.pad - c.K) / c.stride + 1;
-  w = (w + 2 * c.pad - c.K) / c.stride + 1;
+  h = (h + 2 * c.ph - c.KH) / c.sh + 1;
+  w = (w + 2 * c.pw - c.KW) / c.sw + 1;
 }
 
 int resnet_build(const mpn_resnet_weights *rw, int max_h, int max_w, int max_rois, int pooled, ResNetGraph **out) {
@@ -660,6 +661,7 @@ int resnet_build(const mpn_resnet_weights *rw, int max_h, int max_w, int max_roi
   auto take = [&](RnConv &c) -> int {
     if (ci >= rw->n_convs) { set_error("mpn_resnet_create: block table needs more than %d convolutions", rw->n_convs); return MPN_EINVAL; }
     c.Cin = rw->cin[ci]; c.Cout = rw->cout[ci]; c.K = rw->ksize[ci]; c.stride = rw->stride[ci]; c.pad = rw->pad[ci];
+    c.KH = c.KW = c.K; c.sh = c.sw = c.stride; c.ph = c.pw = c.pad;
     if (!(c.Cin > 0 && c.Cout > 0 && c.K > 0 && c.stride > 0 && c.pad >= 0 && rw->w[ci])) { set_error("mpn_resnet_create: bad convolution %d", ci); return MPN_EINVAL; }
     int r = rn_pack(g, c, rw->w[ci], rw->b ? rw->b[ci] : nullptr);
     ++ci;
