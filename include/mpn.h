@@ -293,6 +293,32 @@ typedef struct mpn_resnet_weights {
 int mpn_resnet_create(const mpn_frcnn_config *cfg, const mpn_resnet_weights *rw, const float *d_cls_w, const float *d_cls_b,
                       const float *d_bbox_w, const float *d_bbox_b, mpn_frcnn **out);
 
+/* Branching conv graphs (models/inceptionv3.lua:27-43, BASELINE configs[4]): the trunk (net:get(1..25)) and the per-ROI
+ * classifier (net:get(26..30)) as two op lists over numbered tensors.  Tensor 0 of the trunk list is the transformed image
+ * (3 channels); tensor 0 of the head list is the ROI-pooled map (cfg->pooled_h x pooled_w, channels of `feat_tensor`); the head's
+ * `out_tensor` is averaged over its whole map (the graph's final SpatialAveragePooling + View) and feeds classAndBBoxLinear.
+ * An op reads ALL channels of `src` and writes `cout` (conv) / src's (pools) channels of `dst` starting at channel
+ * `dst_c_off` — an Inception module's DepthConcat is its branches writing side by side into one tensor (offsets and widths
+ * must be multiples of 8; of 16 with bf16).  BatchNorm folded into w / b by the caller (utils.BNtoFixed, inceptionv3.lua:23).
+ * The `.t7` (Moodstocks' conversion of Google's Inception-v3) is not in the tree: PARITY UNPINNED, structure from the public
+ * definition. */
+typedef struct mpn_graph_op {
+  int kind;               /* 0 = convolution (+ bias, ReLU if relu), 1 = max-pool (floor mode, padded cells never win),
+                             2 = average pool, count_include_pad (nn.SpatialAveragePooling's default: always / (kh*kw)) */
+  int src, dst, dst_c_off;
+  int cin, cout;          /* conv: weight shape [cout, cin, kh, kw]; pools: cin = channels of src */
+  int kh, kw, sh, sw, ph, pw;
+  int relu;
+  const float *w, *b;     /* conv only, device pointers */
+} mpn_graph_op;
+typedef struct mpn_graph_weights {
+  int n_trunk_ops;  const mpn_graph_op *trunk_ops;  int n_trunk_tensors;  const int *trunk_tensor_c;  int feat_tensor;
+  int n_head_ops;   const mpn_graph_op *head_ops;   int n_head_tensors;   const int *head_tensor_c;   int out_tensor;
+  int bf16;               /* as mpn_resnet_weights.bf16 */
+} mpn_graph_weights;
+int mpn_graph_create(const mpn_frcnn_config *cfg, const mpn_graph_weights *gw, const float *d_cls_w, const float *d_cls_b,
+                     const float *d_bbox_w, const float *d_bbox_b, mpn_frcnn **out);
+
 /* ImageDetect:detect on a scale-1 image (getImages' resample is the identity):
  * d_image [3,H,W] fp32 in [0,1]; d_boxes [N,4].  Outputs (all optional, device):
  *   d_scores [N,C] softmax, d_bbox [N,4C] decoded + clamped boxes.

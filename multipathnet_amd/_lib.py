@@ -53,6 +53,21 @@ class ResnetWeights(C.Structure):
     ]
 
 
+class GraphOp(C.Structure):
+    """mirror of mpn_graph_op (include/mpn.h)"""
+    _fields_ = [("kind", C.c_int), ("src", C.c_int), ("dst", C.c_int), ("dst_c_off", C.c_int), ("cin", C.c_int), ("cout", C.c_int),
+                ("kh", C.c_int), ("kw", C.c_int), ("sh", C.c_int), ("sw", C.c_int), ("ph", C.c_int), ("pw", C.c_int), ("relu", C.c_int),
+                ("w", f32p), ("b", f32p)]
+
+
+class GraphWeights(C.Structure):
+    """mirror of mpn_graph_weights (include/mpn.h)"""
+    _fields_ = [("n_trunk_ops", C.c_int), ("trunk_ops", C.POINTER(GraphOp)), ("n_trunk_tensors", C.c_int), ("trunk_tensor_c", C.POINTER(C.c_int)),
+                ("feat_tensor", C.c_int),
+                ("n_head_ops", C.c_int), ("head_ops", C.POINTER(GraphOp)), ("n_head_tensors", C.c_int), ("head_tensor_c", C.POINTER(C.c_int)),
+                ("out_tensor", C.c_int), ("bf16", C.c_int)]
+
+
 def lib_path():
     return _LIB_PATH
 

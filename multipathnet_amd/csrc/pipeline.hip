@@ -227,11 +227,12 @@ extern "C" void mpn_frcnn_destroy(mpn_frcnn *p) {
 static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w, const float *const *d_conv_b,
                        const float *d_fc6_w, const float *d_fc6_b, const float *d_fc7_w, const float *d_fc7_b,
                        const float *d_cls_w, const float *d_cls_b, const float *d_bbox_w, const float *d_bbox_b,
-                       const mpn_mpnet_weights *mw, mpn_frcnn **out, const mpn_resnet_weights *rw = nullptr) {
+                       const mpn_mpnet_weights *mw, mpn_frcnn **out, const mpn_resnet_weights *rw = nullptr, const mpn_graph_weights *gw = nullptr) {
   MPN_CHECK_ARG(cfg && d_cls_w && d_bbox_w && out);
-  MPN_CHECK_ARG(rw || (d_conv_w && d_conv_b));
-  MPN_CHECK_ARG(rw || mw || (d_fc6_w && d_fc7_w));
-  MPN_CHECK_ARG(rw || (cfg->n_conv > 0 && cfg->conv_cout && cfg->pool_after && cfg->fc_dim > 0));
+  const bool graph_net = rw || gw;  // the trunk / per-ROI stage live in a ResNetGraph object
+  MPN_CHECK_ARG(graph_net || (d_conv_w && d_conv_b));
+  MPN_CHECK_ARG(graph_net || mw || (d_fc6_w && d_fc7_w));
+  MPN_CHECK_ARG(graph_net || (cfg->n_conv > 0 && cfg->conv_cout && cfg->pool_after && cfg->fc_dim > 0));
   MPN_CHECK_ARG(cfg->pooled_h > 0 && cfg->pooled_w > 0 && cfg->n_classes > 1);
   MPN_CHECK_ARG(cfg->max_h > 0 && cfg->max_w > 0 && cfg->max_rois > 0 && cfg->max_rois <= MPN_NMS_MAX_BOXES);
   MPN_CHECK_ARG(cfg->top_k > 0);
@@ -239,7 +240,7 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
   p->cfg = *cfg;
   if (rw && rw->n_heads > 1) p->n_integral = rw->n_integral > 0 ? rw->n_integral : 1;
   if (mw) { p->is_mpnet = true; p->tap3 = mw->tap_conv3; p->tap4 = mw->tap_conv4; p->n_integral = mw->n_integral > 0 ? mw->n_integral : 1; }
-  const int n_conv = rw ? 0 : cfg->n_conv;
+  const int n_conv = graph_net ? 0 : cfg->n_conv;
   p->cfg.n_conv = n_conv;
   if (n_conv) { p->cout.assign(cfg->conv_cout, cfg->conv_cout + n_conv); p->pool_after.assign(cfg->pool_after, cfg->pool_after + n_conv); }
   p->cfg.conv_cout = p->cout.data();
@@ -279,12 +280,13 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
     p->conv.push_back(L);
   }
   p->feat_c = cin;
-  if (rw) {  // ResNet: the graph object owns the trunk / layer4 weights and activations; the cls + bbox heads read its pooled vector
-    TRY(resnet_build(rw, cfg->max_h, cfg->max_w, cfg->max_rois, cfg->pooled_h, &p->rn));
+  if (graph_net) {  // ResNet / op-list graph: the graph object owns the trunk and per-ROI weights and activations; the cls + bbox heads read its pooled vector
+    if (rw) TRY(resnet_build(rw, cfg->max_h, cfg->max_w, cfg->max_rois, cfg->pooled_h, &p->rn));
+    else TRY(graph_build(gw, cfg->max_h, cfg->max_w, cfg->max_rois, cfg->pooled_h, &p->rn));
     p->feat_c = resnet_feat_channels(p->rn);
   }
   // ---- head
-  const int PP = cfg->pooled_h * cfg->pooled_w, C = cfg->n_classes, F = rw ? resnet_out_channels(p->rn) : cfg->fc_dim;
+  const int PP = cfg->pooled_h * cfg->pooled_w, C = cfg->n_classes, F = graph_net ? resnet_out_channels(p->rn) : cfg->fc_dim;
   p->cfg.fc_dim = F;
   MPN_CHECK_ARG(p->feat_c % 8 == 0);
   p->K6 = p->feat_c * PP;
@@ -348,7 +350,7 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
     TRY(dev_alloc(p, &p->bbox_rm, M * 4 * C * sizeof(float), true));
     for (int t = 0; t < rw->n_heads; ++t) { MPN_CHECK_ARG(rw->head_region[t] >= 0 && rw->head_region[t] < 4); p->rn_region.push_back(rw->head_region[t]); }
   } else {
-  if (!rw) {
+  if (!graph_net) {
   TRY(dev_alloc(p, &p->w6, lin_wpk_elems(K6_32, F) * sizeof(float), false));
   TRY(dev_alloc(p, &p->b6, (size_t)lin_np(F) * sizeof(float), false));
   TRY(pack_linear_weights(d_fc6_w, d_fc6_b, p->K6, F, PP, p->w6, p->b6, nullptr));
@@ -369,7 +371,7 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
     TRY(dev_alloc(p, &p->bh, (size_t)lin_np(5 * C) * sizeof(float), false));
     TRY(pack_linear_weights(tmp_w, tmp_b, F, 5 * C, 1, p->wh, p->bh, nullptr));
   }
-  if (!rw) {
+  if (!graph_net) {
   TRY(dev_alloc(p, &p->x6, (size_t)(K6_32 / 8) * p->Mp * 8 * sizeof(float), true));
   TRY(dev_alloc(p, &p->y6, (size_t)(lin_np(F) / 8) * p->Mp * 8 * sizeof(float), true));
   }
@@ -766,6 +768,12 @@ extern "C" int mpn_resnet_create(const mpn_frcnn_config *cfg, const mpn_resnet_w
                                  const float *d_bbox_w, const float *d_bbox_b, mpn_frcnn **out) {
   MPN_CHECK_ARG(rw != nullptr);
   return create_impl(cfg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_cls_w, d_cls_b, d_bbox_w, d_bbox_b, nullptr, out, rw);
+}
+
+extern "C" int mpn_graph_create(const mpn_frcnn_config *cfg, const mpn_graph_weights *gw, const float *d_cls_w, const float *d_cls_b,
+                                const float *d_bbox_w, const float *d_bbox_b, mpn_frcnn **out) {
+  MPN_CHECK_ARG(gw != nullptr);
+  return create_impl(cfg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_cls_w, d_cls_b, d_bbox_w, d_bbox_b, nullptr, out, nullptr, gw);
 }
 
 extern "C" int mpn_frcnn_set_profiling(mpn_frcnn *p, int enable) {

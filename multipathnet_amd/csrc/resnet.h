@@ -11,12 +11,15 @@
 #include "dense.h"
 
 struct mpn_resnet_weights;
+struct mpn_graph_weights;
 
 namespace mpn {
 
 struct ResNetGraph;
 
 int resnet_build(const mpn_resnet_weights *rw, int max_h, int max_w, int max_rois, int pooled, ResNetGraph **out);
+// the same object driven by two op lists (branching graphs: Inception-v3)
+int graph_build(const mpn_graph_weights *gw, int max_h, int max_w, int max_rois, int pooled, ResNetGraph **out);
 void resnet_free(ResNetGraph *g);
 int resnet_feat_channels(const ResNetGraph *g);   // layer3 output channels (what the ROI pool reads)
 int resnet_out_channels(const ResNetGraph *g);    // layer4 output channels (what the cls / bbox heads read)

@@ -494,6 +494,44 @@ __global__ void avgpool_c8i_bf16_to_c8_kernel(const bf16_t *__restrict__ in, int
   *reinterpret_cast<f32x4 *>(out + ((size_t)cb * Mp + n) * 8 + h * 4) = sacc * inv;
 }
 
+// nn.SpatialAveragePooling(kw,kh,sw,sh,pw,ph), count_include_pad (torch's default): sum over the in-map cells of the window
+// in row-major order, divided by kh*kw regardless of how many cells lie in the padding.  T = float or bf16_t.
+template <typename T>
+__global__ void avgpool2d_c8i_kernel(const T *__restrict__ in, int Cb, int B, int H, int W, size_t pitch_in, int kh, int kw, int sh, int sw, int ph,
+                                     int pw, int OH, int OW, size_t pitch_out, T *__restrict__ out) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)Cb * B * OH * OW * 2;
+  if (t >= total) return;
+  const int h = (int)(t & 1); size_t r = t >> 1;
+  const int ox = (int)(r % OW); r /= OW;
+  const int oy = (int)(r % OH); r /= OH;
+  const int b = (int)(r % B); const size_t cb = r / B;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int ky = 0; ky < kh; ++ky)
+    for (int kx = 0; kx < kw; ++kx) {
+      const int iy = oy * sh + ky - ph, ix = ox * sw + kx - pw;
+      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+      const size_t off = (cb * pitch_in + ((size_t)b * H + iy) * W + ix) * 8 + h * 4;
+      if constexpr (sizeof(T) == 2) {
+        const u16x4 v = *reinterpret_cast<const u16x4 *>(in + off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += bf2f(v[e]);
+      } else {
+        acc += *reinterpret_cast<const f32x4 *>(in + off);
+      }
+    }
+  const float inv = 1.0f / (float)(kh * kw);
+  const size_t oo = (cb * pitch_out + ((size_t)b * OH + oy) * OW + ox) * 8 + h * 4;
+  if constexpr (sizeof(T) == 2) {
+    u16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[e] * inv);
+    *reinterpret_cast<u16x4 *>(out + oo) = o;
+  } else {
+    *reinterpret_cast<f32x4 *>(out + oo) = acc * inv;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 // graph
 // ------------------------------------------------------------------------------------------------------------------------
@@ -509,7 +547,14 @@ struct RnBlock {
   bool has_sc = false;
   RnConv sc;
 };
+struct GTensor { int C = 0, H = 0, W = 0; float *buf = nullptr; };
+struct GOp { int kind = 0, src = 0, dst = 0, dst_c_off = 0, kh = 1, kw = 1, sh = 1, sw = 1, ph = 0, pw = 0, relu = 0; RnConv conv; };
 struct ResNetGraph {
+  // op-list mode (graph_build): branching graphs; tensor 0 = image (trunk) / ROI-pooled map (head)
+  bool is_graph = false;
+  std::vector<GOp> g_trunk, g_head;
+  std::vector<GTensor> t_trunk, t_head;
+  int feat_tensor = 0, out_tensor = 0;
   RnConv conv1;
   std::vector<RnBlock> trunk;
   std::vector<std::vector<RnBlock>> heads;  // one layer4 copy per tower (1 for plain resnet.lua)
@@ -569,7 +614,7 @@ static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b
   return MPN_OK;
 }
 
-static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int relu, hipStream_t s, ActI *o) {
+static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int relu, hipStream_t s, ActI *o, bool allow_gemm = true) {
   if (c.wpk16) {  // bf16 graph
     GConvArgsB b{};
     b.in = reinterpret_cast<const bf16_t *>(in.p); b.wpk = c.wpk16; b.res = reinterpret_cast<const bf16_t *>(res); b.bpk = c.bpk;
@@ -600,7 +645,7 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
   a.P = (long long)in.B * a.OH * a.OW;
   *o = ActI{out, in.B, c.Cout, a.OH, a.OW};
   a.pitch_in = in.pitch(); a.pitch_out = o->pitch();
-  if (c.lin_w && linear_c8_is_direct((int)in.rows(), c.Cout, (int)in.pitch()))  // same rows in and out: the tuned GEMM, residual + ReLU fused
+  if (allow_gemm && c.lin_w && linear_c8_is_direct((int)in.rows(), c.Cout, (int)in.pitch()))  // same rows in and out: the tuned GEMM, residual + ReLU fused
     return linear_c8(in.p, (int)in.rows(), c.Cin, c.lin_w, c.lin_b, c.Cout, relu, out, nullptr, s, (int)in.pitch(), res);
   dim3 grid((unsigned)((a.P + 127) / 128), (unsigned)(a.CoutP / 128));
   if (a.nch % 4 == 0) hipLaunchKernelGGL((conv2d_c8i_kernel<4>), grid, dim3(256), 0, s, a);
@@ -733,6 +778,137 @@ int resnet_out_channels(const ResNetGraph *g) { return g->out_c; }
 int resnet_n_heads(const ResNetGraph *g) { return (int)g->heads.size(); }
 bool resnet_has_features(const ResNetGraph *g, int H, int W) { return g->feat && g->last_h == H && g->last_w == W; }
 
+// ---- op-list graphs ----------------------------------------------------------------------------------------------------
+static void gop_out_dims(const GOp &op, int h, int w, int &oh, int &ow) {
+  oh = (h + 2 * op.ph - op.kh) / op.sh + 1;
+  ow = (w + 2 * op.pw - op.kw) / op.sw + 1;
+}
+
+// propagate the spatial dims of one op list from tensor 0's; checks that concatenated writers agree
+static int graph_dims(const std::vector<GOp> &ops, std::vector<GTensor> &ts, int h0, int w0) {
+  for (auto &t : ts) t.H = t.W = 0;
+  ts[0].H = h0; ts[0].W = w0;
+  for (const GOp &op : ops) {
+    const GTensor &src = ts[op.src];
+    if (src.H <= 0) { set_error("graph: op reads tensor %d before it is written", op.src); return MPN_EINVAL; }
+    int oh, ow;
+    gop_out_dims(op, src.H, src.W, oh, ow);
+    if (oh <= 0 || ow <= 0) { set_error("graph: op on tensor %d (%dx%d) has an empty output", op.src, src.H, src.W); return MPN_EINVAL; }
+    GTensor &dst = ts[op.dst];
+    if (dst.H == 0) { dst.H = oh; dst.W = ow; }
+    else if (dst.H != oh || dst.W != ow) { set_error("graph: writers of tensor %d disagree on its size", op.dst); return MPN_EINVAL; }
+  }
+  return MPN_OK;
+}
+
+static int graph_parse(ResNetGraph *g, int n_ops, const mpn_graph_op *ops, int n_t, const int *tc, std::vector<GOp> &out, std::vector<GTensor> &ts) {
+  MPN_CHECK_ARG(n_ops > 0 && ops && n_t > 1 && tc);
+  ts.resize(n_t);
+  for (int i = 0; i < n_t; ++i) { ts[i].C = tc[i]; MPN_CHECK_ARG(tc[i] > 0); }
+  const int align = g->bf16 ? 16 : 8;
+  for (int i = 0; i < n_ops; ++i) {
+    const mpn_graph_op &o = ops[i];
+    MPN_CHECK_ARG(o.kind >= 0 && o.kind <= 2 && o.src >= 0 && o.src < n_t && o.dst > 0 && o.dst < n_t && o.src != o.dst);
+    MPN_CHECK_ARG(o.kh > 0 && o.kw > 0 && o.sh > 0 && o.sw > 0 && o.ph >= 0 && o.pw >= 0 && o.dst_c_off >= 0 && o.dst_c_off % align == 0);
+    GOp op;
+    op.kind = o.kind; op.src = o.src; op.dst = o.dst; op.dst_c_off = o.dst_c_off;
+    op.kh = o.kh; op.kw = o.kw; op.sh = o.sh; op.sw = o.sw; op.ph = o.ph; op.pw = o.pw; op.relu = o.relu;
+    const int wc = o.kind == 0 ? o.cout : ts[o.src].C;  // channels written
+    if (o.cin != ts[o.src].C || o.dst_c_off + wc > ts[o.dst].C || (o.dst_c_off + wc < ts[o.dst].C && wc % align != 0)) {
+      set_error("graph: op %d: channel mismatch (src %d has %d, writes %d at %d of %d)", i, o.src, ts[o.src].C, wc, o.dst_c_off, ts[o.dst].C);
+      return MPN_EINVAL;
+    }
+    if (o.kind == 0) {
+      MPN_CHECK_ARG(o.w && o.cout > 0);
+      RnConv &c = op.conv;
+      c.Cin = o.cin; c.Cout = o.cout; c.KH = o.kh; c.KW = o.kw; c.sh = o.sh; c.sw = o.sw; c.ph = o.ph; c.pw = o.pw;
+      c.K = o.kh; c.stride = o.sh; c.pad = o.ph;
+      int rc = rn_pack(g, c, o.w, o.b);
+      if (rc) return rc;
+    }
+    out.push_back(op);
+  }
+  return MPN_OK;
+}
+
+int graph_build(const mpn_graph_weights *gw, int max_h, int max_w, int max_rois, int pooled, ResNetGraph **out) {
+  MPN_CHECK_ARG(gw && out && gw->feat_tensor > 0 && gw->feat_tensor < gw->n_trunk_tensors && gw->out_tensor > 0 && gw->out_tensor < gw->n_head_tensors);
+  ResNetGraph *g = new ResNetGraph();
+  g->is_graph = true; g->pooled = pooled; g->max_rois = max_rois; g->bf16 = gw->bf16 != 0;
+  g->feat_tensor = gw->feat_tensor; g->out_tensor = gw->out_tensor;
+  int rc = graph_parse(g, gw->n_trunk_ops, gw->trunk_ops, gw->n_trunk_tensors, gw->trunk_tensor_c, g->g_trunk, g->t_trunk);
+  if (rc == MPN_OK) rc = graph_parse(g, gw->n_head_ops, gw->head_ops, gw->n_head_tensors, gw->head_tensor_c, g->g_head, g->t_head);
+  if (rc == MPN_OK && (g->t_trunk[0].C != 3 || g->t_head[0].C != g->t_trunk[g->feat_tensor].C)) {
+    set_error("graph: tensor 0 must be the 3-channel image (trunk) / carry the feature tensor's channels (head)");
+    rc = MPN_EINVAL;
+  }
+  if (rc == MPN_OK) rc = graph_dims(g->g_trunk, g->t_trunk, max_h, max_w);
+  if (rc == MPN_OK) rc = graph_dims(g->g_head, g->t_head, pooled, pooled);
+  const size_t esz = g->bf16 ? sizeof(bf16_t) : sizeof(float);
+  for (size_t i = 0; rc == MPN_OK && i < g->t_trunk.size(); ++i) {
+    GTensor &t = g->t_trunk[i];
+    if (t.H == 0) continue;  // never written
+    const size_t bytes = c8i_elems(1, i == 0 ? 16 : t.C, t.H, t.W) * esz;
+    rc = rn_alloc(g, &t.buf, bytes);
+    if (rc == MPN_OK && hipMemset(t.buf, 0, bytes) != hipSuccess) rc = MPN_EHIP;
+  }
+  for (size_t i = 0; rc == MPN_OK && i < g->t_head.size(); ++i) {
+    GTensor &t = g->t_head[i];
+    if (t.H == 0) continue;
+    const size_t bytes = c8i_elems(max_rois, t.C, t.H, t.W) * esz;
+    rc = rn_alloc(g, &t.buf, bytes);
+    if (rc == MPN_OK && hipMemset(t.buf, 0, bytes) != hipSuccess) rc = MPN_EHIP;
+  }
+  if (rc != MPN_OK) { resnet_free(g); return rc; }
+  g->feat_c = g->t_trunk[g->feat_tensor].C;
+  g->out_c = g->t_head[g->out_tensor].C;
+  g->img = g->t_trunk[0].buf;
+  g->heads.resize(1);
+  MPN_CHECK_HIP(hipDeviceSynchronize());
+  *out = g;
+  return MPN_OK;
+}
+
+// run one op list on a batch of B maps; dims must have been propagated (graph_dims)
+static int graph_run(ResNetGraph *g, const std::vector<GOp> &ops, std::vector<GTensor> &ts, int B, hipStream_t s) {
+  const size_t esz = g->bf16 ? sizeof(bf16_t) : sizeof(float);
+  for (const GOp &op : ops) {
+    const GTensor &src = ts[op.src];
+    GTensor &dst = ts[op.dst];
+    const ActI in{src.buf, B, src.C, src.H, src.W};
+    const ActI od{dst.buf, B, dst.C, dst.H, dst.W};
+    char *outp = reinterpret_cast<char *>(dst.buf) + (size_t)(op.dst_c_off / 8) * od.pitch() * 8 * esz;  // plane offset = the concat
+    if (op.kind == 0) {
+      ActI o;
+      // the GEMM writes whole 128-channel panels: only when this op owns them (no neighbouring branch inside the panel)
+      const bool own = op.conv.Cout % 128 == 0 || (op.dst_c_off == 0 && op.conv.Cout == dst.C);
+      int rc = rn_conv(op.conv, in, reinterpret_cast<float *>(outp), nullptr, op.relu, s, &o, own);
+      if (rc) return rc;
+    } else {
+      const size_t total = (size_t)in.Cb() * B * dst.H * dst.W * 2;
+      const dim3 grid((unsigned)cdiv_sz(total, 256));
+      if (op.kind == 1) {
+        MPN_CHECK_ARG(op.kh == op.kw && op.sh == op.sw && op.ph == op.pw);
+        if (g->bf16)
+          hipLaunchKernelGGL(maxpool2d_c8i_bf16_kernel, grid, dim3(256), 0, s, reinterpret_cast<const bf16_t *>(src.buf), in.Cb(), B, src.H, src.W, in.pitch(),
+                             op.kh, op.sh, op.ph, dst.H, dst.W, od.pitch(), reinterpret_cast<bf16_t *>(outp));
+        else
+          hipLaunchKernelGGL(maxpool2d_c8i_kernel, grid, dim3(256), 0, s, src.buf, in.Cb(), B, src.H, src.W, in.pitch(), op.kh, op.sh, op.ph, dst.H, dst.W,
+                             od.pitch(), reinterpret_cast<float *>(outp));
+      } else {
+        if (g->bf16)
+          hipLaunchKernelGGL((avgpool2d_c8i_kernel<bf16_t>), grid, dim3(256), 0, s, reinterpret_cast<const bf16_t *>(src.buf), in.Cb(), B, src.H, src.W,
+                             in.pitch(), op.kh, op.kw, op.sh, op.sw, op.ph, op.pw, dst.H, dst.W, od.pitch(), reinterpret_cast<bf16_t *>(outp));
+        else
+          hipLaunchKernelGGL((avgpool2d_c8i_kernel<float>), grid, dim3(256), 0, s, src.buf, in.Cb(), B, src.H, src.W, in.pitch(), op.kh, op.kw, op.sh, op.sw,
+                             op.ph, op.pw, dst.H, dst.W, od.pitch(), reinterpret_cast<float *>(outp));
+      }
+      MPN_CHECK_LAUNCH();
+    }
+  }
+  return MPN_OK;
+}
+
 int resnet_trunk_forward(ResNetGraph *g, const float *d_image, int H, int W, const int *swap, double scale, const double *mean,
                          const double *std, int has_std, hipStream_t s) {
   MPN_CHECK_ARG(g && d_image && H > 0 && W > 0);
@@ -745,6 +921,14 @@ int resnet_trunk_forward(ResNetGraph *g, const float *d_image, int H, int W, con
     hipLaunchKernelGGL(image_transform_c8i_kernel, dim3((unsigned)cdiv_sz(plane, 256)), dim3(256), 0, s, d_image, H, W, swap[0], swap[1], swap[2], scale,
                        mean[0], mean[1], mean[2], has_std ? std[0] : 1.0, has_std ? std[1] : 1.0, has_std ? std[2] : 1.0, has_std, g->img);
   MPN_CHECK_LAUNCH();
+  if (g->is_graph) {
+    int rc = graph_dims(g->g_trunk, g->t_trunk, H, W);
+    if (rc == MPN_OK) rc = graph_run(g, g->g_trunk, g->t_trunk, 1, s);
+    if (rc) return rc;
+    const GTensor &f = g->t_trunk[g->feat_tensor];
+    g->feat = f.buf; g->feat_h = f.H; g->feat_w = f.W; g->last_h = H; g->last_w = W;
+    return MPN_OK;
+  }
   ActI x{g->img, 1, 3, H, W}, y;
   int rc = rn_conv(g->conv1, x, g->tb[0], nullptr, 1, s, &y);
   if (rc) return rc;
@@ -774,18 +958,26 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
                         hipStream_t s) {
   MPN_CHECK_ARG(g && g->feat && d_rois && d_feat_c8 && N > 0 && N <= g->max_rois && head >= 0 && head < (int)g->heads.size());
   const int Cb = (g->feat_c + 7) / 8, PH = g->pooled;
+  float *const pool_dst = g->is_graph ? g->t_head[0].buf : g->hb[0];
   {
     const size_t total = (size_t)N * Cb * PH * PH * 2;
-    const ActI fa{g->feat, 1, g->feat_c, g->feat_h, g->feat_w}, pa{g->hb[0], N, g->feat_c, PH, PH};
+    const ActI fa{g->feat, 1, g->feat_c, g->feat_h, g->feat_w}, pa{pool_dst, N, g->feat_c, PH, PH};
     if (g->bf16)
       hipLaunchKernelGGL(roi_pool_c8i_bf16_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, reinterpret_cast<const bf16_t *>(g->feat), Cb, g->feat_h,
-                         g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale, reinterpret_cast<bf16_t *>(g->hb[0]), pa.pitch());
+                         g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale, reinterpret_cast<bf16_t *>(pool_dst), pa.pitch());
     else
     hipLaunchKernelGGL(roi_pool_c8i_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, g->feat, Cb, g->feat_h, g->feat_w, fa.pitch(), d_rois, roi_stride,
-                       N, PH, PH, spatial_scale, g->hb[0], pa.pitch());
+                       N, PH, PH, spatial_scale, pool_dst, pa.pitch());
     MPN_CHECK_LAUNCH();
   }
-  ActI cur{g->hb[0], N, g->feat_c, PH, PH}, y;
+  ActI cur{pool_dst, N, g->feat_c, PH, PH}, y;
+  if (g->is_graph) {
+    int rc = graph_dims(g->g_head, g->t_head, PH, PH);
+    if (rc == MPN_OK) rc = graph_run(g, g->g_head, g->t_head, N, s);
+    if (rc) return rc;
+    const GTensor &o = g->t_head[g->out_tensor];
+    cur = ActI{o.buf, N, o.C, o.H, o.W};
+  } else
   for (auto &blk : g->heads[head]) {
     int rc = rn_block(blk, cur, g->hb, s, &y);
     if (rc) return rc;

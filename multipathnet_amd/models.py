@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import FrcnnConfig, MpnetWeights, ResnetWeights, check, f32p
+from ._lib import FrcnnConfig, GraphOp, GraphWeights, MpnetWeights, ResnetWeights, check, f32p
 from .nn import _f, _i, _stream
 
 VGG16_CFG = [64, 64, "P", 128, 128, "P", 256, 256, 256, "P", 512, 512, 512, "P", 512, 512, 512]  # vgg.lua:14-27, no pool5
@@ -178,6 +178,148 @@ def ResNetFRCNN(params, **kw):
     return FastRCNN(params, **kw)
 
 
+# ---- Inception-v3 (models/inceptionv3.lua:27-43; the public Inception-v3 definition, BN folded) as two op lists ------------------
+class _GraphBuilder(object):
+    """builds an op list over numbered tensors; kinds: 0 conv(+ReLU), 1 max-pool, 2 average pool (count_include_pad)"""
+
+    def __init__(self, c0, gen, width=1.0):
+        self.ops, self.tc, self.g, self.width = [], [c0], gen, width
+
+    def ch(self, c):  # channel counts scale with `width`, kept multiples of 16 (test-size networks)
+        return c if self.width == 1.0 else max(16, int(round(c * self.width / 16.0)) * 16)
+
+    def tensor(self, c):
+        self.tc.append(c)
+        return len(self.tc) - 1
+
+    def conv(self, src, cout, k, s=1, p=0, dst=None, off=0, damp=1.0):
+        kh, kw = (k, k) if isinstance(k, int) else k
+        ph, pw = (p, p) if isinstance(p, int) else p
+        cin = self.tc[src]
+        if dst is None:
+            dst = self.tensor(cout)
+        w = torch.randn(cout, cin, kh, kw, generator=self.g) * ((2.0 / (cin * kh * kw)) ** 0.5 * damp)
+        b = torch.randn(cout, generator=self.g) * 0.01
+        self.ops.append(dict(kind=0, src=src, dst=dst, off=off, cin=cin, cout=cout, kh=kh, kw=kw, sh=s, sw=s, ph=ph, pw=pw, relu=1, w=w, b=b))
+        return dst
+
+    def pool(self, kind, src, k, s, p, dst=None, off=0):
+        c = self.tc[src]
+        if dst is None:
+            dst = self.tensor(c)
+        self.ops.append(dict(kind=kind, src=src, dst=dst, off=off, cin=c, cout=c, kh=k, kw=k, sh=s, sw=s, ph=p, pw=p, relu=0, w=None, b=None))
+        return dst
+
+    # Inception modules: every branch's last op writes into its slice of the module's output tensor (DepthConcat)
+    def inception_a(self, x, pf):
+        c = self.ch
+        out = self.tensor(c(64) + c(64) + c(96) + c(pf)); o = 0
+        self.conv(x, c(64), 1, dst=out, off=o); o += c(64)
+        t = self.conv(x, c(48), 1); self.conv(t, c(64), 5, p=2, dst=out, off=o); o += c(64)
+        t = self.conv(x, c(64), 1); t = self.conv(t, c(96), 3, p=1); self.conv(t, c(96), 3, p=1, dst=out, off=o); o += c(96)
+        t = self.pool(2, x, 3, 1, 1); self.conv(t, c(pf), 1, dst=out, off=o)
+        return out
+
+    def inception_b(self, x):
+        c = self.ch
+        cin = self.tc[x]
+        out = self.tensor(c(384) + c(96) + cin); o = 0
+        self.conv(x, c(384), 3, s=2, dst=out, off=o); o += c(384)
+        t = self.conv(x, c(64), 1); t = self.conv(t, c(96), 3, p=1); self.conv(t, c(96), 3, s=2, dst=out, off=o); o += c(96)
+        self.pool(1, x, 3, 2, 0, dst=out, off=o)
+        return out
+
+    def inception_c(self, x, c7):
+        c = self.ch
+        c7 = c(c7)
+        out = self.tensor(4 * c(192)); o = 0
+        self.conv(x, c(192), 1, dst=out, off=o); o += c(192)
+        t = self.conv(x, c7, 1); t = self.conv(t, c7, (1, 7), p=(0, 3)); self.conv(t, c(192), (7, 1), p=(3, 0), dst=out, off=o); o += c(192)
+        t = self.conv(x, c7, 1); t = self.conv(t, c7, (7, 1), p=(3, 0)); t = self.conv(t, c7, (1, 7), p=(0, 3))
+        t = self.conv(t, c7, (7, 1), p=(3, 0)); self.conv(t, c(192), (1, 7), p=(0, 3), dst=out, off=o); o += c(192)
+        t = self.pool(2, x, 3, 1, 1); self.conv(t, c(192), 1, dst=out, off=o)
+        return out
+
+    def inception_d(self, x):
+        c = self.ch
+        cin = self.tc[x]
+        out = self.tensor(c(320) + c(192) + cin); o = 0
+        t = self.conv(x, c(192), 1); self.conv(t, c(320), 3, s=2, dst=out, off=o); o += c(320)
+        t = self.conv(x, c(192), 1); t = self.conv(t, c(192), (1, 7), p=(0, 3)); t = self.conv(t, c(192), (7, 1), p=(3, 0))
+        self.conv(t, c(192), 3, s=2, dst=out, off=o); o += c(192)
+        self.pool(1, x, 3, 2, 0, dst=out, off=o)
+        return out
+
+    def inception_e(self, x):
+        c = self.ch
+        out = self.tensor(c(320) + 4 * c(384) + c(192)); o = 0
+        self.conv(x, c(320), 1, dst=out, off=o, damp=0.7); o += c(320)
+        t = self.conv(x, c(384), 1)
+        self.conv(t, c(384), (1, 3), p=(0, 1), dst=out, off=o); o += c(384)
+        self.conv(t, c(384), (3, 1), p=(1, 0), dst=out, off=o); o += c(384)
+        t = self.conv(x, c(448), 1); t = self.conv(t, c(384), 3, p=1)
+        self.conv(t, c(384), (1, 3), p=(0, 1), dst=out, off=o); o += c(384)
+        self.conv(t, c(384), (3, 1), p=(1, 0), dst=out, off=o); o += c(384)
+        t = self.pool(2, x, 3, 1, 1); self.conv(t, c(192), 1, dst=out, off=o)
+        return out
+
+
+def synthetic_inception_v3_params(n_classes=21, seed=557, width=1.0, bbox_norm=True):
+    """Inception-v3 Fast R-CNN (inceptionv3.lua:27-43) as op lists: trunk = stem + Mixed_5b..6e (net:get(1..25), the 17x17 stage
+    at stride 299/17), head = Mixed_7a..7c + the final average pool (net:get(26..30)); ROIPooling(17,17) at 17/299.
+    BN folded, He-scaled random weights; `width` < 1 scales every channel count (test-size networks).  The reference's `.t7`
+    is absent: this is the public Inception-v3 structure (PARITY UNPINNED)."""
+    g = torch.Generator().manual_seed(seed)
+    tb = _GraphBuilder(3, g, width)
+    c = tb.ch
+    x = tb.conv(0, c(32), 3, s=2)
+    x = tb.conv(x, c(32), 3)
+    x = tb.conv(x, c(64), 3, p=1)
+    x = tb.pool(1, x, 3, 2, 0)
+    x = tb.conv(x, c(80), 1)
+    x = tb.conv(x, c(192), 3)
+    x = tb.pool(1, x, 3, 2, 0)
+    x = tb.inception_a(x, 32)
+    x = tb.inception_a(x, 64)
+    x = tb.inception_a(x, 64)
+    x = tb.inception_b(x)
+    for c7 in (128, 160, 160, 192):
+        x = tb.inception_c(x, c7)
+    feat = x
+    hb = _GraphBuilder(tb.tc[feat], g, width)
+    y = hb.inception_d(0)
+    y = hb.inception_e(y)
+    y = hb.inception_e(y)
+    out_c = hb.tc[y]
+    G = dict(trunk_ops=tb.ops, trunk_tensor_c=tb.tc, feat_tensor=feat, head_ops=hb.ops, head_tensor_c=hb.tc, out_tensor=y)
+    G["cls_w"] = torch.randn(n_classes, out_c, generator=g) * 0.01
+    G["cls_b"] = torch.zeros(n_classes)
+    G["bbox_w"] = torch.randn(4 * n_classes, out_c, generator=g) * 0.001
+    G["bbox_b"] = torch.zeros(4 * n_classes)
+    G["bbox_mean"], G["bbox_std"] = ([0.0, 0.0, 0.0, 0.0], [0.1, 0.1, 0.2, 0.2]) if bbox_norm else (None, None)
+    return G
+
+
+INCEPTION_TRANSFORMER = dict(mean=(1.0, 1.0, 1.0), std=None, scale=2.0, swap=(0, 1, 2))  # fbcoco.ImageTransformer({1,1,1},nil,2), inceptionv3.lua:52
+
+
+def graph_params_numpy(G):
+    n = lambda t: None if t is None else t.detach().cpu().numpy()
+    cp = lambda ops: [dict(o, w=n(o["w"]), b=n(o["b"])) for o in ops]
+    out = dict(G, trunk_ops=cp(G["trunk_ops"]), head_ops=cp(G["head_ops"]))
+    for k in ("cls_w", "cls_b", "bbox_w", "bbox_b"):
+        out[k] = n(G[k])
+    return out
+
+
+def InceptionFRCNN(params, **kw):
+    """models/inceptionv3.lua graph as one device pipeline: ROIPooling(17,17) at 17/299, ImageTransformer({1,1,1},nil,2)"""
+    kw.setdefault("pooled", 17)
+    kw.setdefault("spatial_scale", 17.0 / 299.0)
+    kw.setdefault("transformer", INCEPTION_TRANSFORMER)
+    return FastRCNN(params, **kw)
+
+
 # models/multipathnet.lua:78-111: four foveal towers (region i; conv4 if i<=3, conv3 if i==1) + the "het" tower
 # (region 2, all three maps) whose output feeds the box regressor.  Regions are 0-based here.
 MPN_TOWERS = [dict(region=0, use4=1, use3=1), dict(region=1, use4=1, use3=0), dict(region=2, use4=1, use3=0),
@@ -241,10 +383,11 @@ class FastRCNN(object):
         _lib.require_gpu()
         lib = _lib.load()
         self.is_resnet = "trunk_blocks" in params
-        cout, pool = ([], []) if self.is_resnet else cfg_layers(cfg)
+        self.is_graph = "trunk_ops" in params
+        cout, pool = ([], []) if (self.is_resnet or self.is_graph) else cfg_layers(cfg)
         self.is_mpnet = "towers" in params
         self.n_classes = params["n_classes"] if (self.is_mpnet or "head_towers" in params) else params["cls_w"].shape[0]
-        if self.is_resnet:
+        if self.is_resnet or self.is_graph:
             self.fc_dim = params["bbox_w"].shape[1]
         else:
             self.fc_dim = params["towers"][0]["fc7_w"].shape[0] if self.is_mpnet else params["fc7_w"].shape[0]
@@ -279,6 +422,35 @@ class FastRCNN(object):
         dev = torch.device("cuda", torch.cuda.current_device())
         d = lambda t: t.to(dev, torch.float32).contiguous()
         self._h = C.c_void_p()
+        if self.is_graph:
+            keep = []
+
+            def mk(ops):
+                arr = (GraphOp * len(ops))()
+                for i, o in enumerate(ops):
+                    a = arr[i]
+                    a.kind, a.src, a.dst, a.dst_c_off, a.cin, a.cout = o["kind"], o["src"], o["dst"], o["off"], o["cin"], o["cout"]
+                    a.kh, a.kw, a.sh, a.sw, a.ph, a.pw, a.relu = o["kh"], o["kw"], o["sh"], o["sw"], o["ph"], o["pw"], o["relu"]
+                    if o["kind"] == 0:
+                        wd, bd = d(o["w"]), d(o["b"])
+                        keep.extend([wd, bd])
+                        a.w, a.b = _f(wd), _f(bd)
+                return arr
+
+            gw = GraphWeights()
+            self._g_arrays = [mk(params["trunk_ops"]), mk(params["head_ops"]), (C.c_int * len(params["trunk_tensor_c"]))(*params["trunk_tensor_c"]),
+                              (C.c_int * len(params["head_tensor_c"]))(*params["head_tensor_c"])]
+            ga = self._g_arrays
+            gw.n_trunk_ops, gw.trunk_ops = len(params["trunk_ops"]), C.cast(ga[0], C.POINTER(GraphOp))
+            gw.n_head_ops, gw.head_ops = len(params["head_ops"]), C.cast(ga[1], C.POINTER(GraphOp))
+            gw.n_trunk_tensors, gw.trunk_tensor_c = len(params["trunk_tensor_c"]), C.cast(ga[2], C.POINTER(C.c_int))
+            gw.n_head_tensors, gw.head_tensor_c = len(params["head_tensor_c"]), C.cast(ga[3], C.POINTER(C.c_int))
+            gw.feat_tensor, gw.out_tensor, gw.bf16 = params["feat_tensor"], params["out_tensor"], int(bool(bf16))
+            heads = [d(params[k]) for k in ("cls_w", "cls_b", "bbox_w", "bbox_b")]
+            check(lib.mpn_graph_create(C.byref(c), C.byref(gw), *[_f(t) for t in heads], C.byref(self._h)), "mpn_graph_create")
+            torch.cuda.synchronize()
+            self._finish_init(lib, dev, top_k)
+            return
         if self.is_resnet:
             convs, nconv, hassc = [], [], []  # execution order: conv1, then per block its convolutions (+ shortcut)
             convs.append((params["conv1_w"], params["conv1_b"], 2, 3))

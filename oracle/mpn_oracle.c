@@ -601,3 +601,60 @@ void orc_avgpool_global(const float *in, int BC, int H, int W, float *out) {
     out[c] = sacc * inv;
   }
 }
+
+/* ---- branching graphs (models/inceptionv3.lua:27-43): asymmetric kernels and count_include_pad average pooling -------------- */
+void orc_conv2d_rect(const float *in, int B, int Cin, int H, int W, const float *w, const float *bias, int Cout, int KH, int KW, int sh,
+                     int sw, int ph, int pw, int relu, float *out) {
+  const int OH = (H + 2 * ph - KH) / sh + 1, OW = (W + 2 * pw - KW) / sw + 1;
+  const size_t oplane = (size_t)OH * OW, iplane = (size_t)H * W;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+  for (int b = 0; b < B; ++b)
+    for (int co = 0; co < Cout; ++co) {
+      float *o = out + ((size_t)b * Cout + co) * oplane;
+      memset(o, 0, sizeof(float) * oplane);
+      for (int ci = 0; ci < Cin; ++ci) {
+        const float *ip = in + ((size_t)b * Cin + ci) * iplane;
+        for (int ky = 0; ky < KH; ++ky)
+          for (int kx = 0; kx < KW; ++kx) {
+            const float wv = w[(((size_t)co * Cin + ci) * KH + ky) * KW + kx];
+            for (int oy = 0; oy < OH; ++oy) {
+              const int iy = oy * sh + ky - ph;
+              if (iy < 0 || iy >= H) continue;
+              const float *irow = ip + (size_t)iy * W;
+              float *orow = o + (size_t)oy * OW;
+              for (int ox = 0; ox < OW; ++ox) {
+                const int ix = ox * sw + kx - pw;
+                if (ix >= 0 && ix < W) orow[ox] += wv * irow[ix];
+              }
+            }
+          }
+      }
+      const float bv = bias ? bias[co] : 0.0f;
+      for (size_t i = 0; i < oplane; ++i) {
+        const float v = o[i] + bv;
+        o[i] = (relu && v < 0.0f) ? 0.0f : v;
+      }
+    }
+}
+
+/* nn.SpatialAveragePooling(k,k,s,s,p,p) with count_include_pad = true (torch's default): in-map cells summed in row-major
+ * order, divided by k*k whatever the window's overlap with the padding. */
+void orc_avgpool2d(const float *in, int BC, int H, int W, int k, int stride, int pad, float *out) {
+  const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+  const float inv = 1.0f / (float)(k * k);
+#pragma omp parallel for
+  for (int c = 0; c < BC; ++c) {
+    const float *ip = in + (size_t)c * H * W;
+    float *op = out + (size_t)c * OH * OW;
+    for (int oy = 0; oy < OH; ++oy)
+      for (int ox = 0; ox < OW; ++ox) {
+        float sacc = 0.0f;
+        for (int ky = 0; ky < k; ++ky)
+          for (int kx = 0; kx < k; ++kx) {
+            const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) sacc += ip[(size_t)iy * W + ix];
+          }
+        op[(size_t)oy * OW + ox] = sacc * inv;
+      }
+  }
+}

@@ -147,6 +147,7 @@ def bbox_vote(nms_boxes, scored_boxes, thr):
 
 
 ROSS = dict(mean=(102.9801, 115.9465, 122.7717), std=None, scale=255.0, swap=(2, 1, 0))  # model_utils.lua:138-140
+INCEPTION = dict(mean=(1.0, 1.0, 1.0), std=None, scale=2.0, swap=(0, 1, 2))  # fbcoco.ImageTransformer({1,1,1},nil,2), inceptionv3.lua:52
 IMAGENET = dict(mean=(0.48462227599918, 0.45624044862054, 0.40588363755159),
                 std=(0.22889466674951, 0.22446679341259, 0.22495548344775), scale=1.0, swap=(0, 1, 2))
 
@@ -544,3 +545,70 @@ def resnet_mpn_detect(im, boxes, R, transformer=IMAGENET, target=600, max_size=1
     if R.get("bbox_mean") is not None:
         deltas = bbox_norm(deltas, R["bbox_mean"], R["bbox_std"])
     return scores, bbox_decode(boxes, deltas)
+
+
+# ---- op-list graphs (Inception-v3, models/inceptionv3.lua:27-43) ---------------------------------------------------------------
+def avgpool2d(x, k=3, stride=1, pad=1):
+    """nn.SpatialAveragePooling, count_include_pad (always / k*k)"""
+    x = _f32(x)
+    B, Cc, H, W = x.shape
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = np.empty((B, Cc, OH, OW), np.float32)
+    lib().orc_avgpool2d(_p(x), B * Cc, H, W, k, stride, pad, _p(out))
+    return out
+
+
+def conv2d_rect(x, w, b, sh, sw, ph, pw, relu, bf16=False):
+    x, w = _f32(x), _f32(w)
+    if bf16:
+        w = bf16_round(w)
+    b = _f32(b) if b is not None else None
+    B, Cin, H, W = x.shape
+    Cout, _, KH, KW = w.shape
+    OH, OW = (H + 2 * ph - KH) // sh + 1, (W + 2 * pw - KW) // sw + 1
+    out = np.empty((B, Cout, OH, OW), np.float32)
+    lib().orc_conv2d_rect(_p(x), B, Cin, H, W, _p(w), _p(b) if b is not None else None, Cout, KH, KW, sh, sw, ph, pw, int(relu), _p(out))
+    return bf16_round(out) if bf16 else out
+
+
+def graph_run(x0, ops, tensor_c, bf16=False):
+    """executes an op list (include/mpn.h mpn_graph_op) on x0 [B,C0,H,W]; returns the list of tensors"""
+    ts = [None] * len(tensor_c)
+    ts[0] = x0
+    for o in ops:
+        x = ts[o["src"]]
+        if o["kind"] == 0:
+            y = conv2d_rect(x, o["w"], o["b"], o["sh"], o["sw"], o["ph"], o["pw"], o["relu"], bf16)
+        elif o["kind"] == 1:
+            y = maxpool2d(x, o["kh"], o["sh"], o["ph"])
+        else:
+            y = avgpool2d(x, o["kh"], o["sh"], o["ph"])
+            if bf16:
+                y = bf16_round(y)
+        d = o["dst"]
+        if ts[d] is None:
+            ts[d] = np.zeros((y.shape[0], tensor_c[d]) + y.shape[2:], np.float32)
+        ts[d][:, o["off"]:o["off"] + y.shape[1]] = y
+    return ts
+
+
+def graph_detect(im, boxes, G, transformer, target=600, max_size=1000, pooled=17, spatial_scale=17.0 / 299.0):
+    """ImageDetect.lua:156-193 on an op-list model (Inception-v3 Fast R-CNN)"""
+    bf = bool(G.get("bf16"))
+    H, W = im.shape[1:]
+    s = pick_scale(H, W, target, max_size)
+    x = image_transform(im, **transformer)
+    if s != 1.0:
+        x = image_scale(x, int(H * s), int(W * s))
+    if bf:
+        x = bf16_round(x)
+    rois = project_im_rois(boxes, s)
+    feat = graph_run(x[None], G["trunk_ops"], G["trunk_tensor_c"], bf)[G["feat_tensor"]][0]
+    pooledf, _ = roi_pool(feat, rois, pooled, pooled, spatial_scale)
+    y = graph_run(pooledf, G["head_ops"], G["head_tensor_c"], bf)[G["out_tensor"]]
+    f = avgpool_global(y)
+    logits = linear(f, G["cls_w"], G["cls_b"])
+    deltas = linear(f, G["bbox_w"], G["bbox_b"])
+    if G.get("bbox_mean") is not None:
+        deltas = bbox_norm(deltas, G["bbox_mean"], G["bbox_std"])
+    return softmax(logits), bbox_decode(boxes, deltas), logits, deltas

@@ -1,0 +1,39 @@
+"""Inception-v3 Fast R-CNN (models/inceptionv3.lua:27-43, BASELINE configs[4]) through mpn_graph_create vs the oracle's op-list
+executor: a width-scaled network with the full module structure (InceptionA x3, B, C x4 in the trunk; D, E x2 per ROI; 1x7 / 7x1 /
+1x3 / 3x1 kernels, average-pool branches, DepthConcat as side-by-side writes), fp32 and bf16."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(H, W, N, seed):
+    rng = np.random.default_rng(seed)
+    im = rng.uniform(0, 1, (3, H, W)).astype(np.float32)
+    c = rng.uniform([1, 1], [W, H], (N, 2))
+    wh = np.exp(rng.uniform(np.log(16), np.log(min(H, W)), (N, 2)))
+    b = np.concatenate([c - wh / 2, c + wh / 2], 1)
+    b[:, [0, 2]] = np.clip(b[:, [0, 2]], 1, W)
+    b[:, [1, 3]] = np.clip(b[:, [1, 3]], 1, H)
+    return im, b.astype(np.float32)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_inception_frcnn_vs_oracle(O, dev, bf16):
+    from multipathnet_amd import models
+    H, W, N, C = 170, 215, 24, 5
+    G = models.synthetic_inception_v3_params(n_classes=C, width=0.125, seed=13)
+    Gn = models.graph_params_numpy(G)
+    if bf16:
+        Gn["bf16"] = True
+    im, boxes = _inputs(H, W, N, 8)
+    net = models.InceptionFRCNN(G, max_h=H, max_w=W, max_rois=32, top_k=10, bf16=bf16)
+    s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+    so, bo, _, _ = O.graph_detect(im, boxes, Gn, O.INCEPTION, target=min(H, W), max_size=max(H, W))
+    s = s.cpu().numpy()
+    assert np.abs(s - so).max() < (3e-3 if bf16 else 1e-4)
+    assert np.abs(b.cpu().numpy() - O.clamp_boxes(bo, W, H)).max() < (0.5 if bf16 else 1e-2)
+    net.test_one_async(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+    torch.cuda.synchronize()
+    assert int(net._n_dets.item()) > 0

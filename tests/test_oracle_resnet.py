@@ -61,3 +61,33 @@ def test_resnet_graph_vs_torch(O, bt):
         h = block(h, b)
     f = h.mean((2, 3))
     assert np.abs(logits - (f @ R["cls_w"].T + R["cls_b"]).numpy()).max() < 1e-5
+
+
+def test_rect_conv_and_avgpool_vs_torch(O):
+    """asymmetric kernels (1x7 / 7x1 / 1x3 / 3x1) and count_include_pad average pooling of the Inception graph vs PyTorch-CPU"""
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((2, 8, 17, 13)).astype(np.float32)
+    for (kh, kw, sh, sw, ph, pw) in [(1, 7, 1, 1, 0, 3), (7, 1, 1, 1, 3, 0), (1, 3, 1, 1, 0, 1), (3, 1, 1, 1, 1, 0), (3, 3, 2, 2, 0, 0), (5, 5, 1, 1, 2, 2)]:
+        w = (rng.standard_normal((16, 8, kh, kw)) * 0.1).astype(np.float32)
+        b = rng.standard_normal(16).astype(np.float32)
+        ref = F.relu(F.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), stride=(sh, sw), padding=(ph, pw))).numpy()
+        assert np.abs(O.conv2d_rect(x, w, b, sh, sw, ph, pw, True) - ref).max() < 1e-4
+    ref = F.avg_pool2d(torch.from_numpy(x), 3, 1, 1, count_include_pad=True).numpy()
+    assert np.abs(O.avgpool2d(x, 3, 1, 1) - ref).max() < 1e-6
+
+
+def test_inception_graph_builder_shapes():
+    """the op lists reproduce Inception-v3's channel arithmetic: 768-channel 17x17 stage, 2048-channel head, 299 -> 17 -> 8"""
+    from multipathnet_amd import models
+    G = models.synthetic_inception_v3_params(n_classes=3, width=1.0, seed=1)
+    assert G["trunk_tensor_c"][G["feat_tensor"]] == 768 and G["head_tensor_c"][G["out_tensor"]] == 2048
+    assert sum(1 for o in G["trunk_ops"] + G["head_ops"] if o["kind"] == 0) == 94  # the 94 convolutions of Inception-v3 (without the aux head)
+    h = 299
+    dims = {0: h}
+    for o in G["trunk_ops"]:
+        dims.setdefault(o["dst"], (dims[o["src"]] + 2 * o["ph"] - o["kh"]) // o["sh"] + 1)
+    assert dims[G["feat_tensor"]] == 17
+    dims = {0: 17}
+    for o in G["head_ops"]:
+        dims.setdefault(o["dst"], (dims[o["src"]] + 2 * o["ph"] - o["kh"]) // o["sh"] + 1)
+    assert dims[G["out_tensor"]] == 8

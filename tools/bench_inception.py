@@ -1,0 +1,49 @@
+"""BASELINE configs[4] backbone on ONE GPU: Inception-v3 Fast R-CNN (models/inceptionv3.lua graph), 600x1000 image, bf16 by default,
+2000 ROIs — timing of the full per-image path (not a bench.py line; parity is tests/test_gpu_inception.py)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from multipathnet_amd import models
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+bf16 = "fp32" not in sys.argv[2:]
+G = models.synthetic_inception_v3_params(n_classes=81, seed=557)
+net = models.InceptionFRCNN(G, max_h=600, max_w=1000, max_rois=N, bf16=bf16)
+im, boxes = bench.synthetic_inputs()
+rng = np.random.default_rng(556)
+while boxes.shape[0] < N:  # more proposals of the same distribution
+    boxes = np.concatenate([boxes, boxes[rng.permutation(boxes.shape[0])] * np.float32(0.97) + np.float32(1.0)])
+boxes = np.clip(boxes[:N], 1, [1000, 600, 1000, 600]).astype(np.float32)
+dev = torch.device("cuda", 0)
+im, boxes = torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev)
+for _ in range(2):
+    net.test_one_pipelined(im, boxes)
+net.flush(); torch.cuda.synchronize()
+K = 3
+t0 = time.perf_counter()
+for _ in range(K):
+    net.test_one_pipelined(im, boxes)
+net.flush(); torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / K
+
+def flops(ops, h, w):
+    dims, f = {0: (h, w)}, 0.0
+    for o in ops:
+        sh_, sw_ = dims[o["src"]]
+        oh, ow = (sh_ + 2 * o["ph"] - o["kh"]) // o["sh"] + 1, (sw_ + 2 * o["pw"] - o["kw"]) // o["sw"] + 1
+        dims.setdefault(o["dst"], (oh, ow))
+        if o["kind"] == 0:
+            f += 2.0 * o["cout"] * o["cin"] * o["kh"] * o["kw"] * oh * ow
+    return f, dims
+ft, dims = flops(G["trunk_ops"], 600, 1000)
+fh, _ = flops(G["head_ops"], 17, 17)
+total = ft + N * fh
+net.set_profiling(True); net.get_profile(True)
+net.test_one_async(im, boxes); torch.cuda.synchronize()
+prof = net.get_profile(True)
+peak = 2500e12 if bf16 else 157.3e12
+print("Inception-v3 Fast R-CNN %s, %d ROIs, 81 classes: %.2f ms/image  %.0f proposals/s  %.2f TFLOP/image  %.1f TFLOP/s (%.1f%% of the dtype's dense MFMA peak); feature map %dx%d" % (
+    "bf16" if bf16 else "fp32", N, dt * 1e3, N / dt, total / 1e12, total / dt / 1e12, total / dt / peak * 100, *dims[G["feat_tensor"]]))
+for k, (ms, n) in prof.items():
+    if n: print("  %-12s %8.3f ms (%d launch groups)%s" % (k, ms, n, {"conv_direct": "  = trunk (stem + Mixed_5b..6e)", "fc6": "  = ROI pool + per-ROI Mixed_7a..7c + avgpool"}.get(k, "")))
+print("n dets", int(net._n_dets.item()))
