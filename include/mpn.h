@@ -315,6 +315,12 @@ typedef struct mpn_graph_weights {
   int n_trunk_ops;  const mpn_graph_op *trunk_ops;  int n_trunk_tensors;  const int *trunk_tensor_c;  int feat_tensor;
   int n_head_ops;   const mpn_graph_op *head_ops;   int n_head_tensors;   const int *head_tensor_c;   int out_tensor;
   int bf16;               /* as mpn_resnet_weights.bf16 */
+  /* MultiPathNet towers on this backbone (BASELINE configs[4]; this library's extension, see mpn_resnet_weights.n_heads):
+   * n_heads >= 2: head_ops holds n_heads * n_head_ops entries, tower-major, every tower the same op structure with its own
+   * weights; tower t pools Foveal region head_region[t]; the last tower feeds the box regressor. */
+  int n_heads;
+  int head_region[8];
+  int n_integral;
 } mpn_graph_weights;
 int mpn_graph_create(const mpn_frcnn_config *cfg, const mpn_graph_weights *gw, const float *d_cls_w, const float *d_cls_b,
                      const float *d_bbox_w, const float *d_bbox_b, mpn_frcnn **out);

@@ -65,7 +65,7 @@ class GraphWeights(C.Structure):
     _fields_ = [("n_trunk_ops", C.c_int), ("trunk_ops", C.POINTER(GraphOp)), ("n_trunk_tensors", C.c_int), ("trunk_tensor_c", C.POINTER(C.c_int)),
                 ("feat_tensor", C.c_int),
                 ("n_head_ops", C.c_int), ("head_ops", C.POINTER(GraphOp)), ("n_head_tensors", C.c_int), ("head_tensor_c", C.POINTER(C.c_int)),
-                ("out_tensor", C.c_int), ("bf16", C.c_int)]
+                ("out_tensor", C.c_int), ("bf16", C.c_int), ("n_heads", C.c_int), ("head_region", C.c_int * 8), ("n_integral", C.c_int)]
 
 
 def lib_path():

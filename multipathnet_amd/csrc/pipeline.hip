@@ -238,7 +238,9 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
   MPN_CHECK_ARG(cfg->top_k > 0);
   mpn_frcnn *p = new mpn_frcnn();
   p->cfg = *cfg;
-  if (rw && rw->n_heads > 1) p->n_integral = rw->n_integral > 0 ? rw->n_integral : 1;
+  const int tower_heads = rw ? rw->n_heads : (gw ? gw->n_heads : 0);  // > 1: MultiPathNet towers on a ResNet / op-list backbone
+  const int *tower_region = rw ? rw->head_region : (gw ? gw->head_region : nullptr);
+  if (tower_heads > 1) p->n_integral = (rw ? rw->n_integral : gw->n_integral) > 0 ? (rw ? rw->n_integral : gw->n_integral) : 1;
   if (mw) { p->is_mpnet = true; p->tap3 = mw->tap_conv3; p->tap4 = mw->tap_conv4; p->n_integral = mw->n_integral > 0 ? mw->n_integral : 1; }
   const int n_conv = graph_net ? 0 : cfg->n_conv;
   p->cfg.n_conv = n_conv;
@@ -334,9 +336,9 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
     TRY(dev_alloc(p, &p->cat, (size_t)mw->n_towers * (lin_np(F) / 8) * p->Mp * 8 * sizeof(float), true));
     TRY(dev_alloc(p, &p->cls_rm, M * K * C * sizeof(float), true));
     TRY(dev_alloc(p, &p->bbox_rm, M * 4 * C * sizeof(float), true));
-  } else if (rw && rw->n_heads > 1) {  // ResNet towers (this library's extension, see mpn_resnet_weights): same classifier stage as MultiPathNet
-    const int n_fov = rw->n_heads - 1, K = p->n_integral;
-    MPN_CHECK_ARG(C <= 256);
+  } else if (tower_heads > 1) {  // ResNet / graph towers (this library's extension, see mpn_resnet_weights): same classifier stage as MultiPathNet
+    const int n_fov = tower_heads - 1, K = p->n_integral;
+    MPN_CHECK_ARG(C <= 256 && tower_heads <= 8);
     const int KC64 = round_up(n_fov * F, 64);
     TRY(dev_alloc(p, &p->wcls, lin_wpk_elems(KC64, K * C) * sizeof(float), false));
     TRY(dev_alloc(p, &p->bcls, (size_t)lin_np(K * C) * sizeof(float), false));
@@ -345,10 +347,10 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
     TRY(dev_alloc(p, &p->bbbox, (size_t)lin_np(4 * C) * sizeof(float), false));
     TRY(pack_linear_weights(d_bbox_w, d_bbox_b, F, 4 * C, 1, p->wbbox, p->bbbox, nullptr));
     TRY(dev_alloc(p, &p->fov, M * 20 * sizeof(float), true));
-    TRY(dev_alloc(p, &p->cat, (size_t)rw->n_heads * (lin_np(F) / 8) * p->Mp * 8 * sizeof(float), true));
+    TRY(dev_alloc(p, &p->cat, (size_t)tower_heads * (lin_np(F) / 8) * p->Mp * 8 * sizeof(float), true));
     TRY(dev_alloc(p, &p->cls_rm, M * K * C * sizeof(float), true));
     TRY(dev_alloc(p, &p->bbox_rm, M * 4 * C * sizeof(float), true));
-    for (int t = 0; t < rw->n_heads; ++t) { MPN_CHECK_ARG(rw->head_region[t] >= 0 && rw->head_region[t] < 4); p->rn_region.push_back(rw->head_region[t]); }
+    for (int t = 0; t < tower_heads; ++t) { MPN_CHECK_ARG(tower_region[t] >= 0 && tower_region[t] < 4); p->rn_region.push_back(tower_region[t]); }
   } else {
   if (!graph_net) {
   TRY(dev_alloc(p, &p->w6, lin_wpk_elems(K6_32, F) * sizeof(float), false));

@@ -552,7 +552,8 @@ struct GOp { int kind = 0, src = 0, dst = 0, dst_c_off = 0, kh = 1, kw = 1, sh =
 struct ResNetGraph {
   // op-list mode (graph_build): branching graphs; tensor 0 = image (trunk) / ROI-pooled map (head)
   bool is_graph = false;
-  std::vector<GOp> g_trunk, g_head;
+  std::vector<GOp> g_trunk;
+  std::vector<std::vector<GOp>> g_heads;  // one op list per tower (1 for plain inceptionv3.lua), all over the same head tensors
   std::vector<GTensor> t_trunk, t_head;
   int feat_tensor = 0, out_tensor = 0;
   RnConv conv1;
@@ -837,13 +838,17 @@ int graph_build(const mpn_graph_weights *gw, int max_h, int max_w, int max_rois,
   g->is_graph = true; g->pooled = pooled; g->max_rois = max_rois; g->bf16 = gw->bf16 != 0;
   g->feat_tensor = gw->feat_tensor; g->out_tensor = gw->out_tensor;
   int rc = graph_parse(g, gw->n_trunk_ops, gw->trunk_ops, gw->n_trunk_tensors, gw->trunk_tensor_c, g->g_trunk, g->t_trunk);
-  if (rc == MPN_OK) rc = graph_parse(g, gw->n_head_ops, gw->head_ops, gw->n_head_tensors, gw->head_tensor_c, g->g_head, g->t_head);
+  const int n_heads = gw->n_heads > 1 ? gw->n_heads : 1;
+  MPN_CHECK_ARG(n_heads <= 8);
+  g->g_heads.resize(n_heads);
+  for (int t = 0; rc == MPN_OK && t < n_heads; ++t)
+    rc = graph_parse(g, gw->n_head_ops, gw->head_ops + (size_t)t * gw->n_head_ops, gw->n_head_tensors, gw->head_tensor_c, g->g_heads[t], g->t_head);
   if (rc == MPN_OK && (g->t_trunk[0].C != 3 || g->t_head[0].C != g->t_trunk[g->feat_tensor].C)) {
     set_error("graph: tensor 0 must be the 3-channel image (trunk) / carry the feature tensor's channels (head)");
     rc = MPN_EINVAL;
   }
   if (rc == MPN_OK) rc = graph_dims(g->g_trunk, g->t_trunk, max_h, max_w);
-  if (rc == MPN_OK) rc = graph_dims(g->g_head, g->t_head, pooled, pooled);
+  for (int t = 0; rc == MPN_OK && t < n_heads; ++t) rc = graph_dims(g->g_heads[t], g->t_head, pooled, pooled);
   const size_t esz = g->bf16 ? sizeof(bf16_t) : sizeof(float);
   for (size_t i = 0; rc == MPN_OK && i < g->t_trunk.size(); ++i) {
     GTensor &t = g->t_trunk[i];
@@ -863,7 +868,7 @@ int graph_build(const mpn_graph_weights *gw, int max_h, int max_w, int max_rois,
   g->feat_c = g->t_trunk[g->feat_tensor].C;
   g->out_c = g->t_head[g->out_tensor].C;
   g->img = g->t_trunk[0].buf;
-  g->heads.resize(1);
+  g->heads.resize(n_heads);
   MPN_CHECK_HIP(hipDeviceSynchronize());
   *out = g;
   return MPN_OK;
@@ -972,8 +977,8 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
   }
   ActI cur{pool_dst, N, g->feat_c, PH, PH}, y;
   if (g->is_graph) {
-    int rc = graph_dims(g->g_head, g->t_head, PH, PH);
-    if (rc == MPN_OK) rc = graph_run(g, g->g_head, g->t_head, N, s);
+    int rc = graph_dims(g->g_heads[head], g->t_head, PH, PH);
+    if (rc == MPN_OK) rc = graph_run(g, g->g_heads[head], g->t_head, N, s);
     if (rc) return rc;
     const GTensor &o = g->t_head[g->out_tensor];
     cur = ActI{o.buf, N, o.C, o.H, o.W};

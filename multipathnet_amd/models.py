@@ -300,6 +300,30 @@ def synthetic_inception_v3_params(n_classes=21, seed=557, width=1.0, bbox_norm=T
     return G
 
 
+def synthetic_inception_mpn_params(n_classes=81, n_integral=6, seed=557, regions=RESNET_MPN_REGIONS, **kw):
+    """BASELINE configs[4]: MultiPathNet on the Inception-v3 backbone (this library's extension, as synthetic_resnet_mpn_params):
+    one Mixed_7a..7c copy per Foveal tower, K integral classifiers, the last tower feeds the box regressor."""
+    G = synthetic_inception_v3_params(n_classes=n_classes, seed=seed, **kw)
+    g = torch.Generator().manual_seed(seed + 9)
+    towers = [G["head_ops"]]
+    for _ in regions[1:]:
+        tw = []
+        for o in G["head_ops"]:
+            if o["kind"] == 0:
+                tw.append(dict(o, w=torch.randn(o["w"].shape, generator=g) * o["w"].std(), b=torch.randn(o["b"].shape, generator=g) * 0.01))
+            else:
+                tw.append(dict(o))
+        towers.append(tw)
+    out_c = G["bbox_w"].shape[1]
+    G["head_towers"], G["head_regions"] = towers, list(regions)
+    G["cls_w"] = torch.randn(n_integral * n_classes, (len(regions) - 1) * out_c, generator=g) * 0.01
+    G["cls_b"] = torch.zeros(n_integral * n_classes)
+    G["bbox_w"] = torch.randn(4 * n_classes, out_c, generator=g) * 0.001
+    G["bbox_b"] = torch.zeros(4 * n_classes)
+    G["n_integral"], G["n_classes"] = n_integral, n_classes
+    return G
+
+
 INCEPTION_TRANSFORMER = dict(mean=(1.0, 1.0, 1.0), std=None, scale=2.0, swap=(0, 1, 2))  # fbcoco.ImageTransformer({1,1,1},nil,2), inceptionv3.lua:52
 
 
@@ -307,6 +331,8 @@ def graph_params_numpy(G):
     n = lambda t: None if t is None else t.detach().cpu().numpy()
     cp = lambda ops: [dict(o, w=n(o["w"]), b=n(o["b"])) for o in ops]
     out = dict(G, trunk_ops=cp(G["trunk_ops"]), head_ops=cp(G["head_ops"]))
+    if "head_towers" in G:
+        out["head_towers"] = [cp(tw) for tw in G["head_towers"]]
     for k in ("cls_w", "cls_b", "bbox_w", "bbox_b"):
         out[k] = n(G[k])
     return out
@@ -438,7 +464,8 @@ class FastRCNN(object):
                 return arr
 
             gw = GraphWeights()
-            self._g_arrays = [mk(params["trunk_ops"]), mk(params["head_ops"]), (C.c_int * len(params["trunk_tensor_c"]))(*params["trunk_tensor_c"]),
+            towers = params.get("head_towers") or [params["head_ops"]]
+            self._g_arrays = [mk(params["trunk_ops"]), mk([o for tw in towers for o in tw]), (C.c_int * len(params["trunk_tensor_c"]))(*params["trunk_tensor_c"]),
                               (C.c_int * len(params["head_tensor_c"]))(*params["head_tensor_c"])]
             ga = self._g_arrays
             gw.n_trunk_ops, gw.trunk_ops = len(params["trunk_ops"]), C.cast(ga[0], C.POINTER(GraphOp))
@@ -446,6 +473,11 @@ class FastRCNN(object):
             gw.n_trunk_tensors, gw.trunk_tensor_c = len(params["trunk_tensor_c"]), C.cast(ga[2], C.POINTER(C.c_int))
             gw.n_head_tensors, gw.head_tensor_c = len(params["head_tensor_c"]), C.cast(ga[3], C.POINTER(C.c_int))
             gw.feat_tensor, gw.out_tensor, gw.bf16 = params["feat_tensor"], params["out_tensor"], int(bool(bf16))
+            if "head_towers" in params:
+                gw.n_heads, gw.n_integral = len(towers), params["n_integral"]
+                for t, rg in enumerate(params["head_regions"]):
+                    gw.head_region[t] = rg
+                self.noSoftMax = True
             heads = [d(params[k]) for k in ("cls_w", "cls_b", "bbox_w", "bbox_b")]
             check(lib.mpn_graph_create(C.byref(c), C.byref(gw), *[_f(t) for t in heads], C.byref(self._h)), "mpn_graph_create")
             torch.cuda.synchronize()

@@ -612,3 +612,30 @@ def graph_detect(im, boxes, G, transformer, target=600, max_size=1000, pooled=17
     if G.get("bbox_mean") is not None:
         deltas = bbox_norm(deltas, G["bbox_mean"], G["bbox_std"])
     return softmax(logits), bbox_decode(boxes, deltas), logits, deltas
+
+
+def graph_mpn_detect(im, boxes, G, transformer, target=600, max_size=1000, pooled=17, spatial_scale=17.0 / 299.0):
+    """MultiPathNet towers on an op-list backbone (this library's extension, cf. resnet_mpn_detect): returns (scores, decoded boxes)"""
+    bf = bool(G.get("bf16"))
+    H, W = im.shape[1:]
+    s = pick_scale(H, W, target, max_size)
+    x = image_transform(im, **transformer)
+    if s != 1.0:
+        x = image_scale(x, int(H * s), int(W * s))
+    if bf:
+        x = bf16_round(x)
+    rois = project_im_rois(boxes, s)
+    feat = graph_run(x[None], G["trunk_ops"], G["trunk_tensor_c"], bf)[G["feat_tensor"]][0]
+    fov = foveal(rois).reshape(-1, 4, 5)
+    outs = []
+    for tw, rg in zip(G["head_towers"], G["head_regions"]):
+        pooledf, _ = roi_pool(feat, np.ascontiguousarray(fov[:, rg]), pooled, pooled, spatial_scale)
+        outs.append(avgpool_global(graph_run(pooledf, tw, G["head_tensor_c"], bf)[G["out_tensor"]]))
+    cat = np.concatenate(outs[:-1], 1)
+    K, Cn = G["n_integral"], G["n_classes"]
+    logits = linear(cat, G["cls_w"], G["cls_b"]).reshape(-1, K, Cn)
+    probs = np.stack([softmax(np.ascontiguousarray(logits[:, k])) for k in range(K)])
+    deltas = linear(outs[-1], G["bbox_w"], G["bbox_b"])
+    if G.get("bbox_mean") is not None:
+        deltas = bbox_norm(deltas, G["bbox_mean"], G["bbox_std"])
+    return mean_over_k(probs), bbox_decode(boxes, deltas)

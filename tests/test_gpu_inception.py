@@ -37,3 +37,18 @@ def test_inception_frcnn_vs_oracle(O, dev, bf16):
     net.test_one_async(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
     torch.cuda.synchronize()
     assert int(net._n_dets.item()) > 0
+
+
+def test_inception_multipathnet_extension_vs_oracle(O, dev):
+    """BASELINE configs[4] shape: Foveal towers over the Inception trunk, each with its own Mixed_7a..7c copy, K integral
+    classifiers, box tower (this library's extension), in bf16"""
+    from multipathnet_amd import models
+    H, W, N, C, K = 170, 215, 20, 4, 2
+    G = models.synthetic_inception_mpn_params(n_classes=C, n_integral=K, width=0.125, seed=17, regions=[0, 2, 3, 1])
+    Gn = dict(models.graph_params_numpy(G), bf16=True)
+    im, boxes = _inputs(H, W, N, 12)
+    net = models.InceptionFRCNN(G, max_h=H, max_w=W, max_rois=32, top_k=10, bf16=True)
+    s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+    so, bo = O.graph_mpn_detect(im, boxes, Gn, O.INCEPTION, target=min(H, W), max_size=max(H, W))
+    assert np.abs(s.cpu().numpy() - so).max() < 3e-3
+    assert np.abs(b.cpu().numpy() - O.clamp_boxes(bo, W, H)).max() < 0.5

@@ -7,7 +7,8 @@ import bench
 from multipathnet_amd import models
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 bf16 = "fp32" not in sys.argv[2:]
-G = models.synthetic_inception_v3_params(n_classes=81, seed=557)
+mpn = "mpn" in sys.argv[2:]  # BASELINE configs[4]: MultiPathNet towers (4 Foveal scales + box tower) on this backbone
+G = models.synthetic_inception_mpn_params(n_classes=81, n_integral=6, seed=557) if mpn else models.synthetic_inception_v3_params(n_classes=81, seed=557)
 net = models.InceptionFRCNN(G, max_h=600, max_w=1000, max_rois=N, bf16=bf16)
 im, boxes = bench.synthetic_inputs()
 rng = np.random.default_rng(556)
@@ -37,12 +38,12 @@ def flops(ops, h, w):
     return f, dims
 ft, dims = flops(G["trunk_ops"], 600, 1000)
 fh, _ = flops(G["head_ops"], 17, 17)
-total = ft + N * fh
+total = ft + N * fh * (len(G["head_towers"]) if mpn else 1)
 net.set_profiling(True); net.get_profile(True)
 net.test_one_async(im, boxes); torch.cuda.synchronize()
 prof = net.get_profile(True)
 peak = 2500e12 if bf16 else 157.3e12
-print("Inception-v3 Fast R-CNN %s, %d ROIs, 81 classes: %.2f ms/image  %.0f proposals/s  %.2f TFLOP/image  %.1f TFLOP/s (%.1f%% of the dtype's dense MFMA peak); feature map %dx%d" % (
+print(("Inception-v3 MultiPathNet (5 towers, K=6)" if mpn else "Inception-v3 Fast R-CNN") + " %s, %d ROIs, 81 classes: %.2f ms/image  %.0f proposals/s  %.2f TFLOP/image  %.1f TFLOP/s (%.1f%% of the dtype's dense MFMA peak); feature map %dx%d" % (
     "bf16" if bf16 else "fp32", N, dt * 1e3, N / dt, total / 1e12, total / dt / 1e12, total / dt / peak * 100, *dims[G["feat_tensor"]]))
 for k, (ms, n) in prof.items():
     if n: print("  %-12s %8.3f ms (%d launch groups)%s" % (k, ms, n, {"conv_direct": "  = trunk (stem + Mixed_5b..6e)", "fc6": "  = ROI pool + per-ROI Mixed_7a..7c + avgpool"}.get(k, "")))
