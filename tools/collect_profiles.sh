@@ -17,7 +17,7 @@ for set in "sq:GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_A
 done
 ls -la $OUT
 # the two widened configurations (not bench.py lines): per-kernel stats + the tools' own timing lines
-for cfg in "mpn:bench_mpn.py" "resnet50:bench_resnet.py" "resnet50_bf16:bench_resnet.py 50 1000 bf16"; do
+for cfg in "mpn:bench_mpn.py" "resnet50:bench_resnet.py" "resnet50_bf16:bench_resnet.py 50 1000 bf16" "inception_mpn_bf16:bench_inception.py 2000 mpn"; do
   name=${cfg%%:*}; tool=${cfg#*:}
   rm -rf /tmp/kt_$name
   timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt_$name -o kt --output-format csv -- python $R/tools/$tool > $OUT/${TAG}_${name}_timing.txt 2> /tmp/kt_$name.err
