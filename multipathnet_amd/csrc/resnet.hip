@@ -293,7 +293,7 @@ struct GConvArgsB {
   long long P;
 };
 
-// KP = chunk PAIRS (16 input channels) per LDS stage: 4 * KP MFMAs per wave between two barriers
+// KP = chunk PAIRS (16 input channels) per LDS stage: 4 * KP MFMAs per wave between two barriers (instantiated: 1 and 2)
 template <int KP>
 __global__ __launch_bounds__(256) void conv2d_c8i_bf16_kernel(GConvArgsB a) {
   constexpr int NCH = 2 * KP;                       // 8-channel chunks per stage

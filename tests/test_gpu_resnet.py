@@ -107,7 +107,7 @@ def test_resnet_iterative_localisation_and_voting_run(dev):
 def test_resnet_bf16_vs_bf16_oracle_and_fp32(O, dev, bt, blocks, width):
     """bf16 graph (bf16 activations / weights, fp32 accumulate): against the oracle run with the same roundings (weights, the
     transformed image and every layer output rounded to bf16) the scores agree to bf16 accumulation-order noise; against
-    the fp32 oracle they agree to bf16 precision.  width 64 exercises the 64-channel-per-stage kernel variant."""
+    the fp32 oracle they agree to bf16 precision.  width 64 exercises the 32-channel-per-stage kernel variant (widths 16: 16-channel)."""
     from multipathnet_amd import models
     H, W, N, C = 97, 131, 37, 6
     R = models.synthetic_resnet_params(depth=0, n_classes=C, base_width=width, blocks=blocks, block_type=bt, seed=23)
