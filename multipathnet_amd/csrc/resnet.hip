@@ -8,6 +8,7 @@
 // staged through registers into double-buffered LDS; every MFMA operand fetch is then the same conflict-free ds_read_b128
 // as in dense.hip's kernels.  16 KiB of LDS per block lets several blocks share a CU, which hides the gather latency.
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/mpn.h"
@@ -400,6 +401,260 @@ __global__ __launch_bounds__(256) void conv2d_c8i_bf16_kernel(GConvArgsB a) {
   }
 }
 
+// ---- large layers: 256 couts x 256 pixels per block, operands gathered straight into LDS by the DMA engine ----------------
+// The 128 x 128 kernel above loads 1 operand byte per 64 FLOP and is bound by that (L2 -> CU), and its register-staged
+// prefetch is one stage deep.  Here a wave owns 128 x 128 (4 x 4 MFMA tiles, 256 accumulator registers): 128 FLOP per operand
+// byte; a stage is 32 input channels of one tap (16 KiB of weights + 16 KiB of gathered pixels) and lives in a 4-deep LDS
+// ring filled by global_load_lds THREE stages ahead (~3000 cycles of cover with one block per CU) — no staging registers, no
+// ds_write.  Lane = one row of the stage: wave w DMAs rows 64 w .. 64 w + 63 of each of the 4 weight chunks (uniform base +
+// lane * 16) and of the 4 pixel chunks (uniform chunk-plane base + the lane's gathered pixel offset).  A lane whose tap falls
+// outside its map still issues its loads (from its map's first pixel: the per-wave vmcnt bookkeeping needs a fixed number of
+// loads per stage) and overwrites its four records with zeros once they have landed, before the barrier that publishes the stage.
+__device__ __forceinline__ void glds16_s(const void *base_uniform, unsigned lane_byte_off, unsigned lds_byte_addr_uniform) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_byte_addr_uniform), "v"(lane_byte_off), "s"(base_uniform) : "memory");
+}
+
+// NI = 32-pixel MFMA tiles per wave along the pixel axis: 4 -> 256-pixel block tile, 2 -> 128 (picked by the host when that
+// packs the grid into fewer, fuller rounds of 256 blocks: a 512-cout layer on 49 000 pixels is 384 blocks = 1.5 rounds at 256
+// pixels but exactly 3 rounds of half-size blocks at 128).
+template <int NI>
+__global__ __launch_bounds__(256) void conv2d_c8i_bf16_dma_kernel(GConvArgsB a, int nx, int ny) {
+  constexpr int NCH = 4, RING = 4, TN = 64 * NI;
+  constexpr int NB = NI;                                          // pixel-chunk DMA items per wave per stage (weights: 4)
+  constexpr int ITEMS = NCH + NB;
+  constexpr unsigned OPA = NCH * 256 * 16, OPBB = NCH * TN * 16, STAGEB = OPA + OPBB;  // bytes: weights / pixels / stage
+  extern __shared__ __attribute__((aligned(16))) u32x4 ring[];  // [RING][A: NCH x 256 rows | B: NCH x TN rows]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  // block -> tile: a pixel tile's ny cout tiles run back to back on ONE XCD (blocks are dealt to the 8 XCDs round-robin), so the
+  // gathered pixels are fetched into one L2 once
+  const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+  const int ty = kq % ny, tx = (kq / ny) * 8 + xcd;
+  if (tx >= nx) return;
+  const long long p0 = (long long)tx * TN;
+  const int cout0 = ty * 256;
+  const int OHW = a.OH * a.OW;
+  // DMA roles.  Weights: wave w moves rows 64 w .. 64 w + 63 of all 4 chunks.  Pixels, NI = 4: the same; NI = 2 (128 rows):
+  // wave w moves rows 64 (w & 1) .. of chunks 2 (w >> 1) and 2 (w >> 1) + 1.
+  const int prow = NI == 4 ? tid : (tid & 127);                  // this lane's pixel row of the tile
+  const int bch0 = NI == 4 ? 0 : 2 * (wave >> 1);                // its first pixel chunk
+  const long long gpix = p0 + prow;
+  const bool gvalid = gpix < a.P;
+  const int gb = gvalid ? (int)(gpix / OHW) : 0;
+  const int grem = gvalid ? (int)(gpix - (long long)gb * OHW) : 0;
+  const int goy = grem / a.OW, gox = grem - goy * a.OW;
+  const int iy0 = goy * a.sh - a.ph, ix0 = gox * a.sw - a.pw;
+  const unsigned map_off = (unsigned)gb * (unsigned)(a.H * a.W);  // records
+  const bf16_t *const w_tile = a.wpk + (size_t)cout0 * 8;
+  const unsigned ring0 = (unsigned)(size_t)((__attribute__((address_space(3))) const u32x4 *)ring);
+  const unsigned lds_a = ring0 + (unsigned)wave * 1024u;
+  const unsigned lds_b = ring0 + OPA + (unsigned)bch0 * (TN * 16u) + (unsigned)(NI == 4 ? wave : (wave & 1)) * 1024u;
+  const unsigned a_lane = (unsigned)tid * 16u;
+  const int spt = a.nch2 / NCH;
+  const int nstages = a.KH * a.KW * spt;
+
+  // issue cursor (the stage being DMA'd): tap (ky, kx), channel group cg and two running chunk pointers — the packed weights are
+  // [tap][chunk][CoutP][8], i.e. consecutive stages are consecutive memory; the pixel chunk planes restart at every tap
+  int i_cg = 0, i_kx = 0, i_ky = 0;
+  const size_t w_step = (size_t)a.CoutP * 16, b_step = a.pitch_in * 16;
+  const char *i_wp = reinterpret_cast<const char *>(w_tile);
+  const char *const b_base = reinterpret_cast<const char *>(a.in) + (size_t)bch0 * b_step;
+  const char *i_bp = b_base;
+  unsigned i_blane = 0, i_slot = 0;
+  auto issue_begin = [&](int st) -> bool {  // per-lane part (the only VALU work of a stage)
+    const int iy = iy0 + i_ky, ix = ix0 + i_kx;
+    const bool ok = gvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    i_blane = ok ? (map_off + (unsigned)(iy * a.W + ix)) * 16u : map_off * 16u;
+    i_slot = (unsigned)(st & (RING - 1)) * STAGEB;
+    return ok;
+  };
+  auto issue_item = [&](int i) {  // items 0 .. NB-1 interleave pixel chunks between the weight chunks
+    if (i < 2 * NB) {
+      if ((i & 1) == 0) { glds16_s(i_wp, a_lane, lds_a + i_slot + (unsigned)(i >> 1) * 4096u); i_wp += w_step; }
+      else { glds16_s(i_bp, i_blane, lds_b + i_slot + (unsigned)(i >> 1) * (TN * 16u)); i_bp += b_step; }
+    } else {
+      glds16_s(i_wp, a_lane, lds_a + i_slot + (unsigned)(i - NB) * 4096u); i_wp += w_step;
+    }
+  };
+  auto issue_end = [&]() {
+    i_bp += (NCH - NB) * b_step;
+    if (++i_cg == spt) { i_cg = 0; i_bp = b_base; if (++i_kx == a.KW) { i_kx = 0; ++i_ky; } }
+  };
+  auto issue_all = [&](int st) -> bool {
+    const bool ok = issue_begin(st);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) issue_item(i);
+    issue_end();
+    return ok;
+  };
+  auto zero_oob = [&](int st, bool ok) {  // this lane's own NB records of the stage
+    if (!ok) {
+      u32x4 *B = ring + (size_t)(st & (RING - 1)) * (STAGEB / 16) + OPA / 16 + bch0 * TN + prow;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) B[i * TN] = u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto wait_landed = [&](auto in_flight_tag) {  // all but the newest `in flight` stages' loads of this wave
+    constexpr int n = decltype(in_flight_tag)::value * ITEMS;
+    static_assert(n == 0 || n == 6 || n == 8 || n == 12 || n == 16, "");
+    if constexpr (n == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (n == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+
+  f32x16 acc[4][NI];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+  // operand fragments, double-buffered one k-step (16 channels) ahead
+  bf16x8 af[2][4], bf[2][NI];
+  const int frag_row_a = half * 256 + wm * 128 + l31, frag_row_b = OPA / 16 + half * TN + wn * (NI * 32) + l31;
+  auto load_frags = [&](int st, int q, int slot) {
+    const u32x4 *S = ring + (size_t)(st & (RING - 1)) * (STAGEB / 16);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) af[slot][mi] = *reinterpret_cast<const bf16x8 *>(S + q * 512 + frag_row_a + mi * 32);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bf[slot][ni] = *reinterpret_cast<const bf16x8 *>(S + q * 2 * TN + frag_row_b + ni * 32);
+  };
+
+  // ok1 / ok2 / ok3: in-bounds flags of stages st+1 / st+2 / st+3 (issued, not yet published)
+  bool ok0 = issue_all(0), ok1 = false, ok2 = false, ok3 = false;
+  if (nstages > 1) ok1 = issue_all(1);
+  if (nstages > 2) ok2 = issue_all(2);
+  if (nstages > 2) wait_landed(I2{});
+  else if (nstages > 1) wait_landed(I1{});
+  else wait_landed(I0{});
+  zero_oob(0, ok0);
+  __syncthreads();
+  load_frags(0, 0, 0);
+
+  // One stage = 2 k-steps x 4 NI MFMAs, hand-scheduled like gemm_c8_pf_kernel (dense.hip): VALU work from a wave does not overlap
+  // its own MFMAs but LDS reads, SALU and DMA issue do, so the next k-step's fragment reads follow the FIRST MFMA of a k-step, the
+  // DMA items of stage st+3 follow the next MFMAs of k-step 0, and the stage barrier (wait for this wave's stage-st+1 loads, zero
+  // its out-of-map records, s_barrier) sits BEFORE k-step 1's MFMAs — whose operands are already in registers — so that the next
+  // stage's first fragments are fetched under them.
+  auto body = [&](int st, auto issue_tag, auto in_flight_tag, auto next_tag) {
+    constexpr bool ISSUE = decltype(issue_tag)::value;
+    constexpr bool NEXT = decltype(next_tag)::value;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (q == 1 && NEXT) {
+        wait_landed(in_flight_tag);
+        zero_oob(st + 1, ok1);
+        __syncthreads();
+        load_frags(st + 1, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < 4 * NI; ++t) {
+        const int mi = t / NI, ni = t % NI;
+        __builtin_amdgcn_sched_barrier(0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q][mi], bf[q][ni], acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q == 0 && t == 0) load_frags(st, 1, 1);
+        if constexpr (ISSUE) {
+          if (q == 0 && t == 1) ok3 = issue_begin(st + 3);
+          if (q == 0 && t >= 1 && t <= ITEMS) issue_item(t - 1);
+          if (q == 0 && t == ITEMS) issue_end();
+        }
+      }
+    }
+    ok1 = ok2; ok2 = ok3;
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  {
+    int st = 0;
+    for (; st + 3 < nstages; ++st) body(st, T{}, I2{}, T{});   // stages st+2, st+3 may still be in flight at the barrier
+    if (st + 2 < nstages) { body(st, F{}, I1{}, T{}); ++st; }
+    if (st + 1 < nstages) { body(st, F{}, I0{}, T{}); ++st; }
+    body(st, F{}, I0{}, F{});
+  }
+
+  // Epilogue.  (1) Loads are hoisted in front of the stores by hand: on this ISA stores count in vmcnt too, so a load issued after
+  // a store waits for that store's acknowledgement — with one block per CU, 64 interleaved bias / residual loads and stores were
+  // 64 exposed memory round trips (~50 us per block, more than the whole K loop of a 1x1 layer).  (2) The MFMA layout leaves a
+  // pixel's 8-channel record split across lanes l and l + 32 (4 channels = 8 bytes each); the store tail is bound by store
+  // INSTRUCTIONS, not bytes, so pairs of channel blocks are exchanged with v_permlane32_swap (lanes 0-31 end up with the whole
+  // record of block 2p, lanes 32-63 with block 2p + 1) and written / read as 16-byte accesses: half the instructions.
+  const int cb0 = (cout0 + wm * 128) / 8;
+  f32x4 bias[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cb = cb0 + mi * 4 + g;
+      bias[mi][g] = cb < a.Cb_out ? *reinterpret_cast<const f32x4 *>(a.bpk + cb * 8 + half * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  auto swap32 = [](unsigned &lo_keeps, unsigned &hi_keeps) {  // lanes 32-63 of the first <-> lanes 0-31 of the second
+    const auto r = __builtin_amdgcn_permlane32_swap(lo_keeps, hi_keeps, false, false);
+    lo_keeps = r[0]; hi_keeps = r[1];
+  };
+#pragma unroll
+  for (int nh = 0; nh < NI / 2; ++nh) {
+    u32x4 rr[2][4][2];  // residual records of channel block 2 gp + half
+    if (a.res) {
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) {
+        const long long pix = p0 + wn * (NI * 32) + (nh * 2 + nj) * 32 + l31;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int gp = 0; gp < 2; ++gp) {
+            const int cb = cb0 + mi * 4 + gp * 2 + half;
+            rr[nj][mi][gp] = (pix < a.P && cb < a.Cb_out) ? *reinterpret_cast<const u32x4 *>(a.res + ((size_t)cb * a.pitch_out + (size_t)pix) * 8)
+                                                          : u32x4{0u, 0u, 0u, 0u};
+          }
+      }
+    }
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+      const int ni = nh * 2 + nj;
+      const long long pix = p0 + wn * (NI * 32) + ni * 32 + l31;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          f32x4 va, vb;  // this lane's 4 channels of blocks 2 gp and 2 gp + 1
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            va[e] = acc[mi][ni][(gp * 2) * 4 + e] + bias[mi][gp * 2][e];
+            vb[e] = acc[mi][ni][(gp * 2 + 1) * 4 + e] + bias[mi][gp * 2 + 1][e];
+          }
+          if (a.res) {
+            unsigned r0 = rr[nj][mi][gp][0], r1 = rr[nj][mi][gp][1], r2 = rr[nj][mi][gp][2], r3 = rr[nj][mi][gp][3];
+            swap32(r0, r2);  // lanes 0-31: r0 r1 = own low half of block 2gp, r2 r3 = low half of 2gp+1 (from lane + 32);
+            swap32(r1, r3);  // lanes 32-63: r0 r1 = high half of 2gp (from lane - 32), r2 r3 = own high half of 2gp+1
+            va[0] += bf2f((bf16_t)(r0 & 0xffffu)); va[1] += bf2f((bf16_t)(r0 >> 16));
+            va[2] += bf2f((bf16_t)(r1 & 0xffffu)); va[3] += bf2f((bf16_t)(r1 >> 16));
+            vb[0] += bf2f((bf16_t)(r2 & 0xffffu)); vb[1] += bf2f((bf16_t)(r2 >> 16));
+            vb[2] += bf2f((bf16_t)(r3 & 0xffffu)); vb[3] += bf2f((bf16_t)(r3 >> 16));
+          }
+          if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { va[e] = va[e] < 0.0f ? 0.0f : va[e]; vb[e] = vb[e] < 0.0f ? 0.0f : vb[e]; }
+          }
+          unsigned ax = (unsigned)f2bf(va[0]) | ((unsigned)f2bf(va[1]) << 16), ay = (unsigned)f2bf(va[2]) | ((unsigned)f2bf(va[3]) << 16);
+          unsigned bx = (unsigned)f2bf(vb[0]) | ((unsigned)f2bf(vb[1]) << 16), by = (unsigned)f2bf(vb[2]) | ((unsigned)f2bf(vb[3]) << 16);
+          swap32(ax, bx);
+          swap32(ay, by);
+          const int cb = cb0 + mi * 4 + gp * 2 + half;
+          if (pix < a.P && cb < a.Cb_out) *reinterpret_cast<u32x4 *>(a.out + ((size_t)cb * a.pitch_out + (size_t)pix) * 8) = u32x4{ax, ay, bx, by};
+        }
+    }
+  }
+}
+
 __global__ void maxpool2d_c8i_bf16_kernel(const bf16_t *__restrict__ in, int Cb, int B, int H, int W, size_t pitch_in, int k, int stride, int pad,
                                           int OH, int OW, size_t pitch_out, bf16_t *__restrict__ out) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -615,6 +870,8 @@ static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b
   return MPN_OK;
 }
 
+static int g_bf16_dma_tn = 0;  // 0 = pick per layer, 128 / 256 = force (mpn_debug_set_bf16_dma_tn)
+static int g_bf16_dma = 1;  // mpn_debug_set_bf16_dma: 0 = never, 1 = large layers, 2 = every eligible layer (tests)
 static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int relu, hipStream_t s, ActI *o, bool allow_gemm = true) {
   if (c.wpk16) {  // bf16 graph
     GConvArgsB b{};
@@ -629,6 +886,27 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
     b.P = (long long)in.B * b.OH * b.OW;
     *o = ActI{out, in.B, c.Cout, b.OH, b.OW};
     b.pitch_in = in.pitch(); b.pitch_out = o->pitch();
+    // large layers: the 256-cout LDS-DMA kernel (needs whole 256-cout tiles, 32-channel stages, 32-bit record offsets)
+    if (g_bf16_dma && b.CoutP % 256 == 0 && b.nch2 % 4 == 0 && b.P >= (g_bf16_dma == 2 ? 1 : 256 * 128) && (size_t)in.B * in.H * in.W * 16 < ((size_t)1 << 32)) {
+      const int ny = b.CoutP / 256;
+      // pixel-tile width: whichever fills the 256 CUs in fewer block-rounds x work per block
+      auto rounds_cost = [&](int tn) { const long long nb = (b.P + tn - 1) / tn * ny; return (nb + 255) / 256 * tn; };
+      const bool narrow = g_bf16_dma_tn == 128 || (g_bf16_dma_tn == 0 && rounds_cost(128) < rounds_cost(256));
+      const int tn = narrow ? 128 : 256;
+      const size_t LDS = (size_t)4 * (4 * 256 * 16 + 4 * tn * 16);
+      static bool attr = false;
+      if (!attr) {
+        MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768));
+        MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 24576));
+        attr = true;
+      }
+      const int nx = (int)((b.P + tn - 1) / tn);
+      const dim3 gridd((unsigned)(((nx + 7) / 8) * 8 * ny));
+      if (narrow) hipLaunchKernelGGL(conv2d_c8i_bf16_dma_kernel<2>, gridd, dim3(256), LDS, s, b, nx, ny);
+      else hipLaunchKernelGGL(conv2d_c8i_bf16_dma_kernel<4>, gridd, dim3(256), LDS, s, b, nx, ny);
+      MPN_CHECK_LAUNCH();
+      return MPN_OK;
+    }
     dim3 grid((unsigned)((b.P + 127) / 128), (unsigned)(b.CoutP / 128));
     // 32-channel stages (32 KiB of LDS, 4-5 blocks per CU) measured 3 % faster than 64-channel ones on ResNet-50; either way this
     // kernel is bound by its operand loads (64 FLOP per loaded byte at a 128 x 128 tile), not by the bf16 matrix pipe
@@ -1002,3 +1280,6 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
 }
 
 }  // namespace mpn
+
+extern "C" void mpn_debug_set_bf16_dma(int v) { mpn::g_bf16_dma = v; }
+extern "C" void mpn_debug_set_bf16_dma_tn(int v) { mpn::g_bf16_dma_tn = v; }

@@ -103,11 +103,28 @@ def test_resnet_iterative_localisation_and_voting_run(dev):
     assert int(net._n_dets.item()) > 0
 
 
-@pytest.mark.parametrize("bt,blocks,width", [("bottleneck", [1, 1, 1, 1], 16), ("basic", [1, 1, 1, 2], 16), ("bottleneck", [1, 1, 1, 1], 64)])
-def test_resnet_bf16_vs_bf16_oracle_and_fp32(O, dev, bt, blocks, width):
+@pytest.mark.parametrize("bt,blocks,width,dma,tn", [("bottleneck", [1, 1, 1, 1], 16, 1, 0), ("basic", [1, 1, 1, 2], 16, 1, 0), ("bottleneck", [1, 1, 1, 1], 64, 1, 0),
+                                                    ("bottleneck", [1, 1, 1, 1], 64, 2, 256), ("basic", [1, 1, 1, 2], 64, 2, 256),
+                                                    ("bottleneck", [1, 1, 1, 1], 64, 2, 128), ("basic", [1, 1, 1, 2], 64, 2, 128)])
+def test_resnet_bf16_vs_bf16_oracle_and_fp32(O, dev, bt, blocks, width, dma, tn):
     """bf16 graph (bf16 activations / weights, fp32 accumulate): against the oracle run with the same roundings (weights, the
     transformed image and every layer output rounded to bf16) the scores agree to bf16 accumulation-order noise; against
-    the fp32 oracle they agree to bf16 precision.  width 64 exercises the 32-channel-per-stage kernel variant (widths 16: 16-channel)."""
+    the fp32 oracle they agree to bf16 precision.  width 64 exercises the 32-channel-per-stage kernel variant (widths 16: 16-channel);
+    dma=2 forces the 256-cout LDS-DMA kernel onto every eligible layer (by default only layers with >= 32768 output pixels), tn its
+    pixel-tile width (0 = picked per layer)."""
+    from multipathnet_amd import models
+    import multipathnet_amd
+    lib = multipathnet_amd.load()
+    lib.mpn_debug_set_bf16_dma(dma)
+    lib.mpn_debug_set_bf16_dma_tn(tn)
+    try:
+        _bf16_case(O, dev, bt, blocks, width)
+    finally:
+        lib.mpn_debug_set_bf16_dma(1)
+        lib.mpn_debug_set_bf16_dma_tn(0)
+
+
+def _bf16_case(O, dev, bt, blocks, width):
     from multipathnet_amd import models
     H, W, N, C = 97, 131, 37, 6
     R = models.synthetic_resnet_params(depth=0, n_classes=C, base_width=width, blocks=blocks, block_type=bt, seed=23)
