@@ -292,6 +292,8 @@ struct GConvArgsB {
   size_t pitch_in, pitch_out;
   int CoutP, Cb_out, KH, KW, sh, sw, ph, pw, OH, OW, relu;
   long long P;
+  float *part;           // split-K (128 x 128 kernel only): fp32 partial slabs [split][CoutP/8][pitch_out][8], else nullptr
+  int stages_per_split;
 };
 
 // KP = chunk PAIRS (16 input channels) per LDS stage: 4 * KP MFMAs per wave between two barriers (instantiated: 1 and 2)
@@ -350,12 +352,15 @@ __global__ __launch_bounds__(256) void conv2d_c8i_bf16_kernel(GConvArgsB a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
-  fetch(0);
+  // split-K: blockIdx.z owns a contiguous range of stages (small layers: too few 128 x 128 tiles to fill 256 CUs otherwise)
+  const int st0 = a.part ? (int)blockIdx.z * a.stages_per_split : 0;
+  const int st1 = a.part ? min(nstages, st0 + a.stages_per_split) : nstages;
+  fetch(st0);
   stash(0);
   __syncthreads();
-  for (int st = 0; st < nstages; ++st) {
-    const int buf = st & 1;
-    if (st + 1 < nstages) fetch(st + 1);
+  for (int st = st0; st < st1; ++st) {
+    const int buf = (st - st0) & 1;
+    if (st + 1 < st1) fetch(st + 1);
 #pragma unroll
     for (int q = 0; q < KP; ++q) {
       bf16x8 af[2], bf[2];
@@ -369,10 +374,29 @@ __global__ __launch_bounds__(256) void conv2d_c8i_bf16_kernel(GConvArgsB a) {
         for (int ni = 0; ni < 2; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
     }
-    if (st + 1 < nstages) stash(buf ^ 1);
+    if (st + 1 < st1) stash(buf ^ 1);
     __syncthreads();
   }
 
+  if (a.part) {  // raw fp32 partial sums; conv_splitk_finalize_bf16_kernel adds bias / residual, applies ReLU and rounds
+    float *slab = a.part + (size_t)blockIdx.z * (a.CoutP / 8) * a.pitch_out * 8;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const long long pix = p0 + wn * 64 + ni * 32 + l31;
+      if (pix >= a.P) continue;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int cb = (cout0 + wm * 64 + mi * 32) / 8 + g;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][g * 4 + e];
+          *reinterpret_cast<f32x4 *>(slab + ((size_t)cb * a.pitch_out + (size_t)pix) * 8 + half * 4) = v;
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
     const long long pix = p0 + wn * 64 + ni * 32 + l31;
@@ -399,6 +423,34 @@ __global__ __launch_bounds__(256) void conv2d_c8i_bf16_kernel(GConvArgsB a) {
         *reinterpret_cast<u16x4 *>(a.out + off) = o;
       }
   }
+}
+
+// split-K finalize: sum the slabs in a fixed order (deterministic), + bias (+ residual), ReLU, round to bf16
+__global__ void conv_splitk_finalize_bf16_kernel(const float *__restrict__ part, int splits, int CbP, int Cb_out, size_t pitch, long long P,
+                                                 const float *__restrict__ bpk, const bf16_t *res, int relu, bf16_t *out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)Cb_out * (size_t)P * 2;
+  if (t >= total) return;
+  const int h = (int)(t & 1);
+  const size_t r = t >> 1;
+  const size_t pix = r % (size_t)P;
+  const int cb = (int)(r / (size_t)P);
+  const size_t off = ((size_t)cb * pitch + pix) * 8 + h * 4;
+  f32x4 v = *reinterpret_cast<const f32x4 *>(bpk + cb * 8 + h * 4);
+  for (int z = 0; z < splits; ++z) {
+    const f32x4 p4 = *reinterpret_cast<const f32x4 *>(part + (size_t)z * CbP * pitch * 8 + off);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += p4[e];
+  }
+  if (res) {
+    const u16x4 r4 = *reinterpret_cast<const u16x4 *>(res + off);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += bf2f(r4[e]);
+  }
+  u16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = f2bf((relu && v[e] < 0.0f) ? 0.0f : v[e]);
+  *reinterpret_cast<u16x4 *>(out + off) = o;
 }
 
 // ---- large layers: 256 couts x 256 pixels per block, operands gathered straight into LDS by the DMA engine ----------------
@@ -731,7 +783,100 @@ __global__ void roi_pool_c8i_bf16_kernel(const bf16_t *__restrict__ feat, int Cb
   *reinterpret_cast<u16x4 *>(out + ((size_t)cb * pitch_o + ((size_t)n * PH + ph) * PW + pw) * 8 + h * 4) = o;
 }
 
-// average pool of the bf16 maps into the fp32 C8 matrix the (fp32) head GEMM reads
+// ---- ROI max-pooling, bf16, fast path ---------------------------------------------------------------------------------------
+// The kernel above spends ~200 instructions per 8 output bytes (per-thread bin arithmetic, 4 channels per thread).  Here the
+// feature map is first re-coded so that bf16 order is int16 order (negative values: magnitude bits flipped — a monotone,
+// self-inverse map, so max commutes with it and the result is bit-identical), and a thread owns one (roi, bin) for a run of
+// channel blocks: the bin arithmetic is done once, each pixel record (8 channels) costs one 16-byte load + 4 v_pk_max_i16, and a
+// wave's stores are 64 consecutive records.
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf16x2_sortable(unsigned x) { return x ^ (((x >> 15) & 0x00010001u) * 0x7fffu); }
+
+__global__ void bf16_sortable_kernel(const u32x4 *__restrict__ in, size_t n, u32x4 *__restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  u32x4 v = in[t];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = bf16x2_sortable(v[e]);
+  out[t] = v;
+}
+
+template <int CBG>  // channel blocks per thread (grid.y = Cb / CBG)
+__global__ __launch_bounds__(256) void roi_pool_c8i_bf16_sorted_kernel(const u32x4 *__restrict__ feat, int H, int W, size_t pitch_f,
+                                                                        const float *__restrict__ rois, int roi_stride, int N, int PH, int PW, float scale,
+                                                                        u32x4 *__restrict__ out, size_t pitch_o) {
+  const int PP = PH * PW;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (roi, bin): the output row of the pooled batch
+  if (t >= (size_t)N * PP) return;
+  const int n = (int)(t / PP), bin = (int)(t - (size_t)n * PP);
+  const int ph = bin / PW, pw = bin - ph * PW;
+  const float *ro = rois + (size_t)roi_stride * n;
+  const int sw = (int)roundf((ro[1] - 1.0f) * scale), sh = (int)roundf((ro[2] - 1.0f) * scale);
+  const int ew = (int)roundf((ro[3] - 1.0f) * scale), eh = (int)roundf((ro[4] - 1.0f) * scale);
+  const int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
+  const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+  int hs = (int)floorf((float)ph * bh) + sh, he = (int)ceilf((float)(ph + 1) * bh) + sh;
+  int ws = (int)floorf((float)pw * bw) + sw, we = (int)ceilf((float)(pw + 1) * bw) + sw;
+  hs = min(max(hs, 0), H); he = min(max(he, 0), H);
+  ws = min(max(ws, 0), W); we = min(max(we, 0), W);
+  const bool empty = (he <= hs) || (we <= ws);
+  const int cb0 = blockIdx.y * CBG;
+  const u32x4 *fp = feat + (size_t)cb0 * pitch_f;
+  u32x4 *op = out + (size_t)cb0 * pitch_o + t;
+  const unsigned lowest = 0x80008000u;  // int16 minimum in both halves
+  u32x4 m[CBG];
+#pragma unroll
+  for (int c = 0; c < CBG; ++c) m[c] = u32x4{lowest, lowest, lowest, lowest};
+  for (int y = hs; y < he; ++y)
+    for (int x = ws; x < we; ++x) {
+      const size_t px = (size_t)y * W + x;
+#pragma unroll
+      for (int c = 0; c < CBG; ++c) {
+        const u32x4 v = fp[(size_t)c * pitch_f + px];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned cur = m[c][e], val = v[e];  // scalar copies: __builtin_bit_cast of a vector-element lvalue reads element 0
+          const i16x2 mx = __builtin_elementwise_max(__builtin_bit_cast(i16x2, cur), __builtin_bit_cast(i16x2, val));
+          m[c][e] = __builtin_bit_cast(unsigned, mx);
+        }
+      }
+    }
+#pragma unroll
+  for (int c = 0; c < CBG; ++c) {
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = empty ? 0u : bf16x2_sortable(m[c][e]);
+    op[(size_t)c * pitch_o] = o;
+  }
+}
+
+// average pool of the bf16 maps into the fp32 C8 matrix the (fp32) head GEMM reads.  Block = one channel block x 16 maps: the
+// 16 * HW records are read as consecutive 16-byte loads (fully coalesced) into LDS as fp32, then 128 threads (map, channel) sum
+// their HW values in pixel order (the order of the plain kernel below, so the result is bit-identical to it).
+__global__ __launch_bounds__(256) void avgpool_c8i_bf16_to_c8_lds_kernel(const bf16_t *__restrict__ in, int N, int HW, size_t pitch, float inv,
+                                                                          float *__restrict__ out, int Mp) {
+  extern __shared__ float sm[];  // [16 * HW][8 + 1]: odd row stride -> the 128 summing threads hit distinct banks
+  const int cb = blockIdx.y, n0 = blockIdx.x * 16;
+  const int nm = min(16, N - n0);
+  const int nrec = nm * HW;
+  const u32x4 *src = reinterpret_cast<const u32x4 *>(in) + (size_t)cb * pitch + (size_t)n0 * HW;
+  for (int i = threadIdx.x; i < nrec; i += 256) {
+    const u32x4 v = src[i];
+    float *d = sm + i * 9;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { d[2 * e] = __uint_as_float(v[e] << 16); d[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u); }
+  }
+  __syncthreads();
+  const int m = threadIdx.x >> 3, c = threadIdx.x & 7;
+  if (threadIdx.x < 128 && m < nm) {
+    const float *d = sm + (size_t)m * HW * 9 + c;
+    float acc = 0.0f;
+    for (int i = 0; i < HW; ++i) acc += d[i * 9];
+    out[((size_t)cb * Mp + n0 + m) * 8 + c] = acc * inv;
+  }
+}
+
+
 __global__ void avgpool_c8i_bf16_to_c8_kernel(const bf16_t *__restrict__ in, int N, int Cb, int HW, size_t pitch, float inv, float *__restrict__ out,
                                               int Mp) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -796,6 +941,8 @@ struct RnConv {
   float *wpk = nullptr, *bpk = nullptr;
   float *lin_w = nullptr, *lin_b = nullptr;  // 1x1 / stride 1 with Cin % 64 == 0: also packed for the tuned GEMM (linear_c8)
   bf16_t *wpk16 = nullptr;                   // bf16 graph: [tap][nch2][CoutP][8]
+  float *ws = nullptr;                       // the graph's split-K workspace (bf16 graph)
+  size_t ws_bytes = 0;
 };
 struct RnBlock {
   std::vector<RnConv> convs;
@@ -822,8 +969,13 @@ struct ResNetGraph {
   size_t tb_elems = 0, hb_elems = 0;
   float *feat = nullptr;         // points into tb[]: layer3 output of the last trunk run
   int feat_h = 0, feat_w = 0, last_h = -1, last_w = -1;
+  bf16_t *feat_sorted = nullptr; // order-preserving int16 re-coding of the cached feature map (bf16 ROI pooling), rebuilt per trunk run
+  size_t feat_sorted_elems = 0;
+  bool feat_sorted_valid = false;
+  float *splitk_ws = nullptr;    // fp32 partial slabs of split-K convolutions (bf16 graph; one stream at a time, like tb / hb)
   std::vector<void *> allocs;
 };
+constexpr size_t SPLITK_WS_BYTES = (size_t)96 << 20;
 
 static int rn_alloc(ResNetGraph *g, float **p, size_t bytes) {
   void *q = nullptr;
@@ -841,6 +993,11 @@ static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b
     int rc = rn_alloc(g, &w16, total * sizeof(bf16_t));
     if (rc) return rc;
     c.wpk16 = reinterpret_cast<bf16_t *>(w16);
+    if (!g->splitk_ws) {
+      rc = rn_alloc(g, &g->splitk_ws, SPLITK_WS_BYTES);
+      if (rc) return rc;
+    }
+    c.ws = g->splitk_ws; c.ws_bytes = SPLITK_WS_BYTES;
     rc = rn_alloc(g, &c.bpk, (size_t)CoutP * sizeof(float));
     if (rc) return rc;
     MPN_CHECK_HIP(hipMemset(c.bpk, 0, (size_t)CoutP * sizeof(float)));
@@ -870,6 +1027,8 @@ static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b
   return MPN_OK;
 }
 
+static int g_bf16_fast_pool = 3;       // bit 0: sorted-int16 ROI pooling, bit 1: LDS average pooling (0 = the plain kernels; mpn_debug_set_bf16_fast_pool)
+static int g_bf16_split_target = 256;  // split-K aims at this many blocks (0 = never split; mpn_debug_set_bf16_split_target)
 static int g_bf16_dma_tn = 0;  // 0 = pick per layer, 128 / 256 = force (mpn_debug_set_bf16_dma_tn)
 static int g_bf16_dma = 1;  // mpn_debug_set_bf16_dma: 0 = never, 1 = large layers, 2 = every eligible layer (tests)
 static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int relu, hipStream_t s, ActI *o, bool allow_gemm = true) {
@@ -908,6 +1067,29 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
       return MPN_OK;
     }
     dim3 grid((unsigned)((b.P + 127) / 128), (unsigned)(b.CoutP / 128));
+    // small layers (layer2 / layer3 of the trunk: a few dozen tiles for 256 CUs): split K across blockIdx.z into fp32 slabs
+    {
+      const int kp = b.nch2 % 4 == 0 ? 2 : 1;
+      const int nstages = b.KH * b.KW * (b.nch2 / (2 * kp));
+      const long long nblocks = (long long)grid.x * grid.y;
+      const size_t slab = (size_t)b.CoutP * o->pitch() * sizeof(float);
+      int want = (int)std::min<long long>(nstages / 2, (g_bf16_split_target + nblocks - 1) / nblocks);
+      if (c.ws && slab) want = (int)std::min<size_t>((size_t)want, c.ws_bytes / slab); else want = 1;
+      if (g_bf16_split_target > 0 && nblocks < 192 && want >= 2) {
+        b.stages_per_split = (nstages + want - 1) / want;
+        const int splits = (nstages + b.stages_per_split - 1) / b.stages_per_split;
+        b.part = c.ws;
+        grid.z = (unsigned)splits;
+        if (kp == 2) hipLaunchKernelGGL((conv2d_c8i_bf16_kernel<2>), grid, dim3(256), 0, s, b);
+        else hipLaunchKernelGGL((conv2d_c8i_bf16_kernel<1>), grid, dim3(256), 0, s, b);
+        MPN_CHECK_LAUNCH();
+        const size_t total = (size_t)b.Cb_out * (size_t)b.P * 2;
+        hipLaunchKernelGGL(conv_splitk_finalize_bf16_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, c.ws, splits, b.CoutP / 8, b.Cb_out, b.pitch_out,
+                           b.P, b.bpk, b.res, b.relu, b.out);
+        MPN_CHECK_LAUNCH();
+        return MPN_OK;
+      }
+    }
     // 32-channel stages (32 KiB of LDS, 4-5 blocks per CU) measured 3 % faster than 64-channel ones on ResNet-50; either way this
     // kernel is bound by its operand loads (64 FLOP per loaded byte at a 128 x 128 tile), not by the bf16 matrix pipe
     if (b.nch2 % 4 == 0) hipLaunchKernelGGL((conv2d_c8i_bf16_kernel<2>), grid, dim3(256), 0, s, b);
@@ -1211,7 +1393,7 @@ int resnet_trunk_forward(ResNetGraph *g, const float *d_image, int H, int W, con
     if (rc == MPN_OK) rc = graph_run(g, g->g_trunk, g->t_trunk, 1, s);
     if (rc) return rc;
     const GTensor &f = g->t_trunk[g->feat_tensor];
-    g->feat = f.buf; g->feat_h = f.H; g->feat_w = f.W; g->last_h = H; g->last_w = W;
+    g->feat = f.buf; g->feat_h = f.H; g->feat_w = f.W; g->last_h = H; g->last_w = W; g->feat_sorted_valid = false;
     return MPN_OK;
   }
   ActI x{g->img, 1, 3, H, W}, y;
@@ -1235,7 +1417,7 @@ int resnet_trunk_forward(ResNetGraph *g, const float *d_image, int H, int W, con
     if (rc) return rc;
     cur = y;
   }
-  g->feat = cur.p; g->feat_h = cur.H; g->feat_w = cur.W; g->last_h = H; g->last_w = W;
+  g->feat = cur.p; g->feat_h = cur.H; g->feat_w = cur.W; g->last_h = H; g->last_w = W; g->feat_sorted_valid = false;
   return MPN_OK;
 }
 
@@ -1247,7 +1429,24 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
   {
     const size_t total = (size_t)N * Cb * PH * PH * 2;
     const ActI fa{g->feat, 1, g->feat_c, g->feat_h, g->feat_w}, pa{pool_dst, N, g->feat_c, PH, PH};
-    if (g->bf16)
+    if (g->bf16 && (g_bf16_fast_pool & 1) && Cb % 4 == 0) {
+      const size_t need = (size_t)Cb * fa.pitch() * 8;
+      if (g->feat_sorted_elems < need) {  // first use (or a larger image than any before): outside the steady state
+        float *q = nullptr;
+        int rc = rn_alloc(g, &q, need * sizeof(bf16_t));
+        if (rc) return rc;
+        g->feat_sorted = reinterpret_cast<bf16_t *>(q); g->feat_sorted_elems = need; g->feat_sorted_valid = false;
+      }
+      if (!g->feat_sorted_valid) {
+        hipLaunchKernelGGL(bf16_sortable_kernel, dim3((unsigned)cdiv_sz(need / 8, 256)), dim3(256), 0, s, reinterpret_cast<const u32x4 *>(g->feat), need / 8,
+                           reinterpret_cast<u32x4 *>(g->feat_sorted));
+        MPN_CHECK_LAUNCH();
+        g->feat_sorted_valid = true;
+      }
+      hipLaunchKernelGGL(roi_pool_c8i_bf16_sorted_kernel<4>, dim3((unsigned)cdiv_sz((size_t)N * PH * PH, 256), (unsigned)(Cb / 4)), dim3(256), 0, s,
+                         reinterpret_cast<const u32x4 *>(g->feat_sorted), g->feat_h, g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale,
+                         reinterpret_cast<u32x4 *>(pool_dst), pa.pitch());
+    } else if (g->bf16)
       hipLaunchKernelGGL(roi_pool_c8i_bf16_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, reinterpret_cast<const bf16_t *>(g->feat), Cb, g->feat_h,
                          g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale, reinterpret_cast<bf16_t *>(pool_dst), pa.pitch());
     else
@@ -1269,7 +1468,10 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
     cur = y;
   }
   const size_t total = (size_t)N * cur.Cb() * 2;
-  if (g->bf16)
+  if (g->bf16 && (g_bf16_fast_pool & 2) && (size_t)16 * cur.H * cur.W * 9 * sizeof(float) <= 64 * 1024)
+    hipLaunchKernelGGL(avgpool_c8i_bf16_to_c8_lds_kernel, dim3((unsigned)((N + 15) / 16), (unsigned)cur.Cb()), dim3(256), (size_t)16 * cur.H * cur.W * 9 * sizeof(float), s,
+                       reinterpret_cast<const bf16_t *>(cur.p), N, cur.H * cur.W, cur.pitch(), 1.0f / (float)(cur.H * cur.W), d_feat_c8, Mp);
+  else if (g->bf16)
     hipLaunchKernelGGL(avgpool_c8i_bf16_to_c8_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, reinterpret_cast<const bf16_t *>(cur.p), N, cur.Cb(),
                        cur.H * cur.W, cur.pitch(), 1.0f / (float)(cur.H * cur.W), d_feat_c8, Mp);
   else
@@ -1283,3 +1485,5 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
 
 extern "C" void mpn_debug_set_bf16_dma(int v) { mpn::g_bf16_dma = v; }
 extern "C" void mpn_debug_set_bf16_dma_tn(int v) { mpn::g_bf16_dma_tn = v; }
+extern "C" void mpn_debug_set_bf16_split_target(int v) { mpn::g_bf16_split_target = v; }
+extern "C" void mpn_debug_set_bf16_fast_pool(int v) { mpn::g_bf16_fast_pool = v; }

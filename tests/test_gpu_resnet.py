@@ -139,3 +139,27 @@ def _bf16_case(O, dev, bt, blocks, width):
     assert np.abs(s - sb).max() < 3e-3          # same roundings: only fp32 summation order + rare 1-ulp bf16 flips differ
     assert np.abs(s - sf).max() < 3e-2          # bf16 vs fp32 arithmetic
     assert np.abs(s.sum(1) - 1).max() < 1e-5
+
+
+def test_resnet_bf16_fast_pooling_is_bit_identical(dev):
+    """the int16-sortable ROI max-pooling and the LDS average pooling of the bf16 graph reproduce the plain kernels' bits
+    (max commutes with the monotone re-coding; the average sums in the same order)"""
+    import multipathnet_amd
+    from multipathnet_amd import models
+    lib = multipathnet_amd.load()
+    H, W, N, C = 97, 131, 37, 6
+    R = models.synthetic_resnet_params(depth=0, n_classes=C, base_width=16, blocks=[1, 1, 1, 1], block_type="bottleneck", seed=5)
+    im, boxes = _inputs(H, W, N, 9)
+    boxes[0, :] = [120.0, 90.0, 121.0, 91.0]      # a tiny ROI: bins narrower than a feature cell
+    boxes[1, :] = [-40.0, -30.0, 10.0, 12.0]      # partly outside the image: empty bins -> 0
+    net = models.ResNetFRCNN(R, max_h=H, max_w=W, max_rois=64, top_k=20, bf16=True)
+    out = []
+    for fast in (0, 1, 2, 3):  # bit 0: ROI pooling, bit 1: average pooling
+        lib.mpn_debug_set_bf16_fast_pool(fast)
+        try:
+            s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+            out.append((s.cpu().numpy().copy(), b.cpu().numpy().copy()))
+        finally:
+            lib.mpn_debug_set_bf16_fast_pool(3)
+    for k in (1, 2, 3):
+        assert np.array_equal(out[0][0], out[k][0]) and np.array_equal(out[0][1], out[k][1]), k

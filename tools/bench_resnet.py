@@ -5,6 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from multipathnet_amd import models
+import multipathnet_amd
+if os.environ.get("MPN_SPLIT_TARGET"):  # A/B: split-K block target of the bf16 128 x 128 convolution kernel (0 = never split)
+    multipathnet_amd.load().mpn_debug_set_bf16_split_target(int(os.environ["MPN_SPLIT_TARGET"]))
 depth = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 mpn = "mpn" in sys.argv[3:]

@@ -12,7 +12,7 @@ python3 - "$t" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-sel = [r for r in rows if "conv2d_c8i_bf16" in r["Kernel_Name"]]
+sel = [r for r in rows if "mpn::" in r["Kernel_Name"] and "pack_" not in r["Kernel_Name"]]
 n = len(sel) // 6
 for r in sel[-n:]:
     print(r["Kernel_Name"][5:35], r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size"), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000.0)
