@@ -466,12 +466,14 @@ __device__ __forceinline__ void glds16_s(const void *base_uniform, unsigned lane
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_byte_addr_uniform), "v"(lane_byte_off), "s"(base_uniform) : "memory");
 }
 
-// NI = 32-pixel MFMA tiles per wave along the pixel axis: 4 -> 256-pixel block tile, 2 -> 128 (picked by the host when that
-// packs the grid into fewer, fuller rounds of 256 blocks: a 512-cout layer on 49 000 pixels is 384 blocks = 1.5 rounds at 256
-// pixels but exactly 3 rounds of half-size blocks at 128).
+// NI = 32-pixel MFMA tiles per wave along the pixel axis.  NI = 4: 256-pixel block tile, 4-deep ring (128 KiB), all 512
+// registers, one block per CU.  NI = 2: 128-pixel tile, 3-deep ring (72 KiB), <= 256 registers, TWO blocks per CU — one block's
+// prologue / epilogue (~10 us with nothing to overlap them at one block per CU) runs under the other's K loop, and the host picks
+// it when it packs the grid into fuller rounds (a 512-cout layer on 49 000 pixels is 384 blocks = 1.5 rounds of 256 at 256 pixels).
 template <int NI>
-__global__ __launch_bounds__(256) void conv2d_c8i_bf16_dma_kernel(GConvArgsB a, int nx, int ny) {
-  constexpr int NCH = 4, RING = 4, TN = 64 * NI;
+__global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv2d_c8i_bf16_dma_kernel(GConvArgsB a, int nx, int ny) {
+  constexpr int NCH = 4, TN = 64 * NI;
+  constexpr int RING = NI == 2 ? 3 : 4, LOOK = RING - 1;         // stages in the ring / stages the DMA runs ahead
   constexpr int NB = NI;                                          // pixel-chunk DMA items per wave per stage (weights: 4)
   constexpr int ITEMS = NCH + NB;
   constexpr unsigned OPA = NCH * 256 * 16, OPBB = NCH * TN * 16, STAGEB = OPA + OPBB;  // bytes: weights / pixels / stage
@@ -515,14 +517,14 @@ __global__ __launch_bounds__(256) void conv2d_c8i_bf16_dma_kernel(GConvArgsB a, 
   const char *const b_base = reinterpret_cast<const char *>(a.in) + (size_t)bch0 * b_step;
   const char *i_bp = b_base;
   unsigned i_blane = 0, i_slot = 0;
-  auto issue_begin = [&](int st) -> bool {  // per-lane part (the only VALU work of a stage)
+  auto issue_begin = [&](int slot) -> bool {  // per-lane part (the only VALU work of a stage)
     const int iy = iy0 + i_ky, ix = ix0 + i_kx;
     const bool ok = gvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
     i_blane = ok ? (map_off + (unsigned)(iy * a.W + ix)) * 16u : map_off * 16u;
-    i_slot = (unsigned)(st & (RING - 1)) * STAGEB;
+    i_slot = (unsigned)slot * STAGEB;
     return ok;
   };
-  auto issue_item = [&](int i) {  // items 0 .. NB-1 interleave pixel chunks between the weight chunks
+  auto issue_item = [&](int i) {  // items 0 .. 2 NB - 1 interleave pixel chunks between the weight chunks
     if (i < 2 * NB) {
       if ((i & 1) == 0) { glds16_s(i_wp, a_lane, lds_a + i_slot + (unsigned)(i >> 1) * 4096u); i_wp += w_step; }
       else { glds16_s(i_bp, i_blane, lds_b + i_slot + (unsigned)(i >> 1) * (TN * 16u)); i_bp += b_step; }
@@ -534,16 +536,16 @@ __global__ __launch_bounds__(256) void conv2d_c8i_bf16_dma_kernel(GConvArgsB a, 
     i_bp += (NCH - NB) * b_step;
     if (++i_cg == spt) { i_cg = 0; i_bp = b_base; if (++i_kx == a.KW) { i_kx = 0; ++i_ky; } }
   };
-  auto issue_all = [&](int st) -> bool {
-    const bool ok = issue_begin(st);
+  auto issue_all = [&](int slot) -> bool {
+    const bool ok = issue_begin(slot);
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) issue_item(i);
     issue_end();
     return ok;
   };
-  auto zero_oob = [&](int st, bool ok) {  // this lane's own NB records of the stage
+  auto zero_oob = [&](int slot, bool ok) {  // this lane's own NB records of the stage
     if (!ok) {
-      u32x4 *B = ring + (size_t)(st & (RING - 1)) * (STAGEB / 16) + OPA / 16 + bch0 * TN + prow;
+      u32x4 *B = ring + (size_t)slot * (STAGEB / 16) + OPA / 16 + bch0 * TN + prow;
 #pragma unroll
       for (int i = 0; i < NB; ++i) B[i * TN] = u32x4{0u, 0u, 0u, 0u};
     }
@@ -560,6 +562,7 @@ __global__ __launch_bounds__(256) void conv2d_c8i_bf16_dma_kernel(GConvArgsB a, 
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   using I2 = std::integral_constant<int, 2>;
+  auto next_slot = [](int sl) { return sl + 1 == RING ? 0 : sl + 1; };
 
   f32x16 acc[4][NI];
 #pragma unroll
@@ -572,40 +575,44 @@ __global__ __launch_bounds__(256) void conv2d_c8i_bf16_dma_kernel(GConvArgsB a, 
   // operand fragments, double-buffered one k-step (16 channels) ahead
   bf16x8 af[2][4], bf[2][NI];
   const int frag_row_a = half * 256 + wm * 128 + l31, frag_row_b = OPA / 16 + half * TN + wn * (NI * 32) + l31;
-  auto load_frags = [&](int st, int q, int slot) {
-    const u32x4 *S = ring + (size_t)(st & (RING - 1)) * (STAGEB / 16);
+  auto load_frags = [&](int slot, int q, int fs) {
+    const u32x4 *S = ring + (size_t)slot * (STAGEB / 16);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) af[slot][mi] = *reinterpret_cast<const bf16x8 *>(S + q * 512 + frag_row_a + mi * 32);
+    for (int mi = 0; mi < 4; ++mi) af[fs][mi] = *reinterpret_cast<const bf16x8 *>(S + q * 512 + frag_row_a + mi * 32);
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) bf[slot][ni] = *reinterpret_cast<const bf16x8 *>(S + q * 2 * TN + frag_row_b + ni * 32);
+    for (int ni = 0; ni < NI; ++ni) bf[fs][ni] = *reinterpret_cast<const bf16x8 *>(S + q * 2 * TN + frag_row_b + ni * 32);
   };
 
-  // ok1 / ok2 / ok3: in-bounds flags of stages st+1 / st+2 / st+3 (issued, not yet published)
-  bool ok0 = issue_all(0), ok1 = false, ok2 = false, ok3 = false;
-  if (nstages > 1) ok1 = issue_all(1);
-  if (nstages > 2) ok2 = issue_all(2);
-  if (nstages > 2) wait_landed(I2{});
+  // okn[k]: in-bounds flag of stage st + 1 + k (issued, not yet published); slots: stage st lives in ring slot st % RING
+  bool okn[3] = {false, false, false};
+  const bool ok0 = issue_all(0);
+  if (nstages > 1) okn[0] = issue_all(1);
+  if (LOOK > 2 && nstages > 2) okn[1] = issue_all(2);
+  if (LOOK > 2 && nstages > 2) wait_landed(I2{});
   else if (nstages > 1) wait_landed(I1{});
   else wait_landed(I0{});
   zero_oob(0, ok0);
   __syncthreads();
   load_frags(0, 0, 0);
+  int s_cur = 0;                              // slot of stage st
+  int s_iss = nstages > LOOK ? LOOK : 0;      // slot of stage st + LOOK
 
   // One stage = 2 k-steps x 4 NI MFMAs, hand-scheduled like gemm_c8_pf_kernel (dense.hip): VALU work from a wave does not overlap
   // its own MFMAs but LDS reads, SALU and DMA issue do, so the next k-step's fragment reads follow the FIRST MFMA of a k-step, the
-  // DMA items of stage st+3 follow the next MFMAs of k-step 0, and the stage barrier (wait for this wave's stage-st+1 loads, zero
-  // its out-of-map records, s_barrier) sits BEFORE k-step 1's MFMAs — whose operands are already in registers — so that the next
-  // stage's first fragments are fetched under them.
-  auto body = [&](int st, auto issue_tag, auto in_flight_tag, auto next_tag) {
+  // DMA items of stage st+LOOK follow the next MFMAs of k-step 0, and the stage barrier (wait for this wave's stage-st+1 loads,
+  // zero its out-of-map records, s_barrier) sits BEFORE k-step 1's MFMAs — whose operands are already in registers — so that the
+  // next stage's first fragments are fetched under them.
+  auto body = [&](auto issue_tag, auto in_flight_tag, auto next_tag) {
     constexpr bool ISSUE = decltype(issue_tag)::value;
     constexpr bool NEXT = decltype(next_tag)::value;
+    const int s_nxt = next_slot(s_cur);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       if (q == 1 && NEXT) {
         wait_landed(in_flight_tag);
-        zero_oob(st + 1, ok1);
+        zero_oob(s_nxt, okn[0]);
         __syncthreads();
-        load_frags(st + 1, 0, 0);
+        load_frags(s_nxt, 0, 0);
       }
 #pragma unroll
       for (int t = 0; t < 4 * NI; ++t) {
@@ -613,96 +620,97 @@ __global__ __launch_bounds__(256) void conv2d_c8i_bf16_dma_kernel(GConvArgsB a, 
         __builtin_amdgcn_sched_barrier(0);
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q][mi], bf[q][ni], acc[mi][ni], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (q == 0 && t == 0) load_frags(st, 1, 1);
+        if (q == 0 && t == 0) load_frags(s_cur, 1, 1);
         if constexpr (ISSUE) {
-          if (q == 0 && t == 1) ok3 = issue_begin(st + 3);
+          if (q == 0 && t == 1) okn[LOOK - 1] = issue_begin(s_iss);
           if (q == 0 && t >= 1 && t <= ITEMS) issue_item(t - 1);
           if (q == 0 && t == ITEMS) issue_end();
         }
       }
     }
-    ok1 = ok2; ok2 = ok3;
+    okn[0] = okn[1]; okn[1] = okn[2];
+    s_cur = s_nxt; s_iss = next_slot(s_iss);
   };
   using T = std::true_type;
   using F = std::false_type;
   {
     int st = 0;
-    for (; st + 3 < nstages; ++st) body(st, T{}, I2{}, T{});   // stages st+2, st+3 may still be in flight at the barrier
-    if (st + 2 < nstages) { body(st, F{}, I1{}, T{}); ++st; }
-    if (st + 1 < nstages) { body(st, F{}, I0{}, T{}); ++st; }
-    body(st, F{}, I0{}, F{});
+    for (; st + LOOK < nstages; ++st) body(T{}, std::integral_constant<int, LOOK - 1>{}, T{});  // the newer stages may still be in flight
+    if constexpr (LOOK == 3) {
+      if (st + 2 < nstages) { body(F{}, I1{}, T{}); ++st; }
+    }
+    if (st + 1 < nstages) { body(F{}, I0{}, T{}); ++st; }
+    body(F{}, I0{}, F{});
   }
 
-  // Epilogue.  (1) Loads are hoisted in front of the stores by hand: on this ISA stores count in vmcnt too, so a load issued after
-  // a store waits for that store's acknowledgement — with one block per CU, 64 interleaved bias / residual loads and stores were
-  // 64 exposed memory round trips (~50 us per block, more than the whole K loop of a 1x1 layer).  (2) The MFMA layout leaves a
-  // pixel's 8-channel record split across lanes l and l + 32 (4 channels = 8 bytes each); the store tail is bound by store
-  // INSTRUCTIONS, not bytes, so pairs of channel blocks are exchanged with v_permlane32_swap (lanes 0-31 end up with the whole
-  // record of block 2p, lanes 32-63 with block 2p + 1) and written / read as 16-byte accesses: half the instructions.
+  // Epilogue.  (1) On this ISA stores count in vmcnt too, so a load issued after a store waits for that store's acknowledgement:
+  // interleaved bias / residual loads and stores are exposed memory round trips (64 of them took ~50 us per block, more than the
+  // whole K loop of a 1x1 layer).  The loads of channel group mi + 1 are therefore issued BEFORE the stores of group mi.  (2) The
+  // MFMA layout leaves a pixel's 8-channel record split across lanes l and l + 32 (4 channels = 8 bytes each); the store tail is
+  // bound by store INSTRUCTIONS, not bytes, so pairs of channel blocks are exchanged with v_permlane32_swap (lanes 0-31 end up
+  // with the whole record of block 2p, lanes 32-63 with block 2p + 1) and written / read as 16-byte accesses.
   const int cb0 = (cout0 + wm * 128) / 8;
-  f32x4 bias[4][4];
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int cb = cb0 + mi * 4 + g;
-      bias[mi][g] = cb < a.Cb_out ? *reinterpret_cast<const f32x4 *>(a.bpk + cb * 8 + half * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
   auto swap32 = [](unsigned &lo_keeps, unsigned &hi_keeps) {  // lanes 32-63 of the first <-> lanes 0-31 of the second
     const auto r = __builtin_amdgcn_permlane32_swap(lo_keeps, hi_keeps, false, false);
     lo_keeps = r[0]; hi_keeps = r[1];
   };
+  f32x4 bias[2][4];
+  u32x4 rr[2][NI][2];  // residual records of channel block 4 mi + 2 gp + half, pixel tile ni
+  auto preload = [&](int mi, int buf) {
 #pragma unroll
-  for (int nh = 0; nh < NI / 2; ++nh) {
-    u32x4 rr[2][4][2];  // residual records of channel block 2 gp + half
+    for (int g = 0; g < 4; ++g) {
+      const int cb = cb0 + mi * 4 + g;
+      bias[buf][g] = cb < a.Cb_out ? *reinterpret_cast<const f32x4 *>(a.bpk + cb * 8 + half * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     if (a.res) {
 #pragma unroll
-      for (int nj = 0; nj < 2; ++nj) {
-        const long long pix = p0 + wn * (NI * 32) + (nh * 2 + nj) * 32 + l31;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int gp = 0; gp < 2; ++gp) {
-            const int cb = cb0 + mi * 4 + gp * 2 + half;
-            rr[nj][mi][gp] = (pix < a.P && cb < a.Cb_out) ? *reinterpret_cast<const u32x4 *>(a.res + ((size_t)cb * a.pitch_out + (size_t)pix) * 8)
-                                                          : u32x4{0u, 0u, 0u, 0u};
-          }
-      }
-    }
-#pragma unroll
-    for (int nj = 0; nj < 2; ++nj) {
-      const int ni = nh * 2 + nj;
-      const long long pix = p0 + wn * (NI * 32) + ni * 32 + l31;
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int ni = 0; ni < NI; ++ni) {
+        const long long pix = p0 + wn * (NI * 32) + ni * 32 + l31;
 #pragma unroll
         for (int gp = 0; gp < 2; ++gp) {
-          f32x4 va, vb;  // this lane's 4 channels of blocks 2 gp and 2 gp + 1
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            va[e] = acc[mi][ni][(gp * 2) * 4 + e] + bias[mi][gp * 2][e];
-            vb[e] = acc[mi][ni][(gp * 2 + 1) * 4 + e] + bias[mi][gp * 2 + 1][e];
-          }
-          if (a.res) {
-            unsigned r0 = rr[nj][mi][gp][0], r1 = rr[nj][mi][gp][1], r2 = rr[nj][mi][gp][2], r3 = rr[nj][mi][gp][3];
-            swap32(r0, r2);  // lanes 0-31: r0 r1 = own low half of block 2gp, r2 r3 = low half of 2gp+1 (from lane + 32);
-            swap32(r1, r3);  // lanes 32-63: r0 r1 = high half of 2gp (from lane - 32), r2 r3 = own high half of 2gp+1
-            va[0] += bf2f((bf16_t)(r0 & 0xffffu)); va[1] += bf2f((bf16_t)(r0 >> 16));
-            va[2] += bf2f((bf16_t)(r1 & 0xffffu)); va[3] += bf2f((bf16_t)(r1 >> 16));
-            vb[0] += bf2f((bf16_t)(r2 & 0xffffu)); vb[1] += bf2f((bf16_t)(r2 >> 16));
-            vb[2] += bf2f((bf16_t)(r3 & 0xffffu)); vb[3] += bf2f((bf16_t)(r3 >> 16));
-          }
-          if (a.relu) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { va[e] = va[e] < 0.0f ? 0.0f : va[e]; vb[e] = vb[e] < 0.0f ? 0.0f : vb[e]; }
-          }
-          unsigned ax = (unsigned)f2bf(va[0]) | ((unsigned)f2bf(va[1]) << 16), ay = (unsigned)f2bf(va[2]) | ((unsigned)f2bf(va[3]) << 16);
-          unsigned bx = (unsigned)f2bf(vb[0]) | ((unsigned)f2bf(vb[1]) << 16), by = (unsigned)f2bf(vb[2]) | ((unsigned)f2bf(vb[3]) << 16);
-          swap32(ax, bx);
-          swap32(ay, by);
           const int cb = cb0 + mi * 4 + gp * 2 + half;
-          if (pix < a.P && cb < a.Cb_out) *reinterpret_cast<u32x4 *>(a.out + ((size_t)cb * a.pitch_out + (size_t)pix) * 8) = u32x4{ax, ay, bx, by};
+          rr[buf][ni][gp] = (pix < a.P && cb < a.Cb_out) ? *reinterpret_cast<const u32x4 *>(a.res + ((size_t)cb * a.pitch_out + (size_t)pix) * 8)
+                                                         : u32x4{0u, 0u, 0u, 0u};
         }
+      }
+    }
+  };
+  preload(0, 0);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int buf = mi & 1;
+    if (mi + 1 < 4) preload(mi + 1, buf ^ 1);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const long long pix = p0 + wn * (NI * 32) + ni * 32 + l31;
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        f32x4 va, vb;  // this lane's 4 channels of blocks 2 gp and 2 gp + 1
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          va[e] = acc[mi][ni][(gp * 2) * 4 + e] + bias[buf][gp * 2][e];
+          vb[e] = acc[mi][ni][(gp * 2 + 1) * 4 + e] + bias[buf][gp * 2 + 1][e];
+        }
+        if (a.res) {
+          unsigned r0 = rr[buf][ni][gp][0], r1 = rr[buf][ni][gp][1], r2 = rr[buf][ni][gp][2], r3 = rr[buf][ni][gp][3];
+          swap32(r0, r2);  // lanes 0-31: r0 r1 = own low half of block 2gp, r2 r3 = low half of 2gp+1 (from lane + 32);
+          swap32(r1, r3);  // lanes 32-63: r0 r1 = high half of 2gp (from lane - 32), r2 r3 = own high half of 2gp+1
+          va[0] += bf2f((bf16_t)(r0 & 0xffffu)); va[1] += bf2f((bf16_t)(r0 >> 16));
+          va[2] += bf2f((bf16_t)(r1 & 0xffffu)); va[3] += bf2f((bf16_t)(r1 >> 16));
+          vb[0] += bf2f((bf16_t)(r2 & 0xffffu)); vb[1] += bf2f((bf16_t)(r2 >> 16));
+          vb[2] += bf2f((bf16_t)(r3 & 0xffffu)); vb[3] += bf2f((bf16_t)(r3 >> 16));
+        }
+        if (a.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { va[e] = va[e] < 0.0f ? 0.0f : va[e]; vb[e] = vb[e] < 0.0f ? 0.0f : vb[e]; }
+        }
+        unsigned ax = (unsigned)f2bf(va[0]) | ((unsigned)f2bf(va[1]) << 16), ay = (unsigned)f2bf(va[2]) | ((unsigned)f2bf(va[3]) << 16);
+        unsigned bx = (unsigned)f2bf(vb[0]) | ((unsigned)f2bf(vb[1]) << 16), by = (unsigned)f2bf(vb[2]) | ((unsigned)f2bf(vb[3]) << 16);
+        swap32(ax, bx);
+        swap32(ay, by);
+        const int cb = cb0 + mi * 4 + gp * 2 + half;
+        if (pix < a.P && cb < a.Cb_out) *reinterpret_cast<u32x4 *>(a.out + ((size_t)cb * a.pitch_out + (size_t)pix) * 8) = u32x4{ax, ay, bx, by};
+      }
     }
   }
 }
@@ -1049,14 +1057,14 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
     if (g_bf16_dma && b.CoutP % 256 == 0 && b.nch2 % 4 == 0 && b.P >= (g_bf16_dma == 2 ? 1 : 256 * 128) && (size_t)in.B * in.H * in.W * 16 < ((size_t)1 << 32)) {
       const int ny = b.CoutP / 256;
       // pixel-tile width: whichever fills the 256 CUs in fewer block-rounds x work per block
-      auto rounds_cost = [&](int tn) { const long long nb = (b.P + tn - 1) / tn * ny; return (nb + 255) / 256 * tn; };
-      const bool narrow = g_bf16_dma_tn == 128 || (g_bf16_dma_tn == 0 && rounds_cost(128) < rounds_cost(256));
+      auto rounds_cost = [&](int tn) { const long long nb = (b.P + tn - 1) / tn * ny; return (nb + 255) / 256 * tn; };  // (two 128-pixel blocks share a CU: same count)
+      const bool narrow = g_bf16_dma_tn == 128 || (g_bf16_dma_tn == 0 && rounds_cost(128) <= rounds_cost(256));  // ties: two co-resident blocks hide each other's prologue and epilogue
       const int tn = narrow ? 128 : 256;
-      const size_t LDS = (size_t)4 * (4 * 256 * 16 + 4 * tn * 16);
+      const size_t LDS = (size_t)(narrow ? 3 : 4) * (4 * 256 * 16 + 4 * tn * 16);  // ring depth x stage bytes (as in the kernel)
       static bool attr = false;
       if (!attr) {
         MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768));
-        MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 24576));
+        MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 24576));
         attr = true;
       }
       const int nx = (int)((b.P + tn - 1) / tn);
