@@ -466,18 +466,22 @@ __device__ __forceinline__ void glds16_s(const void *base_uniform, unsigned lane
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_byte_addr_uniform), "v"(lane_byte_off), "s"(base_uniform) : "memory");
 }
 
-// NI = 32-pixel MFMA tiles per wave along the pixel axis.  NI = 4: 256-pixel block tile, 4-deep ring (128 KiB), all 512
-// registers, one block per CU.  NI = 2: 128-pixel tile, 3-deep ring (72 KiB), <= 256 registers, TWO blocks per CU — one block's
-// prologue / epilogue (~10 us with nothing to overlap them at one block per CU) runs under the other's K loop, and the host picks
-// it when it packs the grid into fuller rounds (a 512-cout layer on 49 000 pixels is 384 blocks = 1.5 rounds of 256 at 256 pixels).
-template <int NI>
-__global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv2d_c8i_bf16_dma_kernel(GConvArgsB a, int nx, int ny) {
-  constexpr int NCH = 4, TN = 64 * NI;
-  constexpr int RING = NI == 2 ? 3 : 4, LOOK = RING - 1;         // stages in the ring / stages the DMA runs ahead
-  constexpr int NB = NI;                                          // pixel-chunk DMA items per wave per stage (weights: 4)
-  constexpr int ITEMS = NCH + NB;
-  constexpr unsigned OPA = NCH * 256 * 16, OPBB = NCH * TN * 16, STAGEB = OPA + OPBB;  // bytes: weights / pixels / stage
-  extern __shared__ __attribute__((aligned(16))) u32x4 ring[];  // [RING][A: NCH x 256 rows | B: NCH x TN rows]
+// MI x NI = 32 x 32 MFMA tiles per wave along the cout / pixel axes; the block is 2 x 2 waves = 64 MI couts x 64 NI pixels.
+//   <4, 4>: 256 x 256, 4-deep ring (128 KiB), all 512 registers, one block per CU;
+//   <4, 2>: 256 couts x 128 pixels and <2, 4>: 128 couts x 256 pixels: 3-deep ring (72 KiB), <= 256 registers, TWO blocks per CU —
+//           one block's prologue / epilogue (~10 us with nothing to overlap them at one block per CU) runs under the other's K
+//           loop.  The host picks per layer (rn_conv): cout counts that are not multiples of 256 (Inception's 320 / 384) take
+//           <2, 4>, and the narrow shapes also pack some grids into fuller rounds (a 512-cout layer on 49 000 pixels is 384
+//           blocks = 1.5 rounds of 256 at 256 x 256).
+template <int MI, int NI>
+__global__ __launch_bounds__(256, (MI == 4 && NI == 4) ? 1 : 2) void conv2d_c8i_bf16_dma_kernel(GConvArgsB a, int nx, int ny) {
+  static_assert((MI == 4 || MI == 2) && (NI == 4 || NI == 2) && MI + NI >= 6, "");
+  constexpr int NCH = 4, TM = 64 * MI, TN = 64 * NI;
+  constexpr int RING = (MI == 4 && NI == 4) ? 4 : 3, LOOK = RING - 1;  // stages in the ring / stages the DMA runs ahead
+  constexpr int NA = MI, NB = NI;                                 // weight- / pixel-chunk DMA items per wave per stage
+  constexpr int ITEMS = NA + NB;
+  constexpr unsigned OPA = NCH * TM * 16, OPBB = NCH * TN * 16, STAGEB = OPA + OPBB;  // bytes: weights / pixels / stage
+  extern __shared__ __attribute__((aligned(16))) u32x4 ring[];  // [RING][A: NCH x TM rows | B: NCH x TN rows]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
@@ -488,10 +492,12 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv2d_c8i_bf16_dma_kern
   const int ty = kq % ny, tx = (kq / ny) * 8 + xcd;
   if (tx >= nx) return;
   const long long p0 = (long long)tx * TN;
-  const int cout0 = ty * 256;
+  const int cout0 = ty * TM;
   const int OHW = a.OH * a.OW;
-  // DMA roles.  Weights: wave w moves rows 64 w .. 64 w + 63 of all 4 chunks.  Pixels, NI = 4: the same; NI = 2 (128 rows):
-  // wave w moves rows 64 (w & 1) .. of chunks 2 (w >> 1) and 2 (w >> 1) + 1.
+  // DMA roles (one wave-load = 64 rows of one 8-channel chunk).  A 256-row operand: wave w moves rows 64 w .. 64 w + 63 of all 4
+  // chunks; a 128-row operand: wave w moves rows 64 (w & 1) .. of chunks 2 (w >> 1) and 2 (w >> 1) + 1.
+  const int arow = MI == 4 ? tid : (tid & 127);                  // this lane's weight row (cout) of the tile
+  const int ach0 = MI == 4 ? 0 : 2 * (wave >> 1);                // its first weight chunk
   const int prow = NI == 4 ? tid : (tid & 127);                  // this lane's pixel row of the tile
   const int bch0 = NI == 4 ? 0 : 2 * (wave >> 1);                // its first pixel chunk
   const long long gpix = p0 + prow;
@@ -501,11 +507,10 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv2d_c8i_bf16_dma_kern
   const int goy = grem / a.OW, gox = grem - goy * a.OW;
   const int iy0 = goy * a.sh - a.ph, ix0 = gox * a.sw - a.pw;
   const unsigned map_off = (unsigned)gb * (unsigned)(a.H * a.W);  // records
-  const bf16_t *const w_tile = a.wpk + (size_t)cout0 * 8;
   const unsigned ring0 = (unsigned)(size_t)((__attribute__((address_space(3))) const u32x4 *)ring);
-  const unsigned lds_a = ring0 + (unsigned)wave * 1024u;
+  const unsigned lds_a = ring0 + (unsigned)ach0 * (TM * 16u) + (unsigned)(MI == 4 ? wave : (wave & 1)) * 1024u;
   const unsigned lds_b = ring0 + OPA + (unsigned)bch0 * (TN * 16u) + (unsigned)(NI == 4 ? wave : (wave & 1)) * 1024u;
-  const unsigned a_lane = (unsigned)tid * 16u;
+  const unsigned a_lane = (unsigned)arow * 16u;
   const int spt = a.nch2 / NCH;
   const int nstages = a.KH * a.KW * spt;
 
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv2d_c8i_bf16_dma_kern
   // [tap][chunk][CoutP][8], i.e. consecutive stages are consecutive memory; the pixel chunk planes restart at every tap
   int i_cg = 0, i_kx = 0, i_ky = 0;
   const size_t w_step = (size_t)a.CoutP * 16, b_step = a.pitch_in * 16;
-  const char *i_wp = reinterpret_cast<const char *>(w_tile);
+  const char *i_wp = reinterpret_cast<const char *>(a.wpk + (size_t)cout0 * 8) + (size_t)ach0 * w_step;
   const char *const b_base = reinterpret_cast<const char *>(a.in) + (size_t)bch0 * b_step;
   const char *i_bp = b_base;
   unsigned i_blane = 0, i_slot = 0;
@@ -524,15 +529,16 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv2d_c8i_bf16_dma_kern
     i_slot = (unsigned)slot * STAGEB;
     return ok;
   };
-  auto issue_item = [&](int i) {  // items 0 .. 2 NB - 1 interleave pixel chunks between the weight chunks
-    if (i < 2 * NB) {
-      if ((i & 1) == 0) { glds16_s(i_wp, a_lane, lds_a + i_slot + (unsigned)(i >> 1) * 4096u); i_wp += w_step; }
-      else { glds16_s(i_bp, i_blane, lds_b + i_slot + (unsigned)(i >> 1) * (TN * 16u)); i_bp += b_step; }
-    } else {
-      glds16_s(i_wp, a_lane, lds_a + i_slot + (unsigned)(i - NB) * 4096u); i_wp += w_step;
-    }
+  auto issue_a = [&](int k) { glds16_s(i_wp, a_lane, lds_a + i_slot + (unsigned)k * (TM * 16u)); i_wp += w_step; };
+  auto issue_b = [&](int k) { glds16_s(i_bp, i_blane, lds_b + i_slot + (unsigned)k * (TN * 16u)); i_bp += b_step; };
+  auto issue_item = [&](int i) {  // weight and pixel chunks alternate while both last
+    constexpr int M = NA < NB ? NA : NB;
+    if (i < 2 * M) { if ((i & 1) == 0) issue_a(i >> 1); else issue_b(i >> 1); }
+    else if (NA > NB) issue_a(i - M);
+    else issue_b(i - M);
   };
   auto issue_end = [&]() {
+    i_wp += (NCH - NA) * w_step;
     i_bp += (NCH - NB) * b_step;
     if (++i_cg == spt) { i_cg = 0; i_bp = b_base; if (++i_kx == a.KW) { i_kx = 0; ++i_ky; } }
   };
@@ -564,21 +570,21 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv2d_c8i_bf16_dma_kern
   using I2 = std::integral_constant<int, 2>;
   auto next_slot = [](int sl) { return sl + 1 == RING ? 0 : sl + 1; };
 
-  f32x16 acc[4][NI];
+  f32x16 acc[MI][NI];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
   // operand fragments, double-buffered one k-step (16 channels) ahead
-  bf16x8 af[2][4], bf[2][NI];
-  const int frag_row_a = half * 256 + wm * 128 + l31, frag_row_b = OPA / 16 + half * TN + wn * (NI * 32) + l31;
+  bf16x8 af[2][MI], bf[2][NI];
+  const int frag_row_a = half * TM + wm * (MI * 32) + l31, frag_row_b = OPA / 16 + half * TN + wn * (NI * 32) + l31;
   auto load_frags = [&](int slot, int q, int fs) {
     const u32x4 *S = ring + (size_t)slot * (STAGEB / 16);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) af[fs][mi] = *reinterpret_cast<const bf16x8 *>(S + q * 512 + frag_row_a + mi * 32);
+    for (int mi = 0; mi < MI; ++mi) af[fs][mi] = *reinterpret_cast<const bf16x8 *>(S + q * 2 * TM + frag_row_a + mi * 32);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) bf[fs][ni] = *reinterpret_cast<const bf16x8 *>(S + q * 2 * TN + frag_row_b + ni * 32);
   };
@@ -597,7 +603,7 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv2d_c8i_bf16_dma_kern
   int s_cur = 0;                              // slot of stage st
   int s_iss = nstages > LOOK ? LOOK : 0;      // slot of stage st + LOOK
 
-  // One stage = 2 k-steps x 4 NI MFMAs, hand-scheduled like gemm_c8_pf_kernel (dense.hip): VALU work from a wave does not overlap
+  // One stage = 2 k-steps x MI NI MFMAs, hand-scheduled like gemm_c8_pf_kernel (dense.hip): VALU work from a wave does not overlap
   // its own MFMAs but LDS reads, SALU and DMA issue do, so the next k-step's fragment reads follow the FIRST MFMA of a k-step, the
   // DMA items of stage st+LOOK follow the next MFMAs of k-step 0, and the stage barrier (wait for this wave's stage-st+1 loads,
   // zero its out-of-map records, s_barrier) sits BEFORE k-step 1's MFMAs — whose operands are already in registers — so that the
@@ -615,7 +621,7 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv2d_c8i_bf16_dma_kern
         load_frags(s_nxt, 0, 0);
       }
 #pragma unroll
-      for (int t = 0; t < 4 * NI; ++t) {
+      for (int t = 0; t < MI * NI; ++t) {
         const int mi = t / NI, ni = t % NI;
         __builtin_amdgcn_sched_barrier(0);
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q][mi], bf[q][ni], acc[mi][ni], 0, 0, 0);
@@ -649,7 +655,7 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv2d_c8i_bf16_dma_kern
   // MFMA layout leaves a pixel's 8-channel record split across lanes l and l + 32 (4 channels = 8 bytes each); the store tail is
   // bound by store INSTRUCTIONS, not bytes, so pairs of channel blocks are exchanged with v_permlane32_swap (lanes 0-31 end up
   // with the whole record of block 2p, lanes 32-63 with block 2p + 1) and written / read as 16-byte accesses.
-  const int cb0 = (cout0 + wm * 128) / 8;
+  const int cb0 = (cout0 + wm * (MI * 32)) / 8;
   auto swap32 = [](unsigned &lo_keeps, unsigned &hi_keeps) {  // lanes 32-63 of the first <-> lanes 0-31 of the second
     const auto r = __builtin_amdgcn_permlane32_swap(lo_keeps, hi_keeps, false, false);
     lo_keeps = r[0]; hi_keeps = r[1];
@@ -677,9 +683,9 @@ __global__ __launch_bounds__(256, NI == 2 ? 2 : 1) void conv2d_c8i_bf16_dma_kern
   };
   preload(0, 0);
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
+  for (int mi = 0; mi < MI; ++mi) {
     const int buf = mi & 1;
-    if (mi + 1 < 4) preload(mi + 1, buf ^ 1);
+    if (mi + 1 < MI) preload(mi + 1, buf ^ 1);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const long long pix = p0 + wn * (NI * 32) + ni * 32 + l31;
@@ -1037,7 +1043,7 @@ static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b
 
 static int g_bf16_fast_pool = 3;       // bit 0: sorted-int16 ROI pooling, bit 1: LDS average pooling (0 = the plain kernels; mpn_debug_set_bf16_fast_pool)
 static int g_bf16_split_target = 256;  // split-K aims at this many blocks (0 = never split; mpn_debug_set_bf16_split_target)
-static int g_bf16_dma_tn = 0;  // 0 = pick per layer, 128 / 256 = force (mpn_debug_set_bf16_dma_tn)
+static int g_bf16_dma_tn = 0;  // 0 = pick per layer; 128 / 256 = force 256 couts x that many pixels, 1256 = 128 couts x 256 pixels (mpn_debug_set_bf16_dma_tn)
 static int g_bf16_dma = 1;  // mpn_debug_set_bf16_dma: 0 = never, 1 = large layers, 2 = every eligible layer (tests)
 static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int relu, hipStream_t s, ActI *o, bool allow_gemm = true) {
   if (c.wpk16) {  // bf16 graph
@@ -1053,26 +1059,40 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
     b.P = (long long)in.B * b.OH * b.OW;
     *o = ActI{out, in.B, c.Cout, b.OH, b.OW};
     b.pitch_in = in.pitch(); b.pitch_out = o->pitch();
-    // large layers: the 256-cout LDS-DMA kernel (needs whole 256-cout tiles, 32-channel stages, 32-bit record offsets)
-    if (g_bf16_dma && b.CoutP % 256 == 0 && b.nch2 % 4 == 0 && b.P >= (g_bf16_dma == 2 ? 1 : 256 * 128) && (size_t)in.B * in.H * in.W * 16 < ((size_t)1 << 32)) {
-      const int ny = b.CoutP / 256;
-      // pixel-tile width: whichever fills the 256 CUs in fewer block-rounds x work per block
-      auto rounds_cost = [&](int tn) { const long long nb = (b.P + tn - 1) / tn * ny; return (nb + 255) / 256 * tn; };  // (two 128-pixel blocks share a CU: same count)
-      const bool narrow = g_bf16_dma_tn == 128 || (g_bf16_dma_tn == 0 && rounds_cost(128) <= rounds_cost(256));  // ties: two co-resident blocks hide each other's prologue and epilogue
-      const int tn = narrow ? 128 : 256;
-      const size_t LDS = (size_t)(narrow ? 3 : 4) * (4 * 256 * 16 + 4 * tn * 16);  // ring depth x stage bytes (as in the kernel)
-      static bool attr = false;
-      if (!attr) {
-        MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768));
-        MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 24576));
-        attr = true;
+    // large layers: the LDS-DMA kernel (32-channel stages, 32-bit record offsets); tile shape per layer
+    if (g_bf16_dma && b.nch2 % 4 == 0 && b.P >= (g_bf16_dma == 2 ? 1 : 256 * 128) && (size_t)in.B * in.H * in.W * 16 < ((size_t)1 << 32)) {
+      // cost of a shape = block-rounds over the 256 CUs x work per block (the two 3-ring shapes run two blocks per CU at half speed
+      // each: the same count); 256-cout tiles need whole 256-row weight tiles
+      struct Shape { int tm, tn; };
+      const Shape shapes[3] = {{256, 128}, {128, 256}, {256, 256}};  // ties go to the earlier entry
+      int best = -1; long long best_cost = 0;
+      for (int i = 0; i < 3; ++i) {
+        const Shape &sh = shapes[i];
+        if (sh.tm == 256 && b.CoutP % 256 != 0) continue;
+        if (g_bf16_dma_tn && !(sh.tn == g_bf16_dma_tn % 1000 && sh.tm == (g_bf16_dma_tn >= 1000 ? 128 : 256))) continue;
+        const long long nb = (b.P + sh.tn - 1) / sh.tn * (b.CoutP / sh.tm);
+        const long long cost = (nb + 255) / 256 * sh.tm * sh.tn;
+        if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
       }
-      const int nx = (int)((b.P + tn - 1) / tn);
-      const dim3 gridd((unsigned)(((nx + 7) / 8) * 8 * ny));
-      if (narrow) hipLaunchKernelGGL(conv2d_c8i_bf16_dma_kernel<2>, gridd, dim3(256), LDS, s, b, nx, ny);
-      else hipLaunchKernelGGL(conv2d_c8i_bf16_dma_kernel<4>, gridd, dim3(256), LDS, s, b, nx, ny);
-      MPN_CHECK_LAUNCH();
-      return MPN_OK;
+      if (best >= 0) {
+        const int tm = shapes[best].tm, tn = shapes[best].tn;
+        const int ring = (tm == 256 && tn == 256) ? 4 : 3;
+        const size_t LDS = (size_t)ring * 4 * (tm + tn) * 16;  // ring depth x stage bytes (as in the kernel)
+        static bool attr = false;
+        if (!attr) {
+          MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768));
+          MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 24576));
+          MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 24576));
+          attr = true;
+        }
+        const int nx = (int)((b.P + tn - 1) / tn), ny = b.CoutP / tm;
+        const dim3 gridd((unsigned)(((nx + 7) / 8) * 8 * ny));
+        if (tm == 256 && tn == 128) hipLaunchKernelGGL((conv2d_c8i_bf16_dma_kernel<4, 2>), gridd, dim3(256), LDS, s, b, nx, ny);
+        else if (tm == 128) hipLaunchKernelGGL((conv2d_c8i_bf16_dma_kernel<2, 4>), gridd, dim3(256), LDS, s, b, nx, ny);
+        else hipLaunchKernelGGL((conv2d_c8i_bf16_dma_kernel<4, 4>), gridd, dim3(256), LDS, s, b, nx, ny);
+        MPN_CHECK_LAUNCH();
+        return MPN_OK;
+      }
     }
     dim3 grid((unsigned)((b.P + 127) / 128), (unsigned)(b.CoutP / 128));
     // small layers (layer2 / layer3 of the trunk: a few dozen tiles for 256 CUs): split K across blockIdx.z into fp32 slabs
