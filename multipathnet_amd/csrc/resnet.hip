@@ -721,28 +721,37 @@ __global__ __launch_bounds__(256, (MI == 4 && NI == 4) ? 1 : 2) void conv2d_c8i_
   }
 }
 
+// one thread = one 16-byte pixel record (8 channels)
 __global__ void maxpool2d_c8i_bf16_kernel(const bf16_t *__restrict__ in, int Cb, int B, int H, int W, size_t pitch_in, int k, int stride, int pad,
                                           int OH, int OW, size_t pitch_out, bf16_t *__restrict__ out) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t total = (size_t)Cb * B * OH * OW * 2;
+  size_t total = (size_t)Cb * B * OH * OW;
   if (t >= total) return;
-  const int h = (int)(t & 1); size_t r = t >> 1;
+  size_t r = t;
   const int ox = (int)(r % OW); r /= OW;
   const int oy = (int)(r % OH); r /= OH;
   const int b = (int)(r % B); const size_t cb = r / B;
-  f32x4 m = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  float m[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+  const u32x4 *ip = reinterpret_cast<const u32x4 *>(in) + cb * pitch_in + (size_t)b * H * W;
   for (int ky = 0; ky < k; ++ky)
     for (int kx = 0; kx < k; ++kx) {
       const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
       if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-      const u16x4 v = *reinterpret_cast<const u16x4 *>(in + (cb * pitch_in + ((size_t)b * H + iy) * W + ix) * 8 + h * 4);
+      const u32x4 v = ip[(size_t)iy * W + ix];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float f = bf2f(v[e]); m[e] = f > m[e] ? f : m[e]; }
+      for (int e = 0; e < 4; ++e) {
+        const unsigned w = v[e];
+        const float lo = __uint_as_float(w << 16), hi = __uint_as_float(w & 0xffff0000u);
+        m[2 * e] = lo > m[2 * e] ? lo : m[2 * e];
+        m[2 * e + 1] = hi > m[2 * e + 1] ? hi : m[2 * e + 1];
+      }
     }
-  u16x4 o;
+  u32x4 o;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = f2bf(m[e]);
-  *reinterpret_cast<u16x4 *>(out + (cb * pitch_out + ((size_t)b * OH + oy) * OW + ox) * 8 + h * 4) = o;
+  for (int e = 0; e < 4; ++e) o[e] = (unsigned)f2bf(m[2 * e]) | ((unsigned)f2bf(m[2 * e + 1]) << 16);
+  reinterpret_cast<u32x4 *>(out)[cb * pitch_out + ((size_t)b * OH + oy) * OW + ox] = o;
 }
 
 // transformed image as bf16 C8I with TWO channel-block planes (channels 3..15 zero: the MFMA consumes chunk pairs)
@@ -944,6 +953,35 @@ __global__ void avgpool2d_c8i_kernel(const T *__restrict__ in, int Cb, int B, in
   } else {
     *reinterpret_cast<f32x4 *>(out + oo) = acc * inv;
   }
+}
+
+// bf16: one thread = one 16-byte pixel record; same summation order per channel as the template above
+__global__ void avgpool2d_c8i_bf16_kernel(const bf16_t *__restrict__ in, int Cb, int B, int H, int W, size_t pitch_in, int kh, int kw, int sh, int sw,
+                                          int ph, int pw, int OH, int OW, size_t pitch_out, bf16_t *__restrict__ out) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)Cb * B * OH * OW;
+  if (t >= total) return;
+  size_t r = t;
+  const int ox = (int)(r % OW); r /= OW;
+  const int oy = (int)(r % OH); r /= OH;
+  const int b = (int)(r % B); const size_t cb = r / B;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+  const u32x4 *ip = reinterpret_cast<const u32x4 *>(in) + cb * pitch_in + (size_t)b * H * W;
+  for (int ky = 0; ky < kh; ++ky)
+    for (int kx = 0; kx < kw; ++kx) {
+      const int iy = oy * sh + ky - ph, ix = ox * sw + kx - pw;
+      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+      const u32x4 v = ip[(size_t)iy * W + ix];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[2 * e] += __uint_as_float(v[e] << 16); acc[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u); }
+    }
+  const float inv = 1.0f / (float)(kh * kw);
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (unsigned)f2bf(acc[2 * e] * inv) | ((unsigned)f2bf(acc[2 * e + 1] * inv) << 16);
+  reinterpret_cast<u32x4 *>(out)[cb * pitch_out + ((size_t)b * OH + oy) * OW + ox] = o;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -1381,18 +1419,18 @@ static int graph_run(ResNetGraph *g, const std::vector<GOp> &ops, std::vector<GT
       if (rc) return rc;
     } else {
       const size_t total = (size_t)in.Cb() * B * dst.H * dst.W * 2;
-      const dim3 grid((unsigned)cdiv_sz(total, 256));
+      const dim3 grid((unsigned)cdiv_sz(total, 256)), grid16((unsigned)cdiv_sz(total / 2, 256));  // fp32: half records, bf16: whole records per thread
       if (op.kind == 1) {
         MPN_CHECK_ARG(op.kh == op.kw && op.sh == op.sw && op.ph == op.pw);
         if (g->bf16)
-          hipLaunchKernelGGL(maxpool2d_c8i_bf16_kernel, grid, dim3(256), 0, s, reinterpret_cast<const bf16_t *>(src.buf), in.Cb(), B, src.H, src.W, in.pitch(),
+          hipLaunchKernelGGL(maxpool2d_c8i_bf16_kernel, grid16, dim3(256), 0, s, reinterpret_cast<const bf16_t *>(src.buf), in.Cb(), B, src.H, src.W, in.pitch(),
                              op.kh, op.sh, op.ph, dst.H, dst.W, od.pitch(), reinterpret_cast<bf16_t *>(outp));
         else
           hipLaunchKernelGGL(maxpool2d_c8i_kernel, grid, dim3(256), 0, s, src.buf, in.Cb(), B, src.H, src.W, in.pitch(), op.kh, op.sh, op.ph, dst.H, dst.W,
                              od.pitch(), reinterpret_cast<float *>(outp));
       } else {
         if (g->bf16)
-          hipLaunchKernelGGL((avgpool2d_c8i_kernel<bf16_t>), grid, dim3(256), 0, s, reinterpret_cast<const bf16_t *>(src.buf), in.Cb(), B, src.H, src.W,
+          hipLaunchKernelGGL(avgpool2d_c8i_bf16_kernel, grid16, dim3(256), 0, s, reinterpret_cast<const bf16_t *>(src.buf), in.Cb(), B, src.H, src.W,
                              in.pitch(), op.kh, op.kw, op.sh, op.sw, op.ph, op.pw, dst.H, dst.W, od.pitch(), reinterpret_cast<bf16_t *>(outp));
         else
           hipLaunchKernelGGL((avgpool2d_c8i_kernel<float>), grid, dim3(256), 0, s, src.buf, in.Cb(), B, src.H, src.W, in.pitch(), op.kh, op.kw, op.sh, op.sw,
@@ -1432,7 +1470,7 @@ int resnet_trunk_forward(ResNetGraph *g, const float *d_image, int H, int W, con
     const size_t total = (size_t)y.Cb() * OH * OW * 2;
     const ActI po{g->tb[1], 1, y.C, OH, OW};
     if (g->bf16)
-      hipLaunchKernelGGL(maxpool2d_c8i_bf16_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, reinterpret_cast<const bf16_t *>(y.p), y.Cb(), 1,
+      hipLaunchKernelGGL(maxpool2d_c8i_bf16_kernel, dim3((unsigned)cdiv_sz(total / 2, 256)), dim3(256), 0, s, reinterpret_cast<const bf16_t *>(y.p), y.Cb(), 1,
                          y.H, y.W, y.pitch(), 3, 2, 1, OH, OW, po.pitch(), reinterpret_cast<bf16_t *>(g->tb[1]));
     else
     hipLaunchKernelGGL(maxpool2d_c8i_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, y.p, y.Cb(), 1, y.H, y.W, y.pitch(), 3, 2, 1, OH, OW,
