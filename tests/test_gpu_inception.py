@@ -52,3 +52,29 @@ def test_inception_multipathnet_extension_vs_oracle(O, dev):
     so, bo = O.graph_mpn_detect(im, boxes, Gn, O.INCEPTION, target=min(H, W), max_size=max(H, W))
     assert np.abs(s.cpu().numpy() - so).max() < 3e-3
     assert np.abs(b.cpu().numpy() - O.clamp_boxes(bo, W, H)).max() < 0.5
+
+
+@pytest.mark.parametrize("tn", [0, 1256, 256])
+def test_inception_bf16_lds_dma_kernel_forced(O, dev, tn):
+    """the LDS-DMA convolution kernel forced onto every eligible layer of a quarter-width Inception-v3 (by default only layers
+    with >= 32768 output pixels use it): 1x7 / 7x1 / 1x3 / 3x1 taps, stride-2 reductions, DepthConcat slices as outputs, cout
+    counts that are not multiples of the tile; tn = forced tile shape (0 = per layer, 1256 = 128 couts x 256 pixels, 256 = 256 x 256)"""
+    import multipathnet_amd
+    from multipathnet_amd import models
+    lib = multipathnet_amd.load()
+    H, W, N, C = 170, 215, 24, 5
+    G = models.synthetic_inception_v3_params(n_classes=C, width=0.25, seed=29)
+    Gn = dict(models.graph_params_numpy(G), bf16=True)
+    im, boxes = _inputs(H, W, N, 18)
+    lib.mpn_debug_set_bf16_dma(2)
+    lib.mpn_debug_set_bf16_dma_tn(tn)
+    try:
+        net = models.InceptionFRCNN(G, max_h=H, max_w=W, max_rois=32, top_k=10, bf16=True)
+        s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+        s = s.cpu().numpy()
+    finally:
+        lib.mpn_debug_set_bf16_dma(1)
+        lib.mpn_debug_set_bf16_dma_tn(0)
+    so, bo, _, _ = O.graph_detect(im, boxes, Gn, O.INCEPTION, target=min(H, W), max_size=max(H, W))
+    assert np.abs(s - so).max() < 3e-3
+    assert np.abs(b.cpu().numpy() - O.clamp_boxes(bo, W, H)).max() < 0.5
