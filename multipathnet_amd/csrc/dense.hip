@@ -1779,6 +1779,8 @@ struct GemmArgs {
   const float *bpk;
   float *y;                     // [NP/8][Mp][8]   (split: partial slabs [S][NP/8][Mp][8])
   int M, nstages, stages_per_split, relu, n_mt, n_nt, direct;
+  int n_fast;  // tile order: 0 = all row tiles of one column tile first (the weights are the big operand: fc6), 1 = all column tiles of one
+               // row tile first (the activations are: ResNet's pointwise convolutions over 10^5 pixel rows) — the big operand is streamed once
   int ablate;  // timing experiments only (results wrong): 1 = no DMA in loop, 2 = no barrier in loop, 4 = no ds_reads in loop
   const float *res;  // optional residual in y's layout, added before the ReLU (direct mode only; ResNet 1x1 convolutions)
 };
@@ -1803,7 +1805,7 @@ __global__ __launch_bounds__(256) void gemm_c8_kernel(GemmArgs a) {
   int b = blockIdx.x;
   const int nb = gridDim.x;
   if ((nb & 7) == 0) b = (b & 7) * (nb >> 3) + (b >> 3);
-  const int nt = b / a.n_mt, mt = b - nt * a.n_mt;
+  const int nt = a.n_fast ? b % a.n_nt : b / a.n_mt, mt = a.n_fast ? b / a.n_nt : b - nt * a.n_mt;
   const int n0 = nt * 128, m0 = mt * 128;
   const int split = blockIdx.y;
   const int st0 = split * a.stages_per_split;
@@ -1927,7 +1929,7 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
   int b = blockIdx.x;
   const int nb = gridDim.x;
   if ((nb & 7) == 0) b = (b & 7) * (nb >> 3) + (b >> 3);
-  const int nt = b / a.n_mt, mt = b - nt * a.n_mt;
+  const int nt = a.n_fast ? b % a.n_nt : b / a.n_mt, mt = a.n_fast ? b / a.n_nt : b - nt * a.n_mt;
   const int n0 = nt * 128, m0 = mt * 128;
   const int split = blockIdx.y;
   const int st0 = split * a.stages_per_split;
@@ -2086,6 +2088,7 @@ int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float
   a.M = M; a.relu = relu; a.ablate = g_gemm_ablate;
   const int K64 = round_up(K, 64);
   a.n_mt = a.Mp / 128; a.n_nt = a.NP / 128;
+  a.n_fast = a.n_mt > a.n_nt ? 1 : 0;
   const int tiles = a.n_mt * a.n_nt;
   // long-K, enough tiles to fill the chip: 64-k stages; otherwise 32-k stages (finer split-K granularity)
   const int kch = g_gemm_kch ? g_gemm_kch : 4;  // 64-k stages measured no faster than 32-k (tools/bench_layers.py)

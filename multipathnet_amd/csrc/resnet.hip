@@ -66,8 +66,14 @@ __global__ __launch_bounds__(256) void conv2d_c8i_kernel(GConvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
-  const long long p0 = (long long)blockIdx.x * 128;
-  const int cout0 = blockIdx.y * 128;
+  // block -> tile: a pixel tile's cout tiles run back to back on ONE XCD (blocks are dealt to the 8 XCDs round-robin): the gathered
+  // activations — the big operand of a per-ROI layer (10^5 pixel rows) — enter one L2 once instead of once per cout tile
+  const int ny = a.CoutP / 128, nx = (int)((a.P + 127) / 128);
+  const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+  const int ty = kq % ny, tx = (kq / ny) * 8 + xcd;
+  if (tx >= nx) return;
+  const long long p0 = (long long)tx * 128;
+  const int cout0 = ty * 128;
   const int OHW = a.OH * a.OW;
 
   // staging roles: thread = (row tid>>1, 16-byte half tid&1) of both 128 x 8 slices of every chunk of the stage
@@ -306,8 +312,14 @@ __global__ __launch_bounds__(256) void conv2d_c8i_bf16_kernel(GConvArgsB a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
-  const long long p0 = (long long)blockIdx.x * 128;
-  const int cout0 = blockIdx.y * 128;
+  // block -> tile: a pixel tile's cout tiles run back to back on ONE XCD (blocks are dealt to the 8 XCDs round-robin): the gathered
+  // activations — the big operand of a per-ROI layer (10^5 pixel rows) — enter one L2 once instead of once per cout tile
+  const int ny = a.CoutP / 128, nx = (int)((a.P + 127) / 128);
+  const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+  const int ty = kq % ny, tx = (kq / ny) * 8 + xcd;
+  if (tx >= nx) return;
+  const long long p0 = (long long)tx * 128;
+  const int cout0 = ty * 128;
   const int OHW = a.OH * a.OW;
 
   // staging roles: thread = row tid & 127, chunks (tid >> 7) + 2 i
@@ -1132,12 +1144,13 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
         return MPN_OK;
       }
     }
-    dim3 grid((unsigned)((b.P + 127) / 128), (unsigned)(b.CoutP / 128));
+    dim3 grid((unsigned)(((b.P + 127) / 128 + 7) / 8 * 8 * (b.CoutP / 128)));  // pixel tiles rounded up to the 8 XCDs x cout tiles (see the kernel)
+    const long long n_tiles = (b.P + 127) / 128 * (b.CoutP / 128);
     // small layers (layer2 / layer3 of the trunk: a few dozen tiles for 256 CUs): split K across blockIdx.z into fp32 slabs
     {
       const int kp = b.nch2 % 4 == 0 ? 2 : 1;
       const int nstages = b.KH * b.KW * (b.nch2 / (2 * kp));
-      const long long nblocks = (long long)grid.x * grid.y;
+      const long long nblocks = n_tiles;
       const size_t slab = (size_t)b.CoutP * o->pitch() * sizeof(float);
       int want = (int)std::min<long long>(nstages / 2, (g_bf16_split_target + nblocks - 1) / nblocks);
       if (c.ws && slab) want = (int)std::min<size_t>((size_t)want, c.ws_bytes / slab); else want = 1;
@@ -1176,7 +1189,7 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
   a.pitch_in = in.pitch(); a.pitch_out = o->pitch();
   if (allow_gemm && c.lin_w && linear_c8_is_direct((int)in.rows(), c.Cout, (int)in.pitch()))  // same rows in and out: the tuned GEMM, residual + ReLU fused
     return linear_c8(in.p, (int)in.rows(), c.Cin, c.lin_w, c.lin_b, c.Cout, relu, out, nullptr, s, (int)in.pitch(), res);
-  dim3 grid((unsigned)((a.P + 127) / 128), (unsigned)(a.CoutP / 128));
+  dim3 grid((unsigned)(((a.P + 127) / 128 + 7) / 8 * 8 * (a.CoutP / 128)));  // pixel tiles rounded up to the 8 XCDs x cout tiles (see the kernel)
   if (a.nch % 4 == 0) hipLaunchKernelGGL((conv2d_c8i_kernel<4>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((conv2d_c8i_kernel<1>), grid, dim3(256), 0, s, a);
   MPN_CHECK_LAUNCH();

@@ -1,9 +1,9 @@
 #!/bin/bash
-# rocprofv3 kernel stats of the ResNet-50 bf16 Fast R-CNN bench -> gpurun_out/prof_rn/
+# rocprofv3 kernel stats + per-launch timeline of tools/bench_resnet.py (args: its args; default "50 1000 bf16") -> gpurun_out/prof_rn/
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $GRAFT_REPO_ROOT/gpurun_out/prof_rn
 mkdir -p /tmp/prof_rn
-rocprofv3 --kernel-trace --stats -d /tmp/prof_rn -o rn --output-format csv -- python $GRAFT_REPO_ROOT/tools/bench_resnet.py 50 1000 bf16 > /tmp/prof_rn/log.txt 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/prof_rn -o rn --output-format csv -- python $GRAFT_REPO_ROOT/tools/bench_resnet.py ${@:-50 1000 bf16} > /tmp/prof_rn/log.txt 2>&1
 f=$(find /tmp/prof_rn -name '*kernel_stats.csv' | head -1)
 cp "$f" $GRAFT_REPO_ROOT/gpurun_out/prof_rn/kernel_stats.csv
 head -12 "$f" | cut -c1-200
