@@ -996,6 +996,41 @@ __global__ void avgpool2d_c8i_bf16_kernel(const bf16_t *__restrict__ in, int Cb,
   reinterpret_cast<u32x4 *>(out)[cb * pitch_out + ((size_t)b * OH + oy) * OW + ox] = o;
 }
 
+// stride-1 average pooling of SMALL maps (per-ROI 8x8 in Inception's Mixed_7b/7c: H*W <= 256) through LDS: a block owns
+// 256 / (H*W) consecutive maps of one channel block, reads their records once (consecutive 16-byte loads) and takes the window
+// cells from LDS — the plain kernel issues kh*kw global loads per output.  Same cells, same order: bit-identical to it.
+__global__ __launch_bounds__(256) void avgpool2d_c8i_bf16_small_kernel(const bf16_t *__restrict__ in, int B, int H, int W, size_t pitch_in, int kh, int kw,
+                                                                        int ph, int pw, size_t pitch_out, bf16_t *__restrict__ out) {
+  __shared__ u32x4 tile[256];
+  const int HW = H * W, mpb = 256 / HW;           // maps per block
+  const int cb = blockIdx.y;
+  const int b0 = blockIdx.x * mpb;
+  const int nrec = min(mpb, B - b0) * HW;
+  const int t = threadIdx.x;
+  const u32x4 *ip = reinterpret_cast<const u32x4 *>(in) + (size_t)cb * pitch_in + (size_t)b0 * HW;
+  if (t < nrec) tile[t] = ip[t];
+  __syncthreads();
+  if (t >= nrec) return;
+  const int m = t / HW, r = t - m * HW;
+  const int oy = r / W, ox = r - oy * W;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+  for (int ky = 0; ky < kh; ++ky)
+    for (int kx = 0; kx < kw; ++kx) {
+      const int iy = oy + ky - ph, ix = ox + kx - pw;
+      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+      const u32x4 v = tile[m * HW + iy * W + ix];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[2 * e] += __uint_as_float(v[e] << 16); acc[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u); }
+    }
+  const float inv = 1.0f / (float)(kh * kw);
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (unsigned)f2bf(acc[2 * e] * inv) | ((unsigned)f2bf(acc[2 * e + 1] * inv) << 16);
+  reinterpret_cast<u32x4 *>(out)[(size_t)cb * pitch_out + (size_t)b0 * HW + t] = o;
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 // graph
 // ------------------------------------------------------------------------------------------------------------------------
@@ -1442,7 +1477,12 @@ static int graph_run(ResNetGraph *g, const std::vector<GOp> &ops, std::vector<GT
           hipLaunchKernelGGL(maxpool2d_c8i_kernel, grid, dim3(256), 0, s, src.buf, in.Cb(), B, src.H, src.W, in.pitch(), op.kh, op.sh, op.ph, dst.H, dst.W,
                              od.pitch(), reinterpret_cast<float *>(outp));
       } else {
-        if (g->bf16)
+        if (g->bf16 && op.sh == 1 && op.sw == 1 && dst.H == src.H && dst.W == src.W && src.H * src.W <= 256) {
+          const int mpb = 256 / (src.H * src.W);
+          hipLaunchKernelGGL(avgpool2d_c8i_bf16_small_kernel, dim3((unsigned)((B + mpb - 1) / mpb), (unsigned)in.Cb()), dim3(256), 0, s,
+                             reinterpret_cast<const bf16_t *>(src.buf), B, src.H, src.W, in.pitch(), op.kh, op.kw, op.ph, op.pw, od.pitch(),
+                             reinterpret_cast<bf16_t *>(outp));
+        } else if (g->bf16)
           hipLaunchKernelGGL(avgpool2d_c8i_bf16_kernel, grid16, dim3(256), 0, s, reinterpret_cast<const bf16_t *>(src.buf), in.Cb(), B, src.H, src.W,
                              in.pitch(), op.kh, op.kw, op.sh, op.sw, op.ph, op.pw, dst.H, dst.W, od.pitch(), reinterpret_cast<bf16_t *>(outp));
         else
