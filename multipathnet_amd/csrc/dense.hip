@@ -2009,22 +2009,40 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
   for (; st < st1 - 1; st += 2) { body(st, std::true_type{}, P0{}); body(st + 1, std::true_type{}, P1{}); }
   body(st1 - 1, std::false_type{}, P0{});
 
+  // Epilogue: every bias / residual load is issued before the first store (the empty asm is a compiler barrier for memory
+  // operations).  Stores count in vmcnt on this ISA, so a load that follows a store in program order waits for the store's
+  // acknowledgement; interleaved, the 16 (bias, residual) -> store groups of a tile are 16 exposed round trips, and the two
+  // blocks that share a CU run in lockstep (launched together, same length), so they reach their epilogues together and the
+  // matrix pipe idles for all of it.
   float *yb = a.y + (a.direct ? (size_t)0 : (size_t)split * (a.NP / 8) * a.Mp * 8);
+  f32x4 b4[2][4], r4[2][4][2];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int nb8 = (n0 + wm * 64 + mi * 32) / 8 + g;
-      f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (a.direct) b4 = *reinterpret_cast<const f32x4 *>(a.bpk + nb8 * 8 + half * 4);
+      b4[mi][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a.direct) b4[mi][g] = *reinterpret_cast<const f32x4 *>(a.bpk + nb8 * 8 + half * 4);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int m = m0 + wn * 64 + ni * 32 + l31;
+        r4[mi][g][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.res && m < a.M) r4[mi][g][ni] = *reinterpret_cast<const f32x4 *>(a.res + ((size_t)nb8 * a.Mp + m) * 8 + half * 4);
+      }
+    }
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nb8 = (n0 + wm * 64 + mi * 32) / 8 + g;
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
         const int m = m0 + wn * 64 + ni * 32 + l31;
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float t = acc[mi][ni][g * 4 + e] + b4[e];
-          if (a.res && m < a.M) t += a.res[((size_t)nb8 * a.Mp + m) * 8 + half * 4 + e];
+          float t = acc[mi][ni][g * 4 + e] + b4[mi][g][e] + r4[mi][g][ni][e];
           if (a.direct && a.relu) t = t < 0.0f ? 0.0f : t;
           v[e] = t;
         }
