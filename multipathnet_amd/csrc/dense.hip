@@ -627,912 +627,6 @@ static int launch_conv_wino(const ConvArgs &a, int tiles_y, hipStream_t s) {
   }
 }
 
-// -------------------------------------------------------------------------------------------------
-// Winograd conv, 8-wave form: the same block tile (64 couts x 16x16 px), LDS image and DMA schedule, but 512 threads.
-// With 256 accumulator registers per wave the 4-wave kernel runs ONE wave per SIMD, and a wave's own VALU / LDS /
-// DMA-issue work never overlaps its MFMAs (SQ_VALU_MFMA_COEXEC_CYCLES = 0): the matrix pipe idled ~45 % of the time.
-// Here the 16 Winograd components are split between two waves (wave>>2 = xi half: components xi in {0,1} / {2,3}), so
-// every SIMD holds two waves of 128 accumulator registers and one wave's transforms, waits and epilogue run under the
-// other's MFMAs.  The output transform is linear in the components: each wave forms the partial 2x2 outputs of its
-// half, the two halves swap what the other needs through LDS once per tile, and each finishes half of the channels.
-// -------------------------------------------------------------------------------------------------
-template <int ABL>
-__global__ __launch_bounds__(512) void conv3x3_wino8_kernel(ConvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *const raw_lds = lds;
-  float *const v_lds = lds + 2 * WG_RAW_FLOATS;
-  float *const u_lds = v_lds + 2 * WG_V_FLOATS;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7
-  const int half = lane >> 5, l31 = lane & 31;
-  const int ch = wave >> 2;  // component half: xi in {2ch, 2ch+1}
-  const int ct = blockIdx.x % a.n_ct, sp = blockIdx.x / a.n_ct;
-  const int tyb = sp / a.tiles_x, txb = sp - tyb * a.tiles_x;
-  const int y0 = tyb * 16, x0 = txb * 16, cout0 = ct * 64;
-  const int mbase = ((wave >> 1) & 1) * 32, nbase = (wave & 1) * 32;
-
-  // DMA items: raw tile = 12 wave-loads (item A: t = wave; item B: t = 8 + wave for waves 0-3), weights = 32 (4 per wave)
-  unsigned raw_rel[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int p = min((i * 8 + wave) * 64 + lane, WG_RAW_PIECES - 1);
-    int r = p / 36, o = p - r * 36;
-    raw_rel[i] = (unsigned)(((r * a.in_Wp) * 8 + o * 4) * 4);
-  }
-  const unsigned u_lane = (unsigned)((((wave & 1) * 64 + lane) * 4) * 4);
-  const size_t u_chunk = (size_t)16 * a.CoutP * 8;
-  const float *const in_tile = a.in + (size_t)(y0 * a.in_Wp + x0) * 8;
-  const float *const w_tile = a.wpk + (size_t)cout0 * 8;
-  auto issue_raw = [&](int c, int buf) {
-    const float *src = in_tile + (size_t)c * a.in_plane;
-    glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(src) + (size_t)raw_rel[0]), raw_lds + buf * WG_RAW_FLOATS + wave * 256);
-    if (wave < 4)
-      glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(src) + (size_t)raw_rel[1]), raw_lds + buf * WG_RAW_FLOATS + (8 + wave) * 256);
-  };
-  auto issue_u = [&](int c, int buf, int i) {  // item t = i*8 + wave: component t>>1 = i*4 + (wave>>1), half-slice wave&1
-    const float *slice = w_tile + (size_t)c * u_chunk + (size_t)((i * 4 + (wave >> 1)) * a.CoutP) * 8;
-    glds16(reinterpret_cast<const float *>(reinterpret_cast<const char *>(slice) + (size_t)u_lane), u_lds + buf * WG_U_FLOATS + (i * 8 + wave) * 256);
-  };
-
-  // input transform: this wave produces components xi in {2ch, 2ch+1} for tiles 16*(wave&3) .. +15; lane = tile*4 + channel pair
-  const int tf_tile = (wave & 3) * 16 + (lane >> 2), tf_cp = lane & 3;
-  const int tf_rd = ((2 * (tf_tile >> 3) + ch) * 18 + 2 * (tf_tile & 7)) * 8 + 2 * tf_cp;  // rows ch .. ch+2 of the 4x4 patch
-  const int tf_wr = (ch * 8 * 64 + tf_tile) * 8 + 2 * tf_cp;
-  f32x2 d[12], t[8];
-  auto tf_load = [&](int buf) {
-    const float *R = raw_lds + buf * WG_RAW_FLOATS + tf_rd;
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) d[r * 4 + q] = *reinterpret_cast<const f32x2 *>(R + (r * 18 + q) * 8);
-  };
-  auto tf_rows = [&]() {  // ch 0: t0 = d0 - d2, t1 = d1 + d2 (patch rows 0,1,2);  ch 1: t2 = d2 - d1, t3 = d1 - d3 (patch rows 1,2,3)
-    if (ch == 0) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { t[q] = d[q] - d[8 + q]; t[4 + q] = d[4 + q] + d[8 + q]; }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { t[q] = d[4 + q] - d[q]; t[4 + q] = d[q] - d[8 + q]; }
-    }
-  };
-  auto tf_cols_store = [&](int k, int buf) {  // component row xi = 2ch + k
-    float *Vw = v_lds + buf * WG_V_FLOATS + tf_wr + k * 4 * 512;
-    *reinterpret_cast<f32x2 *>(Vw + 0 * 512) = t[k * 4 + 0] - t[k * 4 + 2];
-    *reinterpret_cast<f32x2 *>(Vw + 1 * 512) = t[k * 4 + 1] + t[k * 4 + 2];
-    *reinterpret_cast<f32x2 *>(Vw + 2 * 512) = t[k * 4 + 2] - t[k * 4 + 1];
-    *reinterpret_cast<f32x2 *>(Vw + 3 * 512) = t[k * 4 + 1] - t[k * 4 + 3];
-  };
-
-  const int c0 = blockIdx.y * a.chunks_per_split;
-  const int c1 = min(a.nchunks, c0 + a.chunks_per_split);
-  issue_raw(c0, 0);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) issue_u(c0, 0, i);
-  issue_raw(min(c0 + 1, c1 - 1), 1);
-  f32x16 acc[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
-  __syncthreads();
-  tf_load(0);
-  tf_rows();
-  tf_cols_store(0, 0);
-  tf_cols_store(1, 0);
-  __syncthreads();
-
-  const int frag_u = (ch * 8 * 64 + mbase + l31) * 8 + half * 4, frag_v = (ch * 8 * 64 + nbase + l31) * 8 + half * 4;
-  f32x4 af[2][2], bf[2][2];
-  auto load_frags = [&](int buf, int pr, int slot) {  // pair pr of this wave's 4: components ch*8 + 2pr, +1
-    const float *Ul = u_lds + buf * WG_U_FLOATS + frag_u, *Vl = v_lds + buf * WG_V_FLOATS + frag_v;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      af[slot][k] = *reinterpret_cast<const f32x4 *>(Ul + (2 * pr + k) * 512);
-      bf[slot][k] = *reinterpret_cast<const f32x4 *>(Vl + (2 * pr + k) * 512);
-    }
-  };
-  load_frags(0, 0, 0);
-  auto body = [&](int c, auto more_tag) {
-    constexpr bool MORE = decltype(more_tag)::value;
-    const int s = (c - c0) & 1;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int cur = p & 1;
-      if (p == 3 && MORE) {
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's last reads of U[s]/V[s] are done before others may overwrite them
-        if constexpr (!(ABL & 2)) __syncthreads();
-        load_frags(s ^ 1, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      acc[2 * p] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0][0], bf[cur][0][0], acc[2 * p], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (p + 1 < 4) load_frags(s, p + 1, cur ^ 1);
-      if constexpr (MORE) {
-        if (p == 0 && !(ABL & 4)) tf_load(s ^ 1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][1][0], bf[cur][1][0], acc[2 * p + 1], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (MORE) {
-        if constexpr (!(ABL & 1)) {
-          if (p == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) issue_u(c + 1, s ^ 1, i);
-            issue_raw(min(c + 2, c1 - 1), s);
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      acc[2 * p] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0][1], bf[cur][0][1], acc[2 * p], 0, 0, 0);
-      acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][1][1], bf[cur][1][1], acc[2 * p + 1], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (MORE) {
-        if constexpr (!(ABL & 4)) {
-          if (p == 1) { tf_rows(); tf_cols_store(0, s ^ 1); }
-          if (p == 2) tf_cols_store(1, s ^ 1);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 2; j < 4; ++j) {
-        acc[2 * p] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][0][j], bf[cur][0][j], acc[2 * p], 0, 0, 0);
-        acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][1][j], bf[cur][1][j], acc[2 * p + 1], 0, 0, 0);
-      }
-    }
-  };
-  for (int c = c0; c < c1 - 1; ++c) body(c, std::true_type{});
-  body(c1 - 1, std::false_type{});
-
-  if constexpr ((ABL & 8) != 0) {
-    if (a.H < 0) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) *reinterpret_cast<f32x16 *>(a.part + (size_t)k * 16 + lane * 256) = acc[k];
-    }
-    return;
-  }
-  // ---- epilogue.  Partial 2x2 outputs of this wave's component half for accumulator register r (acc[nu] = M[2ch][nu],
-  // acc[4+nu] = M[2ch+1][nu]):  ch 0: s = M0 + M1, u = M1;  ch 1: s = M2, u = -M2 - M3;  then
-  // Y00 = s0+s1+s2, Y01 = s1-s2-s3, Y10 = u0+u1+u2, Y11 = u1-u2-u3 (linear, so the halves just add).
-  auto partial = [&](int r, float (&Y)[4]) {
-    float sv[4], uv[4];
-#pragma unroll
-    for (int nu = 0; nu < 4; ++nu) {
-      if (ch == 0) { sv[nu] = acc[nu][r] + acc[4 + nu][r]; uv[nu] = acc[4 + nu][r]; }
-      else { sv[nu] = acc[nu][r]; uv[nu] = -acc[nu][r] - acc[4 + nu][r]; }
-    }
-    Y[0] = sv[0] + sv[1] + sv[2]; Y[1] = sv[1] - sv[2] - sv[3];
-    Y[2] = uv[0] + uv[1] + uv[2]; Y[3] = uv[1] - uv[2] - uv[3];
-  };
-  __syncthreads();  // every wave is done with the stage buffers: reuse them as the exchange area
-  float *const xbuf = lds;  // [wave 8][slot 32][lane 64]
-  // this wave finishes channel groups g in {2ch, 2ch+1} (accumulator registers 8ch .. 8ch+7); the partner (wave ^ 4) the others
-  {
-    float *xw = xbuf + (wave * 32) * 64 + lane;
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      float Y[4];
-      partial((1 - ch) * 8 + rr, Y);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) xw[(rr * 4 + k) * 64] = Y[k];
-    }
-  }
-  f32x4 Yk[2][4];  // [group in my half][pixel k] x 4 channels
-#pragma unroll
-  for (int gg = 0; gg < 2; ++gg)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float Y[4];
-      partial(ch * 8 + gg * 4 + e, Y);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) Yk[gg][k][e] = Y[k];
-    }
-  __syncthreads();
-  {
-    const float *xr = xbuf + ((wave ^ 4) * 32) * 64 + lane;
-#pragma unroll
-    for (int gg = 0; gg < 2; ++gg)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) Yk[gg][k][e] += xr[((gg * 4 + e) * 4 + k) * 64];
-  }
-  const int tau = nbase + l31;
-  const int y = y0 + 2 * (tau >> 3), x = x0 + 2 * (tau & 7);
-  const int pix = ((y + 1) * a.out_Wp + x + 1) * 8 + half * 4;
-#pragma unroll
-  for (int gg = 0; gg < 2; ++gg) {
-    const int cb = __builtin_amdgcn_readfirstlane((cout0 + mbase) / 8 + ch * 2 + gg);
-    if (cb >= a.out_cb) continue;
-    if (a.splits > 1) {  // raw partial sums; conv_splitk_reduce_kernel finishes the layer
-      float *const dst = a.part + (size_t)blockIdx.y * a.part_slab + (size_t)cb * a.out_plane;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int yy = y + (k >> 1), xx = x + (k & 1);
-        if (yy < a.H && xx < a.W) *reinterpret_cast<f32x4 *>(dst + pix + ((k >> 1) * a.out_Wp + (k & 1)) * 8) = Yk[gg][k];
-      }
-      continue;
-    }
-    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bpk + cb * 8 + half * 4);
-    f32x4 m = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    float *const dst = a.out ? a.out + (size_t)cb * a.out_plane : nullptr;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int yy = y + (k >> 1), xx = x + (k & 1);
-      const bool ok = yy < a.H && xx < a.W;
-      f32x4 v = Yk[gg][k] + b4;
-      if (a.relu) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.0f ? 0.0f : v[e];
-      }
-      if (ok && dst) *reinterpret_cast<f32x4 *>(dst + pix + ((k >> 1) * a.out_Wp + (k & 1)) * 8) = v;
-      if (ok) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
-      }
-    }
-    if (a.pool) {
-      const int py = y >> 1, px = x >> 1;
-      if (py < a.pool_H && px < a.pool_W)
-        *reinterpret_cast<f32x4 *>(a.pool + (size_t)cb * a.pool_plane + ((py + 1) * a.pool_Wp + px + 1) * 8 + half * 4) = m;
-    }
-  }
-}
-
-template <int ABL>
-static int launch_conv_wino8_t(const ConvArgs &a, int tiles_y, hipStream_t s) {
-  auto kern = conv3x3_wino8_kernel<ABL>;
-  static bool attr = false;
-  if (!attr) {
-    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS_BYTES));
-    attr = true;
-  }
-  dim3 grid((unsigned)(a.n_ct * tiles_y * a.tiles_x), (unsigned)a.splits);
-  hipLaunchKernelGGL(kern, grid, dim3(512), WG_LDS_BYTES, s, a);
-  MPN_CHECK_LAUNCH();
-  return MPN_OK;
-}
-
-static int launch_conv_wino8(const ConvArgs &a, int tiles_y, hipStream_t s) {
-  switch (a.ablate) {  // timing experiments only (wrong results)
-    case 1: return launch_conv_wino8_t<1>(a, tiles_y, s);
-    case 2: return launch_conv_wino8_t<2>(a, tiles_y, s);
-    case 4: return launch_conv_wino8_t<4>(a, tiles_y, s);
-    case 8: return launch_conv_wino8_t<8>(a, tiles_y, s);
-    case 7: return launch_conv_wino8_t<7>(a, tiles_y, s);
-    case 15: return launch_conv_wino8_t<15>(a, tiles_y, s);
-    default: return launch_conv_wino8_t<0>(a, tiles_y, s);
-  }
-}
-
-
-// =================================================================================================
-// Persistent stream-K conv3x3: ONE block per CU for the whole layer.
-//   * work = T tiles x nchunks K-chunks = U units; block p owns the contiguous unit range
-//     [u0(p), u0(p+1)) (sizes differ by at most one chunk) — no round quantisation, no idle tail;
-//   * the LDS staging pipeline is CONTINUOUS across tile boundaries: the first chunk of the next tile is in
-//     flight while the current tile's last chunk is on the matrix pipe, so no per-tile prologue latency;
-//   * a tile whose chunks all fall inside one block is finished in registers (bias / ReLU / pool / C8P store);
-//     a tile cut by a block boundary leaves raw partial sums in slab j (j = index of the block inside the tile)
-//     and conv_streamk_fixup_kernel adds the slabs in j order (deterministic) and applies the epilogue.
-// =================================================================================================
-struct PersistArgs {
-  ConvArgs c;
-  int T, U, P, base, rem, tiles_y;  // units per block = base (+1 for the first `rem` blocks)
-};
-
-__host__ __device__ inline int sk_u0(int p, int base, int rem) { return p * base + (p < rem ? p : rem); }
-__host__ __device__ inline int sk_block_of(int u, int base, int rem) {
-  const int cut = rem * (base + 1);
-  return u < cut ? u / (base + 1) : rem + (u - cut) / base;
-}
-
-template <int BM, int TH, int WM, int WN>
-__global__ __launch_bounds__(256) void conv3x3_c8p_persistent_kernel(PersistArgs pa) {
-  const ConvArgs &a = pa.c;
-  constexpr int MI = BM / WM / 32, NI = TH / WN;
-  static_assert(WM * WN == 4 && NI == 2, "4 waves, 2 rows per wave (fused pool)");
-  constexpr int IN_PIECES = (TH + 2) * 68;
-  constexpr int IN_LOADS = (IN_PIECES + 63) / 64;
-  constexpr int IN_FLOATS = IN_LOADS * 256;
-  constexpr int W_LOADS = 9 * BM / 32;
-  constexpr int W_FLOATS = 9 * BM * 8;
-  constexpr int STAGE = IN_FLOATS + W_FLOATS;
-  constexpr int IN_IT = (IN_LOADS + 3) / 4, W_IT = (W_LOADS + 3) / 4;
-  constexpr int ITEMS = IN_IT + W_IT, PER_TAP = (ITEMS + 8) / 9;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5, l31 = lane & 31;
-  const int wm = wave / WN, wn = wave % WN;
-  const int mbase = wm * (BM / WM), rbase = wn * NI;
-  const int lane_off = l31 * 8 + half * 4;
-
-  // staging offsets that do not depend on the tile: (row r, piece o) of the halo tile, (tap, cout, half) of the slab
-  int in_rel[IN_IT]; bool in_ok[IN_IT];
-#pragma unroll
-  for (int i = 0; i < IN_IT; ++i) {
-    int t = i * 4 + wave, p = t * 64 + lane;
-    in_ok[i] = (t < IN_LOADS) && (p < IN_PIECES);
-    int r = p / 68, o = p - r * 68;
-    in_rel[i] = (r * a.in_Wp) * 8 + o * 4;
-  }
-  int w_rel[W_IT]; bool w_ok[W_IT];
-#pragma unroll
-  for (int i = 0; i < W_IT; ++i) {
-    int t = i * 4 + wave, p = t * 64 + lane;
-    w_ok[i] = t < W_LOADS;
-    int tap = p / (BM * 2), rem = p - tap * (BM * 2);
-    w_rel[i] = (tap * a.CoutP) * 8 + rem * 4;
-  }
-  const size_t w_chunk = (size_t)9 * a.CoutP * 8;
-
-  const int p = blockIdx.x;
-  const int u_begin = sk_u0(p, pa.base, pa.rem), u_end = sk_u0(p + 1, pa.base, pa.rem);
-  if (u_begin >= u_end) return;
-
-  // tile decode: t -> (cout tile fastest, then x, then y)
-  auto tile_geo = [&](int t, int &y0, int &x0, int &cout0) {
-    const int ct = t % a.n_ct, sp = t / a.n_ct;
-    const int ty = sp / a.tiles_x, tx = sp - ty * a.tiles_x;
-    y0 = ty * TH; x0 = tx * 32; cout0 = ct * BM;
-  };
-  // the unit whose DMA is being issued, as two wave-uniform source pointers.  Advancing to the next unit is
-  // "next chunk of the same tile" (two pointer bumps) except at a tile boundary, where the tile is re-decoded.
-  const float *nx_in = nullptr, *nx_w = nullptr;
-  int nx_t = 0, nx_c = 0;
-  auto decode_tile = [&]() {
-    int y0, x0, cout0;
-    tile_geo(nx_t, y0, x0, cout0);
-    nx_in = a.in + (size_t)nx_c * a.in_plane + (size_t)(y0 * a.in_Wp + x0) * 8;
-    nx_w = a.wpk + (size_t)nx_c * w_chunk + (size_t)cout0 * 8;
-  };
-  auto advance_unit = [&]() {
-    if (++nx_c < a.nchunks) { nx_in += a.in_plane; nx_w += w_chunk; }
-    else { nx_c = 0; ++nx_t; decode_tile(); }
-  };
-  auto issue_item = [&](int s, int item) {  // decoded unit -> stage buffer s
-    float *st = lds + s * STAGE;
-    if (item < IN_IT) {
-      const int i = item;
-      if (in_ok[i]) glds16(nx_in + in_rel[i], st + (i * 4 + wave) * 256);
-    } else if (item - IN_IT < W_IT) {
-      const int i = item - IN_IT;
-      if (w_ok[i]) glds16(nx_w + w_rel[i], st + IN_FLOATS + (i * 4 + wave) * 256);
-    }
-  };
-
-  f32x16 acc[MI][NI];
-  auto zero_acc = [&]() {
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
-  };
-  zero_acc();
-
-  nx_t = u_begin / a.nchunks; nx_c = u_begin - nx_t * a.nchunks;
-  decode_tile();
-#pragma unroll
-  for (int it = 0; it < ITEMS; ++it) issue_item(0, it);
-  __syncthreads();
-
-  int seg_first = u_begin;  // first unit of the tile segment being accumulated
-  int t = nx_t, c = nx_c;    // the unit on the matrix pipe
-
-  for (int u = u_begin; u < u_end; ++u) {
-    const int s = (u - u_begin) & 1;
-    const bool more = u + 1 < u_end;
-    if (more) advance_unit();
-    const float *Il = lds + s * STAGE + lane_off;
-    const float *Wl = lds + s * STAGE + IN_FLOATS + lane_off;
-    f32x4 af[2][MI], bf[2][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) af[0][mi] = *reinterpret_cast<const f32x4 *>(Wl + (mbase + mi * 32) * 8);
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) bf[0][ni] = *reinterpret_cast<const f32x4 *>(Il + ((rbase + ni) * 34) * 8);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int cur = tap & 1;
-      if (tap + 1 < 9) {
-        const int nt = tap + 1, dy = nt / 3, dx = nt % 3;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) af[cur ^ 1][mi] = *reinterpret_cast<const f32x4 *>(Wl + (nt * BM + mbase + mi * 32) * 8);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) bf[cur ^ 1][ni] = *reinterpret_cast<const f32x4 *>(Il + ((rbase + ni + dy) * 34 + dx) * 8);
-      }
-      if (more) {
-#pragma unroll
-        for (int q = 0; q < PER_TAP; ++q) issue_item(s ^ 1, tap * PER_TAP + q);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][mi][j], bf[cur][ni][j], acc[mi][ni], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-
-    // ---- end of a tile segment?  (last chunk of the tile, or last unit of this block)
-    if (c == a.nchunks - 1 || !more) {
-      int y0, x0, cout0;
-      tile_geo(t, y0, x0, cout0);
-      const int cs = seg_first - t * a.nchunks;
-      const bool whole = (cs == 0) && (c == a.nchunks - 1);
-      const int x = x0 + l31;
-      const bool xok = x < a.W;
-      if (!whole) {  // raw partial sums into slab j = position of this block among the blocks that cut the tile
-        const int j = p - sk_block_of(t * a.nchunks, pa.base, pa.rem);
-        float *pb = a.part + (size_t)j * a.part_slab;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int cb = (cout0 + mbase + mi * 32) / 8 + g;
-            if (cb >= a.out_cb) continue;
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-              const int y = y0 + rbase + ni;
-              if (xok && y < a.H) {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][g * 4 + e];
-                *reinterpret_cast<f32x4 *>(pb + (size_t)cb * a.out_plane + ((size_t)(y + 1) * a.out_Wp + x + 1) * 8 + half * 4) = v;
-              }
-            }
-          }
-      } else {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int cb = (cout0 + mbase + mi * 32) / 8 + g;
-            if (cb >= a.out_cb) continue;
-            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bpk + cb * 8 + half * 4);
-            f32x4 v[NI];
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-              const int y = y0 + rbase + ni;
-              const bool ok = xok && (y < a.H);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                float tv = acc[mi][ni][g * 4 + e] + b4[e];
-                if (a.relu) tv = tv < 0.0f ? 0.0f : tv;
-                v[ni][e] = tv;
-              }
-              if (ok && a.out)
-                *reinterpret_cast<f32x4 *>(a.out + (size_t)cb * a.out_plane + ((size_t)(y + 1) * a.out_Wp + x + 1) * 8 + half * 4) = v[ni];
-              if (!ok) v[ni] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-            }
-            if (a.pool) {
-              f32x4 m;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                float tv = fmaxf(v[0][e], v[1][e]);
-                m[e] = fmaxf(tv, __shfl_xor(tv, 1));
-              }
-              const int py = (y0 + rbase) >> 1, px = x >> 1;
-              if (!(l31 & 1) && py < a.pool_H && px < a.pool_W)
-                *reinterpret_cast<f32x4 *>(a.pool + (size_t)cb * a.pool_plane + ((size_t)(py + 1) * a.pool_Wp + px + 1) * 8 + half * 4) = m;
-            }
-          }
-        }
-      }
-      zero_acc();
-      seg_first = u + 1;
-    }
-    if (++c == a.nchunks) { c = 0; ++t; }
-    __syncthreads();
-  }
-}
-
-// Finishes the tiles that a block boundary cut: one block per tile; tiles owned by a single block exit at once.
-template <int BM, int TH, int TW>
-__device__ __forceinline__ void streamk_fixup_tile(const PersistArgs &pa, int t) {
-  const ConvArgs &a = pa.c;
-  const int pf = sk_block_of(t * a.nchunks, pa.base, pa.rem), pl = sk_block_of(t * a.nchunks + a.nchunks - 1, pa.base, pa.rem);
-  const int nseg = pl - pf + 1;
-  if (nseg == 1) return;
-  const int ct = t % a.n_ct, sp = t / a.n_ct;
-  const int ty = sp / a.tiles_x, tx = sp - ty * a.tiles_x;
-  const int y0 = ty * TH, x0 = tx * TW, cb0 = ct * BM / 8;
-  // items: (cb in tile, pooled-or-full row pair, column pair, half) — each thread finishes a 2x2 pixel quad of 4 channels
-  constexpr int QY = TH / 2, QX = TW / 2;
-  const int items = (BM / 8) * QY * QX * 2;
-  for (int it = threadIdx.x; it < items; it += blockDim.x) {
-    const int h = it & 1; int r = it >> 1;
-    const int qx = r % QX; r /= QX;
-    const int qy = r % QY; const int cbl = r / QY;
-    const int cb = cb0 + cbl;
-    if (cb >= a.out_cb) continue;
-    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bpk + cb * 8 + h * 4);
-    f32x4 m = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    bool any = false;
-#pragma unroll
-    for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-      for (int dx = 0; dx < 2; ++dx) {
-        const int y = y0 + 2 * qy + dy, x = x0 + 2 * qx + dx;
-        if (y >= a.H || x >= a.W) continue;
-        const size_t off = (size_t)cb * a.out_plane + ((size_t)(y + 1) * a.out_Wp + x + 1) * 8 + h * 4;
-        f32x4 v = *reinterpret_cast<const f32x4 *>(a.part + off);
-        for (int j = 1; j < nseg; ++j) v += *reinterpret_cast<const f32x4 *>(a.part + (size_t)j * a.part_slab + off);
-        v += b4;
-        if (a.relu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.0f ? 0.0f : v[e];
-        }
-        if (a.out) *reinterpret_cast<f32x4 *>(a.out + off) = v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
-        any = true;
-      }
-    if (a.pool && any) {
-      const int py = (y0 >> 1) + qy, px = (x0 >> 1) + qx;
-      if (py < a.pool_H && px < a.pool_W)
-        *reinterpret_cast<f32x4 *>(a.pool + (size_t)cb * a.pool_plane + ((size_t)(py + 1) * a.pool_Wp + px + 1) * 8 + h * 4) = m;
-    }
-  }
-}
-
-template <int BM, int TH, int TW = 32>
-__global__ __launch_bounds__(256) void conv_streamk_fixup_kernel(PersistArgs pa) {  // one block per tile
-  streamk_fixup_tile<BM, TH, TW>(pa, blockIdx.x);
-}
-
-// one block per block BOUNDARY (P-1 blocks instead of T): boundary j sits at unit u0(j+1); it finishes the tile it cuts, unless
-// an earlier boundary lies strictly inside the same tile (that one's block does it)
-template <int BM, int TH, int TW>
-__global__ __launch_bounds__(256) void conv_streamk_fixup_cut_kernel(PersistArgs pa) {
-  const int nch = pa.c.nchunks;
-  const int ub = sk_u0(blockIdx.x + 1, pa.base, pa.rem);
-  const int t = ub / nch;
-  if (ub == t * nch) return;                                   // the boundary coincides with a tile boundary
-  if (sk_u0(blockIdx.x, pa.base, pa.rem) > t * nch) return;     // not the first boundary inside this tile
-  streamk_fixup_tile<BM, TH, TW>(pa, t);
-}
-
-// =================================================================================================
-// Winograd conv, persistent stream-K form: P = #CUs blocks, block p runs the contiguous unit range
-// [u0(p), u0(p+1)) of the (tile, 8-channel chunk) stream.  The DMA / transform / MFMA pipeline of
-// conv3x3_wino_kernel simply keeps running across tile boundaries (the next tile's raw tiles and weight slices
-// are already in flight while the finished tile's accumulators are transformed and stored), so the per-tile
-// prologue (a DMA round trip + the first transform, ~4 chunk times with one block per CU) and the round
-// quantisation of a one-block-per-tile grid disappear.  Tiles cut by a block boundary leave raw partial sums in
-// per-segment slabs; conv_streamk_fixup_kernel adds them in block order (deterministic).
-// =================================================================================================
-template <int ABL>
-__global__ __launch_bounds__(256) void conv3x3_wino_persistent_kernel(PersistArgs pa) {
-  const ConvArgs &a = pa.c;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *const raw_lds = lds;
-  float *const v_lds = lds + 2 * WG_RAW_FLOATS;
-  float *const u_lds = v_lds + 2 * WG_V_FLOATS;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5, l31 = lane & 31;
-  const int mbase = (wave >> 1) * 32, nbase = (wave & 1) * 32;
-  const int p = blockIdx.x;
-  const int u_begin = sk_u0(p, pa.base, pa.rem), u_end = sk_u0(p + 1, pa.base, pa.rem);
-  if (u_begin >= u_end) return;
-
-  // tile-independent staging offsets (see conv3x3_wino_kernel)
-  // DMA sources are (wave-uniform 64-bit base) + (32-bit per-lane byte offset): the saddr form of global_load_lds,
-  // no 64-bit VALU address arithmetic in the loop and one offset VGPR instead of a 64-bit pair per item
-  constexpr int RAW_IT = (WG_RAW_LOADS + 3) / 4;
-  unsigned raw_rel[RAW_IT];
-#pragma unroll
-  for (int i = 0; i < RAW_IT; ++i) {
-    int q = min((i * 4 + wave) * 64 + lane, WG_RAW_PIECES - 1);
-    int r = q / 36, o = q - r * 36;
-    raw_rel[i] = (unsigned)(((r * a.in_Wp) * 8 + o * 4) * 4);
-  }
-  // weight slice item i of this wave: component (i*4+wave)/2 (uniform), 16-byte piece (wave&1)*64 + lane of its 64 couts
-  const unsigned u_lane = (unsigned)((((wave & 1) * 64 + lane) * 4) * 4);
-  const size_t u_chunk = (size_t)16 * a.CoutP * 8;
-  auto tile_geo = [&](int t, int &y0, int &x0, int &cout0) {
-    const int ct = t % a.n_ct, sp = t / a.n_ct;
-    const int ty = sp / a.tiles_x, tx = sp - ty * a.tiles_x;
-    y0 = ty * 16; x0 = tx * 16; cout0 = ct * 64;
-  };
-  // stream cursors (wave-uniform): a unit's raw-tile source and weight-slice source
-  struct Cur { int t, c; const float *in, *w; };
-  auto decode = [&](Cur &k) {
-    int y0, x0, cout0;
-    tile_geo(k.t, y0, x0, cout0);
-    k.in = a.in + (size_t)k.c * a.in_plane + (size_t)(y0 * a.in_Wp + x0) * 8;
-    k.w = a.wpk + (size_t)k.c * u_chunk + (size_t)cout0 * 8;
-  };
-  auto advance = [&](Cur &k) {
-    if (++k.c < a.nchunks) { k.in += a.in_plane; k.w += u_chunk; }
-    else { k.c = 0; ++k.t; decode(k); }
-  };
-  const unsigned lds0 = lds_byte_addr(lds);
-  const unsigned raw_slot = lds0 + (unsigned)(wave * 256) * 4, u_slot = lds0 + (unsigned)(2 * WG_RAW_FLOATS + 2 * WG_V_FLOATS + wave * 256) * 4;
-  auto issue_raw_item = [&](const float *src, int buf, int i) { glds16_saddr(src, raw_rel[i], raw_slot + (unsigned)(buf * WG_RAW_FLOATS + i * 1024) * 4); };
-  auto issue_raw = [&](const float *src, int buf) {
-#pragma unroll
-    for (int i = 0; i < RAW_IT; ++i) issue_raw_item(src, buf, i);
-  };
-  auto issue_u = [&](const float *src, int buf, int i) {
-    glds16_saddr(src + (size_t)(((i * 4 + wave) >> 1) * a.CoutP) * 8, u_lane, u_slot + (unsigned)(buf * WG_U_FLOATS + i * 1024) * 4);
-  };
-
-  const int tf_tile = wave * 16 + (lane >> 2), tf_cp = lane & 3;
-  const int tf_rd = ((2 * (tf_tile >> 3)) * 18 + 2 * (tf_tile & 7)) * 8 + 2 * tf_cp;
-  const int tf_wr = tf_tile * 8 + 2 * tf_cp;
-  f32x2 d[16], t[16];
-  auto tf_load = [&](int buf) {
-    const float *R = raw_lds + buf * WG_RAW_FLOATS + tf_rd;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) d[r * 4 + q] = *reinterpret_cast<const f32x2 *>(R + (r * 18 + q) * 8);
-  };
-  auto tf_rows = [&]() {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      t[0 + q] = d[0 + q] - d[8 + q];
-      t[4 + q] = d[4 + q] + d[8 + q];
-      t[8 + q] = d[8 + q] - d[4 + q];
-      t[12 + q] = d[4 + q] - d[12 + q];
-    }
-  };
-  auto tf_cols_store = [&](int xi, int buf) {
-    float *Vw = v_lds + buf * WG_V_FLOATS + tf_wr + xi * 4 * 512;
-    *reinterpret_cast<f32x2 *>(Vw + 0 * 512) = t[xi * 4 + 0] - t[xi * 4 + 2];
-    *reinterpret_cast<f32x2 *>(Vw + 1 * 512) = t[xi * 4 + 1] + t[xi * 4 + 2];
-    *reinterpret_cast<f32x2 *>(Vw + 2 * 512) = t[xi * 4 + 2] - t[xi * 4 + 1];
-    *reinterpret_cast<f32x2 *>(Vw + 3 * 512) = t[xi * 4 + 1] - t[xi * 4 + 3];
-  };
-
-  auto tf_load_item = [&](int buf, int i) {
-    const float *R = raw_lds + buf * WG_RAW_FLOATS + tf_rd + ((i >> 1) * 18 + (i & 1) * 2) * 8;
-    d[2 * i] = *reinterpret_cast<const f32x2 *>(R);
-    d[2 * i + 1] = *reinterpret_cast<const f32x2 *>(R + 8);
-  };
-  auto tf_cols_compute = [&](int xi) {
-    const f32x2 v0 = t[xi * 4 + 0] - t[xi * 4 + 2], v1 = t[xi * 4 + 1] + t[xi * 4 + 2];
-    const f32x2 v2 = t[xi * 4 + 2] - t[xi * 4 + 1], v3 = t[xi * 4 + 1] - t[xi * 4 + 3];
-    t[xi * 4 + 0] = v0; t[xi * 4 + 1] = v1; t[xi * 4 + 2] = v2; t[xi * 4 + 3] = v3;
-  };
-  auto tf_store_item = [&](int i, int buf) {
-    float *Vw = v_lds + buf * WG_V_FLOATS + tf_wr + (2 * i) * 512;
-    *reinterpret_cast<f32x2 *>(Vw) = t[2 * i];
-    *reinterpret_cast<f32x2 *>(Vw + 512) = t[2 * i + 1];
-  };
-
-  Cur cu, cr;  // cu: the unit whose weight slices are DMA'd next (u+1); cr: the unit whose raw tile is DMA'd next (u+2)
-  cu.t = u_begin / a.nchunks; cu.c = u_begin - cu.t * a.nchunks;
-  decode(cu);
-  int tcur = cu.t;  // the tile on the matrix pipe
-  issue_raw(cu.in, 0);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) issue_u(cu.w, 0, i);
-  if (u_begin + 1 < u_end) advance(cu);
-  issue_raw(cu.in, 1);
-  cr = cu;
-  if (u_begin + 2 < u_end) advance(cr);
-  f32x16 acc[16];
-  auto zero_acc = [&]() {
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
-  };
-  zero_acc();
-  dma_wait_all();
-  __syncthreads();
-  tf_load(0);
-  tf_rows();
-#pragma unroll
-  for (int xi = 0; xi < 4; ++xi) tf_cols_store(xi, 0);
-  __syncthreads();
-
-  const int frag_u = (mbase + l31) * 8 + half * 4, frag_v = (nbase + l31) * 8 + half * 4;
-  f32x4 af[2][2], bf[2][2];
-  auto load_frags = [&](int buf, int pr, int slot) {
-    const float *Ul = u_lds + buf * WG_U_FLOATS + frag_u, *Vl = v_lds + buf * WG_V_FLOATS + frag_v;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      af[slot][k] = *reinterpret_cast<const f32x4 *>(Ul + (2 * pr + k) * 512);
-      bf[slot][k] = *reinterpret_cast<const f32x4 *>(Vl + (2 * pr + k) * 512);
-    }
-  };
-  load_frags(0, 0, 0);
-
-  // one unit on the matrix pipe (schedule: see conv3x3_wino_kernel)
-  auto body = [&](int s, auto more_tag) {
-    constexpr bool MORE = decltype(more_tag)::value;
-#pragma unroll
-    for (int pp = 0; pp < 8; ++pp) {
-      const int cur = pp & 1;
-      if (pp == 7 && MORE) {
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        dma_wait_all();
-        if constexpr (!(ABL & 2)) __syncthreads();
-        if constexpr (!(ABL & 16)) load_frags(s ^ 1, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        __builtin_amdgcn_sched_barrier(0);
-        acc[2 * pp + (i & 1)] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i & 1][i >> 1], bf[cur][i & 1][i >> 1], acc[2 * pp + (i & 1)], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (i == 0 && pp + 1 < 8 && !(ABL & 16)) load_frags(s, pp + 1, cur ^ 1);
-        if constexpr (MORE) {
-          const int m = pp * 8 + i;
-          if constexpr (!(ABL & 1)) {
-            if (m >= 1 && m <= 8) issue_u(cu.w, s ^ 1, m - 1);
-            else if (m >= 9 && m <= 11) issue_raw_item(cr.in, s, m - 9);
-          }
-          if constexpr (!(ABL & 4)) {
-            if (m >= 12 && m <= 19) tf_load_item(s ^ 1, m - 12);
-            else if (m == 27) {
-              tf_rows();
-#pragma unroll
-              for (int xi = 0; xi < 4; ++xi) tf_cols_compute(xi);
-            } else if (m >= 28 && m <= 35) tf_store_item(m - 28, s ^ 1);
-          }
-        }
-      }
-    }
-  };
-
-  // end of a tile segment: output transform A^T M A (register-local), then either the finished layer output
-  // (bias, ReLU, fused 2x2 max-pool) or raw partial sums into this segment's slab
-  const int tau = nbase + l31;
-  auto finish_segment = [&](int tt, bool whole, int slab) {
-    if constexpr ((ABL & 8) != 0) {
-      if (a.H < 0) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) *reinterpret_cast<f32x16 *>(a.part + (size_t)k * 16 + lane * 256) = acc[k];
-      }
-      return;
-    }
-    int y0, x0, cout0;
-    tile_geo(tt, y0, x0, cout0);
-    const int y = y0 + 2 * (tau >> 3), x = x0 + 2 * (tau & 7);
-    // wave-uniform 64-bit bases + one 32-bit per-lane offset (a channel-block plane is far below 4 GiB)
-    const int pix = ((y + 1) * a.out_Wp + x + 1) * 8 + half * 4;
-    float *const pb = a.part + (size_t)slab * a.part_slab;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int cb = __builtin_amdgcn_readfirstlane((cout0 + mbase) / 8 + g);
-      if (cb >= a.out_cb) continue;
-      f32x4 Y[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = g * 4 + e;
-        const float s0 = acc[0][r] + acc[4][r] + acc[8][r], s1 = acc[1][r] + acc[5][r] + acc[9][r];
-        const float s2 = acc[2][r] + acc[6][r] + acc[10][r], s3 = acc[3][r] + acc[7][r] + acc[11][r];
-        const float q0 = acc[4][r] - acc[8][r] - acc[12][r], q1 = acc[5][r] - acc[9][r] - acc[13][r];
-        const float q2 = acc[6][r] - acc[10][r] - acc[14][r], q3 = acc[7][r] - acc[11][r] - acc[15][r];
-        Y[0][e] = s0 + s1 + s2; Y[1][e] = s1 - s2 - s3;
-        Y[2][e] = q0 + q1 + q2; Y[3][e] = q1 - q2 - q3;
-      }
-      if (!whole) {
-        float *const dst = pb + (size_t)cb * a.out_plane;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int yy = y + (k >> 1), xx = x + (k & 1);
-          if (yy < a.H && xx < a.W) *reinterpret_cast<f32x4 *>(dst + pix + ((k >> 1) * a.out_Wp + (k & 1)) * 8) = Y[k];
-        }
-        continue;
-      }
-      const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bpk + cb * 8 + half * 4);
-      f32x4 m = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      float *const dst = a.out ? a.out + (size_t)cb * a.out_plane : nullptr;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int yy = y + (k >> 1), xx = x + (k & 1);
-        const bool ok = yy < a.H && xx < a.W;
-        f32x4 v = Y[k] + b4;
-        if (a.relu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.0f ? 0.0f : v[e];
-        }
-        if (ok && dst) *reinterpret_cast<f32x4 *>(dst + pix + ((k >> 1) * a.out_Wp + (k & 1)) * 8) = v;
-        if (ok) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
-        }
-      }
-      if (a.pool) {
-        const int py = y >> 1, px = x >> 1;
-        if (py < a.pool_H && px < a.pool_W)
-          *reinterpret_cast<f32x4 *>(a.pool + (size_t)cb * a.pool_plane + ((py + 1) * a.pool_Wp + px + 1) * 8 + half * 4) = m;
-      }
-    }
-  };
-
-  // outer loop: tile segments; inner loop: the branch-free MFMA pipeline.  (The epilogue stays out of the inner
-  // loop so that its address arithmetic is not hoisted into — and spilled inside — the hot loop.)
-  int u = u_begin, seg_first = u_begin;
-  while (true) {
-    const int tile_end = (tcur + 1) * a.nchunks;
-    const bool last_seg = tile_end >= u_end;
-    const int seg_end = last_seg ? u_end : tile_end;
-    const int inner_end = last_seg ? seg_end - 1 : seg_end;
-    for (; u < inner_end; ++u) {
-      body((u - u_begin) & 1, std::true_type{});
-      if (u + 2 < u_end) advance(cu);
-      if (u + 3 < u_end) advance(cr);
-    }
-    if (last_seg) { body((u - u_begin) & 1, std::false_type{}); ++u; }
-    const bool whole = (seg_first == tcur * a.nchunks) && (seg_end == tile_end);
-    finish_segment(tcur, whole, p - sk_block_of(tcur * a.nchunks, pa.base, pa.rem));
-    if (last_seg) break;
-    zero_acc();
-    ++tcur;
-    seg_first = u;
-  }
-}
-
-template <int ABL>
-static int launch_conv_wino_persistent_t(PersistArgs &pa, hipStream_t s) {
-  auto kern = conv3x3_wino_persistent_kernel<ABL>;
-  static bool attr = false;
-  if (!attr) {
-    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS_BYTES));
-    attr = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(pa.P), dim3(256), WG_LDS_BYTES, s, pa);
-  MPN_CHECK_LAUNCH();
-  if (pa.P > 1 && (pa.U % pa.P != 0 || pa.base % pa.c.nchunks != 0)) {  // some tile is cut by a block boundary
-    hipLaunchKernelGGL((conv_streamk_fixup_cut_kernel<64, 16, 16>), dim3(pa.P - 1), dim3(256), 0, s, pa);
-    MPN_CHECK_LAUNCH();
-  }
-  return MPN_OK;
-}
-
-static int launch_conv_wino_persistent(PersistArgs &pa, hipStream_t s) {
-  switch (pa.c.ablate) {  // timing experiments only (wrong results)
-    case 1: return launch_conv_wino_persistent_t<1>(pa, s);
-    case 2: return launch_conv_wino_persistent_t<2>(pa, s);
-    case 4: return launch_conv_wino_persistent_t<4>(pa, s);
-    case 8: return launch_conv_wino_persistent_t<8>(pa, s);
-    case 7: return launch_conv_wino_persistent_t<7>(pa, s);
-    case 15: return launch_conv_wino_persistent_t<15>(pa, s);
-    case 31: return launch_conv_wino_persistent_t<31>(pa, s);
-    default: return launch_conv_wino_persistent_t<0>(pa, s);
-  }
-}
-
-// Measured on MI355X (tools/bench_layers.py, tools/conv_shape_probe.py): the persistent stream-K kernel removes round
-// quantisation but its K loop runs 3-5 % slower than the plain kernel's (extra scalar state around the MFMA blocks), and a
-// deferred (interleaved) epilogue made it 15 % slower — so the VGG trunk is 3.69 ms with it vs 3.52 ms block-per-tile +
-// split-K.  It therefore stays an option (mode 1), fully parity-tested; the default is mode 0.
-// The persistent Winograd kernel is 2-3 % faster than block-per-tile in isolation (trunk 2.22 vs 2.28 ms), but a grid that
-// pins one 155-KB-LDS block on every CU for the whole layer leaves the pipelined detector's NMS / top-k side stream
-// nowhere to run: end to end it is SLOWER (233.6k vs 241.7k proposals/s).  Default = block per tile.
-static int g_conv_mode = 0;  // 0 = one block per tile (+ split-K, default), 1 = persistent stream-K
-static int g_num_cus = 0;
-static int g_persist_blocks = 0;  // persistent kernels: blocks to launch (0 = one per CU); < #CUs leaves CUs to a concurrent stream
-
-template <int BM, int TH, int WM, int WN>
-static int launch_conv_persistent(PersistArgs &pa, hipStream_t s) {
-  constexpr int IN_LOADS = ((TH + 2) * 68 + 63) / 64;
-  constexpr size_t LDS = (size_t)2 * (IN_LOADS * 256 + 9 * BM * 8) * sizeof(float);
-  auto kern = conv3x3_c8p_persistent_kernel<BM, TH, WM, WN>;
-  static bool attr = false;
-  if (!attr) {
-    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-    attr = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(pa.P), dim3(256), LDS, s, pa);
-  MPN_CHECK_LAUNCH();
-  if (pa.U % pa.P != 0 || pa.base % pa.c.nchunks != 0) {  // some tile is cut by a block boundary
-    hipLaunchKernelGGL((conv_streamk_fixup_kernel<BM, TH>), dim3(pa.T), dim3(256), 0, s, pa);
-    MPN_CHECK_LAUNCH();
-  }
-  return MPN_OK;
-}
-
 // split-K finish: sums S partial slabs in split order (deterministic), + bias, ReLU; writes the C8P
 // output and/or its ceil-mode 2x2 max-pool.  One thread per (channel block, pooled-or-full pixel, half).
 __global__ void conv_splitk_reduce_kernel(const float *__restrict__ part, size_t slab, int S, size_t plane, int Wp, int H, int W,
@@ -1618,7 +712,7 @@ int conv3x3_variant_for(int Cout, bool has_wino) {
   // measured on MI355X (tools/bench_layers.py): Winograd F(2x2,3x3) beats the direct kernels on every VGG layer with
   // >= 16 input channels (2.33 vs 3.53 ms for the trunk); among the direct kernels one 4-wave block per CU (9 taps per
   // stage) beats the 3-blocks-per-CU variants — co-resident waves only time-share the SIMD's matrix pipe.
-  if ((variant == 7 || variant == 8) && !has_wino) variant = 0;
+  if (variant == 7 && !has_wino) variant = 0;
   if (variant == 0) variant = has_wino ? 7 : ((Cout <= 64) ? 2 : 1);
   return variant;
 }
@@ -1639,42 +733,13 @@ int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int re
   if (pooled.p) MPN_CHECK_ARG(pooled.H == (in.H + 1) / 2 && pooled.W == (in.W + 1) / 2 && pooled.C == Cout);
   int variant = conv3x3_variant_for(Cout, d_wino != nullptr);
   if (!d_wpk) variant = 7;
-  if (variant == 7 || variant == 8) {  // Winograd F(2x2,3x3): 64 couts x 16x16 px per block (7 = 4-wave kernel, 8 = 8-wave kernel)
+  if (variant == 7) {  // Winograd F(2x2,3x3): 64 couts x 16x16 px per block
     a.wpk = d_wino;
     a.tiles_x = cdiv(in.W, 16);
     const int tiles_y = cdiv(in.H, 16);
     a.n_ct = cdiv(Cout, 64);
     const int blocks = a.n_ct * tiles_y * a.tiles_x;
     Act geo = out.p ? out : make_act(nullptr, Cout, in.H, in.W);
-    if (g_conv_mode == 1 && g_conv_split == 0 && variant == 7) {  // persistent stream-K (opt-in, see the note at g_conv_mode)
-      if (g_num_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        MPN_CHECK_HIP(hipGetDevice(&dev));
-        MPN_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-        g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-      }
-      PersistArgs pa{};
-      pa.T = blocks; pa.U = blocks * a.nchunks; pa.tiles_y = tiles_y;
-      const int pmax = (g_persist_blocks > 0 && g_persist_blocks < g_num_cus) ? g_persist_blocks : g_num_cus;
-      pa.P = pa.U < pmax ? pa.U : pmax;
-      pa.base = pa.U / pa.P; pa.rem = pa.U % pa.P;
-      a.out_plane = geo.plane(); a.out_Wp = geo.Wp;
-      a.part_slab = geo.elems();
-      const int nseg_max = (a.nchunks - 1) / pa.base + 2;  // blocks that can cut one tile
-      const size_t need = a.part_slab * (size_t)nseg_max * sizeof(float);
-      if (need > g_conv_ws_bytes) {
-        MPN_CHECK_HIP(hipStreamSynchronize(s));
-        if (g_conv_ws) (void)hipFree(g_conv_ws);
-        g_conv_ws = nullptr; g_conv_ws_bytes = 0;
-        MPN_CHECK_HIP(hipMalloc(&g_conv_ws, need));
-        g_conv_ws_bytes = need;
-      }
-      a.part = g_conv_ws;
-      a.splits = 1; a.chunks_per_split = a.nchunks;
-      pa.c = a;
-      return launch_conv_wino_persistent(pa, s);
-    }
     a.splits = wino_pick_splits(blocks, a.nchunks, geo.elems() * sizeof(float));
     a.chunks_per_split = cdiv(a.nchunks, a.splits);
     a.splits = cdiv(a.nchunks, a.chunks_per_split);
@@ -1691,7 +756,7 @@ int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int re
       }
       a.part = g_conv_ws;
     }
-    int rc = variant == 8 ? launch_conv_wino8(a, tiles_y, s) : launch_conv_wino(a, tiles_y, s);
+    int rc = launch_conv_wino(a, tiles_y, s);
     if (rc != MPN_OK || a.splits == 1) return rc;
     const int GH = pooled.p ? pooled.H : in.H, GW = pooled.p ? pooled.W : in.W;
     const size_t total = (size_t)a.out_cb * GH * GW * 2;
@@ -1705,35 +770,6 @@ int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int re
   const int tiles_y = cdiv(in.H, th);
   a.n_ct = cdiv(Cout, wide ? 128 : 64);
   const int blocks = a.n_ct * tiles_y * a.tiles_x;
-  if (g_conv_mode == 1 && (variant == 1 || variant == 2) && g_conv_split == 0) {
-    if (g_num_cus == 0) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      MPN_CHECK_HIP(hipGetDevice(&dev));
-      MPN_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-      g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    PersistArgs pa{};
-    pa.T = blocks; pa.U = blocks * a.nchunks; pa.tiles_y = tiles_y;
-    pa.P = pa.U < g_num_cus ? pa.U : g_num_cus;
-    pa.base = pa.U / pa.P; pa.rem = pa.U % pa.P;
-    Act geo = out.p ? out : make_act(nullptr, Cout, in.H, in.W);
-    a.out_plane = geo.plane(); a.out_Wp = geo.Wp;
-    a.part_slab = geo.elems();
-    const int nseg_max = (a.nchunks - 1) / pa.base + 2;  // blocks that can cut one tile
-    const size_t need = a.part_slab * (size_t)nseg_max * sizeof(float);
-    if (need > g_conv_ws_bytes) {
-      MPN_CHECK_HIP(hipStreamSynchronize(s));
-      if (g_conv_ws) (void)hipFree(g_conv_ws);
-      g_conv_ws = nullptr; g_conv_ws_bytes = 0;
-      MPN_CHECK_HIP(hipMalloc(&g_conv_ws, need));
-      g_conv_ws_bytes = need;
-    }
-    a.part = g_conv_ws;
-    a.splits = 1; a.chunks_per_split = a.nchunks;
-    pa.c = a;
-    return wide ? launch_conv_persistent<128, 4, 2, 2>(pa, s) : launch_conv_persistent<64, 8, 1, 4>(pa, s);
-  }
   const int slots = (variant == 1 || variant >= 5) ? 256 : (variant == 2 ? 512 : 768);  // co-resident blocks on 256 CUs (LDS / VGPR bound)
   a.splits = conv_pick_splits(blocks, a.nchunks, slots);
   a.chunks_per_split = cdiv(a.nchunks, a.splits);
@@ -1785,134 +821,8 @@ struct GemmArgs {
   const float *res;  // optional residual in y's layout, added before the ReLU (direct mode only; ResNet 1x1 convolutions)
 };
 
-// KCH = 8-wide K chunks per LDS stage (4 -> 32 k per stage, 32 KiB per stage);  NBUF = LDS ring depth:
-//   2: next stage's DMA issued at the top of the current stage, `vmcnt(0)` + barrier at its end;
-//   3: DMA runs TWO stages ahead; the end-of-stage wait is a counted `vmcnt(2*IT)` (only the older stage must
-//      have landed) followed by a raw s_barrier, so HBM / cross-XCD latency up to ~2 stage times stays hidden.
-template <int KCH, int NBUF>
-__global__ __launch_bounds__(256) void gemm_c8_kernel(GemmArgs a) {
-  constexpr int OP_FLOATS = KCH * 128 * 8;  // per operand per stage
-  constexpr int STAGE = 2 * OP_FLOATS;
-  constexpr int LOADS = OP_FLOATS / 256;    // 1 KiB wave-loads per operand
-  constexpr int IT = LOADS / 4;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5, l31 = lane & 31;
-  // XCD-aware tile order: blocks b, b+8, ... share an XCD (L2); give each XCD a contiguous run of
-  // logical tiles = the m-tiles of one weight panel, so the panel is fetched from HBM once per XCD.
-  int b = blockIdx.x;
-  const int nb = gridDim.x;
-  if ((nb & 7) == 0) b = (b & 7) * (nb >> 3) + (b >> 3);
-  const int nt = a.n_fast ? b % a.n_nt : b / a.n_mt, mt = a.n_fast ? b / a.n_nt : b - nt * a.n_mt;
-  const int n0 = nt * 128, m0 = mt * 128;
-  const int split = blockIdx.y;
-  const int st0 = split * a.stages_per_split;
-  const int st1 = min(a.nstages, st0 + a.stages_per_split);
-  const int wm = wave >> 1, wn = wave & 1;
-
-  int a_off[IT], b_off[IT];
-#pragma unroll
-  for (int i = 0; i < IT; ++i) {
-    int p = (i * 4 + wave) * 64 + lane;  // 16-byte piece inside the [KCH][128][8] operand tile
-    int kk = p >> 8, rem = p & 255;
-    a_off[i] = (kk * a.NP + n0) * 8 + rem * 4;
-    b_off[i] = (kk * a.Mp + m0) * 8 + rem * 4;
-  }
-  const size_t a_stage = (size_t)KCH * a.NP * 8, b_stage = (size_t)KCH * a.Mp * 8;
-
-  auto issue = [&](int st, int s) {  // 2*IT global_load_lds per wave
-    const float *ab = a.wpk + (size_t)st * a_stage;
-    const float *bb = a.x + (size_t)st * b_stage;
-    float *l = lds + s * STAGE;
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      glds16(ab + a_off[i], l + (i * 4 + wave) * 256);
-      glds16(bb + b_off[i], l + OP_FLOATS + (i * 4 + wave) * 256);
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
-
-  const int lane_off = l31 * 8 + half * 4;
-  if (st0 < st1) issue(st0, 0);
-  if constexpr (NBUF == 3) {
-    if (st0 + 1 < st1) issue(st0 + 1, 1);
-    if (st0 + 1 < st1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IT) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  } else {
-    __syncthreads();
-  }
-  int s = 0;  // ring slot of the stage being computed
-  for (int st = st0; st < st1; ++st) {
-    if constexpr (NBUF == 3) {
-      if (st + 2 < st1 && !(a.ablate & 1)) issue(st + 2, s >= 1 ? s - 1 : 2);  // slot (s+2)%3
-    } else {
-      if (st + 1 < st1 && !(a.ablate & 1)) issue(st + 1, s ^ 1);
-    }
-    const float *Al = lds + s * STAGE + lane_off;
-    const float *Bl = Al + OP_FLOATS;
-#pragma unroll
-    for (int kk = 0; kk < KCH; ++kk) {
-      f32x4 af[2], bf[2];
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) af[mi] = *reinterpret_cast<const f32x4 *>(Al + (kk * 128 + wm * 64 + mi * 32) * 8);
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) bf[ni] = *reinterpret_cast<const f32x4 *>(Bl + (kk * 128 + wn * 64 + ni * 32) * 8);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
-    }
-    if constexpr (NBUF == 3) {
-      // stage st+1 must have landed (all but the newest 2*IT DMAs of this wave), then every wave must agree
-      if (st + 2 < st1 && !(a.ablate & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IT) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      s = (s == 2) ? 0 : s + 1;
-    } else {
-      if (!(a.ablate & 2)) __syncthreads();
-      s ^= 1;
-    }
-  }
-
-  float *yb = a.y + (a.direct ? (size_t)0 : (size_t)split * (a.NP / 8) * a.Mp * 8);
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int nb8 = (n0 + wm * 64 + mi * 32) / 8 + g;
-      f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (a.direct) b4 = *reinterpret_cast<const f32x4 *>(a.bpk + nb8 * 8 + half * 4);
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int m = m0 + wn * 64 + ni * 32 + l31;
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float t = acc[mi][ni][g * 4 + e] + b4[e];
-          if (a.res && m < a.M) t += a.res[((size_t)nb8 * a.Mp + m) * 8 + half * 4 + e];
-          if (a.direct && a.relu) t = t < 0.0f ? 0.0f : t;
-          v[e] = t;
-        }
-        if (m < a.M) *reinterpret_cast<f32x4 *>(yb + ((size_t)nb8 * a.Mp + m) * 8 + half * 4) = v;
-      }
-    }
-}
-
-// Same GEMM, software-pipelined by hand (see the scheduling notes in conv3x3_wino_kernel): branch-free stage body,
+// C8 GEMM  y[NP/8][Mp][8] = x[K/8][Mp][8] . wpk[K/8][NP][8]: 128 x 128 tile per block, KCH 8-wide K chunks per LDS stage (4 -> 32 k, 32 KiB per
+// stage), two stages in LDS, operands by LDS-DMA.  Software-pipelined by hand (see the scheduling notes in conv3x3_wino_kernel): branch-free stage body,
 // operand fragments double-buffered in registers one K chunk ahead, each chunk's first MFMA issued BEFORE the next
 // chunk's fragment loads (so the lgkmcnt(0) the compiler forces after LDS-DMA only covers loads issued 15 MFMAs
 // earlier), the next stage's DMA spread behind MFMAs 1-4 of the first chunk, and the stage barrier placed before the
@@ -2085,9 +995,7 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ part, int S, int 
   }
 }
 
-static int g_gemm_regstage = 0;  // (retired; kept so the debug hook stays a no-op)
 static int g_gemm_kch = 0;       // test/bench hook: force 4 or 8 K chunks per stage
-static int g_gemm_nbuf = 4;      // 4 = hand-pipelined kernel (default, +5% on fc6/fc7); 2 / 3 = plain kernel with a 2- / 3-deep LDS ring
 static int g_gemm_split = 0;  // test/bench hook: force a split-K factor
 static float *g_splitk_ws = nullptr;
 static size_t g_splitk_ws_bytes = 0;
@@ -2126,9 +1034,6 @@ int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float
   a.res = d_res_c8;
   static bool attr = false;
   if (!attr) {
-    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_c8_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 4 * 128 * 8 * 4));
-    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_c8_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 8 * 128 * 8 * 4));
-    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_c8_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 4 * 128 * 8 * 4));
     MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_c8_pf_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 4 * 128 * 8 * 4));
     MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_c8_pf_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 8 * 128 * 8 * 4));
     attr = true;
@@ -2147,11 +1052,8 @@ int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float
     a.y = g_splitk_ws;
   }
   dim3 grid((unsigned)tiles, (unsigned)S);
-  if (g_gemm_nbuf == 4 && kch == 8) hipLaunchKernelGGL((gemm_c8_pf_kernel<8>), grid, dim3(256), (size_t)2 * 2 * 8 * 128 * 8 * 4, s, a);
-  else if (g_gemm_nbuf == 4) hipLaunchKernelGGL((gemm_c8_pf_kernel<4>), grid, dim3(256), (size_t)2 * 2 * 4 * 128 * 8 * 4, s, a);
-  else if (kch == 8) hipLaunchKernelGGL((gemm_c8_kernel<8, 2>), grid, dim3(256), (size_t)2 * 2 * 8 * 128 * 8 * 4, s, a);
-  else if (g_gemm_nbuf == 3) hipLaunchKernelGGL((gemm_c8_kernel<4, 3>), grid, dim3(256), (size_t)3 * 2 * 4 * 128 * 8 * 4, s, a);
-  else hipLaunchKernelGGL((gemm_c8_kernel<4, 2>), grid, dim3(256), (size_t)2 * 2 * 4 * 128 * 8 * 4, s, a);
+  if (kch == 8) hipLaunchKernelGGL((gemm_c8_pf_kernel<8>), grid, dim3(256), (size_t)2 * 2 * 8 * 128 * 8 * 4, s, a);
+  else hipLaunchKernelGGL((gemm_c8_pf_kernel<4>), grid, dim3(256), (size_t)2 * 2 * 4 * 128 * 8 * 4, s, a);
   MPN_CHECK_LAUNCH();
   if (!direct) {
     size_t total = (size_t)(a.NP / 8) * M;
@@ -2642,13 +1544,9 @@ using namespace mpn;
 // ---- test / bench hooks (not part of the reference surface) -------------------------------------
 extern "C" void mpn_debug_set_wino_trace(void *p) { g_wino_trace = static_cast<unsigned long long *>(p); }
 extern "C" void mpn_debug_set_conv_variant(int v) { g_conv_variant = v; }
-extern "C" void mpn_debug_set_gemm_regstage(int v) { g_gemm_regstage = v; }
 extern "C" void mpn_debug_set_conv_split(int v) { g_conv_split = v; }
-extern "C" void mpn_debug_set_conv_persist_blocks(int v) { g_persist_blocks = v; }
-extern "C" void mpn_debug_set_conv_mode(int v) { g_conv_mode = v; }  // 1 = persistent stream-K, 0 = block per tile
 extern "C" void mpn_debug_set_gemm_split(int v) { g_gemm_split = v; }
 extern "C" void mpn_debug_set_gemm_kch(int v) { g_gemm_kch = (v == 4 || v == 8) ? v : 0; }
-extern "C" void mpn_debug_set_gemm_nbuf(int v) { g_gemm_nbuf = (v == 2 || v == 3) ? v : 4; }  // 0 / 4 = default hand-pipelined kernel
 extern "C" void mpn_debug_set_gemm_ablate(int v) { g_gemm_ablate = v; }
 
 // Kernel-only timing of one conv layer / one linear layer in the pipeline's own layouts (tools/bench_layers.py).

@@ -22,14 +22,13 @@ def _conv(dev, x, w, b, relu=True):
 
 @pytest.mark.parametrize("ci,co,h,w", [(3, 64, 40, 70), (8, 64, 33, 31), (64, 64, 19, 45), (64, 128, 16, 96), (128, 256, 9, 33),
                                        (24, 40, 8, 8), (16, 200, 5, 37), (256, 512, 12, 20)])
-@pytest.mark.parametrize("variant,split,mode", [(0, 0, 1), (1, 0, 1), (2, 0, 1), (0, 0, 0), (1, 0, 0), (2, 0, 0), (3, 0, 0), (4, 0, 0), (5, 0, 0), (6, 0, 0), (5, 2, 0), (6, 3, 0),
-                                                (1, 2, 0), (2, 3, 0), (3, 2, 0), (4, 3, 0), (0, 4, 0), (7, 0, 0), (7, 0, 1), (7, 2, 0), (7, 3, 0), (8, 0, 0), (8, 2, 0), (8, 3, 0)])
-def test_conv3x3_vs_oracle(O, dev, ci, co, h, w, variant, split, mode):
-    """mode 0 = one block per tile (+ split-K; default), 1 = persistent stream-K kernel; variant 7 / 8 = Winograd F(2x2,3x3), 4-wave / 8-wave kernel"""
+@pytest.mark.parametrize("variant,split", [(0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (5, 0), (6, 0), (5, 2), (6, 3), (1, 2), (2, 3), (3, 2), (4, 3), (0, 4),
+                                           (7, 0), (7, 2), (7, 3)])
+def test_conv3x3_vs_oracle(O, dev, ci, co, h, w, variant, split):
+    """variant 0 = the default choice per layer, 1-6 = direct-convolution tilings, 7 = Winograd F(2x2,3x3); split = forced split-K factor (0 = cost model)"""
     import multipathnet_amd
     lib = multipathnet_amd.load()
     lib.mpn_debug_set_conv_split(split)
-    lib.mpn_debug_set_conv_mode(mode)
     rng = np.random.default_rng(ci * 1000 + co)
     x = rng.standard_normal((ci, h, w)).astype(np.float32)
     wt = (rng.standard_normal((co, ci, 3, 3)) * (2.0 / (ci * 9)) ** 0.5).astype(np.float32)
@@ -41,7 +40,6 @@ def test_conv3x3_vs_oracle(O, dev, ci, co, h, w, variant, split, mode):
     finally:
         lib.mpn_debug_set_conv_variant(0)
         lib.mpn_debug_set_conv_split(0)
-        lib.mpn_debug_set_conv_mode(0)
     ref = O.conv3x3(x, wt, b, relu=True)
     assert y.shape == ref.shape
     assert np.abs(y - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
@@ -81,19 +79,14 @@ def _linear(dev, x, w, b, relu=False):
 
 
 @pytest.mark.parametrize("M,K,N", [(1, 8, 1), (40, 512, 9), (130, 300, 70), (257, 4096, 105), (1000, 1024, 512), (64, 25088, 128)])
-@pytest.mark.parametrize("regstage", [0, 1])
-def test_linear_vs_oracle(O, dev, M, K, N, regstage):
+def test_linear_vs_oracle(O, dev, M, K, N):
     import multipathnet_amd
     lib = multipathnet_amd.load()
     rng = np.random.default_rng(M + K + N)
     x = rng.standard_normal((M, K)).astype(np.float32)
     w = (rng.standard_normal((N, K)) * (1.0 / K) ** 0.5).astype(np.float32)
     b = rng.standard_normal(N).astype(np.float32)
-    lib.mpn_debug_set_gemm_regstage(regstage)
-    try:
-        y = _linear(dev, x, w, b, relu=True).cpu().numpy()
-    finally:
-        lib.mpn_debug_set_gemm_regstage(0)
+    y = _linear(dev, x, w, b, relu=True).cpu().numpy()
     ref = O.linear(x, w, b, relu=True)
     assert np.abs(y - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
 
@@ -130,74 +123,43 @@ def test_split_batch_invariance_exact(O, dev):
     assert (full - parts).abs().max().item() == 0
 
 
-@pytest.mark.parametrize("nbuf", [3, 4])
 @pytest.mark.parametrize("M,K,N", [(130, 300, 70), (1000, 1024, 512), (64, 25088, 128), (257, 4096, 105), (5, 8, 3)])
-def test_linear_three_stage_ring(O, dev, M, K, N, nbuf):
-    """the depth-2-prefetch GEMM (nbuf 3: 3 LDS buffers, counted vmcnt + raw s_barrier) and the hand-pipelined GEMM
-    (nbuf 4: register-prefetched fragments, barrier before the last chunk) give bit-identical results to the plain
-    2-buffer kernel (same k order) — run several times to screen for DMA/read races"""
-    import multipathnet_amd
-    lib = multipathnet_amd.load()
+def test_linear_repeatable(O, dev, M, K, N):
+    """the hand-pipelined LDS-DMA GEMM gives bit-identical results run after run (screens for DMA / read races) and matches the oracle"""
     rng = np.random.default_rng(M * 7 + N)
     x = rng.standard_normal((M, K)).astype(np.float32)
     w = (rng.standard_normal((N, K)) * (1.0 / K) ** 0.5).astype(np.float32)
     b = rng.standard_normal(N).astype(np.float32)
-    try:
-        lib.mpn_debug_set_gemm_nbuf(2)
-        base = _linear(dev, x, w, b, relu=True).clone()
-        lib.mpn_debug_set_gemm_nbuf(nbuf)
-        for _ in range(5):
-            assert torch.equal(_linear(dev, x, w, b, relu=True), base)
-    finally:
-        lib.mpn_debug_set_gemm_nbuf(0)
+    base = _linear(dev, x, w, b, relu=True).clone()
+    for _ in range(5):
+        assert torch.equal(_linear(dev, x, w, b, relu=True), base)
     assert np.abs(base.cpu().numpy() - O.linear(x, w, b, relu=True)).max() < 1e-4 * max(1.0, float(base.abs().max()))
 
 
-def test_conv_streamk_cut_tiles_deterministic(O, dev):
-    """a layer whose tiles are cut by block boundaries (U not a multiple of the CU count): fixed-order slab sums give
-    bit-identical results run after run, and match the block-per-tile kernel within fp32 reassociation"""
-    import multipathnet_amd
-    lib = multipathnet_amd.load()
-    rng = np.random.default_rng(5)
-    x = rng.standard_normal((72, 75, 125)).astype(np.float32)
-    wt = (rng.standard_normal((200, 72, 3, 3)) * 0.05).astype(np.float32)
-    b = rng.standard_normal(200).astype(np.float32)
-    lib.mpn_debug_set_conv_mode(1)  # persistent stream-K
-    try:
-        a = _conv(dev, x, wt, b)
-        for _ in range(3):
-            assert np.array_equal(_conv(dev, x, wt, b), a)
-    finally:
-        lib.mpn_debug_set_conv_mode(0)
-    c = _conv(dev, x, wt, b)  # block per tile (+ split-K)
-    ref = O.conv3x3(x, wt, b, relu=True)
-    assert np.abs(a - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
-    assert np.abs(a - c).max() < 1e-4 * max(1.0, np.abs(ref).max())
-
-
+@pytest.mark.parametrize("variant", [1, 7])
 @pytest.mark.parametrize("ci,co,h,w", [(72, 200, 75, 125), (64, 64, 150, 200), (256, 96, 40, 333)])
-def test_conv_wino_streamk_deterministic(O, dev, ci, co, h, w):
-    """the persistent Winograd kernel on layers whose tiles are cut by block boundaries: bit-identical run after run
-    (fixed-order slab sums), equal to the block-per-tile Winograd kernel within fp32 reassociation, and within the
-    north_star tolerance of the oracle"""
+def test_conv_splitk_deterministic(O, dev, ci, co, h, w, variant):
+    """split-K over the input-channel chunks (fp32 slabs summed in a fixed order): bit-identical run after run, equal to the unsplit
+    kernel within fp32 reassociation, and within the north_star tolerance of the oracle; direct (1) and Winograd (7) kernels"""
     import multipathnet_amd
     lib = multipathnet_amd.load()
     rng = np.random.default_rng(ci + co)
     x = rng.standard_normal((ci, h, w)).astype(np.float32)
     wt = (rng.standard_normal((co, ci, 3, 3)) * (2.0 / (ci * 9)) ** 0.5).astype(np.float32)
     b = rng.standard_normal(co).astype(np.float32)
-    lib.mpn_debug_set_conv_variant(7)
-    lib.mpn_debug_set_conv_mode(1)
+    lib.mpn_debug_set_conv_variant(variant)
+    lib.mpn_debug_set_conv_split(3)
     try:
         a = _conv(dev, x, wt, b)
         for _ in range(3):
             assert np.array_equal(_conv(dev, x, wt, b), a)
-        lib.mpn_debug_set_conv_mode(0)
+        lib.mpn_debug_set_conv_split(1)
         c = _conv(dev, x, wt, b)
     finally:
-        lib.mpn_debug_set_conv_mode(0)
+        lib.mpn_debug_set_conv_split(0)
         lib.mpn_debug_set_conv_variant(0)
     ref = O.conv3x3(x, wt, b, relu=True)
-    tol = 1e-4 * max(1.0, np.abs(ref).max())
-    assert np.abs(a - ref).max() < tol
-    assert np.abs(a - c).max() < tol
+    assert np.abs(a - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    assert np.abs(a - c).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+

@@ -47,21 +47,19 @@ def small(O, dev):
     return dict(net=net, im=im, boxes=boxes, P=Pn, feat=feat, pooled=pooled, logits=logits, deltas=deltas)
 
 
-@pytest.mark.parametrize("fuse_pool,split,mode", [(1, 0, 1), (0, 0, 1), (1, 0, 0), (0, 0, 0), (1, 2, 0), (0, 3, 0)])
-def test_pipeline_stages_vs_oracle(O, dev, small, fuse_pool, split, mode):
+@pytest.mark.parametrize("fuse_pool,split", [(1, 0), (0, 0), (1, 2), (0, 3)])
+def test_pipeline_stages_vs_oracle(O, dev, small, fuse_pool, split):
     import multipathnet_amd
     lib = multipathnet_amd.load()
     s, net = SMALL, small["net"]
     lib.mpn_debug_set_fuse_pool(fuse_pool)
     lib.mpn_debug_set_conv_split(split)
-    lib.mpn_debug_set_conv_mode(mode)
     try:
         scores, bbox = net.detect(torch.from_numpy(small["im"]).to(dev), torch.from_numpy(small["boxes"]).to(dev))
         torch.cuda.synchronize()
     finally:
         lib.mpn_debug_set_fuse_pool(1)
         lib.mpn_debug_set_conv_split(0)
-        lib.mpn_debug_set_conv_mode(0)
     feat = small["feat"]
     conv5 = net.debug_tensor("conv5", feat.shape).cpu().numpy()
     assert np.abs(conv5 - feat).max() < 1e-4 * max(1.0, np.abs(feat).max())

@@ -4,7 +4,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import multipathnet_amd
 lib = multipathnet_amd.load()
 lib.mpn_debug_set_conv_variant(7)
-lib.mpn_debug_set_conv_mode(int(sys.argv[1]) if len(sys.argv) > 1 else 0)  # 1 = persistent, 0 = block per tile
 for (ci, co, h, w) in [(128, 128, 300, 500), (512, 512, 75, 125)]:
     for ab in [0, 1, 2, 4, 8, 7, 15, 31]:
         lib.mpn_debug_set_gemm_ablate(ab)

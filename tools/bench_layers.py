@@ -6,7 +6,6 @@ lib = multipathnet_amd.load()
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 split = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 lib.mpn_debug_set_conv_variant(variant); lib.mpn_debug_set_conv_split(split)
-lib.mpn_debug_set_conv_mode(int(sys.argv[3]) if len(sys.argv) > 3 else 0)
 cfg = [64, 64, "P", 128, 128, "P", 256, 256, 256, "P", 512, 512, 512, "P", 512, 512, 512]
 h, w, cin = 600, 1000, 3
 layers = []
@@ -23,9 +22,8 @@ for (ci, co, hh, ww, pool) in layers:
     tot_ms += ms.value; tot_fl += fl
     print("conv %3d->%3d %4dx%-4d pool=%d  %8.1f us  %6.1f TF/s (%4.1f%%) rc=%d" % (ci, co, hh, ww, pool, ms.value * 1e3, fl / ms.value / 1e9, fl / ms.value / 1e9 / 1.573, rc))
 print("trunk total %.3f ms  %.1f TF/s" % (tot_ms, tot_fl / tot_ms / 1e9))
-for (M, K, N, gs) in [(1000, 25088, 4096, 2), (1000, 25088, 4096, 3), (1000, 25088, 4096, 4), (1000, 4096, 4096, 2), (1000, 4096, 4096, 4), (1000, 4096, 105, 2), (1000, 4096, 105, 4)]:
+for (M, K, N) in [(1000, 25088, 4096), (1000, 4096, 4096), (1000, 4096, 105)]:
     ms = C.c_float()
-    lib.mpn_debug_set_gemm_nbuf(gs)
     rc = lib.mpn_debug_bench_linear(M, K, N, 10, C.byref(ms))
     fl = 2.0 * M * K * N
-    print("linear nbuf=%d M=%d K=%d N=%d  %8.1f us  %6.1f TF/s (%4.1f%%) rc=%d" % (gs, M, K, N, ms.value * 1e3, fl / ms.value / 1e9, fl / ms.value / 1e9 / 1.573, rc))
+    print("linear M=%d K=%d N=%d  %8.1f us  %6.1f TF/s (%4.1f%%) rc=%d" % (M, K, N, ms.value * 1e3, fl / ms.value / 1e9, fl / ms.value / 1e9 / 1.573, rc))
