@@ -1048,7 +1048,11 @@ struct RnBlock {
   bool has_sc = false;
   RnConv sc;
 };
-struct GTensor { int C = 0, H = 0, W = 0; float *buf = nullptr; };
+struct GTensor {
+  int C = 0, H = 0, W = 0;
+  float *buf = nullptr;
+  int alias_of = -1, alias_c_off = 0;  // >= 0: this tensor is channels [alias_c_off, alias_c_off + C) of tensor alias_of (fused sibling convolutions)
+};
 struct GOp { int kind = 0, src = 0, dst = 0, dst_c_off = 0, kh = 1, kw = 1, sh = 1, sw = 1, ph = 0, pw = 0, relu = 0; RnConv conv; };
 struct ResNetGraph {
   // op-list mode (graph_build): branching graphs; tensor 0 = image (trunk) / ROI-pooled map (head)
@@ -1374,18 +1378,67 @@ static int graph_dims(const std::vector<GOp> &ops, std::vector<GTensor> &ts, int
     GTensor &dst = ts[op.dst];
     if (dst.H == 0) { dst.H = oh; dst.W = ow; }
     else if (dst.H != oh || dst.W != ow) { set_error("graph: writers of tensor %d disagree on its size", op.dst); return MPN_EINVAL; }
+    for (auto &t : ts)
+      if (t.alias_of == op.dst) { t.H = oh; t.W = ow; }
   }
   return MPN_OK;
 }
 
-static int graph_parse(ResNetGraph *g, int n_ops, const mpn_graph_op *ops, int n_t, const int *tc, std::vector<GOp> &out, std::vector<GTensor> &ts) {
-  MPN_CHECK_ARG(n_ops > 0 && ops && n_t > 1 && tc);
+static int g_graph_fuse = 1;  // mpn_debug_set_graph_fuse: 0 = run the op list as given
+static int graph_parse(ResNetGraph *g, int n_ops, const mpn_graph_op *ops_in, int n_t, const int *tc, std::vector<GOp> &out, std::vector<GTensor> &ts) {
+  MPN_CHECK_ARG(n_ops > 0 && ops_in && n_t > 1 && tc);
   ts.resize(n_t);
   for (int i = 0; i < n_t; ++i) { ts[i].C = tc[i]; MPN_CHECK_ARG(tc[i] > 0); }
   const int align = g->bf16 ? 16 : 8;
+  for (int i = 0; i < n_t; ++i) { ts[i].alias_of = -1; ts[i].alias_c_off = 0; }
+  // Sibling fusion: pointwise (1x1 / stride 1) convolutions that read the SAME tensor and each own a whole private tensor
+  // (Inception's branch stems: Mixed_7a's two 768 -> 192, Mixed_7b/7c's 1280 -> 384 and -> 448) become ONE convolution whose
+  // output tensor holds their channels side by side; the original tensors become channel-plane views of it (a plane offset in
+  // this layout).  The big operand — the per-ROI activation batch, 0.3-0.9 GB — is then read once instead of once per branch,
+  // and 192 + 192 couts fill three 128-wide tiles instead of four.
+  std::vector<mpn_graph_op> fused(ops_in, ops_in + n_ops);
+  std::vector<char> dead((size_t)n_ops, 0);
+  auto pointwise_private = [&](const mpn_graph_op &o) {
+    return o.kind == 0 && o.kh == 1 && o.kw == 1 && o.sh == 1 && o.sw == 1 && o.ph == 0 && o.pw == 0 && o.dst_c_off == 0 && o.dst > 0 && o.dst < n_t &&
+           o.src >= 0 && o.src < n_t && o.cout == tc[o.dst] && o.cout % align == 0 && o.w;
+  };
+  for (int i = 0; g_graph_fuse && i < n_ops; ++i) {
+    if (dead[i] || !pointwise_private(fused[i])) continue;
+    std::vector<int> grp{i};
+    for (int j = i + 1; j < n_ops; ++j) {
+      if (ops_in[j].dst == fused[i].src) break;  // the shared input is rewritten: stop looking
+      if (!dead[j] && pointwise_private(ops_in[j]) && ops_in[j].src == fused[i].src && ops_in[j].relu == fused[i].relu && ops_in[j].cin == fused[i].cin &&
+          ops_in[j].dst != fused[i].dst)
+        grp.push_back(j);
+    }
+    if (grp.size() < 2) continue;
+    int ctot = 0;
+    for (int j : grp) ctot += ops_in[j].cout;
+    const int cin = fused[i].cin;
+    float *wsum = nullptr, *bsum = nullptr;
+    int rc = rn_alloc(g, &wsum, (size_t)ctot * cin * sizeof(float));
+    if (rc == MPN_OK) rc = rn_alloc(g, &bsum, (size_t)ctot * sizeof(float));
+    if (rc) return rc;
+    MPN_CHECK_HIP(hipMemset(bsum, 0, (size_t)ctot * sizeof(float)));
+    const int fid = (int)ts.size();
+    GTensor ft; ft.C = ctot;
+    int off = 0;
+    for (int j : grp) {
+      const mpn_graph_op &oj = ops_in[j];
+      MPN_CHECK_HIP(hipMemcpy(wsum + (size_t)off * cin, oj.w, (size_t)oj.cout * cin * sizeof(float), hipMemcpyDeviceToDevice));
+      if (oj.b) MPN_CHECK_HIP(hipMemcpy(bsum + off, oj.b, (size_t)oj.cout * sizeof(float), hipMemcpyDeviceToDevice));
+      ts[oj.dst].alias_of = fid; ts[oj.dst].alias_c_off = off;
+      if (j != i) dead[j] = 1;
+      off += oj.cout;
+    }
+    ts.push_back(ft);
+    fused[i].cout = ctot; fused[i].dst = fid; fused[i].w = wsum; fused[i].b = bsum;
+  }
+  const int n_t_all = (int)ts.size();
   for (int i = 0; i < n_ops; ++i) {
-    const mpn_graph_op &o = ops[i];
-    MPN_CHECK_ARG(o.kind >= 0 && o.kind <= 2 && o.src >= 0 && o.src < n_t && o.dst > 0 && o.dst < n_t && o.src != o.dst);
+    if (dead[i]) continue;
+    const mpn_graph_op &o = fused[i];
+    MPN_CHECK_ARG(o.kind >= 0 && o.kind <= 2 && o.src >= 0 && o.src < n_t && o.dst > 0 && o.dst < n_t_all && o.src != o.dst);
     MPN_CHECK_ARG(o.kh > 0 && o.kw > 0 && o.sh > 0 && o.sw > 0 && o.ph >= 0 && o.pw >= 0 && o.dst_c_off >= 0 && o.dst_c_off % align == 0);
     GOp op;
     op.kind = o.kind; op.src = o.src; op.dst = o.dst; op.dst_c_off = o.dst_c_off;
@@ -1428,14 +1481,14 @@ int graph_build(const mpn_graph_weights *gw, int max_h, int max_w, int max_rois,
   const size_t esz = g->bf16 ? sizeof(bf16_t) : sizeof(float);
   for (size_t i = 0; rc == MPN_OK && i < g->t_trunk.size(); ++i) {
     GTensor &t = g->t_trunk[i];
-    if (t.H == 0) continue;  // never written
+    if (t.H == 0 || t.alias_of >= 0) continue;  // never written / a view of a fused tensor
     const size_t bytes = c8i_elems(1, i == 0 ? 16 : t.C, t.H, t.W) * esz;
     rc = rn_alloc(g, &t.buf, bytes);
     if (rc == MPN_OK && hipMemset(t.buf, 0, bytes) != hipSuccess) rc = MPN_EHIP;
   }
   for (size_t i = 0; rc == MPN_OK && i < g->t_head.size(); ++i) {
     GTensor &t = g->t_head[i];
-    if (t.H == 0) continue;
+    if (t.H == 0 || t.alias_of >= 0) continue;
     const size_t bytes = c8i_elems(max_rois, t.C, t.H, t.W) * esz;
     rc = rn_alloc(g, &t.buf, bytes);
     if (rc == MPN_OK && hipMemset(t.buf, 0, bytes) != hipSuccess) rc = MPN_EHIP;
@@ -1454,7 +1507,12 @@ int graph_build(const mpn_graph_weights *gw, int max_h, int max_w, int max_rois,
 static int graph_run(ResNetGraph *g, const std::vector<GOp> &ops, std::vector<GTensor> &ts, int B, hipStream_t s) {
   const size_t esz = g->bf16 ? sizeof(bf16_t) : sizeof(float);
   for (const GOp &op : ops) {
-    const GTensor &src = ts[op.src];
+    GTensor src = ts[op.src];
+    if (src.alias_of >= 0) {  // channel-plane view of a fused tensor (same rows, so the same pitch)
+      const GTensor &par = ts[src.alias_of];
+      const ActI pa{par.buf, B, par.C, par.H, par.W};
+      src.buf = reinterpret_cast<float *>(reinterpret_cast<char *>(par.buf) + (size_t)(src.alias_c_off / 8) * pa.pitch() * 8 * esz);
+    }
     GTensor &dst = ts[op.dst];
     const ActI in{src.buf, B, src.C, src.H, src.W};
     const ActI od{dst.buf, B, dst.C, dst.H, dst.W};
@@ -1606,3 +1664,4 @@ extern "C" void mpn_debug_set_bf16_dma(int v) { mpn::g_bf16_dma = v; }
 extern "C" void mpn_debug_set_bf16_dma_tn(int v) { mpn::g_bf16_dma_tn = v; }
 extern "C" void mpn_debug_set_bf16_split_target(int v) { mpn::g_bf16_split_target = v; }
 extern "C" void mpn_debug_set_bf16_fast_pool(int v) { mpn::g_bf16_fast_pool = v; }
+extern "C" void mpn_debug_set_graph_fuse(int v) { mpn::g_graph_fuse = v; }

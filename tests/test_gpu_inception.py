@@ -78,3 +78,26 @@ def test_inception_bf16_lds_dma_kernel_forced(O, dev, tn):
     so, bo, _, _ = O.graph_detect(im, boxes, Gn, O.INCEPTION, target=min(H, W), max_size=max(H, W))
     assert np.abs(s - so).max() < 3e-3
     assert np.abs(b.cpu().numpy() - O.clamp_boxes(bo, W, H)).max() < 0.5
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_inception_sibling_fusion_equivalent(dev, bf16):
+    """graph_parse fuses pointwise convolutions that read the same tensor into one convolution whose output the branches view
+    by channel planes; the same network built with the fusion off (mpn_debug_set_graph_fuse(0)) gives the same scores"""
+    import multipathnet_amd
+    from multipathnet_amd import models
+    lib = multipathnet_amd.load()
+    H, W, N, C = 170, 215, 24, 5
+    G = models.synthetic_inception_v3_params(n_classes=C, width=0.25, seed=31)
+    im, boxes = _inputs(H, W, N, 21)
+    out = []
+    for fuse in (1, 0):
+        lib.mpn_debug_set_graph_fuse(fuse)
+        try:
+            net = models.InceptionFRCNN(G, max_h=H, max_w=W, max_rois=32, top_k=10, bf16=bf16)
+        finally:
+            lib.mpn_debug_set_graph_fuse(1)
+        s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+        out.append((s.cpu().numpy().copy(), b.cpu().numpy().copy()))
+    assert np.abs(out[0][0] - out[1][0]).max() < (1e-3 if bf16 else 1e-6)
+    assert np.abs(out[0][1] - out[1][1]).max() < (0.25 if bf16 else 1e-3)
