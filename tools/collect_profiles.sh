@@ -24,3 +24,5 @@ for cfg in "mpn:bench_mpn.py" "resnet50:bench_resnet.py" "resnet50_bf16:bench_re
   cp $(find /tmp/kt_$name -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${name}_kernel_stats.csv
 done
 ls -la $OUT
+# per-launch timeline of the bf16 ResNet-50 image (kernel, grid threads, us)
+bash $R/tools/prof_resnet.sh 50 1000 bf16 > $OUT/${TAG}_resnet50_bf16_layers.txt 2>&1
