@@ -55,6 +55,8 @@ struct GConvArgs {
   size_t pitch_in, pitch_out;  // rows per channel-block plane
   int CoutP, Cb_out, KH, KW, sh, sw, ph, pw, OH, OW, relu;
   long long P;  // B * OH * OW output pixels
+  float *part;           // split-K: fp32 partial slabs [split][CoutP/8][pitch_out][8] (conv_splitk_finalize_kernel finishes), else nullptr
+  int stages_per_split;
 };
 
 // KC = 8-channel chunks per LDS stage (all of the same filter tap): 16 * KC MFMAs per wave between two barriers.  KC = 4
@@ -121,13 +123,16 @@ __global__ __launch_bounds__(256) void conv2d_c8i_kernel(GConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
-  fetch(0);
+  // split-K: blockIdx.z owns a contiguous range of stages (small layers: too few 128 x 128 tiles to fill 256 CUs otherwise)
+  const int st0 = a.part ? (int)blockIdx.z * a.stages_per_split : 0;
+  const int st1 = a.part ? min(nstages, st0 + a.stages_per_split) : nstages;
+  fetch(st0);
   stash(0);
   __syncthreads();
   const int frag = l31 * 8 + half * 4;
-  for (int st = 0; st < nstages; ++st) {
-    const int buf = st & 1;
-    if (st + 1 < nstages) fetch(st + 1);  // global loads in flight under this stage's MFMAs
+  for (int st = st0; st < st1; ++st) {
+    const int buf = (st - st0) & 1;
+    if (st + 1 < st1) fetch(st + 1);  // global loads in flight under this stage's MFMAs
 #pragma unroll
     for (int q = 0; q < KC; ++q) {
       f32x4 af[2], bf[2];
@@ -143,10 +148,29 @@ __global__ __launch_bounds__(256) void conv2d_c8i_kernel(GConvArgs a) {
           for (int ni = 0; ni < 2; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
     }
-    if (st + 1 < nstages) stash(buf ^ 1);
+    if (st + 1 < st1) stash(buf ^ 1);
     __syncthreads();
   }
 
+  if (a.part) {  // raw partial sums
+    float *slab = a.part + (size_t)blockIdx.z * (a.CoutP / 8) * a.pitch_out * 8;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const long long pix = p0 + wn * 64 + ni * 32 + l31;
+      if (pix >= a.P) continue;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int cb = (cout0 + wm * 64 + mi * 32) / 8 + g;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][g * 4 + e];
+          *reinterpret_cast<f32x4 *>(slab + ((size_t)cb * a.pitch_out + (size_t)pix) * 8 + half * 4) = v;
+        }
+    }
+    return;
+  }
   // epilogue: + bias (+ residual) -> ReLU -> C8I float4 stores
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
@@ -171,6 +195,27 @@ __global__ __launch_bounds__(256) void conv2d_c8i_kernel(GConvArgs a) {
         *reinterpret_cast<f32x4 *>(a.out + off) = v;
       }
   }
+}
+
+// split-K finalize (fp32 graph): sum the slabs in a fixed order (deterministic), + bias (+ residual), ReLU
+__global__ void conv_splitk_finalize_kernel(const float *__restrict__ part, int splits, int CbP, int Cb_out, size_t pitch, long long P,
+                                            const float *__restrict__ bpk, const float *res, int relu, float *out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)Cb_out * (size_t)P * 2;
+  if (t >= total) return;
+  const int h = (int)(t & 1);
+  const size_t r = t >> 1;
+  const size_t pix = r % (size_t)P;
+  const int cb = (int)(r / (size_t)P);
+  const size_t off = ((size_t)cb * pitch + pix) * 8 + h * 4;
+  f32x4 v = *reinterpret_cast<const f32x4 *>(bpk + cb * 8 + h * 4);
+  for (int z = 0; z < splits; ++z) v += *reinterpret_cast<const f32x4 *>(part + (size_t)z * CbP * pitch * 8 + off);
+  if (res) v += *reinterpret_cast<const f32x4 *>(res + off);
+  if (relu) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.0f ? 0.0f : v[e];
+  }
+  *reinterpret_cast<f32x4 *>(out + off) = v;
 }
 
 // nn.SpatialMaxPooling(k,k,s,s,p,p), floor mode, on C8I
@@ -1113,6 +1158,11 @@ static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b
   const size_t total = (size_t)KK * nch * CoutP * 8;
   int rc = rn_alloc(g, &c.wpk, total * sizeof(float));
   if (rc) return rc;
+  if (!g->splitk_ws) {
+    rc = rn_alloc(g, &g->splitk_ws, SPLITK_WS_BYTES);
+    if (rc) return rc;
+  }
+  c.ws = g->splitk_ws; c.ws_bytes = SPLITK_WS_BYTES;
   rc = rn_alloc(g, &c.bpk, (size_t)CoutP * sizeof(float));
   if (rc) return rc;
   const size_t threads = total > (size_t)CoutP ? total : (size_t)CoutP;
@@ -1131,7 +1181,7 @@ static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b
 }
 
 static int g_bf16_fast_pool = 3;       // bit 0: sorted-int16 ROI pooling, bit 1: LDS average pooling (0 = the plain kernels; mpn_debug_set_bf16_fast_pool)
-static int g_bf16_split_target = 256;  // split-K aims at this many blocks (0 = never split; mpn_debug_set_bf16_split_target)
+static int g_bf16_split_target = 256;  // split-K (both dtypes) aims at this many blocks (0 = never split; mpn_debug_set_bf16_split_target)
 static int g_bf16_dma_tn = 0;  // 0 = pick per layer; 128 / 256 = force 256 couts x that many pixels, 1256 = 128 couts x 256 pixels (mpn_debug_set_bf16_dma_tn)
 static int g_bf16_dma = 1;  // mpn_debug_set_bf16_dma: 0 = never, 1 = large layers, 2 = every eligible layer (tests)
 static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int relu, hipStream_t s, ActI *o, bool allow_gemm = true) {
@@ -1229,6 +1279,28 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
   if (allow_gemm && c.lin_w && linear_c8_is_direct((int)in.rows(), c.Cout, (int)in.pitch()))  // same rows in and out: the tuned GEMM, residual + ReLU fused
     return linear_c8(in.p, (int)in.rows(), c.Cin, c.lin_w, c.lin_b, c.Cout, relu, out, nullptr, s, (int)in.pitch(), res);
   dim3 grid((unsigned)(((a.P + 127) / 128 + 7) / 8 * 8 * (a.CoutP / 128)));  // pixel tiles rounded up to the 8 XCDs x cout tiles (see the kernel)
+  {  // small layers: split K across blockIdx.z into fp32 slabs (as the bf16 graph does)
+    const int kc = a.nch % 4 == 0 ? 4 : 1;
+    const int nstages = a.KH * a.KW * (a.nch / kc);
+    const long long n_tiles = (a.P + 127) / 128 * (a.CoutP / 128);
+    const size_t slab = (size_t)a.CoutP * o->pitch() * sizeof(float);
+    int want = (int)std::min<long long>(nstages / 2, (g_bf16_split_target + n_tiles - 1) / n_tiles);
+    if (c.ws && slab) want = (int)std::min<size_t>((size_t)want, c.ws_bytes / slab); else want = 1;
+    if (g_bf16_split_target > 0 && n_tiles < 192 && want >= 2) {
+      a.stages_per_split = (nstages + want - 1) / want;
+      const int splits = (nstages + a.stages_per_split - 1) / a.stages_per_split;
+      a.part = c.ws;
+      grid.z = (unsigned)splits;
+      if (kc == 4) hipLaunchKernelGGL((conv2d_c8i_kernel<4>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((conv2d_c8i_kernel<1>), grid, dim3(256), 0, s, a);
+      MPN_CHECK_LAUNCH();
+      const size_t total = (size_t)a.Cb_out * (size_t)a.P * 2;
+      hipLaunchKernelGGL(conv_splitk_finalize_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, c.ws, splits, a.CoutP / 8, a.Cb_out, a.pitch_out, a.P,
+                         a.bpk, a.res, a.relu, a.out);
+      MPN_CHECK_LAUNCH();
+      return MPN_OK;
+    }
+  }
   if (a.nch % 4 == 0) hipLaunchKernelGGL((conv2d_c8i_kernel<4>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((conv2d_c8i_kernel<1>), grid, dim3(256), 0, s, a);
   MPN_CHECK_LAUNCH();
