@@ -778,6 +778,184 @@ __global__ __launch_bounds__(256, (MI == 4 && NI == 4) ? 1 : 2) void conv2d_c8i_
   }
 }
 
+// ---- fp32 generic convolution, LDS-DMA + hand-pipelined form (32-channel stages) ------------------------------------------
+// Same tile and arithmetic as conv2d_c8i_kernel<4> (128 couts x 128 pixels, 4 waves of 64 x 64, fp32 MFMA, stage = 32 input
+// channels of one tap, two stages in LDS), but built like dense.hip's gemm_c8_pf_kernel: both operands go global -> LDS through
+// global_load_lds (SADDR form; the weights are a linear copy — consecutive stages are consecutive memory in
+// [tap][chunk][CoutP][8] — and the im2col gather is `chunk plane + the lane's pixel offset`), no staging registers or ds_write;
+// fragments are double-buffered one 8-channel chunk ahead, each chunk's first MFMA is issued before the next chunk's fragment
+// reads, the next stage's 8 DMA items follow MFMAs 1..4 of the first chunk, and the stage barrier sits before the LAST chunk's
+// MFMAs.  Thread = (row tid >> 1, 16-byte half tid & 1) of the 128-row slices, i.e. DMA piece wave * 64 + lane of each chunk.  A
+// lane whose tap falls outside its map loads its map's first pixel and overwrites the four records with zeros once they landed.
+__global__ __launch_bounds__(256) void conv2d_c8i_pf_kernel(GConvArgs a) {
+  constexpr int KCH = 4, OP_FLOATS = KCH * 128 * 8, STAGE = 2 * OP_FLOATS;
+  extern __shared__ __attribute__((aligned(16))) float ldsf[];  // [2 stages][A | B][chunk][128 rows][8]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ny = a.CoutP / 128, nx = (int)((a.P + 127) / 128);
+  const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+  const int ty = kq % ny, tx = (kq / ny) * 8 + xcd;
+  if (tx >= nx) return;
+  const long long p0 = (long long)tx * 128;
+  const int cout0 = ty * 128;
+  const int OHW = a.OH * a.OW;
+  const int srow = tid >> 1, sh = tid & 1;
+  const long long gpix = p0 + srow;
+  const bool gvalid = gpix < a.P;
+  const int gb = gvalid ? (int)(gpix / OHW) : 0;
+  const int grem = gvalid ? (int)(gpix - (long long)gb * OHW) : 0;
+  const int goy = grem / a.OW, gox = grem - goy * a.OW;
+  const int iy0 = goy * a.sh - a.ph, ix0 = gox * a.sw - a.pw;
+  const unsigned map_off = (unsigned)gb * (unsigned)(a.H * a.W);  // records of 32 bytes
+
+  const int spt = a.nch / KCH;
+  const int nstages = a.KH * a.KW * spt;
+  const int st0 = a.part ? (int)blockIdx.z * a.stages_per_split : 0;
+  const int st1 = a.part ? min(nstages, st0 + a.stages_per_split) : nstages;
+  if (st0 >= st1) return;  // (never: every split owns at least one stage)
+
+  // issue cursor, positioned at stage st0
+  int i_tap = st0 / spt, i_cg = st0 - i_tap * spt;
+  int i_ky = i_tap / a.KW, i_kx = i_tap - i_ky * a.KW;
+  const size_t w_step = (size_t)a.CoutP * 32, b_step = a.pitch_in * 32;  // bytes per chunk
+  const char *i_wp = reinterpret_cast<const char *>(a.wpk + (size_t)cout0 * 8) + ((size_t)i_tap * a.nch + (size_t)i_cg * KCH) * w_step;
+  const char *const b_base = reinterpret_cast<const char *>(a.in);
+  const char *i_bp = b_base + (size_t)i_cg * KCH * b_step;
+  const unsigned a_lane = (unsigned)tid * 16u;
+  unsigned i_blane = 0;
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) const float *)ldsf) + (unsigned)wave * 1024u;
+  auto issue_begin = [&]() -> bool {
+    const int iy = iy0 + i_ky, ix = ix0 + i_kx;
+    const bool ok = gvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    i_blane = (ok ? (map_off + (unsigned)(iy * a.W + ix)) : map_off) * 32u + (unsigned)sh * 16u;
+    return ok;
+  };
+  auto issue_pair = [&](int s, int i) {  // chunk i of both operands into stage buffer s
+    glds16_s(i_wp, a_lane, lds0 + (unsigned)(s * STAGE + i * 1024) * 4u); i_wp += w_step;
+    glds16_s(i_bp, i_blane, lds0 + (unsigned)(s * STAGE + OP_FLOATS + i * 1024) * 4u); i_bp += b_step;
+  };
+  auto issue_end = [&]() {
+    if (++i_cg == spt) { i_cg = 0; i_bp = b_base; if (++i_kx == a.KW) { i_kx = 0; ++i_ky; } }
+  };
+  auto zero_oob = [&](int s, bool ok) {
+    if (!ok) {
+      float *B = ldsf + s * STAGE + OP_FLOATS + tid * 4;
+#pragma unroll
+      for (int i = 0; i < KCH; ++i) *reinterpret_cast<f32x4 *>(B + i * 1024) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+  const int lane_off = l31 * 8 + half * 4;
+  f32x4 af[2][2], bf[2][2];
+  auto load_frags = [&](int s, int kk, int slot) {
+    const float *Al = ldsf + s * STAGE + lane_off, *Bl = Al + OP_FLOATS;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) af[slot][mi] = *reinterpret_cast<const f32x4 *>(Al + (kk * 128 + wm * 64 + mi * 32) * 8);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) bf[slot][ni] = *reinterpret_cast<const f32x4 *>(Bl + (kk * 128 + wn * 64 + ni * 32) * 8);
+  };
+
+  const int n_more = st1 - 1 - st0;  // stages that prefetch a successor
+  const int b0 = n_more & 1;         // stage st lives in buffer (st - st0 + b0) & 1: the LAST stage is always in buffer 0
+  bool ok_next = issue_begin();
+#pragma unroll
+  for (int i = 0; i < KCH; ++i) issue_pair(b0, i);
+  issue_end();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  zero_oob(b0, ok_next);
+  __syncthreads();
+  load_frags(b0, 0, 0);
+
+  auto body = [&](auto more_tag, auto parity_tag) {  // buffer parity is a compile-time tag: LDS offsets become immediates
+    constexpr bool MORE = decltype(more_tag)::value;
+    constexpr int s = decltype(parity_tag)::value;
+#pragma unroll
+    for (int kk = 0; kk < KCH; ++kk) {
+      const int cur = kk & 1;
+      if (kk == KCH - 1 && MORE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next stage this wave issued has landed
+        zero_oob(s ^ 1, ok_next);
+        __syncthreads();                                   // (+ lgkmcnt(0): this wave's last reads of stage s are done)
+        load_frags(s ^ 1, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int j = t >> 2, mi = (t >> 1) & 1, ni = t & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][mi][j], bf[cur][ni][j], acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t == 0 && kk + 1 < KCH) load_frags(s, kk + 1, cur ^ 1);
+        if constexpr (MORE) {
+          if (kk == 0 && t == 0) ok_next = issue_begin();
+          if (kk == 0 && t >= 1 && t <= KCH) issue_pair(s ^ 1, t - 1);
+          if (kk == 0 && t == KCH) issue_end();
+        }
+      }
+    }
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  {
+    int st = st0;
+    if (n_more & 1) { body(std::true_type{}, P1{}); ++st; }
+    for (; st < st1 - 1; st += 2) { body(std::true_type{}, P0{}); body(std::true_type{}, P1{}); }
+    body(std::false_type{}, P0{});
+  }
+
+  if (a.part) {  // raw partial sums
+    float *slab = a.part + (size_t)blockIdx.z * (a.CoutP / 8) * a.pitch_out * 8;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const long long pix = p0 + wn * 64 + ni * 32 + l31;
+      if (pix >= a.P) continue;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int cb = (cout0 + wm * 64 + mi * 32) / 8 + g;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][g * 4 + e];
+          *reinterpret_cast<f32x4 *>(slab + ((size_t)cb * a.pitch_out + (size_t)pix) * 8 + half * 4) = v;
+        }
+    }
+    return;
+  }
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const long long pix = p0 + wn * 64 + ni * 32 + l31;
+    if (pix >= a.P) continue;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cb = (cout0 + wm * 64 + mi * 32) / 8 + g;
+        if (cb >= a.Cb_out) continue;
+        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bpk + cb * 8 + half * 4);
+        const size_t off = ((size_t)cb * a.pitch_out + (size_t)pix) * 8 + half * 4;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][g * 4 + e] + b4[e];
+        if (a.res) v += *reinterpret_cast<const f32x4 *>(a.res + off);
+        if (a.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.0f ? 0.0f : v[e];
+        }
+        *reinterpret_cast<f32x4 *>(a.out + off) = v;
+      }
+  }
+}
+
 // one thread = one 16-byte pixel record (8 channels)
 __global__ void maxpool2d_c8i_bf16_kernel(const bf16_t *__restrict__ in, int Cb, int B, int H, int W, size_t pitch_in, int k, int stride, int pad,
                                           int OH, int OW, size_t pitch_out, bf16_t *__restrict__ out) {
@@ -1181,6 +1359,7 @@ static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b
 }
 
 static int g_bf16_fast_pool = 3;       // bit 0: sorted-int16 ROI pooling, bit 1: LDS average pooling (0 = the plain kernels; mpn_debug_set_bf16_fast_pool)
+static int g_fp32_pf = 1;              // fp32 graph: conv2d_c8i_pf_kernel for 32-channel-stage layers (0 = conv2d_c8i_kernel<4>; mpn_debug_set_fp32_pf)
 static int g_bf16_split_target = 256;  // split-K (both dtypes) aims at this many blocks (0 = never split; mpn_debug_set_bf16_split_target)
 static int g_bf16_dma_tn = 0;  // 0 = pick per layer; 128 / 256 = force 256 couts x that many pixels, 1256 = 128 couts x 256 pixels (mpn_debug_set_bf16_dma_tn)
 static int g_bf16_dma = 1;  // mpn_debug_set_bf16_dma: 0 = never, 1 = large layers, 2 = every eligible layer (tests)
@@ -1279,6 +1458,16 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
   if (allow_gemm && c.lin_w && linear_c8_is_direct((int)in.rows(), c.Cout, (int)in.pitch()))  // same rows in and out: the tuned GEMM, residual + ReLU fused
     return linear_c8(in.p, (int)in.rows(), c.Cin, c.lin_w, c.lin_b, c.Cout, relu, out, nullptr, s, (int)in.pitch(), res);
   dim3 grid((unsigned)(((a.P + 127) / 128 + 7) / 8 * 8 * (a.CoutP / 128)));  // pixel tiles rounded up to the 8 XCDs x cout tiles (see the kernel)
+  // 32-channel stages: the LDS-DMA / hand-pipelined kernel (32-bit gather offsets: the input batch must stay under 4 GiB)
+  constexpr size_t PF_LDS = (size_t)2 * 2 * 4 * 128 * 8 * sizeof(float);
+  const bool pf_ok = g_fp32_pf && (size_t)in.B * in.H * in.W * 32 < ((size_t)1 << 32);
+  {
+    static bool attr = false;
+    if (!attr) {
+      MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_c8i_pf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PF_LDS));
+      attr = true;
+    }
+  }
   {  // small layers: split K across blockIdx.z into fp32 slabs (as the bf16 graph does)
     const int kc = a.nch % 4 == 0 ? 4 : 1;
     const int nstages = a.KH * a.KW * (a.nch / kc);
@@ -1291,7 +1480,8 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
       const int splits = (nstages + a.stages_per_split - 1) / a.stages_per_split;
       a.part = c.ws;
       grid.z = (unsigned)splits;
-      if (kc == 4) hipLaunchKernelGGL((conv2d_c8i_kernel<4>), grid, dim3(256), 0, s, a);
+      if (kc == 4 && pf_ok) hipLaunchKernelGGL(conv2d_c8i_pf_kernel, grid, dim3(256), PF_LDS, s, a);
+      else if (kc == 4) hipLaunchKernelGGL((conv2d_c8i_kernel<4>), grid, dim3(256), 0, s, a);
       else hipLaunchKernelGGL((conv2d_c8i_kernel<1>), grid, dim3(256), 0, s, a);
       MPN_CHECK_LAUNCH();
       const size_t total = (size_t)a.Cb_out * (size_t)a.P * 2;
@@ -1301,7 +1491,8 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
       return MPN_OK;
     }
   }
-  if (a.nch % 4 == 0) hipLaunchKernelGGL((conv2d_c8i_kernel<4>), grid, dim3(256), 0, s, a);
+  if (a.nch % 4 == 0 && pf_ok) hipLaunchKernelGGL(conv2d_c8i_pf_kernel, grid, dim3(256), PF_LDS, s, a);
+  else if (a.nch % 4 == 0) hipLaunchKernelGGL((conv2d_c8i_kernel<4>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((conv2d_c8i_kernel<1>), grid, dim3(256), 0, s, a);
   MPN_CHECK_LAUNCH();
   return MPN_OK;
@@ -1737,3 +1928,4 @@ extern "C" void mpn_debug_set_bf16_dma_tn(int v) { mpn::g_bf16_dma_tn = v; }
 extern "C" void mpn_debug_set_bf16_split_target(int v) { mpn::g_bf16_split_target = v; }
 extern "C" void mpn_debug_set_bf16_fast_pool(int v) { mpn::g_bf16_fast_pool = v; }
 extern "C" void mpn_debug_set_graph_fuse(int v) { mpn::g_graph_fuse = v; }
+extern "C" void mpn_debug_set_fp32_pf(int v) { mpn::g_fp32_pf = v; }

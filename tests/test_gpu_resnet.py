@@ -21,7 +21,18 @@ def _inputs(H, W, N, seed):
 
 @pytest.mark.parametrize("bt,blocks,width,pooled,N", [("bottleneck", [1, 1, 1, 1], 8, 14, 37), ("basic", [1, 2, 1, 2], 8, 14, 37), ("bottleneck", [2, 1, 2, 1], 16, 6, 37),
                                                    ("bottleneck", [1, 1, 1, 2], 16, 14, 150)])  # the last one is large enough for the 1x1 convolutions to take the GEMM path
-def test_resnet_frcnn_vs_oracle(O, dev, bt, blocks, width, pooled, N):
+@pytest.mark.parametrize("pf", [1, 0])  # 1 = LDS-DMA hand-pipelined convolution kernel for 32-channel-stage layers (default), 0 = the register-staged kernel
+def test_resnet_frcnn_vs_oracle(O, dev, bt, blocks, width, pooled, N, pf):
+    import multipathnet_amd
+    lib = multipathnet_amd.load()
+    lib.mpn_debug_set_fp32_pf(pf)
+    try:
+        _fp32_case(O, dev, bt, blocks, width, pooled, N)
+    finally:
+        lib.mpn_debug_set_fp32_pf(1)
+
+
+def _fp32_case(O, dev, bt, blocks, width, pooled, N):
     from multipathnet_amd import models
     H, W, C = 97, 131, 6
     R = models.synthetic_resnet_params(depth=0, n_classes=C, base_width=width, blocks=blocks, block_type=bt, seed=21)
