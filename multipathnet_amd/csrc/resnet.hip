@@ -287,6 +287,51 @@ __global__ void roi_pool_c8i_kernel(const float *__restrict__ feat, int Cb, int 
   *reinterpret_cast<f32x4 *>(out + ((size_t)cb * pitch_o + ((size_t)n * PH + ph) * PW + pw) * 8 + h * 4) = m;
 }
 
+// the same pooling with the bin arithmetic done once per (roi, bin): a thread owns one output row for CBG channel blocks, reads
+// whole 32-byte records and a wave stores 64 consecutive records (the kernel above spends most of its instructions on the
+// per-thread bin arithmetic for 16 output bytes).  Same cells, same comparisons: bit-identical.
+template <int CBG>
+__global__ __launch_bounds__(256) void roi_pool_c8i_rows_kernel(const float *__restrict__ feat, int H, int W, size_t pitch_f, const float *__restrict__ rois,
+                                                                 int roi_stride, int N, int PH, int PW, float scale, float *__restrict__ out, size_t pitch_o) {
+  const int PP = PH * PW;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)N * PP) return;
+  const int n = (int)(t / PP), bin = (int)(t - (size_t)n * PP);
+  const int ph = bin / PW, pw = bin - ph * PW;
+  const float *ro = rois + (size_t)roi_stride * n;
+  const int sw = (int)roundf((ro[1] - 1.0f) * scale), sh = (int)roundf((ro[2] - 1.0f) * scale);
+  const int ew = (int)roundf((ro[3] - 1.0f) * scale), eh = (int)roundf((ro[4] - 1.0f) * scale);
+  const int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
+  const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+  int hs = (int)floorf((float)ph * bh) + sh, he = (int)ceilf((float)(ph + 1) * bh) + sh;
+  int ws = (int)floorf((float)pw * bw) + sw, we = (int)ceilf((float)(pw + 1) * bw) + sw;
+  hs = min(max(hs, 0), H); he = min(max(he, 0), H);
+  ws = min(max(ws, 0), W); we = min(max(we, 0), W);
+  const bool empty = (he <= hs) || (we <= ws);
+  const int cb0 = blockIdx.y * CBG;
+  const float *fp = feat + (size_t)cb0 * pitch_f * 8;
+  float *op = out + ((size_t)cb0 * pitch_o + t) * 8;
+  const float lowest = empty ? 0.0f : -INFINITY;
+  f32x4 lo[CBG], hi[CBG];
+#pragma unroll
+  for (int c = 0; c < CBG; ++c) lo[c] = hi[c] = f32x4{lowest, lowest, lowest, lowest};
+  for (int y = hs; y < he; ++y)
+    for (int x = ws; x < we; ++x) {
+      const float *px = fp + ((size_t)y * W + x) * 8;
+#pragma unroll
+      for (int c = 0; c < CBG; ++c) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(px + (size_t)c * pitch_f * 8), b = *reinterpret_cast<const f32x4 *>(px + (size_t)c * pitch_f * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo[c][e] = a[e] > lo[c][e] ? a[e] : lo[c][e]; hi[c][e] = b[e] > hi[c][e] ? b[e] : hi[c][e]; }
+      }
+    }
+#pragma unroll
+  for (int c = 0; c < CBG; ++c) {
+    *reinterpret_cast<f32x4 *>(op + (size_t)c * pitch_o * 8) = lo[c];
+    *reinterpret_cast<f32x4 *>(op + (size_t)c * pitch_o * 8 + 4) = hi[c];
+  }
+}
+
 // 7x7 global average pool of [N][Cb][H][W][8] into the C8 matrix [Cb][Mp][8] the head GEMM reads (row = roi); the sum
 // runs in row-major order like the oracle's, then * 1/(H*W)
 __global__ void avgpool_c8i_to_c8_kernel(const float *__restrict__ in, int N, int Cb, int HW, size_t pitch, float inv, float *__restrict__ out,
@@ -1358,7 +1403,7 @@ static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b
   return MPN_OK;
 }
 
-static int g_bf16_fast_pool = 3;       // bit 0: sorted-int16 ROI pooling, bit 1: LDS average pooling (0 = the plain kernels; mpn_debug_set_bf16_fast_pool)
+static int g_bf16_fast_pool = 3;       // bit 0: row-per-thread ROI pooling (bf16: on the int16-sortable map), bit 1: LDS average pooling (bf16) (0 = the plain kernels; mpn_debug_set_bf16_fast_pool)
 static int g_fp32_pf = 1;              // fp32 graph: conv2d_c8i_pf_kernel for 32-channel-stage layers (0 = conv2d_c8i_kernel<4>; mpn_debug_set_fp32_pf)
 static int g_bf16_split_target = 256;  // split-K (both dtypes) aims at this many blocks (0 = never split; mpn_debug_set_bf16_split_target)
 static int g_bf16_dma_tn = 0;  // 0 = pick per layer; 128 / 256 = force 256 couts x that many pixels, 1256 = 128 couts x 256 pixels (mpn_debug_set_bf16_dma_tn)
@@ -1889,6 +1934,9 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
     } else if (g->bf16)
       hipLaunchKernelGGL(roi_pool_c8i_bf16_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, reinterpret_cast<const bf16_t *>(g->feat), Cb, g->feat_h,
                          g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale, reinterpret_cast<bf16_t *>(pool_dst), pa.pitch());
+    else if ((g_bf16_fast_pool & 1) && Cb % 4 == 0)
+      hipLaunchKernelGGL(roi_pool_c8i_rows_kernel<4>, dim3((unsigned)cdiv_sz((size_t)N * PH * PH, 256), (unsigned)(Cb / 4)), dim3(256), 0, s, g->feat, g->feat_h,
+                         g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale, pool_dst, pa.pitch());
     else
     hipLaunchKernelGGL(roi_pool_c8i_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, g->feat, Cb, g->feat_h, g->feat_w, fa.pitch(), d_rois, roi_stride,
                        N, PH, PH, spatial_scale, pool_dst, pa.pitch());

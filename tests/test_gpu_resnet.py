@@ -153,9 +153,10 @@ def _bf16_case(O, dev, bt, blocks, width):
     assert np.abs(s.sum(1) - 1).max() < 1e-5
 
 
-def test_resnet_bf16_fast_pooling_is_bit_identical(dev):
-    """the int16-sortable ROI max-pooling and the LDS average pooling of the bf16 graph reproduce the plain kernels' bits
-    (max commutes with the monotone re-coding; the average sums in the same order)"""
+@pytest.mark.parametrize("bf16", [True, False])
+def test_resnet_fast_pooling_is_bit_identical(dev, bf16):
+    """the row-per-thread ROI max-pooling (bf16: on the int16-sortable re-coding of the map) and the LDS average pooling of the
+    bf16 graph reproduce the plain kernels' bits (max commutes with the monotone re-coding; the average sums in the same order)"""
     import multipathnet_amd
     from multipathnet_amd import models
     lib = multipathnet_amd.load()
@@ -164,7 +165,7 @@ def test_resnet_bf16_fast_pooling_is_bit_identical(dev):
     im, boxes = _inputs(H, W, N, 9)
     boxes[0, :] = [120.0, 90.0, 121.0, 91.0]      # a tiny ROI: bins narrower than a feature cell
     boxes[1, :] = [-40.0, -30.0, 10.0, 12.0]      # partly outside the image: empty bins -> 0
-    net = models.ResNetFRCNN(R, max_h=H, max_w=W, max_rois=64, top_k=20, bf16=True)
+    net = models.ResNetFRCNN(R, max_h=H, max_w=W, max_rois=64, top_k=20, bf16=bf16)
     out = []
     for fast in (0, 1, 2, 3):  # bit 0: ROI pooling, bit 1: average pooling
         lib.mpn_debug_set_bf16_fast_pool(fast)
