@@ -6,6 +6,8 @@ import torch
 import bench
 from multipathnet_amd import models
 import multipathnet_amd
+if os.environ.get("MPN_BF16_DMA"):  # A/B: 0 = never use the LDS-DMA bf16 convolution, 1 = large layers (default), 2 = every eligible layer
+    multipathnet_amd.load().mpn_debug_set_bf16_dma(int(os.environ["MPN_BF16_DMA"]))
 if os.environ.get("MPN_DMA_TN"):  # A/B: pixel-tile width of the bf16 LDS-DMA convolution kernel (128 / 256; 0 = per layer)
     multipathnet_amd.load().mpn_debug_set_bf16_dma_tn(int(os.environ["MPN_DMA_TN"]))
 if os.environ.get("MPN_SPLIT_TARGET"):  # A/B: split-K block target of the bf16 128 x 128 convolution kernel (0 = never split)
