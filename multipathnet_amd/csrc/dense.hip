@@ -662,7 +662,7 @@ __global__ void conv_splitk_reduce_kernel(const float *__restrict__ part, size_t
   if (pooling) *reinterpret_cast<f32x4 *>(pool + (size_t)cb * pool_plane + ((size_t)(gy + 1) * pool_Wp + gx + 1) * 8 + h * 4) = m;
 }
 
-static int g_gemm_ablate = 0;         // timing-experiment switch shared by conv and gemm
+static int g_gemm_ablate = 0;         // timing-experiment switch of the convolution kernels (tools/ablate_conv.py, tools/ablate_wino.py)
 static unsigned long long *g_wino_trace = nullptr;  // tools/wino_trace.py
 static int g_conv_split = 0;          // 0 = auto, >0 = force this many splits (test/bench hook)
 static float *g_conv_ws = nullptr;    // library-owned split-K scratch (grown on demand, single stream)
@@ -817,7 +817,6 @@ struct GemmArgs {
   int M, nstages, stages_per_split, relu, n_mt, n_nt, direct;
   int n_fast;  // tile order: 0 = all row tiles of one column tile first (the weights are the big operand: fc6), 1 = all column tiles of one
                // row tile first (the activations are: ResNet's pointwise convolutions over 10^5 pixel rows) — the big operand is streamed once
-  int ablate;  // timing experiments only (results wrong): 1 = no DMA in loop, 2 = no barrier in loop, 4 = no ds_reads in loop
   const float *res;  // optional residual in y's layout, added before the ReLU (direct mode only; ResNet 1x1 convolutions)
 };
 
@@ -1011,7 +1010,7 @@ int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float
   MPN_CHECK_ARG(Mp_override == 0 || (Mp_override >= M && Mp_override % 128 == 0));
   GemmArgs a{};
   a.x = d_x_c8; a.Mp = Mp_override ? Mp_override : lin_mp(M); a.wpk = d_wpk; a.NP = lin_np(N); a.bpk = d_bpk;
-  a.M = M; a.relu = relu; a.ablate = g_gemm_ablate;
+  a.M = M; a.relu = relu;
   const int K64 = round_up(K, 64);
   a.n_mt = a.Mp / 128; a.n_nt = a.NP / 128;
   a.n_fast = a.n_mt > a.n_nt ? 1 : 0;
