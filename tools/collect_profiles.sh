@@ -26,3 +26,8 @@ done
 ls -la $OUT
 # per-launch timeline of the bf16 ResNet-50 image (kernel, grid threads, us)
 bash $R/tools/prof_resnet.sh 50 1000 bf16 > $OUT/${TAG}_resnet50_bf16_layers.txt 2>&1
+# SQ counters of the bf16 ResNet-50 run (matrix-pipe busy %, waits, LDS bank conflicts per kernel)
+rm -rf /tmp/pmc_rn
+timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT -d /tmp/pmc_rn -o p --output-format csv -- python $R/tools/bench_resnet.py 50 1000 bf16 > /tmp/pmc_rn.log 2>&1
+D=$(dirname $(find /tmp/pmc_rn -name "*counter_collection.csv" | head -1))
+python $R/tools/pmc_summary.py $D > $OUT/${TAG}_resnet50_bf16_pmc_sq.summary.txt 2>&1
