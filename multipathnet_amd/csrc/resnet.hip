@@ -390,6 +390,7 @@ struct GConvArgsB {
   long long P;
   float *part;           // split-K (128 x 128 kernel only): fp32 partial slabs [split][CoutP/8][pitch_out][8], else nullptr
   int stages_per_split;
+  unsigned long long *trace;  // tools/dma_trace.py: s_memtime stamps of wave 0 of block 0 (LDS-DMA kernel), else nullptr
 };
 
 // KP = chunk PAIRS (16 input channels) per LDS stage: 4 * KP MFMAs per wave between two barriers (instantiated: 1 and 2)
@@ -705,6 +706,9 @@ __global__ __launch_bounds__(256, (MI == 4 && NI == 4) ? 1 : 2) void conv2d_c8i_
   int s_cur = 0;                              // slot of stage st
   int s_iss = nstages > LOOK ? LOOK : 0;      // slot of stage st + LOOK
 
+  unsigned long long *const tr = (a.trace && blockIdx.x == 0 && tid == 0) ? a.trace + 8 : nullptr;  // [stage][q0 start, before wait, after wait, after barrier]
+  int tr_n = 0;
+  if (tr) a.trace[0] = __builtin_amdgcn_s_memtime();
   // One stage = 2 k-steps x MI NI MFMAs, hand-scheduled like gemm_c8_pf_kernel (dense.hip): VALU work from a wave does not overlap
   // its own MFMAs but LDS reads, SALU and DMA issue do, so the next k-step's fragment reads follow the FIRST MFMA of a k-step, the
   // DMA items of stage st+LOOK follow the next MFMAs of k-step 0, and the stage barrier (wait for this wave's stage-st+1 loads,
@@ -717,11 +721,15 @@ __global__ __launch_bounds__(256, (MI == 4 && NI == 4) ? 1 : 2) void conv2d_c8i_
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       if (q == 1 && NEXT) {
+        if (tr && tr_n < 96) tr[tr_n * 4 + 1] = __builtin_amdgcn_s_memtime();
         wait_landed(in_flight_tag);
+        if (tr && tr_n < 96) tr[tr_n * 4 + 2] = __builtin_amdgcn_s_memtime();
         zero_oob(s_nxt, okn[0]);
         __syncthreads();
+        if (tr && tr_n < 96) tr[tr_n * 4 + 3] = __builtin_amdgcn_s_memtime();
         load_frags(s_nxt, 0, 0);
       }
+      if (q == 0 && tr && tr_n < 96) tr[tr_n * 4] = __builtin_amdgcn_s_memtime();
 #pragma unroll
       for (int t = 0; t < MI * NI; ++t) {
         const int mi = t / NI, ni = t % NI;
@@ -738,6 +746,7 @@ __global__ __launch_bounds__(256, (MI == 4 && NI == 4) ? 1 : 2) void conv2d_c8i_
     }
     okn[0] = okn[1]; okn[1] = okn[2];
     s_cur = s_nxt; s_iss = next_slot(s_iss);
+    ++tr_n;
   };
   using T = std::true_type;
   using F = std::false_type;
@@ -757,6 +766,7 @@ __global__ __launch_bounds__(256, (MI == 4 && NI == 4) ? 1 : 2) void conv2d_c8i_
   // MFMA layout leaves a pixel's 8-channel record split across lanes l and l + 32 (4 channels = 8 bytes each); the store tail is
   // bound by store INSTRUCTIONS, not bytes, so pairs of channel blocks are exchanged with v_permlane32_swap (lanes 0-31 end up
   // with the whole record of block 2p, lanes 32-63 with block 2p + 1) and written / read as 16-byte accesses.
+  if (tr) a.trace[1] = __builtin_amdgcn_s_memtime();
   const int cb0 = (cout0 + wm * (MI * 32)) / 8;
   auto swap32 = [](unsigned &lo_keeps, unsigned &hi_keeps) {  // lanes 32-63 of the first <-> lanes 0-31 of the second
     const auto r = __builtin_amdgcn_permlane32_swap(lo_keeps, hi_keeps, false, false);
@@ -821,6 +831,7 @@ __global__ __launch_bounds__(256, (MI == 4 && NI == 4) ? 1 : 2) void conv2d_c8i_
       }
     }
   }
+  if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); a.trace[2] = __builtin_amdgcn_s_memtime(); a.trace[3] = (unsigned long long)nstages; }
 }
 
 // ---- fp32 generic convolution, LDS-DMA + hand-pipelined form (32-channel stages) ------------------------------------------
@@ -1403,6 +1414,8 @@ static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b
   return MPN_OK;
 }
 
+static unsigned long long *g_bf16_trace = nullptr;  // mpn_debug_set_bf16_trace (tools/dma_trace.py)
+static int g_bf16_trace_kh = 3;
 static int g_bf16_fast_pool = 3;       // bit 0: row-per-thread ROI pooling (bf16: on the int16-sortable map), bit 1: LDS average pooling (bf16) (0 = the plain kernels; mpn_debug_set_bf16_fast_pool)
 static int g_fp32_pf = 1;              // fp32 graph: conv2d_c8i_pf_kernel for 32-channel-stage layers (0 = conv2d_c8i_kernel<4>; mpn_debug_set_fp32_pf)
 static int g_bf16_split_target = 256;  // split-K (both dtypes) aims at this many blocks (0 = never split; mpn_debug_set_bf16_split_target)
@@ -1449,6 +1462,7 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
           attr = true;
         }
         const int nx = (int)((b.P + tn - 1) / tn), ny = b.CoutP / tm;
+        b.trace = (g_bf16_trace && b.KH == g_bf16_trace_kh) ? g_bf16_trace : nullptr;
         const dim3 gridd((unsigned)(((nx + 7) / 8) * 8 * ny));
         if (tm == 256 && tn == 128) hipLaunchKernelGGL((conv2d_c8i_bf16_dma_kernel<4, 2>), gridd, dim3(256), LDS, s, b, nx, ny);
         else if (tm == 128) hipLaunchKernelGGL((conv2d_c8i_bf16_dma_kernel<2, 4>), gridd, dim3(256), LDS, s, b, nx, ny);
@@ -1977,3 +1991,4 @@ extern "C" void mpn_debug_set_bf16_split_target(int v) { mpn::g_bf16_split_targe
 extern "C" void mpn_debug_set_bf16_fast_pool(int v) { mpn::g_bf16_fast_pool = v; }
 extern "C" void mpn_debug_set_graph_fuse(int v) { mpn::g_graph_fuse = v; }
 extern "C" void mpn_debug_set_fp32_pf(int v) { mpn::g_fp32_pf = v; }
+extern "C" void mpn_debug_set_bf16_trace(void *p, int kh) { mpn::g_bf16_trace = static_cast<unsigned long long *>(p); mpn::g_bf16_trace_kh = kh; }
