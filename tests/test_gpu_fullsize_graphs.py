@@ -59,3 +59,44 @@ def test_inception_v3_fullsize_scores_vs_oracle_on_roi_sample(O, dev, bf16):
     so, bo, _, _ = O.graph_detect(im, boxes[idx], Gn, O.INCEPTION, target=min(H, W), max_size=max(H, W))
     assert np.abs(s[idx] - so).max() < (3e-3 if bf16 else 1e-4)
     assert np.abs(b[idx] - O.clamp_boxes(bo.copy(), W, H)).max() < (0.5 if bf16 else 1e-2)
+
+
+def test_resnet50_multipathnet_fullsize_vs_oracle_on_roi_sample(O, dev):
+    """BASELINE configs[3] at full size (ResNet-50, 5 Foveal towers, K = 6, 81 classes, 1000 ROIs) in fp32: 6 sampled ROIs"""
+    import bench
+    from multipathnet_amd import models
+    H, W, N = bench.H, bench.W, bench.N_ROIS
+    R = models.synthetic_resnet_mpn_params(depth=50, n_classes=81, n_integral=6, seed=93)
+    Rn = models.resnet_params_numpy(R)
+    im, boxes = bench.synthetic_inputs()
+    net = models.ResNetFRCNN(R, max_h=H, max_w=W, max_rois=N)
+    s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+    s, b = s.cpu().numpy(), b.cpu().numpy()
+    idx = np.random.default_rng(13).choice(N, 6, replace=False)
+    so, bo = O.resnet_mpn_detect(im, boxes[idx], Rn, target=min(H, W), max_size=max(H, W))
+    assert np.abs(s[idx] - so).max() < 1e-4
+    assert np.abs(b[idx] - O.clamp_boxes(bo.copy(), W, H)).max() < 1e-2
+
+
+def test_inception_multipathnet_fullsize_vs_oracle_on_roi_sample(O, dev):
+    """BASELINE configs[4] at full size (Inception-v3, 5 Foveal towers, K = 6, 81 classes, 2000 ROIs, bf16): 4 sampled ROIs"""
+    import bench
+    from multipathnet_amd import models
+    H, W, N = bench.H, bench.W, 2000
+    G = models.synthetic_inception_mpn_params(n_classes=81, n_integral=6, seed=95)
+    Gn = dict(models.graph_params_numpy(G), bf16=True)
+    rng = np.random.default_rng(6)
+    im = rng.uniform(0, 1, (3, H, W)).astype(np.float32)
+    c = rng.uniform([1, 1], [W, H], (N, 2))
+    wh = np.exp(rng.uniform(np.log(16), np.log(min(H, W)), (N, 2)))
+    boxes = np.concatenate([c - wh / 2, c + wh / 2], 1)
+    boxes[:, [0, 2]] = np.clip(boxes[:, [0, 2]], 1, W)
+    boxes[:, [1, 3]] = np.clip(boxes[:, [1, 3]], 1, H)
+    boxes = boxes.astype(np.float32)
+    net = models.InceptionFRCNN(G, max_h=H, max_w=W, max_rois=N, bf16=True)
+    s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+    s, b = s.cpu().numpy(), b.cpu().numpy()
+    idx = rng.choice(N, 4, replace=False)
+    so, bo = O.graph_mpn_detect(im, boxes[idx], Gn, O.INCEPTION, target=min(H, W), max_size=max(H, W))
+    assert np.abs(s[idx] - so).max() < 3e-3
+    assert np.abs(b[idx] - O.clamp_boxes(bo.copy(), W, H)).max() < 0.5
