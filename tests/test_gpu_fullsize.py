@@ -75,3 +75,31 @@ def test_fullsize_properties(O, dev, full):
     allk = np.concatenate([keep[c, :int(nk[c]), 4] for c in range(C - 1)])
     thr = np.sort(allk)[::-1][min(100, allk.size) - 1]
     assert n == int((allk >= thr).sum()) and dets[:, 4].min() >= thr
+
+
+def test_multipathnet_fullsize_scores_vs_oracle_on_roi_sample(O, dev):
+    """BASELINE configs[2] at full size (VGG-16 MultiPathNet: 4 foveal towers + box tower with conv3/4/5 skip pooling, K = 6
+    integral classifiers, 81 classes, 1000 ROIs on the 600x1000 image — what tools/bench_mpn.py times): the oracle runs the
+    trunk with its conv3 / conv4 / conv5 taps and the head for 6 of the 1000 ROIs (rows are independent)."""
+    import bench
+    from multipathnet_amd import models
+    P = models.synthetic_mpnet_params(models.VGG16_CFG, pooled=7, fc_dim=4096, n_classes=81, n_integral=6, seed=557)
+    net = models.MultiPathNet(P, max_h=bench.H, max_w=bench.W, max_rois=bench.N_ROIS)
+    im, boxes = bench.synthetic_inputs()
+    scores, bbox = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+    scores, bbox = scores.cpu().numpy(), bbox.cpu().numpy()
+    assert np.abs(scores.sum(1) - 1).max() < 1e-5
+    def tree(v):
+        if isinstance(v, dict):
+            return {k: tree(x) for k, x in v.items()}
+        if isinstance(v, list):
+            return [tree(x) for x in v]
+        return v.numpy() if hasattr(v, "numpy") else v
+    Pn = tree(P)
+    taps = {}
+    O.vgg_trunk(O.image_transform(im, **O.ROSS), Pn["conv_w"], Pn["conv_b"], taps=taps)
+    idx = np.random.default_rng(17).choice(boxes.shape[0], 6, replace=False)
+    ref_scores, deltas = O.mpnet_head([taps["conv5"], taps["conv4"], taps["conv3"]], O.project_im_rois(boxes[idx], 1.0), Pn)
+    ref_bbox = O.clamp_boxes(O.bbox_decode(boxes[idx], deltas), im.shape[2], im.shape[1])
+    assert np.abs(scores[idx] - ref_scores).max() < 1e-4
+    assert np.abs(bbox[idx] - ref_bbox).max() < 1e-4 * im.shape[2]
