@@ -1906,8 +1906,8 @@ int resnet_trunk_forward(ResNetGraph *g, const float *d_image, int H, int W, con
       hipLaunchKernelGGL(maxpool2d_c8i_bf16_kernel, dim3((unsigned)cdiv_sz(total / 2, 256)), dim3(256), 0, s, reinterpret_cast<const bf16_t *>(y.p), y.Cb(), 1,
                          y.H, y.W, y.pitch(), 3, 2, 1, OH, OW, po.pitch(), reinterpret_cast<bf16_t *>(g->tb[1]));
     else
-    hipLaunchKernelGGL(maxpool2d_c8i_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, y.p, y.Cb(), 1, y.H, y.W, y.pitch(), 3, 2, 1, OH, OW,
-                       po.pitch(), g->tb[1]);
+      hipLaunchKernelGGL(maxpool2d_c8i_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, y.p, y.Cb(), 1, y.H, y.W, y.pitch(), 3, 2, 1, OH, OW,
+                         po.pitch(), g->tb[1]);
     MPN_CHECK_LAUNCH();
   }
   ActI cur{g->tb[1], 1, y.C, OH, OW};
@@ -1952,8 +1952,8 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
       hipLaunchKernelGGL(roi_pool_c8i_rows_kernel<4>, dim3((unsigned)cdiv_sz((size_t)N * PH * PH, 256), (unsigned)(Cb / 4)), dim3(256), 0, s, g->feat, g->feat_h,
                          g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale, pool_dst, pa.pitch());
     else
-    hipLaunchKernelGGL(roi_pool_c8i_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, g->feat, Cb, g->feat_h, g->feat_w, fa.pitch(), d_rois, roi_stride,
-                       N, PH, PH, spatial_scale, pool_dst, pa.pitch());
+      hipLaunchKernelGGL(roi_pool_c8i_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, g->feat, Cb, g->feat_h, g->feat_w, fa.pitch(), d_rois, roi_stride,
+                         N, PH, PH, spatial_scale, pool_dst, pa.pitch());
     MPN_CHECK_LAUNCH();
   }
   ActI cur{pool_dst, N, g->feat_c, PH, PH}, y;
@@ -1977,8 +1977,8 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
     hipLaunchKernelGGL(avgpool_c8i_bf16_to_c8_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, reinterpret_cast<const bf16_t *>(cur.p), N, cur.Cb(),
                        cur.H * cur.W, cur.pitch(), 1.0f / (float)(cur.H * cur.W), d_feat_c8, Mp);
   else
-  hipLaunchKernelGGL(avgpool_c8i_to_c8_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, cur.p, N, cur.Cb(), cur.H * cur.W, cur.pitch(),
-                     1.0f / (float)(cur.H * cur.W), d_feat_c8, Mp);
+    hipLaunchKernelGGL(avgpool_c8i_to_c8_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, cur.p, N, cur.Cb(), cur.H * cur.W, cur.pitch(),
+                       1.0f / (float)(cur.H * cur.W), d_feat_c8, Mp);
   MPN_CHECK_LAUNCH();
   return MPN_OK;
 }
