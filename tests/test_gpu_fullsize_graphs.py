@@ -9,21 +9,23 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("bf16", [False, True])
-def test_resnet50_fullsize_scores_vs_oracle_on_roi_sample(O, dev, bf16):
+@pytest.mark.parametrize("bf16,N", [(False, 1000), (True, 1000), (True, 173), (False, 173)])  # 173 ROIs: 33 908 pooled pixels, just past the large-layer threshold, ragged tiles
+def test_resnet50_fullsize_scores_vs_oracle_on_roi_sample(O, dev, bf16, N):
     import bench
     from multipathnet_amd import models
-    H, W, N = bench.H, bench.W, bench.N_ROIS
+    H, W = bench.H, bench.W
     R = models.synthetic_resnet_params(depth=50, n_classes=21, seed=91)
     Rn = models.resnet_params_numpy(R)
     if bf16:
         Rn = dict(Rn, bf16=True)
     im, boxes = bench.synthetic_inputs()
-    net = models.ResNetFRCNN(R, max_h=H, max_w=W, max_rois=N, bf16=bf16)
+    boxes = np.ascontiguousarray(boxes[:N])
+    net = models.ResNetFRCNN(R, max_h=H, max_w=W, max_rois=1000, bf16=bf16)
     s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
     s, b = s.cpu().numpy(), b.cpu().numpy()
     assert np.isfinite(s).all() and np.abs(s.sum(1) - 1).max() < 1e-5
     idx = np.random.default_rng(11).choice(N, 12, replace=False)
+    idx[0] = N - 1  # the last ROI: the ragged end of the last pixel tile
     so, bo, _, _ = O.resnet_detect(im, boxes[idx], Rn, target=min(H, W), max_size=max(H, W))  # scale 1, as the pipeline
     assert np.abs(s[idx] - so).max() < (3e-3 if bf16 else 1e-4)
     assert np.abs(b[idx] - O.clamp_boxes(bo.copy(), W, H)).max() < (0.5 if bf16 else 1e-2)
