@@ -1212,7 +1212,7 @@ __global__ void avgpool_c8i_bf16_to_c8_kernel(const bf16_t *__restrict__ in, int
 // in row-major order, divided by kh*kw regardless of how many cells lie in the padding.  T = float or bf16_t.
 template <typename T>
 __global__ void avgpool2d_c8i_kernel(const T *__restrict__ in, int Cb, int B, int H, int W, size_t pitch_in, int kh, int kw, int sh, int sw, int ph,
-                                     int pw, int OH, int OW, size_t pitch_out, T *__restrict__ out) {
+                                     int pw, int OH, int OW, size_t pitch_out, T *__restrict__ out, const float *__restrict__ bias, int relu) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)Cb * B * OH * OW * 2;
   if (t >= total) return;
@@ -1236,19 +1236,24 @@ __global__ void avgpool2d_c8i_kernel(const T *__restrict__ in, int Cb, int B, in
     }
   const float inv = 1.0f / (float)(kh * kw);
   const size_t oo = (cb * pitch_out + ((size_t)b * OH + oy) * OW + ox) * 8 + h * 4;
+  acc = acc * inv;
+  if (bias) {  // a commuted pool -> pointwise-convolution pair (graph_parse): the convolution's bias and ReLU follow the pool
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { acc[e] += bias[cb * 8 + h * 4 + e]; if (relu && acc[e] < 0.0f) acc[e] = 0.0f; }
+  }
   if constexpr (sizeof(T) == 2) {
     u16x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[e] * inv);
+    for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[e]);
     *reinterpret_cast<u16x4 *>(out + oo) = o;
   } else {
-    *reinterpret_cast<f32x4 *>(out + oo) = acc * inv;
+    *reinterpret_cast<f32x4 *>(out + oo) = acc;
   }
 }
 
 // bf16: one thread = one 16-byte pixel record; same summation order per channel as the template above
 __global__ void avgpool2d_c8i_bf16_kernel(const bf16_t *__restrict__ in, int Cb, int B, int H, int W, size_t pitch_in, int kh, int kw, int sh, int sw,
-                                          int ph, int pw, int OH, int OW, size_t pitch_out, bf16_t *__restrict__ out) {
+                                          int ph, int pw, int OH, int OW, size_t pitch_out, bf16_t *__restrict__ out, const float *__restrict__ bias, int relu) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)Cb * B * OH * OW;
   if (t >= total) return;
@@ -1269,9 +1274,14 @@ __global__ void avgpool2d_c8i_bf16_kernel(const bf16_t *__restrict__ in, int Cb,
       for (int e = 0; e < 4; ++e) { acc[2 * e] += __uint_as_float(v[e] << 16); acc[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u); }
     }
   const float inv = 1.0f / (float)(kh * kw);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    acc[e] *= inv;
+    if (bias) { acc[e] += bias[cb * 8 + e]; if (relu && acc[e] < 0.0f) acc[e] = 0.0f; }
+  }
   u32x4 o;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = (unsigned)f2bf(acc[2 * e] * inv) | ((unsigned)f2bf(acc[2 * e + 1] * inv) << 16);
+  for (int e = 0; e < 4; ++e) o[e] = (unsigned)f2bf(acc[2 * e]) | ((unsigned)f2bf(acc[2 * e + 1]) << 16);
   reinterpret_cast<u32x4 *>(out)[cb * pitch_out + ((size_t)b * OH + oy) * OW + ox] = o;
 }
 
@@ -1279,7 +1289,8 @@ __global__ void avgpool2d_c8i_bf16_kernel(const bf16_t *__restrict__ in, int Cb,
 // 256 / (H*W) consecutive maps of one channel block, reads their records once (consecutive 16-byte loads) and takes the window
 // cells from LDS — the plain kernel issues kh*kw global loads per output.  Same cells, same order: bit-identical to it.
 __global__ __launch_bounds__(256) void avgpool2d_c8i_bf16_small_kernel(const bf16_t *__restrict__ in, int B, int H, int W, size_t pitch_in, int kh, int kw,
-                                                                        int ph, int pw, size_t pitch_out, bf16_t *__restrict__ out) {
+                                                                        int ph, int pw, size_t pitch_out, bf16_t *__restrict__ out,
+                                                                        const float *__restrict__ bias, int relu) {
   __shared__ u32x4 tile[256];
   const int HW = H * W, mpb = 256 / HW;           // maps per block
   const int cb = blockIdx.y;
@@ -1304,9 +1315,14 @@ __global__ __launch_bounds__(256) void avgpool2d_c8i_bf16_small_kernel(const bf1
       for (int e = 0; e < 4; ++e) { acc[2 * e] += __uint_as_float(v[e] << 16); acc[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u); }
     }
   const float inv = 1.0f / (float)(kh * kw);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    acc[e] *= inv;
+    if (bias) { acc[e] += bias[cb * 8 + e]; if (relu && acc[e] < 0.0f) acc[e] = 0.0f; }
+  }
   u32x4 o;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = (unsigned)f2bf(acc[2 * e] * inv) | ((unsigned)f2bf(acc[2 * e + 1] * inv) << 16);
+  for (int e = 0; e < 4; ++e) o[e] = (unsigned)f2bf(acc[2 * e]) | ((unsigned)f2bf(acc[2 * e + 1]) << 16);
   reinterpret_cast<u32x4 *>(out)[(size_t)cb * pitch_out + (size_t)b0 * HW + t] = o;
 }
 
@@ -1332,7 +1348,11 @@ struct GTensor {
   float *buf = nullptr;
   int alias_of = -1, alias_c_off = 0;  // >= 0: this tensor is channels [alias_c_off, alias_c_off + C) of tensor alias_of (fused sibling convolutions)
 };
-struct GOp { int kind = 0, src = 0, dst = 0, dst_c_off = 0, kh = 1, kw = 1, sh = 1, sw = 1, ph = 0, pw = 0, relu = 0; RnConv conv; };
+struct GOp {
+  int kind = 0, src = 0, dst = 0, dst_c_off = 0, kh = 1, kw = 1, sh = 1, sw = 1, ph = 0, pw = 0, relu = 0;
+  RnConv conv;
+  float *pool_bias = nullptr;  // average pool only: bias (+ ReLU if relu) applied after the pool (commuted pool -> pointwise convolution)
+};
 struct ResNetGraph {
   // op-list mode (graph_build): branching graphs; tensor 0 = image (trunk) / ROI-pooled map (head)
   bool is_graph = false;
@@ -1706,7 +1726,7 @@ static int graph_dims(const std::vector<GOp> &ops, std::vector<GTensor> &ts, int
   return MPN_OK;
 }
 
-static int g_graph_fuse = 1;  // mpn_debug_set_graph_fuse: 0 = run the op list as given
+static int g_graph_fuse = 3;  // mpn_debug_set_graph_fuse: bit 0 = fuse sibling pointwise convolutions, bit 1 = commute average-pool -> pointwise convolution; 0 = run the op list as given
 static int graph_parse(ResNetGraph *g, int n_ops, const mpn_graph_op *ops_in, int n_t, const int *tc, std::vector<GOp> &out, std::vector<GTensor> &ts) {
   MPN_CHECK_ARG(n_ops > 0 && ops_in && n_t > 1 && tc);
   ts.resize(n_t);
@@ -1724,7 +1744,7 @@ static int graph_parse(ResNetGraph *g, int n_ops, const mpn_graph_op *ops_in, in
     return o.kind == 0 && o.kh == 1 && o.kw == 1 && o.sh == 1 && o.sw == 1 && o.ph == 0 && o.pw == 0 && o.dst_c_off == 0 && o.dst > 0 && o.dst < n_t &&
            o.src >= 0 && o.src < n_t && o.cout == tc[o.dst] && o.cout % align == 0 && o.w;
   };
-  for (int i = 0; g_graph_fuse && i < n_ops; ++i) {
+  for (int i = 0; (g_graph_fuse & 1) && i < n_ops; ++i) {
     if (dead[i] || !pointwise_private(fused[i])) continue;
     std::vector<int> grp{i};
     for (int j = i + 1; j < n_ops; ++j) {
@@ -1756,11 +1776,42 @@ static int graph_parse(ResNetGraph *g, int n_ops, const mpn_graph_op *ops_in, in
     ts.push_back(ft);
     fused[i].cout = ctot; fused[i].dst = fid; fused[i].w = wsum; fused[i].b = bsum;
   }
+  // Commute  average-pool(3x3 / 1, pad 1, count_include_pad) -> pointwise convolution  (Inception's pool branches: 1280 / 2048
+  // channels pooled, then reduced to 192): both are linear, so pool(conv(x)) == conv(pool(x)) exactly in real arithmetic, and the
+  // pool then runs on the convolution's few output channels instead of its many input channels; the convolution's bias and ReLU
+  // move behind the pool.  (Intermediate rounding differs: fp32 sums in another order, bf16 rounds conv(x) instead of pool(x).)
+  for (int i = 0; (g_graph_fuse & 2) && i < n_ops; ++i) {
+    const mpn_graph_op pi = fused[i];
+    if (dead[i] || pi.kind != 2 || pi.kh != 3 || pi.kw != 3 || pi.sh != 1 || pi.sw != 1 || pi.ph != 1 || pi.pw != 1 || pi.dst_c_off != 0) continue;
+    if (pi.dst <= 0 || pi.dst >= n_t || pi.src < 0 || pi.src >= n_t || tc[pi.dst] != tc[pi.src] || ts[pi.src].alias_of >= 0) continue;
+    int cons = -1, n_cons = 0, n_writers = 0;
+    for (int j = 0; j < n_ops; ++j) {
+      if (dead[j]) continue;
+      if (fused[j].src == pi.dst) { cons = j; ++n_cons; }
+      if (fused[j].dst == pi.dst) ++n_writers;
+    }
+    if (n_cons != 1 || n_writers != 1 || cons <= i) continue;
+    const mpn_graph_op cj = fused[cons];
+    if (cj.kind != 0 || cj.kh != 1 || cj.kw != 1 || cj.sh != 1 || cj.sw != 1 || cj.ph != 0 || cj.pw != 0 || !cj.w || cj.cout % align != 0) continue;
+    const int tid_new = (int)ts.size();
+    GTensor tt; tt.C = cj.cout;
+    ts.push_back(tt);
+    float *zb = nullptr;
+    int rc = rn_alloc(g, &zb, (size_t)cj.cout * sizeof(float));
+    if (rc) return rc;
+    MPN_CHECK_HIP(hipMemset(zb, 0, (size_t)cj.cout * sizeof(float)));
+    mpn_graph_op conv = cj;   // the convolution first: same weights, no bias, no ReLU, on the pool's input
+    conv.src = pi.src; conv.dst = tid_new; conv.dst_c_off = 0; conv.relu = 0; conv.b = zb;
+    mpn_graph_op pool = pi;   // then the pool, into the convolution's destination, + its bias and ReLU
+    pool.src = tid_new; pool.dst = cj.dst; pool.dst_c_off = cj.dst_c_off; pool.cin = cj.cout; pool.relu = cj.relu; pool.b = cj.b ? cj.b : zb;
+    fused[i] = conv;
+    fused[cons] = pool;
+  }
   const int n_t_all = (int)ts.size();
   for (int i = 0; i < n_ops; ++i) {
     if (dead[i]) continue;
     const mpn_graph_op &o = fused[i];
-    MPN_CHECK_ARG(o.kind >= 0 && o.kind <= 2 && o.src >= 0 && o.src < n_t && o.dst > 0 && o.dst < n_t_all && o.src != o.dst);
+    MPN_CHECK_ARG(o.kind >= 0 && o.kind <= 2 && o.src >= 0 && o.src < n_t_all && o.dst > 0 && o.dst < n_t_all && o.src != o.dst);
     MPN_CHECK_ARG(o.kh > 0 && o.kw > 0 && o.sh > 0 && o.sw > 0 && o.ph >= 0 && o.pw >= 0 && o.dst_c_off >= 0 && o.dst_c_off % align == 0);
     GOp op;
     op.kind = o.kind; op.src = o.src; op.dst = o.dst; op.dst_c_off = o.dst_c_off;
@@ -1769,6 +1820,13 @@ static int graph_parse(ResNetGraph *g, int n_ops, const mpn_graph_op *ops_in, in
     if (o.cin != ts[o.src].C || o.dst_c_off + wc > ts[o.dst].C || (o.dst_c_off + wc < ts[o.dst].C && wc % align != 0)) {
       set_error("graph: op %d: channel mismatch (src %d has %d, writes %d at %d of %d)", i, o.src, ts[o.src].C, wc, o.dst_c_off, ts[o.dst].C);
       return MPN_EINVAL;
+    }
+    if (o.kind == 2 && o.b) {  // commuted pool: a private copy of the convolution's bias, padded to whole channel blocks
+      const size_t nb = (size_t)round_up(ts[o.src].C, 8);
+      int rc = rn_alloc(g, &op.pool_bias, nb * sizeof(float));
+      if (rc) return rc;
+      MPN_CHECK_HIP(hipMemset(op.pool_bias, 0, nb * sizeof(float)));
+      MPN_CHECK_HIP(hipMemcpy(op.pool_bias, o.b, (size_t)ts[o.src].C * sizeof(float), hipMemcpyDeviceToDevice));
     }
     if (o.kind == 0) {
       MPN_CHECK_ARG(o.w && o.cout > 0);
@@ -1861,13 +1919,13 @@ static int graph_run(ResNetGraph *g, const std::vector<GOp> &ops, std::vector<GT
           const int mpb = 256 / (src.H * src.W);
           hipLaunchKernelGGL(avgpool2d_c8i_bf16_small_kernel, dim3((unsigned)((B + mpb - 1) / mpb), (unsigned)in.Cb()), dim3(256), 0, s,
                              reinterpret_cast<const bf16_t *>(src.buf), B, src.H, src.W, in.pitch(), op.kh, op.kw, op.ph, op.pw, od.pitch(),
-                             reinterpret_cast<bf16_t *>(outp));
+                             reinterpret_cast<bf16_t *>(outp), op.pool_bias, op.relu);
         } else if (g->bf16)
           hipLaunchKernelGGL(avgpool2d_c8i_bf16_kernel, grid16, dim3(256), 0, s, reinterpret_cast<const bf16_t *>(src.buf), in.Cb(), B, src.H, src.W,
-                             in.pitch(), op.kh, op.kw, op.sh, op.sw, op.ph, op.pw, dst.H, dst.W, od.pitch(), reinterpret_cast<bf16_t *>(outp));
+                             in.pitch(), op.kh, op.kw, op.sh, op.sw, op.ph, op.pw, dst.H, dst.W, od.pitch(), reinterpret_cast<bf16_t *>(outp), op.pool_bias, op.relu);
         else
           hipLaunchKernelGGL((avgpool2d_c8i_kernel<float>), grid, dim3(256), 0, s, src.buf, in.Cb(), B, src.H, src.W, in.pitch(), op.kh, op.kw, op.sh, op.sw,
-                             op.ph, op.pw, dst.H, dst.W, od.pitch(), reinterpret_cast<float *>(outp));
+                             op.ph, op.pw, dst.H, dst.W, od.pitch(), reinterpret_cast<float *>(outp), op.pool_bias, op.relu);
       }
       MPN_CHECK_LAUNCH();
     }
