@@ -1438,6 +1438,7 @@ static unsigned long long *g_bf16_trace = nullptr;  // mpn_debug_set_bf16_trace 
 static int g_bf16_trace_kh = 3;
 static int g_bf16_fast_pool = 3;       // bit 0: row-per-thread ROI pooling (bf16: on the int16-sortable map), bit 1: LDS average pooling (bf16) (0 = the plain kernels; mpn_debug_set_bf16_fast_pool)
 static int g_fp32_pf = 1;              // fp32 graph: conv2d_c8i_pf_kernel for 32-channel-stage layers (0 = conv2d_c8i_kernel<4>; mpn_debug_set_fp32_pf)
+static int g_split_max_tiles = 192;     // split-K only layers with fewer 128 x 128 tiles than this (mpn_debug_set_split_max_tiles)
 static int g_bf16_split_target = 256;  // split-K (both dtypes) aims at this many blocks (0 = never split; mpn_debug_set_bf16_split_target)
 static int g_bf16_dma_tn = 0;  // 0 = pick per layer; 128 / 256 = force 256 couts x that many pixels, 1256 = 128 couts x 256 pixels (mpn_debug_set_bf16_dma_tn)
 static int g_bf16_dma = 1;  // mpn_debug_set_bf16_dma: 0 = never, 1 = large layers, 2 = every eligible layer (tests)
@@ -1501,7 +1502,7 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
       const size_t slab = (size_t)b.CoutP * o->pitch() * sizeof(float);
       int want = (int)std::min<long long>(nstages / 2, (g_bf16_split_target + nblocks - 1) / nblocks);
       if (c.ws && slab) want = (int)std::min<size_t>((size_t)want, c.ws_bytes / slab); else want = 1;
-      if (g_bf16_split_target > 0 && nblocks < 192 && want >= 2) {
+      if (g_bf16_split_target > 0 && nblocks < g_split_max_tiles && want >= 2) {
         b.stages_per_split = (nstages + want - 1) / want;
         const int splits = (nstages + b.stages_per_split - 1) / b.stages_per_split;
         b.part = c.ws;
@@ -1554,7 +1555,7 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
     const size_t slab = (size_t)a.CoutP * o->pitch() * sizeof(float);
     int want = (int)std::min<long long>(nstages / 2, (g_bf16_split_target + n_tiles - 1) / n_tiles);
     if (c.ws && slab) want = (int)std::min<size_t>((size_t)want, c.ws_bytes / slab); else want = 1;
-    if (g_bf16_split_target > 0 && n_tiles < 192 && want >= 2) {
+    if (g_bf16_split_target > 0 && n_tiles < g_split_max_tiles && want >= 2) {
       a.stages_per_split = (nstages + want - 1) / want;
       const int splits = (nstages + a.stages_per_split - 1) / a.stages_per_split;
       a.part = c.ws;
@@ -2050,3 +2051,4 @@ extern "C" void mpn_debug_set_bf16_fast_pool(int v) { mpn::g_bf16_fast_pool = v;
 extern "C" void mpn_debug_set_graph_fuse(int v) { mpn::g_graph_fuse = v; }
 extern "C" void mpn_debug_set_fp32_pf(int v) { mpn::g_fp32_pf = v; }
 extern "C" void mpn_debug_set_bf16_trace(void *p, int kh) { mpn::g_bf16_trace = static_cast<unsigned long long *>(p); mpn::g_bf16_trace_kh = kh; }
+extern "C" void mpn_debug_set_split_max_tiles(int v) { mpn::g_split_max_tiles = v; }

@@ -5,6 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
 from multipathnet_amd import models
+import multipathnet_amd
+if os.environ.get("MPN_SPLIT_MAX_TILES"):  # A/B: split-K only layers with fewer 128 x 128 tiles than this
+    multipathnet_amd.load().mpn_debug_set_split_max_tiles(int(os.environ["MPN_SPLIT_MAX_TILES"]))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 bf16 = "fp32" not in sys.argv[2:]
 mpn = "mpn" in sys.argv[2:]  # BASELINE configs[4]: MultiPathNet towers (4 Foveal scales + box tower) on this backbone
