@@ -1,6 +1,6 @@
 """s_memtime trace of the 4-wave Winograd kernel's chunk loop (wave 0 of blocks 0..3): cycles from chunk start to the
 pre-barrier point (MFMA pairs 0-6 + everything interleaved), the lgkmcnt(0) wait, and the vmcnt(0)+s_barrier wait.
-s_memtime ticks at 100 MHz on gfx9 (10 ns) — coarse, so look at sums over the chunks."""
+s_memtime counts shader cycles on gfx950."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,7 +25,7 @@ for (ci, co, h, w) in [(128, 128, 300, 500), (512, 512, 75, 125)]:
             rows = [r for r in t[b].tolist() if r[0] != 0]
             if not rows: continue
             t0 = rows[0][0]
-            print(" block %d: chunks traced %d; per chunk [start-offset, pairs0-6, lgkm wait, vm+barrier wait] (memtime ticks):" % (b, len(rows)))
+            print(" block %d: chunks traced %d; per chunk [start-offset, pairs0-6, lgkm wait, vm+barrier wait] (cycles):" % (b, len(rows)))
             print("   " + " ".join("[%d %d %d %d]" % (r[0] - t0, r[1], r[2], r[3]) for r in rows[:8]))
             pr = pairs[b].tolist()
             print("   block phases [prologue, K loop, epilogue issue]: %s" % phases[b].tolist()[:3])
