@@ -9,6 +9,7 @@
 // as in dense.hip's kernels.  16 KiB of LDS per block lets several blocks share a CU, which hides the gather latency.
 #include <algorithm>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../include/mpn.h"
@@ -57,6 +58,7 @@ struct GConvArgs {
   long long P;  // B * OH * OW output pixels
   float *part;           // split-K: fp32 partial slabs [split][CoutP/8][pitch_out][8] (conv_splitk_finalize_kernel finishes), else nullptr
   int stages_per_split;
+  int norelu_cb0, norelu_cb1;  // channel blocks [cb0, cb1) skip the ReLU (fused sibling convolutions with mixed activations); empty by default
 };
 
 // KC = 8-channel chunks per LDS stage (all of the same filter tap): 16 * KC MFMAs per wave between two barriers.  KC = 4
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256) void conv2d_c8i_kernel(GConvArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][g * 4 + e] + b4[e];
         if (a.res) v += *reinterpret_cast<const f32x4 *>(a.res + off);
-        if (a.relu) {
+        if (a.relu && !(cb >= a.norelu_cb0 && cb < a.norelu_cb1)) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.0f ? 0.0f : v[e];
         }
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256) void conv2d_c8i_kernel(GConvArgs a) {
 
 // split-K finalize (fp32 graph): sum the slabs in a fixed order (deterministic), + bias (+ residual), ReLU
 __global__ void conv_splitk_finalize_kernel(const float *__restrict__ part, int splits, int CbP, int Cb_out, size_t pitch, long long P,
-                                            const float *__restrict__ bpk, const float *res, int relu, float *out) {
+                                            const float *__restrict__ bpk, const float *res, int relu, float *out, int norelu_cb0, int norelu_cb1) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)Cb_out * (size_t)P * 2;
   if (t >= total) return;
@@ -211,7 +213,7 @@ __global__ void conv_splitk_finalize_kernel(const float *__restrict__ part, int 
   f32x4 v = *reinterpret_cast<const f32x4 *>(bpk + cb * 8 + h * 4);
   for (int z = 0; z < splits; ++z) v += *reinterpret_cast<const f32x4 *>(part + (size_t)z * CbP * pitch * 8 + off);
   if (res) v += *reinterpret_cast<const f32x4 *>(res + off);
-  if (relu) {
+  if (relu && !(cb >= norelu_cb0 && cb < norelu_cb1)) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.0f ? 0.0f : v[e];
   }
@@ -391,6 +393,7 @@ struct GConvArgsB {
   float *part;           // split-K (128 x 128 kernel only): fp32 partial slabs [split][CoutP/8][pitch_out][8], else nullptr
   int stages_per_split;
   unsigned long long *trace;  // tools/dma_trace.py: s_memtime stamps of wave 0 of block 0 (LDS-DMA kernel), else nullptr
+  int norelu_cb0, norelu_cb1;  // channel blocks [cb0, cb1) skip the ReLU (fused sibling convolutions with mixed activations); empty by default
 };
 
 // KP = chunk PAIRS (16 input channels) per LDS stage: 4 * KP MFMAs per wave between two barriers (instantiated: 1 and 2)
@@ -521,8 +524,9 @@ __global__ __launch_bounds__(256) void conv2d_c8i_bf16_kernel(GConvArgsB a) {
           for (int e = 0; e < 4; ++e) v[e] += bf2f(r4[e]);
         }
         u16x4 o;
+        const bool rl = a.relu && !(cb >= a.norelu_cb0 && cb < a.norelu_cb1);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = f2bf((a.relu && v[e] < 0.0f) ? 0.0f : v[e]);
+        for (int e = 0; e < 4; ++e) o[e] = f2bf((rl && v[e] < 0.0f) ? 0.0f : v[e]);
         *reinterpret_cast<u16x4 *>(a.out + off) = o;
       }
   }
@@ -530,7 +534,7 @@ __global__ __launch_bounds__(256) void conv2d_c8i_bf16_kernel(GConvArgsB a) {
 
 // split-K finalize: sum the slabs in a fixed order (deterministic), + bias (+ residual), ReLU, round to bf16
 __global__ void conv_splitk_finalize_bf16_kernel(const float *__restrict__ part, int splits, int CbP, int Cb_out, size_t pitch, long long P,
-                                                 const float *__restrict__ bpk, const bf16_t *res, int relu, bf16_t *out) {
+                                                 const float *__restrict__ bpk, const bf16_t *res, int relu, bf16_t *out, int norelu_cb0, int norelu_cb1) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)Cb_out * (size_t)P * 2;
   if (t >= total) return;
@@ -551,8 +555,9 @@ __global__ void conv_splitk_finalize_bf16_kernel(const float *__restrict__ part,
     for (int e = 0; e < 4; ++e) v[e] += bf2f(r4[e]);
   }
   u16x4 o;
+  const bool rl = relu && !(cb >= norelu_cb0 && cb < norelu_cb1);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = f2bf((relu && v[e] < 0.0f) ? 0.0f : v[e]);
+  for (int e = 0; e < 4; ++e) o[e] = f2bf((rl && v[e] < 0.0f) ? 0.0f : v[e]);
   *reinterpret_cast<u16x4 *>(out + off) = o;
 }
 
@@ -818,9 +823,11 @@ __global__ __launch_bounds__(256, (MI == 4 && NI == 4) ? 1 : 2) void conv2d_c8i_
           vb[0] += bf2f((bf16_t)(r2 & 0xffffu)); vb[1] += bf2f((bf16_t)(r2 >> 16));
           vb[2] += bf2f((bf16_t)(r3 & 0xffffu)); vb[3] += bf2f((bf16_t)(r3 >> 16));
         }
-        if (a.relu) {
+        {
+          const int cba = cb0 + mi * 4 + gp * 2;  // va: block cba, vb: block cba + 1
+          const bool rla = a.relu && !(cba >= a.norelu_cb0 && cba < a.norelu_cb1), rlb = a.relu && !(cba + 1 >= a.norelu_cb0 && cba + 1 < a.norelu_cb1);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { va[e] = va[e] < 0.0f ? 0.0f : va[e]; vb[e] = vb[e] < 0.0f ? 0.0f : vb[e]; }
+          for (int e = 0; e < 4; ++e) { va[e] = (rla && va[e] < 0.0f) ? 0.0f : va[e]; vb[e] = (rlb && vb[e] < 0.0f) ? 0.0f : vb[e]; }
         }
         unsigned ax = (unsigned)f2bf(va[0]) | ((unsigned)f2bf(va[1]) << 16), ay = (unsigned)f2bf(va[2]) | ((unsigned)f2bf(va[3]) << 16);
         unsigned bx = (unsigned)f2bf(vb[0]) | ((unsigned)f2bf(vb[1]) << 16), by = (unsigned)f2bf(vb[2]) | ((unsigned)f2bf(vb[3]) << 16);
@@ -1003,7 +1010,7 @@ __global__ __launch_bounds__(256) void conv2d_c8i_pf_kernel(GConvArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][g * 4 + e] + b4[e];
         if (a.res) v += *reinterpret_cast<const f32x4 *>(a.res + off);
-        if (a.relu) {
+        if (a.relu && !(cb >= a.norelu_cb0 && cb < a.norelu_cb1)) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.0f ? 0.0f : v[e];
         }
@@ -1335,7 +1342,8 @@ struct RnConv {
   float *wpk = nullptr, *bpk = nullptr;
   float *lin_w = nullptr, *lin_b = nullptr;  // 1x1 / stride 1 with Cin % 64 == 0: also packed for the tuned GEMM (linear_c8)
   bf16_t *wpk16 = nullptr;                   // bf16 graph: [tap][nch2][CoutP][8]
-  float *ws = nullptr;                       // the graph's split-K workspace (bf16 graph)
+  int norelu_c0 = 0, norelu_c1 = 0;          // output channels [c0, c1) skip the ReLU (fused siblings with mixed activations; multiples of 8)
+  float *ws = nullptr;                       // the graph's split-K workspace
   size_t ws_bytes = 0;
 };
 struct RnBlock {
@@ -1451,7 +1459,7 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
     b.CoutP = round_up(c.Cout, 128); b.Cb_out = (c.Cout + 7) / 8;
     b.KH = c.KH; b.KW = c.KW; b.sh = c.sh; b.sw = c.sw; b.ph = c.ph; b.pw = c.pw;
     b.OH = (in.H + 2 * c.ph - c.KH) / c.sh + 1; b.OW = (in.W + 2 * c.pw - c.KW) / c.sw + 1;
-    b.relu = relu;
+    b.relu = relu; b.norelu_cb0 = c.norelu_c0 / 8; b.norelu_cb1 = c.norelu_c1 / 8;
     MPN_CHECK_ARG(in.C == c.Cin && b.OH > 0 && b.OW > 0);
     b.P = (long long)in.B * b.OH * b.OW;
     *o = ActI{out, in.B, c.Cout, b.OH, b.OW};
@@ -1512,7 +1520,7 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
         MPN_CHECK_LAUNCH();
         const size_t total = (size_t)b.Cb_out * (size_t)b.P * 2;
         hipLaunchKernelGGL(conv_splitk_finalize_bf16_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, c.ws, splits, b.CoutP / 8, b.Cb_out, b.pitch_out,
-                           b.P, b.bpk, b.res, b.relu, b.out);
+                           b.P, b.bpk, b.res, b.relu, b.out, b.norelu_cb0, b.norelu_cb1);
         MPN_CHECK_LAUNCH();
         return MPN_OK;
       }
@@ -1530,12 +1538,12 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
   a.CoutP = round_up(c.Cout, 128); a.Cb_out = (c.Cout + 7) / 8;
   a.KH = c.KH; a.KW = c.KW; a.sh = c.sh; a.sw = c.sw; a.ph = c.ph; a.pw = c.pw;
   a.OH = (in.H + 2 * c.ph - c.KH) / c.sh + 1; a.OW = (in.W + 2 * c.pw - c.KW) / c.sw + 1;
-  a.relu = relu;
+  a.relu = relu; a.norelu_cb0 = c.norelu_c0 / 8; a.norelu_cb1 = c.norelu_c1 / 8;
   MPN_CHECK_ARG(in.C == c.Cin && a.OH > 0 && a.OW > 0);
   a.P = (long long)in.B * a.OH * a.OW;
   *o = ActI{out, in.B, c.Cout, a.OH, a.OW};
   a.pitch_in = in.pitch(); a.pitch_out = o->pitch();
-  if (allow_gemm && c.lin_w && linear_c8_is_direct((int)in.rows(), c.Cout, (int)in.pitch()))  // same rows in and out: the tuned GEMM, residual + ReLU fused
+  if (allow_gemm && c.lin_w && c.norelu_c1 == c.norelu_c0 && linear_c8_is_direct((int)in.rows(), c.Cout, (int)in.pitch()))  // same rows in and out: the tuned GEMM, residual + ReLU fused
     return linear_c8(in.p, (int)in.rows(), c.Cin, c.lin_w, c.lin_b, c.Cout, relu, out, nullptr, s, (int)in.pitch(), res);
   dim3 grid((unsigned)(((a.P + 127) / 128 + 7) / 8 * 8 * (a.CoutP / 128)));  // pixel tiles rounded up to the 8 XCDs x cout tiles (see the kernel)
   // 32-channel stages: the LDS-DMA / hand-pipelined kernel (32-bit gather offsets: the input batch must stay under 4 GiB)
@@ -1566,7 +1574,7 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
       MPN_CHECK_LAUNCH();
       const size_t total = (size_t)a.Cb_out * (size_t)a.P * 2;
       hipLaunchKernelGGL(conv_splitk_finalize_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, c.ws, splits, a.CoutP / 8, a.Cb_out, a.pitch_out, a.P,
-                         a.bpk, a.res, a.relu, a.out);
+                         a.bpk, a.res, a.relu, a.out, a.norelu_cb0, a.norelu_cb1);
       MPN_CHECK_LAUNCH();
       return MPN_OK;
     }
@@ -1734,49 +1742,14 @@ static int graph_parse(ResNetGraph *g, int n_ops, const mpn_graph_op *ops_in, in
   for (int i = 0; i < n_t; ++i) { ts[i].C = tc[i]; MPN_CHECK_ARG(tc[i] > 0); }
   const int align = g->bf16 ? 16 : 8;
   for (int i = 0; i < n_t; ++i) { ts[i].alias_of = -1; ts[i].alias_c_off = 0; }
-  // Sibling fusion: pointwise (1x1 / stride 1) convolutions that read the SAME tensor and each own a whole private tensor
-  // (Inception's branch stems: Mixed_7a's two 768 -> 192, Mixed_7b/7c's 1280 -> 384 and -> 448) become ONE convolution whose
-  // output tensor holds their channels side by side; the original tensors become channel-plane views of it (a plane offset in
-  // this layout).  The big operand — the per-ROI activation batch, 0.3-0.9 GB — is then read once instead of once per branch,
-  // and 192 + 192 couts fill three 128-wide tiles instead of four.
+  // Two build-time rewrites of the op list (mpn_debug_set_graph_fuse switches them off); `fused` is the rewritten list.
   std::vector<mpn_graph_op> fused(ops_in, ops_in + n_ops);
   std::vector<char> dead((size_t)n_ops, 0);
+  std::vector<std::pair<int, int>> norelu_of((size_t)n_ops, std::make_pair(0, 0));  // fused op -> output channels without ReLU
   auto pointwise_private = [&](const mpn_graph_op &o) {
-    return o.kind == 0 && o.kh == 1 && o.kw == 1 && o.sh == 1 && o.sw == 1 && o.ph == 0 && o.pw == 0 && o.dst_c_off == 0 && o.dst > 0 && o.dst < n_t &&
-           o.src >= 0 && o.src < n_t && o.cout == tc[o.dst] && o.cout % align == 0 && o.w;
+    return o.kind == 0 && o.kh == 1 && o.kw == 1 && o.sh == 1 && o.sw == 1 && o.ph == 0 && o.pw == 0 && o.dst_c_off == 0 && o.dst > 0 &&
+           o.dst < (int)ts.size() && o.src >= 0 && o.src < (int)ts.size() && o.cout == ts[o.dst].C && o.cout % align == 0 && o.w;
   };
-  for (int i = 0; (g_graph_fuse & 1) && i < n_ops; ++i) {
-    if (dead[i] || !pointwise_private(fused[i])) continue;
-    std::vector<int> grp{i};
-    for (int j = i + 1; j < n_ops; ++j) {
-      if (ops_in[j].dst == fused[i].src) break;  // the shared input is rewritten: stop looking
-      if (!dead[j] && pointwise_private(ops_in[j]) && ops_in[j].src == fused[i].src && ops_in[j].relu == fused[i].relu && ops_in[j].cin == fused[i].cin &&
-          ops_in[j].dst != fused[i].dst)
-        grp.push_back(j);
-    }
-    if (grp.size() < 2) continue;
-    int ctot = 0;
-    for (int j : grp) ctot += ops_in[j].cout;
-    const int cin = fused[i].cin;
-    float *wsum = nullptr, *bsum = nullptr;
-    int rc = rn_alloc(g, &wsum, (size_t)ctot * cin * sizeof(float));
-    if (rc == MPN_OK) rc = rn_alloc(g, &bsum, (size_t)ctot * sizeof(float));
-    if (rc) return rc;
-    MPN_CHECK_HIP(hipMemset(bsum, 0, (size_t)ctot * sizeof(float)));
-    const int fid = (int)ts.size();
-    GTensor ft; ft.C = ctot;
-    int off = 0;
-    for (int j : grp) {
-      const mpn_graph_op &oj = ops_in[j];
-      MPN_CHECK_HIP(hipMemcpy(wsum + (size_t)off * cin, oj.w, (size_t)oj.cout * cin * sizeof(float), hipMemcpyDeviceToDevice));
-      if (oj.b) MPN_CHECK_HIP(hipMemcpy(bsum + off, oj.b, (size_t)oj.cout * sizeof(float), hipMemcpyDeviceToDevice));
-      ts[oj.dst].alias_of = fid; ts[oj.dst].alias_c_off = off;
-      if (j != i) dead[j] = 1;
-      off += oj.cout;
-    }
-    ts.push_back(ft);
-    fused[i].cout = ctot; fused[i].dst = fid; fused[i].w = wsum; fused[i].b = bsum;
-  }
   // Commute  average-pool(3x3 / 1, pad 1, count_include_pad) -> pointwise convolution  (Inception's pool branches: 1280 / 2048
   // channels pooled, then reduced to 192): both are linear, so pool(conv(x)) == conv(pool(x)) exactly in real arithmetic, and the
   // pool then runs on the convolution's few output channels instead of its many input channels; the convolution's bias and ReLU
@@ -1808,6 +1781,50 @@ static int graph_parse(ResNetGraph *g, int n_ops, const mpn_graph_op *ops_in, in
     fused[i] = conv;
     fused[cons] = pool;
   }
+  // Sibling fusion: pointwise (1x1 / stride 1) convolutions that read the SAME tensor and each own a whole private tensor
+  // (Inception's branch stems: Mixed_7a's two 768 -> 192, Mixed_7b/7c's 1280 -> 384 and -> 448) become ONE convolution whose
+  // output tensor holds their channels side by side; the original tensors become channel-plane views of it (a plane offset in
+  // this layout).  The big operand — the per-ROI activation batch, 0.3-0.9 GB — is then read once instead of once per branch,
+  // and 192 + 192 couts fill three 128-wide tiles instead of four.  It runs second, so that the commuted pool branches'
+  // convolutions (no bias, no ReLU, same input) join their module's group: ReLU-less members go last and the fused convolution
+  // skips the ReLU on their channel range (RnConv.norelu_c0 / c1).
+  for (int i = 0; (g_graph_fuse & 1) && i < n_ops; ++i) {
+    if (dead[i] || !pointwise_private(fused[i])) continue;
+    std::vector<int> grp{i};
+    for (int j = i + 1; j < n_ops; ++j) {
+      if (!dead[j] && fused[j].dst == fused[i].src) break;  // the shared input is rewritten: stop looking
+      if (!dead[j] && pointwise_private(fused[j]) && fused[j].src == fused[i].src && fused[j].cin == fused[i].cin && fused[j].dst != fused[i].dst)
+        grp.push_back(j);
+    }
+    if (grp.size() < 2) continue;
+    std::stable_sort(grp.begin(), grp.end(), [&](int x, int y) { return fused[x].relu > fused[y].relu; });  // ReLU members first
+    int ctot = 0, c_norelu = -1;
+    for (int j : grp) {
+      if (!fused[j].relu && c_norelu < 0) c_norelu = ctot;
+      ctot += fused[j].cout;
+    }
+    const int cin = fused[i].cin;
+    float *wsum = nullptr, *bsum = nullptr;
+    int rc = rn_alloc(g, &wsum, (size_t)ctot * cin * sizeof(float));
+    if (rc == MPN_OK) rc = rn_alloc(g, &bsum, (size_t)ctot * sizeof(float));
+    if (rc) return rc;
+    MPN_CHECK_HIP(hipMemset(bsum, 0, (size_t)ctot * sizeof(float)));
+    const int fid = (int)ts.size();
+    GTensor ft; ft.C = ctot;
+    int off = 0;
+    for (int j : grp) {
+      const mpn_graph_op oj = fused[j];
+      MPN_CHECK_HIP(hipMemcpy(wsum + (size_t)off * cin, oj.w, (size_t)oj.cout * cin * sizeof(float), hipMemcpyDeviceToDevice));
+      if (oj.b) MPN_CHECK_HIP(hipMemcpy(bsum + off, oj.b, (size_t)oj.cout * sizeof(float), hipMemcpyDeviceToDevice));
+      ts[oj.dst].alias_of = fid; ts[oj.dst].alias_c_off = off;
+      if (j != i) dead[j] = 1;
+      off += oj.cout;
+    }
+    ts.push_back(ft);
+    const int any_relu = fused[grp[0]].relu;
+    fused[i].cout = ctot; fused[i].dst = fid; fused[i].w = wsum; fused[i].b = bsum; fused[i].relu = any_relu;
+    norelu_of[i] = (any_relu && c_norelu >= 0) ? std::make_pair(c_norelu, ctot) : std::make_pair(0, 0);
+  }
   const int n_t_all = (int)ts.size();
   for (int i = 0; i < n_ops; ++i) {
     if (dead[i]) continue;
@@ -1834,6 +1851,7 @@ static int graph_parse(ResNetGraph *g, int n_ops, const mpn_graph_op *ops_in, in
       RnConv &c = op.conv;
       c.Cin = o.cin; c.Cout = o.cout; c.KH = o.kh; c.KW = o.kw; c.sh = o.sh; c.sw = o.sw; c.ph = o.ph; c.pw = o.pw;
       c.K = o.kh; c.stride = o.sh; c.pad = o.ph;
+      c.norelu_c0 = norelu_of[i].first; c.norelu_c1 = norelu_of[i].second;
       int rc = rn_pack(g, c, o.w, o.b);
       if (rc) return rc;
     }
