@@ -91,3 +91,22 @@ def test_inception_graph_builder_shapes():
     for o in G["head_ops"]:
         dims.setdefault(o["dst"], (dims[o["src"]] + 2 * o["ph"] - o["kh"]) // o["sh"] + 1)
     assert dims[G["out_tensor"]] == 8
+
+
+def test_average_pool_commutes_with_pointwise_convolution(O):
+    """the identity behind graph_parse's pool-branch rewrite (resnet.hip): a count_include_pad 3x3/1 average pool and a 1x1
+    convolution are both linear and the pool pads with zeros, so relu(conv(pool(x)) + b) == relu(pool(conv(x)) + b) up to fp32
+    summation order — including the border cells, where the window overlaps the padding"""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((3, 40, 8, 8)).astype(np.float32)
+    w = (rng.standard_normal((24, 40, 1, 1)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(24).astype(np.float32)
+    ref = O.conv2d(O.avgpool2d(x, 3, 1, 1), w, b, relu=True)
+    pooled = O.avgpool2d(O.conv2d(x, w, None), 3, 1, 1)
+    alt = np.maximum(pooled + b[None, :, None, None], 0.0)
+    assert np.abs(ref - alt).max() < 1e-5 * max(1.0, np.abs(ref).max())
+    # with bf16 storage the two orders differ only by where the intermediate is rounded
+    xb = O.bf16_round(x)
+    refb = O.conv2d(O.bf16_round(O.avgpool2d(xb, 3, 1, 1)), w, b, relu=True, bf16=True)
+    altb = O.bf16_round(np.maximum(O.avgpool2d(O.conv2d(xb, w, None, bf16=True), 3, 1, 1) + b[None, :, None, None], 0.0))
+    assert np.abs(refb - altb).max() < 2e-2 * max(1.0, np.abs(refb).max())
