@@ -2,22 +2,34 @@
 """bench.py — proposals/sec of the per-image detection hot path (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = one pass of the hot path over one synthetic 600x1000 image with 1000 ROIs through VGG-16
-Fast R-CNN (BASELINE configs[1]): image transform -> 13 conv / 4 pool trunk -> ROI pool -> fc6/fc7 ->
-cls/bbox heads -> softmax / BBoxNorm / decode / clamp -> per-class NMS -> top-100 -> (N>1) all-gather of
-the scored-box record.  Inputs are resident in HBM before the timed region; weights are seeded
-random (no pretrained blobs offline).  Images shard across ranks (weak scaling, one image per rank
-per step); value = all ranks' proposals / max-over-ranks time.
+N > 1 without a launcher (no WORLD_SIZE in the environment): this script re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`, one rank per GPU; launched
+by torch.distributed.run directly it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as usual.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, fp32-MFMA bound; per-launch
-durations from HIP events recorded on the launch stream in a second, equally long profiled pass) and
-"cpu_baseline" (the oracle's CPU restatement timed on this box's host cores, rank 0, N=1 only).
+A step = one pass of the hot path over one synthetic 600x1000 image with 1000 ROIs through VGG-16 Fast R-CNN
+(BASELINE configs[1]), starting — as Tester_FRCNN.lua:64-66 / ImageDetect.lua:148-151 do — from a HOST image and HOST
+boxes: H2D upload (pinned buffers, the pipeline's copy stream, double-buffered so that it overlaps the previous image's
+kernels) -> image transform -> 13 conv / 4 pool trunk -> ROI pool -> fc6/fc7 -> cls/bbox heads -> softmax / BBoxNorm /
+decode / clamp -> per-class NMS -> top-100 -> (N>1) RCCL all-gather of the scored-box record through the C ABI
+(mpn_gather_dets).  Weights are seeded random (no pretrained blobs offline).  Images shard across ranks (weak scaling, one
+image per rank per step); value = all ranks' proposals / max-over-ranks time.  `value_inputs_resident` repeats the
+measurement with the image and boxes already in HBM (no per-step upload).
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  "roofline"      dominant kernel group (the Winograd convolutions), fp32-MFMA bound.  `achieved` / `frac` count the FLOPs the
+                  matrix pipe EXECUTES (Winograd F(2x2,3x3): 16 multiplies per 4 outputs instead of 36 => direct-conv FLOPs /
+                  2.25), so frac <= 1; `algorithmic_equiv_*` is the direct-convolution-equivalent rate (can exceed the peak).
+                  Per-launch durations come from HIP events recorded on the launch stream in a second, equally long pass.
+  "cpu_baseline"  the same path on this box's host cores: PyTorch-CPU (oneDNN conv2d / max_pool2d(ceil_mode) / linear) +
+                  the oracle's ROI pool + the reference's own nms.c, at all cores and at 1 thread, plus the plain C oracle
+                  port; rank 0, N=1 only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,10 +40,11 @@ sys.path.insert(0, ROOT)
 
 H, W, N_ROIS, N_CLASSES = 600, 1000, 1000, 21
 FP32_MFMA_PEAK = 157.3e12  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+WINO_MUL_RATIO = 36.0 / 16.0  # direct 3x3 multiplies per Winograd F(2x2,3x3) multiply
 
 
 def conv_flops(cfg, h, w):
-    """per-layer algorithmic FLOPs (2*H*W*Cin*9*Cout with the REAL Cin) and which tile variant runs it"""
+    """per-layer algorithmic FLOPs (2*H*W*Cin*9*Cout with the REAL Cin) and which kernel family runs it"""
     out, cin = [], 3
     for item in cfg:
         if item == "P":
@@ -56,32 +69,98 @@ def synthetic_inputs():
     return im, boxes
 
 
-def cpu_baseline(P, im, boxes, rois_sample):
-    """The oracle (CPU restatement, OpenMP over the host cores) on one image; the ROI head is timed on a
-    bounded sample of ROIs and scaled (rows are independent), NMS on all classes of the sample."""
+def _np_params(P):
+    return {k: ([t.numpy() for t in v] if isinstance(v, list) and v and hasattr(v[0], "numpy") else (v.numpy() if hasattr(v, "numpy") else v))
+            for k, v in P.items()}
+
+
+def cpu_path_torch(P, im, boxes, threads, n_rois):
+    """The reference's per-image path on host cores with the strongest CPU kernels available here: PyTorch-CPU (oneDNN) for
+    the trunk and the fc layers, the oracle's C ROI pool, numpy decode, and the reference's own compiled nms.c (single
+    thread, as Tester_FRCNN.lua:117 runs it).  Returns seconds for (trunk, head on n_rois ROIs, nms on n_rois ROIs)."""
+    import torch
+    import torch.nn.functional as F
     from oracle import mpn_oracle as O
-    Pn = {k: ([t.numpy() for t in v] if isinstance(v, list) and v and hasattr(v[0], "numpy") else (v.numpy() if hasattr(v, "numpy") else v))
-          for k, v in P.items()}
+    from multipathnet_amd import models
+    torch.set_num_threads(threads)
+    Pn = _np_params(P)
+    with torch.no_grad():
+        t0 = time.time()
+        x = torch.from_numpy(O.image_transform(im, **O.ROSS)).unsqueeze(0)
+        li = 0
+        for item in models.VGG16_CFG:
+            if item == "P":
+                x = F.max_pool2d(x, 2, 2, ceil_mode=True)
+            else:
+                x = F.relu(F.conv2d(x, P["conv_w"][li], P["conv_b"][li], padding=1))
+                li += 1
+        feat = x[0].numpy()
+        t_trunk = time.time() - t0
+        t0 = time.time()
+        b = boxes[:n_rois]
+        pooled, _ = O.roi_pool(feat, O.project_im_rois(b, 1.0), 7, 7, 1.0 / 16)
+        h = torch.from_numpy(pooled.reshape(b.shape[0], -1))
+        h = F.relu(F.linear(h, P["fc6_w"], P["fc6_b"]))
+        h = F.relu(F.linear(h, P["fc7_w"], P["fc7_b"]))
+        logits = F.linear(h, P["cls_w"], P["cls_b"]).numpy()
+        deltas = F.linear(h, P["bbox_w"], P["bbox_b"]).numpy()
+        if Pn.get("bbox_mean") is not None:
+            deltas = O.bbox_norm(deltas, Pn["bbox_mean"], Pn["bbox_std"])
+        scores = O.softmax(logits)
+        dec = O.clamp_boxes(O.bbox_decode(b, deltas), W, H)
+        t_head = time.time() - t0
+        t0 = time.time()
+        nms = O.ref_nms if O.have_ref() else O.nms
+        for j in range(1, scores.shape[1]):
+            sb, _ = O.select_scored(scores, dec, j, -1.5)
+            nms(sb, 0.3)
+        t_nms = time.time() - t0
+    return t_trunk, t_head, t_nms
+
+
+def cpu_baseline(P, im, boxes, rois_sample):
+    from oracle import mpn_oracle as O
+    ncpu = os.cpu_count() or 1
+    out = {"unit": "proposals/s", "kind": "port",
+           "what": "PyTorch-CPU (oneDNN) conv2d / max_pool2d(ceil_mode) / linear + oracle C ROI pool + numpy decode + "
+                   + ("the reference's own nms.c (compiled unmodified, 1 thread)" if O.have_ref() else "oracle NMS port")}
+    # all cores: one warm-up pass over the trunk is part of a cold oneDNN start; time the second image
+    cpu_path_torch(P, im, boxes, ncpu, 64)
+    tt, th, tn = cpu_path_torch(P, im, boxes, ncpu, N_ROIS)
+    total = tt + th + tn
+    out.update({"value": round(N_ROIS / total, 1), "cores": ncpu, "seconds_per_image": round(total, 3),
+                "sample": "1 image 600x1000, all %d ROIs, after one warm-up image: trunk %.2fs + ROI pool/fc/heads %.2fs + NMS %.2fs" % (N_ROIS, tt, th, tn)})
+    # one thread: full trunk, head + NMS on a bounded ROI sample scaled to 1000 (rows / boxes are independent)
+    tt1, th1, tn1 = cpu_path_torch(P, im, boxes, 1, rois_sample)
+    sc = N_ROIS / float(rois_sample)
+    total1 = tt1 + (th1 + tn1) * sc
+    out["one_thread"] = {"value": round(N_ROIS / total1, 1), "cores": 1, "seconds_per_image": round(total1, 3),
+                         "sample": "full trunk %.2fs + head on %d of %d ROIs scaled %.2fs + NMS scaled %.2fs" % (tt1, rois_sample, N_ROIS, th1 * sc, tn1 * sc)}
+    # the plain C restatement (oracle/, OpenMP over all cores) — the checker itself, for reference
+    Pn = _np_params(P)
     t0 = time.time()
-    x = O.image_transform(im, **O.ROSS)
-    feat = O.vgg_trunk(x, Pn["conv_w"], Pn["conv_b"])
+    feat = O.vgg_trunk(O.image_transform(im, **O.ROSS), Pn["conv_w"], Pn["conv_b"])
     t_trunk = time.time() - t0
     t0 = time.time()
     b = boxes[:rois_sample]
-    logits, deltas = O.frcnn_head(feat, O.project_im_rois(b, 1.0), Pn, chunk=500)
-    scores = O.softmax(logits)
-    dec = O.clamp_boxes(O.bbox_decode(b, deltas), W, H)
-    t_head = (time.time() - t0) * (N_ROIS / float(rois_sample))
-    t0 = time.time()
-    for j in range(1, scores.shape[1]):
-        sb, _ = O.select_scored(scores, dec, j, -1.5)
-        (O.ref_nms if O.have_ref() else O.nms)(sb, 0.3)
-    t_nms = (time.time() - t0) * (N_ROIS / float(rois_sample))
-    total = t_trunk + t_head + t_nms
-    return {"value": N_ROIS / total, "unit": "proposals/s", "cores": os.cpu_count(),
-            "kind": "port", "sample": "1 image 600x1000: full trunk (%.1fs) + ROI head on %d of %d ROIs scaled (%.1fs) + NMS %s (%.2fs)"
-            % (t_trunk, rois_sample, N_ROIS, t_head, "reference nms.c" if O.have_ref() else "port", t_nms),
-            "seconds_per_image": total}
+    O.frcnn_head(feat, O.project_im_rois(b, 1.0), Pn, chunk=500)
+    t_head = (time.time() - t0) * sc
+    out["oracle_port"] = {"value": round(N_ROIS / (t_trunk + t_head + tn), 1), "cores": ncpu,
+                          "sample": "oracle/mpn_oracle.c: full trunk %.2fs + head on %d ROIs scaled %.2fs (+ the NMS time above)" % (t_trunk, rois_sample, t_head)}
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher: run N ranks of this script under torch.distributed.run."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -92,6 +171,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rois", type=int, default=250)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -104,37 +185,53 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d" % (args.gpus, world))
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: only %d HIP devices are visible" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # bootstrap + the timing reduction only
+    comm = parallel.Comm.from_torch_distributed()  # the data-path collective: mpn_gather_dets (RCCL through the C ABI)
 
     P = models.synthetic_params(models.VGG16_CFG, pooled=7, fc_dim=4096, n_classes=N_CLASSES, seed=557)
     net = models.FastRCNN(P, max_h=H, max_w=W, max_rois=N_ROIS)
     im_np, boxes_np = synthetic_inputs()
-    im, boxes = torch.from_numpy(im_np).to(dev), torch.from_numpy(boxes_np).to(dev)
+    im_host = [torch.from_numpy(im_np).clone().pin_memory() for _ in range(2)]      # two pinned sets, alternated
+    boxes_host = [torch.from_numpy(boxes_np).clone().pin_memory() for _ in range(2)]
+    im_dev, boxes_dev = torch.from_numpy(im_np).to(dev), torch.from_numpy(boxes_np).to(dev)
     top_cap = net._dets.size(0)
-    gathered = torch.empty((world, top_cap * 6 + 1), dtype=torch.float32, device=dev)
+    gathered = [torch.empty((world, comm.record_floats(top_cap)), dtype=torch.float32, device=dev) for _ in range(2)]
+    gstream = torch.cuda.Stream(device=dev)  # the gather never blocks the compute stream for longer than one image of drift
+    main = torch.cuda.current_stream(dev)
 
-    pending = [None]
+    state = {"pending": None, "seq": 0}
 
     def gather(bufs):
-        if world > 1 and bufs is not None:  # RCCL gather of the scored-box record only (a few KB per rank)
-            parallel.gather_detections(parallel.pack_record(bufs[0], bufs[1], top_cap), out=gathered)
+        if world > 1 and bufs is not None:  # RCCL all-gather of the scored-box record only (~11 KB per rank)
+            main.wait_stream(gstream)       # bounded drift: the previous gather has finished before its buffers are reused
+            gstream.wait_stream(main)       # the record's rows are ordered on `main` by the pipelined call that just returned
+            with torch.cuda.stream(gstream):
+                comm.gather_dets(bufs[0], bufs[1], out=gathered[state["seq"] & 1])
 
-    def step():
-        # Tester:test loop form: image i's NMS/top-k tail runs on the pipeline's side stream and overlaps image
-        # i+1's trunk; its detections are stream-ordered one call later, when they are gathered.
-        cur = net.test_one_pipelined(im, boxes)
-        gather(pending[0])
-        pending[0] = cur
+    def make_step(host_fed):
+        def step():
+            # Tester:test loop form: image i's NMS/top-k tail runs on the pipeline's side stream and overlaps image
+            # i+1's trunk; its detections are stream-ordered one call later, when they are gathered.
+            b = state["seq"] & 1
+            cur = net.test_one_pipelined_host(im_host[b], boxes_host[b]) if host_fed else net.test_one_pipelined(im_dev, boxes_dev)
+            gather(state["pending"])
+            state["pending"] = cur
+            state["seq"] += 1
+        return step
 
     def drain():
         net.flush()
-        gather(pending[0])
-        pending[0] = None
+        gather(state["pending"])
+        state["pending"] = None
+        main.wait_stream(gstream)
 
     def fence():
         torch.cuda.synchronize()
@@ -142,27 +239,33 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    drain()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()  # every step's tail and gather completes inside the timed region
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    value = args.steps * N_ROIS * world / dt
+    def timed(step):
+        for _ in range(args.warmup):
+            step()
+        drain()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        drain()  # every step's tail and gather completes inside the timed region
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
 
-    # ---- roofline leg: same number of steps with HIP events around every kernel group
+    dt = timed(make_step(True))            # the metric: host image + boxes in, H2D inside the timed region
+    dt_res = timed(make_step(False))       # inputs already resident in HBM
+    value = args.steps * N_ROIS * world / dt
+    value_res = args.steps * N_ROIS * world / dt_res
+
+    # ---- roofline leg: same number of steps with HIP events around every kernel group (un-pipelined, single stream)
     net.set_profiling(True)
     net.get_profile(reset=True)
     for _ in range(args.steps):
-        net.test_one_async(im, boxes)
+        net.test_one_async(im_dev, boxes_dev)
     torch.cuda.synchronize()
     prof = net.get_profile(reset=True)
     net.set_profiling(False)
@@ -171,35 +274,56 @@ def main():
         cf = conv_flops(models.VGG16_CFG, H, W)
         flops = {"conv_wino": sum(f for f, v in cf if v == "conv_wino"), "conv_direct": sum(f for f, v in cf if v == "conv_direct"),
                  "fc6": 2.0 * N_ROIS * 25088 * 4096, "fc7": 2.0 * N_ROIS * 4096 * 4096, "heads": 2.0 * N_ROIS * 4096 * 5 * N_CLASSES}
+        executed = dict(flops)
+        executed["conv_wino"] = flops["conv_wino"] / WINO_MUL_RATIO
         launches = {"conv_wino": sum(1 for f, v in cf if v == "conv_wino"), "conv_direct": sum(1 for f, v in cf if v == "conv_direct")}
+        hbm_bytes = {"roi_pool": 4.0 * (512 * 38 * 63 + 5 * N_ROIS + N_ROIS * 512 * 49),
+                     "conv_direct": 4.0 * (8 * 602 * 1002 + 64 * 600 * 1000) + 4.0 * 64 * 27}     # conv1_1: C8P image in, 64-channel map out
         kernels = {}
         for tag, (ms, cnt) in prof.items():
             if cnt:
                 per_image_ms = ms / args.steps
                 k = {"ms_per_image": round(per_image_ms, 4), "launches_per_image": cnt / args.steps}
                 if tag in flops:
-                    k["tflops"] = round(flops[tag] / (per_image_ms * 1e-3) / 1e12, 2)
-                    k["frac_of_fp32_mfma_peak"] = round(flops[tag] / (per_image_ms * 1e-3) / FP32_MFMA_PEAK, 4)
+                    k["executed_tflops"] = round(executed[tag] / (per_image_ms * 1e-3) / 1e12, 2)
+                    k["executed_frac_of_fp32_mfma_peak"] = round(executed[tag] / (per_image_ms * 1e-3) / FP32_MFMA_PEAK, 4)
+                if tag in hbm_bytes:
+                    k["algorithmic_GBps"] = round(hbm_bytes[tag] / (per_image_ms * 1e-3) / 1e9, 1)
+                    k["frac_of_hbm_peak_8TBps"] = round(hbm_bytes[tag] / (per_image_ms * 1e-3) / 8.0e12, 4)
                 kernels[tag] = k
         dom = max((t for t in kernels if t in flops), key=lambda t: kernels[t]["ms_per_image"])
         n_launch = launches.get(dom, 1)
-        achieved = flops[dom] / (kernels[dom]["ms_per_image"] * 1e-3) / 1e12
+        sec = kernels[dom]["ms_per_image"] * 1e-3
+        achieved = executed[dom] / sec / 1e12
         total_flops = sum(f for f, _ in cf) + N_ROIS * 2.0 * (25088 * 4096 + 4096 * 4096 + 4096 * 105)
+        total_exec = total_flops - flops["conv_wino"] + executed["conv_wino"]
         out = {
             "metric": "proposals/sec (1000 ROIs, 600x1000 img) VGG-16 Fast R-CNN",
             "value": round(value, 1), "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "VGG-16 Fast R-CNN, 1 image 600x1000 x 1000 ROIs per GPU per step, 21 classes, NMS 0.3, top-100 (BASELINE configs[1])",
-                       "parallelism": "image-sharded x%d, all-gather of scored boxes only" % world},
-            "whole_path_frac_of_fp32_mfma_peak": round(value / world * (total_flops / N_ROIS) / FP32_MFMA_PEAK, 4),
+            "config": {"workload": "VGG-16 Fast R-CNN, 1 image 600x1000 x 1000 ROIs per GPU per step, 21 classes, NMS 0.3, top-100 (BASELINE configs[1]); "
+                                   "host image + boxes uploaded inside the step (pinned, copy stream, double-buffered)",
+                       "parallelism": "image-sharded over %d RCCL rank%s (one process per GPU), all-gather of scored boxes only via mpn_gather_dets"
+                                      % (comm.world, "" if comm.world == 1 else "s")},
+            "value_inputs_resident": round(value_res, 1), "ms_per_step_inputs_resident": round(dt_res / args.steps * 1e3, 4),
+            "whole_path": {"algorithmic_gflop_per_image": round(total_flops / 1e9, 2), "executed_gflop_per_image": round(total_exec / 1e9, 2),
+                           "executed_frac_of_fp32_mfma_peak": round(value / world * (total_exec / N_ROIS) / FP32_MFMA_PEAK, 4),
+                           "algorithmic_equiv_frac_of_fp32_mfma_peak": round(value / world * (total_flops / N_ROIS) / FP32_MFMA_PEAK, 4)},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                          "frac": round(achieved * 1e12 / FP32_MFMA_PEAK, 4), "traffic": None,
-                         "flops_per_launch": flops[dom] / n_launch,
+                         "flops_per_launch": executed[dom] / n_launch,
                          "avg_launch_ms": round(kernels[dom]["ms_per_image"] / n_launch, 5),
-                         "how": "HIP events on the launch stream around each kernel group, %d profiled steps after the timed region" % args.steps},
+                         "how": "HIP events on the launch stream around each kernel group (a layer's split-K reduce kernel included), "
+                                "%d profiled steps after the timed region" % args.steps},
             "kernels": kernels,
         }
+        if dom == "conv_wino":
+            out["roofline"]["algorithm"] = ("Winograd F(2x2,3x3) in fp32: achieved / frac count the FLOPs the matrix pipe executes "
+                                            "(direct-convolution FLOPs / 2.25); algorithmic_equiv_* is the direct-convolution-equivalent rate")
+            out["roofline"]["algorithmic_equiv_tflops"] = round(achieved * WINO_MUL_RATIO, 2)
+            out["roofline"]["algorithmic_equiv_frac"] = round(achieved * WINO_MUL_RATIO * 1e12 / FP32_MFMA_PEAK, 4)
+            out["roofline"]["algorithmic_flops_per_launch"] = flops[dom] / n_launch
         tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC passes cannot run inside the timed process: measured offline
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
@@ -207,14 +331,11 @@ def main():
                 out["roofline"]["traffic"] = tj[dom]["bytes_per_launch"]
                 out["roofline"]["traffic_unit"] = "HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)"
                 out["roofline"]["traffic_source"] = tj.get("_source")
-        if dom == "conv_wino":  # the MFMA pipe executes 16 multiplies per 4 outputs instead of 36
-            out["roofline"]["algorithm"] = ("Winograd F(2x2,3x3) in fp32: 'achieved' counts the ALGORITHMIC flops (2*H*W*Cin*9*Cout); the matrix "
-                                            "pipe executes 1/2.25 of them, see executed_*")
-            out["roofline"]["executed_tflops"] = round(achieved / 2.25, 2)
-            out["roofline"]["executed_frac_of_peak"] = round(achieved / 2.25 * 1e12 / FP32_MFMA_PEAK, 4)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(P, im_np, boxes_np, args.cpu_rois)
         print(json.dumps(out))
+        sys.stdout.flush()
+    comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

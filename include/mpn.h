@@ -14,11 +14,13 @@
  *   - Return value: MPN_OK or a negative mpn_status; mpn_last_error() gives a thread-local message.
  *     Nothing aborts.  Module-level calls allocate only what a `ws` (workspace) argument documents, plus the shared
  *     scratch named under Concurrency; pipeline handles allocate everything at creation.
- *   - Concurrency: one GPU per process, one calling thread per device (the reference's own test-time design,
- *     test_runner.lua:55-66).  The dense entry points (conv / linear / the mpn_frcnn pipelines) share library-owned
- *     split-K and NMS scratch that grows on demand: calls on ONE stream at a time are ordered and safe; driving two
- *     pipeline handles concurrently from different streams of the same process is not supported.  (A pipeline's
- *     internal side stream for the NMS / top-k tail uses handle-owned buffers only.)
+ *   - Concurrency: re-entrant.  The reference host runs one worker thread per GPU inside ONE process
+ *     (test_runner.lua:55-66: Threads(nGPU) + cutorch.setDevice per thread); this library has no process-global device
+ *     state.  A pipeline handle (mpn_frcnn) owns every buffer it uses, including its split-K / NMS scratch, and lives on
+ *     the device that was current at creation: drive ONE handle from one thread at a time (with that device current);
+ *     different handles — same or different devices — may run concurrently from different host threads and streams.
+ *     Module-level calls keep their grow-on-demand scratch per (device, stream) pair, so calls on different streams
+ *     or devices never share it either.
  *   - Integer results (argmax, keep indices, counts) are bit-exact vs the reference semantics; fp32
  *     box arithmetic is evaluated without FMA contraction, in the reference's operation order.
  */
@@ -32,14 +34,14 @@
 extern "C" {
 #endif
 
-#define MPN_VERSION 100
+#define MPN_VERSION 200
 
 typedef enum mpn_status {
   MPN_OK = 0,
   MPN_EINVAL = -1,   /* bad argument (null pointer, non-positive size, unsupported shape) */
   MPN_EHIP = -2,     /* a HIP runtime call or kernel launch failed */
   MPN_ENOMEM = -3,   /* workspace too small / allocation failed */
-  MPN_ENCCL = -4,    /* collective failure (reserved; collectives run in the host layer) */
+  MPN_ENCCL = -4,    /* an RCCL call failed (mpn_comm_*, mpn_gather_dets) */
   MPN_ESTATE = -5    /* object used in the wrong state */
 } mpn_status;
 
@@ -60,7 +62,8 @@ int mpn_device_info(char *name, int name_len, int *cu_count, size_t *hbm_bytes);
  *   d_n_keep    [n_cls]               number kept
  * Greedy selection, IoU with the +1 convention (nms.c:14-41), suppression when IoU > thr,
  * tie-breaking among bit-equal scores identical to nms.c:74-98 (swap + stable partition history).
- * One 64-lane wavefront per class; boxes live in LDS.  m_stride <= MPN_NMS_MAX_BOXES. */
+ * Tables up to MPN_NMS_MAX_BOXES rows per class run LDS-resident (bitonic sort -> suppression bitmask -> wave scan);
+ * wider tables are accepted too (nms.c has no size limit) and take the exact sweep kernel on HBM-resident arrays. */
 #define MPN_NMS_MAX_BOXES 6144
 int mpn_nms_batched(const float *d_scored, const int *d_counts, int n_cls, int m_stride, float thr, float *d_keep,
                     int *d_keep_idx, int *d_n_keep, void *stream);
@@ -174,7 +177,9 @@ int mpn_select_scored(const float *d_scores, const float *d_bbox, int N, int C, 
 /* utils.keep_top_k (utils.lua:75-96): threshold = k-th largest kept score over all classes (ties
  * survive).  d_keep [n_cls, m_stride, 5] / d_n_keep [n_cls] as written by mpn_nms_batched.
  * Writes *d_thresh (device float) and compacts survivors into d_out [max_out, 6] =
- * {x1,y1,x2,y2,score,class(1-based, as float)} class-major, and *d_n_out (clipped to max_out). */
+ * {x1,y1,x2,y2,score,class(1-based, as float)} class-major.  *d_n_out receives the UNTRUNCATED number of survivors:
+ * when it exceeds max_out (many ties at the threshold), only the first max_out rows were written and the caller
+ * knows rows were dropped (utils.keep_top_k itself never truncates). */
 int mpn_keep_top_k(const float *d_keep, const int *d_n_keep, int n_cls, int m_stride, int k, float *d_thresh,
                    float *d_out, int max_out, int *d_n_out, void *stream);
 
@@ -218,7 +223,8 @@ typedef struct mpn_frcnn_config {
   float score_thresh;      /* -1.5 (Tester_FRCNN.lua:50) */
   int top_k;               /* 100 (Tester_FRCNN.lua:163) */
   /* accuracy knobs of Tester_FRCNN (all off in the reference's default config): */
-  int num_iter;            /* opt.test_num_iterative_loc (1 = off; 2 = one SelectBoxes + head-only pass on cached features) */
+  int num_iter;            /* opt.test_num_iterative_loc (1 = off; i = 2..num_iter: SelectBoxes + a head-only pass on the cached
+                              trunk features; num_iter * max_rois <= MPN_NMS_MAX_BOXES) */
   int bbox_voting;         /* opt.test_bbox_voting */
   float bbox_vote_thresh;  /* opt.test_bbox_voting_nms_threshold (0.5).  The reference passes an unset field here
                               (Tester_FRCNN.lua:123 vs :29); we use the configured threshold. */
@@ -226,6 +232,9 @@ typedef struct mpn_frcnn_config {
   /* getImages (ImageDetect.lua:34-43): 0 = feed the image as it is; otherwise rescale so that the short side is
    * scale_target (600), capped so that the long side stays <= scale_max (1000).  max_h / max_w bound the RESCALED image. */
   double scale_target, scale_max;
+  int use_rbox_scores;     /* opt.test_use_rbox_scores (Tester_FRCNN.lua:91-97): needs num_iter > 1; the scores of pass i+1 are
+                              paired with the boxes of pass i (the first score table and the last box table are dropped), so
+                              (num_iter - 1) * N rows reach the NMS */
 } mpn_frcnn_config;
 
 typedef struct mpn_frcnn mpn_frcnn; /* opaque */
@@ -325,14 +334,16 @@ typedef struct mpn_graph_weights {
 int mpn_graph_create(const mpn_frcnn_config *cfg, const mpn_graph_weights *gw, const float *d_cls_w, const float *d_cls_b,
                      const float *d_bbox_w, const float *d_bbox_b, mpn_frcnn **out);
 
-/* ImageDetect:detect on a scale-1 image (getImages' resample is the identity):
+/* ImageDetect:detect (ImageDetect.lua:156-193; getImages' rescaling per cfg.scale_target):
  * d_image [3,H,W] fp32 in [0,1]; d_boxes [N,4].  Outputs (all optional, device):
- *   d_scores [N,C] softmax, d_bbox [N,4C] decoded + clamped boxes.
+ *   d_scores [N,C] softmax, d_bbox [N,4C] decoded boxes.  clamp = 0 returns them as ImageDetect:detect does (unclamped);
+ *   clamp = 1 additionally applies Tester_FRCNN.lua:75-78's clamp to the image, which the reference applies to the FIRST
+ *   detect() of testOne only (passes 2..num_iter of iterative localisation stay unclamped, Tester_FRCNN.lua:82-89).
  * d_image == NULL means recompute_features = false (ImageDetect.lua:107-111): the trunk output of the previous
  * call on this handle is reused and only the ROI head runs on the new boxes (iterative localisation,
  * Tester_FRCNN.lua:82-89); H, W must equal the cached image's size. */
 int mpn_frcnn_detect(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N, float *d_scores,
-                     float *d_bbox, void *stream);
+                     float *d_bbox, int clamp, void *stream);
 
 /* Tester:testOne + keep_top_k: detect, per-class NMS, global top-k.
  *   d_dets [top_cap,6] {x1,y1,x2,y2,score,class}, *d_n_dets; raw per-class NMS results stay readable
@@ -346,8 +357,43 @@ int mpn_frcnn_test_one(mpn_frcnn *p, const float *d_image, int H, int W, const f
 int mpn_frcnn_test_one_pipelined(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N,
                                  float *d_dets, int top_cap, int *d_n_dets, void *stream);
 int mpn_frcnn_flush(mpn_frcnn *p, void *stream);
+/* The same throughput form fed from HOST buffers, as the reference's loop is (Tester_FRCNN.lua:64-66 gets a CPU image and
+ * CPU boxes; ImageDetect.lua:148-151 copies them to the GPU): the upload of image i (7.2 MB + 16 KB at 600x1000 / 1000 ROIs)
+ * runs on the handle's copy stream into one of two handle-owned staging sets and overlaps image i-1's kernels; `stream`
+ * waits for it only where the trunk starts.  h_image / h_boxes should be pinned (hipHostMalloc / hipHostRegister /
+ * torch pin_memory) — pageable memory works but serialises the copy; they may be reused as soon as the call returns
+ * only if pinned memory is NOT rewritten before the copy ran: alternate two host buffers like the output buffers. */
+int mpn_frcnn_test_one_pipelined_host(mpn_frcnn *p, const float *h_image, int H, int W, const float *h_boxes, int N,
+                                      float *d_dets, int top_cap, int *d_n_dets, void *stream);
 int mpn_frcnn_nms_results(mpn_frcnn *p, const float **d_keep, const int **d_keep_idx, const int **d_n_keep,
                           int *m_stride);
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU: images shard across GPUs, the only exchange is an RCCL all-gather of SCORED BOXES
+ * (replaces test_runner.lua:91-104's result hand-back and ModelParallelTable.lua:204-236's feature broadcast)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mpn_comm mpn_comm; /* opaque: one RCCL communicator rank, bound to the device current at creation */
+#define MPN_UNIQUE_ID_BYTES 128
+/* One process per GPU: rank 0 calls mpn_comm_get_unique_id and hands the 128 bytes to the other ranks out of band
+ * (a file, an env var, torch.distributed's store ...); every rank then calls mpn_comm_init_rank (collective).
+ * world == 1 with id128 == NULL never loads RCCL (the gather degenerates to the pack kernel); world == 1 with an id
+ * creates a real one-rank communicator. */
+int mpn_comm_get_unique_id(void *id128);
+int mpn_comm_init_rank(const void *id128, int world, int rank, mpn_comm **out);
+/* The reference's process model — ONE process, one worker thread per GPU (test_runner.lua:55-66): creates the n_dev
+ * communicators at once; worker i uses out[i] with device h_devices[i] (NULL: device i) current. */
+int mpn_comm_init_all(int n_dev, const int *h_devices, mpn_comm **out);
+int mpn_comm_world(const mpn_comm *c);
+int mpn_comm_rank(const mpn_comm *c);
+void mpn_comm_destroy(mpn_comm *c);
+/* A rank's record for one image: top_cap rows {x1,y1,x2,y2,score,class} (rows at / beyond the count zeroed) + the count
+ * as a float = top_cap*6 + 1 floats (~10 KB for top_cap = 464). */
+size_t mpn_det_record_floats(int top_cap);
+int mpn_pack_det_record(const float *d_dets, const int *d_n_dets, int top_cap, float *d_rec, void *stream);
+/* Packs this rank's (d_dets, *d_n_dets) — mpn_frcnn_test_one's outputs — and all-gathers the records of all ranks into
+ * d_out [world, top_cap*6 + 1]; record r belongs to the image rank r processed in this step.  Stream-ordered on
+ * `stream`, no host synchronisation; every rank must call it the same number of times. */
+int mpn_gather_dets(mpn_comm *c, const float *d_dets, const int *d_n_dets, int top_cap, float *d_out, void *stream);
+
 /* Per-kernel-group timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  * Tags index the arrays returned by mpn_frcnn_get_profile (accumulated ms and launch-group counts). */
 enum {

@@ -9,7 +9,8 @@
  * callee resizes it (THFloatTensor_resize2d / resizeAs — resolved from the libTH the host process
  * has already loaded) and fills it; inputs are borrowed, never modified; M = 0 gives a [0,5] result.
  * Both calls are synchronous and run the wavefront kernels of libmpn_hip.so on the current device
- * (mpn_nms_host / mpn_bbox_vote_host).  A failure raises through THError like a THAssert would.
+ * (mpn_nms_host / mpn_bbox_vote_host); any M is accepted, as nms.c does.  A failure (non-contiguous input, no usable
+ * device) raises through libTH's _THError like the reference's THAssert when libTH is in the process, and aborts otherwise.
  */
 #ifndef MPN_LIBNMS_H
 #define MPN_LIBNMS_H

@@ -8,7 +8,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libmpn_hip.so")
-_lib = None
+_DBG_PATH = os.path.join(_HERE, "libmpn_hip_dbg.so")  # same sources, -DMPN_DEBUG_HOOKS: mpn_debug_* test / timing hooks
+_libs = {}
+_flavour = "debug" if os.environ.get("MPN_FLAVOUR") == "debug" else "product"
 
 f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)
@@ -28,7 +30,7 @@ class FrcnnConfig(C.Structure):
         ("bbox_mean", C.c_float * 4), ("bbox_std", C.c_float * 4), ("nms_thresh", C.c_float),
         ("score_thresh", C.c_float), ("top_k", C.c_int),
         ("num_iter", C.c_int), ("bbox_voting", C.c_int), ("bbox_vote_thresh", C.c_float), ("bbox_vote_score_pow", C.c_float),
-        ("scale_target", C.c_double), ("scale_max", C.c_double),
+        ("scale_target", C.c_double), ("scale_max", C.c_double), ("use_rbox_scores", C.c_int),
     ]
 
 
@@ -72,22 +74,47 @@ def lib_path():
     return _LIB_PATH
 
 
-def load():
-    """Load libmpn_hip.so (built in-tree by `make -C multipathnet_amd/csrc` / __graft_entry__.build())."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(_LIB_PATH):
+def load(flavour=None):
+    """Load libmpn_hip.so (built in-tree by `make -C multipathnet_amd/csrc` / __graft_entry__.build()).
+
+    flavour None = the process's current one: "product" unless MPN_FLAVOUR=debug or inside `debug_hooks()`.  The debug
+    flavour (libmpn_hip_dbg.so) is the same code with the mpn_debug_* variant / ablation hooks compiled in; it exists for
+    the test suite and tools/ only.  The two libraries share no state: a handle must be used with the library that made it
+    (models.FastRCNN remembers its own)."""
+    fl = flavour or _flavour
+    if fl in _libs:
+        return _libs[fl]
+    path = _DBG_PATH if fl == "debug" else _LIB_PATH
+    if not os.path.exists(path):
         raise MpnError(
-            "libmpn_hip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(hipcc --offload-arch=gfx950). multipathnet_amd has no CPU fallback." % _LIB_PATH)
-    lib = C.CDLL(_LIB_PATH, mode=C.RTLD_GLOBAL)
+            "%s not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). multipathnet_amd has no CPU fallback." % (os.path.basename(path), path))
+    lib = C.CDLL(path, mode=C.RTLD_LOCAL)
     lib.mpn_last_error.restype = C.c_char_p
     lib.mpn_pick_scale.restype = C.c_double
     lib.mpn_pick_scale.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double]
     lib.mpn_conv3x3_workspace_bytes.restype = C.c_size_t
-    _lib = lib
+    lib.mpn_det_record_floats.restype = C.c_size_t
+    lib.mpn_comm_destroy.restype = None
+    lib.mpn_frcnn_destroy.restype = None
+    _libs[fl] = lib
     return lib
+
+
+class debug_hooks(object):
+    """`with _lib.debug_hooks() as lib:` — inside the block every op of this package runs on libmpn_hip_dbg.so (the flavour
+    with the mpn_debug_* hooks); `lib` is that library.  Test / tools use only."""
+
+    def __enter__(self):
+        global _flavour
+        self._prev = _flavour
+        _flavour = "debug"
+        return load("debug")
+
+    def __exit__(self, *exc):
+        global _flavour
+        _flavour = self._prev
+        return False
 
 
 def check(rc, what=""):

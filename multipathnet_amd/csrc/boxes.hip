@@ -209,84 +209,130 @@ __device__ __forceinline__ float key2f(unsigned k) {
   return __uint_as_float(u);
 }
 
+// Layout of the work: the kept rows of all classes form ONE flattened list (class-major, NMS selection order inside a
+// class = the order utils.keep_top_k preserves).  Their order-preserving integer keys are staged once in LDS (up to
+// kTopkLdsKeys of them; beyond that the passes re-read HBM), so the 4 radix passes and the compaction touch HBM once.
+// Wave w owns the contiguous slice [w*seg, (w+1)*seg) of the list: its survivors are counted and later written at
+// (sum of earlier waves' counts) + rank-in-slice — an ordered compaction with two block barriers in total.
+constexpr int kTopkLdsKeys = 32768;  // 128 KiB of the CU's 160 KiB
+constexpr int kTopkMaxCls = 1024;
+
+__device__ __forceinline__ int topk_class_of(const int *__restrict__ cls_off, int n_cls, int i) {  // last c with cls_off[c] <= i
+  int lo = 0, hi = n_cls - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (cls_off[mid] <= i) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
 __global__ __launch_bounds__(1024) void keep_top_k_kernel(const float *__restrict__ keep, const int *__restrict__ n_keep,
                                                           int n_cls, int m_stride, int k, float *__restrict__ thresh_out,
                                                           float *__restrict__ out, int max_out, int *__restrict__ n_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned topk_keys[];  // [min(total, kTopkLdsKeys)]
+  __shared__ int cls_off[kTopkMaxCls + 1];
   __shared__ unsigned hist[256];
   __shared__ unsigned sel_prefix, sel_rank;
-  __shared__ int total_s;
   __shared__ int wave_cnt[16];
-  __shared__ int base_s;
-  const int tid = threadIdx.x;
-  if (tid == 0) {
-    int t = 0;
-    for (int c = 0; c < n_cls; ++c) t += min(n_keep[c], m_stride);
-    total_s = t;
-    sel_prefix = 0;
-    sel_rank = (unsigned)max(min(t, k), 1);  // 1-based rank from the top
-    base_s = 0;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
+  // ---- class offsets (exclusive prefix sum of the per-class counts): one wave, 64 classes per step
+  if (wid == 0) {
+    int run = 0;
+    for (int c0 = 0; c0 < n_cls; c0 += 64) {
+      const int c = c0 + lane;
+      int v = c < n_cls ? min(n_keep[c], m_stride) : 0;
+      if (v < 0) v = 0;
+      int incl = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+      }
+      if (c < n_cls) cls_off[c] = run + incl - v;
+      run += __shfl(incl, 63);
+    }
+    if (lane == 0) cls_off[n_cls] = run;
   }
   __syncthreads();
-  const int total = total_s;
+  const int total = cls_off[n_cls];
   if (total == 0) {
     if (tid == 0) { *thresh_out = 0.0f; *n_out = 0; }  // utils.lua:77-79
     return;
   }
+  const int n_lds = min(total, kTopkLdsKeys);
+  auto load_key = [&](int i) -> unsigned {
+    const int c = topk_class_of(cls_off, n_cls, i);
+    return f2key(keep[((size_t)c * m_stride + (i - cls_off[c])) * 5 + 4]);
+  };
+  for (int i = tid; i < n_lds; i += blockDim.x) topk_keys[i] = load_key(i);
+  if (tid == 0) { sel_prefix = 0; sel_rank = (unsigned)max(min(total, k), 1); }  // 1-based rank from the top
+  // ---- MSB-first radix select of the k-th largest key: 4 passes x 8 bits
   unsigned prefix_mask = 0;
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = 24 - 8 * pass;
     for (int b = tid; b < 256; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     const unsigned prefix = sel_prefix;
-    for (int c = 0; c < n_cls; ++c) {
-      int nk = min(n_keep[c], m_stride);
-      for (int j = tid; j < nk; j += blockDim.x) {
-        unsigned key = f2key(keep[((size_t)c * m_stride + j) * 5 + 4]);
-        if ((key & prefix_mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-      }
+    for (int i = tid; i < total; i += blockDim.x) {
+      const unsigned key = i < n_lds ? topk_keys[i] : load_key(i);
+      if ((key & prefix_mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      unsigned rank = sel_rank, acc = 0;
-      int b = 255;
-      for (; b > 0; --b) {
-        if (acc + hist[b] >= rank) break;
-        acc += hist[b];
+    if (wid == 0) {  // the bin that holds the rank: suffix sums over the 256 bins, 4 bins per lane (lane 0 = bins 252..255)
+      const int b0 = 252 - 4 * lane;
+      const unsigned h3 = hist[b0 + 3], h2 = hist[b0 + 2], h1 = hist[b0 + 1], h0 = hist[b0];
+      const unsigned mine = h0 + h1 + h2 + h3;
+      unsigned incl = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
       }
-      sel_rank = rank - acc;
-      sel_prefix = prefix | ((unsigned)b << shift);
+      const unsigned before = incl - mine;  // keys in bins above this lane's four
+      const unsigned rank = sel_rank;
+      const bool hit = before < rank && incl >= rank;
+      const unsigned long long hm = __ballot(hit);
+      // rank > total cannot happen (rank <= total); the bin search mirrors the serial scan: bins 255 -> 1, bin 0 as the rest
+      if (hm && lane == __builtin_ctzll(hm)) {
+        unsigned acc = before;
+        int b = b0 + 3;
+        if (acc + h3 < rank) { acc += h3; b = b0 + 2; if (acc + h2 < rank) { acc += h2; b = b0 + 1; if (acc + h1 < rank) { acc += h1; b = b0; } } }
+        sel_rank = rank - acc;
+        sel_prefix = prefix | ((unsigned)b << shift);
+      }
     }
     prefix_mask |= 0xffu << shift;
     __syncthreads();
   }
-  const float thr = key2f(sel_prefix);
-  if (tid == 0) *thresh_out = thr;
-  // ordered compaction
-  const int lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
-  for (int c = 0; c < n_cls; ++c) {
-    int nk = min(n_keep[c], m_stride);
-    for (int j0 = 0; j0 < nk; j0 += blockDim.x) {
-      int j = j0 + tid;
-      bool take = false;
-      const float *row = keep + ((size_t)c * m_stride + j) * 5;
-      float s = 0.f;
-      if (j < nk) { s = row[4]; take = s >= thr; }
-      unsigned long long mask = __ballot(take);
-      int before = __popcll(mask & ((1ull << lane) - 1ull));
-      if (lane == 0) wave_cnt[wid] = __popcll(mask);
-      __syncthreads();
-      int off = base_s;
-      for (int w = 0; w < wid; ++w) off += wave_cnt[w];
-      if (take && off + before < max_out) {
-        float *o = out + 6 * (size_t)(off + before);
-        o[0] = row[0]; o[1] = row[1]; o[2] = row[2]; o[3] = row[3]; o[4] = s; o[5] = (float)(c + 1);
-      }
-      __syncthreads();
-      if (tid == 0) { int t = 0; for (int w = 0; w < nw; ++w) t += wave_cnt[w]; base_s += t; }
-      __syncthreads();
-    }
+  const unsigned thr_key = sel_prefix;
+  if (tid == 0) *thresh_out = key2f(thr_key);
+  // ---- ordered compaction of the survivors (key >= threshold key <=> score >= threshold)
+  const int seg = (total + nw - 1) / nw;
+  const int s0 = min(wid * seg, total), s1 = min(s0 + seg, total);
+  int cnt = 0;
+  for (int i0 = s0; i0 < s1; i0 += 64) {
+    const int i = i0 + lane;
+    const bool take = i < s1 && (i < n_lds ? topk_keys[i] : load_key(i)) >= thr_key;
+    cnt += __popcll(__ballot(take));
   }
-  if (tid == 0) *n_out = min(base_s, max_out);
+  if (lane == 0) wave_cnt[wid] = cnt;
+  __syncthreads();
+  int off = 0, all = 0;
+  for (int w = 0; w < nw; ++w) { const int v = wave_cnt[w]; if (w < wid) off += v; all += v; }
+  for (int i0 = s0; i0 < s1; i0 += 64) {
+    const int i = i0 + lane;
+    const bool take = i < s1 && (i < n_lds ? topk_keys[i] : load_key(i)) >= thr_key;
+    const unsigned long long m = __ballot(take);
+    const int o = off + __popcll(m & ((1ull << lane) - 1ull));
+    if (take && o < max_out) {
+      const int c = topk_class_of(cls_off, n_cls, i);
+      const float *row = keep + ((size_t)c * m_stride + (i - cls_off[c])) * 5;
+      float *q = out + 6 * (size_t)o;
+      q[0] = row[0]; q[1] = row[1]; q[2] = row[2]; q[3] = row[3]; q[4] = row[4]; q[5] = (float)(c + 1);
+    }
+    off += __popcll(m);
+  }
+  if (tid == 0) *n_out = all;  // the UNTRUNCATED survivor count: > max_out tells the caller rows were dropped
 }
 
 // image.scale(src, W2, H2) 'bilinear' (external `image` rock, ImageDetect.lua:41; parity unpinned — see mpn.h):
@@ -526,7 +572,11 @@ extern "C" int mpn_keep_top_k(const float *d_keep, const int *d_n_keep, int n_cl
   MPN_CHECK_ARG(n_cls >= 0 && m_stride >= 0 && k > 0 && max_out >= 0);
   MPN_CHECK_ARG(d_thresh && d_n_out && (max_out == 0 || d_out));
   MPN_CHECK_ARG(n_cls == 0 || (d_keep && d_n_keep));
-  hipLaunchKernelGGL(keep_top_k_kernel, dim3(1), dim3(1024), 0, as_stream(stream), d_keep, d_n_keep, n_cls, m_stride, k,
+  MPN_CHECK_ARG(n_cls <= kTopkMaxCls);
+  size_t nkeys = (size_t)n_cls * (size_t)m_stride;
+  if (nkeys > (size_t)kTopkLdsKeys) nkeys = kTopkLdsKeys;
+  { int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(keep_top_k_kernel), kTopkLdsKeys * 4); if (rc_attr) return rc_attr; }
+  hipLaunchKernelGGL(keep_top_k_kernel, dim3(1), dim3(1024), nkeys * 4 + 16, as_stream(stream), d_keep, d_n_keep, n_cls, m_stride, k,
                      d_thresh, d_out, max_out, d_n_out);
   MPN_CHECK_LAUNCH();
   return MPN_OK;

@@ -1,4 +1,9 @@
 // common.hip — error reporting, version, device query.
+#include <map>
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "mpn_internal.h"
 
 namespace mpn {
@@ -8,6 +13,52 @@ void set_error(const char *fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+void Scratch::release() {
+  for (int i = 0; i < SCR_NSLOTS; ++i) {
+    if (buf[i]) (void)hipFree(buf[i]);
+    buf[i] = nullptr; bytes[i] = 0;
+  }
+}
+
+static thread_local Scratch *t_scratch = nullptr;
+ScratchScope::ScratchScope(Scratch *sc) : prev(t_scratch) { t_scratch = sc; }
+ScratchScope::~ScratchScope() { t_scratch = prev; }
+
+static std::mutex g_reg_mu;
+static std::map<std::pair<int, hipStream_t>, Scratch *> g_registry;   // module-level calls: one Scratch per (device, stream)
+static std::set<std::pair<const void *, int>> g_attr_done;            // (kernel, device) pairs whose LDS limit is raised
+
+int scratch_get(ScratchSlot slot, size_t need, hipStream_t s, void **out) {
+  Scratch *sc = t_scratch;
+  if (!sc) {
+    int dev = 0;
+    MPN_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    Scratch *&e = g_registry[{dev, s}];
+    if (!e) { e = new Scratch(); e->device = dev; }
+    sc = e;
+  }
+  if (need > sc->bytes[slot]) {  // grows monotonically; steady state allocates nothing
+    MPN_CHECK_HIP(hipStreamSynchronize(s));
+    if (sc->buf[slot]) (void)hipFree(sc->buf[slot]);
+    sc->buf[slot] = nullptr; sc->bytes[slot] = 0;
+    MPN_CHECK_HIP(hipMalloc(&sc->buf[slot], need));
+    sc->bytes[slot] = need;
+  }
+  *out = sc->buf[slot];
+  return MPN_OK;
+}
+
+int set_max_dyn_lds(const void *fn, int bytes) {
+  int dev = 0;
+  MPN_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  if (g_attr_done.count({fn, dev})) return MPN_OK;
+  MPN_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  g_attr_done.insert({fn, dev});
+  return MPN_OK;
 }
 }  // namespace mpn
 

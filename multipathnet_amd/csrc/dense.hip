@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void conv3x3_c8p_kernel(ConvArgs a) {
   constexpr int PER_TAP = (ITEMS + TPS - 1) / TPS;  // DMA items issued per tap: the next stage is fully in flight by the last tap
   for (int q = q0; q < q1; ++q) {
     const int c = q / G, g = q - c * G;
-    const bool more = (q + 1 < q1) && !(a.ablate & 1);
+    const bool more = (q + 1 < q1) && !MPN_ABLATE(a.ablate & 1);
     const float *Il = in_lds + (c & 1) * IN_FLOATS + lane_off + (TPS == 3 ? g * 34 * 8 : 0);
     const float *Wl = w_lds + (q & 1) * W_FLOATS + lane_off;
     // operand fragments are double-buffered in registers: tap t+1's ds_reads are issued before tap t's
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void conv3x3_c8p_kernel(ConvArgs a) {
     for (int mi = 0; mi < MI; ++mi) af[0][mi] = *reinterpret_cast<const f32x4 *>(Wl + (mbase + mi * 32) * 8);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) bf[0][ni] = *reinterpret_cast<const f32x4 *>(Il + ((rbase + ni) * 34) * 8);
-    if (a.ablate & 4) {
+    if (MPN_ABLATE(a.ablate & 4)) {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) af[1][mi] = af[0][mi];
 #pragma unroll
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void conv3x3_c8p_kernel(ConvArgs a) {
 #pragma unroll
     for (int t = 0; t < TPS; ++t) {
       const int cur = t & 1;
-      if (t + 1 < TPS && !(a.ablate & 4)) {
+      if (t + 1 < TPS && !MPN_ABLATE(a.ablate & 4)) {
         const int nt = t + 1, dy = (TPS == 9) ? nt / 3 : 0, dx = nt % 3;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) af[cur ^ 1][mi] = *reinterpret_cast<const f32x4 *>(Wl + (nt * BM + mbase + mi * 32) * 8);
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void conv3x3_c8p_kernel(ConvArgs a) {
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][mi][j], bf[cur][ni][j], acc[mi][ni], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (!(a.ablate & 2)) __syncthreads();
+    if (!MPN_ABLATE(a.ablate & 2)) __syncthreads();
   }
 
   const int x = x0 + l31;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void conv3x3_c8p_kernel(ConvArgs a) {
     return;
   }
   // ---- epilogue: bias + ReLU, C8P float4 stores, optional fused ceil-mode 2x2 max-pool
-  if (a.ablate & 8) {  // timing experiment: skip the output stores (the never-true store keeps the accumulators live)
+  if (MPN_ABLATE(a.ablate & 8)) {  // timing experiment: skip the output stores (the never-true store keeps the accumulators live)
     if (a.H < 0) {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
@@ -274,11 +274,7 @@ static int launch_conv(const ConvArgs &a0, int tiles_y, hipStream_t s) {
   constexpr int IN_LOADS = ((TH + 2) * 68 + 63) / 64;
   constexpr size_t LDS = (size_t)2 * (IN_LOADS * 256 + TPS * BM * 8) * sizeof(float);
   auto kern = conv3x3_c8p_kernel<BM, TH, WM, WN, TPS>;
-  static bool attr = false;
-  if (!attr) {
-    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-    attr = true;
-  }
+  { int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(kern), (int)LDS); if (rc_attr) return rc_attr; }
   dim3 grid((unsigned)(a.n_ct * tiles_y * a.tiles_x), (unsigned)a.splits);
   hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, a);
   MPN_CHECK_LAUNCH();
@@ -602,11 +598,7 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
 template <int ABL>
 static int launch_conv_wino_t(const ConvArgs &a, int tiles_y, hipStream_t s) {
   auto kern = conv3x3_wino_kernel<ABL>;
-  static bool attr = false;
-  if (!attr) {
-    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS_BYTES));
-    attr = true;
-  }
+  { int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(kern), (int)WG_LDS_BYTES); if (rc_attr) return rc_attr; }
   dim3 grid((unsigned)(a.n_ct * tiles_y * a.tiles_x), (unsigned)a.splits);
   hipLaunchKernelGGL(kern, grid, dim3(256), WG_LDS_BYTES, s, a);
   MPN_CHECK_LAUNCH();
@@ -614,7 +606,8 @@ static int launch_conv_wino_t(const ConvArgs &a, int tiles_y, hipStream_t s) {
 }
 
 static int launch_conv_wino(const ConvArgs &a, int tiles_y, hipStream_t s) {
-  switch (a.ablate) {  // timing experiments only (wrong results)
+#ifdef MPN_DEBUG_HOOKS
+  switch (a.ablate) {  // timing experiments only (wrong results); debug flavour of the library only
     case 1: return launch_conv_wino_t<1>(a, tiles_y, s);
     case 2: return launch_conv_wino_t<2>(a, tiles_y, s);
     case 4: return launch_conv_wino_t<4>(a, tiles_y, s);
@@ -623,8 +616,10 @@ static int launch_conv_wino(const ConvArgs &a, int tiles_y, hipStream_t s) {
     case 23: return launch_conv_wino_t<23>(a, tiles_y, s);
     case 31: return launch_conv_wino_t<31>(a, tiles_y, s);
     case 64: return launch_conv_wino_t<64>(a, tiles_y, s);
-    default: return launch_conv_wino_t<0>(a, tiles_y, s);
+    default: break;
   }
+#endif
+  return launch_conv_wino_t<0>(a, tiles_y, s);
 }
 
 // split-K finish: sums S partial slabs in split order (deterministic), + bias, ReLU; writes the C8P
@@ -662,11 +657,9 @@ __global__ void conv_splitk_reduce_kernel(const float *__restrict__ part, size_t
   if (pooling) *reinterpret_cast<f32x4 *>(pool + (size_t)cb * pool_plane + ((size_t)(gy + 1) * pool_Wp + gx + 1) * 8 + h * 4) = m;
 }
 
-static int g_gemm_ablate = 0;         // timing-experiment switch of the convolution kernels (tools/ablate_conv.py, tools/ablate_wino.py)
-static unsigned long long *g_wino_trace = nullptr;  // tools/wino_trace.py
-static int g_conv_split = 0;          // 0 = auto, >0 = force this many splits (test/bench hook)
-static float *g_conv_ws = nullptr;    // library-owned split-K scratch (grown on demand, single stream)
-static size_t g_conv_ws_bytes = 0;
+MPN_KNOB(int, g_gemm_ablate, 0);         // timing-experiment switch of the convolution kernels (tools/ablate_conv.py, tools/ablate_wino.py)
+MPN_KNOB(unsigned long long *, g_wino_trace, nullptr);  // tools/wino_trace.py
+MPN_KNOB(int, g_conv_split, 0);          // 0 = auto, >0 = force this many splits (test/bench hook)
 
 // Fill model: 256 CUs, one 128x4 (or two 64x8) blocks resident per CU -> a launch of b equal blocks takes
 // ceil(b/slots) rounds.  Split K when that lifts the fill by a margin that pays for the extra slab pass.
@@ -704,7 +697,7 @@ static int wino_pick_splits(int blocks, int nchunks, size_t out_bytes) {
   return best;
 }
 
-static int g_conv_variant = 0;  // 0 = auto; test/bench hook: 1 = 128x4 tile / 9 taps per stage, 2 = 64x8 / 9, 3 = 128x4 / 3, 4 = 64x8 / 3,
+MPN_KNOB(int, g_conv_variant, 0);  // 0 = auto; test/bench hook: 1 = 128x4 tile / 9 taps per stage, 2 = 64x8 / 9, 3 = 128x4 / 3, 4 = 64x8 / 3,
                                  // 5 = 128 couts x 8 rows (64x128 per wave, 8 accumulators), 6 = 64 couts x 16 rows
 
 int conv3x3_variant_for(int Cout, bool has_wino) {
@@ -747,14 +740,9 @@ int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int re
       a.part_slab = geo.elems();
       a.out_plane = geo.plane(); a.out_Wp = geo.Wp;
       size_t need = a.part_slab * a.splits * sizeof(float);
-      if (need > g_conv_ws_bytes) {
-        MPN_CHECK_HIP(hipStreamSynchronize(s));
-        if (g_conv_ws) (void)hipFree(g_conv_ws);
-        g_conv_ws = nullptr; g_conv_ws_bytes = 0;
-        MPN_CHECK_HIP(hipMalloc(&g_conv_ws, need));
-        g_conv_ws_bytes = need;
-      }
-      a.part = g_conv_ws;
+      void *ws = nullptr;
+      { int rc_ws = scratch_get(SCR_CONV_SPLITK, need, s, &ws); if (rc_ws) return rc_ws; }
+      a.part = static_cast<float *>(ws);
     }
     int rc = launch_conv_wino(a, tiles_y, s);
     if (rc != MPN_OK || a.splits == 1) return rc;
@@ -779,14 +767,9 @@ int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int re
     a.part_slab = geo.elems();
     a.out_plane = geo.plane(); a.out_Wp = geo.Wp;
     size_t need = a.part_slab * a.splits * sizeof(float);
-    if (need > g_conv_ws_bytes) {
-      MPN_CHECK_HIP(hipStreamSynchronize(s));
-      if (g_conv_ws) (void)hipFree(g_conv_ws);
-      g_conv_ws = nullptr; g_conv_ws_bytes = 0;
-      MPN_CHECK_HIP(hipMalloc(&g_conv_ws, need));
-      g_conv_ws_bytes = need;
-    }
-    a.part = g_conv_ws;
+    void *ws = nullptr;
+    { int rc_ws = scratch_get(SCR_CONV_SPLITK, need, s, &ws); if (rc_ws) return rc_ws; }
+    a.part = static_cast<float *>(ws);
   }
   int rc;
   switch (variant) {
@@ -994,10 +977,8 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ part, int S, int 
   }
 }
 
-static int g_gemm_kch = 0;       // test/bench hook: force 4 or 8 K chunks per stage
-static int g_gemm_split = 0;  // test/bench hook: force a split-K factor
-static float *g_splitk_ws = nullptr;
-static size_t g_splitk_ws_bytes = 0;
+MPN_KNOB(int, g_gemm_kch, 0);       // test/bench hook: force 4 or 8 K chunks per stage
+MPN_KNOB(int, g_gemm_split, 0);  // test/bench hook: force a split-K factor
 
 bool linear_c8_is_direct(int M, int N, int Mp_override) {
   const int Mp = Mp_override ? Mp_override : lin_mp(M);
@@ -1031,24 +1012,18 @@ int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float
   a.direct = direct ? 1 : 0;
   if (d_res_c8 && !direct) { set_error("linear_c8: a residual needs the direct (un-split, C8 output) form"); return MPN_EINVAL; }
   a.res = d_res_c8;
-  static bool attr = false;
-  if (!attr) {
-    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_c8_pf_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 4 * 128 * 8 * 4));
-    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_c8_pf_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 8 * 128 * 8 * 4));
-    attr = true;
+  {
+    int rc_attr = kch == 8 ? set_max_dyn_lds(reinterpret_cast<const void *>(gemm_c8_pf_kernel<8>), 2 * 2 * 8 * 128 * 8 * 4)
+                           : set_max_dyn_lds(reinterpret_cast<const void *>(gemm_c8_pf_kernel<4>), 2 * 2 * 4 * 128 * 8 * 4);
+    if (rc_attr) return rc_attr;
   }
   if (direct) {
     a.y = d_y_c8;
   } else {
     size_t need = (size_t)S * (a.NP / 8) * a.Mp * 8 * sizeof(float);
-    if (need > g_splitk_ws_bytes) {  // grows monotonically; steady state allocates nothing
-      MPN_CHECK_HIP(hipStreamSynchronize(s));
-      if (g_splitk_ws) (void)hipFree(g_splitk_ws);
-      g_splitk_ws = nullptr; g_splitk_ws_bytes = 0;
-      MPN_CHECK_HIP(hipMalloc(&g_splitk_ws, need));
-      g_splitk_ws_bytes = need;
-    }
-    a.y = g_splitk_ws;
+    void *ws = nullptr;
+    { int rc_ws = scratch_get(SCR_GEMM_SPLITK, need, s, &ws); if (rc_ws) return rc_ws; }
+    a.y = static_cast<float *>(ws);
   }
   dim3 grid((unsigned)tiles, (unsigned)S);
   if (kch == 8) hipLaunchKernelGGL((gemm_c8_pf_kernel<8>), grid, dim3(256), (size_t)2 * 2 * 8 * 128 * 8 * 4, s, a);
@@ -1394,22 +1369,15 @@ __global__ __launch_bounds__(256) void l2norm_apply_kernel(float *__restrict__ x
   *reinterpret_cast<f32x4 *>(p) = v;
 }
 
-static float *g_l2_ws = nullptr;   // library-owned scratch for the partial sums (grown on demand, single stream)
-static size_t g_l2_ws_bytes = 0;
 
 int l2norm_scale_c8(float *d_x_c8, int n_records, int Mp, int N, float mul, hipStream_t s) {
   MPN_CHECK_ARG(d_x_c8 && n_records > 0 && N > 0 && Mp >= N);
   const int per = 49;  // one channel block's bins per partial sum
   const int G = cdiv(n_records, per);
   const size_t need = ((size_t)G + 1) * N * sizeof(float);
-  if (need > g_l2_ws_bytes) {
-    MPN_CHECK_HIP(hipStreamSynchronize(s));
-    if (g_l2_ws) (void)hipFree(g_l2_ws);
-    g_l2_ws = nullptr; g_l2_ws_bytes = 0;
-    MPN_CHECK_HIP(hipMalloc(&g_l2_ws, need));
-    g_l2_ws_bytes = need;
-  }
-  float *part = g_l2_ws, *nrm = g_l2_ws + (size_t)G * N;
+  void *ws = nullptr;
+  { int rc_ws = scratch_get(SCR_L2NORM, need, s, &ws); if (rc_ws) return rc_ws; }
+  float *part = static_cast<float *>(ws), *nrm = part + (size_t)G * N;
   hipLaunchKernelGGL(l2norm_partial_kernel, dim3(cdiv(N, 256), G), dim3(256), 0, s, d_x_c8, n_records, per, Mp, N, part);
   MPN_CHECK_LAUNCH();
   hipLaunchKernelGGL(l2norm_finish_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, part, G, N, nrm);
@@ -1540,7 +1508,8 @@ int roi_pool_c8(Act feat, const float *d_rois, int N, int PH, int PW, float scal
 
 using namespace mpn;
 
-// ---- test / bench hooks (not part of the reference surface) -------------------------------------
+// ---- test / bench hooks (not part of the reference surface; DEBUG flavour of the library only) ------
+#ifdef MPN_DEBUG_HOOKS
 extern "C" void mpn_debug_set_wino_trace(void *p) { g_wino_trace = static_cast<unsigned long long *>(p); }
 extern "C" void mpn_debug_set_conv_variant(int v) { g_conv_variant = v; }
 extern "C" void mpn_debug_set_conv_split(int v) { g_conv_split = v; }
@@ -1671,6 +1640,8 @@ extern "C" int mpn_debug_roi_pool_rmq_mismatches(const float *d_feat_nchw, int C
   return rc;
 }
 
+#endif  // MPN_DEBUG_HOOKS
+
 // ---- module-level C entry points (NCHW / row-major Torch layouts) -------------------------------
 extern "C" size_t mpn_conv3x3_workspace_bytes(int B, int Cin, int H, int W, int Cout) {
   (void)B;
@@ -1724,18 +1695,11 @@ extern "C" int mpn_linear_forward(const float *d_x, int M, int K, const float *d
                                   float *d_y, void *stream) {
   MPN_CHECK_ARG(d_x && d_w && d_y && M > 0 && K > 0 && N > 0);
   hipStream_t s = as_stream(stream);
-  static float *scratch = nullptr;
-  static size_t scratch_bytes = 0;
   size_t xe = mat_c8_elems(M, round_up(K, 64)), we = lin_wpk_elems(round_up(K, 64), N), be = lin_np(N);
   size_t need = (xe + we + be) * sizeof(float);
-  if (need > scratch_bytes) {
-    MPN_CHECK_HIP(hipStreamSynchronize(s));
-    if (scratch) (void)hipFree(scratch);
-    scratch = nullptr; scratch_bytes = 0;
-    MPN_CHECK_HIP(hipMalloc(&scratch, need));
-    scratch_bytes = need;
-  }
-  float *xc8 = scratch, *wpk = scratch + xe, *bpk = wpk + we;
+  void *ws = nullptr;
+  { int rc_ws = scratch_get(SCR_LINEAR_PACK, need, s, &ws); if (rc_ws) return rc_ws; }
+  float *xc8 = static_cast<float *>(ws), *wpk = xc8 + xe, *bpk = wpk + we;
   MPN_CHECK_HIP(hipMemsetAsync(xc8, 0, xe * sizeof(float), s));
   int rc = rowmajor_to_c8(d_x, M, K, xc8, s);
   if (rc) return rc;

@@ -35,6 +35,43 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 constexpr int kWave = 64;
 
+// ---- library-owned device scratch ---------------------------------------------------------------------------
+// Split-K slabs, NMS masks and the like are grown on demand and kept.  They are never process-global: a Scratch
+// belongs either to ONE pipeline handle (mpn_frcnn; bound to the calling thread for the duration of an entry point
+// by ScratchScope) or, for module-level calls, to ONE (device, stream) pair of a registry that common.hip guards
+// with a mutex.  Work on a stream is ordered, so one Scratch per stream of work is race-free; two handles, two host
+// threads or two devices never share a buffer (the reference host runs one worker thread per GPU in ONE process,
+// test_runner.lua:55-66).
+enum ScratchSlot { SCR_CONV_SPLITK = 0, SCR_GEMM_SPLITK, SCR_L2NORM, SCR_NMS, SCR_LINEAR_PACK, SCR_GRAPH_SPLITK, SCR_MISC, SCR_NSLOTS };
+struct Scratch {
+  int device = -1;
+  void *buf[SCR_NSLOTS] = {};
+  size_t bytes[SCR_NSLOTS] = {};
+  void release();  // hipFree everything (the owner has synchronised)
+};
+// The current thread's Scratch for `s`: the ScratchScope override if one is active, else the registry entry of
+// (current device, s).  Returns a buffer of at least `need` bytes in *out (grown by sync(s) + free + malloc).
+int scratch_get(ScratchSlot slot, size_t need, hipStream_t s, void **out);
+struct ScratchScope {
+  Scratch *prev;
+  explicit ScratchScope(Scratch *sc);
+  ~ScratchScope();
+};
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): function attributes are per device.
+int set_max_dyn_lds(const void *fn, int bytes);
+
+// ---- tuning knobs ---------------------------------------------------------------------------------------------
+// Test / timing hooks (forced kernel variants, split factors, ablations, traces) exist only in the DEBUG flavour of
+// the library (make DEBUG_HOOKS=1 -> libmpn_hip_dbg.so, -DMPN_DEBUG_HOOKS).  In the product build every knob is a
+// compile-time constant, no mpn_debug_* symbol is exported and the timing-only kernel instantiations are not built.
+#ifdef MPN_DEBUG_HOOKS
+#define MPN_KNOB(type, name, init) static type name = init
+#define MPN_ABLATE(expr) (expr)
+#else
+#define MPN_KNOB(type, name, init) static constexpr type name = init
+#define MPN_ABLATE(expr) 0
+#endif
+
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ inline size_t cdiv_sz(size_t a, size_t b) { return (a + b - 1) / b; }
 

@@ -57,11 +57,14 @@ constexpr int kDead = 0x7fffffff;
 __global__ __launch_bounds__(64) void nms_wave_kernel(const float *__restrict__ scored, const int *__restrict__ counts,
                                                       int m_stride, float thr, float *__restrict__ keep,
                                                       int *__restrict__ keep_idx, int *__restrict__ n_keep,
-                                                      int m_cap, const int *__restrict__ flags) {
+                                                      int m_cap, const int *__restrict__ flags, float *__restrict__ gwork) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   if (flags && flags[blockIdx.x] != 2) return;  // this class took a sorted/bitmask path
-  float *X1 = lds, *Y1 = lds + m_cap, *X2 = lds + 2 * m_cap, *Y2 = lds + 3 * m_cap, *S = lds + 4 * m_cap;
-  int *POS = reinterpret_cast<int *>(lds + 5 * m_cap);
+  // the class's six working arrays: LDS, or (tables wider than MPN_NMS_MAX_BOXES — nms.c itself has no size limit) a
+  // per-class slice of HBM scratch; one wave owns them, __syncthreads() orders its lanes' accesses at workgroup scope
+  float *base = gwork ? gwork + (size_t)blockIdx.x * 6 * m_cap : lds;
+  float *X1 = base, *Y1 = base + m_cap, *X2 = base + 2 * m_cap, *Y2 = base + 3 * m_cap, *S = base + 4 * m_cap;
+  int *POS = reinterpret_cast<int *>(base + 5 * m_cap);
 
   const int cls = blockIdx.x;
   const int lane = threadIdx.x;
@@ -206,7 +209,9 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float *__restrict_
   __syncthreads();
   if (tid == 0) {
     int f = hasnan ? 2 : ((bad || force_mode == 2) ? 1 : 0);
-    if (f == 1 && m > kTieMax) f = 2;
+    // the host launches nms_tie_kernel only when m_stride <= kTieMax (its LDS tables are sized by m_stride): a class with
+    // ties in a wider table goes to the exact sweep kernel, whatever its own count
+    if (f == 1 && m_stride > kTieMax) f = 2;
     flags[cls] = f;
     n_sel[cls] = nsel;
   }
@@ -574,13 +579,14 @@ __global__ void boxoverlap_kernel(const float *__restrict__ a, int n, float bx1,
 
 using namespace mpn;
 
-static int g_nms_force_exact = 0;  // test hook: 1 = always the exact IoU-sweep kernel, 2 = always the tie (slot-emulation) kernel
+MPN_KNOB(int, g_nms_force_exact, 0);  // test hook: 1 = always the exact IoU-sweep kernel, 2 = always the tie (slot-emulation) kernel
+#ifdef MPN_DEBUG_HOOKS
 extern "C" void mpn_debug_set_nms_force_exact(int v) { g_nms_force_exact = v; }
+#endif
 
 extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n_cls, int m_stride, float thr,
                                float *d_keep, int *d_keep_idx, int *d_n_keep, void *stream) {
   MPN_CHECK_ARG(n_cls >= 0 && m_stride >= 0);
-  MPN_CHECK_ARG(m_stride <= MPN_NMS_MAX_BOXES);
   MPN_CHECK_ARG(d_n_keep != nullptr);
   if (n_cls == 0) return MPN_OK;
   if (m_stride == 0) {
@@ -589,19 +595,27 @@ extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n
   }
   MPN_CHECK_ARG(d_scored != nullptr && d_keep != nullptr);
   hipStream_t st = as_stream(stream);
+  if (m_stride > MPN_NMS_MAX_BOXES) {  // beyond the LDS-resident paths: the exact sweep kernel on HBM-resident working arrays
+    const int m_cap = (m_stride + 3) & ~3;
+    void *ws = nullptr;
+    int rc_ws = scratch_get(SCR_NMS, (size_t)n_cls * 6 * m_cap * sizeof(float), st, &ws);
+    if (rc_ws) return rc_ws;
+    hipLaunchKernelGGL(nms_wave_kernel, dim3(n_cls), dim3(kWave), 0, st, d_scored, d_counts, m_stride, thr, d_keep, d_keep_idx, d_n_keep, m_cap,
+                       (const int *)nullptr, static_cast<float *>(ws));
+    MPN_CHECK_LAUNCH();
+    return MPN_OK;
+  }
   // ---- scratch for the fast path (library-owned, grown on demand, one stream at a time)
   const int w64 = (m_stride + 63) / 64;
   const size_t n_rows = (size_t)n_cls * m_stride;
   const size_t need = n_rows * (sizeof(float4) + sizeof(float) + sizeof(int)) + n_rows * w64 * sizeof(unsigned long long) +
                       (size_t)n_cls * 2 * sizeof(int) + 256;
-  static char *scratch = nullptr;
-  static size_t scratch_bytes = 0;
-  if (need > scratch_bytes) {
-    MPN_CHECK_HIP(hipStreamSynchronize(st));
-    if (scratch) (void)hipFree(scratch);
-    scratch = nullptr; scratch_bytes = 0;
-    MPN_CHECK_HIP(hipMalloc(&scratch, need));
-    scratch_bytes = need;
+  char *scratch = nullptr;
+  {
+    void *ws = nullptr;
+    int rc_ws = scratch_get(SCR_NMS, need, st, &ws);
+    if (rc_ws) return rc_ws;
+    scratch = static_cast<char *>(ws);
   }
   unsigned long long *mask = reinterpret_cast<unsigned long long *>(scratch);
   float4 *sbox = reinterpret_cast<float4 *>(scratch + n_rows * w64 * sizeof(unsigned long long));
@@ -609,12 +623,7 @@ extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n
   int *sidx = reinterpret_cast<int *>(sscore + n_rows);
   int *n_sel = sidx + n_rows;
   int *flags = n_sel + n_cls;
-  static bool sort_attr = false;
-  if (!sort_attr) {
-    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      kSortMax * 8));
-    sort_attr = true;
-  }
+  { int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(nms_sort_kernel), kSortMax * 8); if (rc_attr) return rc_attr; }
   int n_pad = 64;
   while (n_pad < m_stride && n_pad < kSortMax) n_pad <<= 1;
   const int sort_threads = n_pad / 2 < 64 ? 64 : (n_pad / 2 > 1024 ? 1024 : n_pad / 2);
@@ -627,13 +636,12 @@ extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n
     MPN_CHECK_LAUNCH();
     {  // tie classes (exact slot emulation on the bitmask); both instantiations exit at once when not needed
       const int tcap = (m_stride + 3) & ~3;
-      static bool tie_attr = false;
       const size_t lds_a = (size_t)kTieLdsMask * (kTieLdsMask / 64) * 8 + (size_t)5 * kTieLdsMask * 4 + 512;
       const size_t lds_b = (size_t)5 * kTieMax * 4 + 512;
-      if (!tie_attr) {
-        MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_tie_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
-        MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_tie_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-        tie_attr = true;
+      {
+        int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(nms_tie_kernel<true>), (int)lds_a);
+        if (rc_attr == MPN_OK) rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(nms_tie_kernel<false>), (int)lds_b);
+        if (rc_attr) return rc_attr;
       }
       if (m_stride <= kTieMax) {
         const int cap_a = tcap < kTieLdsMask ? tcap : kTieLdsMask;
@@ -657,14 +665,9 @@ extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n
   }
   int m_cap = (m_stride + 3) & ~3;
   size_t lds = (size_t)m_cap * 6 * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nms_wave_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, MPN_NMS_MAX_BOXES * 6 * 4));
-    attr_set = true;
-  }
+  { int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(nms_wave_kernel), MPN_NMS_MAX_BOXES * 6 * 4); if (rc_attr) return rc_attr; }
   hipLaunchKernelGGL(nms_wave_kernel, dim3(n_cls), dim3(kWave), lds, st, d_scored, d_counts, m_stride,
-                     thr, d_keep, d_keep_idx, d_n_keep, m_cap, flags);
+                     thr, d_keep, d_keep_idx, d_n_keep, m_cap, flags, (float *)nullptr);
   MPN_CHECK_LAUNCH();
   return MPN_OK;
 }

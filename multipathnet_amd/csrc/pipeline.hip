@@ -35,11 +35,11 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(const float *__restri
   for (int c = lane; c < C; c += 64) scores[(size_t)row * C + c] = expf(r[c] - mx) / sum;
 }
 
-// BBoxNorm (modules/BBoxNorm.lua:28-29) + convertFrom (utils.lua:229-247) + clamp
+// BBoxNorm (modules/BBoxNorm.lua:28-29) + convertFrom (utils.lua:229-247) + optional clamp
 // (Tester_FRCNN.lua:75-78) on head[:, C:5C]; thread per (roi, class)
 __global__ void head_decode_kernel(const float *__restrict__ head, int ld, int col0, int M, int C, const float *__restrict__ boxes,
                                    int has_norm, float m0, float m1, float m2, float m3, float s0, float s1, float s2,
-                                   float s3, float im_w, float im_h, float *__restrict__ raw, float *__restrict__ out) {
+                                   float s3, int clamp, float im_w, float im_h, float *__restrict__ raw, float *__restrict__ out) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)M * C) return;
   int i = (int)(t / C), c = (int)(t - (size_t)i * C);
@@ -61,10 +61,12 @@ __global__ void head_decode_kernel(const float *__restrict__ head, int ld, int c
   float wt = expf(d2) * w, ht = expf(d3) * h;
   float hw = wt * 0.5f, hh = ht * 0.5f;
   float o0 = xtc - hw, o1 = ytc - hh, o2 = xtc + hw, o3 = ytc + hh;
-  o0 = o0 < 1.0f ? 1.0f : (o0 > im_w ? im_w : o0);
-  o2 = o2 < 1.0f ? 1.0f : (o2 > im_w ? im_w : o2);
-  o1 = o1 < 1.0f ? 1.0f : (o1 > im_h ? im_h : o1);
-  o3 = o3 < 1.0f ? 1.0f : (o3 > im_h ? im_h : o3);
+  if (clamp) {  // Tester_FRCNN.lua:75-78 — the first detect() of testOne only
+    o0 = o0 < 1.0f ? 1.0f : (o0 > im_w ? im_w : o0);
+    o2 = o2 < 1.0f ? 1.0f : (o2 > im_w ? im_w : o2);
+    o1 = o1 < 1.0f ? 1.0f : (o1 > im_h ? im_h : o1);
+    o3 = o3 < 1.0f ? 1.0f : (o3 > im_h ? im_h : o3);
+  }
   float *o = out + 4 * t;
   o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3;
 }
@@ -167,6 +169,15 @@ struct mpn_frcnn {
   float *vmax_tab[3] = {nullptr, nullptr, nullptr};  // vertical range-max tables of the three maps (MultiPathNet ROI pools)
   bool vmax_valid = false;                            // built for the current tap_act maps
   std::vector<void *> allocs;
+  Scratch scratch;  // split-K slabs, NMS masks, ... of THIS handle (bound to the calling thread by ScratchScope in every entry point)
+  int device = 0;   // the handle lives on the device that was current at creation
+  // host-fed throughput form (mpn_frcnn_test_one_pipelined_host): two staging sets filled by the copy stream
+  hipStream_t copy = nullptr;
+  float *stage_img[2] = {nullptr, nullptr}, *stage_boxes[2] = {nullptr, nullptr};
+  size_t stage_cap[2] = {0, 0};
+  hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
+  bool used_pending[2] = {false, false};
+  unsigned long long up_seq = 0;
   // optional per-kernel-group timing with HIP events recorded on the launch stream
   bool prof = false;
   std::vector<hipEvent_t> ev_pool;
@@ -193,8 +204,10 @@ struct ProfScope {
   }
 };
 
-static int g_fuse_pool = 1;
+MPN_KNOB(int, g_fuse_pool, 1);
+#ifdef MPN_DEBUG_HOOKS
 extern "C" void mpn_debug_set_fuse_pool(int v) { g_fuse_pool = v; }
+#endif
 
 template <typename T>
 static int dev_alloc(mpn_frcnn *p, T **ptr, size_t bytes, bool zero) {
@@ -216,6 +229,10 @@ extern "C" void mpn_frcnn_destroy(mpn_frcnn *p) {
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   for (int i = 0; i < 2; ++i) { if (p->ev_head[i]) (void)hipEventDestroy(p->ev_head[i]); if (p->ev_tail[i]) (void)hipEventDestroy(p->ev_tail[i]); }
   if (p->side) (void)hipStreamDestroy(p->side);
+  if (p->copy) (void)hipStreamDestroy(p->copy);
+  for (int i = 0; i < 2; ++i) { if (p->ev_up[i]) (void)hipEventDestroy(p->ev_up[i]); if (p->ev_consumed[i]) (void)hipEventDestroy(p->ev_consumed[i]); }
+  p->scratch.release();
+  for (int i = 0; i < 2; ++i) if (p->stage_img[i]) (void)hipFree(p->stage_img[i]);
   for (void *q : p->allocs) (void)hipFree(q);
   resnet_free(p->rn);
   if (p->scaled) (void)hipFree(p->scaled);
@@ -238,6 +255,9 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
   MPN_CHECK_ARG(cfg->top_k > 0);
   mpn_frcnn *p = new mpn_frcnn();
   p->cfg = *cfg;
+  if (hipGetDevice(&p->device) != hipSuccess) { delete p; set_error("mpn_frcnn_create: no current HIP device"); return MPN_EHIP; }
+  p->scratch.device = p->device;
+  ScratchScope scratch_scope(&p->scratch);
   const int tower_heads = rw ? rw->n_heads : (gw ? gw->n_heads : 0);  // > 1: MultiPathNet towers on a ResNet / op-list backbone
   const int *tower_region = rw ? rw->head_region : (gw ? gw->head_region : nullptr);
   if (tower_heads > 1) p->n_integral = (rw ? rw->n_integral : gw->n_integral) > 0 ? (rw ? rw->n_integral : gw->n_integral) : 1;
@@ -385,7 +405,8 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
   TRY(dev_alloc(p, &p->bbox, M * 4 * C * sizeof(float), true));
   TRY(dev_alloc(p, &p->bbox_raw, M * 4 * C * sizeof(float), true));
   const int n_it = cfg->num_iter > 1 ? cfg->num_iter : 1;
-  MPN_CHECK_ARG(n_it <= 2 && (size_t)n_it * M <= MPN_NMS_MAX_BOXES);
+  MPN_CHECK_ARG((size_t)n_it * M <= MPN_NMS_MAX_BOXES);
+  MPN_CHECK_ARG(!cfg->use_rbox_scores || n_it > 1);  // Tester_FRCNN.lua:92 assert(#all_output > 1)
   p->cfg.num_iter = n_it;
   const size_t MR = M * n_it;  // rows that reach NMS per class
   if (n_it > 1) {
@@ -467,9 +488,9 @@ static int run_trunk(mpn_frcnn *p, const float *d_image, int H, int W, hipStream
 // {ROI pools of conv5 / conv4 / conv3 written side by side = the channel concat, per-map L2 normalise * 1000,
 // 1x1 conv mix as a GEMM over (bin, roi) rows whose output IS the fc6 operand, fc6, fc7 into the tower concat}
 // -> K integral classifiers (mean of softmaxes) + bbox regressor on the "het" tower.
-static int run_integral_heads(mpn_frcnn *p, const float *d_boxes, int N, int H, int W, int n_fov, hipStream_t s);
+static int run_integral_heads(mpn_frcnn *p, const float *d_boxes, int N, int H, int W, int n_fov, hipStream_t s, int clamp);
 
-static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int W, hipStream_t s) {
+static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int W, hipStream_t s, int clamp) {
   const mpn_frcnn_config &c = p->cfg;
   const int F = c.fc_dim, PP = c.pooled_h * c.pooled_w, Mp = lin_mp(N);
   int rc = mpn_foveal_forward(p->rois, N, p->fov, s);
@@ -508,12 +529,12 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
     if (rc) return rc;
     ++ti;
   }
-  return run_integral_heads(p, d_boxes, N, H, W, (int)p->towers.size() - 1, s);
+  return run_integral_heads(p, d_boxes, N, H, W, (int)p->towers.size() - 1, s, clamp);
 }
 
 // the stage after the towers (model_utils.lua:296-315, multipathnet.lua:112-120): K classifier clones on the concatenated
 // classification towers -> mean of their softmaxes; box regressor on the last tower; decode + clamp
-static int run_integral_heads(mpn_frcnn *p, const float *d_boxes, int N, int H, int W, int n_fov, hipStream_t s) {
+static int run_integral_heads(mpn_frcnn *p, const float *d_boxes, int N, int H, int W, int n_fov, hipStream_t s, int clamp) {
   const mpn_frcnn_config &c = p->cfg;
   const int C = c.n_classes, F = c.fc_dim, Mp = lin_mp(N), K = p->n_integral;
   const int Fcb = lin_np(F) / 8;
@@ -528,14 +549,14 @@ static int run_integral_heads(mpn_frcnn *p, const float *d_boxes, int N, int H, 
   const bool norm = c.bbox_std[0] != 0.0f;
   hipLaunchKernelGGL(head_decode_kernel, dim3((unsigned)cdiv_sz((size_t)N * C, 256)), dim3(256), 0, s, p->bbox_rm, 4 * C, 0, N, C, d_boxes,
                      norm ? 1 : 0, c.bbox_mean[0], c.bbox_mean[1], c.bbox_mean[2], c.bbox_mean[3], c.bbox_std[0], c.bbox_std[1],
-                     c.bbox_std[2], c.bbox_std[3], (float)W, (float)H, p->bbox_raw, p->bbox);
+                     c.bbox_std[2], c.bbox_std[3], clamp, (float)W, (float)H, p->bbox_raw, p->bbox);
   MPN_CHECK_LAUNCH();
   return MPN_OK;
 }
 
 // d_image == nullptr: recompute_features = false (ImageDetect.lua:107-111) — reuse the trunk output of the last
 // call on this handle (iterative localisation, Tester_FRCNN.lua:82-89) and run only the ROI head on new boxes.
-static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const float *d_boxes, int N, hipStream_t s) {
+static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const float *d_boxes, int N, hipStream_t s, int clamp = 1) {
   const mpn_frcnn_config &c = p->cfg;
   MPN_CHECK_ARG(p && d_boxes);
   MPN_CHECK_ARG(H0 > 0 && W0 > 0 && N > 0 && N <= c.max_rois);
@@ -584,7 +605,7 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const 
   // decode uses the ORIGINAL boxes and clamps to the ORIGINAL image (ImageDetect.lua:183-185, Tester_FRCNN.lua:75-78)
   H = H0; W = W0;
   if (p->is_mpnet) {
-    rc = run_mpnet_head(p, d_boxes, N, H, W, s);
+    rc = run_mpnet_head(p, d_boxes, N, H, W, s, clamp);
     p->last_n = N;
     return rc;
   }
@@ -598,7 +619,7 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const 
       rc = resnet_head_forward(p->rn, (int)t, p->fov + 5 * p->rn_region[t], 20, N, c.spatial_scale, p->cat + t * (size_t)Fcb * Mp * 8, Mp, s);
       if (rc) return rc;
     }
-    rc = run_integral_heads(p, d_boxes, N, H, W, (int)p->rn_region.size() - 1, s);
+    rc = run_integral_heads(p, d_boxes, N, H, W, (int)p->rn_region.size() - 1, s, clamp);
     p->last_n = N;
     return rc;
   }
@@ -623,18 +644,19 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const 
   const bool norm = c.bbox_std[0] != 0.0f;
   hipLaunchKernelGGL(head_decode_kernel, dim3((unsigned)cdiv_sz((size_t)N * C, 256)), dim3(256), 0, s, p->head, 5 * C, C, N, C, d_boxes,
                      norm ? 1 : 0, c.bbox_mean[0], c.bbox_mean[1], c.bbox_mean[2], c.bbox_mean[3], c.bbox_std[0], c.bbox_std[1],
-                     c.bbox_std[2], c.bbox_std[3], (float)W, (float)H, p->bbox_raw, p->bbox);
+                     c.bbox_std[2], c.bbox_std[3], clamp, (float)W, (float)H, p->bbox_raw, p->bbox);
   MPN_CHECK_LAUNCH();
   p->last_n = N;
   return MPN_OK;
 }
 
 extern "C" int mpn_frcnn_detect(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N,
-                                float *d_scores, float *d_bbox, void *stream) {
+                                float *d_scores, float *d_bbox, int clamp, void *stream) {
   MPN_CHECK_ARG(p != nullptr);
+  ScratchScope scratch_scope(&p->scratch);
   if (d_image == nullptr) { int rcf = mpn_frcnn_flush(p, stream); if (rcf) return rcf; }
   hipStream_t s = as_stream(stream);
-  int rc = run_detect(p, d_image, H, W, d_boxes, N, s);
+  int rc = run_detect(p, d_image, H, W, d_boxes, N, s, clamp ? 1 : 0);
   if (rc) return rc;
   const int C = p->cfg.n_classes;
   if (d_scores) MPN_CHECK_HIP(hipMemcpyAsync(d_scores, p->scores, (size_t)N * C * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -677,23 +699,28 @@ static int run_tail(mpn_frcnn *p, int N, float *d_dets, int top_cap, int *d_n_de
   return mpn_keep_top_k(final_tables, p->n_keep, C - 1, N, c.top_k, p->thresh, d_dets, top_cap, d_n_dets, t);
 }
 
-// Tester_FRCNN.lua:72-100: detect; for i = 2..num_iter: SelectBoxes -> detect on the refined boxes with
-// recompute_features = false; the rows of all passes are concatenated before the per-class NMS.
+// Tester_FRCNN.lua:72-100: detect (clamped, :75-78); for i = 2..num_iter: SelectBoxes on the previous pass -> detect on the refined
+// boxes with recompute_features = false (NOT clamped: only the first bbox_pred is); the rows of all passes are concatenated
+// before the per-class NMS.  opt.test_use_rbox_scores (:91-97): the scores of pass i+1 go with the boxes of pass i.
 static int run_detect_iter(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N, hipStream_t s, int *n_rows) {
-  int rc = run_detect(p, d_image, H, W, d_boxes, N, s);
+  int rc = run_detect(p, d_image, H, W, d_boxes, N, s, 1);
   *n_rows = N;
   const mpn_frcnn_config &c = p->cfg;
   if (rc || c.num_iter <= 1) return rc;
   const int C = c.n_classes;
-  MPN_CHECK_HIP(hipMemcpyAsync(p->it_scores, p->scores, (size_t)N * C * sizeof(float), hipMemcpyDeviceToDevice, s));
-  MPN_CHECK_HIP(hipMemcpyAsync(p->it_bbox, p->bbox, (size_t)N * 4 * C * sizeof(float), hipMemcpyDeviceToDevice, s));
-  rc = mpn_select_boxes_forward(p->scores, p->bbox, N, C, p->it_boxes, s);
-  if (rc) return rc;
-  rc = run_detect(p, nullptr, H, W, p->it_boxes, N, s);
-  if (rc) return rc;
-  MPN_CHECK_HIP(hipMemcpyAsync(p->it_scores + (size_t)N * C, p->scores, (size_t)N * C * sizeof(float), hipMemcpyDeviceToDevice, s));
-  MPN_CHECK_HIP(hipMemcpyAsync(p->it_bbox + (size_t)N * 4 * C, p->bbox, (size_t)N * 4 * C * sizeof(float), hipMemcpyDeviceToDevice, s));
-  *n_rows = 2 * N;
+  const size_t srow = (size_t)N * C, brow = (size_t)N * 4 * C;
+  const bool rbox = c.use_rbox_scores != 0;
+  for (int it = 1;; ++it) {  // pass `it` (1-based) has just run: p->scores / p->bbox hold its output
+    const int sslot = rbox ? it - 2 : it - 1, bslot = it - 1;  // rbox: drop the first score table and the last box table
+    if (sslot >= 0) MPN_CHECK_HIP(hipMemcpyAsync(p->it_scores + sslot * srow, p->scores, srow * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (!(rbox && it == c.num_iter)) MPN_CHECK_HIP(hipMemcpyAsync(p->it_bbox + bslot * brow, p->bbox, brow * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (it == c.num_iter) break;
+    rc = mpn_select_boxes_forward(p->scores, p->bbox, N, C, p->it_boxes, s);
+    if (rc) return rc;
+    rc = run_detect(p, nullptr, H, W, p->it_boxes, N, s, 0);
+    if (rc) return rc;
+  }
+  *n_rows = (rbox ? c.num_iter - 1 : c.num_iter) * N;
   return MPN_OK;
 }
 
@@ -716,6 +743,7 @@ extern "C" int mpn_frcnn_flush(mpn_frcnn *p, void *stream) {
 extern "C" int mpn_frcnn_test_one(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N,
                                   float *d_dets, int top_cap, int *d_n_dets, void *stream) {
   MPN_CHECK_ARG(p != nullptr && d_n_dets && (top_cap == 0 || d_dets) && top_cap >= 0);
+  ScratchScope scratch_scope(&p->scratch);
   hipStream_t s = as_stream(stream);
   int rc = mpn_frcnn_flush(p, stream);  // a pipelined predecessor may still own a buffer set
   if (rc) return rc;
@@ -734,6 +762,7 @@ extern "C" int mpn_frcnn_test_one(mpn_frcnn *p, const float *d_image, int H, int
 extern "C" int mpn_frcnn_test_one_pipelined(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N,
                                             float *d_dets, int top_cap, int *d_n_dets, void *stream) {
   MPN_CHECK_ARG(p != nullptr && d_n_dets && (top_cap == 0 || d_dets) && top_cap >= 0);
+  ScratchScope scratch_scope(&p->scratch);
   hipStream_t s = as_stream(stream);
   const int b = (int)(p->seq & 1);
   int rc = join_tail(p, b, s);  // buffer set b was last used two calls ago
@@ -750,6 +779,50 @@ extern "C" int mpn_frcnn_test_one_pipelined(mpn_frcnn *p, const float *d_image, 
   rc = join_tail(p, b ^ 1, s);  // the previous image's detections become visible to `stream` here
   p->seq++;
   return rc;
+}
+
+// Host-fed throughput form: the reference's loop hands testOne a CPU image and CPU boxes (Tester_FRCNN.lua:64-66) and
+// ImageDetect copies them to the GPU (ImageDetect.lua:148-151).  Here the upload of image i is issued on the handle's copy
+// stream into staging set i & 1 — it runs while image i-1's kernels are still executing — and `stream` waits for it only
+// at the point where the trunk starts.  The copy stream in turn waits until image i-2 (the previous user of the set) has
+// been consumed.
+extern "C" int mpn_frcnn_test_one_pipelined_host(mpn_frcnn *p, const float *h_image, int H, int W, const float *h_boxes, int N,
+                                                 float *d_dets, int top_cap, int *d_n_dets, void *stream) {
+  MPN_CHECK_ARG(p != nullptr && h_image && h_boxes && H > 0 && W > 0 && N > 0 && N <= p->cfg.max_rois);
+  hipStream_t s = as_stream(stream);
+  const size_t img_n = (size_t)3 * H * W;
+  if (!p->copy) {  // first use: copy stream, events, the two box staging buffers
+    MPN_CHECK_HIP(hipStreamCreateWithFlags(&p->copy, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      MPN_CHECK_HIP(hipEventCreateWithFlags(&p->ev_up[i], hipEventDisableTiming));
+      MPN_CHECK_HIP(hipEventCreateWithFlags(&p->ev_consumed[i], hipEventDisableTiming));
+      int rc0 = dev_alloc(p, &p->stage_boxes[i], (size_t)p->cfg.max_rois * 4 * sizeof(float), false);
+      if (rc0) return rc0;
+    }
+  }
+  const int b = (int)(p->up_seq & 1);
+  if (img_n > p->stage_cap[b]) {  // image staging grows on demand (getImages may be handed images larger than max_h x max_w)
+    MPN_CHECK_HIP(hipStreamSynchronize(p->copy));
+    MPN_CHECK_HIP(hipStreamSynchronize(s));
+    if (p->stage_img[b]) (void)hipFree(p->stage_img[b]);
+    p->stage_img[b] = nullptr; p->stage_cap[b] = 0;
+    size_t cap = (size_t)3 * p->cfg.max_h * p->cfg.max_w;
+    if (cap < img_n) cap = img_n;
+    MPN_CHECK_HIP(hipMalloc(&p->stage_img[b], cap * sizeof(float)));
+    p->stage_cap[b] = cap;
+  }
+  if (p->used_pending[b]) { MPN_CHECK_HIP(hipStreamWaitEvent(p->copy, p->ev_consumed[b], 0)); p->used_pending[b] = false; }
+  MPN_CHECK_HIP(hipMemcpyAsync(p->stage_img[b], h_image, img_n * sizeof(float), hipMemcpyHostToDevice, p->copy));
+  MPN_CHECK_HIP(hipMemcpyAsync(p->stage_boxes[b], h_boxes, (size_t)N * 4 * sizeof(float), hipMemcpyHostToDevice, p->copy));
+  MPN_CHECK_HIP(hipEventRecord(p->ev_up[b], p->copy));
+  MPN_CHECK_HIP(hipStreamWaitEvent(s, p->ev_up[b], 0));
+  int rc = mpn_frcnn_test_one_pipelined(p, p->stage_img[b], H, W, p->stage_boxes[b], N, d_dets, top_cap, d_n_dets, stream);
+  if (rc) return rc;
+  // the image is consumed by the trunk's first kernel and the boxes by the decode kernel: both are behind this point of `stream`
+  MPN_CHECK_HIP(hipEventRecord(p->ev_consumed[b], s));
+  p->used_pending[b] = true;
+  p->up_seq++;
+  return MPN_OK;
 }
 
 extern "C" int mpn_frcnn_create(const mpn_frcnn_config *cfg, const float *const *d_conv_w, const float *const *d_conv_b,

@@ -1442,14 +1442,14 @@ static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b
   return MPN_OK;
 }
 
-static unsigned long long *g_bf16_trace = nullptr;  // mpn_debug_set_bf16_trace (tools/dma_trace.py)
-static int g_bf16_trace_kh = 3;
-static int g_bf16_fast_pool = 3;       // bit 0: row-per-thread ROI pooling (bf16: on the int16-sortable map), bit 1: LDS average pooling (bf16) (0 = the plain kernels; mpn_debug_set_bf16_fast_pool)
-static int g_fp32_pf = 1;              // fp32 graph: conv2d_c8i_pf_kernel for 32-channel-stage layers (0 = conv2d_c8i_kernel<4>; mpn_debug_set_fp32_pf)
-static int g_split_max_tiles = 192;     // split-K only layers with fewer 128 x 128 tiles than this (mpn_debug_set_split_max_tiles)
-static int g_bf16_split_target = 256;  // split-K (both dtypes) aims at this many blocks (0 = never split; mpn_debug_set_bf16_split_target)
-static int g_bf16_dma_tn = 0;  // 0 = pick per layer; 128 / 256 = force 256 couts x that many pixels, 1256 = 128 couts x 256 pixels (mpn_debug_set_bf16_dma_tn)
-static int g_bf16_dma = 1;  // mpn_debug_set_bf16_dma: 0 = never, 1 = large layers, 2 = every eligible layer (tests)
+MPN_KNOB(unsigned long long *, g_bf16_trace, nullptr);  // mpn_debug_set_bf16_trace (tools/dma_trace.py)
+MPN_KNOB(int, g_bf16_trace_kh, 3);
+MPN_KNOB(int, g_bf16_fast_pool, 3);       // bit 0: row-per-thread ROI pooling (bf16: on the int16-sortable map), bit 1: LDS average pooling (bf16) (0 = the plain kernels; mpn_debug_set_bf16_fast_pool)
+MPN_KNOB(int, g_fp32_pf, 1);              // fp32 graph: conv2d_c8i_pf_kernel for 32-channel-stage layers (0 = conv2d_c8i_kernel<4>; mpn_debug_set_fp32_pf)
+MPN_KNOB(int, g_split_max_tiles, 192);     // split-K only layers with fewer 128 x 128 tiles than this (mpn_debug_set_split_max_tiles)
+MPN_KNOB(int, g_bf16_split_target, 256);  // split-K (both dtypes) aims at this many blocks (0 = never split; mpn_debug_set_bf16_split_target)
+MPN_KNOB(int, g_bf16_dma_tn, 0);  // 0 = pick per layer; 128 / 256 = force 256 couts x that many pixels, 1256 = 128 couts x 256 pixels (mpn_debug_set_bf16_dma_tn)
+MPN_KNOB(int, g_bf16_dma, 1);  // mpn_debug_set_bf16_dma: 0 = never, 1 = large layers, 2 = every eligible layer (tests)
 static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int relu, hipStream_t s, ActI *o, bool allow_gemm = true) {
   if (c.wpk16) {  // bf16 graph
     GConvArgsB b{};
@@ -1483,12 +1483,11 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
         const int tm = shapes[best].tm, tn = shapes[best].tn;
         const int ring = (tm == 256 && tn == 256) ? 4 : 3;
         const size_t LDS = (size_t)ring * 4 * (tm + tn) * 16;  // ring depth x stage bytes (as in the kernel)
-        static bool attr = false;
-        if (!attr) {
-          MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768));
-          MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 24576));
-          MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 24576));
-          attr = true;
+        {
+          int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<4, 4>), 4 * 32768);
+          if (rc_attr == MPN_OK) rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<4, 2>), 3 * 24576);
+          if (rc_attr == MPN_OK) rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<2, 4>), 3 * 24576);
+          if (rc_attr) return rc_attr;
         }
         const int nx = (int)((b.P + tn - 1) / tn), ny = b.CoutP / tm;
         b.trace = (g_bf16_trace && b.KH == g_bf16_trace_kh) ? g_bf16_trace : nullptr;
@@ -1549,13 +1548,7 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
   // 32-channel stages: the LDS-DMA / hand-pipelined kernel (32-bit gather offsets: the input batch must stay under 4 GiB)
   constexpr size_t PF_LDS = (size_t)2 * 2 * 4 * 128 * 8 * sizeof(float);
   const bool pf_ok = g_fp32_pf && (size_t)in.B * in.H * in.W * 32 < ((size_t)1 << 32);
-  {
-    static bool attr = false;
-    if (!attr) {
-      MPN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv2d_c8i_pf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PF_LDS));
-      attr = true;
-    }
-  }
+  { int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(conv2d_c8i_pf_kernel), (int)PF_LDS); if (rc_attr) return rc_attr; }
   {  // small layers: split K across blockIdx.z into fp32 slabs (as the bf16 graph does)
     const int kc = a.nch % 4 == 0 ? 4 : 1;
     const int nstages = a.KH * a.KW * (a.nch / kc);
@@ -1735,7 +1728,7 @@ static int graph_dims(const std::vector<GOp> &ops, std::vector<GTensor> &ts, int
   return MPN_OK;
 }
 
-static int g_graph_fuse = 3;  // mpn_debug_set_graph_fuse: bit 0 = fuse sibling pointwise convolutions, bit 1 = commute average-pool -> pointwise convolution; 0 = run the op list as given
+MPN_KNOB(int, g_graph_fuse, 3);  // mpn_debug_set_graph_fuse: bit 0 = fuse sibling pointwise convolutions, bit 1 = commute average-pool -> pointwise convolution; 0 = run the op list as given
 static int graph_parse(ResNetGraph *g, int n_ops, const mpn_graph_op *ops_in, int n_t, const int *tc, std::vector<GOp> &out, std::vector<GTensor> &ts) {
   MPN_CHECK_ARG(n_ops > 0 && ops_in && n_t > 1 && tc);
   ts.resize(n_t);
@@ -2062,6 +2055,7 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
 
 }  // namespace mpn
 
+#ifdef MPN_DEBUG_HOOKS
 extern "C" void mpn_debug_set_bf16_dma(int v) { mpn::g_bf16_dma = v; }
 extern "C" void mpn_debug_set_bf16_dma_tn(int v) { mpn::g_bf16_dma_tn = v; }
 extern "C" void mpn_debug_set_bf16_split_target(int v) { mpn::g_bf16_split_target = v; }
@@ -2070,3 +2064,4 @@ extern "C" void mpn_debug_set_graph_fuse(int v) { mpn::g_graph_fuse = v; }
 extern "C" void mpn_debug_set_fp32_pf(int v) { mpn::g_fp32_pf = v; }
 extern "C" void mpn_debug_set_bf16_trace(void *p, int kh) { mpn::g_bf16_trace = static_cast<unsigned long long *>(p); mpn::g_bf16_trace_kh = kh; }
 extern "C" void mpn_debug_set_split_max_tiles(int v) { mpn::g_split_max_tiles = v; }
+#endif  // MPN_DEBUG_HOOKS

@@ -15,8 +15,14 @@ void THFloatTensor_resizeAs(THFloatTensor *self, THFloatTensor *src);
 int THFloatTensor_isContiguous(const THFloatTensor *self);
 }
 
+// libTH's error hook (TH/THGeneral.h: #define THError(...) _THError(__FILE__, __LINE__, __VA_ARGS__)); weak: resolved in a
+// Torch7 process, absent elsewhere
+extern "C" void _THError(const char *file, const int line, const char *fmt, ...) __attribute__((weak));
+
 static void die(const char *what) {
-  // the reference aborts the Lua call through THAssert/THError; without libTH's error hook we print and abort
+  // the reference raises a Lua error through THAssert -> THError (longjmp back into the interpreter); do the same when
+  // libTH is in the process, otherwise there is nobody to catch it: print and abort
+  if (_THError) _THError(__FILE__, __LINE__, "libnms.so (mpn): %s: %s", what, mpn_last_error());
   std::fprintf(stderr, "libnms.so (mpn): %s: %s\n", what, mpn_last_error());
   std::abort();
 }

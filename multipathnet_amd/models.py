@@ -404,8 +404,10 @@ class FastRCNN(object):
 
     def __init__(self, params, cfg=VGG16_CFG, pooled=7, spatial_scale=1.0 / 16, transformer=None, max_h=600, max_w=1000,
                  max_rois=1000, nms_thresh=0.3, score_thresh=-1.5, top_k=100, num_iter=1, bbox_voting=False, bbox_vote_thresh=0.5,
-                 bbox_vote_score_pow=1.0, scale=None, max_size=None, bf16=False):
-        """scale / max_size: getImages' rescaling (ImageDetect.lua:34-43) on the device; None feeds images as they are."""
+                 bbox_vote_score_pow=1.0, scale=None, max_size=None, bf16=False, use_rbox_scores=False):
+        """scale / max_size: getImages' rescaling (ImageDetect.lua:34-43) on the device; None feeds images as they are.
+        num_iter / bbox_voting / use_rbox_scores: opt.test_num_iterative_loc / test_bbox_voting / test_use_rbox_scores
+        (Tester_FRCNN.lua:82-99,118-124) inside the fused test_one."""
         _lib.require_gpu()
         lib = _lib.load()
         self.is_resnet = "trunk_blocks" in params
@@ -444,6 +446,8 @@ class FastRCNN(object):
         c.num_iter, c.bbox_voting, c.bbox_vote_thresh, c.bbox_vote_score_pow = num_iter, int(bbox_voting), bbox_vote_thresh, bbox_vote_score_pow
         self.num_iter = num_iter
         c.scale_target, c.scale_max = float(scale or 0.0), float(max_size or 0.0)
+        c.use_rbox_scores = int(bool(use_rbox_scores))
+        self.scale, self.max_size = scale, max_size
         self._cfg = c
         dev = torch.device("cuda", torch.cuda.current_device())
         d = lambda t: t.to(dev, torch.float32).contiguous()
@@ -560,15 +564,17 @@ class FastRCNN(object):
         except Exception:
             pass
 
-    def detect(self, image, boxes, recompute_features=True):
-        """image [3,H,W] fp32 in [0,1] (device), boxes [N,4] (device) -> (scores [N,C], boxes [N,4C] decoded+clamped).
+    def detect(self, image, boxes, recompute_features=True, clamp=True):
+        """image [3,H,W] fp32 in [0,1] (device), boxes [N,4] (device) -> (scores [N,C], boxes [N,4C] decoded).
+        clamp=True also applies Tester_FRCNN.lua:75-78's clamp to the image (what testOne does to its first detect());
+        clamp=False is ImageDetect:detect's own (unclamped) output.
         recompute_features=False (ImageDetect.lua:107-111) reuses the cached trunk output of the previous call."""
         H, W = image.shape[1:]
         N = boxes.size(0)
         scores = torch.empty((N, self.n_classes), dtype=torch.float32, device=self.device)
         bbox = torch.empty((N, 4 * self.n_classes), dtype=torch.float32, device=self.device)
         img_ptr = _f(image, "image") if recompute_features else None
-        check(self._lib.mpn_frcnn_detect(self._h, img_ptr, H, W, _f(boxes, "boxes"), N, _f(scores), _f(bbox), _stream()),
+        check(self._lib.mpn_frcnn_detect(self._h, img_ptr, H, W, _f(boxes, "boxes"), N, _f(scores), _f(bbox), int(bool(clamp)), _stream()),
               "mpn_frcnn_detect")
         return scores, bbox
 
@@ -588,6 +594,19 @@ class FastRCNN(object):
         dets, n = self._dets2[b], self._n_dets2[b]
         check(self._lib.mpn_frcnn_test_one_pipelined(self._h, _f(image, "image"), H, W, _f(boxes, "boxes"), boxes.size(0), _f(dets),
                                                      dets.size(0), _i(n), _stream()), "mpn_frcnn_test_one_pipelined")
+        return dets, n
+
+    def test_one_pipelined_host(self, image_pinned, boxes_pinned):
+        """mpn_frcnn_test_one_pipelined_host: the same throughput form fed from (pinned) HOST tensors — the upload runs on the
+        handle's copy stream and overlaps the previous image's kernels.  Alternate two host buffers between calls."""
+        H, W = image_pinned.shape[1:]
+        assert not image_pinned.is_cuda and not boxes_pinned.is_cuda and image_pinned.dtype == torch.float32
+        b = self._pipe_seq & 1
+        self._pipe_seq += 1
+        dets, n = self._dets2[b], self._n_dets2[b]
+        check(self._lib.mpn_frcnn_test_one_pipelined_host(self._h, C.cast(image_pinned.data_ptr(), f32p), H, W,
+                                                          C.cast(boxes_pinned.data_ptr(), f32p), boxes_pinned.size(0), _f(dets),
+                                                          dets.size(0), _i(n), _stream()), "mpn_frcnn_test_one_pipelined_host")
         return dets, n
 
     def flush(self):

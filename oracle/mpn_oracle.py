@@ -368,15 +368,33 @@ def detect(im, boxes, P, transformer=ROSS, target=600, max_size=1000, cfg=None, 
     return softmax(logits), dec, logits, deltas
 
 
-def test_one(im, boxes, P, nms_thresh=0.3, score_thresh=-1.5, use_ref_nms=False, **kw):
-    """Tester_FRCNN.lua:54-139 (num_iter=1, no voting): detect -> clamp -> per-class select -> NMS.
-    Returns (list over classes 1..C-1 of [K,5]), (scores, clamped boxes)."""
+def test_one(im, boxes, P, nms_thresh=0.3, score_thresh=-1.5, use_ref_nms=False, num_iter=1, use_rbox_scores=False,
+             bbox_voting=False, bbox_vote_thresh=0.5, **kw):
+    """Tester_FRCNN.lua:54-139: detect -> clamp the FIRST pass only (:75-78) -> for i = 2..num_iter: SelectBoxes on the previous
+    pass, detect on the refined boxes (recompute_features = false: same trunk output; NOT clamped) (:82-89) ->
+    opt.test_use_rbox_scores drops the first score table and the last box table (:91-97) -> joinTable -> per-class select ->
+    NMS (-> bbox_vote, :118-124; the reference passes an unset threshold field there, we take bbox_vote_thresh).
+    Returns (list over classes 1..C-1 of [K,5]), (scores, boxes) as joined."""
     scores, dec, _, _ = detect(im, boxes, P, **kw)
     dec = clamp_boxes(dec, im.shape[2], im.shape[1])
+    all_s, all_b = [scores], [dec]
+    for _ in range(2, num_iter + 1):
+        new_boxes = select_boxes(scores, dec)
+        scores, dec, _, _ = detect(im, new_boxes, P, **kw)
+        all_s.append(scores)
+        all_b.append(dec)
+    if use_rbox_scores:
+        assert len(all_s) > 1
+        all_s.pop(0)
+        all_b.pop()
+    scores, dec = np.concatenate(all_s), np.concatenate(all_b)
     out = []
     for j in range(1, scores.shape[1]):
         sb, _ = select_scored(scores, dec, j, score_thresh)
-        out.append(ref_nms(sb, nms_thresh) if use_ref_nms else nms(sb, nms_thresh))
+        kept = ref_nms(sb, nms_thresh) if use_ref_nms else nms(sb, nms_thresh)
+        if bbox_voting:
+            kept = (ref_bbox_vote if use_ref_nms else bbox_vote)(kept, sb, bbox_vote_thresh)
+        out.append(kept)
     return out, (scores, dec)
 
 

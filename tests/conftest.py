@@ -1,3 +1,4 @@
+import contextlib
 import os
 import sys
 
@@ -29,6 +30,33 @@ def dev():
     import multipathnet_amd
     multipathnet_amd.load()
     return torch.device("cuda", 0)
+
+
+HOOK_DEFAULTS = dict(conv_variant=0, conv_split=0, gemm_split=0, fuse_pool=1, nms_force_exact=0, fp32_pf=1, bf16_dma=1, bf16_dma_tn=0,
+                     bf16_fast_pool=3, graph_fuse=3)
+
+
+@contextlib.contextmanager
+def hooks(**settings):
+    """Forced kernel variants / split factors for a test: `with hooks(conv_variant=7, conv_split=2): ...`.
+
+    The PRODUCT library (libmpn_hip.so) has no such switches — its knobs are compile-time constants — so a non-default
+    setting runs the block on libmpn_hip_dbg.so (same sources, -DMPN_DEBUG_HOOKS; multipathnet_amd._lib.debug_hooks) with
+    mpn_debug_set_<name>(value) applied and reset afterwards.  All-default settings leave the block on the product library:
+    the default dispatch is always tested on the library that ships."""
+    from multipathnet_amd import _lib
+    changed = {k: v for k, v in settings.items() if HOOK_DEFAULTS[k] != v}
+    if not changed:
+        yield None
+        return
+    with _lib.debug_hooks() as lib:
+        for k, v in changed.items():
+            getattr(lib, "mpn_debug_set_" + k)(v)
+        try:
+            yield lib
+        finally:
+            for k in changed:
+                getattr(lib, "mpn_debug_set_" + k)(HOOK_DEFAULTS[k])
 
 
 def random_scored_boxes(rng, n, regime="distinct", span=1000.0, lo=16.0, hi=400.0):

@@ -21,8 +21,27 @@ def test_libmpn_exports_every_declared_symbol():
     assert len(names) >= 30
     for n in names:
         assert hasattr(lib, n), "libmpn_hip.so does not export %s" % n
-    assert lib.mpn_version() >= 100
+    assert lib.mpn_version() >= 200
     assert abs(lib.mpn_pick_scale(600, 1000, 600.0, 1000.0) - 1.0) == 0.0
+
+
+def test_product_library_has_no_test_hooks():
+    """timing-experiment code and mpn_debug_* switches must not ship.  The product .so exports none of them
+    (its knobs are compile-time constants); they live in libmpn_hip_dbg.so (-DMPN_DEBUG_HOOKS), which exports the same ABI
+    plus the hooks."""
+    so = os.path.join(ROOT, "multipathnet_amd", "libmpn_hip.so")
+    dbg = os.path.join(ROOT, "multipathnet_amd", "libmpn_hip_dbg.so")
+    sym = subprocess.check_output(["nm", "-D", "--defined-only", so]).decode()
+    assert "mpn_debug" not in sym
+    assert not re.search(r"conv3x3_wino_kernel.*Li[1-9]", sym), "ablation instantiations of the Winograd kernel in the product build"
+    dsym = subprocess.check_output(["nm", "-D", "--defined-only", dbg]).decode()
+    assert "mpn_debug_set_conv_variant" in dsym and "mpn_debug_set_nms_force_exact" in dsym
+    for n in _declared("mpn.h"):
+        assert re.search(r" T %s\b" % n, dsym), n
+    # no process-global device scratch: the only device-pointer statics allowed are inside the registry (common.hip)
+    for f in ("dense.hip", "nms.hip", "resnet.hip", "boxes.hip", "pipeline.hip"):
+        txt = open(os.path.join(ROOT, "multipathnet_amd", "csrc", f)).read()
+        assert not re.search(r"^\s*static\s+(float|char|void)\s*\*\s*\w+\s*=\s*nullptr", txt, flags=re.M), f
 
 
 def test_libnms_dropin_exports():

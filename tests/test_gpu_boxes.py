@@ -116,6 +116,18 @@ def test_select_scored_and_keep_top_k(O, dev):
             assert np.array_equal(src[j - 1, :n].cpu().numpy(), idx)
     per = [np.concatenate([rng.random((k, 4)), np.round(rng.random((k, 1)) * 200) / 200], 1).astype(np.float32)
            for k in (300, 0, 90, 5, 1000, 17)]
+    # overflow is reported, not hidden: *n_out is the untruncated survivor count, rows beyond max_out are not written
+    flat = [torch.cat([_t(p, dev), torch.zeros((1000 - p.shape[0], 5), device=dev)]) if p.size else torch.zeros((1000, 5), device=dev) for p in per]
+    d_keep = torch.stack(flat).contiguous()
+    d_n = torch.tensor([p.shape[0] for p in per], dtype=torch.int32, device=dev)
+    out = torch.full((8, 6), -1.0, device=dev)
+    thr = torch.zeros(1, device=dev)
+    n_out = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().mpn_keep_top_k(nn._f(d_keep), nn._i(d_n), len(per), 1000, 100, nn._f(thr), nn._f(out), 5, nn._i(n_out), None))
+    torch.cuda.synchronize()
+    ref100, t100 = O.keep_top_k(per, 100)
+    assert int(n_out.item()) == sum(r.shape[0] for r in ref100) > 5 and float(thr.item()) == t100
+    assert float(out[5:].max()) == -1.0 and float(out[:5, 5].min()) >= 1.0   # exactly max_out rows written
     for k in (100, 3, 5000):
         ref, t = O.keep_top_k(per, k)
         got, tg = utils.keep_top_k([_t(p, dev) if p.size else torch.zeros((0, 5), device=dev) for p in per], k)

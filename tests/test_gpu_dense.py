@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import hooks
+
 pytestmark = pytest.mark.gpu
 
 
@@ -26,20 +28,13 @@ def _conv(dev, x, w, b, relu=True):
                                            (7, 0), (7, 2), (7, 3)])
 def test_conv3x3_vs_oracle(O, dev, ci, co, h, w, variant, split):
     """variant 0 = the default choice per layer, 1-6 = direct-convolution tilings, 7 = Winograd F(2x2,3x3); split = forced split-K factor (0 = cost model)"""
-    import multipathnet_amd
-    lib = multipathnet_amd.load()
-    lib.mpn_debug_set_conv_split(split)
     rng = np.random.default_rng(ci * 1000 + co)
     x = rng.standard_normal((ci, h, w)).astype(np.float32)
     wt = (rng.standard_normal((co, ci, 3, 3)) * (2.0 / (ci * 9)) ** 0.5).astype(np.float32)
     b = (rng.standard_normal(co) * 0.1).astype(np.float32)
-    lib.mpn_debug_set_conv_variant(variant)
-    try:
+    with hooks(conv_variant=variant, conv_split=split):  # (0, 0) = the product library's own dispatch
         y = _conv(dev, x, wt, b, relu=True)
         y2 = _conv(dev, x, wt, None, relu=False)
-    finally:
-        lib.mpn_debug_set_conv_variant(0)
-        lib.mpn_debug_set_conv_split(0)
     ref = O.conv3x3(x, wt, b, relu=True)
     assert y.shape == ref.shape
     assert np.abs(y - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
@@ -51,16 +46,11 @@ def test_conv_transpose_detecting(O, dev):
     x = np.zeros((8, 12, 40), np.float32)
     x[3, 5, 17] = 1.0
     wt = np.arange(16 * 8 * 9, dtype=np.float32).reshape(16, 8, 3, 3) / 100.0
-    import multipathnet_amd
-    lib = multipathnet_amd.load()
     ref = O.conv3x3(x, wt, None, relu=False)
     y = _conv(dev, x, wt, None, relu=False)  # default: Winograd (fp32 transforms -> not bit-exact; adjacent weights differ by 1e-2)
     assert np.abs(y - ref).max() < 1e-4
-    lib.mpn_debug_set_conv_variant(1)  # direct kernel: one product per output -> exact
-    try:
+    with hooks(conv_variant=1):  # direct kernel: one product per output -> exact
         assert np.array_equal(_conv(dev, x, wt, None, relu=False), ref)
-    finally:
-        lib.mpn_debug_set_conv_variant(0)
 
 
 def test_maxpool_ceil_exact(O, dev):
@@ -141,23 +131,16 @@ def test_linear_repeatable(O, dev, M, K, N):
 def test_conv_splitk_deterministic(O, dev, ci, co, h, w, variant):
     """split-K over the input-channel chunks (fp32 slabs summed in a fixed order): bit-identical run after run, equal to the unsplit
     kernel within fp32 reassociation, and within the north_star tolerance of the oracle; direct (1) and Winograd (7) kernels"""
-    import multipathnet_amd
-    lib = multipathnet_amd.load()
     rng = np.random.default_rng(ci + co)
     x = rng.standard_normal((ci, h, w)).astype(np.float32)
     wt = (rng.standard_normal((co, ci, 3, 3)) * (2.0 / (ci * 9)) ** 0.5).astype(np.float32)
     b = rng.standard_normal(co).astype(np.float32)
-    lib.mpn_debug_set_conv_variant(variant)
-    lib.mpn_debug_set_conv_split(3)
-    try:
+    with hooks(conv_variant=variant, conv_split=3):
         a = _conv(dev, x, wt, b)
         for _ in range(3):
             assert np.array_equal(_conv(dev, x, wt, b), a)
-        lib.mpn_debug_set_conv_split(1)
+    with hooks(conv_variant=variant, conv_split=1):
         c = _conv(dev, x, wt, b)
-    finally:
-        lib.mpn_debug_set_conv_split(0)
-        lib.mpn_debug_set_conv_variant(0)
     ref = O.conv3x3(x, wt, b, relu=True)
     assert np.abs(a - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
     assert np.abs(a - c).max() < 1e-4 * max(1.0, np.abs(ref).max())

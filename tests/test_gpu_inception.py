@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import hooks
+
 pytestmark = pytest.mark.gpu
 
 
@@ -59,22 +61,16 @@ def test_inception_bf16_lds_dma_kernel_forced(O, dev, tn):
     """the LDS-DMA convolution kernel forced onto every eligible layer of a quarter-width Inception-v3 (by default only layers
     with >= 32768 output pixels use it): 1x7 / 7x1 / 1x3 / 3x1 taps, stride-2 reductions, DepthConcat slices as outputs, cout
     counts that are not multiples of the tile; tn = forced tile shape (0 = per layer, 1256 = 128 couts x 256 pixels, 256 = 256 x 256)"""
-    import multipathnet_amd
     from multipathnet_amd import models
-    lib = multipathnet_amd.load()
     H, W, N, C = 170, 215, 24, 5
     G = models.synthetic_inception_v3_params(n_classes=C, width=0.25, seed=29)
     Gn = dict(models.graph_params_numpy(G), bf16=True)
     im, boxes = _inputs(H, W, N, 18)
-    lib.mpn_debug_set_bf16_dma(2)
-    lib.mpn_debug_set_bf16_dma_tn(tn)
-    try:
+    with hooks(bf16_dma=2, bf16_dma_tn=tn):
         net = models.InceptionFRCNN(G, max_h=H, max_w=W, max_rois=32, top_k=10, bf16=True)
         s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
         s = s.cpu().numpy()
-    finally:
-        lib.mpn_debug_set_bf16_dma(1)
-        lib.mpn_debug_set_bf16_dma_tn(0)
+        b = b.cpu()
     so, bo, _, _ = O.graph_detect(im, boxes, Gn, O.INCEPTION, target=min(H, W), max_size=max(H, W))
     assert np.abs(s - so).max() < 3e-3
     assert np.abs(b.cpu().numpy() - O.clamp_boxes(bo, W, H)).max() < 0.5
@@ -86,21 +82,17 @@ def test_inception_sibling_fusion_equivalent(dev, bf16):
     by channel planes (bit 0), and commutes average-pool -> pointwise convolution (bit 1: the pool then runs on the convolution's
     output channels; exact in real arithmetic, another summation / rounding order in floating point); the same network built
     with the rewrites off (mpn_debug_set_graph_fuse(0)) gives the same scores to rounding"""
-    import multipathnet_amd
     from multipathnet_amd import models
-    lib = multipathnet_amd.load()
     H, W, N, C = 170, 215, 24, 5
     G = models.synthetic_inception_v3_params(n_classes=C, width=0.25, seed=31)
     im, boxes = _inputs(H, W, N, 21)
     out = []
     for fuse in (3, 0, 1):
-        lib.mpn_debug_set_graph_fuse(fuse)
-        try:
+        with hooks(graph_fuse=fuse):  # 3 = the product library
             net = models.InceptionFRCNN(G, max_h=H, max_w=W, max_rois=32, top_k=10, bf16=bf16)
-        finally:
-            lib.mpn_debug_set_graph_fuse(3)
-        s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
-        out.append((s.cpu().numpy().copy(), b.cpu().numpy().copy()))
+            s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+            out.append((s.cpu().numpy().copy(), b.cpu().numpy().copy()))
+            del net
     assert np.abs(out[2][0] - out[1][0]).max() < (1e-3 if bf16 else 1e-6)   # sibling fusion alone: the same dot products
     assert np.abs(out[2][1] - out[1][1]).max() < (0.25 if bf16 else 1e-3)
     assert np.abs(out[0][0] - out[1][0]).max() < (2e-3 if bf16 else 2e-5)   # + the commuted pools

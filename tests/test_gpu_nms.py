@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import random_scored_boxes
+from conftest import hooks, random_scored_boxes
 
 pytestmark = pytest.mark.gpu
 
@@ -20,11 +20,8 @@ def _t(a, dev):
 def nms_path(request):
     """0 = default dispatch (chunked bitmask scan for tie-free classes, slot-emulating tie kernel for classes with
     bit-equal scores, IoU-sweep kernel for NaN / oversize); 1 = IoU-sweep kernel only; 2 = tie kernel wherever it applies"""
-    import multipathnet_amd
-    lib = multipathnet_amd.load()
-    lib.mpn_debug_set_nms_force_exact(request.param)
-    yield request.param
-    lib.mpn_debug_set_nms_force_exact(0)
+    with hooks(nms_force_exact=request.param):  # 0 = the product library's own dispatch
+        yield request.param
 
 
 @pytest.mark.parametrize("regime", ["distinct", "ties", "saturated", "allequal"])
@@ -80,6 +77,30 @@ def test_nms_batched_ragged(O, dev, nms_path):
         ref, ridx = O.nms(sb[c, :counts[c]], 0.3, return_index=True)
         assert nk[c] == ref.shape[0]
         assert np.array_equal(keep[c, :nk[c]], ref) and np.array_equal(idx[c, :nk[c]], ridx)
+
+
+@pytest.mark.parametrize("M", [4500, 5000, 6144])
+def test_nms_batched_ragged_wide_table_with_ties(O, dev, M):
+    """a table wider than the tie kernel's 4096-box limit whose classes hold FEWER than 4096 rows and tied scores
+    (two localisation passes, or a score threshold that drops rows).  The sort kernel's tie / sweep decision must agree with
+    the host's launch decision, or such a class is processed by no kernel and stale rows reach voting and top-k."""
+    from multipathnet_amd import utils
+    rng = np.random.default_rng(M)
+    n_cls = 6
+    counts = np.array([300, 4096, 0, 4097, 2500, M], np.int32)
+    sb = np.stack([random_scored_boxes(rng, M, ["ties", "saturated", "distinct", "ties", "allequal", "ties"][c]) for c in range(n_cls)])
+    d_keep = torch.full((n_cls, M, 5), -7.0, device=dev)  # poison: an unprocessed class would leave these behind
+    from multipathnet_amd import _lib, nn
+    d_idx = torch.full((n_cls, M), -7, dtype=torch.int32, device=dev)
+    d_n = torch.full((n_cls,), -7, dtype=torch.int32, device=dev)
+    d_sb, d_counts = _t(sb, dev), _t(counts, dev)
+    _lib.check(_lib.load().mpn_nms_batched(nn._f(d_sb), nn._i(d_counts), n_cls, M, ctypes.c_float(0.3), nn._f(d_keep), nn._i(d_idx), nn._i(d_n), None))
+    torch.cuda.synchronize()
+    keep, idx, nk = d_keep.cpu().numpy(), d_idx.cpu().numpy(), d_n.cpu().numpy()
+    for c in range(n_cls):
+        ref, ridx = O.nms(sb[c, :counts[c]], 0.3, return_index=True)
+        assert nk[c] == ref.shape[0], c
+        assert np.array_equal(keep[c, :nk[c]], ref) and np.array_equal(idx[c, :nk[c]], ridx), c
 
 
 @pytest.mark.parametrize("regime", ["distinct", "ties"])
@@ -138,3 +159,15 @@ def test_libnms_dropin_th_abi(O, dev):
     t_empty = shim.mpn_th_shim_from(sb.ctypes.data_as(f32p), 0, 5)
     dll.NMS(t_keep, t_empty, 0.3)
     assert shim.mpn_th_shim_size(t_keep, 0) == 0
+
+
+@pytest.mark.parametrize("regime", ["distinct", "ties"])
+def test_nms_wider_than_the_lds_paths(O, dev, regime):
+    """nms.c has no size limit; tables wider than MPN_NMS_MAX_BOXES (6144) take the exact sweep kernel on HBM-resident arrays"""
+    from multipathnet_amd import utils
+    rng = np.random.default_rng(11)
+    sb = random_scored_boxes(rng, 7000, regime, span=3000.0)
+    ref, ridx = O.nms(sb, 0.3, return_index=True)
+    keep, idx = utils.nms_with_index(_t(sb, dev), 0.3)
+    assert np.array_equal(keep.cpu().numpy(), ref)
+    assert np.array_equal(idx.cpu().numpy(), ridx)

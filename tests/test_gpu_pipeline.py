@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import hooks
+
 pytestmark = pytest.mark.gpu
 
 
@@ -44,22 +46,18 @@ def small(O, dev):
     rois = O.project_im_rois(boxes, 1.0)
     pooled, _ = O.roi_pool(feat, rois, 7, 7, s["scale"])
     logits, deltas = O.frcnn_head(feat, rois, Pn, pooled=7, spatial_scale=s["scale"], chunk=500)
-    return dict(net=net, im=im, boxes=boxes, P=Pn, feat=feat, pooled=pooled, logits=logits, deltas=deltas)
+    return dict(net=net, im=im, boxes=boxes, P=Pn, P_torch=P, feat=feat, pooled=pooled, logits=logits, deltas=deltas)
 
 
 @pytest.mark.parametrize("fuse_pool,split", [(1, 0), (0, 0), (1, 2), (0, 3)])
 def test_pipeline_stages_vs_oracle(O, dev, small, fuse_pool, split):
-    import multipathnet_amd
-    lib = multipathnet_amd.load()
-    s, net = SMALL, small["net"]
-    lib.mpn_debug_set_fuse_pool(fuse_pool)
-    lib.mpn_debug_set_conv_split(split)
-    try:
+    from multipathnet_amd import models
+    s = SMALL
+    with hooks(fuse_pool=fuse_pool, conv_split=split):  # (1, 0) = the product library; the others build their handle on the debug flavour
+        net = small["net"] if (fuse_pool, split) == (1, 0) else models.FastRCNN(
+            small["P_torch"], cfg=s["cfg"], pooled=7, spatial_scale=s["scale"], max_h=s["H"], max_w=s["W"], max_rois=s["N"])
         scores, bbox = net.detect(torch.from_numpy(small["im"]).to(dev), torch.from_numpy(small["boxes"]).to(dev))
         torch.cuda.synchronize()
-    finally:
-        lib.mpn_debug_set_fuse_pool(1)
-        lib.mpn_debug_set_conv_split(0)
     feat = small["feat"]
     conv5 = net.debug_tensor("conv5", feat.shape).cpu().numpy()
     assert np.abs(conv5 - feat).max() < 1e-4 * max(1.0, np.abs(feat).max())
@@ -325,3 +323,141 @@ def test_image_scale_kernel_vs_oracle(O, dev):
         _lib.check(_lib.load().mpn_image_scale(nn._f(d_in), 3, h, w, h2, w2, nn._f(tmp), nn._f(out), None))
         torch.cuda.synchronize()
         assert np.abs(out.cpu().numpy() - O.image_scale(im, h2, w2)).max() < 1e-6
+
+
+def test_detect_unclamped_is_imagedetect_semantics(O, dev, small):
+    """ImageDetect:detect returns UNCLAMPED decoded boxes (ImageDetect.lua:183-193); the clamp is Tester_FRCNN's (:75-78)."""
+    from multipathnet_amd import detect
+    s, net = SMALL, small["net"]
+    im, boxes = torch.from_numpy(small["im"]).to(dev), torch.from_numpy(small["boxes"]).to(dev)
+    sc_c, bb_c = net.detect(im, boxes)                    # clamp=True: what testOne holds after :75-78
+    sc_u, bb_u = net.detect(im, boxes, clamp=False)
+    assert torch.equal(sc_c, sc_u)
+    ref_u = O.bbox_decode(small["boxes"], small["deltas"])
+    assert np.abs(bb_u.cpu().numpy() - ref_u).max() < 1e-4 * s["W"]
+    assert (np.abs(ref_u - O.clamp_boxes(ref_u, s["W"], s["H"])) > 0).any(), "the case must have boxes that leave the image"
+    assert np.array_equal(O.clamp_boxes(bb_u.cpu().numpy(), s["W"], s["H"]), bb_c.cpu().numpy())
+    d = detect.ImageDetect(net)
+    _, bb_m = d.detect(im, boxes)
+    assert torch.equal(bb_m, bb_u)
+    with pytest.raises(ValueError):
+        detect.ImageDetect(net, scale=[600], max_size=1000)   # the model's pipeline was built without getImages' rescaling
+
+
+@pytest.mark.parametrize("num_iter,rbox,voting", [(2, False, False), (2, True, False), (3, False, True), (3, True, False)])
+def test_iterative_localisation_vs_oracle(O, dev, small, num_iter, rbox, voting):
+    """Tester_FRCNN.lua:72-100 against the ORACLE's restatement of the whole loop (first pass clamped, refinement passes not,
+    SelectBoxes between passes, test_use_rbox_scores pairing): the device's joined score / box tables match it to the
+    north_star tolerance, and the per-class NMS (+ voting) of the device's own rows is bit-exact — for the fused device path
+    and for the host mirror."""
+    from multipathnet_amd import models, detect
+    s = SMALL
+    net = models.FastRCNN(small["P_torch"], cfg=s["cfg"], pooled=7, spatial_scale=s["scale"], max_h=s["H"], max_w=s["W"], max_rois=s["N"],
+                          num_iter=num_iter, use_rbox_scores=rbox, bbox_voting=voting, bbox_vote_thresh=0.5)
+    im, boxes = torch.from_numpy(small["im"]).to(dev), torch.from_numpy(small["boxes"]).to(dev)
+    dets, n = net.test_one_async(im, boxes)
+    torch.cuda.synchronize()
+    keep, idx, nk = [t.cpu().numpy() for t in net.nms_results()]
+    rows = (num_iter - 1 if rbox else num_iter) * s["N"]
+    assert keep.shape[1] == rows
+    tester = detect.Tester_FRCNN(small["net"], opt={"test_num_iterative_loc": num_iter, "test_use_rbox_scores": rbox, "test_bbox_voting": voting,
+                                                    "test_bbox_voting_nms_threshold": 0.5})
+    img_boxes, (output, bbox_pred) = tester.testOne(im, boxes)
+    assert output.shape[0] == rows and bbox_pred.shape[0] == rows
+    for j, kb in enumerate(img_boxes):
+        assert np.array_equal(keep[j, : nk[j]], kb.cpu().numpy(), equal_nan=True), j
+    # the oracle's whole loop on the same inputs (its own fp32 summation order => tolerance on the tables)
+    _, (osc, obb) = O.test_one(small["im"], small["boxes"], small["P"], num_iter=num_iter, use_rbox_scores=rbox, cfg=s["cfg"],
+                               target=s["H"], max_size=s["W"])
+    sc, bb = output.cpu().numpy(), bbox_pred.cpu().numpy()
+    assert np.abs(sc - osc).max() < 1e-4
+    assert np.abs(bb - obb).max() < 2e-3 * s["W"]   # refinement passes decode from boxes that already carry the first pass's rounding
+    n_first = s["N"]
+    if not rbox:  # first-pass boxes are clamped, later passes are not
+        assert bb[:n_first].min() >= 1.0 and bb[:n_first, 0::2].max() <= s["W"] and bb[:n_first, 1::2].max() <= s["H"]
+        assert (bb[n_first:] < 1.0).any() or (bb[n_first:, 0::2] > s["W"]).any() or (bb[n_first:, 1::2] > s["H"]).any()
+    # NMS / voting of the device's rows: bit-exact against the oracle (== compiled nms.c, tests/test_oracle_nms.py)
+    per = []
+    for j in range(1, s["C"]):
+        sb, _ = O.select_scored(sc, bb, j, -1.5)
+        ref = O.nms(sb, 0.3)
+        if voting:
+            ref = O.bbox_vote(ref, sb, 0.5)
+        assert np.array_equal(keep[j - 1, : nk[j - 1]], ref, equal_nan=True)
+        per.append(ref)
+    kept, _ = O.keep_top_k(per, 100)
+    exp = np.concatenate([np.concatenate([k, np.full((k.shape[0], 1), j + 1, np.float32)], 1) for j, k in enumerate(kept) if k.size])
+    assert np.array_equal(dets[: int(n.item())].cpu().numpy(), exp, equal_nan=True)
+
+
+def test_host_fed_pipeline_equals_device_fed(dev, small):
+    """mpn_frcnn_test_one_pipelined_host (upload on the handle's copy stream into two staging sets) == the device-fed form,
+    image after image, including a size change in the middle of the stream."""
+    net = small["net"]
+    rng = np.random.default_rng(7)
+    s = SMALL
+    ims = [rng.random((3, s["H"], s["W"]), dtype=np.float32) for _ in range(5)] + [rng.random((3, 120, 200), dtype=np.float32)]
+    bxs = [_boxes(rng, s["N"], im.shape[2], im.shape[1]) for im in ims]
+    ref = []
+    for im, b in zip(ims, bxs):
+        d, n = net.test_one_async(torch.from_numpy(im).to(dev), torch.from_numpy(b).to(dev))
+        torch.cuda.synchronize()
+        ref.append(d[: int(n.item())].clone())
+    pin = [(torch.from_numpy(im).pin_memory(), torch.from_numpy(b).pin_memory()) for im, b in zip(ims, bxs)]
+    outs = [net.test_one_pipelined_host(i, b) for i, b in pin[:1]]
+    got = []
+    for i, b in pin[1:]:
+        cur = net.test_one_pipelined_host(i, b)
+        prev = outs[-1]
+        got.append(prev[0][: int(prev[1].item())].clone())   # valid one call later (the .item() syncs the launch stream)
+        outs.append(cur)
+    net.flush()
+    torch.cuda.synchronize()
+    got.append(outs[-1][0][: int(outs[-1][1].item())].clone())
+    assert len(got) == len(ref)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+
+
+def test_two_handles_two_threads_two_streams(dev, small):
+    """SURVEY §8b 'Threading' / test_runner.lua:55-66: the reference drives one worker thread per GPU inside ONE process.
+    No library state is process-global: two pipeline handles (different networks, so different split-K / NMS scratch sizes)
+    driven concurrently from two host threads on two streams give exactly their serial results, repeatedly."""
+    import threading
+    from multipathnet_amd import models
+    s = SMALL
+    cfg_b = [8, 8, "P", 16, "P", 24, 24]
+    Pb = models.synthetic_params(cfg_b, pooled=7, fc_dim=64, n_classes=11, seed=99)
+    net_a = small["net"]
+    net_b = models.FastRCNN(Pb, cfg=cfg_b, pooled=7, spatial_scale=0.25, max_h=100, max_w=180, max_rois=300)
+    rng = np.random.default_rng(3)
+    im_a, bx_a = torch.from_numpy(small["im"]).to(dev), torch.from_numpy(small["boxes"]).to(dev)
+    im_b = torch.from_numpy(rng.random((3, 100, 180), dtype=np.float32)).to(dev)
+    bx_b = torch.from_numpy(_boxes(rng, 300, 180, 100)).to(dev)
+
+    def run(net, im, bx):
+        d, n = net.test_one_async(im, bx)
+        torch.cuda.current_stream().synchronize()
+        return d[: int(n.item())].clone(), [t.clone() for t in net.detect(im, bx)]
+
+    ref_a, ref_b = run(net_a, im_a, bx_a), run(net_b, im_b, bx_b)
+    errs = []
+
+    def worker(net, im, bx, ref):
+        try:
+            torch.cuda.set_device(dev)
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                for _ in range(12):
+                    d, (sc, bb) = run(net, im, bx)
+                    if not (torch.equal(d, ref[0]) and torch.equal(sc, ref[1][0]) and torch.equal(bb, ref[1][1])):
+                        errs.append("mismatch")
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(net_a, im_a, bx_a, ref_a)), threading.Thread(target=worker, args=(net_b, im_b, bx_b, ref_b))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not errs, errs[:3]

@@ -1,8 +1,14 @@
-"""RCCL smoke on one GPU: the exact collective bench.py issues for N>1 (all_gather_into_tensor of the scored-box record on
-the device, stream-ordered) with backend "nccl" (== RCCL on ROCm) and world_size 1.  The real N>1 runs are the driver's;
-the multi-rank logic is covered on CPU by tests/test_dist_gloo.py."""
+"""The scored-box gather of the C ABI (mpn_comm_*, mpn_gather_dets: pack kernel + ncclAllGather bound from librccl at run
+time) — what replaces test_runner.lua:91-104's result hand-back.
+
+  * one GPU: a real one-rank RCCL communicator (the collective code path, stream-ordered) and the RCCL-free world-1 form;
+  * two GPUs (skipped on a one-GPU box): two PROCESSES with a file-exchanged unique id (mpn_comm_init_rank), and the
+    reference's own process model — two worker THREADS in one process (mpn_comm_init_all, test_runner.lua:55-66).
+The sharding / merge logic around it is covered on CPU by tests/test_dist_gloo.py."""
+import ctypes as C
 import os
-import socket
+import tempfile
+import threading
 
 import pytest
 import torch
@@ -10,25 +16,126 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.timeout(180)
-def test_rccl_all_gather_record_world1(dev):
-    import torch.distributed as dist
+def _dets(dev, top_cap, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    d = torch.rand((top_cap, 6), generator=g).to(dev)
+    return d, torch.tensor([n], dtype=torch.int32, device=dev)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("use_rccl", [False, True])
+def test_gather_dets_world1(dev, use_rccl):
     from multipathnet_amd import parallel
-    if dist.is_initialized():
-        pytest.skip("a process group already exists")
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    comm = parallel.Comm.single(use_rccl=use_rccl)
     try:
         top_cap = 464
-        dets = torch.rand((top_cap, 6), device=dev)
-        n = torch.tensor([100], dtype=torch.int32, device=dev)
-        rec = parallel.pack_record(dets, n, top_cap)
-        out = torch.empty((1, rec.numel()), device=dev)
-        dist.all_gather_into_tensor(out.view(-1), rec)   # what gather_detections does for world > 1
-        torch.cuda.synchronize()
-        assert torch.equal(out[0], rec)
-        assert torch.equal(parallel.unpack_record(out[0], top_cap), dets[:100])
-        dist.barrier()
+        for n in (100, 0, 464, 9999):  # 9999: a count beyond the capacity is clipped in the record
+            dets, nd = _dets(dev, top_cap, n, n)
+            out = comm.gather_dets(dets, nd)
+            torch.cuda.synchronize()
+            assert out.shape == (1, top_cap * 6 + 1)
+            k = min(n, top_cap)
+            assert int(out[0, -1].item()) == k
+            rows = out[0, : top_cap * 6].view(top_cap, 6)
+            assert torch.equal(rows[:k], dets[:k]) and (k == top_cap or float(rows[k:].abs().max()) == 0.0)
+            assert torch.equal(parallel.unpack_record(out[0], top_cap), dets[:k])
+            assert torch.equal(out[0], parallel.pack_record(dets, torch.tensor([k]), top_cap))  # same record as the host-side packer
     finally:
-        dist.destroy_process_group()
+        comm.close()
+
+
+def _proc_worker(rank, world, id_path, top_cap, q):
+    import time
+    import multipathnet_amd
+    from multipathnet_amd import _lib
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    lib = multipathnet_amd.load()
+    idbuf = (C.c_char * 128)()
+    if rank == 0:
+        _lib.check(lib.mpn_comm_get_unique_id(idbuf), "unique id")
+        with open(id_path + ".tmp", "wb") as f:
+            f.write(bytes(idbuf))
+        os.replace(id_path + ".tmp", id_path)  # out-of-band hand-over, as a Lua host would do it
+    else:
+        t0 = time.time()
+        while not os.path.exists(id_path):
+            if time.time() - t0 > 120:
+                raise RuntimeError("no unique id")
+            time.sleep(0.05)
+        idbuf = (C.c_char * 128).from_buffer_copy(open(id_path, "rb").read())
+    h = C.c_void_p()
+    _lib.check(lib.mpn_comm_init_rank(idbuf, world, rank, C.byref(h)), "init_rank")
+    rec = int(lib.mpn_det_record_floats(top_cap))
+    ok = True
+    for step in range(3):
+        dets, nd = _dets(dev, top_cap, 10 * rank + step + 1, 100 * step + rank)
+        out = torch.empty((world, rec), device=dev)
+        _lib.check(lib.mpn_gather_dets(h, C.cast(dets.data_ptr(), _lib.f32p), C.cast(nd.data_ptr(), _lib.i32p), top_cap,
+                                       C.cast(out.data_ptr(), _lib.f32p), None), "gather")
+        torch.cuda.synchronize()
+        for r in range(world):
+            er, _ = _dets(dev, top_cap, 0, 100 * step + r)
+            k = 10 * r + step + 1
+            ok = ok and int(out[r, -1].item()) == k and torch.equal(out[r, : k * 6].view(k, 6), er[:k])
+    lib.mpn_comm_destroy(h)
+    q.put((rank, ok))
+
+
+@pytest.mark.timeout(600)
+def test_gather_dets_two_processes(dev):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with tempfile.TemporaryDirectory() as d:
+        id_path = os.path.join(d, "rccl_id")
+        procs = [ctx.Process(target=_proc_worker, args=(r, 2, id_path, 64, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=300) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()  # the exact child we started
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+@pytest.mark.timeout(600)
+def test_gather_dets_two_threads_one_process(dev):
+    """test_runner.lua:55-66: Threads(nGPU), cutorch.setDevice(i) per thread, ONE process."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    import multipathnet_amd
+    from multipathnet_amd import _lib
+    lib = multipathnet_amd.load()
+    world, top_cap = 2, 64
+    comms = (C.c_void_p * world)()
+    devs = (C.c_int * world)(0, 1)
+    _lib.check(lib.mpn_comm_init_all(world, devs, comms), "init_all")
+    rec = int(lib.mpn_det_record_floats(top_cap))
+    results = [None] * world
+
+    def worker(r):
+        torch.cuda.set_device(r)
+        d = torch.device("cuda", r)
+        dets, nd = _dets(d, top_cap, 5 + r, r)
+        out = torch.empty((world, rec), device=d)
+        rc = lib.mpn_gather_dets(C.c_void_p(comms[r]), C.cast(dets.data_ptr(), _lib.f32p), C.cast(nd.data_ptr(), _lib.i32p), top_cap,
+                                 C.cast(out.data_ptr(), _lib.f32p), None)
+        torch.cuda.synchronize(d)
+        ok = rc == 0
+        for q in range(world):
+            eq, _ = _dets(d, top_cap, 0, q)
+            ok = ok and int(out[q, -1].item()) == 5 + q and torch.equal(out[q, : (5 + q) * 6].view(5 + q, 6), eq[: 5 + q])
+        results[r] = ok
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    for r in range(world):
+        lib.mpn_comm_destroy(C.c_void_p(comms[r]))
+    assert results == [True, True]

@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import hooks
+
 pytestmark = pytest.mark.gpu
 
 
@@ -23,13 +25,8 @@ def _inputs(H, W, N, seed):
                                                    ("bottleneck", [1, 1, 1, 2], 16, 14, 150)])  # the last one is large enough for the 1x1 convolutions to take the GEMM path
 @pytest.mark.parametrize("pf", [1, 0])  # 1 = LDS-DMA hand-pipelined convolution kernel for 32-channel-stage layers (default), 0 = the register-staged kernel
 def test_resnet_frcnn_vs_oracle(O, dev, bt, blocks, width, pooled, N, pf):
-    import multipathnet_amd
-    lib = multipathnet_amd.load()
-    lib.mpn_debug_set_fp32_pf(pf)
-    try:
+    with hooks(fp32_pf=pf):
         _fp32_case(O, dev, bt, blocks, width, pooled, N)
-    finally:
-        lib.mpn_debug_set_fp32_pf(1)
 
 
 def _fp32_case(O, dev, bt, blocks, width, pooled, N):
@@ -124,16 +121,8 @@ def test_resnet_bf16_vs_bf16_oracle_and_fp32(O, dev, bt, blocks, width, dma, tn)
     the fp32 oracle they agree to bf16 precision.  width 64 exercises the 32-channel-per-stage kernel variant (widths 16: 16-channel);
     dma=2 forces the 256-cout LDS-DMA kernel onto every eligible layer (by default only layers with >= 32768 output pixels), tn its
     tile shape (0 = picked per layer, 128 / 256 = 256 couts x that many pixels, 1256 = 128 couts x 256 pixels)."""
-    from multipathnet_amd import models
-    import multipathnet_amd
-    lib = multipathnet_amd.load()
-    lib.mpn_debug_set_bf16_dma(dma)
-    lib.mpn_debug_set_bf16_dma_tn(tn)
-    try:
+    with hooks(bf16_dma=dma, bf16_dma_tn=tn):
         _bf16_case(O, dev, bt, blocks, width)
-    finally:
-        lib.mpn_debug_set_bf16_dma(1)
-        lib.mpn_debug_set_bf16_dma_tn(0)
 
 
 def _bf16_case(O, dev, bt, blocks, width):
@@ -157,22 +146,18 @@ def _bf16_case(O, dev, bt, blocks, width):
 def test_resnet_fast_pooling_is_bit_identical(dev, bf16):
     """the row-per-thread ROI max-pooling (bf16: on the int16-sortable re-coding of the map) and the LDS average pooling of the
     bf16 graph reproduce the plain kernels' bits (max commutes with the monotone re-coding; the average sums in the same order)"""
-    import multipathnet_amd
     from multipathnet_amd import models
-    lib = multipathnet_amd.load()
     H, W, N, C = 97, 131, 37, 6
     R = models.synthetic_resnet_params(depth=0, n_classes=C, base_width=16, blocks=[1, 1, 1, 1], block_type="bottleneck", seed=5)
     im, boxes = _inputs(H, W, N, 9)
     boxes[0, :] = [120.0, 90.0, 121.0, 91.0]      # a tiny ROI: bins narrower than a feature cell
     boxes[1, :] = [-40.0, -30.0, 10.0, 12.0]      # partly outside the image: empty bins -> 0
-    net = models.ResNetFRCNN(R, max_h=H, max_w=W, max_rois=64, top_k=20, bf16=bf16)
     out = []
-    for fast in (0, 1, 2, 3):  # bit 0: ROI pooling, bit 1: average pooling
-        lib.mpn_debug_set_bf16_fast_pool(fast)
-        try:
+    for fast in (0, 1, 2, 3):  # bit 0: ROI pooling, bit 1: average pooling; 3 = the product library
+        with hooks(bf16_fast_pool=fast):
+            net = models.ResNetFRCNN(R, max_h=H, max_w=W, max_rois=64, top_k=20, bf16=bf16)
             s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
             out.append((s.cpu().numpy().copy(), b.cpu().numpy().copy()))
-        finally:
-            lib.mpn_debug_set_bf16_fast_pool(3)
+            del net
     for k in (1, 2, 3):
         assert np.array_equal(out[0][0], out[k][0]) and np.array_equal(out[0][1], out[k][1]), k

@@ -61,8 +61,8 @@ def test_roi_pool_range_max_tables_equal_direct(dev, C, H, W, N, scale):
     """the MultiPathNet head's ROI pool reads vertical range-max tables (2 x bin-width reads per bin): its output must be
     identical to the direct kernel's — signed features, regions up to 4x the image (Foveal), degenerate and outside boxes"""
     import ctypes
-    import multipathnet_amd
-    lib = multipathnet_amd.load()
+    from multipathnet_amd import _lib
+    lib = _lib.load("debug")  # the comparison helper is a test hook: libmpn_hip_dbg.so only (same kernels as the product library)
     rng = np.random.default_rng(C * 100 + H)
     feat = rng.standard_normal((C, H, W)).astype(np.float32)
     img_w, img_h = W / scale, H / scale
