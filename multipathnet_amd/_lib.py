@@ -89,6 +89,10 @@ def load(flavour=None):
         raise MpnError(
             "%s not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). multipathnet_amd has no CPU fallback." % (os.path.basename(path), path))
+    # One HIP runtime per process: PyTorch ships its own libamdhip64 (SONAME libamdhip64.so.7).  Loaded first, it is the one
+    # this library's DT_NEEDED resolves to; loaded second, the process would hold two runtimes with separate device state
+    # (torch's tensors would be foreign pointers here).  A non-Python host has a single system runtime and no such issue.
+    import torch  # noqa: F401
     lib = C.CDLL(path, mode=C.RTLD_LOCAL)
     lib.mpn_last_error.restype = C.c_char_p
     lib.mpn_pick_scale.restype = C.c_double

@@ -66,6 +66,11 @@ int image_transform_c8p(const float *d_in, int H, int W, const int *swap, double
 // d_wino (optional): Winograd-transformed weights; used when the variant selector picks the Winograd kernel.
 int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int relu, Act out, Act pooled, hipStream_t s,
                 const float *d_wino = nullptr);
+// first layer (<= 4 input channels): K = 9 taps x 4 channels formulation, weights [36][CoutP] (pack_conv_weights_first);
+// bias from the direct packing's d_bpk; no fused pool / split-K (the layer is bound by its output stores)
+size_t conv_first_elems(int Cout);
+int pack_conv_weights_first(const float *d_w, int Cin, int Cout, float *d_w36, hipStream_t s);
+int conv3x3_first_c8p(Act in, const float *d_w36, const float *d_bpk, int Cout, int relu, Act out, hipStream_t s);
 int conv3x3_variant_for(int Cout, bool has_wino = false);  // 7 = Winograd, 1 = direct 128 couts x 4 rows x 32 cols tile, 2 = direct 64 x 8 x 32
 int maxpool2x2_c8p(Act in, Act out, hipStream_t s);
 // y = relu?(x W^T + b).  x: C8 matrix [K8/8][Mp][8]; y: C8 matrix [NP/8][Mp][8] (y_c8) and/or

@@ -65,6 +65,11 @@ struct ConvArgs {
   // geometry; conv_splitk_reduce_kernel adds them in split order and applies bias/ReLU/pool.
   int splits, chunks_per_split;
   float *part; size_t part_slab;
+  // Winograd kernel, tail split: blocks [0, tail_first) run their whole K range and finish their tiles themselves; every
+  // tile from tail_first on (the launch's last, partly filled round of CUs) is cut into tail_splits K ranges of tail_cps
+  // chunks that write partial slabs — the tail round then takes ~1/tail_splits of a full block's time.  0 = off.
+  int tail_first, tail_splits, tail_cps;
+  int wino_tc;  // Winograd block geometry: 8 = 8 x 8 tiles (16 x 16 px), 16 = 4 x 16 tiles (8 x 32 px)
   int ablate;  // timing experiments only (results wrong): 1 = no DMA in loop, 2 = no barrier, 4 = no ds_reads
   unsigned long long *trace;  // tools/wino_trace.py: per-chunk s_memtime stamps of wave 0 of blocks 0..3 (Winograd kernel, ABL 64)
 };
@@ -268,6 +273,118 @@ __global__ __launch_bounds__(256) void conv3x3_c8p_kernel(ConvArgs a) {
   }
 }
 
+// =================================================================================================
+// First layer (<= 4 input channels; VGG conv1_1: 3 -> 64 on the full-resolution image).
+// The generic kernel spends 9 taps x 8-channel chunks = 72 K-steps on a layer whose real K is 27, and the layer is
+// HBM-bound on its output (154 MB at 600 x 1000): here K = 9 taps x 4 channels = 36 (18 MFMA k-pairs, the 4th channel is
+// the C8P record's zero pad), weights live in registers for the whole block, the (TH+2) x 34 x 4-channel input tile is
+// staged once into LDS as channel planes (conflict-free ds_read_b32: lanes = consecutive pixels), and ~16 KB of LDS lets
+// several blocks share a CU so that one block's store burst overlaps another's MFMAs.
+// Packed weights: w36[(tap*2 + p)*2 + half][CoutP] = w[cout][cin = 2p + half][tap]  (cin >= Cin -> 0).
+// =================================================================================================
+constexpr int kF_TH = 8;                       // rows per block tile (4 waves x 2 rows), 32 columns
+constexpr int kF_PL = (kF_TH + 2) * 34 + 12;   // floats per channel plane of the LDS tile (352: 16-byte multiple)
+__global__ __launch_bounds__(256) void conv3x3_first_kernel(const float *__restrict__ in, int in_Wp, const float *__restrict__ w36,
+                                                            int CoutP, const float *__restrict__ bpk, float *__restrict__ out,
+                                                            size_t out_plane, int out_Wp, int H, int W, int out_cb, int relu,
+                                                            int n_ct, int tiles_x) {
+  __shared__ float tile[4 * kF_PL];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ct = blockIdx.x % n_ct, sp = blockIdx.x / n_ct;
+  const int ty = sp / tiles_x, tx = sp - ty * tiles_x;
+  const int y0 = ty * kF_TH, x0 = tx * 32, cout0 = ct * 64;
+  // weights: this lane's 2 x 18 A-operand values (cout = cout0 + mi*32 + l31, k = 2*ks + half)
+  float af[2][18];
+#pragma unroll
+  for (int ks = 0; ks < 18; ++ks)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) af[mi][ks] = w36[(size_t)(ks * 2 + half) * CoutP + cout0 + mi * 32 + l31];
+  // input tile: channels 0..3 of (TH+2) x 34 pixel records -> 4 planes
+  for (int p = tid; p < (kF_TH + 2) * 34; p += 256) {
+    const int r = p / 34, c = p - r * 34;
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(in + ((size_t)(y0 + r) * in_Wp + x0 + c) * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[e * kF_PL + p] = v[e];
+  }
+  __syncthreads();
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+  const float *tb = tile + half * kF_PL + (wave * 2) * 34 + l31;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int dy = t / 3, dx = t - dy * 3;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      float bfr[2];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) bfr[ni] = tb[2 * p * kF_PL + (ni + dy) * 34 + dx];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][t * 2 + p], bfr[ni], acc[mi][ni], 0, 0, 0);
+    }
+  }
+  // epilogue: bias + ReLU, 1 KiB-contiguous float4 stores in the next layer's C8P layout
+  const int x = x0 + l31;
+  const bool xok = x < W;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cb = (cout0 + mi * 32) / 8 + g;
+      if (cb >= out_cb) continue;
+      const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bpk + cb * 8 + half * 4);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int y = y0 + wave * 2 + ni;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float tv = acc[mi][ni][g * 4 + e] + b4[e];
+          if (relu) tv = tv < 0.0f ? 0.0f : tv;
+          v[e] = tv;
+        }
+        if (xok && y < H) *reinterpret_cast<f32x4 *>(out + (size_t)cb * out_plane + ((size_t)(y + 1) * out_Wp + x + 1) * 8 + half * 4) = v;
+      }
+    }
+}
+
+__global__ void pack_conv_w_first_kernel(const float *__restrict__ w, int Cin, int Cout, int CoutP, float *__restrict__ w36) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 36 * CoutP) return;
+  const int row = t / CoutP, co = t - row * CoutP;   // row = (tap*2 + p)*2 + half
+  const int hf = row & 1, ks = row >> 1, p = ks & 1, tap = ks >> 1;
+  const int cin = 2 * p + hf;
+  w36[t] = (co < Cout && cin < Cin) ? w[((size_t)co * Cin + cin) * 9 + tap] : 0.0f;
+}
+
+size_t conv_first_elems(int Cout) { return (size_t)36 * conv_coutp(Cout); }
+
+int pack_conv_weights_first(const float *d_w, int Cin, int Cout, float *d_w36, hipStream_t s) {
+  MPN_CHECK_ARG(d_w && d_w36 && Cin > 0 && Cin <= 4 && Cout > 0);
+  const int CoutP = conv_coutp(Cout);
+  hipLaunchKernelGGL(pack_conv_w_first_kernel, dim3(cdiv(36 * CoutP, 256)), dim3(256), 0, s, d_w, Cin, Cout, CoutP, d_w36);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+int conv3x3_first_c8p(Act in, const float *d_w36, const float *d_bpk, int Cout, int relu, Act out, hipStream_t s) {
+  MPN_CHECK_ARG(in.p && d_w36 && d_bpk && out.p && in.C <= 4 && out.H == in.H && out.W == in.W && out.C == Cout);
+  const int tiles_x = cdiv(in.W, 32), tiles_y = cdiv(in.H, kF_TH), n_ct = cdiv(Cout, 64);
+  hipLaunchKernelGGL(conv3x3_first_kernel, dim3((unsigned)(n_ct * tiles_y * tiles_x)), dim3(256), 0, s, in.p, in.Wp, d_w36, conv_coutp(Cout), d_bpk,
+                     out.p, out.plane(), out.Wp, in.H, in.W, (Cout + 7) / 8, relu, n_ct, tiles_x);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
 template <int BM, int TH, int WM, int WN, int TPS>
 static int launch_conv(const ConvArgs &a0, int tiles_y, hipStream_t s) {
   ConvArgs a = a0;
@@ -298,15 +415,26 @@ static int launch_conv(const ConvArgs &a0, int tiles_y, hipStream_t s) {
 //     output transform A^T M A, bias, ReLU and the 2x2 max-pool (a Winograd tile IS a pooling window) are
 //     register-local; float4 stores go straight into the next layer's C8P layout.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int WG_RAW_PIECES = 18 * 36;                 // 18 rows x 18 px x two 16-byte pieces
-constexpr int WG_RAW_LOADS = 12;                      // 10.1 wave-loads of data; padded to 3 per wave so the DMA issue is branch-free
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {  // a - b as ONE v_pk_add_f32 (negated second operand)
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// Two block geometries over the same 64 Winograd tiles: TC = 8 -> 8 x 8 tiles = 16 x 16 output px (raw halo tile 18 x 18 px),
+// TC = 16 -> 4 x 16 tiles = 8 rows x 32 columns (raw tile 10 x 34 px).  The host picks per layer whichever pads the map
+// less (VGG conv5 at 38 x 63: 48 x 64 px of tiles vs 40 x 64).  Both need 11 wave-loads for the raw tile.
+constexpr int WG_RAW_LOADS = 12;                      // 10.1 / 10.6 wave-loads of data; padded to 3 per wave so the DMA issue is branch-free
 constexpr int WG_RAW_FLOATS = WG_RAW_LOADS * 256;
 constexpr int WG_V_FLOATS = 16 * 64 * 8;
 constexpr int WG_U_FLOATS = 16 * 64 * 8;
 constexpr size_t WG_LDS_BYTES = (size_t)2 * (WG_RAW_FLOATS + WG_V_FLOATS + WG_U_FLOATS) * sizeof(float);
 
-template <int ABL>  // ABL: compile-time timing-experiment switches (0 in production; see tools/ablate_wino.py)
+template <int ABL, int TC>  // ABL: compile-time timing-experiment switches (0 in production; see tools/ablate_wino.py); TC: tiles per block row
 __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
+  constexpr int TR = 64 / TC;                         // tile rows per block
+  constexpr int RC = 2 * TC + 2, RR = 2 * TR + 2;     // raw halo tile: RR rows x RC px
+  constexpr int WG_RAW_PIECES = RR * RC * 2;          // two 16-byte pieces per pixel record
+  static_assert((WG_RAW_PIECES + 63) / 64 <= WG_RAW_LOADS, "raw tile DMA slots");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *const raw_lds = lds;
   float *const v_lds = lds + 2 * WG_RAW_FLOATS;
@@ -316,9 +444,15 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
   if constexpr ((ABL & 64) != 0) tk0 = __builtin_amdgcn_s_memtime();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  const int ct = blockIdx.x % a.n_ct, sp = blockIdx.x / a.n_ct;
+  int bid = blockIdx.x, split = blockIdx.y, cps = a.chunks_per_split;
+  bool partial = a.splits > 1;
+  if (a.tail_splits > 1 && bid >= a.tail_first) {
+    const int t = bid - a.tail_first;
+    split = t % a.tail_splits; bid = a.tail_first + t / a.tail_splits; cps = a.tail_cps; partial = true;
+  }
+  const int ct = bid % a.n_ct, sp = bid / a.n_ct;
   const int tyb = sp / a.tiles_x, txb = sp - tyb * a.tiles_x;
-  const int y0 = tyb * 16, x0 = txb * 16, cout0 = ct * 64;
+  const int y0 = tyb * (2 * TR), x0 = txb * (2 * TC), cout0 = ct * 64;
   const int mbase = (wave >> 1) * 32, nbase = (wave & 1) * 32;
 
   // DMA sources are (wave-uniform 64-bit base) + (32-bit per-lane byte offset): no 64-bit VALU address arithmetic in
@@ -328,7 +462,7 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
 #pragma unroll
   for (int i = 0; i < RAW_IT; ++i) {
     int p = min((i * 4 + wave) * 64 + lane, WG_RAW_PIECES - 1);  // slots past the tile re-load its last piece (never read)
-    int r = p / 36, o = p - r * 36;
+    int r = p / (RC * 2), o = p - r * (RC * 2);
     raw_rel[i] = (unsigned)(((r * a.in_Wp) * 8 + o * 4) * 4);
   }
   // weight slice item i of this wave: component (i*4+wave)/2 (uniform), 16-byte piece (wave&1)*64 + lane of its 64 couts
@@ -354,7 +488,7 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
   // 64 ds_write_b64 of one component cover 512 contiguous bytes and each half-wave's ds_read_b64 hits 32 distinct
   // bank pairs (a tile-per-lane mapping was 8-way bank-conflicted and made the LDS pipe the bottleneck)
   const int tf_tile = wave * 16 + (lane >> 2), tf_cp = lane & 3;
-  const int tf_rd = ((2 * (tf_tile >> 3)) * 18 + 2 * (tf_tile & 7)) * 8 + 2 * tf_cp;
+  const int tf_rd = ((2 * (tf_tile / TC)) * RC + 2 * (tf_tile % TC)) * 8 + 2 * tf_cp;
   const int tf_wr = tf_tile * 8 + 2 * tf_cp;
   f32x2 d[16], t[16];
   auto tf_load = [&](int buf) {
@@ -362,7 +496,7 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) d[r * 4 + q] = *reinterpret_cast<const f32x2 *>(R + (r * 18 + q) * 8);
+      for (int q = 0; q < 4; ++q) d[r * 4 + q] = *reinterpret_cast<const f32x2 *>(R + (r * RC + q) * 8);
   };
   auto tf_rows = [&]() {  // t = B^T d
 #pragma unroll
@@ -383,7 +517,7 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
 
   // the same work cut into single-shadow items for the loop schedule below
   auto tf_load_item = [&](int buf, int i) {  // two adjacent pixels of one patch row: one ds_read2_b64
-    const float *R = raw_lds + buf * WG_RAW_FLOATS + tf_rd + ((i >> 1) * 18 + (i & 1) * 2) * 8;
+    const float *R = raw_lds + buf * WG_RAW_FLOATS + tf_rd + ((i >> 1) * RC + (i & 1) * 2) * 8;
     d[2 * i] = *reinterpret_cast<const f32x2 *>(R);
     d[2 * i + 1] = *reinterpret_cast<const f32x2 *>(R + 8);
   };
@@ -404,8 +538,8 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
     *reinterpret_cast<f32x2 *>(Vw + 512) = t[2 * i + 1];
   };
 
-  const int c0 = blockIdx.y * a.chunks_per_split;
-  const int c1 = min(a.nchunks, c0 + a.chunks_per_split);
+  const int c0 = split * cps;
+  const int c1 = min(a.nchunks, c0 + cps);
   // prologue: one DMA round trip for both raw tiles and the first weight slices (the accumulator zeroing
   // overlaps it), then the first input transform
   const int n_more = c1 - 1 - c0;  // chunks that prefetch a successor
@@ -530,56 +664,57 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
     }
     return;
   }
+  // VALU time is fully exposed here (nothing left to overlap it with), so the epilogue is written for instruction count:
+  // two accumulator registers per packed op (v_pk_add_f32 / v_pk_max_f32), one wave-uniform 64-bit base per channel block
+  // and 32-bit per-lane byte offsets for the stores (no 64-bit VALU address arithmetic).
   const int tau = nbase + l31;
-  const int y = y0 + 2 * (tau >> 3), x = x0 + 2 * (tau & 7);
-  float *const obase = (a.splits > 1) ? a.part + (size_t)blockIdx.y * a.part_slab : a.out;
+  const int y = y0 + 2 * (tau / TC), x = x0 + 2 * (tau % TC);
+  float *const obase = partial ? a.part + (size_t)split * a.part_slab : a.out;
+  const unsigned off00 = (unsigned)((((y + 1) * a.out_Wp + x + 1) * 8 + half * 4) * 4);  // byte offset of output pixel (y, x) in a plane
+  const unsigned row_b = (unsigned)(a.out_Wp * 32);
+  const bool okx1 = x + 1 < a.W, oky1 = y + 1 < a.H, ok00 = y < a.H && x < a.W;
+  const bool okk[4] = {ok00, ok00 && okx1, ok00 && oky1, ok00 && okx1 && oky1};
+  const unsigned offk[4] = {off00, off00 + 32u, off00 + row_b, off00 + row_b + 32u};
+  const int py = y >> 1, px = x >> 1;
+  const bool okp = a.pool && py < a.pool_H && px < a.pool_W;
+  const unsigned offp = (unsigned)((((py + 1) * a.pool_Wp + px + 1) * 8 + half * 4) * 4);
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    const int cb = (cout0 + mbase) / 8 + g;
+    const int cb = (cout0 + mbase) / 8 + g;  // wave-uniform
     if (cb >= a.out_cb) continue;
-    f32x4 Y[4];
+    f32x2 Y[4][2];  // [output pixel k][element pair]
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int r = g * 4 + e;
-      const float s0 = acc[0][r] + acc[4][r] + acc[8][r], s1 = acc[1][r] + acc[5][r] + acc[9][r];
-      const float s2 = acc[2][r] + acc[6][r] + acc[10][r], s3 = acc[3][r] + acc[7][r] + acc[11][r];
-      const float u0 = acc[4][r] - acc[8][r] - acc[12][r], u1 = acc[5][r] - acc[9][r] - acc[13][r];
-      const float u2 = acc[6][r] - acc[10][r] - acc[14][r], u3 = acc[7][r] - acc[11][r] - acc[15][r];
-      Y[0][e] = s0 + s1 + s2; Y[1][e] = s1 - s2 - s3;
-      Y[2][e] = u0 + u1 + u2; Y[3][e] = u1 - u2 - u3;
+    for (int ep = 0; ep < 2; ++ep) {
+      const int r = g * 4 + ep * 2;
+      f32x2 m[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) m[k] = f32x2{acc[k][r], acc[k][r + 1]};
+      const f32x2 s0 = m[0] + m[4] + m[8], s1 = m[1] + m[5] + m[9], s2 = m[2] + m[6] + m[10], s3 = m[3] + m[7] + m[11];
+      // (the compiler scalarises a packed fsub whose operands come out of accumulator registers: spell it as the instruction)
+      const f32x2 u0 = pk_sub(pk_sub(m[4], m[8]), m[12]), u1 = pk_sub(pk_sub(m[5], m[9]), m[13]);
+      const f32x2 u2 = pk_sub(pk_sub(m[6], m[10]), m[14]), u3 = pk_sub(pk_sub(m[7], m[11]), m[15]);
+      Y[0][ep] = s0 + s1 + s2; Y[1][ep] = pk_sub(pk_sub(s1, s2), s3);
+      Y[2][ep] = u0 + u1 + u2; Y[3][ep] = pk_sub(pk_sub(u1, u2), u3);
     }
-    if (a.splits > 1) {  // raw partial sums; conv_splitk_reduce_kernel finishes the layer
+    if (partial) {  // raw partial sums; conv_splitk_reduce_kernel finishes the layer (or the layer's tail tiles)
+      char *const pb = reinterpret_cast<char *>(obase + (size_t)cb * a.out_plane);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int yy = y + (k >> 1), xx = x + (k & 1);
-        if (yy < a.H && xx < a.W)
-          *reinterpret_cast<f32x4 *>(obase + (size_t)cb * a.out_plane + ((size_t)(yy + 1) * a.out_Wp + xx + 1) * 8 + half * 4) = Y[k];
-      }
+      for (int k = 0; k < 4; ++k)
+        if (okk[k]) *reinterpret_cast<f32x4 *>(pb + offk[k]) = f32x4{Y[k][0][0], Y[k][0][1], Y[k][1][0], Y[k][1][1]};
       continue;
     }
-    const f32x4 b4 = bias4[g];
-    f32x4 m = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    const f32x2 b01 = f32x2{bias4[g][0], bias4[g][1]}, b23 = f32x2{bias4[g][2], bias4[g][3]};
+    const f32x2 zero2 = f32x2{0.0f, 0.0f};
+    f32x2 mx0 = f32x2{-INFINITY, -INFINITY}, mx1 = mx0;
+    char *const ob = reinterpret_cast<char *>(a.out + (size_t)cb * a.out_plane);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int yy = y + (k >> 1), xx = x + (k & 1);
-      const bool ok = yy < a.H && xx < a.W;
-      f32x4 v = Y[k] + b4;
-      if (a.relu) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.0f ? 0.0f : v[e];
-      }
-      if (ok && a.out)
-        *reinterpret_cast<f32x4 *>(a.out + (size_t)cb * a.out_plane + ((size_t)(yy + 1) * a.out_Wp + xx + 1) * 8 + half * 4) = v;
-      if (ok) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
-      }
+      f32x2 v0 = Y[k][0] + b01, v1 = Y[k][1] + b23;
+      if (a.relu) { v0 = __builtin_elementwise_max(v0, zero2); v1 = __builtin_elementwise_max(v1, zero2); }
+      if (okk[k] && a.out) *reinterpret_cast<f32x4 *>(ob + offk[k]) = f32x4{v0[0], v0[1], v1[0], v1[1]};
+      if (okk[k]) { mx0 = __builtin_elementwise_max(mx0, v0); mx1 = __builtin_elementwise_max(mx1, v1); }
     }
-    if (a.pool) {
-      const int py = y >> 1, px = x >> 1;
-      if (py < a.pool_H && px < a.pool_W)
-        *reinterpret_cast<f32x4 *>(a.pool + (size_t)cb * a.pool_plane + ((size_t)(py + 1) * a.pool_Wp + px + 1) * 8 + half * 4) = m;
-    }
+    if (okp) *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(a.pool + (size_t)cb * a.pool_plane) + offp) = f32x4{mx0[0], mx0[1], mx1[0], mx1[1]};
   }
   if constexpr ((ABL & 64) != 0) {
     const unsigned long long tk3 = __builtin_amdgcn_s_memtime();
@@ -597,9 +732,10 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
 
 template <int ABL>
 static int launch_conv_wino_t(const ConvArgs &a, int tiles_y, hipStream_t s) {
-  auto kern = conv3x3_wino_kernel<ABL>;
+  auto kern = a.wino_tc == 16 ? conv3x3_wino_kernel<ABL, 16> : conv3x3_wino_kernel<ABL, 8>;
   { int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(kern), (int)WG_LDS_BYTES); if (rc_attr) return rc_attr; }
-  dim3 grid((unsigned)(a.n_ct * tiles_y * a.tiles_x), (unsigned)a.splits);
+  const int blocks = a.n_ct * tiles_y * a.tiles_x;
+  dim3 grid((unsigned)(a.tail_splits > 1 ? a.tail_first + (blocks - a.tail_first) * a.tail_splits : blocks), (unsigned)a.splits);
   hipLaunchKernelGGL(kern, grid, dim3(256), WG_LDS_BYTES, s, a);
   MPN_CHECK_LAUNCH();
   return MPN_OK;
@@ -626,15 +762,23 @@ static int launch_conv_wino(const ConvArgs &a, int tiles_y, hipStream_t s) {
 // output and/or its ceil-mode 2x2 max-pool.  One thread per (channel block, pooled-or-full pixel, half).
 __global__ void conv_splitk_reduce_kernel(const float *__restrict__ part, size_t slab, int S, size_t plane, int Wp, int H, int W,
                                           int out_cb, const float *__restrict__ bpk, int relu, float *__restrict__ out,
-                                          float *__restrict__ pool, size_t pool_plane, int pool_Wp, int pool_H, int pool_W) {
+                                          float *__restrict__ pool, size_t pool_plane, int pool_Wp, int pool_H, int pool_W,
+                                          int tile_first, int tiles_x, int g_start, int th_log, int tw_log) {
+  // tile_first > 0 (Winograd tail split): only the (1 << th_log) x (1 << tw_log)-pixel tiles with index >= tile_first carry
+  // partial slabs; the grid covers output rows g_start .. only
   const bool pooling = pool != nullptr;
-  const int GH = pooling ? pool_H : H, GW = pooling ? pool_W : W;
+  const int GHf = pooling ? pool_H : H, GW = pooling ? pool_W : W;
+  const int GH = GHf - g_start;
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)out_cb * GH * GW * 2;
   if (t >= total) return;
   const int h = (int)(t & 1); size_t r = t >> 1;
   const int gx = (int)(r % GW); r /= GW;
-  const int gy = (int)(r % GH); const int cb = (int)(r / GH);
+  const int gy = g_start + (int)(r % GH); const int cb = (int)(r / GH);
+  if (tile_first > 0) {
+    const int ty = (pooling ? 2 * gy : gy) >> th_log, tx = (pooling ? 2 * gx : gx) >> tw_log;
+    if (ty * tiles_x + tx < tile_first) return;
+  }
   const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bpk + cb * 8 + h * 4);
   f32x4 m = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
   const int ny = pooling ? 2 : 1, nx = pooling ? 2 : 1;
@@ -665,6 +809,7 @@ MPN_KNOB(int, g_conv_split, 0);          // 0 = auto, >0 = force this many split
 // ceil(b/slots) rounds.  Split K when that lifts the fill by a margin that pays for the extra slab pass.
 static int conv_pick_splits(int blocks, int nchunks, int slots) {
   if (g_conv_split > 0) return g_conv_split < nchunks ? g_conv_split : nchunks;
+  if (g_conv_split < 0) return 1;
   auto fill = [&](int b) { return (double)b / ((double)slots * ((b + slots - 1) / slots)); };
   int best = 1;
   double best_score = fill(blocks);
@@ -682,6 +827,7 @@ static int conv_pick_splits(int blocks, int nchunks, int slots) {
 // calibrated against tools/wino_split_sweep.py).
 static int wino_pick_splits(int blocks, int nchunks, size_t out_bytes) {
   if (g_conv_split > 0) return g_conv_split < nchunks ? g_conv_split : nchunks;
+  if (g_conv_split < 0) return 1;
   const double t_chunk = 4740.0, t_ovh = 14000.0, hz = 2.35e9;
   int best = 1;
   double best_t = 1e30;
@@ -697,6 +843,49 @@ static int wino_pick_splits(int blocks, int nchunks, size_t out_bytes) {
   return best;
 }
 
+// Uniform split-K or a TAIL split (ConvArgs::tail_*), whichever the same cost model rates faster.  A launch of B equal blocks
+// on 256 one-block CUs runs floor(B / 256) full rounds and then a round in which only B % 256 CUs work for a whole block
+// time; cutting just those tiles' K range in S pieces makes that last round ~1/S as long (VGG conv3_x at 150 x 250: 640
+// blocks = 2.5 rounds -> 3 block times before, 2 + 0.5 after), for one small reduce over the tail tiles only.
+struct WinoPlan { int splits, tail_first, tail_splits, tail_cps; };
+static WinoPlan wino_pick_plan(int blocks, int n_ct, int nchunks, size_t out_bytes) {
+  WinoPlan p{1, 0, 0, 0};
+  if (g_conv_split < 0) {  // test hook: force a tail split of -g_conv_split over the second half of the tiles
+    const int S = -g_conv_split < nchunks ? -g_conv_split : nchunks;
+    const int first = (blocks / 2 / n_ct) * n_ct;
+    if (S > 1 && first > 0 && first < blocks) {
+      p.tail_cps = cdiv(nchunks, S); p.tail_splits = cdiv(nchunks, p.tail_cps); p.tail_first = first;
+      if (p.tail_splits < 2) p = WinoPlan{1, 0, 0, 0};
+    }
+    return p;
+  }
+  p.splits = wino_pick_splits(blocks, nchunks, out_bytes);
+  if (g_conv_split > 0) return p;
+  const double t_chunk = 4740.0, t_ovh = 14000.0, hz = 2.35e9;
+  auto t_uniform = [&](int S) {
+    const int cps = cdiv(nchunks, S);
+    const long long rounds = ((long long)blocks * cdiv(nchunks, cps) + 255) / 256;
+    double t = rounds * (cps * t_chunk + t_ovh);
+    if (S > 1) t += ((S + 1) * (double)out_bytes / 8.0e12 + 3e-6) * hz;
+    return t;
+  };
+  double best_t = t_uniform(p.splits);
+  const int full = (blocks / 256) * 256 / n_ct * n_ct, rem = blocks - full;
+  if (full > 0 && rem > 0) {
+    const double tile_bytes = 64.0 * 256.0 * 4.0;  // one block's outputs
+    for (int S = 2; S <= 8 && S <= nchunks / 2; ++S) {
+      const int cps = cdiv(nchunks, S), Se = cdiv(nchunks, cps);
+      if (Se != S) continue;
+      const long long rounds = ((long long)rem * S + 255) / 256;
+      const double t = (double)(full / 256) * (nchunks * t_chunk + t_ovh) + rounds * (cps * t_chunk + t_ovh) +
+                       ((S + 1) * rem * tile_bytes / 8.0e12 + 3e-6) * hz;
+      if (t < best_t * 0.98) { best_t = t; p = WinoPlan{1, full, S, cps}; }
+    }
+  }
+  return p;
+}
+
+MPN_KNOB(int, g_wino_tc, 0);  // test hook: force the Winograd block geometry (8 / 16; 0 = per layer)
 MPN_KNOB(int, g_conv_variant, 0);  // 0 = auto; test/bench hook: 1 = 128x4 tile / 9 taps per stage, 2 = 64x8 / 9, 3 = 128x4 / 3, 4 = 64x8 / 3,
                                  // 5 = 128 couts x 8 rows (64x128 per wave, 8 accumulators), 6 = 64 couts x 16 rows
 
@@ -728,28 +917,42 @@ int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int re
   if (!d_wpk) variant = 7;
   if (variant == 7) {  // Winograd F(2x2,3x3): 64 couts x 16x16 px per block
     a.wpk = d_wino;
-    a.tiles_x = cdiv(in.W, 16);
-    const int tiles_y = cdiv(in.H, 16);
+    // block geometry: 16 x 16 px or 8 x 32 px of outputs, whichever pads this map less
+    const long px_sq = (long)cdiv(in.H, 16) * 16 * cdiv(in.W, 16) * 16, px_wide = (long)cdiv(in.H, 8) * 8 * cdiv(in.W, 32) * 32;
+    a.wino_tc = (g_wino_tc == 8 || g_wino_tc == 16) ? g_wino_tc : (px_wide < px_sq ? 16 : 8);
+    const int tpx_h = a.wino_tc == 16 ? 8 : 16, tpx_w = a.wino_tc == 16 ? 32 : 16;
+    a.tiles_x = cdiv(in.W, tpx_w);
+    const int tiles_y = cdiv(in.H, tpx_h);
     a.n_ct = cdiv(Cout, 64);
     const int blocks = a.n_ct * tiles_y * a.tiles_x;
     Act geo = out.p ? out : make_act(nullptr, Cout, in.H, in.W);
-    a.splits = wino_pick_splits(blocks, a.nchunks, geo.elems() * sizeof(float));
+    const WinoPlan plan = wino_pick_plan(blocks, a.n_ct, a.nchunks, geo.elems() * sizeof(float));
+    a.splits = plan.splits;
     a.chunks_per_split = cdiv(a.nchunks, a.splits);
     a.splits = cdiv(a.nchunks, a.chunks_per_split);
-    if (a.splits > 1) {
+    a.tail_first = plan.tail_first; a.tail_splits = plan.tail_splits; a.tail_cps = plan.tail_cps;
+    const int n_slabs = a.tail_splits > 1 ? a.tail_splits : a.splits;
+    if (n_slabs > 1) {
       a.part_slab = geo.elems();
       a.out_plane = geo.plane(); a.out_Wp = geo.Wp;
-      size_t need = a.part_slab * a.splits * sizeof(float);
+      size_t need = a.part_slab * n_slabs * sizeof(float);
       void *ws = nullptr;
       { int rc_ws = scratch_get(SCR_CONV_SPLITK, need, s, &ws); if (rc_ws) return rc_ws; }
       a.part = static_cast<float *>(ws);
     }
     int rc = launch_conv_wino(a, tiles_y, s);
-    if (rc != MPN_OK || a.splits == 1) return rc;
+    if (rc != MPN_OK || n_slabs == 1) return rc;
     const int GH = pooled.p ? pooled.H : in.H, GW = pooled.p ? pooled.W : in.W;
-    const size_t total = (size_t)a.out_cb * GH * GW * 2;
-    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, a.part, a.part_slab, a.splits, geo.plane(),
-                       geo.Wp, in.H, in.W, a.out_cb, d_bpk, relu, out.p, pooled.p, a.pool_plane, a.pool_Wp, a.pool_H, a.pool_W);
+    int tile_first = 0, g_start = 0;
+    if (a.tail_splits > 1) {  // only the tail tiles have partial slabs
+      tile_first = a.tail_first / a.n_ct;
+      const int y_start = (tile_first / a.tiles_x) * tpx_h;
+      g_start = pooled.p ? y_start / 2 : y_start;
+    }
+    const size_t total = (size_t)a.out_cb * (GH - g_start) * GW * 2;
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, a.part, a.part_slab, n_slabs, geo.plane(),
+                       geo.Wp, in.H, in.W, a.out_cb, d_bpk, relu, out.p, pooled.p, a.pool_plane, a.pool_Wp, a.pool_H, a.pool_W, tile_first,
+                       a.tiles_x, g_start, a.wino_tc == 16 ? 3 : 4, a.wino_tc == 16 ? 5 : 4);
     MPN_CHECK_LAUNCH();
     return MPN_OK;
   }
@@ -784,7 +987,7 @@ int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int re
   const int GH = pooled.p ? pooled.H : in.H, GW = pooled.p ? pooled.W : in.W;
   const size_t total = (size_t)a.out_cb * GH * GW * 2;
   hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, a.part, a.part_slab, a.splits, geo.plane(),
-                     geo.Wp, in.H, in.W, a.out_cb, d_bpk, relu, out.p, pooled.p, a.pool_plane, a.pool_Wp, a.pool_H, a.pool_W);
+                     geo.Wp, in.H, in.W, a.out_cb, d_bpk, relu, out.p, pooled.p, a.pool_plane, a.pool_Wp, a.pool_H, a.pool_W, 0, 0, 0, 4, 4);
   MPN_CHECK_LAUNCH();
   return MPN_OK;
 }
@@ -1512,6 +1715,7 @@ using namespace mpn;
 #ifdef MPN_DEBUG_HOOKS
 extern "C" void mpn_debug_set_wino_trace(void *p) { g_wino_trace = static_cast<unsigned long long *>(p); }
 extern "C" void mpn_debug_set_conv_variant(int v) { g_conv_variant = v; }
+extern "C" void mpn_debug_set_wino_tc(int v) { g_wino_tc = v; }
 extern "C" void mpn_debug_set_conv_split(int v) { g_conv_split = v; }
 extern "C" void mpn_debug_set_gemm_split(int v) { g_gemm_split = v; }
 extern "C" void mpn_debug_set_gemm_kch(int v) { g_gemm_kch = (v == 4 || v == 8) ? v : 0; }

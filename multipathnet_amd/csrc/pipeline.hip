@@ -120,6 +120,7 @@ using namespace mpn;
 struct ConvLayer {
   int Cin, Cout, pool;
   float *wpk = nullptr, *bpk = nullptr, *wino = nullptr;  // direct-conv and Winograd-transformed weights
+  float *w36 = nullptr;     // first layer (<= 4 input channels, no pool): the K = 36 formulation's weights
   float *out = nullptr;     // C8P buffer for the conv output (max image size)
   float *pooled = nullptr;  // C8P buffer for the pooled output (when pool)
 };
@@ -205,8 +206,10 @@ struct ProfScope {
 };
 
 MPN_KNOB(int, g_fuse_pool, 1);
+MPN_KNOB(int, g_first_k36, 1);  // 0: the first layer on the generic direct kernel
 #ifdef MPN_DEBUG_HOOKS
 extern "C" void mpn_debug_set_fuse_pool(int v) { g_fuse_pool = v; }
+extern "C" void mpn_debug_set_first_k36(int v) { g_first_k36 = v; }
 #endif
 
 template <typename T>
@@ -281,7 +284,11 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
     TRY(dev_alloc(p, &L.wpk, conv_wpk_elems(L.Cin, L.Cout) * sizeof(float), false));
     TRY(dev_alloc(p, &L.bpk, (size_t)conv_coutp(L.Cout) * sizeof(float), false));
     TRY(pack_conv_weights(d_conv_w[l], d_conv_b[l], L.Cin, L.Cout, L.wpk, L.bpk, nullptr));
-    if (L.Cin >= 16) {  // the first layer (3 channels) is HBM-bound either way: keep it on the direct kernel
+    if (L.Cin <= 4 && !L.pool && !(mw && (l == mw->tap_conv3 || l == mw->tap_conv4))) {
+      TRY(dev_alloc(p, &L.w36, conv_first_elems(L.Cout) * sizeof(float), false));
+      TRY(pack_conv_weights_first(d_conv_w[l], L.Cin, L.Cout, L.w36, nullptr));
+    }
+    if (L.Cin >= 16) {  // fewer input channels: direct kernels (the 3-channel first layer is bound by its output stores either way)
       TRY(dev_alloc(p, &L.wino, conv_wino_elems(L.Cin, L.Cout) * sizeof(float), false));
       TRY(pack_conv_weights_wino(d_conv_w[l], L.Cin, L.Cout, L.wino, nullptr));
     }
@@ -474,7 +481,8 @@ static int run_trunk(mpn_frcnn *p, const float *d_image, int H, int W, hipStream
       if (rc) return rc;
       cur = pooled; h = pooled.H; w = pooled.W;
     } else {
-      { ProfScope ps(p, ctag, s); rc = conv3x3_c8p(cur, L.wpk, L.bpk, L.Cout, 1, out, Act{}, s, L.wino); }
+      { ProfScope ps(p, ctag, s);
+        rc = (L.w36 && g_first_k36) ? conv3x3_first_c8p(cur, L.w36, L.bpk, L.Cout, 1, out, s) : conv3x3_c8p(cur, L.wpk, L.bpk, L.Cout, 1, out, Act{}, s, L.wino); }
       if (rc) return rc;
       cur = out;
     }

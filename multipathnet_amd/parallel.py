@@ -53,7 +53,7 @@ class Comm(object):
             dist.broadcast(t, src=0, group=group)
             idbuf = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().tolist()))
         h = C.c_void_p()
-        _lib.check(lib.mpn_comm_init_rank(idbuf, world, rank, C.byref(h)), "mpn_comm_init_rank")
+        _lib.check(lib.mpn_comm_init_rank(idbuf if world > 1 else None, world, rank, C.byref(h)), "mpn_comm_init_rank")
         return cls(h, world, rank, lib)
 
     def record_floats(self, top_cap):

@@ -25,9 +25,10 @@ def _conv(dev, x, w, b, relu=True):
 @pytest.mark.parametrize("ci,co,h,w", [(3, 64, 40, 70), (8, 64, 33, 31), (64, 64, 19, 45), (64, 128, 16, 96), (128, 256, 9, 33),
                                        (24, 40, 8, 8), (16, 200, 5, 37), (256, 512, 12, 20)])
 @pytest.mark.parametrize("variant,split", [(0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (5, 0), (6, 0), (5, 2), (6, 3), (1, 2), (2, 3), (3, 2), (4, 3), (0, 4),
-                                           (7, 0), (7, 2), (7, 3)])
+                                           (7, 0), (7, 2), (7, 3), (7, -2), (7, -3)])
 def test_conv3x3_vs_oracle(O, dev, ci, co, h, w, variant, split):
-    """variant 0 = the default choice per layer, 1-6 = direct-convolution tilings, 7 = Winograd F(2x2,3x3); split = forced split-K factor (0 = cost model)"""
+    """variant 0 = the default choice per layer, 1-6 = direct-convolution tilings, 7 = Winograd F(2x2,3x3); split = forced split-K factor
+    (0 = cost model; negative = a TAIL split of that many K ranges over the second half of the tiles, the first half un-split)"""
     rng = np.random.default_rng(ci * 1000 + co)
     x = rng.standard_normal((ci, h, w)).astype(np.float32)
     wt = (rng.standard_normal((co, ci, 3, 3)) * (2.0 / (ci * 9)) ** 0.5).astype(np.float32)
@@ -39,6 +40,21 @@ def test_conv3x3_vs_oracle(O, dev, ci, co, h, w, variant, split):
     assert y.shape == ref.shape
     assert np.abs(y - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
     assert np.abs(y2 - O.conv3x3(x, wt, None, relu=False)).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("ci,co,h,w", [(64, 64, 19, 45), (128, 256, 9, 33), (16, 200, 5, 37), (256, 512, 12, 20), (24, 40, 38, 63), (32, 64, 75, 125)])
+@pytest.mark.parametrize("tc,split", [(8, 0), (16, 0), (16, 2), (16, -2), (8, -3)])
+def test_conv3x3_winograd_block_geometries(O, dev, ci, co, h, w, tc, split):
+    """the Winograd kernel's two block geometries (tc = 8: 16 x 16 output px, tc = 16: 8 rows x 32 columns; the host picks per layer
+    whichever pads the map less) with uniform / tail split-K, bias + ReLU and the module-level path's layouts"""
+    rng = np.random.default_rng(ci * 31 + co + tc)
+    x = rng.standard_normal((ci, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((co, ci, 3, 3)) * (2.0 / (ci * 9)) ** 0.5).astype(np.float32)
+    b = (rng.standard_normal(co) * 0.1).astype(np.float32)
+    with hooks(conv_variant=7, conv_split=split, wino_tc=tc):
+        y = _conv(dev, x, wt, b, relu=True)
+    ref = O.conv3x3(x, wt, b, relu=True)
+    assert np.abs(y - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
 
 
 def test_conv_transpose_detecting(O, dev):

@@ -49,12 +49,13 @@ def small(O, dev):
     return dict(net=net, im=im, boxes=boxes, P=Pn, P_torch=P, feat=feat, pooled=pooled, logits=logits, deltas=deltas)
 
 
-@pytest.mark.parametrize("fuse_pool,split", [(1, 0), (0, 0), (1, 2), (0, 3)])
-def test_pipeline_stages_vs_oracle(O, dev, small, fuse_pool, split):
+@pytest.mark.parametrize("fuse_pool,split,k36", [(1, 0, 1), (0, 0, 1), (1, 2, 1), (0, 3, 1), (1, 0, 0)])
+def test_pipeline_stages_vs_oracle(O, dev, small, fuse_pool, split, k36):
     from multipathnet_amd import models
     s = SMALL
-    with hooks(fuse_pool=fuse_pool, conv_split=split):  # (1, 0) = the product library; the others build their handle on the debug flavour
-        net = small["net"] if (fuse_pool, split) == (1, 0) else models.FastRCNN(
+    # k36 = 0: the first layer on the generic direct kernel instead of its K = 36 formulation
+    with hooks(fuse_pool=fuse_pool, conv_split=split, first_k36=k36):  # (1, 0, 1) = the product library; the others build their handle on the debug flavour
+        net = small["net"] if (fuse_pool, split, k36) == (1, 0, 1) else models.FastRCNN(
             small["P_torch"], cfg=s["cfg"], pooled=7, spatial_scale=s["scale"], max_h=s["H"], max_w=s["W"], max_rois=s["N"])
         scores, bbox = net.detect(torch.from_numpy(small["im"]).to(dev), torch.from_numpy(small["boxes"]).to(dev))
         torch.cuda.synchronize()

@@ -1,7 +1,7 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import multipathnet_amd
-lib = multipathnet_amd.load()
+lib = multipathnet_amd._lib.load("debug")  # libmpn_hip_dbg.so: the flavour with the mpn_debug_* hooks
 lib.mpn_debug_set_conv_split(1)
 for (ci, co, h, w) in [(128, 128, 300, 500), (64, 64, 600, 1000)]:
     for ab in (0, 1, 2, 4, 5, 7):

@@ -2,10 +2,10 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import multipathnet_amd
-lib = multipathnet_amd.load()
+lib = multipathnet_amd._lib.load("debug")  # libmpn_hip_dbg.so: the flavour with the mpn_debug_* hooks
 lib.mpn_debug_set_conv_variant(7)
-for (ci, co, h, w) in [(128, 128, 300, 500), (512, 512, 75, 125)]:
-    for ab in [0, 1, 2, 4, 8, 7, 15, 31]:
+for (ci, co, h, w) in [(64, 64, 600, 1000), (128, 128, 300, 500), (512, 512, 38, 63)]:
+    for ab in [0, 1, 2, 4, 8, 5, 23, 31]:
         lib.mpn_debug_set_gemm_ablate(ab)
         ms = C.c_float()
         lib.mpn_debug_bench_conv(ci, co, h, w, 0, 10, C.byref(ms))

@@ -2,7 +2,7 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import multipathnet_amd
-lib = multipathnet_amd.load()
+lib = multipathnet_amd._lib.load("debug")  # libmpn_hip_dbg.so: the flavour with the mpn_debug_* hooks
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 split = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 lib.mpn_debug_set_conv_variant(variant); lib.mpn_debug_set_conv_split(split)

@@ -7,7 +7,7 @@ from multipathnet_amd import utils
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from conftest import random_scored_boxes
 
-lib = multipathnet_amd.load()
+lib = multipathnet_amd._lib.load("debug")  # libmpn_hip_dbg.so: the flavour with the mpn_debug_* hooks
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(0)
 n_cls, M = 20, int(sys.argv[1]) if len(sys.argv) > 1 else 1000

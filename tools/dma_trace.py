@@ -8,7 +8,7 @@ import torch
 import multipathnet_amd
 from multipathnet_amd import models
 import bench
-lib = multipathnet_amd.load()
+lib = multipathnet_amd._lib.load("debug")  # libmpn_hip_dbg.so: the flavour with the mpn_debug_* hooks
 kh = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 H, W, N = 600, 1000, 1000
 R = models.synthetic_resnet_params(depth=50, n_classes=21, seed=3)

@@ -2,7 +2,7 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import multipathnet_amd
-lib = multipathnet_amd.load()
+lib = multipathnet_amd._lib.load("debug")  # libmpn_hip_dbg.so: the flavour with the mpn_debug_* hooks
 for kch in (4, 8):
     lib.mpn_debug_set_gemm_kch(kch)
     for (M, K, N) in [(1000, 25088, 4096), (1000, 4096, 4096)]:

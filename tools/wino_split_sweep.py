@@ -2,7 +2,7 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import multipathnet_amd
-lib = multipathnet_amd.load()
+lib = multipathnet_amd._lib.load("debug")  # libmpn_hip_dbg.so: the flavour with the mpn_debug_* hooks
 lib.mpn_debug_set_conv_variant(7)
 shapes = [(64, 64, 600, 1000), (64, 128, 300, 500), (128, 128, 300, 500), (128, 256, 150, 250), (256, 256, 150, 250), (256, 512, 75, 125), (512, 512, 75, 125), (512, 512, 38, 63)]
 for (ci, co, h, w) in shapes:

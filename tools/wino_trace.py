@@ -5,11 +5,11 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import multipathnet_amd
-lib = multipathnet_amd.load()
+lib = multipathnet_amd._lib.load("debug")  # libmpn_hip_dbg.so: the flavour with the mpn_debug_* hooks
 lib.mpn_debug_set_conv_variant(7)
 buf = torch.zeros(4 * 64 * 4 + 48 + 4096 * 3, dtype=torch.int64, device="cuda")
 lib.mpn_debug_set_wino_trace(C.c_void_p(buf.data_ptr()))
-for (ci, co, h, w) in [(128, 128, 300, 500), (512, 512, 75, 125)]:
+for (ci, co, h, w) in [(64, 64, 600, 1000), (128, 128, 300, 500), (256, 256, 150, 250), (512, 512, 75, 125), (512, 512, 38, 63)]:
     for ab in (64,):
         buf.zero_()
         lib.mpn_debug_set_gemm_ablate(ab)
