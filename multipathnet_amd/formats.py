@@ -3,6 +3,12 @@
   prepare_proposals     DataSetJSON.lua:157-239  filterArea -> filterScore (best_n by score) -> {2,1,4,3} column permute
   detections_to_coco    testCoco/init.lua:65-85  per-class [K,5] tables -> [n,7] rows {img, x, y, w, h, score, category}
   save_results          utils.lua:335-372        flat boxes / scores / categories / images tables
+  load_proposals        DataSetJSON.lua:124-160  torch.load of one or several proposal `.t7` files, merged by image name
+  roidb_from_proposals  DataSetJSON.lua:188-239  per dataset image: float() -> filterArea -> filterScore -> permute
+  save_boxes / load_boxes, save_results_file    run_test.lua:62,72-76 (`boxes.t7`), utils.lua:335-372 (torch.save of the flat table)
+
+The `.t7` files are read and written by multipathnet_amd/t7.py (Torch7's binary serialisation), so real proposal tables flow in
+and `boxes.t7` / results tables flow out to the reference's evaluation scripts unchanged.
 
 Host orchestration is torch indexing; the per-row arithmetic runs in libmpn_hip.so (mpn_proposals_permute_filter,
 mpn_dets_to_coco_rows).
@@ -62,3 +68,80 @@ def save_results(aboxes, dataset_name):
     cat = lambda xs, w: torch.cat([x.cpu() for x in xs]) if xs else torch.empty((0,) + w)
     return {"dataset": dataset_name, "images": torch.arange(1, n_images + 1, dtype=torch.float32),
             "detections": {"boxes": cat(boxes, (4,)), "scores": cat(scores, ()), "categories": cat(cats, ()), "images": cat(imgs, ())}}
+
+
+def load_proposals(roidbfile):
+    """DataSetCOCO:loadAndMergeProposals (DataSetJSON.lua:124-160): one `.t7` path, or a list of them merged by image name
+    (boxes / scores of an image concatenated in file order; files without scores count as score 0).
+    Returns {"boxes": [ndarray [n,4] per image], "scores": [...] or None, "images": [str]}."""
+    import numpy as np
+    from . import t7
+    if isinstance(roidbfile, str):
+        dt = t7.load(roidbfile)
+        return {"boxes": list(dt["boxes"]), "scores": list(dt["scores"]) if dt.get("scores") is not None else None, "images": list(dt["images"])}
+    out = {"boxes": [], "scores": [], "images": []}
+    img2idx = {}
+    for path in roidbfile:
+        dt2 = t7.load(path)
+        for k, v in enumerate(dt2["images"]):
+            if v not in img2idx:
+                out["images"].append(v)
+                out["boxes"].append(None)
+                out["scores"].append(None)
+                img2idx[v] = len(out["images"]) - 1
+            i = img2idx[v]
+            b = np.asarray(dt2["boxes"][k], np.float32)
+            sc = np.asarray(dt2["scores"][k], np.float32).reshape(-1) if dt2.get("scores") is not None else np.zeros(b.shape[0], np.float32)
+            out["boxes"][i] = b if out["boxes"][i] is None else np.concatenate([out["boxes"][i], b], 0)   # TableConcat
+            out["scores"][i] = sc if out["scores"][i] is None else np.concatenate([out["scores"][i], sc], 0)
+    return out
+
+
+def roidb_from_proposals(dt, file_names, best_number=None, min_area=0.0, allow_missing=False, device=None):
+    """DataSetCOCO:loadROIDB (DataSetJSON.lua:188-239): for every dataset image (by file name) its proposals as float {x1,y1,x2,y2}
+    boxes after filterArea / filterScore / the {2,1,4,3} permute, on `device` (rows through mpn_proposals_permute_filter).
+    Returns (roidb list, scoredb list); a missing image raises unless allow_missing (then None)."""
+    im2box = {name: i for i, name in enumerate(dt["images"])}
+    if dt.get("scores") is not None:
+        assert len(dt["boxes"]) == len(dt["scores"])
+        assert isinstance(best_number, (int, float)), "best_number has to be a valid number, e.g. 500 or 5000"
+    dev = device or torch.device("cuda", torch.cuda.current_device())
+    roidb, scoredb = [], []
+    for name in file_names:
+        if name not in im2box:
+            if not allow_missing:
+                raise KeyError(name + " is not in proposals")
+            roidb.append(None)
+            scoredb.append(None)
+            continue
+        k = im2box[name]
+        b = torch.as_tensor(dt["boxes"][k], dtype=torch.float32).to(dev)
+        sc = torch.as_tensor(dt["scores"][k], dtype=torch.float32).reshape(-1).to(dev) if dt.get("scores") is not None else None
+        boxes, scores = prepare_proposals(b, sc, min_area=min_area, best_number=int(best_number) if best_number is not None else None)
+        roidb.append(boxes)
+        scoredb.append(scores)
+    return roidb, scoredb
+
+
+def save_boxes(path, aboxes):
+    """run_test.lua:72-76 `torch.save(dir/boxes.t7, aboxes)`: aboxes[class][image] = FloatTensor [K,5] (empty = no detections)."""
+    import numpy as np
+    from . import t7
+    t7.save(path, [[(np.zeros((0,), np.float32) if (d is None or len(d) == 0) else np.asarray(d.detach().cpu() if hasattr(d, "detach") else d, np.float32))
+                    for d in per_img] for per_img in aboxes])
+
+
+def load_boxes(path):
+    """run_test.lua:62 `aboxes = torch.load(opt.test_load_aboxes)` -> aboxes[class][image] as float32 arrays ([0,5] when empty)."""
+    import numpy as np
+    from . import t7
+    ab = t7.load(path)
+    fix = lambda d: np.zeros((0, 5), np.float32) if d is None or np.size(d) == 0 else np.asarray(d, np.float32)
+    cls_tables = ab if isinstance(ab, list) else [ab[k] for k in sorted(ab)]
+    return [[fix(d) for d in (per if isinstance(per, list) else [per[k] for k in sorted(per)])] for per in cls_tables]
+
+
+def save_results_file(path, aboxes, dataset_name):
+    """utils.saveResults (utils.lua:335-372): the flat table, torch.save()d."""
+    from . import t7
+    t7.save(path, save_results(aboxes, dataset_name))

@@ -1,0 +1,116 @@
+"""The Lua/LuaJIT side of the boundary cannot run here (no Lua in the image).  What can be verified without it, and is:
+
+  * multipathnet_amd/lua/mpn_cdef.lua is exactly what tools/gen_lua_cdef.py produces from include/mpn.h (never hand-edited);
+  * every function prototype in the cdef is exported by libmpn_hip.so and has the header's parameter list;
+  * every `C.mpn_*(...)` call in mpn.lua names a declared function and passes exactly as many arguments as its prototype;
+  * every `cfg.<field>` assigned in mpn.lua is a field of mpn_frcnn_config, and the Python ctypes mirror of that struct
+    (multipathnet_amd/_lib.FrcnnConfig) lists the same fields in the same order with matching C types."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LUA = os.path.join(ROOT, "multipathnet_amd", "lua")
+
+
+def _strip_comments(src):
+    return re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", "", src, flags=re.S))
+
+
+def _prototypes(src):
+    """name -> list of parameter declarations"""
+    out = {}
+    for m in re.finditer(r"\b([A-Za-z_][\w \*]*?)\b(mpn_\w+)\s*\(([^;{}()]*)\)\s*;", _strip_comments(src)):
+        params = [p.strip() for p in re.sub(r"\s+", " ", m.group(3)).split(",")]
+        out[m.group(2)] = [] if params == ["void"] else params
+    return out
+
+
+def _cdef_text():
+    txt = open(os.path.join(LUA, "mpn_cdef.lua")).read()
+    return txt[txt.index("return [[") + 9: txt.rindex("]]")]
+
+
+def test_cdef_is_generated_from_the_header():
+    rc = subprocess.call([sys.executable, os.path.join(ROOT, "tools", "gen_lua_cdef.py"), "--check"])
+    assert rc == 0, "multipathnet_amd/lua/mpn_cdef.lua is stale: run python tools/gen_lua_cdef.py"
+
+
+def test_cdef_prototypes_match_header_and_library():
+    import multipathnet_amd
+    lib = multipathnet_amd.load()
+    hdr = _prototypes(open(os.path.join(ROOT, "include", "mpn.h")).read())
+    cdef = _prototypes(_cdef_text())
+    assert len(hdr) >= 50 and set(hdr) == set(cdef)
+    for name, params in hdr.items():
+        assert cdef[name] == params, name
+        assert hasattr(lib, name), "libmpn_hip.so does not export " + name
+    assert "#" not in _cdef_text() and "extern" not in _cdef_text()   # nothing LuaJIT's cdef parser rejects
+
+
+def _split_args(s):
+    args, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            args.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        args.append(cur.strip())
+    return args
+
+
+def test_lua_calls_match_prototypes():
+    src = re.sub(r"--\[\[.*?\]\]", "", open(os.path.join(LUA, "mpn.lua")).read(), flags=re.S)
+    src = re.sub(r"--[^\n]*", "", src)
+    protos = _prototypes(_cdef_text())
+    calls = 0
+    for m in re.finditer(r"\bC\.(mpn_\w+)\s*\(", src):
+        name, i, depth = m.group(1), m.end(), 1
+        j = i
+        while depth:
+            depth += {"(": 1, ")": -1}.get(src[j], 0)
+            j += 1
+        args = _split_args(src[i:j - 1])
+        assert name in protos, "mpn.lua calls undeclared " + name
+        assert len(args) == len(protos[name]), "%s: %d arguments passed, prototype has %d" % (name, len(args), len(protos[name]))
+        calls += 1
+    assert calls >= 10
+    for m in re.finditer(r"\bC\.(mpn_\w+)\b(?!\s*\()", src):   # function values (ffi.gc finalisers)
+        assert m.group(1) in protos
+
+
+def test_config_struct_fields_agree_between_header_lua_and_ctypes():
+    from multipathnet_amd import _lib
+    hdr = _strip_comments(open(os.path.join(ROOT, "include", "mpn.h")).read())
+    body = hdr[hdr.index("typedef struct mpn_frcnn_config {") + len("typedef struct mpn_frcnn_config {"): hdr.index("} mpn_frcnn_config;")]
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ctype, names = decl.rsplit(" ", 1)[0], decl
+        m = re.match(r"(const\s+)?(\w+)\s+(.*)", decl)
+        base = m.group(2)
+        for nm in m.group(3).split(","):
+            nm = nm.strip()
+            ptr = nm.startswith("*")
+            arr = re.search(r"\[(\d+)\]", nm)
+            fields.append((re.sub(r"[\*\[\]\d ]", "", nm), base, ptr, int(arr.group(1)) if arr else 0))
+    py = _lib.FrcnnConfig._fields_
+    assert [f[0] for f in fields] == [f[0] for f in py]
+    cmap = {"int": C.c_int, "float": C.c_float, "double": C.c_double}
+    for (name, base, ptr, arr), (pname, ptype) in zip(fields, py):
+        want = C.POINTER(cmap[base]) if ptr else (cmap[base] * arr if arr else cmap[base])
+        assert ptype is want or (arr and ptype._type_ is cmap[base] and ptype._length_ == arr), name
+    lua = open(os.path.join(LUA, "mpn.lua")).read()
+    names = {f[0] for f in fields}
+    used = set(re.findall(r"\bcfg\.(\w+)", lua))
+    assert used and used <= names, used - names
