@@ -152,6 +152,11 @@ __device__ __forceinline__ unsigned nms_f2key(float f) {
 constexpr int kSortMax = 8192;  // 64 KiB of LDS keys
 constexpr int kTieMax = 4096;   // nms_tie_kernel: one 64-bit alive/occupancy word per lane
 constexpr int kTieLdsMask = 1024;  // full symmetric mask kept in LDS up to this many boxes (128 KiB)
+// Classes with up to this many tied adjacent pairs take the chunked scan with position replay (flag 3).  0 = never by default:
+// measured on MI355X (tools/nms_trace.py) the replay — per-pick VALU <-> SALU round trips of ~40 cycles each — costs more than
+// the slot-emulating kernel it was meant to undercut (850 k vs 320 k cycles for 1000 boxes with four tied pairs); it stays in the
+// library as a second, independent exact implementation (test path 3) until its per-pick work is vectorised.
+constexpr int kFewTies = 0;
 
 __global__ __launch_bounds__(1024) void nms_sort_kernel(const float *__restrict__ scored, const int *__restrict__ counts,
                                                         int m_stride, float4 *__restrict__ sbox, float *__restrict__ sscore,
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float *__restrict_
   // flags[c]: 0 = tie-free -> chunked scan; 1 = ties -> nms_tie_kernel (exact slot emulation on the
   // bitmask); 2 = NaN scores or too many boxes -> nms_wave_kernel (exact IoU sweep)
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
-  __shared__ int bad, nsel, hasnan;
+  __shared__ int bad, nsel, hasnan;  // bad = number of bit-equal adjacent score pairs
   const int cls = blockIdx.x, tid = threadIdx.x;
   int m = counts ? counts[cls] : m_stride;
   if (m > m_stride) m = m_stride;
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float *__restrict_
   for (int p = tid; p < m; p += blockDim.x) {
     unsigned long long k = keys[p];
     int i = (int)(unsigned)k;
-    if (p + 1 < m && (unsigned)(keys[p + 1] >> 32) == (unsigned)(k >> 32)) bad = 1;  // bit-equal scores
+    if (p + 1 < m && (unsigned)(keys[p + 1] >> 32) == (unsigned)(k >> 32)) atomicAdd(&bad, 1);  // bit-equal scores
     const float *r = src + 5 * (size_t)i;
     float s = r[4];
     ob[p] = make_float4(r[0], r[1], r[2], r[3]);
@@ -208,7 +213,9 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float *__restrict_
   atomicAdd(&nsel, local_sel);
   __syncthreads();
   if (tid == 0) {
-    int f = hasnan ? 2 : ((bad || force_mode == 2) ? 1 : 0);
+    // 0 = tie-free, 3 = a few tied pairs (the chunked scan with position replay), 1 = many ties (slot emulation on the
+    // LDS-staged bitmask), 2 = NaN scores (exact sweep)
+    int f = hasnan ? 2 : (force_mode == 2 ? 1 : (force_mode == 3 ? 3 : (bad == 0 ? 0 : (bad <= kFewTies ? 3 : 1))));
     // the host launches nms_tie_kernel only when m_stride <= kTieMax (its LDS tables are sized by m_stride): a class with
     // ties in a wider table goes to the exact sweep kernel, whatever its own count
     if (f == 1 && m_stride > kTieMax) f = 2;
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float4 *__restrict_
   const int cls = blockIdx.z;
   const int flag = flags[cls];
   if (flag == 2) return;
-  const bool full = flag == 1;  // tie classes: full symmetric rows over ALL boxes (unpickable ones can still be suppressed)
+  const bool full = flag == 1 || flag == 3;  // tie classes: full symmetric rows over ALL boxes (unpickable ones can still be suppressed)
   const int n = n_sel[cls];     // rows: only pickable ranks ever suppress
   int m = counts ? counts[cls] : m_stride;
   if (m > m_stride) m = m_stride;
@@ -246,7 +253,9 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float4 *__restrict_
   const int jn = min(64, ncol - w * 64);
   for (int jj = 0; jj < jn; ++jj) {
     const int j = w * 64 + jj;
-    if (full ? (j == i) : (j <= i)) continue;
+    // the chunk's own (diagonal) word is always symmetric: the scan resolves a chunk by a fixpoint over "no kept lower rank
+    // overlaps me", which reads the lower triangle of that word
+    if ((full || (i >> 6) == w) ? (j == i) : (j <= i)) continue;
     const float4 c = cols[jj];
     float iou = iou_plus1(a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w);  // overlap(best, other), nms.c:92
     if (!(iou <= thr)) bits |= 1ull << jj;
@@ -254,88 +263,344 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float4 *__restrict_
   mask[((size_t)cls * m_stride + i) * w64 + w] = bits;
 }
 
+__device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int l) {
+  unsigned lo = __shfl((unsigned)v, l), hi = __shfl((unsigned)(v >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
 __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
   unsigned lo = __builtin_amdgcn_readlane((unsigned)v, l);
   unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), l);
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// Chunked scan, with the reference's position history replayed when the class has (a few) bit-equal scores.
+//
+// Tie-free class (flag 0): the pick order is the rank order, a chunk of 64 ranks is resolved with wave-uniform bit
+// arithmetic on its diagonal word and the kept rows are OR-ed into the per-lane `removed` words.
+//
+// Class with a few tied pairs (flag 3): nms.c picks, among bit-equal scores, the box that sits FIRST in its array
+// (nms.c:74-81), and the array is permuted by every round — the old first element takes the picked box's place
+// (nms.c:83-85), the survivors keep their order (nms.c:91-98).  Which tied box comes first therefore depends on the whole
+// history, so the history is replayed — but cheaply, and only the part that matters:
+//   * positions ("slots") only ever matter when two alive boxes tie.  A chunk in which no alive rank has an alive-tied
+//     successor (alive & tie word == 0) is resolved exactly as in the tie-free case;
+//   * the replay of a pick needs the round's head = the alive box with the smallest slot.  A round vacates the head's slot and
+//     moves boxes only to LATER slots, so the head slot strictly increases: one pointer sweeps the slots once per class.
+//     "Alive at round i" is a comparison with the box's death round, recorded when a row is folded in; the sweep tests 64
+//     slots per ballot from a register window.  Cost per pick: a ballot, two readlanes and (if the head is not the pick)
+//     two LDS writes — instead of the slot-emulating kernel's chain of dependent LDS reads;
+//   * a chunk whose first alive ranks DO tie falls back, pick by pick, to the exact rule (min slot among the alive members
+//     of the run, rows applied one at a time) until the ambiguity is gone.
+// LDS (flag 3 only): int16 pos[rank] / occ[slot] / death[rank].  Rows are full (symmetric) for flag 3: a tied box picked
+// before a lower-ranked member of its run must still suppress it.
+constexpr short kAliveForever = 0x7fff;
 template <int WPL>  // 64-bit `removed` words per lane: covers m <= 4096 * WPL
 __global__ __launch_bounds__(64) void nms_scan_kernel(const float4 *__restrict__ sbox, const float *__restrict__ sscore,
                                                       const int *__restrict__ sidx, const int *__restrict__ n_sel,
-                                                      const int *__restrict__ flags, int m_stride, int w64,
+                                                      const int *__restrict__ flags, const int *__restrict__ counts, int m_stride, int w64,
                                                       const unsigned long long *__restrict__ mask, float *__restrict__ keep,
-                                                      int *__restrict__ keep_idx, int *__restrict__ n_keep) {
+                                                      int *__restrict__ keep_idx, int *__restrict__ n_keep, int m_cap,
+                                                      unsigned long long *__restrict__ trace) {
+  extern __shared__ __attribute__((aligned(16))) short lds16[];  // pos[m_cap], occ[m_cap], death[m_cap]   (flag 3)
+  // tools/nms_trace.py (debug flavour): s_memtime stamps of class 0's chunks -> trace[c * 8 + k]
+#define NMS_STAMP(k) do { if (MPN_ABLATE(trace != nullptr) && blockIdx.x == 0 && lane == 0 && c < 64) trace[c * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+  __shared__ unsigned long long tiew[64 * WPL];
   const int cls = blockIdx.x, lane = threadIdx.x;
-  if (flags[cls] != 0) return;
+  const int flag = flags[cls];
+  if (flag != 0 && flag != 3) return;
+  const bool replay = flag == 3;
   const int n = n_sel[cls];
+  int m = counts ? counts[cls] : m_stride;
+  if (m > m_stride) m = m_stride;
   const float4 *b = sbox + (size_t)cls * m_stride;
   const float *sc = sscore + (size_t)cls * m_stride;
   const int *si = sidx + (size_t)cls * m_stride;
   const unsigned long long *mk = mask + (size_t)cls * m_stride * w64;
   float *kout = keep + (size_t)cls * m_stride * 5;
   int *kidx = keep_idx ? keep_idx + (size_t)cls * m_stride : nullptr;
-  unsigned long long removed[WPL];
+  short *pos = lds16, *occ = lds16 + m_cap, *death = lds16 + 2 * m_cap;
+  unsigned long long removed[WPL], tw[WPL];
 #pragma unroll
-  for (int h = 0; h < WPL; ++h) removed[h] = 0;
+  for (int h = 0; h < WPL; ++h) { removed[h] = 0; tw[h] = 0; }
+  if (replay) {
+    for (int r = lane; r < m; r += kWave) {
+      const int x = si[r];
+      pos[r] = (short)x; occ[x] = (short)r; death[r] = kAliveForever;
+    }
+    for (int r0 = 0; r0 < 64 * 64 * WPL && r0 < m; r0 += kWave) {  // bit r of the tie words: ranks r and r+1 are pickable and carry the same score
+      const int r = r0 + lane;
+      const bool tie = (r + 1 < n) && (sc[r] == sc[r + 1]);
+      const unsigned long long bal = __ballot(tie);
+      if (lane == 0) tiew[r0 >> 6] = bal;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < WPL; ++h) tw[h] = (lane + 64 * h) * 64 < m ? tiew[lane + 64 * h] : 0ull;
+  }
+  // replay state: slots < hp are vacated or hold dead boxes; the register window caches occ / death of slots [W0, W0 + 64)
+  int hp = 0, W0 = -64;
+  int wf = -1, wd = 0;
+  auto window_load = [&](int w0) {
+    W0 = w0;
+    const int sl = w0 + lane;
+    wf = sl < m ? (int)occ[sl] : -1;
+    wd = wf >= 0 ? (int)death[wf] : 0;
+  };
+  // one round of nms.c:74-85 on the slot model: `rank` was picked in round i (1-based)
+  // `sb` = the pick's slot.  Returns ((f - chunk_base) << 16 | sb) when the moved box f is a rank of the current chunk (whose
+  // slots the caller caches in registers), else -1.
+  auto head_step = [&](int i, int rank, int sb, int chunk_base) -> int {
+    int hs, f, fd;
+    for (;;) {
+      if (hp - W0 >= 64 || hp < W0) window_load(hp & ~63);
+      const unsigned long long cand = __ballot(wf >= 0 && wd >= i) & (~0ull << (hp - W0));
+      if (cand) {
+        const int l = __builtin_ctzll(cand);
+        hs = W0 + l;
+        f = __builtin_amdgcn_readlane(wf, l);
+        fd = __builtin_amdgcn_readlane(wd, l);
+        break;
+      }
+      hp = W0 + 64;
+    }
+    hp = hs + 1;
+    if (f == rank) return -1;
+    // boxes[0] <-> boxes[best]: the old head takes the pick's slot
+    if (lane == 0) { occ[sb] = (short)f; pos[f] = (short)sb; }
+    if (sb - W0 < 64 && lane == sb - W0) { wf = f; wd = fd; }
+    return (chunk_base >= 0 && f >= chunk_base && f < chunk_base + 64) ? (((f - chunk_base) << 16) | sb) : -1;
+  };
+  auto word_of = [&](int w) -> unsigned long long {  // removed word w (wave-uniform index)
+    unsigned long long v = readlane64(removed[0], w & 63);
+    if constexpr (WPL > 1) { if (w >= 64) v = readlane64(removed[1], w & 63); }
+    return v;
+  };
+  auto tie_word = [&](int w) -> unsigned long long {
+    unsigned long long v = readlane64(tw[0], w & 63);
+    if constexpr (WPL > 1) { if (w >= 64) v = readlane64(tw[1], w & 63); }
+    return v;
+  };
+  // fold one row into `removed`, recording the death round of every box it newly removes (replay only)
+  auto record_deaths = [&](unsigned long long newly, int word, int round) {
+    while (newly) {
+      const int bit = __builtin_ctzll(newly);
+      newly &= newly - 1;
+      death[word * 64 + bit] = (short)round;
+    }
+  };
   int kept = 0;
   const int nchunks = (n + 63) >> 6;
-  unsigned long long diag = (lane < n) ? mk[(size_t)lane * w64] : 0ull;
+  // the chunk's diagonal word, one row per lane, fetched a chunk ahead (its latency would otherwise sit in front of every chunk)
+  unsigned long long diag_cur = (lane < n) ? mk[(size_t)lane * w64] : 0ull;
   for (int c = 0; c < nchunks; ++c) {
     const int base = c << 6;
-    // speculative: every row of this chunk, this lane's word(s) — independent loads, all in flight
-    unsigned long long rows[64];
-    if (lane > c && lane < w64) {
-#pragma unroll
-      for (int r = 0; r < 64; ++r) rows[r] = (base + r < n) ? mk[(size_t)(base + r) * w64 + lane] : 0ull;
-    } else {
-#pragma unroll
-      for (int r = 0; r < 64; ++r) rows[r] = 0ull;
-    }
-    unsigned long long diag_next = 0ull;
-    if (c + 1 < nchunks && base + 64 + lane < n) diag_next = mk[(size_t)(base + 64 + lane) * w64 + (c + 1)];
-    // resolve the chunk's own 64x64 block serially with wave-uniform bit arithmetic
-    unsigned long long rsel = removed[0];
-    if constexpr (WPL > 1) { if (c >= 64) rsel = removed[1]; }
-    const unsigned long long rem_c = readlane64(rsel, c & 63);
+    const unsigned long long diag = diag_cur;
+    if (c + 1 < nchunks) diag_cur = (base + 64 + lane < n) ? mk[(size_t)(base + 64 + lane) * w64 + (c + 1)] : 0ull;
     const int nv = min(64, n - base);
-    unsigned long long alive = ~rem_c & (nv == 64 ? ~0ull : ((1ull << nv) - 1ull));
-    unsigned long long keptmask = 0ull;
-    while (alive) {
-      const int bit = __builtin_ctzll(alive);
-      keptmask |= 1ull << bit;
-      alive &= ~readlane64(diag, bit);
-      alive &= ~(1ull << bit);
-    }
-    // emit kept boxes in rank order
-    const bool mine = (keptmask >> lane) & 1ull;
-    if (mine) {
-      const int o = kept + __popcll(keptmask & ((1ull << lane) - 1ull));
-      const float4 bx = b[base + lane];
-      float *q = kout + (size_t)o * 5;
-      q[0] = bx.x; q[1] = bx.y; q[2] = bx.z; q[3] = bx.w; q[4] = sc[base + lane];
-      if (kidx) kidx[o] = si[base + lane];
-    }
-    kept += __popcll(keptmask);
-    // fold the kept rows into `removed` (words after this chunk)
-    unsigned long long acc = 0ull;
-#pragma unroll
-    for (int r = 0; r < 64; ++r) acc |= ((keptmask >> r) & 1ull) ? rows[r] : 0ull;
-    removed[0] |= acc;
-    if constexpr (WPL > 1) {  // second word per lane (m > 4096): non-speculative, batched
-      const int wsec = lane + 64;
-      if (wsec < w64 && wsec > c) {
-        unsigned long long km = keptmask;
-        unsigned long long acc2 = 0ull;
-        while (km) {
-          const int r = __builtin_ctzll(km);
-          km &= km - 1;
-          acc2 |= mk[(size_t)(base + r) * w64 + wsec];
+    const unsigned long long valid = nv == 64 ? ~0ull : ((1ull << nv) - 1ull);
+    // A chunk is resolved in passes: alive ranks below the first alive rank that carries a tie bit go through the tie-free
+    // rule (bit arithmetic on the diagonal word, rows folded in a batch, heads replayed from registers); a first alive rank
+    // WITH a tie bit is resolved by the exact pick-by-pick rule; repeat until the chunk is done.
+    for (;;) {
+      const unsigned long long rem_c = word_of(c);
+      unsigned long long alive_all = ~rem_c & valid;
+      if (!alive_all) break;
+      const unsigned long long tiesel = replay ? (alive_all & tie_word(c)) : 0ull;
+      const int first = __builtin_ctzll(alive_all);
+      if (tiesel && __builtin_ctzll(tiesel) == first) {
+        // ---- exact rule for one pick: among the alive members of r0's equal-score run, the one sitting first in the array
+        const int r0 = base + first;
+        int e = r0;  // last rank of the run = the first rank >= r0 whose tie bit is clear
+        for (;;) {
+          const unsigned long long ones = tie_word(e >> 6) >> (e & 63);
+          const int span = 64 - (e & 63);
+          const int cnt = (~ones) ? __builtin_ctzll(~ones) : 64;
+          if (cnt < span) { e += cnt; break; }
+          e += span;
+          if (e >= n) { e = n - 1; break; }
         }
-        removed[1] |= acc2;
+        int bp = 0x7fffffff, br = -1;
+        for (int rr = r0; rr <= e; rr += kWave) {
+          const int r = rr + lane;
+          bool ok = r <= e;
+          const int w = (ok ? r : r0) >> 6;
+          unsigned long long rw = shfl64(removed[0], w & 63);
+          if constexpr (WPL > 1) { const unsigned long long r1 = shfl64(removed[1], w & 63); if (w >= 64) rw = r1; }
+          ok = ok && !((rw >> (r & 63)) & 1ull);
+          const int p = ok ? (int)pos[r] : 0x7fffffff;
+          if (p < bp) { bp = p; br = r; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          const int op = __shfl_xor(bp, off), orr = __shfl_xor(br, off);
+          if (op < bp) { bp = op; br = orr; }
+        }
+        const int pick = __builtin_amdgcn_readfirstlane(br);
+        const int round = kept + 1;
+        if (lane == 0) {
+          const float4 bx = b[pick];
+          float *q = kout + (size_t)kept * 5;
+          q[0] = bx.x; q[1] = bx.y; q[2] = bx.z; q[3] = bx.w; q[4] = sc[pick];
+          if (kidx) kidx[kept] = si[pick];
+          death[pick] = (short)round;
+        }
+#pragma unroll
+        for (int h = 0; h < WPL; ++h) {
+          const int w = lane + 64 * h;
+          if (w < w64 && w * 64 < m) {
+            const unsigned long long row = mk[(size_t)pick * w64 + w];
+            unsigned long long newly = row & ~removed[h];
+            if (w == (pick >> 6)) newly &= ~(1ull << (pick & 63));
+            record_deaths(newly, w, round);
+            removed[h] |= row;
+            if (w == (pick >> 6)) removed[h] |= 1ull << (pick & 63);
+          }
+        }
+        __syncthreads();
+        window_load(hp & ~63);  // deaths changed: refresh the cached window
+        head_step(round, pick, __builtin_amdgcn_readfirstlane((int)pos[pick]), -1);
+        __syncthreads();
+        ++kept;
+        continue;
       }
+      // ---- tie-free rule for the alive ranks below `limit`
+      NMS_STAMP(0);
+      const int limit = tiesel ? __builtin_ctzll(tiesel) : 64;
+      const unsigned long long lim_mask = limit == 64 ? ~0ull : ((1ull << limit) - 1ull);
+      // speculative: the rows of this range, this lane's word(s) — independent loads, all in flight
+      unsigned long long rows[64];
+      if (lane > c && lane < w64) {  // unconditional loads off one base pointer (rows past n / the range are read but never used)
+        const unsigned long long *rp = mk + (size_t)base * w64 + lane;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) rows[r] = rp[(size_t)r * w64];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 64; ++r) rows[r] = 0ull;
+      }
+      // resolve the range: rank l is kept iff it is alive and no KEPT lower rank overlaps it.  That recurrence has a unique
+      // solution, so any fixpoint of "kept_l = alive_l && !(lower overlapping ranks & kept)" is the greedy answer; starting from
+      // kept = alive it settles in (longest suppression chain) rounds of one ballot each, all 64 ranks at once — a serial
+      // ctz / readlane walk measured ~150 cycles per kept box, a static 64-step SALU walk 85 per rank.
+      unsigned long long keptmask, diag_acc;
+      {
+        const unsigned long long alive0 = alive_all & lim_mask;
+        const unsigned long long lower = diag & ((1ull << lane) - 1ull);   // the symmetric diagonal word: lower ranks that overlap me
+        const bool alive_l = (alive0 >> lane) & 1ull;
+        NMS_STAMP(1);
+        keptmask = alive0;
+        for (;;) {
+          const unsigned long long kn = __ballot(alive_l && !(lower & keptmask));
+          if (kn == keptmask) break;
+          keptmask = kn;
+        }
+        diag_acc = __ballot((diag & keptmask) != 0ull);  // every rank of the chunk overlapped by a kept one
+      }
+      if (replay) {
+        // death rounds of this chunk's ranks, all lanes at once: a picked rank dies in its own round; a suppressed one in the round of
+        // the FIRST kept rank that overlaps it — the rows are symmetric (flag 3), so that is the lowest set bit of
+        // (own row & kept ranks below it)
+        const bool was_alive = (alive_all >> lane) & 1ull;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const bool picked = (keptmask >> lane) & 1ull;
+        const unsigned long long killers = diag & keptmask & below;
+        if (was_alive && (picked || killers)) {
+          const int kr = picked ? lane : __builtin_ctzll(killers);
+          death[base + lane] = (short)(kept + __popcll(keptmask & ((1ull << kr) - 1ull)) + 1);
+        }
+      }
+      // emit kept boxes in rank order
+      NMS_STAMP(2);
+      const bool mine = (keptmask >> lane) & 1ull;
+      if (mine) {
+        const int o = kept + __popcll(keptmask & ((1ull << lane) - 1ull));
+        const float4 bx = b[base + lane];
+        float *q = kout + (size_t)o * 5;
+        q[0] = bx.x; q[1] = bx.y; q[2] = bx.z; q[3] = bx.w; q[4] = sc[base + lane];
+        if (kidx) kidx[o] = si[base + lane];
+      }
+      // fold the kept rows into `removed`: words after this chunk, and the chunk's own word (resolved range + in-chunk kills)
+      NMS_STAMP(3);
+      if (replay) {
+        unsigned long long run = removed[0];
+        int rnd = kept;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) {
+          if ((keptmask >> r) & 1ull) {  // wave-uniform
+            ++rnd;
+            record_deaths(rows[r] & ~run, lane, rnd);
+            run |= rows[r];
+          }
+        }
+        removed[0] = run;
+      } else {
+        unsigned long long acc = 0ull;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) acc |= ((keptmask >> r) & 1ull) ? rows[r] : 0ull;
+        removed[0] |= acc;
+      }
+      if (lane == c) removed[0] |= (valid & lim_mask) | (diag_acc & valid);
+      if constexpr (WPL > 1) {  // second word per lane (m > 4096): non-speculative, batched
+        const int wsec = lane + 64;
+        if (wsec < w64 && wsec > c) {
+          unsigned long long km = keptmask;
+          int rnd = kept;
+          while (km) {
+            const int r = __builtin_ctzll(km);
+            km &= km - 1;
+            ++rnd;
+            const unsigned long long row = mk[(size_t)(base + r) * w64 + wsec];
+            if (replay) record_deaths(row & ~removed[1], wsec, rnd);
+            removed[1] |= row;
+          }
+        }
+        if (wsec == c) removed[1] |= (valid & lim_mask) | (diag_acc & valid);
+      }
+      NMS_STAMP(4);
+      if (replay) {
+        __syncthreads();
+        window_load(hp & ~63);
+        int posr = base + lane < m ? (int)pos[base + lane] : 0;  // slots of this chunk's ranks, kept current in registers
+        // Heads of this chunk's rounds.  Eligibility masks (slot holds a box alive at the round) for 8 rounds at a time are 8
+        // independent ballots; the sweep itself is SALU; the moved box and the pick's slot are read with readlane only to feed LDS
+        // writes and a rare-path test (a move INTO the register window, or the window running out).
+        unsigned long long km = keptmask;
+        int rnd = kept;
+        while (km) {
+          unsigned long long elig[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) elig[q] = __ballot(wf >= 0 && wd >= rnd + 1 + q);
+          bool redo = false;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            if (km && !redo) {
+              const int sh = hp - W0;
+              const unsigned long long cand = sh >= 64 ? 0ull : (elig[q] & (~0ull << sh));
+              if (!cand) { redo = true; hp = W0 + 64; window_load(hp & ~63); }   // window exhausted: reload and recompute the masks
+              else {
+                const int r = __builtin_ctzll(km);
+                km &= km - 1;
+                ++rnd;
+                const int l = __builtin_ctzll(cand);
+                const int f = __builtin_amdgcn_readlane(wf, l), fd = __builtin_amdgcn_readlane(wd, l);
+                const int sb = __builtin_amdgcn_readlane(posr, r);
+                hp = W0 + l + 1;
+                // boxes[0] <-> boxes[best] (nms.c:83-85): the old head takes the pick's slot (a no-op when the head IS the pick)
+                if (lane == 0) { occ[sb] = (short)f; pos[f] = (short)sb; }
+                if (lane == f - base) posr = sb;
+                if (sb - W0 < 64) {  // rare: the move lands inside the register window -> later rounds' masks change
+                  if (lane == sb - W0) { wf = f; wd = fd; }
+                  redo = true;
+                }
+              }
+            }
+          }
+        }
+        __syncthreads();
+      }
+      NMS_STAMP(5);
+      kept += __popcll(keptmask);
+      if (limit == 64) break;
     }
-    diag = diag_next;
   }
   if (lane == 0) n_keep[cls] = kept;
 }
@@ -348,10 +613,6 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float4 *__restrict__
 // equal-score run take the smallest slot -> head = first occupied slot holding an alive box (lazy
 // deletion) -> the head inherits the pick's slot -> alive &= ~row[pick].  One wave per class does the
 // serial part; the block's other waves only help stage the mask into LDS.
-__device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int l) {
-  unsigned lo = __shfl((unsigned)v, l), hi = __shfl((unsigned)(v >> 32), l);
-  return ((unsigned long long)hi << 32) | lo;
-}
 
 template <bool LDSMASK>
 __global__ __launch_bounds__(256) void nms_tie_kernel(const float4 *__restrict__ sbox, const float *__restrict__ sscore,
@@ -579,9 +840,11 @@ __global__ void boxoverlap_kernel(const float *__restrict__ a, int n, float bx1,
 
 using namespace mpn;
 
-MPN_KNOB(int, g_nms_force_exact, 0);  // test hook: 1 = always the exact IoU-sweep kernel, 2 = always the tie (slot-emulation) kernel
+MPN_KNOB(int, g_nms_force_exact, 0);  // test hook: 1 = always the exact IoU-sweep kernel, 2 = always the tie (slot-emulation) kernel, 3 = always the replaying scan
+MPN_KNOB(unsigned long long *, g_nms_trace, nullptr);
 #ifdef MPN_DEBUG_HOOKS
 extern "C" void mpn_debug_set_nms_force_exact(int v) { g_nms_force_exact = v; }
+extern "C" void mpn_debug_set_nms_trace(void *p) { g_nms_trace = static_cast<unsigned long long *>(p); }
 #endif
 
 extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n_cls, int m_stride, float thr,
@@ -609,7 +872,7 @@ extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n
   const int w64 = (m_stride + 63) / 64;
   const size_t n_rows = (size_t)n_cls * m_stride;
   const size_t need = n_rows * (sizeof(float4) + sizeof(float) + sizeof(int)) + n_rows * w64 * sizeof(unsigned long long) +
-                      (size_t)n_cls * 2 * sizeof(int) + 256;
+                      (size_t)n_cls * 2 * sizeof(int) + 256 + (size_t)64 * w64 * sizeof(unsigned long long);  // + a chunk of rows the scan may over-read
   char *scratch = nullptr;
   {
     void *ws = nullptr;
@@ -655,13 +918,20 @@ extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n
         }
       }
     }
-    if (w64 <= 64)
-      hipLaunchKernelGGL(nms_scan_kernel<1>, dim3(n_cls), dim3(kWave), 0, st, sbox, sscore, sidx, n_sel, flags, m_stride, w64, mask,
-                         d_keep, d_keep_idx, d_n_keep);
-    else
-      hipLaunchKernelGGL(nms_scan_kernel<2>, dim3(n_cls), dim3(kWave), 0, st, sbox, sscore, sidx, n_sel, flags, m_stride, w64, mask,
-                         d_keep, d_keep_idx, d_n_keep);
-    MPN_CHECK_LAUNCH();
+    {
+      const int scap = (m_stride + 7) & ~7;
+      const size_t slds = (size_t)3 * scap * sizeof(short);
+      int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(nms_scan_kernel<1>), 3 * 4096 * 2);
+      if (rc_attr == MPN_OK) rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(nms_scan_kernel<2>), 3 * 8192 * 2);
+      if (rc_attr) return rc_attr;
+      if (w64 <= 64)
+        hipLaunchKernelGGL(nms_scan_kernel<1>, dim3(n_cls), dim3(kWave), slds, st, sbox, sscore, sidx, n_sel, flags, d_counts, m_stride, w64, mask,
+                           d_keep, d_keep_idx, d_n_keep, scap, g_nms_trace);
+      else
+        hipLaunchKernelGGL(nms_scan_kernel<2>, dim3(n_cls), dim3(kWave), slds, st, sbox, sscore, sidx, n_sel, flags, d_counts, m_stride, w64, mask,
+                           d_keep, d_keep_idx, d_n_keep, scap, g_nms_trace);
+      MPN_CHECK_LAUNCH();
+    }
   }
   int m_cap = (m_stride + 3) & ~3;
   size_t lds = (size_t)m_cap * 6 * sizeof(float);

@@ -16,10 +16,11 @@ def _t(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["auto", "sweepkernel", "tiekernel"])
+@pytest.fixture(params=[0, 1, 2, 3], ids=["auto", "sweepkernel", "tiekernel", "replayscan"])
 def nms_path(request):
-    """0 = default dispatch (chunked bitmask scan for tie-free classes, slot-emulating tie kernel for classes with
-    bit-equal scores, IoU-sweep kernel for NaN / oversize); 1 = IoU-sweep kernel only; 2 = tie kernel wherever it applies"""
+    """0 = default dispatch (chunked bitmask scan — with the position replay for classes with a few tied pairs —, the slot-emulating
+    tie kernel for classes with many bit-equal scores, the IoU-sweep kernel for NaN / oversize); 1 = IoU-sweep kernel only; 2 = tie
+    kernel wherever it applies; 3 = the replaying scan for every class, however many ties it has (its pick-by-pick rule)"""
     with hooks(nms_force_exact=request.param):  # 0 = the product library's own dispatch
         yield request.param
 

@@ -11,19 +11,32 @@ lib = multipathnet_amd._lib.load("debug")  # libmpn_hip_dbg.so: the flavour with
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(0)
 n_cls, M = 20, int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-for regime in ("distinct", "ties", "saturated"):
-    sb = np.stack([random_scored_boxes(rng, M, regime) for _ in range(n_cls)])
+only_regimes = sys.argv[2].split(",") if len(sys.argv) > 2 else None   # e.g. fewties
+only_modes = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else None   # e.g. 0,3
+from multipathnet_amd import _lib
+for regime in ("distinct", "fewties", "ties", "saturated"):
+    if only_regimes and regime not in only_regimes:
+        continue
+    sb = np.stack([random_scored_boxes(rng, M, "distinct" if regime == "fewties" else regime) for _ in range(n_cls)])
+    if regime == "fewties":  # what real softmax scores look like: a handful of bit-equal pairs per class
+        for c in range(n_cls):
+            k = rng.choice(M, 8, replace=False)
+            sb[c, k[:4], 4] = sb[c, k[4:], 4]
     d = torch.from_numpy(sb).to(dev)
-    for mode, name in ((0, "auto"), (2, "tie-kernel"), (1, "sweep-kernel")):
+    for mode, name in ((0, "auto"), (3, "replay-scan"), (2, "tie-kernel"), (1, "sweep-kernel")):
+        if only_modes and mode not in only_modes:
+            continue
         lib.mpn_debug_set_nms_force_exact(mode)
-        for _ in range(2):
+        with _lib.debug_hooks():
+          for _ in range(2):
             keep, idx, nk = utils.nms_batched(d, None, 0.3)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(5):
+        with _lib.debug_hooks():
+          for _ in range(5):
             keep, idx, nk = utils.nms_batched(d, None, 0.3)
         e1.record()
         torch.cuda.synchronize()
-        print("%-9s M=%d %-12s %8.1f us/call  kept/class mean %.0f" % (regime, M, name, e0.elapsed_time(e1) / 5 * 1e3, nk.float().mean().item()))
+        print("%-9s M=%d %-12s %8.1f us/call (20 classes, %.1f us/class if serial)  kept/class mean %.0f" % (regime, M, name, e0.elapsed_time(e1) / 5 * 1e3, e0.elapsed_time(e1) / 5 * 1e3 / n_cls, nk.float().mean().item()))
 lib.mpn_debug_set_nms_force_exact(0)
