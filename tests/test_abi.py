@@ -33,7 +33,9 @@ def test_product_library_has_no_test_hooks():
     dbg = os.path.join(ROOT, "multipathnet_amd", "libmpn_hip_dbg.so")
     sym = subprocess.check_output(["nm", "-D", "--defined-only", so]).decode()
     assert "mpn_debug" not in sym
-    assert not re.search(r"conv3x3_wino_kernel.*Li[1-9]", sym), "ablation instantiations of the Winograd kernel in the product build"
+    # conv3x3_wino_kernel<ABL, TC>: only ABL = 0 (no timing-experiment switches) ships; TC = 8 / 16 are the two block geometries
+    assert not re.search(r"conv3x3_wino_kernelILi[1-9]", sym), "ablation instantiations of the Winograd kernel in the product build"
+    assert re.search(r"conv3x3_wino_kernelILi0ELi8E", sym) and re.search(r"conv3x3_wino_kernelILi0ELi16E", sym)
     dsym = subprocess.check_output(["nm", "-D", "--defined-only", dbg]).decode()
     assert "mpn_debug_set_conv_variant" in dsym and "mpn_debug_set_nms_force_exact" in dsym
     for n in _declared("mpn.h"):
