@@ -302,7 +302,8 @@ typedef struct mpn_resnet_weights {
 int mpn_resnet_create(const mpn_frcnn_config *cfg, const mpn_resnet_weights *rw, const float *d_cls_w, const float *d_cls_b,
                       const float *d_bbox_w, const float *d_bbox_b, mpn_frcnn **out);
 
-/* Branching conv graphs (models/inceptionv3.lua:27-43, BASELINE configs[4]): the trunk (net:get(1..25)) and the per-ROI
+/* Branching conv graphs (models/inceptionv3.lua:27-43, BASELINE configs[4]; models/alexnet.lua:14-27, BASELINE configs[0], whose
+ * `top` — fc6 / fc7 on the flattened 6x6 ROI-pooled map — is a 6x6 and a 1x1 convolution in the head list): the trunk (net:get(1..25)) and the per-ROI
  * classifier (net:get(26..30)) as two op lists over numbered tensors.  Tensor 0 of the trunk list is the transformed image
  * (3 channels); tensor 0 of the head list is the ROI-pooled map (cfg->pooled_h x pooled_w, channels of `feat_tensor`); the head's
  * `out_tensor` is averaged over its whole map (the graph's final SpatialAveragePooling + View) and feeds classAndBBoxLinear.
@@ -312,13 +313,20 @@ int mpn_resnet_create(const mpn_frcnn_config *cfg, const mpn_resnet_weights *rw,
  * The `.t7` (Moodstocks' conversion of Google's Inception-v3) is not in the tree: PARITY UNPINNED, structure from the public
  * definition. */
 typedef struct mpn_graph_op {
-  int kind;               /* 0 = convolution (+ bias, ReLU if relu), 1 = max-pool (floor mode, padded cells never win),
-                             2 = average pool, count_include_pad (nn.SpatialAveragePooling's default: always / (kh*kw)) */
+  int kind;               /* 0 = convolution (+ bias, ReLU if relu), 1 = max-pool (padded cells never win; floor mode unless ceil_mode),
+                             2 = average pool, count_include_pad (nn.SpatialAveragePooling's default: always / (kh*kw)),
+                             3 = cross-channel LRN, nn.SpatialCrossMapLRN(size = kh, lrn_alpha, lrn_beta, lrn_k) (alexnet.lua's trunk):
+                                 out_c = in_c * (lrn_k + lrn_alpha / size * sum_{|c' - c| <= (size-1)/2} in_c'^2) ^ -lrn_beta */
   int src, dst, dst_c_off;
   int cin, cout;          /* conv: weight shape [cout, cin, kh, kw]; pools: cin = channels of src */
   int kh, kw, sh, sw, ph, pw;
   int relu;
   const float *w, *b;     /* conv only, device pointers */
+  int src_c_off;          /* the op reads channels [src_c_off, src_c_off + cin) of `src` (a multiple of 8; 0 = from the first): a grouped
+                             convolution (alexnet.lua's conv2 / conv4 / conv5, groups = 2) is one op per group */
+  int ceil_mode;          /* max-pool: nn.SpatialMaxPooling(...):ceil() / Caffe output size — ceil((H + 2p - k) / s) + 1, minus one when the
+                             last window would start beyond the padded input */
+  float lrn_alpha, lrn_beta, lrn_k;   /* kind 3 */
 } mpn_graph_op;
 typedef struct mpn_graph_weights {
   int n_trunk_ops;  const mpn_graph_op *trunk_ops;  int n_trunk_tensors;  const int *trunk_tensor_c;  int feat_tensor;

@@ -59,7 +59,8 @@ class GraphOp(C.Structure):
     """mirror of mpn_graph_op (include/mpn.h)"""
     _fields_ = [("kind", C.c_int), ("src", C.c_int), ("dst", C.c_int), ("dst_c_off", C.c_int), ("cin", C.c_int), ("cout", C.c_int),
                 ("kh", C.c_int), ("kw", C.c_int), ("sh", C.c_int), ("sw", C.c_int), ("ph", C.c_int), ("pw", C.c_int), ("relu", C.c_int),
-                ("w", f32p), ("b", f32p)]
+                ("w", f32p), ("b", f32p), ("src_c_off", C.c_int), ("ceil_mode", C.c_int), ("lrn_alpha", C.c_float), ("lrn_beta", C.c_float),
+                ("lrn_k", C.c_float)]
 
 
 class GraphWeights(C.Structure):

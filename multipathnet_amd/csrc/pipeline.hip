@@ -895,7 +895,7 @@ extern "C" int mpn_frcnn_nms_results(mpn_frcnn *p, const float **d_keep, const i
 
 extern "C" int mpn_frcnn_debug_tensor(mpn_frcnn *p, const char *name, const float **d_ptr, size_t *n_elems) {
   MPN_CHECK_ARG(p && name && d_ptr && n_elems);
-  if (p->last_h <= 0 || p->last_n <= 0) { set_error("mpn_frcnn_debug_tensor: run detect first"); return MPN_ESTATE; }
+  if (p->last_n <= 0 || (!p->rn && p->last_h <= 0)) { set_error("mpn_frcnn_debug_tensor: run detect first"); return MPN_ESTATE; }
   const mpn_frcnn_config &c = p->cfg;
   const int N = p->last_n, C = c.n_classes, F = c.fc_dim, PP = c.pooled_h * c.pooled_w;
   int h = p->last_h, w = p->last_w;
@@ -909,6 +909,7 @@ extern "C" int mpn_frcnn_debug_tensor(mpn_frcnn *p, const char *name, const floa
   else if (nm == "bbox_raw") n = (size_t)N * 4 * C;
   else { set_error("mpn_frcnn_debug_tensor: unknown tensor '%s'", name); return MPN_EINVAL; }
   if (p->is_mpnet && nm != "conv5" && nm != "bbox_raw") { set_error("mpn_frcnn_debug_tensor: '%s' is not kept by the MultiPathNet head", name); return MPN_EINVAL; }
+  if (p->rn && nm != "bbox_raw" && !(nm == "cls" && p->rn_region.empty())) { set_error("mpn_frcnn_debug_tensor: '%s' is not kept by the op-list / ResNet pipelines", name); return MPN_EINVAL; }
   MPN_CHECK_HIP(hipDeviceSynchronize());
   if (n * sizeof(float) > p->dbg_bytes) {
     if (p->dbg) (void)hipFree(p->dbg);

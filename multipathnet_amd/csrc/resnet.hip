@@ -1336,6 +1336,46 @@ __global__ __launch_bounds__(256) void avgpool2d_c8i_bf16_small_kernel(const bf1
 // ------------------------------------------------------------------------------------------------------------------------
 // graph
 // ------------------------------------------------------------------------------------------------------------------------
+// nn.SpatialCrossMapLRN(size, alpha, beta, k) on C8I (models/alexnet.lua's trunk: norm1 / norm2): one thread per (pixel row, channel
+// block); the window spans at most one block either side (size <= 17).  fp32, squares summed in ascending channel order.
+__global__ void lrn_c8i_kernel(const float *__restrict__ in, int Cb, int C, size_t rows, size_t pitch_in, int size, float alpha, float beta, float k,
+                               size_t pitch_out, float *__restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * Cb) return;
+  const size_t row = t % rows;
+  const int cb = (int)(t / rows);
+  float v[24];  // channels 8*cb - 8 .. 8*cb + 15
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int b = cb - 1 + q;
+    f32x4 lo = f32x4{0, 0, 0, 0}, hi = lo;
+    if (b >= 0 && b < Cb) {
+      const float *p = in + ((size_t)b * pitch_in + row) * 8;
+      lo = *reinterpret_cast<const f32x4 *>(p); hi = *reinterpret_cast<const f32x4 *>(p + 4);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[q * 8 + e] = lo[e]; v[q * 8 + 4 + e] = hi[e]; }
+  }
+  const int half = (size - 1) / 2;
+  const float a = alpha / (float)size;
+  float o[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = cb * 8 + j;
+    float ssum = 0.0f;
+#pragma unroll
+    for (int d = -8; d <= 8; ++d) {  // static register indices; the window is [-half, half]
+      const int cc = c + d;
+      if (d >= -half && d <= half && cc >= 0 && cc < C) { const float x = v[8 + j + d]; ssum = ssum + x * x; }
+    }
+    const float sc = k + a * ssum;
+    o[j] = c < C ? v[8 + j] * powf(sc, -beta) : 0.0f;
+  }
+  float *q = out + ((size_t)cb * pitch_out + row) * 8;
+  *reinterpret_cast<f32x4 *>(q) = f32x4{o[0], o[1], o[2], o[3]};
+  *reinterpret_cast<f32x4 *>(q + 4) = f32x4{o[4], o[5], o[6], o[7]};
+}
+
 struct RnConv {
   int Cin = 0, Cout = 0, K = 0, stride = 1, pad = 0;  // square form (ResNet); KH/KW/sh/sw/ph/pw below are what the kernels use
   int KH = 0, KW = 0, sh = 1, sw = 1, ph = 0, pw = 0;
@@ -1358,6 +1398,8 @@ struct GTensor {
 };
 struct GOp {
   int kind = 0, src = 0, dst = 0, dst_c_off = 0, kh = 1, kw = 1, sh = 1, sw = 1, ph = 0, pw = 0, relu = 0;
+  int src_c_off = 0, cin = 0, ceil_mode = 0;   // the op reads channels [src_c_off, src_c_off + cin) of src
+  float lrn_alpha = 0.f, lrn_beta = 0.f, lrn_k = 1.f;
   RnConv conv;
   float *pool_bias = nullptr;  // average pool only: bias (+ ReLU if relu) applied after the pool (commuted pool -> pointwise convolution)
 };
@@ -1705,8 +1747,15 @@ bool resnet_has_features(const ResNetGraph *g, int H, int W) { return g->feat &&
 
 // ---- op-list graphs ----------------------------------------------------------------------------------------------------
 static void gop_out_dims(const GOp &op, int h, int w, int &oh, int &ow) {
+  if (op.kind == 3) { oh = h; ow = w; return; }  // LRN
   oh = (h + 2 * op.ph - op.kh) / op.sh + 1;
   ow = (w + 2 * op.pw - op.kw) / op.sw + 1;
+  if (op.kind == 1 && op.ceil_mode) {  // nn.SpatialMaxPooling:ceil() / Caffe: round up, but the last window must start inside the padded input
+    oh = (h + 2 * op.ph - op.kh + op.sh - 1) / op.sh + 1;
+    ow = (w + 2 * op.pw - op.kw + op.sw - 1) / op.sw + 1;
+    if (op.ph > 0 && (oh - 1) * op.sh >= h + op.ph) --oh;
+    if (op.pw > 0 && (ow - 1) * op.sw >= w + op.pw) --ow;
+  }
 }
 
 // propagate the spatial dims of one op list from tensor 0's; checks that concatenated writers agree
@@ -1740,7 +1789,7 @@ static int graph_parse(ResNetGraph *g, int n_ops, const mpn_graph_op *ops_in, in
   std::vector<char> dead((size_t)n_ops, 0);
   std::vector<std::pair<int, int>> norelu_of((size_t)n_ops, std::make_pair(0, 0));  // fused op -> output channels without ReLU
   auto pointwise_private = [&](const mpn_graph_op &o) {
-    return o.kind == 0 && o.kh == 1 && o.kw == 1 && o.sh == 1 && o.sw == 1 && o.ph == 0 && o.pw == 0 && o.dst_c_off == 0 && o.dst > 0 &&
+    return o.kind == 0 && o.kh == 1 && o.kw == 1 && o.sh == 1 && o.sw == 1 && o.ph == 0 && o.pw == 0 && o.dst_c_off == 0 && o.src_c_off == 0 && o.dst > 0 &&
            o.dst < (int)ts.size() && o.src >= 0 && o.src < (int)ts.size() && o.cout == ts[o.dst].C && o.cout % align == 0 && o.w;
   };
   // Commute  average-pool(3x3 / 1, pad 1, count_include_pad) -> pointwise convolution  (Inception's pool branches: 1280 / 2048
@@ -1749,7 +1798,7 @@ static int graph_parse(ResNetGraph *g, int n_ops, const mpn_graph_op *ops_in, in
   // move behind the pool.  (Intermediate rounding differs: fp32 sums in another order, bf16 rounds conv(x) instead of pool(x).)
   for (int i = 0; (g_graph_fuse & 2) && i < n_ops; ++i) {
     const mpn_graph_op pi = fused[i];
-    if (dead[i] || pi.kind != 2 || pi.kh != 3 || pi.kw != 3 || pi.sh != 1 || pi.sw != 1 || pi.ph != 1 || pi.pw != 1 || pi.dst_c_off != 0) continue;
+    if (dead[i] || pi.kind != 2 || pi.kh != 3 || pi.kw != 3 || pi.sh != 1 || pi.sw != 1 || pi.ph != 1 || pi.pw != 1 || pi.dst_c_off != 0 || pi.src_c_off != 0) continue;
     if (pi.dst <= 0 || pi.dst >= n_t || pi.src < 0 || pi.src >= n_t || tc[pi.dst] != tc[pi.src] || ts[pi.src].alias_of >= 0) continue;
     int cons = -1, n_cons = 0, n_writers = 0;
     for (int j = 0; j < n_ops; ++j) {
@@ -1759,7 +1808,7 @@ static int graph_parse(ResNetGraph *g, int n_ops, const mpn_graph_op *ops_in, in
     }
     if (n_cons != 1 || n_writers != 1 || cons <= i) continue;
     const mpn_graph_op cj = fused[cons];
-    if (cj.kind != 0 || cj.kh != 1 || cj.kw != 1 || cj.sh != 1 || cj.sw != 1 || cj.ph != 0 || cj.pw != 0 || !cj.w || cj.cout % align != 0) continue;
+    if (cj.kind != 0 || cj.kh != 1 || cj.kw != 1 || cj.sh != 1 || cj.sw != 1 || cj.ph != 0 || cj.pw != 0 || !cj.w || cj.cout % align != 0 || cj.src_c_off != 0) continue;
     const int tid_new = (int)ts.size();
     GTensor tt; tt.C = cj.cout;
     ts.push_back(tt);
@@ -1822,17 +1871,27 @@ static int graph_parse(ResNetGraph *g, int n_ops, const mpn_graph_op *ops_in, in
   for (int i = 0; i < n_ops; ++i) {
     if (dead[i]) continue;
     const mpn_graph_op &o = fused[i];
-    MPN_CHECK_ARG(o.kind >= 0 && o.kind <= 2 && o.src >= 0 && o.src < n_t_all && o.dst > 0 && o.dst < n_t_all && o.src != o.dst);
+    MPN_CHECK_ARG(o.kind >= 0 && o.kind <= 3 && o.src >= 0 && o.src < n_t_all && o.dst > 0 && o.dst < n_t_all && o.src != o.dst);
     MPN_CHECK_ARG(o.kh > 0 && o.kw > 0 && o.sh > 0 && o.sw > 0 && o.ph >= 0 && o.pw >= 0 && o.dst_c_off >= 0 && o.dst_c_off % align == 0);
+    MPN_CHECK_ARG(o.src_c_off >= 0 && o.src_c_off % align == 0 && o.cin > 0);
+    if (o.kind == 3) {
+      if (g->bf16) { set_error("graph: op %d: cross-channel LRN is fp32 only", i); return MPN_EINVAL; }
+      MPN_CHECK_ARG(o.kh % 2 == 1 && o.kh <= 17 && o.lrn_beta > 0.0f);
+    }
     GOp op;
     op.kind = o.kind; op.src = o.src; op.dst = o.dst; op.dst_c_off = o.dst_c_off;
     op.kh = o.kh; op.kw = o.kw; op.sh = o.sh; op.sw = o.sw; op.ph = o.ph; op.pw = o.pw; op.relu = o.relu;
-    const int wc = o.kind == 0 ? o.cout : ts[o.src].C;  // channels written
-    if (o.cin != ts[o.src].C || o.dst_c_off + wc > ts[o.dst].C || (o.dst_c_off + wc < ts[o.dst].C && wc % align != 0)) {
+    op.src_c_off = o.src_c_off; op.cin = o.cin; op.ceil_mode = o.ceil_mode;
+    op.lrn_alpha = o.lrn_alpha; op.lrn_beta = o.lrn_beta; op.lrn_k = o.lrn_k;
+    const int wc = o.kind == 0 ? o.cout : o.cin;  // channels written
+    // a channel range inside a wider tensor must consist of whole channel blocks (its last block may be ragged only at the tensor's end)
+    if (o.src_c_off + o.cin > ts[o.src].C || (o.src_c_off + o.cin < ts[o.src].C && o.cin % align != 0) || o.dst_c_off + wc > ts[o.dst].C ||
+        (o.dst_c_off + wc < ts[o.dst].C && wc % align != 0)) {
       set_error("graph: op %d: channel mismatch (src %d has %d, writes %d at %d of %d)", i, o.src, ts[o.src].C, wc, o.dst_c_off, ts[o.dst].C);
       return MPN_EINVAL;
     }
     if (o.kind == 2 && o.b) {  // commuted pool: a private copy of the convolution's bias, padded to whole channel blocks
+      MPN_CHECK_ARG(o.src_c_off == 0 && o.cin == ts[o.src].C);
       const size_t nb = (size_t)round_up(ts[o.src].C, 8);
       int rc = rn_alloc(g, &op.pool_bias, nb * sizeof(float));
       if (rc) return rc;
@@ -1905,6 +1964,11 @@ static int graph_run(ResNetGraph *g, const std::vector<GOp> &ops, std::vector<GT
       const ActI pa{par.buf, B, par.C, par.H, par.W};
       src.buf = reinterpret_cast<float *>(reinterpret_cast<char *>(par.buf) + (size_t)(src.alias_c_off / 8) * pa.pitch() * 8 * esz);
     }
+    if (op.src_c_off > 0 || op.cin != src.C) {  // a channel range of the source (grouped convolutions): plane offset, narrower tensor
+      const ActI full{src.buf, B, src.C, src.H, src.W};
+      src.buf = reinterpret_cast<float *>(reinterpret_cast<char *>(src.buf) + (size_t)(op.src_c_off / 8) * full.pitch() * 8 * esz);
+      src.C = op.cin;
+    }
     GTensor &dst = ts[op.dst];
     const ActI in{src.buf, B, src.C, src.H, src.W};
     const ActI od{dst.buf, B, dst.C, dst.H, dst.W};
@@ -1918,7 +1982,11 @@ static int graph_run(ResNetGraph *g, const std::vector<GOp> &ops, std::vector<GT
     } else {
       const size_t total = (size_t)in.Cb() * B * dst.H * dst.W * 2;
       const dim3 grid((unsigned)cdiv_sz(total, 256)), grid16((unsigned)cdiv_sz(total / 2, 256));  // fp32: half records, bf16: whole records per thread
-      if (op.kind == 1) {
+      if (op.kind == 3) {
+        const size_t rows = (size_t)B * src.H * src.W;
+        hipLaunchKernelGGL(lrn_c8i_kernel, dim3((unsigned)cdiv_sz(rows * in.Cb(), 256)), dim3(256), 0, s, src.buf, in.Cb(), src.C, rows, in.pitch(), op.kh,
+                           op.lrn_alpha, op.lrn_beta, op.lrn_k, od.pitch(), reinterpret_cast<float *>(outp));
+      } else if (op.kind == 1) {
         MPN_CHECK_ARG(op.kh == op.kw && op.sh == op.sw && op.ph == op.pw);
         if (g->bf16)
           hipLaunchKernelGGL(maxpool2d_c8i_bf16_kernel, grid16, dim3(256), 0, s, reinterpret_cast<const bf16_t *>(src.buf), in.Cb(), B, src.H, src.W, in.pitch(),

@@ -203,11 +203,32 @@ class _GraphBuilder(object):
         self.ops.append(dict(kind=0, src=src, dst=dst, off=off, cin=cin, cout=cout, kh=kh, kw=kw, sh=s, sw=s, ph=ph, pw=pw, relu=1, w=w, b=b))
         return dst
 
-    def pool(self, kind, src, k, s, p, dst=None, off=0):
+    def pool(self, kind, src, k, s, p, dst=None, off=0, ceil=0):
         c = self.tc[src]
         if dst is None:
             dst = self.tensor(c)
-        self.ops.append(dict(kind=kind, src=src, dst=dst, off=off, cin=c, cout=c, kh=k, kw=k, sh=s, sw=s, ph=p, pw=p, relu=0, w=None, b=None))
+        self.ops.append(dict(kind=kind, src=src, dst=dst, off=off, cin=c, cout=c, kh=k, kw=k, sh=s, sw=s, ph=p, pw=p, relu=0, w=None, b=None, ceil=ceil))
+        return dst
+
+    def grouped_conv(self, src, cout, k, groups, s=1, p=0, scale=1.0):
+        """cudnn.SpatialConvolution(..., groups): one op per group — it reads its channel range of `src` (src_off) and writes its range
+        of the output (off)"""
+        cin = self.tc[src]
+        assert cin % (8 * groups) == 0 and cout % (8 * groups) == 0, "group channel ranges must be whole 8-channel blocks"
+        cg, og = cin // groups, cout // groups
+        dst = self.tensor(cout)
+        for gi in range(groups):
+            w = torch.randn(og, cg, k, k, generator=self.g) * ((2.0 / (cg * k * k)) ** 0.5 * scale)
+            b = torch.randn(og, generator=self.g) * 0.01
+            self.ops.append(dict(kind=0, src=src, dst=dst, off=gi * og, src_off=gi * cg, cin=cg, cout=og, kh=k, kw=k, sh=s, sw=s, ph=p, pw=p, relu=1, w=w, b=b))
+        return dst
+
+    def lrn(self, src, size=5, alpha=1e-4, beta=0.75, k=1.0):
+        """nn.SpatialCrossMapLRN(size, alpha, beta, k)"""
+        c = self.tc[src]
+        dst = self.tensor(c)
+        self.ops.append(dict(kind=3, src=src, dst=dst, off=0, cin=c, cout=c, kh=size, kw=1, sh=1, sw=1, ph=0, pw=0, relu=0, w=None, b=None,
+                             lrn=(alpha, beta, k)))
         return dst
 
     # Inception modules: every branch's last op writes into its slice of the module's output tensor (DepthConcat)
@@ -298,6 +319,46 @@ def synthetic_inception_v3_params(n_classes=21, seed=557, width=1.0, bbox_norm=T
     G["bbox_b"] = torch.zeros(4 * n_classes)
     G["bbox_mean"], G["bbox_std"] = ([0.0, 0.0, 0.0, 0.0], [0.1, 0.1, 0.2, 0.2]) if bbox_norm else (None, None)
     return G
+
+
+def synthetic_alexnet_params(n_classes=21, seed=557, width=1.0, fc_dim=4096, bbox_norm=True):
+    """BASELINE configs[0]: AlexNet / CaffeNet Fast R-CNN (models/alexnet.lua:14-27) as op lists.  `features` = the public Fast R-CNN
+    CaffeNet trunk — conv1 11x11/4 pad 5 (96) - ReLU - max-pool 3x3/2 pad 1 (ceil) - LRN(5, 1e-4, 0.75) - conv2 5x5 pad 2 groups 2 (256) -
+    ReLU - max-pool - LRN - conv3 3x3 (384) - conv4 3x3 groups 2 (384) - conv5 3x3 groups 2 (256), stride 16 — then
+    inn.ROIPooling(6,6,1/16), and `top` = fc6 / fc7 (4096, Dropout = identity in evaluate mode) expressed on the pooled [256,6,6] map as
+    a 6x6 and a 1x1 convolution (the View(-1) flattening is exactly the [cout][cin][6][6] weight order).  The reference's
+    imagenet_pretrained_alexnet.t7 is absent: structure from the public definition, seeded weights (PARITY UNPINNED).
+    `width` < 1 scales the channel counts (test-size networks; multiples of 16 so that the two groups stay whole channel blocks)."""
+    g = torch.Generator().manual_seed(seed)
+    tb = _GraphBuilder(3, g, width)
+    c = tb.ch
+    x = tb.conv(0, c(96), 11, s=4, p=5, damp=1.0 / 70.0)   # sees mean-subtracted 0..255 pixels (as synthetic_params' first conv)
+    x = tb.pool(1, x, 3, 2, 1, ceil=1)
+    x = tb.lrn(x)
+    x = tb.grouped_conv(x, c(256), 5, 2, p=2)
+    x = tb.pool(1, x, 3, 2, 1, ceil=1)
+    x = tb.lrn(x)
+    x = tb.conv(x, c(384), 3, p=1)
+    x = tb.grouped_conv(x, c(384), 3, 2, p=1)
+    x = tb.grouped_conv(x, c(256), 3, 2, p=1)
+    feat = x
+    hb = _GraphBuilder(tb.tc[feat], g, 1.0)
+    y = hb.conv(0, fc_dim, 6)     # fc6 on the 6x6 pooled map
+    y = hb.conv(y, fc_dim, 1)     # fc7
+    G = dict(trunk_ops=tb.ops, trunk_tensor_c=tb.tc, feat_tensor=feat, head_ops=hb.ops, head_tensor_c=hb.tc, out_tensor=y)
+    G["cls_w"] = torch.randn(n_classes, fc_dim, generator=g) * 0.01
+    G["cls_b"] = torch.zeros(n_classes)
+    G["bbox_w"] = torch.randn(4 * n_classes, fc_dim, generator=g) * 0.001
+    G["bbox_b"] = torch.zeros(4 * n_classes)
+    G["bbox_mean"], G["bbox_std"] = ([0.0, 0.0, 0.0, 0.0], [0.1, 0.1, 0.2, 0.2]) if bbox_norm else (None, None)
+    return G
+
+
+def AlexNetFRCNN(params, **kw):
+    """models/alexnet.lua graph as one device pipeline: ROIPooling(6,6,1/16), RossTransformer (alexnet.lua:23,32)"""
+    kw.setdefault("pooled", 6)
+    kw.setdefault("spatial_scale", 1.0 / 16)
+    return FastRCNN(params, **kw)
 
 
 def synthetic_inception_mpn_params(n_classes=81, n_integral=6, seed=557, regions=RESNET_MPN_REGIONS, **kw):
@@ -461,6 +522,9 @@ class FastRCNN(object):
                     a = arr[i]
                     a.kind, a.src, a.dst, a.dst_c_off, a.cin, a.cout = o["kind"], o["src"], o["dst"], o["off"], o["cin"], o["cout"]
                     a.kh, a.kw, a.sh, a.sw, a.ph, a.pw, a.relu = o["kh"], o["kw"], o["sh"], o["sw"], o["ph"], o["pw"], o["relu"]
+                    a.src_c_off, a.ceil_mode = o.get("src_off", 0), o.get("ceil", 0)
+                    if o["kind"] == 3:
+                        a.lrn_alpha, a.lrn_beta, a.lrn_k = o["lrn"]
                     if o["kind"] == 0:
                         wd, bd = d(o["w"]), d(o["b"])
                         keep.extend([wd, bd])

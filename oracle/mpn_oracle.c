@@ -590,6 +590,47 @@ void orc_maxpool2d(const float *in, int BC, int H, int W, int k, int stride, int
   }
 }
 
+/* nn.SpatialMaxPooling(k,k,s,s,p,p) with an explicit output size (:ceil() / Caffe rounding is decided by the caller): windows are
+ * clipped to the map, padded cells never win.  models/alexnet.lua's pool1 / pool2 (external nn rock; parity unpinned, cross-checked
+ * against PyTorch-CPU max_pool2d(ceil_mode=True)). */
+void orc_maxpool2d_out(const float *in, int BC, int H, int W, int k, int stride, int pad, int OH, int OW, float *out) {
+#pragma omp parallel for
+  for (int c = 0; c < BC; ++c) {
+    const float *ip = in + (size_t)c * H * W;
+    float *op = out + (size_t)c * OH * OW;
+    for (int oy = 0; oy < OH; ++oy)
+      for (int ox = 0; ox < OW; ++ox) {
+        float m = -INFINITY;
+        for (int ky = 0; ky < k; ++ky)
+          for (int kx = 0; kx < k; ++kx) {
+            const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) { const float v = ip[(size_t)iy * W + ix]; if (v > m) m = v; }
+          }
+        op[(size_t)oy * OW + ox] = m;
+      }
+  }
+}
+
+/* nn.SpatialCrossMapLRN(size, alpha, beta, k) (external nn rock; models/alexnet.lua's norm1 / norm2; parity unpinned, cross-checked
+ * against PyTorch-CPU local_response_norm): out_c = in_c * (k + alpha/size * sum_{|c'-c| <= (size-1)/2} in_c'^2) ^ -beta, squares
+ * summed in ascending channel order, fp32. */
+void orc_lrn(const float *in, int B, int C, int HW, int size, float alpha, float beta, float k, float *out) {
+  const int half = (size - 1) / 2;
+  const float a = alpha / (float)size;
+#pragma omp parallel for
+  for (int b = 0; b < B; ++b)
+    for (int c = 0; c < C; ++c)
+      for (int p = 0; p < HW; ++p) {
+        float ssum = 0.0f;
+        for (int d = -half; d <= half; ++d) {
+          const int cc = c + d;
+          if (cc >= 0 && cc < C) { const float x = in[((size_t)b * C + cc) * HW + p]; ssum = ssum + x * x; }
+        }
+        const float sc = k + a * ssum;
+        out[((size_t)b * C + c) * HW + p] = in[((size_t)b * C + c) * HW + p] * powf(sc, -beta);
+      }
+}
+
 /* nn.SpatialAveragePooling over the whole map (7x7 after layer4): sum in row-major order, then * 1/(H*W). */
 void orc_avgpool_global(const float *in, int BC, int H, int W, float *out) {
   const float inv = 1.0f / (float)(H * W);

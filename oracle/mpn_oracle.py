@@ -468,6 +468,34 @@ def maxpool2d(x, k=3, stride=2, pad=1):
     return out
 
 
+def pool_out_size(h, k, stride, pad, ceil_mode):
+    """nn.SpatialMaxPooling output size: floor mode, or :ceil() / Caffe (round up; the last window must start inside the padded input)"""
+    if not ceil_mode:
+        return (h + 2 * pad - k) // stride + 1
+    o = -(-(h + 2 * pad - k) // stride) + 1
+    if pad > 0 and (o - 1) * stride >= h + pad:
+        o -= 1
+    return o
+
+
+def maxpool2d_mode(x, k, stride, pad, ceil_mode):
+    x = _f32(x)
+    B, Cc, H, W = x.shape
+    OH, OW = pool_out_size(H, k, stride, pad, ceil_mode), pool_out_size(W, k, stride, pad, ceil_mode)
+    out = np.empty((B, Cc, OH, OW), np.float32)
+    lib().orc_maxpool2d_out(_p(x), B * Cc, H, W, k, stride, pad, OH, OW, _p(out))
+    return out
+
+
+def lrn(x, size=5, alpha=1e-4, beta=0.75, k=1.0):
+    """nn.SpatialCrossMapLRN(size, alpha, beta, k) on [B,C,H,W]"""
+    x = _f32(x)
+    B, Cc, H, W = x.shape
+    out = np.empty_like(x)
+    lib().orc_lrn(_p(x), B, Cc, H * W, int(size), C.c_float(alpha), C.c_float(beta), C.c_float(k), _p(out))
+    return out
+
+
 def avgpool_global(x):
     x = _f32(x)
     B, Cc, H, W = x.shape
@@ -595,10 +623,15 @@ def graph_run(x0, ops, tensor_c, bf16=False):
     ts[0] = x0
     for o in ops:
         x = ts[o["src"]]
+        c0 = o.get("src_off", 0)
+        if c0 or o["cin"] != x.shape[1]:  # a channel range of the source: one group of a grouped convolution
+            x = np.ascontiguousarray(x[:, c0:c0 + o["cin"]])
         if o["kind"] == 0:
             y = conv2d_rect(x, o["w"], o["b"], o["sh"], o["sw"], o["ph"], o["pw"], o["relu"], bf16)
         elif o["kind"] == 1:
-            y = maxpool2d(x, o["kh"], o["sh"], o["ph"])
+            y = maxpool2d_mode(x, o["kh"], o["sh"], o["ph"], o.get("ceil", 0))
+        elif o["kind"] == 3:
+            y = lrn(x, o["kh"], o["lrn"][0], o["lrn"][1], o["lrn"][2])
         else:
             y = avgpool2d(x, o["kh"], o["sh"], o["ph"])
             if bf16:

@@ -1,0 +1,63 @@
+"""BASELINE configs[0]: AlexNet / CaffeNet Fast R-CNN (models/alexnet.lua:14-27) through the op-list pipeline — grouped convolutions as
+channel-range ops, cross-channel LRN, ceil-mode max-pooling, inn.ROIPooling(6,6,1/16), fc6 / fc7 as a 6x6 / 1x1 convolution —
+against the oracle (cross-checked against PyTorch-CPU in tests/test_oracle_alexnet.py), at test size and at the config's full size
+(600x1000 image, 300 ROIs)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(H, W, N, seed):
+    rng = np.random.default_rng(seed)
+    im = rng.random((3, H, W), dtype=np.float32)
+    c = rng.uniform([1, 1], [W, H], (N, 2))
+    wh = np.exp(rng.uniform(np.log(12), np.log(min(H, W)), (N, 2)))
+    boxes = np.clip(np.concatenate([c - wh / 2, c + wh / 2], 1), 1, [W, H, W, H]).astype(np.float32)
+    return im, boxes
+
+
+@pytest.mark.parametrize("H,W,N,width", [(150, 250, 40, 0.25), (131, 97, 25, 0.5)])
+def test_alexnet_frcnn_vs_oracle(O, dev, H, W, N, width):
+    from multipathnet_amd import models
+    G = models.synthetic_alexnet_params(n_classes=6, width=width, fc_dim=128, seed=H)
+    Gn = models.graph_params_numpy(G)
+    im, boxes = _inputs(H, W, N, W)
+    net = models.AlexNetFRCNN(G, max_h=H, max_w=W, max_rois=64, top_k=20)
+    s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+    so, bo, _, _ = O.graph_detect(im, boxes, Gn, O.ROSS, target=min(H, W), max_size=max(H, W), pooled=6, spatial_scale=1.0 / 16)
+    assert np.abs(s.cpu().numpy() - so).max() < 1e-4
+    assert np.abs(b.cpu().numpy() - O.clamp_boxes(bo, W, H)).max() < 1e-4 * max(H, W)
+    # the whole testOne path runs on it too: per-class NMS of the device's rows == the oracle's
+    dets, n = net.test_one_async(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+    torch.cuda.synchronize()
+    keep, _, nk = [t.cpu().numpy() for t in net.nms_results()]
+    sn, bn = s.cpu().numpy(), b.cpu().numpy()
+    for j in range(1, 6):
+        sb, _ = O.select_scored(sn, bn, j, -1.5)
+        ref = O.nms(sb, 0.3)
+        assert nk[j - 1] == ref.shape[0] and np.array_equal(keep[j - 1, : nk[j - 1]], ref)
+
+
+def test_alexnet_fullsize_config0(O, dev):
+    """configs[0] at full size: 600x1000 image, 300 ROIs, 21 classes, full-width CaffeNet (conv5 map 39 x 64 at stride 16).  The oracle
+    runs the whole trunk and the head of a 60-ROI sample; logits / deltas within 1e-4 absolute."""
+    from multipathnet_amd import models
+    H, W, N = 600, 1000, 300
+    G = models.synthetic_alexnet_params(n_classes=21, seed=557)
+    Gn = models.graph_params_numpy(G)
+    im, boxes = _inputs(H, W, N, 556)
+    net = models.AlexNetFRCNN(G, max_h=H, max_w=W, max_rois=N)
+    s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+    s, b = s.cpu().numpy(), b.cpu().numpy()
+    assert np.abs(s.sum(1) - 1).max() < 1e-5
+    idx = np.random.default_rng(5).choice(N, 60, replace=False)
+    so, bo, logits, deltas = O.graph_detect(im, boxes[idx], Gn, O.ROSS, pooled=6, spatial_scale=1.0 / 16)
+    assert np.abs(s[idx] - so).max() < 1e-4
+    assert np.abs(b[idx] - O.clamp_boxes(bo, W, H)).max() < 1e-2
+    raw = net.debug_tensor("bbox_raw", (N, 4 * 21)).cpu().numpy()
+    assert np.abs(raw[idx] - deltas).max() < 1e-4
+    dets, n = net.test_one_async(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+    torch.cuda.synchronize()
+    assert 0 < int(n.item()) <= dets.size(0)
