@@ -16,7 +16,16 @@ for set in "sq:GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_A
   python $R/tools/pmc_summary.py $D > $OUT/${TAG}_pmc_$name.summary.txt 2>&1
 done
 ls -la $OUT
-# the two widened configurations (not bench.py lines): per-kernel stats + the tools' own timing lines
+# the other BASELINE configs as bench.py lines (own metric strings, never the headline)
+for c in c1 c3 c4 c5; do
+  timeout 600 python $R/bench.py --config $c --steps 6 --warmup 2 > $OUT/${TAG}_bench_$c.json 2> /tmp/bench_$c.err
+done
+timeout 600 python $R/bench.py --config c4 --dtype bf16 --steps 6 --warmup 2 > $OUT/${TAG}_bench_c4_bf16.json 2> /tmp/bench_c4b.err
+# NMS: per-path latency on the SURVEY 8d micro-inputs + the chunked scan's per-chunk cycle trace
+timeout 300 python $R/tools/bench_nms.py > $OUT/${TAG}_nms_paths.txt 2>&1
+timeout 300 python $R/tools/nms_trace.py > $OUT/${TAG}_nms_trace.txt 2>&1
+timeout 300 python $R/tools/bench_layers.py > $OUT/${TAG}_vgg_layers.txt 2>&1
+# the widened configurations: per-kernel stats + the tools' own timing lines
 for cfg in "mpn:bench_mpn.py" "resnet50:bench_resnet.py" "resnet50_bf16:bench_resnet.py 50 1000 bf16" "inception_mpn_bf16:bench_inception.py 2000 mpn"; do
   name=${cfg%%:*}; tool=${cfg#*:}
   rm -rf /tmp/kt_$name
