@@ -86,6 +86,12 @@ bool linear_c8_is_direct(int M, int N, int Mp_override = 0);  // would linear_c8
 // Mp: row pitch of the output matrix (0 = lin_mp(N)).
 int roi_pool_c8(Act feat, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset, int end_adjust,
                 float *d_x_c8, int32_t *d_argmax, hipStream_t s, int roi_stride = 5, int Mp = 0);
+// The same pooling from a pixel-major copy [y][x][Cb*8] of the map (one contiguous 1 KiB per pixel and 256 channels; bit-identical
+// output, no argmax): c8p_to_pixel_major once per image, then roi_pool_pm.
+size_t pixel_major_elems(Act feat);
+int c8p_to_pixel_major(Act feat, float *d_pm, hipStream_t s);
+int roi_pool_pm(Act feat, const float *d_pm, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset, int end_adjust,
+                float *d_x_c8, hipStream_t s, int roi_stride = 5, int Mp = 0);
 // vertical range-max tables of a C8P map (levels 1..vmax_levels_for(H), each feat.elems() floats) and the ROI max-pool that
 // reads them: identical output to roi_pool_c8 (no argmax), cost 2 x bin-width reads per bin instead of bin-height x bin-width
 int vmax_levels_for(int H);

@@ -1697,6 +1697,93 @@ int roi_pool_c8_rmq(Act feat, const float *d_tables, const float *d_rois, int N,
   return MPN_OK;
 }
 
+// ---- ROI max-pool from a pixel-major copy of the map --------------------------------------------------------------------------
+// roi_pool_c8_kernel's wave reads 32 different ROIs' windows per load instruction: 32 cache lines, a quarter of each used — the vector
+// L1's line rate, not HBM, is its limit (1.0 TB/s of algorithmic traffic).  With the map copied once per image to pixel-major order
+// [y][x][C] (4.9 MB for conv5), a wave is ONE (roi, bin) and its 64 lanes are 256 consecutive channels: a load instruction is one
+// contiguous 1 KiB (8 fully used lines), the window bounds are wave-uniform (no divergence), and the four waves of a block are four
+// consecutive ROIs whose outputs are staged in LDS and leave as whole 128-byte lines of the fc6 operand.  Max is exact: the output
+// is bit-identical to roi_pool_c8_kernel's.
+__global__ void c8p_to_pixel_major_kernel(const float *__restrict__ in, int Cb, int H, int W, int Hp, int Wp, float *__restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)H * W * Cb * 2;
+  if (t >= total) return;
+  const int q = (int)(t % (Cb * 2)); const size_t px = t / (Cb * 2);   // q = cb * 2 + half: consecutive lanes write consecutive 16 bytes
+  const int x = (int)(px % W), y = (int)(px / W);
+  const int cb = q >> 1, h = q & 1;
+  *reinterpret_cast<f32x4 *>(out + px * (size_t)Cb * 8 + q * 4) =
+      *reinterpret_cast<const f32x4 *>(in + (size_t)cb * Hp * Wp * 8 + ((size_t)(y + 1) * Wp + x + 1) * 8 + h * 4);
+}
+
+__global__ __launch_bounds__(256) void roi_pool_pm_kernel(const float *__restrict__ pm, int Cb, int H, int W, const float *__restrict__ rois,
+                                                          int roi_stride, int N, int PH, int PW, float scale, float coord_offset,
+                                                          int end_adjust, float *__restrict__ xc8, int Mp) {
+  __shared__ f32x4 stage[4][64];   // [roi of the quad][lane] = 4 channels
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n0 = blockIdx.x * 4, n = n0 + wave;
+  const int bin = blockIdx.y, cq = blockIdx.z;   // cq: which 256-channel slice
+  const int ph = bin / PW, pw = bin - ph * PW;
+  const int C = Cb * 8;
+  f32x4 m = f32x4{0, 0, 0, 0};
+  if (n < N) {
+    const float *ro = rois + (size_t)roi_stride * n;
+    const int sw = (int)roundf((ro[1] - coord_offset) * scale);
+    const int sh = (int)roundf((ro[2] - coord_offset) * scale);
+    const int ew = (int)roundf((ro[3] - coord_offset) * scale) + end_adjust;
+    const int eh = (int)roundf((ro[4] - coord_offset) * scale) + end_adjust;
+    const int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
+    const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+    int hs = (int)floorf((float)ph * bh) + sh, he = (int)ceilf((float)(ph + 1) * bh) + sh;
+    int ws = (int)floorf((float)pw * bw) + sw, we = (int)ceilf((float)(pw + 1) * bw) + sw;
+    hs = min(max(hs, 0), H); he = min(max(he, 0), H);
+    ws = min(max(ws, 0), W); we = min(max(we, 0), W);
+    hs = __builtin_amdgcn_readfirstlane(hs); he = __builtin_amdgcn_readfirstlane(he);
+    ws = __builtin_amdgcn_readfirstlane(ws); we = __builtin_amdgcn_readfirstlane(we);
+    const int ch = cq * 256 + lane * 4;
+    if (he > hs && we > ws && ch < C) {
+      m = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      for (int y = hs; y < he; ++y) {
+        const float *row = pm + ((size_t)y * W + ws) * C + ch;
+        for (int x = ws; x < we; ++x, row += C) {
+          const f32x4 v = *reinterpret_cast<const f32x4 *>(row);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+        }
+      }
+    }
+  }
+  stage[wave][lane] = m;
+  __syncthreads();
+  // 32 channel blocks x (4 rois x 8 floats = 128 contiguous bytes): thread = (channel block, 16-byte piece of the line)
+  const int t = threadIdx.x, cbl = t >> 3, j4 = t & 7, roi = j4 >> 1, hf = j4 & 1;
+  const int cb = cq * 32 + cbl;
+  if (cb < Cb && n0 + roi < N) {
+    const f32x4 v = stage[roi][cbl * 2 + hf];
+    *reinterpret_cast<f32x4 *>(xc8 + (((size_t)cb * PH * PW + bin) * Mp + n0) * 8 + j4 * 4) = v;
+  }
+}
+
+size_t pixel_major_elems(Act feat) { return (size_t)feat.H * feat.W * feat.Cb() * 8; }
+
+int c8p_to_pixel_major(Act feat, float *d_pm, hipStream_t s) {
+  MPN_CHECK_ARG(feat.p && d_pm);
+  const size_t total = (size_t)feat.H * feat.W * feat.Cb() * 2;
+  hipLaunchKernelGGL(c8p_to_pixel_major_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, feat.p, feat.Cb(), feat.H, feat.W, feat.Hp,
+                     feat.Wp, d_pm);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+int roi_pool_pm(Act feat, const float *d_pm, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset, int end_adjust,
+                float *d_x_c8, hipStream_t s, int roi_stride, int Mp) {
+  MPN_CHECK_ARG(d_pm && d_rois && d_x_c8 && N > 0 && PH > 0 && PW > 0);
+  hipLaunchKernelGGL(roi_pool_pm_kernel, dim3((unsigned)cdiv(N, 4), (unsigned)(PH * PW), (unsigned)cdiv(feat.Cb(), 32)), dim3(256), 0, s, d_pm,
+                     feat.Cb(), feat.H, feat.W, d_rois, roi_stride, N, PH, PW, scale, coord_offset, end_adjust, d_x_c8, Mp > 0 ? Mp : lin_mp(N));
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
 int roi_pool_c8(Act feat, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset, int end_adjust,
                 float *d_x_c8, int32_t *d_argmax, hipStream_t s, int roi_stride, int Mp) {
   MPN_CHECK_ARG(feat.p && d_rois && d_x_c8 && N > 0 && PH > 0 && PW > 0);

@@ -138,6 +138,8 @@ struct mpn_frcnn {
   int K6 = 0, Mp = 0, n_head = 0;
   float *w6 = nullptr, *b6 = nullptr, *w7 = nullptr, *b7 = nullptr, *wh = nullptr, *bh = nullptr;
   float *rois = nullptr, *x6 = nullptr, *y6 = nullptr, *y7 = nullptr, *head = nullptr;
+  float *feat_pm = nullptr;   // pixel-major copy of the last trunk map (plain Fast R-CNN head: roi_pool_pm)
+  bool feat_pm_valid = false;
   float *scores = nullptr, *bbox = nullptr, *bbox_raw = nullptr;
   // NMS-stage buffers: two sets so that image i's NMS (side stream) overlaps image i+1's trunk
   float *scored_b[2] = {nullptr, nullptr}, *keep_b[2] = {nullptr, nullptr}, *thresh_b[2] = {nullptr, nullptr};
@@ -207,9 +209,11 @@ struct ProfScope {
 
 MPN_KNOB(int, g_fuse_pool, 1);
 MPN_KNOB(int, g_first_k36, 1);  // 0: the first layer on the generic direct kernel
+MPN_KNOB(int, g_roi_pool_pm, 1);  // 0: ROI pooling straight from the C8P map (roi_pool_c8_kernel)
 #ifdef MPN_DEBUG_HOOKS
 extern "C" void mpn_debug_set_fuse_pool(int v) { g_fuse_pool = v; }
 extern "C" void mpn_debug_set_first_k36(int v) { g_first_k36 = v; }
+extern "C" void mpn_debug_set_roi_pool_pm(int v) { g_roi_pool_pm = v; }
 #endif
 
 template <typename T>
@@ -401,6 +405,11 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
     TRY(pack_linear_weights(tmp_w, tmp_b, F, 5 * C, 1, p->wh, p->bh, nullptr));
   }
   if (!graph_net) {
+  {  // pixel-major copy of the final map at its largest size
+    int fh = cfg->max_h, fw = cfg->max_w;
+    for (int l = 0; l < n_conv; ++l) if (p->pool_after[l]) { fh = (fh + 1) / 2; fw = (fw + 1) / 2; }
+    TRY(dev_alloc(p, &p->feat_pm, (size_t)fh * fw * ((p->feat_c + 7) / 8) * 8 * sizeof(float), false));
+  }
   TRY(dev_alloc(p, &p->x6, (size_t)(K6_32 / 8) * p->Mp * 8 * sizeof(float), true));
   TRY(dev_alloc(p, &p->y6, (size_t)(lin_np(F) / 8) * p->Mp * 8 * sizeof(float), true));
   }
@@ -457,6 +466,7 @@ static int run_trunk(mpn_frcnn *p, const float *d_image, int H, int W, hipStream
   }
   Act cur = make_act(p->img_c8p, 3, H, W);
   p->vmax_valid = false;
+  p->feat_pm_valid = false;
   int rc;
   { ProfScope ps(p, MPN_PROF_TRANSFORM, s);
     rc = image_transform_c8p(d_image, H, W, c.tf_swap, c.tf_scale, c.tf_mean, c.tf_std, c.tf_std[0] != 0.0, cur, s); }
@@ -637,7 +647,12 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const 
     if (rc) return rc;
   } else {
   { ProfScope ps(p, MPN_PROF_ROIPOOL, s);
-    rc = roi_pool_c8(feat, p->rois, N, c.pooled_h, c.pooled_w, c.spatial_scale, 1.0f, 0, p->x6, nullptr, s); }
+    if (p->feat_pm && g_roi_pool_pm) {
+      if (!p->feat_pm_valid) { rc = c8p_to_pixel_major(feat, p->feat_pm, s); if (rc) return rc; p->feat_pm_valid = true; }  // once per trunk run
+      rc = roi_pool_pm(feat, p->feat_pm, p->rois, N, c.pooled_h, c.pooled_w, c.spatial_scale, 1.0f, 0, p->x6, s);
+    } else {
+      rc = roi_pool_c8(feat, p->rois, N, c.pooled_h, c.pooled_w, c.spatial_scale, 1.0f, 0, p->x6, nullptr, s);
+    } }
   if (rc) return rc;
   { ProfScope ps(p, MPN_PROF_FC6, s); rc = linear_c8(p->x6, N, p->K6, p->w6, p->b6, F, 1, p->y6, nullptr, s); }
   if (rc) return rc;

@@ -49,13 +49,14 @@ def small(O, dev):
     return dict(net=net, im=im, boxes=boxes, P=Pn, P_torch=P, feat=feat, pooled=pooled, logits=logits, deltas=deltas)
 
 
-@pytest.mark.parametrize("fuse_pool,split,k36", [(1, 0, 1), (0, 0, 1), (1, 2, 1), (0, 3, 1), (1, 0, 0)])
-def test_pipeline_stages_vs_oracle(O, dev, small, fuse_pool, split, k36):
+@pytest.mark.parametrize("fuse_pool,split,k36,pm", [(1, 0, 1, 1), (0, 0, 1, 1), (1, 2, 1, 1), (0, 3, 1, 1), (1, 0, 0, 1), (1, 0, 1, 0)])
+def test_pipeline_stages_vs_oracle(O, dev, small, fuse_pool, split, k36, pm):
     from multipathnet_amd import models
     s = SMALL
     # k36 = 0: the first layer on the generic direct kernel instead of its K = 36 formulation
-    with hooks(fuse_pool=fuse_pool, conv_split=split, first_k36=k36):  # (1, 0, 1) = the product library; the others build their handle on the debug flavour
-        net = small["net"] if (fuse_pool, split, k36) == (1, 0, 1) else models.FastRCNN(
+    # pm = 0: ROI pooling straight from the C8P map instead of from the pixel-major copy (the pooled tensor is compared bit for bit below)
+    with hooks(fuse_pool=fuse_pool, conv_split=split, first_k36=k36, roi_pool_pm=pm):  # all defaults = the product library; the others build their handle on the debug flavour
+        net = small["net"] if (fuse_pool, split, k36, pm) == (1, 0, 1, 1) else models.FastRCNN(
             small["P_torch"], cfg=s["cfg"], pooled=7, spatial_scale=s["scale"], max_h=s["H"], max_w=s["W"], max_rois=s["N"])
         scores, bbox = net.detect(torch.from_numpy(small["im"]).to(dev), torch.from_numpy(small["boxes"]).to(dev))
         torch.cuda.synchronize()
@@ -462,3 +463,22 @@ def test_two_handles_two_threads_two_streams(dev, small):
     for t in ts:
         t.join(timeout=300)
     assert not errs, errs[:3]
+
+
+def test_roi_pool_pixel_major_is_bit_identical(dev, small):
+    """the pipeline pools from a pixel-major copy of the final map (one contiguous KiB per pixel and 256 channels); max is exact, so the
+    pooled tensor and everything after it must equal the per-bin kernel's bit for bit — including degenerate and outside boxes"""
+    from multipathnet_amd import models
+    s = SMALL
+    boxes = small["boxes"].copy()
+    boxes[0] = [5, 5, 5, 5]                      # 1-pixel box
+    boxes[1] = [s["W"] - 1, s["H"] - 1, s["W"], s["H"]]
+    boxes[2] = [1, 1, s["W"], s["H"]]           # the whole image
+    im, bx = torch.from_numpy(small["im"]).to(dev), torch.from_numpy(boxes).to(dev)
+    a_s, a_b = small["net"].detect(im, bx)
+    a_p = small["net"].debug_tensor("pooled", small["pooled"].shape).clone()
+    with hooks(roi_pool_pm=0):
+        net0 = models.FastRCNN(small["P_torch"], cfg=s["cfg"], pooled=7, spatial_scale=s["scale"], max_h=s["H"], max_w=s["W"], max_rois=s["N"])
+        b_s, b_b = net0.detect(im, bx)
+        b_p = net0.debug_tensor("pooled", small["pooled"].shape).clone()
+    assert torch.equal(a_p, b_p) and torch.equal(a_s, b_s) and torch.equal(a_b, b_b)
