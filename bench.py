@@ -428,7 +428,7 @@ def main():
         return dt
 
     dt = timed(make_step(True))            # the metric: host image + boxes in, H2D inside the timed region
-    dt_res = timed(make_step(False))       # inputs already resident in HBM
+    dt_res = min(timed(make_step(False)) for _ in range(2))  # inputs already resident in HBM (auxiliary figure: best of two passes)
     value = args.steps * n_rois_cfg * world / dt
     value_res = args.steps * n_rois_cfg * world / dt_res
     if other is not None:  # one of the widened configurations: whole-path rates, its own metric string

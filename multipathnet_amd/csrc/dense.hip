@@ -273,6 +273,8 @@ __global__ __launch_bounds__(256) void conv3x3_c8p_kernel(ConvArgs a) {
   }
 }
 
+MPN_KNOB(int, g_gemm_ablate, 0);         // timing-experiment switch of the convolution kernels (tools/ablate_conv.py, tools/ablate_wino.py)
+
 // =================================================================================================
 // First layer (<= 4 input channels; VGG conv1_1: 3 -> 64 on the full-resolution image).
 // The generic kernel spends 9 taps x 8-channel chunks = 72 K-steps on a layer whose real K is 27, and the layer is
@@ -284,77 +286,129 @@ __global__ __launch_bounds__(256) void conv3x3_c8p_kernel(ConvArgs a) {
 // =================================================================================================
 constexpr int kF_TH = 8;                       // rows per block tile (4 waves x 2 rows), 32 columns
 constexpr int kF_PL = (kF_TH + 2) * 34 + 12;   // floats per channel plane of the LDS tile (352: 16-byte multiple)
-__global__ __launch_bounds__(256) void conv3x3_first_kernel(const float *__restrict__ in, int in_Wp, const float *__restrict__ w36,
-                                                            int CoutP, const float *__restrict__ bpk, float *__restrict__ out,
-                                                            size_t out_plane, int out_Wp, int H, int W, int out_cb, int relu,
-                                                            int n_ct, int tiles_x) {
-  __shared__ float tile[4 * kF_PL];
+template <int ABL>  // ABL: compile-time timing-experiment switches (0 in production; tools/ablate_first.py): 1 no stores, 2 no MFMAs
+__global__ __launch_bounds__(256, 5) void conv3x3_first_kernel(const float *__restrict__ in, int in_Wp, const float *__restrict__ w36,
+                                                               int CoutP, const float *__restrict__ bpk, float *__restrict__ out,
+                                                               size_t out_plane, int out_Wp, int H, int W, int out_cb, int relu,
+                                                               int tiles_x, int n_tiles) {
+  // Persistent over tiles (grid = 4 blocks per CU): the 36 x 64 weight block is staged ONCE into LDS, and the input tile of the
+  // block's next tile is fetched into registers before the current tile's MFMAs and parked in the other LDS buffer after them —
+  // the layer is latency-bound otherwise (one block = weight loads -> tile load -> 72 MFMAs -> stores, nothing overlapping
+  // within the block).  Operands come from LDS per tap (A: one ds_read2_b32, B: two ds_read_b32 per k-pair), which keeps the
+  // kernel under 128 VGPRs = 4 waves per SIMD.
+  __shared__ float tile[2][4 * kF_PL];
+  __shared__ float wl[36 * 64];
+  __shared__ float bl[64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  const int ct = blockIdx.x % n_ct, sp = blockIdx.x / n_ct;
-  const int ty = sp / tiles_x, tx = sp - ty * tiles_x;
-  const int y0 = ty * kF_TH, x0 = tx * 32, cout0 = ct * 64;
-  // weights: this lane's 2 x 18 A-operand values (cout = cout0 + mi*32 + l31, k = 2*ks + half)
-  float af[2][18];
+  const int cout0 = blockIdx.y * 64;
+  for (int i = tid; i < 36 * 64; i += 256) wl[i] = w36[(size_t)(i >> 6) * CoutP + cout0 + (i & 63)];
+  if (tid < 64) bl[tid] = bpk[cout0 + tid];
+  constexpr int NPX = (kF_TH + 2) * 34;  // 340 pixel records per tile: at most 2 per thread
+  const int p0 = tid, p1 = tid + 256;
+  const int r0 = p0 / 34, c0 = p0 - r0 * 34, r1 = p1 / 34, c1 = p1 - r1 * 34;
+  const int off0 = (r0 * in_Wp + c0) * 8, off1 = p1 < NPX ? (r1 * in_Wp + c1) * 8 : off0;
+  auto fetch = [&](int t, f32x4 &v0, f32x4 &v1) {
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const float *base = in + ((size_t)(ty * kF_TH) * in_Wp + tx * 32) * 8;
+    v0 = *reinterpret_cast<const f32x4 *>(base + off0);
+    v1 = *reinterpret_cast<const f32x4 *>(base + off1);
+  };
+  auto park = [&](int buf, const f32x4 &v0, const f32x4 &v1) {
 #pragma unroll
-  for (int ks = 0; ks < 18; ++ks)
+    for (int e = 0; e < 4; ++e) tile[buf][e * kF_PL + p0] = v0[e];
+    if (p1 < NPX) {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) af[mi][ks] = w36[(size_t)(ks * 2 + half) * CoutP + cout0 + mi * 32 + l31];
-  // input tile: channels 0..3 of (TH+2) x 34 pixel records -> 4 planes
-  for (int p = tid; p < (kF_TH + 2) * 34; p += 256) {
-    const int r = p / 34, c = p - r * 34;
-    const f32x4 v = *reinterpret_cast<const f32x4 *>(in + ((size_t)(y0 + r) * in_Wp + x0 + c) * 8);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) tile[e * kF_PL + p] = v[e];
-  }
+      for (int e = 0; e < 4; ++e) tile[buf][e * kF_PL + p1] = v1[e];
+    }
+  };
+  // vmcnt counts loads and stores in issue order on this ISA: a wait for a load also waits for every OLDER store.  So nothing in
+  // the loop waits on a global load younger than the tile's stores (bias comes from LDS; the next input tile is fetched BEFORE
+  // this tile's stores and parked a whole MFMA phase later), and a tile's 16 stores drain under the next tile's MFMAs.
+  int t = blockIdx.x;
+  if (t >= n_tiles) return;
+  const int step = gridDim.x;
+  f32x4 n0, n1;
+  fetch(t, n0, n1);
+  park(0, n0, n1);
+  if (t + step < n_tiles) fetch(t + step, n0, n1);
   __syncthreads();
-  f32x16 acc[2][2];
+  const float *wa = wl + half * 64 + l31;
+  int buf = 0;
+  for (; t < n_tiles; t += step, buf ^= 1) {
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int y0 = ty * kF_TH, x0 = tx * 32;
+    const float *tb = tile[buf] + half * kF_PL + (wave * 2) * 34 + l31;
+    // output addressing: a uniform (SGPR) plane base + one 32-bit per-lane byte offset per output row (hoisted 64-bit per-store
+    // pointers would cost 32 VGPRs)
+    const int x = x0 + l31;
+    bool xok = x < W;
+    if constexpr ((ABL & 1) != 0) xok = xok && in_Wp == 7;  // never true: keeps the accumulators live
+    const int yw = y0 + wave * 2;
+    const unsigned voff = (unsigned)(((yw + 1) * out_Wp + x + 1) * 8 + half * 4) * 4u;  // bytes inside a channel-block plane
+    const unsigned vrow = (unsigned)out_Wp * 32u;
+    const bool ok0 = xok && yw < H, ok1 = xok && yw + 1 < H;
+    // Two halves of 32 output channels: 36 MFMAs (two independent accumulator chains), then that half's 8 stores — the first
+    // stores leave after a quarter of the block's MFMA work and the other half's MFMAs (and the other waves') run while they
+    // drain; a whole-tile epilogue leaves HBM idle for the first MFMA phase and the MFMA pipe idle for the last store phase.
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < 2; ++mi) {
+      f32x16 acc[2];
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
-  const float *tb = tile + half * kF_PL + (wave * 2) * 34 + l31;
+        for (int r = 0; r < 16; ++r) acc[ni][r] = 0.0f;
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const int dy = t / 3, dx = t - dy * 3;
+      for (int tp = 0; tp < 9; ++tp) {
+        const int dy = tp / 3, dx = tp - dy * 3;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      float bfr[2];
+        for (int p = 0; p < 2; ++p) {
+          const float afr = wa[(tp * 2 + p) * 128 + mi * 32];
+          float bfr[2];
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) bfr[ni] = tb[2 * p * kF_PL + (ni + dy) * 34 + dx];
+          for (int ni = 0; ni < 2; ++ni) bfr[ni] = tb[2 * p * kF_PL + (ni + dy) * 34 + dx];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][t * 2 + p], bfr[ni], acc[mi][ni], 0, 0, 0);
-    }
-  }
-  // epilogue: bias + ReLU, 1 KiB-contiguous float4 stores in the next layer's C8P layout
-  const int x = x0 + l31;
-  const bool xok = x < W;
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int cb = (cout0 + mi * 32) / 8 + g;
-      if (cb >= out_cb) continue;
-      const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bpk + cb * 8 + half * 4);
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int y = y0 + wave * 2 + ni;
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float tv = acc[mi][ni][g * 4 + e] + b4[e];
-          if (relu) tv = tv < 0.0f ? 0.0f : tv;
-          v[e] = tv;
+          for (int ni = 0; ni < 2; ++ni) {
+            if constexpr ((ABL & 2) == 0) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr, bfr[ni], acc[ni], 0, 0, 0);
+            else acc[ni][(tp + p) & 15] += afr * bfr[ni];
+          }
         }
-        if (xok && y < H) *reinterpret_cast<f32x4 *>(out + (size_t)cb * out_plane + ((size_t)(y + 1) * out_Wp + x + 1) * 8 + half * 4) = v;
+        if ((tp % 3) == 2) __builtin_amdgcn_sched_barrier(0);  // operand loads at most three taps ahead (VGPR budget)
       }
+      if (mi == 1) {
+        // the next tile: park what was fetched one tile ago (the other buffer's last readers finished before the previous
+        // barrier), then start the fetch of the one after it — ahead of this half's stores
+        const int tn = t + step;
+        if (tn < n_tiles) {
+          park(buf ^ 1, n0, n1);
+          if (tn + step < n_tiles) fetch(tn + step, n0, n1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // bias + ReLU, 1 KiB-contiguous float4 stores in the next layer's C8P layout
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cb = __builtin_amdgcn_readfirstlane((cout0 + mi * 32) / 8 + g);
+        if (cb >= out_cb) continue;
+        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bl + (mi * 4 + g) * 8 + half * 4);
+        char *pb = reinterpret_cast<char *>(out + (size_t)cb * out_plane);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float tv = acc[ni][g * 4 + e] + b4[e];
+            if (relu) tv = tv < 0.0f ? 0.0f : tv;
+            v[e] = tv;
+          }
+          if (ni ? ok1 : ok0) *reinterpret_cast<f32x4 *>(pb + (voff + (ni ? vrow : 0u))) = v;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    __syncthreads();
+  }
 }
 
 __global__ void pack_conv_w_first_kernel(const float *__restrict__ w, int Cin, int Cout, int CoutP, float *__restrict__ w36) {
@@ -379,8 +433,20 @@ int pack_conv_weights_first(const float *d_w, int Cin, int Cout, float *d_w36, h
 int conv3x3_first_c8p(Act in, const float *d_w36, const float *d_bpk, int Cout, int relu, Act out, hipStream_t s) {
   MPN_CHECK_ARG(in.p && d_w36 && d_bpk && out.p && in.C <= 4 && out.H == in.H && out.W == in.W && out.C == Cout);
   const int tiles_x = cdiv(in.W, 32), tiles_y = cdiv(in.H, kF_TH), n_ct = cdiv(Cout, 64);
-  hipLaunchKernelGGL(conv3x3_first_kernel, dim3((unsigned)(n_ct * tiles_y * tiles_x)), dim3(256), 0, s, in.p, in.Wp, d_w36, conv_coutp(Cout), d_bpk,
-                     out.p, out.plane(), out.Wp, in.H, in.W, (Cout + 7) / 8, relu, n_ct, tiles_x);
+  const int n_tiles = tiles_x * tiles_y;
+  // persistent grid: at most 5 resident blocks per CU (71 VGPRs, 20.5 KB LDS each), every block the same number of tiles
+  // (2400 tiles at 600 x 1000 -> 1200 blocks x 2 tiles)
+  const char *e_cap = MPN_ABLATE(1) ? getenv("MPN_FIRST_BLOCKS") : nullptr;  // timing experiment (debug flavour only)
+  const int cap = e_cap ? atoi(e_cap) : 1280;
+  const int blocks = cdiv(n_tiles, cdiv(n_tiles, cap));
+  auto kern = conv3x3_first_kernel<0>;
+#ifdef MPN_DEBUG_HOOKS
+  if ((g_gemm_ablate & 3) == 1) kern = conv3x3_first_kernel<1>;
+  if ((g_gemm_ablate & 3) == 2) kern = conv3x3_first_kernel<2>;
+  if ((g_gemm_ablate & 3) == 3) kern = conv3x3_first_kernel<3>;
+#endif
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)n_ct), dim3(256), 0, s, in.p, in.Wp, d_w36, conv_coutp(Cout), d_bpk, out.p,
+                     out.plane(), out.Wp, in.H, in.W, (Cout + 7) / 8, relu, tiles_x, n_tiles);
   MPN_CHECK_LAUNCH();
   return MPN_OK;
 }
@@ -801,7 +867,6 @@ __global__ void conv_splitk_reduce_kernel(const float *__restrict__ part, size_t
   if (pooling) *reinterpret_cast<f32x4 *>(pool + (size_t)cb * pool_plane + ((size_t)(gy + 1) * pool_Wp + gx + 1) * 8 + h * 4) = m;
 }
 
-MPN_KNOB(int, g_gemm_ablate, 0);         // timing-experiment switch of the convolution kernels (tools/ablate_conv.py, tools/ablate_wino.py)
 MPN_KNOB(unsigned long long *, g_wino_trace, nullptr);  // tools/wino_trace.py
 MPN_KNOB(int, g_conv_split, 0);          // 0 = auto, >0 = force this many splits (test/bench hook)
 
@@ -1852,10 +1917,15 @@ extern "C" int mpn_debug_bench_conv(int Cin, int Cout, int H, int W, int pool, i
   MPN_CHECK_HIP(hipEventCreate(&e0));
   MPN_CHECK_HIP(hipEventCreate(&e1));
   int rc = MPN_OK;
-  for (int i = 0; i < 2 && rc == MPN_OK; ++i) rc = pool ? conv3x3_c8p(ai, wpk, bpk, Cout, 1, Act{}, ap, nullptr, wino) : conv3x3_c8p(ai, wpk, bpk, Cout, 1, ao, Act{}, nullptr, wino);
+  const bool first = Cin <= 4 && !pool;  // the K = 36 first-layer kernel (its w36 block fits inside the wino allocation)
+  auto run = [&]() {
+    if (first) return conv3x3_first_c8p(ai, wino, bpk, Cout, 1, ao, nullptr);
+    return pool ? conv3x3_c8p(ai, wpk, bpk, Cout, 1, Act{}, ap, nullptr, wino) : conv3x3_c8p(ai, wpk, bpk, Cout, 1, ao, Act{}, nullptr, wino);
+  };
+  for (int i = 0; i < 2 && rc == MPN_OK; ++i) rc = run();
   MPN_CHECK_HIP(hipDeviceSynchronize());
   MPN_CHECK_HIP(hipEventRecord(e0, nullptr));
-  for (int i = 0; i < iters && rc == MPN_OK; ++i) rc = pool ? conv3x3_c8p(ai, wpk, bpk, Cout, 1, Act{}, ap, nullptr, wino) : conv3x3_c8p(ai, wpk, bpk, Cout, 1, ao, Act{}, nullptr, wino);
+  for (int i = 0; i < iters && rc == MPN_OK; ++i) rc = run();
   MPN_CHECK_HIP(hipEventRecord(e1, nullptr));
   MPN_CHECK_HIP(hipEventSynchronize(e1));
   float ms = 0.f;
