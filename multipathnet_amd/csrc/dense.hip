@@ -1780,6 +1780,7 @@ __global__ void c8p_to_pixel_major_kernel(const float *__restrict__ in, int Cb, 
       *reinterpret_cast<const f32x4 *>(in + (size_t)cb * Hp * Wp * 8 + ((size_t)(y + 1) * Wp + x + 1) * 8 + h * 4);
 }
 
+template <int ABL>  // ABL: timing experiments (debug flavour): 1 no feature loads, 2 no stores, 4 no ROI decode (fixed 3x3 bin)
 __global__ __launch_bounds__(256) void roi_pool_pm_kernel(const float *__restrict__ pm, int Cb, int H, int W, const float *__restrict__ rois,
                                                           int roi_stride, int N, int PH, int PW, float scale, float coord_offset,
                                                           int end_adjust, float *__restrict__ xc8, int Mp) {
@@ -1805,6 +1806,8 @@ __global__ __launch_bounds__(256) void roi_pool_pm_kernel(const float *__restric
     ws = min(max(ws, 0), W); we = min(max(we, 0), W);
     hs = __builtin_amdgcn_readfirstlane(hs); he = __builtin_amdgcn_readfirstlane(he);
     ws = __builtin_amdgcn_readfirstlane(ws); we = __builtin_amdgcn_readfirstlane(we);
+    if constexpr ((ABL & 4) != 0) { hs = (n * 7 + ph) % (H - 3); he = hs + 3; ws = (n * 13 + pw) % (W - 3); we = ws + 3; }
+    if constexpr ((ABL & 1) != 0) { he = hs; }
     const int ch = cq * 256 + lane * 4;
     if (he > hs && we > ws && ch < C) {
       m = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -1823,7 +1826,7 @@ __global__ __launch_bounds__(256) void roi_pool_pm_kernel(const float *__restric
   // 32 channel blocks x (4 rois x 8 floats = 128 contiguous bytes): thread = (channel block, 16-byte piece of the line)
   const int t = threadIdx.x, cbl = t >> 3, j4 = t & 7, roi = j4 >> 1, hf = j4 & 1;
   const int cb = cq * 32 + cbl;
-  if (cb < Cb && n0 + roi < N) {
+  if (cb < Cb && n0 + roi < N && !((ABL & 2) != 0 && Mp != 7)) {
     const f32x4 v = stage[roi][cbl * 2 + hf];
     *reinterpret_cast<f32x4 *>(xc8 + (((size_t)cb * PH * PW + bin) * Mp + n0) * 8 + j4 * 4) = v;
   }
@@ -1843,7 +1846,18 @@ int c8p_to_pixel_major(Act feat, float *d_pm, hipStream_t s) {
 int roi_pool_pm(Act feat, const float *d_pm, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset, int end_adjust,
                 float *d_x_c8, hipStream_t s, int roi_stride, int Mp) {
   MPN_CHECK_ARG(d_pm && d_rois && d_x_c8 && N > 0 && PH > 0 && PW > 0);
-  hipLaunchKernelGGL(roi_pool_pm_kernel, dim3((unsigned)cdiv(N, 4), (unsigned)(PH * PW), (unsigned)cdiv(feat.Cb(), 32)), dim3(256), 0, s, d_pm,
+  auto kern = roi_pool_pm_kernel<0>;
+#ifdef MPN_DEBUG_HOOKS
+  switch (g_gemm_ablate & 7) {
+    case 1: kern = roi_pool_pm_kernel<1>; break;
+    case 2: kern = roi_pool_pm_kernel<2>; break;
+    case 3: kern = roi_pool_pm_kernel<3>; break;
+    case 4: kern = roi_pool_pm_kernel<4>; break;
+    case 6: kern = roi_pool_pm_kernel<6>; break;
+    default: break;
+  }
+#endif
+  hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(N, 4), (unsigned)(PH * PW), (unsigned)cdiv(feat.Cb(), 32)), dim3(256), 0, s, d_pm,
                      feat.Cb(), feat.H, feat.W, d_rois, roi_stride, N, PH, PW, scale, coord_offset, end_adjust, d_x_c8, Mp > 0 ? Mp : lin_mp(N));
   MPN_CHECK_LAUNCH();
   return MPN_OK;
@@ -1933,6 +1947,37 @@ extern "C" int mpn_debug_bench_conv(int Cin, int Cout, int H, int W, int pool, i
   *ms_out = ms / iters;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(in); (void)hipFree(out); (void)hipFree(pl); (void)hipFree(wpk); (void)hipFree(bpk); (void)hipFree(wino);
+  return rc;
+}
+
+// Kernel-only timing of the pixel-major ROI pooling on a 512 x 38 x 63 map (tools/ablate_roipool.py); rois: N x 5 host floats.
+extern "C" int mpn_debug_bench_roipool(const float *h_rois, int N, int C, int H, int W, int iters, float *ms_out) {
+  MPN_CHECK_ARG(h_rois && N > 0 && C % 8 == 0 && iters > 0 && ms_out);
+  Act feat = make_act(nullptr, C, H, W);
+  float *pm = nullptr, *rois = nullptr, *x = nullptr;
+  const size_t pe = pixel_major_elems(feat), xe = (size_t)(C / 8) * 49 * lin_mp(N) * 8;
+  MPN_CHECK_HIP(hipMalloc(&pm, pe * 4)); MPN_CHECK_HIP(hipMalloc(&rois, (size_t)N * 5 * 4)); MPN_CHECK_HIP(hipMalloc(&x, xe * 4));
+  {
+    std::vector<float> h(pe);
+    unsigned s = 99u;
+    for (auto &v : h) { s = s * 1664525u + 1013904223u; v = (s >> 8) * (1.0f / 16777216.0f); }
+    MPN_CHECK_HIP(hipMemcpy(pm, h.data(), pe * 4, hipMemcpyHostToDevice));
+    MPN_CHECK_HIP(hipMemcpy(rois, h_rois, (size_t)N * 5 * 4, hipMemcpyHostToDevice));
+  }
+  hipEvent_t e0, e1;
+  MPN_CHECK_HIP(hipEventCreate(&e0)); MPN_CHECK_HIP(hipEventCreate(&e1));
+  int rc = MPN_OK;
+  for (int i = 0; i < 2 && rc == MPN_OK; ++i) rc = roi_pool_pm(feat, pm, rois, N, 7, 7, 1.0f / 16, 0.0f, 0, x, nullptr, 5, 0);
+  MPN_CHECK_HIP(hipDeviceSynchronize());
+  MPN_CHECK_HIP(hipEventRecord(e0, nullptr));
+  for (int i = 0; i < iters && rc == MPN_OK; ++i) rc = roi_pool_pm(feat, pm, rois, N, 7, 7, 1.0f / 16, 0.0f, 0, x, nullptr, 5, 0);
+  MPN_CHECK_HIP(hipEventRecord(e1, nullptr));
+  MPN_CHECK_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  MPN_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = ms / iters;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(pm); (void)hipFree(rois); (void)hipFree(x);
   return rc;
 }
 
