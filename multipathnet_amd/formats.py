@@ -36,7 +36,7 @@ def prepare_proposals(boxes_yxyx, scores=None, min_area=0.0, best_number=None):
     out = out.index_select(0, idx)
     sc = scores.to(torch.float32).reshape(-1).index_select(0, idx) if scores is not None else None
     if sc is not None and best_number is not None and out.size(0) > best_number:  # filterScore
-        _, order = sc.sort(descending=True)
+        _, order = sc.sort(descending=True, stable=True)  # equal scores: lower row first (Torch7's own tie order is unspecified)
         order = order[:best_number]
         out, sc = out.index_select(0, order), sc.index_select(0, order)
     return out.contiguous(), sc

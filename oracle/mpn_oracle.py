@@ -690,3 +690,63 @@ def graph_mpn_detect(im, boxes, G, transformer, target=600, max_size=1000, poole
     if G.get("bbox_mean") is not None:
         deltas = bbox_norm(deltas, G["bbox_mean"], G["bbox_std"])
     return mean_over_k(probs), bbox_decode(boxes, deltas)
+
+
+# ---- wire formats either side of the path ----------------------------------------------------------------------
+def filter_area(boxes, scores, area):
+    """DataSetJSON.lua:171-186 filterArea: boxes are {y1,x1,y2,x2} rows; keep rows with (col3-col1)*(col4-col2) > area, in row
+    order (`s:gt(area):nonzero()`); area == 0 returns everything (line 172)."""
+    boxes = np.asarray(boxes, np.float32)
+    if area == 0:
+        return boxes, scores
+    wh = boxes[:, 2:4] - boxes[:, 0:2]                       # narrow(2,3,2):clone():add(-1, narrow(2,1,2)), fp32
+    idx = np.nonzero(wh[:, 0] * wh[:, 1] > np.float32(area))[0]
+    return boxes[idx], (None if scores is None else np.asarray(scores, np.float32)[idx])
+
+
+def filter_score(boxes, scores, best_number):
+    """DataSetJSON.lua:157-169 filterScore: when there are more than best_number rows, `scores:sort(true)` and the first
+    best_number indices.  Torch7's sort is TH's quicksort, whose order AMONG EQUAL scores is an implementation detail of a
+    library that is not in the reference tree (unpinned); this restatement — and the device path — break ties by the lower
+    original index (a stable sort).  With distinct scores the order is fully determined."""
+    if scores is None:
+        return boxes, None
+    boxes, scores = np.asarray(boxes, np.float32), np.asarray(scores, np.float32)
+    if best_number is not None and boxes.shape[0] > best_number:
+        idx = np.argsort(-scores.astype(np.float64), kind="stable")[:best_number]
+        boxes, scores = boxes[idx], scores[idx]
+    return boxes, scores
+
+
+def prepare_proposals(boxes_yxyx, scores=None, min_area=0.0, best_number=None):
+    """DataSetJSON.lua:216-233 (loadROIDB's per-image body): float() -> filterArea -> filterScore -> index(2, {2,1,4,3})."""
+    b, s = filter_area(boxes_yxyx, scores, min_area)
+    b, s = filter_score(b, s, best_number)
+    b = np.asarray(b, np.float32).reshape(-1, 4)
+    return b[:, [1, 0, 3, 2]], s
+
+
+def coco_rows(dets, image_id, category_ids):
+    """testCoco/init.lua:69-85: per detection {x1,y1,x2,y2,score,class(1-based)} -> {image id, x1-1, y1-1, x2-x1, y2-y1, score,
+    categories.id[class]} (fp32 arithmetic, as the FloatTensor `boxt` holds it)."""
+    d = np.asarray(dets, np.float32).reshape(-1, 6)
+    cats = np.asarray(category_ids, np.float32)
+    one = np.float32(1.0)
+    return np.stack([np.full(d.shape[0], np.float32(image_id), np.float32), d[:, 0] - one, d[:, 1] - one, d[:, 2] - d[:, 0], d[:, 3] - d[:, 1],
+                     d[:, 4], cats[d[:, 5].astype(np.int64) - 1]], 1).astype(np.float32)
+
+
+def save_results_table(aboxes, dataset_name):
+    """utils.lua:335-372 saveResults: aboxes[class][image] = [K,5] -> flat boxes / scores / categories / images tables, class-major,
+    images inside a class in index order, empty entries skipped."""
+    boxes, scores, cats, imgs = [], [], [], []
+    for cls, per_img in enumerate(aboxes, start=1):
+        for i, data in enumerate(per_img, start=1):
+            if data is not None and np.asarray(data).size > 0:
+                data = np.asarray(data, np.float32).reshape(-1, 5)
+                boxes.append(data[:, :4]); scores.append(data[:, 4])
+                cats.append(np.full(data.shape[0], cls, np.float32)); imgs.append(np.full(data.shape[0], i, np.float32))
+    cat = lambda xs, w: np.concatenate(xs) if xs else np.zeros((0,) + w, np.float32)
+    n_images = len(aboxes[0]) if aboxes else 0
+    return {"dataset": dataset_name, "images": np.arange(1, n_images + 1, dtype=np.float32),
+            "detections": {"boxes": cat(boxes, (4,)), "scores": cat(scores, ()), "categories": cat(cats, ()), "images": cat(imgs, ())}}

@@ -162,6 +162,48 @@ def test_libnms_dropin_th_abi(O, dev):
     assert shim.mpn_th_shim_size(t_keep, 0) == 0
 
 
+def test_libnms_dropin_cost_per_class_call(O, dev):
+    """What an UNCHANGED Tester_FRCNN.lua:117 pays per `utils.nms` call through libnms.so (host tensor in, H2D, sort / mask /
+    scan kernels, D2H, host tensor out — synchronous, 20 calls per image) next to the reference's own nms.c on the host.  A
+    measurement, printed for DESIGN.md / INTEGRATION.md (`pytest -s`); the only assertion is equality of the results."""
+    import time
+    if not O.have_ref():
+        pytest.skip("needs the TH shim that ships inside oracle/_ref/libnms_ref.so")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shim = ctypes.CDLL(os.path.join(root, "oracle", "_ref", "libnms_ref.so"), mode=ctypes.RTLD_GLOBAL)
+    dll = ctypes.CDLL(os.path.join(root, "multipathnet_amd", "libnms.so"))
+    f32p = ctypes.POINTER(ctypes.c_float)
+    shim.mpn_th_shim_from.restype = ctypes.c_void_p
+    shim.mpn_th_shim_from.argtypes = [f32p, ctypes.c_long, ctypes.c_long]
+    shim.mpn_th_shim_new.restype = ctypes.c_void_p
+    shim.THFloatTensor_data.restype = f32p
+    shim.THFloatTensor_data.argtypes = [ctypes.c_void_p]
+    shim.mpn_th_shim_size.restype = ctypes.c_long
+    shim.mpn_th_shim_size.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    for lib in (dll, shim):
+        lib.NMS.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float]
+    rng = np.random.default_rng(5)
+    for regime in ("distinct", "ties"):
+        for m in (300, 1000, 2000):
+            sb = random_scored_boxes(rng, m, regime)
+            t_in = shim.mpn_th_shim_from(sb.ctypes.data_as(f32p), m, 5)
+            k_dev, k_ref = shim.mpn_th_shim_new(), shim.mpn_th_shim_new()
+            out = {}
+            for name, lib, keep in (("libnms.so (device)", dll, k_dev), ("nms.c (host)", shim, k_ref)):
+                lib.NMS(keep, t_in, 0.3)  # warm-up (first call creates the stream / scratch)
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    lib.NMS(keep, t_in, 0.3)
+                out[name] = (time.perf_counter() - t0) / 20 * 1e6
+            k = shim.mpn_th_shim_size(k_dev, 0)
+            assert k == shim.mpn_th_shim_size(k_ref, 0)
+            a = np.ctypeslib.as_array(shim.THFloatTensor_data(k_dev), shape=(k, 5))
+            b = np.ctypeslib.as_array(shim.THFloatTensor_data(k_ref), shape=(k, 5))
+            assert np.array_equal(a, b)
+            print("NMS drop-in, %4d boxes, %-8s: kept %4d   libnms.so %7.1f us/call   reference nms.c %7.1f us/call" % (
+                m, regime, k, out["libnms.so (device)"], out["nms.c (host)"]))
+
+
 @pytest.mark.parametrize("regime", ["distinct", "ties"])
 def test_nms_wider_than_the_lds_paths(O, dev, regime):
     """nms.c has no size limit; tables wider than MPN_NMS_MAX_BOXES (6144) take the exact sweep kernel on HBM-resident arrays"""
