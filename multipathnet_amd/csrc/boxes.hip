@@ -226,15 +226,23 @@ __device__ __forceinline__ int topk_class_of(const int *__restrict__ cls_off, in
   return lo;
 }
 
+#ifdef MPN_DEBUG_HOOKS
+__device__ unsigned long long g_topk_trace[8];  // s_memtime stamps of thread 0 at the phase boundaries (tools/topk_trace.py)
+#define TOPK_STAMP(i) do { if (threadIdx.x == 0) g_topk_trace[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TOPK_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(1024) void keep_top_k_kernel(const float *__restrict__ keep, const int *__restrict__ n_keep,
                                                           int n_cls, int m_stride, int k, float *__restrict__ thresh_out,
                                                           float *__restrict__ out, int max_out, int *__restrict__ n_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned topk_keys[];  // [min(total, kTopkLdsKeys)]
   __shared__ int cls_off[kTopkMaxCls + 1];
   __shared__ unsigned hist[256];
-  __shared__ unsigned sel_prefix, sel_rank;
+  __shared__ unsigned sel_bin, sel_rank;
+  __shared__ unsigned wave_lo[16], wave_hi[16];
   __shared__ int wave_cnt[16];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
+  TOPK_STAMP(0);
   // ---- class offsets (exclusive prefix sum of the per-class counts): one wave, 64 classes per step
   if (wid == 0) {
     int run = 0;
@@ -260,22 +268,56 @@ __global__ __launch_bounds__(1024) void keep_top_k_kernel(const float *__restric
     return;
   }
   const int n_lds = min(total, kTopkLdsKeys);
+  TOPK_STAMP(1);
   auto load_key = [&](int i) -> unsigned {
     const int c = topk_class_of(cls_off, n_cls, i);
     return f2key(keep[((size_t)c * m_stride + (i - cls_off[c])) * 5 + 4]);
   };
-  for (int i = tid; i < n_lds; i += blockDim.x) topk_keys[i] = load_key(i);
-  if (tid == 0) { sel_prefix = 0; sel_rank = (unsigned)max(min(total, k), 1); }  // 1-based rank from the top
-  // ---- MSB-first radix select of the k-th largest key: 4 passes x 8 bits
-  unsigned prefix_mask = 0;
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = 24 - 8 * pass;
+  // key staging: 8 independent gathers in flight per thread (a one-load-per-trip loop pays the ~1.5 us global round trip 13
+  // times in a row at 13 k detections: most of the kernel's time)
+  for (int base = tid; base < n_lds; base += 8 * (int)blockDim.x) {
+    unsigned kv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * (int)blockDim.x;
+      kv[u] = i < n_lds ? load_key(i) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * (int)blockDim.x;
+      if (i < n_lds) topk_keys[i] = kv[u];
+    }
+  }
+  TOPK_STAMP(2);
+  if (tid == 0) sel_rank = (unsigned)max(min(total, k), 1);  // 1-based rank from the top
+  // ---- radix select of the k-th largest key on digits of the keys' OWN range: scores of one image share their top bits (the
+  // top byte of 13 k detection scores takes 2-3 values), and a histogram on raw bytes serialises ~13 k LDS atomics on those
+  // bins (measured: 20 us of the kernel's 28).  Each pass histograms (key - lo) >> shift over the current [lo, hi] with
+  // shift = bits(hi - lo) - 8, picks the bin that holds the rank and narrows [lo, hi] to it: <= 4 passes, ~128 bins in use.
+  unsigned mn = 0xffffffffu, mx = 0u;
+  for (int i = tid; i < total; i += blockDim.x) {
+    const unsigned key = i < n_lds ? topk_keys[i] : load_key(i);
+    mn = min(mn, key); mx = max(mx, key);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    mn = min(mn, (unsigned)__shfl_xor((int)mn, off));
+    mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
+  }
+  if (lane == 0) { wave_lo[wid] = mn; wave_hi[wid] = mx; }
+  __syncthreads();
+  unsigned lo = 0xffffffffu, hi = 0u;
+  for (int w = 0; w < nw; ++w) { lo = min(lo, wave_lo[w]); hi = max(hi, wave_hi[w]); }
+  TOPK_STAMP(3);
+  while (hi > lo) {  // block-uniform: lo / hi derive from shared values only
+    const unsigned width = hi - lo;
+    const int nb = 32 - __clz((int)width);
+    const int shift = nb > 8 ? nb - 8 : 0;
     for (int b = tid; b < 256; b += blockDim.x) hist[b] = 0;
     __syncthreads();
-    const unsigned prefix = sel_prefix;
     for (int i = tid; i < total; i += blockDim.x) {
       const unsigned key = i < n_lds ? topk_keys[i] : load_key(i);
-      if ((key & prefix_mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+      if (key >= lo && key <= hi) atomicAdd(&hist[(key - lo) >> shift], 1u);
     }
     __syncthreads();
     if (wid == 0) {  // the bin that holds the rank: suffix sums over the 256 bins, 4 bins per lane (lane 0 = bins 252..255)
@@ -292,19 +334,22 @@ __global__ __launch_bounds__(1024) void keep_top_k_kernel(const float *__restric
       const unsigned rank = sel_rank;
       const bool hit = before < rank && incl >= rank;
       const unsigned long long hm = __ballot(hit);
-      // rank > total cannot happen (rank <= total); the bin search mirrors the serial scan: bins 255 -> 1, bin 0 as the rest
+      // rank <= (keys inside [lo, hi]) by construction, so exactly one lane hits
       if (hm && lane == __builtin_ctzll(hm)) {
         unsigned acc = before;
         int b = b0 + 3;
         if (acc + h3 < rank) { acc += h3; b = b0 + 2; if (acc + h2 < rank) { acc += h2; b = b0 + 1; if (acc + h1 < rank) { acc += h1; b = b0; } } }
         sel_rank = rank - acc;
-        sel_prefix = prefix | ((unsigned)b << shift);
+        sel_bin = (unsigned)b;
       }
     }
-    prefix_mask |= 0xffu << shift;
     __syncthreads();
+    lo += sel_bin << shift;
+    hi = min(hi, lo + ((1u << shift) - 1u));
+    // (the next pass's hist zeroing is ordered after every thread's read of sel_bin by the barrier that follows it)
   }
-  const unsigned thr_key = sel_prefix;
+  const unsigned thr_key = lo;
+  TOPK_STAMP(4);
   if (tid == 0) *thresh_out = key2f(thr_key);
   // ---- ordered compaction of the survivors (key >= threshold key <=> score >= threshold)
   const int seg = (total + nw - 1) / nw;
@@ -317,6 +362,7 @@ __global__ __launch_bounds__(1024) void keep_top_k_kernel(const float *__restric
   }
   if (lane == 0) wave_cnt[wid] = cnt;
   __syncthreads();
+  TOPK_STAMP(5);
   int off = 0, all = 0;
   for (int w = 0; w < nw; ++w) { const int v = wave_cnt[w]; if (w < wid) off += v; all += v; }
   for (int i0 = s0; i0 < s1; i0 += 64) {
@@ -332,6 +378,7 @@ __global__ __launch_bounds__(1024) void keep_top_k_kernel(const float *__restric
     }
     off += __popcll(m);
   }
+  TOPK_STAMP(6);
   if (tid == 0) *n_out = all;  // the UNTRUNCATED survivor count: > max_out tells the caller rows were dropped
 }
 
@@ -581,3 +628,11 @@ extern "C" int mpn_keep_top_k(const float *d_keep, const int *d_n_keep, int n_cl
   MPN_CHECK_LAUNCH();
   return MPN_OK;
 }
+
+#ifdef MPN_DEBUG_HOOKS
+extern "C" int mpn_debug_get_topk_trace(unsigned long long *h_out8) {
+  MPN_CHECK_ARG(h_out8);
+  MPN_CHECK_HIP(hipMemcpyFromSymbol(h_out8, HIP_SYMBOL(mpn::g_topk_trace), 8 * sizeof(unsigned long long)));
+  return MPN_OK;
+}
+#endif
