@@ -9,7 +9,7 @@ def run(ab):
     rc = lib.mpn_debug_bench_conv(3, 64, 600, 1000, 0, 20, C.byref(ms))
     assert rc == 0
     return ms.value * 1e3
-for blocks in sys.argv[1:] or ["1024"]:
+for blocks in sys.argv[1:] or ["1280"]:  # 1280 = the product default (-> 1200 blocks x 2 tiles at 600 x 1000)
     os.environ["MPN_FIRST_BLOCKS"] = blocks
     for ab in [0, 1, 2, 3]:
         us = run(ab)

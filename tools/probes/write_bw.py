@@ -1,3 +1,5 @@
+"""HBM write / copy ceiling with plain streaming kernels (torch fill_ / copy_), at the sizes of the path's big writers: conv1_1's
+154 MB output and ROI pooling's 100 MB.  The figure an HBM-bound kernel's stores are judged against."""
 import torch, time
 dev=torch.device("cuda",0)
 for mb in (154, 77, 38):

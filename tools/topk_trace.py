@@ -24,7 +24,8 @@ for name, gen in (("distinct", lambda n: np.sort(rng.random(n).astype(np.float32
     tr = (C.c_ulonglong * 8)()
     lib.mpn_debug_get_topk_trace(tr)
     t = [int(x) for x in tr]
-    names = ["class offsets", "setup", "key staging", "min/max", "radix select", "count", "compaction"]
-    print("%s: %d keys, kept %d, %.1f us (events; null stream)  s_memtime ticks (100 MHz):" % (name, int(n.sum()), int(no.item()), e0.elapsed_time(e1) * 1e3))
+    names = ["class offsets", "key staging", "min / max", "radix select", "count", "compaction"]
+    tot = t[6] - t[0]
+    print("%s: %d keys, kept %d, %.1f us (events; null stream); s_memtime (shader cycles), %d in total:" % (name, int(n.sum()), int(no.item()), e0.elapsed_time(e1) * 1e3, tot))
     for i in range(6):
-        print("   %-14s %6d ticks = %6.2f us" % (names[i if i < 1 else i], t[i + 1] - t[i], (t[i + 1] - t[i]) / 100.0))
+        print("   %-14s %6d cycles = %4.1f %%" % (names[i], t[i + 1] - t[i], 100.0 * (t[i + 1] - t[i]) / tot))

@@ -3,7 +3,7 @@ dominant kernel groups (FETCH_SIZE / WRITE_SIZE are in KB; gfx950 correction fro
 counts the 128-byte requests of wide coalesced reads as 64 B, so it is doubled)."""
 import json, re, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-groups = {"conv_wino": "conv3x3_wino_kernel", "fc": "gemm_c8_pf_kernel", "conv_direct": "conv3x3_first_kernel", "roi_pool": "roi_pool_c8"}
+groups = {"conv_wino": "conv3x3_wino_kernel", "fc": "gemm_c8_pf_kernel", "conv_direct": "conv3x3_first_kernel", "roi_pool": "roi_pool_pm_kernel"}
 def load(path, key):
     out = {}
     for line in open(path):
