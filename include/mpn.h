@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MPN_VERSION 200
+#define MPN_VERSION 201
 
 typedef enum mpn_status {
   MPN_OK = 0,
@@ -265,6 +265,9 @@ typedef struct mpn_mpnet_weights {
   int tap_conv3, tap_conv4;  /* 0-based conv-layer indices whose pre-pool outputs are "conv3"/"conv4" (VGG-16: 6, 9) */
   int n_integral;            /* K (opt.nDonkeys in the reference, 6 in scripts/train_multipathnet_coco.sh:8) */
   const float *mix_w[8], *mix_b[8], *fc6_w[8], *fc6_b[8], *fc7_w[8], *fc7_b[8];
+  int conv345_unnormalized;  /* 0 (default, opt.model_conv345_norm = true): per-map nn.Normalize(2) then MulConstant(1000);
+                              * 1: the isNormalized = false branch, MulConstant(1), (1/30), (1/200) on conv5 / conv4 / conv3 and
+                              * no x1000 (model_utils.lua:214-223,231-244).  (added in MPN_VERSION 201, at the END of the struct) */
 } mpn_mpnet_weights;
 int mpn_mpnet_create(const mpn_frcnn_config *cfg, const float *const *d_conv_w, const float *const *d_conv_b,
                      const mpn_mpnet_weights *mw, const float *d_cls_w, const float *d_cls_b, const float *d_bbox_w,

@@ -40,6 +40,7 @@ class MpnetWeights(C.Structure):
         ("n_towers", C.c_int), ("region", C.c_int * 8), ("use_conv4", C.c_int * 8), ("use_conv3", C.c_int * 8),
         ("tap_conv3", C.c_int), ("tap_conv4", C.c_int), ("n_integral", C.c_int),
         ("mix_w", f32p * 8), ("mix_b", f32p * 8), ("fc6_w", f32p * 8), ("fc6_b", f32p * 8), ("fc7_w", f32p * 8), ("fc7_b", f32p * 8),
+        ("conv345_unnormalized", C.c_int),
     ]
 
 

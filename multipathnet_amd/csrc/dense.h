@@ -100,5 +100,6 @@ int roi_pool_c8_rmq(Act feat, const float *d_tables, const float *d_rois, int N,
                     int end_adjust, float *d_x_c8, hipStream_t s, int roi_stride = 5, int Mp = 0);
 // in-place x * (mul / sqrt(sum x^2 + 1e-10)) per ROI over n_records 8-float records of a C8 matrix
 int l2norm_scale_c8(float *d_x_c8, int n_records, int Mp, int N, float mul, hipStream_t s);
+int mul_const_c8(float *d_x_c8, int n_records, int Mp, int N, float mul, hipStream_t s);  // nn.MulConstant on the same layout
 
 }  // namespace mpn

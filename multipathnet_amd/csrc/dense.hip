@@ -1631,9 +1631,14 @@ __global__ __launch_bounds__(256) void l2norm_apply_kernel(float *__restrict__ x
   const size_t r = q / N;
   float *p = x + (r * Mp + n) * 8 + h * 4;
   f32x4 v = *reinterpret_cast<f32x4 *>(p);
-  const float d = nrm[n];
+  if (nrm) {
+    const float d = nrm[n];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = (v[e] / d) * mul;
+    for (int e = 0; e < 4; ++e) v[e] = (v[e] / d) * mul;
+  } else {  // nn.MulConstant(mul): the isNormalized = false branch of conv345Combine (model_utils.lua:222-223)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] * mul;
+  }
   *reinterpret_cast<f32x4 *>(p) = v;
 }
 
@@ -1652,6 +1657,15 @@ int l2norm_scale_c8(float *d_x_c8, int n_records, int Mp, int N, float mul, hipS
   MPN_CHECK_LAUNCH();
   const size_t total = (size_t)n_records * N * 2;
   hipLaunchKernelGGL(l2norm_apply_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, d_x_c8, (size_t)n_records, Mp, N, nrm, mul);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+int mul_const_c8(float *d_x_c8, int n_records, int Mp, int N, float mul, hipStream_t s) {
+  MPN_CHECK_ARG(d_x_c8 && n_records > 0 && N > 0 && Mp >= N);
+  if (mul == 1.0f) return MPN_OK;  // x * 1.0f == x bit for bit
+  const size_t total = (size_t)n_records * N * 2;
+  hipLaunchKernelGGL(l2norm_apply_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, d_x_c8, (size_t)n_records, Mp, N, (const float *)nullptr, mul);
   MPN_CHECK_LAUNCH();
   return MPN_OK;
 }

@@ -165,6 +165,7 @@ struct mpn_frcnn {
   std::vector<int> rn_region;   // ResNet towers: Foveal region per tower (empty = plain resnet.lua)
   ResNetGraph *rn = nullptr;  // ResNet Fast R-CNN (mpn_resnet_create): trunk + per-ROI layer4 replace the VGG convs / fc6 / fc7
   int tap3 = -1, tap4 = -1, n_integral = 1;
+  bool conv345_norm = true;  // model_conv345_norm (model_utils.lua:209): false = the MulConstant(1, 1/30, 1/200) branch
   std::vector<Tower> towers;
   float *fov = nullptr, *tx = nullptr, *ty = nullptr, *tz6 = nullptr, *cat = nullptr, *cls_rm = nullptr, *bbox_rm = nullptr;
   float *wcls = nullptr, *bcls = nullptr, *wbbox = nullptr, *bbbox = nullptr;
@@ -268,7 +269,7 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
   const int tower_heads = rw ? rw->n_heads : (gw ? gw->n_heads : 0);  // > 1: MultiPathNet towers on a ResNet / op-list backbone
   const int *tower_region = rw ? rw->head_region : (gw ? gw->head_region : nullptr);
   if (tower_heads > 1) p->n_integral = (rw ? rw->n_integral : gw->n_integral) > 0 ? (rw ? rw->n_integral : gw->n_integral) : 1;
-  if (mw) { p->is_mpnet = true; p->tap3 = mw->tap_conv3; p->tap4 = mw->tap_conv4; p->n_integral = mw->n_integral > 0 ? mw->n_integral : 1; }
+  if (mw) { p->is_mpnet = true; p->tap3 = mw->tap_conv3; p->tap4 = mw->tap_conv4; p->n_integral = mw->n_integral > 0 ? mw->n_integral : 1; p->conv345_norm = !mw->conv345_unnormalized; }
   const int n_conv = graph_net ? 0 : cfg->n_conv;
   p->cfg.n_conv = n_conv;
   if (n_conv) { p->cout.assign(cfg->conv_cout, cfg->conv_cout + n_conv); p->pool_after.assign(cfg->pool_after, cfg->pool_after + n_conv); }
@@ -515,6 +516,7 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
   if (rc) return rc;
   const Act maps[3] = {p->tap_act[0], p->tap_act[1], p->tap_act[2]};
   const float scales[3] = {c.spatial_scale, c.spatial_scale * 2.0f, c.spatial_scale * 4.0f};
+  const float kConv345Factor[3] = {1.0f, (float)(1.0 / 30), (float)(1.0 / 200)};  // model_utils.lua:231-237 normFactor (Lua doubles -> float)
   const int Fcb = lin_np(F) / 8;
   if (!p->vmax_valid) {  // once per trunk run; iterative localisation on the cached maps reuses them
     ProfScope ps(p, MPN_PROF_ROIPOOL, s);
@@ -532,7 +534,8 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
       float *dst = p->tx + (size_t)cb_off * PP * Mp * 8;
       { ProfScope ps(p, MPN_PROF_ROIPOOL, s);
         rc = roi_pool_c8_rmq(maps[m], p->vmax_tab[m], reg, N, c.pooled_h, c.pooled_w, scales[m], 1.0f, 0, dst, s, 20, Mp);
-        if (rc == MPN_OK) rc = l2norm_scale_c8(dst, maps[m].Cb() * PP, Mp, N, 1000.0f, s); }
+        if (rc == MPN_OK) rc = p->conv345_norm ? l2norm_scale_c8(dst, maps[m].Cb() * PP, Mp, N, 1000.0f, s)
+                                               : mul_const_c8(dst, maps[m].Cb() * PP, Mp, N, kConv345Factor[m], s); }
       if (rc) return rc;
       cb_off += maps[m].Cb();
     }

@@ -596,6 +596,7 @@ class FastRCNN(object):
             mw.n_towers = len(tow)
             mw.tap_conv3, mw.tap_conv4 = conv_tap_indices(cfg)
             mw.n_integral = params["n_integral"]
+            mw.conv345_unnormalized = 0 if params.get("conv345_norm", True) else 1  # opt.model_conv345_norm (model_utils.lua:209)
             keep = []
             for t, T in enumerate(tow):
                 mw.region[t], mw.use_conv4[t], mw.use_conv3[t] = T["region"], T["use4"], T["use3"]

@@ -399,17 +399,27 @@ def test_one(im, boxes, P, nms_thresh=0.3, score_thresh=-1.5, use_ref_nms=False,
 
 
 # ---------------------------------------------------------------- MultiPathNet head (models/multipathnet.lua:64-120)
-def conv345_combine(maps, region_rois, T, pooled=7, spatial_scale=1.0 / 16):
-    """model_utils.lua:209-251 with isNormalized=true: per map ROIPooling(7,7,scale_m) -> View(-1, C*49) -> nn.Normalize(2)
-    -> View(-1,C,7,7); JoinTable(2) [conv5, conv4, conv3]; MulConstant(1000); 1x1 conv mix; View(-1)."""
+CONV345_NORM_FACTOR = (1.0, 1.0 / 30, 1.0 / 200)  # model_utils.lua:231-237: normFactor of conv5 / conv4 / conv3
+
+
+def conv345_combine(maps, region_rois, T, pooled=7, spatial_scale=1.0 / 16, is_normalized=True):
+    """model_utils.lua:209-251.  isNormalized=true: per map ROIPooling(7,7,scale_m) -> View(-1, C*49) -> nn.Normalize(2)
+    -> View(-1,C,7,7); JoinTable(2) [conv5, conv4, conv3]; MulConstant(1000); 1x1 conv mix; View(-1).
+    isNormalized=false (lines 222-223): nn.MulConstant(normFactor) per map instead of the normalisation, and no x1000
+    (line 243 is inside `if isNormalized`).  MulConstant multiplies the FloatTensor by the Lua double: x * float32(factor) in fp32."""
     parts = []
     for m, use in enumerate((1, T["use4"], T["use3"])):
         if not use:
             continue
         pool, _ = roi_pool(maps[m], region_rois, pooled, pooled, spatial_scale * (2 ** m))
         n = pool.shape[0]
-        parts.append(l2_normalize(pool.reshape(n, -1)).reshape(pool.shape))
-    x = np.concatenate(parts, 1) * np.float32(1000.0)                     # [N, totalFeat, 7, 7]
+        if is_normalized:
+            parts.append(l2_normalize(pool.reshape(n, -1)).reshape(pool.shape))
+        else:
+            parts.append(pool * np.float32(CONV345_NORM_FACTOR[m]))
+    x = np.concatenate(parts, 1)                                          # [N, totalFeat, 7, 7]
+    if is_normalized:
+        x = x * np.float32(1000.0)
     n, tf = x.shape[:2]
     rows = np.ascontiguousarray(x.transpose(0, 2, 3, 1).reshape(-1, tf))  # one row per (roi, bin): the 1x1 conv is a linear over channels
     y = linear(rows, T["mix_w"], T["mix_b"])                              # [N*49, c5]
@@ -421,7 +431,7 @@ def mpnet_head(maps, rois, P, pooled=7, spatial_scale=1.0 / 16):
     fov = foveal(rois).reshape(-1, 4, 5)
     outs = []
     for T in P["towers"]:
-        x = conv345_combine(maps, np.ascontiguousarray(fov[:, T["region"]]), T, pooled, spatial_scale)
+        x = conv345_combine(maps, np.ascontiguousarray(fov[:, T["region"]]), T, pooled, spatial_scale, is_normalized=P.get("conv345_norm", True))
         x = linear(x, T["fc6_w"], T["fc6_b"], relu=True)
         outs.append(linear(x, T["fc7_w"], T["fc7_b"], relu=True))
     cat = np.concatenate(outs[:-1], 1)                                    # ModelParallelTable concat along dim 2 + Narrow

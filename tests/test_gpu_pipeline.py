@@ -196,14 +196,20 @@ def _np_tree(v):
     return v.numpy() if hasattr(v, "numpy") else v
 
 
-def test_multipathnet_head_vs_oracle(O, dev):
+@pytest.mark.parametrize("conv345_norm", [True, False])
+def test_multipathnet_head_vs_oracle(O, dev, conv345_norm):
     """BASELINE configs[2] graph at an oracle-sized scale: Foveal -> 5 towers (conv345Combine skip pooling + per-map L2
     normalise + 1x1 mix, fc6, fc7) -> K integral classifiers (mean of softmaxes) + het-tower box regressor
-    (multipathnet.lua:64-120, model_utils.lua:209-251,275-317)."""
+    (multipathnet.lua:64-120, model_utils.lua:209-251,275-317).  conv345_norm = False is opt.model_conv345_norm = false:
+    MulConstant(1), (1/30), (1/200) per map instead of the L2 normalisation, no x1000 (model_utils.lua:222-223,239-241)."""
     from multipathnet_amd import models
     cfg = [8, 16, "P", 16, 24, "P", 32, 32, "P", 64, "P", 64]
     H, W, N, Cn, K = 150, 250, 120, 9, 3
     P = models.synthetic_mpnet_params(cfg, pooled=7, fc_dim=128, n_classes=Cn, n_integral=K, seed=11)
+    P["conv345_norm"] = conv345_norm
+    if not conv345_norm:  # unnormalised features are ~1000x smaller than the x1000 normalised ones: keep the head's inputs O(1)
+        for T in P["towers"]:
+            T["mix_w"] = T["mix_w"] * 300.0
     rng = np.random.default_rng(21)
     im = rng.random((3, H, W), dtype=np.float32)
     boxes = _boxes(rng, N, W, H, lo=12)
