@@ -36,7 +36,7 @@ def _worker(rank, world, port, n_images, top_cap, q):
         per_step.append(parallel.gather_detections(rec).clone())
     merged = parallel.merge_by_image(per_step, world, n_images, top_cap)
     if rank == 0:
-        q.put([m.clone() for m in merged])
+        q.put([m.numpy().copy() for m in merged])  # by value (numpy pickles): torch tensors travel as shared-memory handles that tie the child's exit to the parent
     dist.barrier()
     dist.destroy_process_group()
 
@@ -49,7 +49,7 @@ def _run_world2(n_images, top_cap, world):
     for p in procs:
         p.start()
     try:
-        merged = q.get(timeout=180)
+        merged = [torch.from_numpy(x) for x in q.get(timeout=180)]
     except Exception:
         merged = None
     ok = merged is not None
