@@ -216,6 +216,7 @@ __device__ __forceinline__ float key2f(unsigned k) {
 // (sum of earlier waves' counts) + rank-in-slice — an ordered compaction with two block barriers in total.
 constexpr int kTopkLdsKeys = 32768;  // 128 KiB of the CU's 160 KiB
 constexpr int kTopkMaxCls = 1024;
+constexpr int kTopkCand = 2048;   // keep_top_k: candidate list of the radix select (keys of the bin the first pass picked)
 
 __device__ __forceinline__ int topk_class_of(const int *__restrict__ cls_off, int n_cls, int i) {  // last c with cls_off[c] <= i
   int lo = 0, hi = n_cls - 1;
@@ -238,7 +239,8 @@ __global__ __launch_bounds__(1024) void keep_top_k_kernel(const float *__restric
   extern __shared__ __attribute__((aligned(16))) unsigned topk_keys[];  // [min(total, kTopkLdsKeys)]
   __shared__ int cls_off[kTopkMaxCls + 1];
   __shared__ unsigned hist[256];
-  __shared__ unsigned sel_bin, sel_rank;
+  __shared__ unsigned sel_bin, sel_rank, sel_cnt;
+  __shared__ int cand_n;
   __shared__ unsigned wave_lo[16], wave_hi[16];
   __shared__ int wave_cnt[16];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
@@ -275,6 +277,7 @@ __global__ __launch_bounds__(1024) void keep_top_k_kernel(const float *__restric
   };
   // key staging: 8 independent gathers in flight per thread (a one-load-per-trip loop pays the ~1.5 us global round trip 13
   // times in a row at 13 k detections: most of the kernel's time)
+  unsigned mn = 0xffffffffu, mx = 0u;  // the keys' range, gathered while they pass through registers
   for (int base = tid; base < n_lds; base += 8 * (int)blockDim.x) {
     unsigned kv[8];
 #pragma unroll
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(1024) void keep_top_k_kernel(const float *__restric
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = base + u * (int)blockDim.x;
-      if (i < n_lds) topk_keys[i] = kv[u];
+      if (i < n_lds) { topk_keys[i] = kv[u]; mn = min(mn, kv[u]); mx = max(mx, kv[u]); }
     }
   }
   TOPK_STAMP(2);
@@ -294,9 +297,8 @@ __global__ __launch_bounds__(1024) void keep_top_k_kernel(const float *__restric
   // top byte of 13 k detection scores takes 2-3 values), and a histogram on raw bytes serialises ~13 k LDS atomics on those
   // bins (measured: 20 us of the kernel's 28).  Each pass histograms (key - lo) >> shift over the current [lo, hi] with
   // shift = bits(hi - lo) - 8, picks the bin that holds the rank and narrows [lo, hi] to it: <= 4 passes, ~128 bins in use.
-  unsigned mn = 0xffffffffu, mx = 0u;
-  for (int i = tid; i < total; i += blockDim.x) {
-    const unsigned key = i < n_lds ? topk_keys[i] : load_key(i);
+  for (int i = n_lds + tid; i < total; i += blockDim.x) {  // keys beyond the LDS stage (> 32 768 rows): straight from memory
+    const unsigned key = load_key(i);
     mn = min(mn, key); mx = max(mx, key);
   }
 #pragma unroll
@@ -309,15 +311,28 @@ __global__ __launch_bounds__(1024) void keep_top_k_kernel(const float *__restric
   unsigned lo = 0xffffffffu, hi = 0u;
   for (int w = 0; w < nw; ++w) { lo = min(lo, wave_lo[w]); hi = max(hi, wave_hi[w]); }
   TOPK_STAMP(3);
+  // After the first pass the rank lives in ONE bin (~1 % of the keys): those keys are compacted into a small LDS list and the
+  // remaining passes walk only that list instead of all the keys again (unless ties put more than kTopkCand keys into the bin).
+  unsigned *const cand = topk_keys + n_lds + 4;
+  bool use_cand = false;
+  int ncand = 0;
+  if (tid == 0) cand_n = 0;
   while (hi > lo) {  // block-uniform: lo / hi derive from shared values only
     const unsigned width = hi - lo;
     const int nb = 32 - __clz((int)width);
     const int shift = nb > 8 ? nb - 8 : 0;
     for (int b = tid; b < 256; b += blockDim.x) hist[b] = 0;
     __syncthreads();
-    for (int i = tid; i < total; i += blockDim.x) {
-      const unsigned key = i < n_lds ? topk_keys[i] : load_key(i);
-      if (key >= lo && key <= hi) atomicAdd(&hist[(key - lo) >> shift], 1u);
+    if (use_cand) {
+      for (int i = tid; i < ncand; i += blockDim.x) {
+        const unsigned key = cand[i];
+        if (key >= lo && key <= hi) atomicAdd(&hist[(key - lo) >> shift], 1u);
+      }
+    } else {
+      for (int i = tid; i < total; i += blockDim.x) {
+        const unsigned key = i < n_lds ? topk_keys[i] : load_key(i);
+        if (key >= lo && key <= hi) atomicAdd(&hist[(key - lo) >> shift], 1u);
+      }
     }
     __syncthreads();
     if (wid == 0) {  // the bin that holds the rank: suffix sums over the 256 bins, 4 bins per lane (lane 0 = bins 252..255)
@@ -336,17 +351,27 @@ __global__ __launch_bounds__(1024) void keep_top_k_kernel(const float *__restric
       const unsigned long long hm = __ballot(hit);
       // rank <= (keys inside [lo, hi]) by construction, so exactly one lane hits
       if (hm && lane == __builtin_ctzll(hm)) {
-        unsigned acc = before;
+        unsigned acc = before, cnt = h3;
         int b = b0 + 3;
-        if (acc + h3 < rank) { acc += h3; b = b0 + 2; if (acc + h2 < rank) { acc += h2; b = b0 + 1; if (acc + h1 < rank) { acc += h1; b = b0; } } }
+        if (acc + h3 < rank) { acc += h3; b = b0 + 2; cnt = h2; if (acc + h2 < rank) { acc += h2; b = b0 + 1; cnt = h1; if (acc + h1 < rank) { acc += h1; b = b0; cnt = h0; } } }
         sel_rank = rank - acc;
         sel_bin = (unsigned)b;
+        sel_cnt = cnt;
       }
     }
     __syncthreads();
     lo += sel_bin << shift;
     hi = min(hi, lo + ((1u << shift) - 1u));
     // (the next pass's hist zeroing is ordered after every thread's read of sel_bin by the barrier that follows it)
+    if (!use_cand && hi > lo && sel_cnt <= (unsigned)kTopkCand) {
+      for (int i = tid; i < total; i += blockDim.x) {
+        const unsigned key = i < n_lds ? topk_keys[i] : load_key(i);
+        if (key >= lo && key <= hi) cand[atomicAdd(&cand_n, 1)] = key;
+      }
+      __syncthreads();
+      ncand = cand_n;
+      use_cand = true;
+    }
   }
   const unsigned thr_key = lo;
   TOPK_STAMP(4);
@@ -622,8 +647,8 @@ extern "C" int mpn_keep_top_k(const float *d_keep, const int *d_n_keep, int n_cl
   MPN_CHECK_ARG(n_cls <= kTopkMaxCls);
   size_t nkeys = (size_t)n_cls * (size_t)m_stride;
   if (nkeys > (size_t)kTopkLdsKeys) nkeys = kTopkLdsKeys;
-  { int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(keep_top_k_kernel), kTopkLdsKeys * 4); if (rc_attr) return rc_attr; }
-  hipLaunchKernelGGL(keep_top_k_kernel, dim3(1), dim3(1024), nkeys * 4 + 16, as_stream(stream), d_keep, d_n_keep, n_cls, m_stride, k,
+  { int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(keep_top_k_kernel), kTopkLdsKeys * 4 + 32 + kTopkCand * 4); if (rc_attr) return rc_attr; }
+  hipLaunchKernelGGL(keep_top_k_kernel, dim3(1), dim3(1024), nkeys * 4 + 32 + kTopkCand * 4, as_stream(stream), d_keep, d_n_keep, n_cls, m_stride, k,
                      d_thresh, d_out, max_out, d_n_out);
   MPN_CHECK_LAUNCH();
   return MPN_OK;
