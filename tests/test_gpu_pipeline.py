@@ -155,6 +155,35 @@ def test_other_image_sizes_rezero_halo(O, dev, H, W):
     assert np.abs(bbox.cpu().numpy() - ref_bbox).max() < 1e-4 * W
 
 
+def test_ragged_shapes_one_handle(O, dev):
+    """one handle, a sequence of odd image sizes and ROI counts (1 ROI, counts that are not a multiple of the 4-ROI pooling
+    groups, maps narrower than one conv tile, a 1-tile first layer): scores, boxes and the whole testOne tail vs the oracle"""
+    from multipathnet_amd import models
+    cfg = [8, 8, "P", 16, "P", 16]
+    P = models.synthetic_params(cfg, pooled=7, fc_dim=32, n_classes=5, seed=3)
+    Pn = _np_params(P)
+    net = models.FastRCNN(P, cfg=cfg, pooled=7, spatial_scale=0.25, max_h=160, max_w=256, max_rois=70)
+    rng = np.random.default_rng(99)
+    for (H, W, N) in [(160, 256, 70), (17, 23, 1), (33, 31, 3), (8, 32, 5), (9, 33, 6), (101, 7, 2), (64, 200, 69), (40, 40, 13)]:
+        im = rng.random((3, H, W), dtype=np.float32)
+        boxes = _boxes(rng, N, W, H, lo=2)
+        imd, bd = torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev)
+        scores, bbox = net.detect(imd, bd)
+        feat = O.vgg_trunk(O.image_transform(im, **O.ROSS), Pn["conv_w"], Pn["conv_b"], cfg)
+        logits, deltas = O.frcnn_head(feat, O.project_im_rois(boxes, 1.0), Pn, pooled=7, spatial_scale=0.25)
+        assert scores.shape == (N, 5)
+        assert np.abs(scores.cpu().numpy() - O.softmax(logits)).max() < 1e-4, (H, W, N)
+        assert np.abs(bbox.cpu().numpy() - O.clamp_boxes(O.bbox_decode(boxes, deltas), W, H)).max() < 1e-4 * max(W, H), (H, W, N)
+        dets, n = net.test_one_async(imd, bd)
+        torch.cuda.synchronize()
+        s, b = scores.cpu().numpy(), bbox.cpu().numpy()
+        per = [O.nms(O.select_scored(s, b, j, -1.5)[0], 0.3) for j in range(1, 5)]
+        kept, _ = O.keep_top_k(per, 100)
+        rows = [np.concatenate([k, np.full((k.shape[0], 1), j + 1, np.float32)], 1) for j, k in enumerate(kept) if k.size]
+        exp = np.concatenate(rows) if rows else np.zeros((0, 6), np.float32)
+        assert np.array_equal(dets[: int(n.item())].cpu().numpy(), exp), (H, W, N)
+
+
 def test_pipelined_equals_serial(dev, small):
     """mpn_frcnn_test_one_pipelined (NMS tail on the side stream, overlapping the next image) returns exactly what the
     serial form returns, image after image, with results valid one call later / after flush."""
