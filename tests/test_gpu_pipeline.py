@@ -456,6 +456,40 @@ def test_host_fed_pipeline_equals_device_fed(dev, small):
         assert torch.equal(a, b)
 
 
+def test_pipelined_host_fed_soak(dev, small):
+    """240 images through the host-fed pipelined loop without a host sync in between (three different images and sizes in
+    rotation, results read back only at the end from per-step output buffers): every step must reproduce the serial result of its
+    image bit for bit — a race between the copy stream, the launch stream and the side stream's NMS tail shows up here"""
+    net = small["net"]
+    rng = np.random.default_rng(17)
+    s = SMALL
+    shapes = [(s["H"], s["W"], s["N"]), (120, 200, 150), (s["H"], s["W"], 64)]
+    ims = [rng.random((3, h, w), dtype=np.float32) for h, w, _ in shapes]
+    bxs = [_boxes(rng, n, w, h) for h, w, n in shapes]
+    ref = []
+    for im, b in zip(ims, bxs):
+        d, n = net.test_one_async(torch.from_numpy(im).to(dev), torch.from_numpy(b).to(dev))
+        torch.cuda.synchronize()
+        ref.append(d[: int(n.item())].clone())
+    pin = [(torch.from_numpy(im).pin_memory(), torch.from_numpy(b).pin_memory()) for im, b in zip(ims, bxs)]
+    steps = 240
+    snap_d, snap_n = [], []
+    prev = None
+    for t_ in range(steps):
+        cur = net.test_one_pipelined_host(*pin[t_ % 3])
+        if prev is not None:  # image t-1's record is stream-ordered now: copy it aside on the launch stream (no host sync)
+            snap_d.append(prev[0].clone()); snap_n.append(prev[1].clone())
+        prev = cur
+    net.flush()
+    snap_d.append(prev[0].clone()); snap_n.append(prev[1].clone())
+    torch.cuda.synchronize()
+    assert len(snap_d) == steps
+    for t_ in range(steps):
+        n = int(snap_n[t_].item())
+        assert n == ref[t_ % 3].shape[0], t_
+        assert torch.equal(snap_d[t_][:n], ref[t_ % 3]), t_
+
+
 def test_two_handles_two_threads_two_streams(dev, small):
     """SURVEY §8b 'Threading' / test_runner.lua:55-66: the reference drives one worker thread per GPU inside ONE process.
     No library state is process-global: two pipeline handles (different networks, so different split-K / NMS scratch sizes)
