@@ -279,9 +279,10 @@ MPN_KNOB(int, g_gemm_ablate, 0);         // timing-experiment switch of the conv
 // First layer (<= 4 input channels; VGG conv1_1: 3 -> 64 on the full-resolution image).
 // The generic kernel spends 9 taps x 8-channel chunks = 72 K-steps on a layer whose real K is 27, and the layer is
 // HBM-bound on its output (154 MB at 600 x 1000): here K = 9 taps x 4 channels = 36 (18 MFMA k-pairs, the 4th channel is
-// the C8P record's zero pad), weights live in registers for the whole block, the (TH+2) x 34 x 4-channel input tile is
-// staged once into LDS as channel planes (conflict-free ds_read_b32: lanes = consecutive pixels), and ~16 KB of LDS lets
-// several blocks share a CU so that one block's store burst overlaps another's MFMAs.
+// the C8P record's zero pad), the 36 x 64 weight block and the bias live in LDS for the whole (persistent) block, the
+// (TH+2) x 34 x 4-channel input tile is staged into LDS as channel planes (conflict-free ds_read_b32: lanes = consecutive
+// pixels), double-buffered, and 20.5 KB of LDS + 71 VGPRs let five blocks share a CU so that one block's stores overlap
+// another's MFMAs (see the kernel body for the ordering rules that make that overlap actually happen).
 // Packed weights: w36[(tap*2 + p)*2 + half][CoutP] = w[cout][cin = 2p + half][tap]  (cin >= Cin -> 0).
 // =================================================================================================
 constexpr int kF_TH = 8;                       // rows per block tile (4 waves x 2 rows), 32 columns
