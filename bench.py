@@ -16,6 +16,18 @@ decode / clamp -> per-class NMS -> top-100 -> (N>1) RCCL all-gather of the score
 image per rank per step); value = all ranks' proposals / max-over-ranks time.  `value_inputs_resident` repeats the
 measurement with the image and boxes already in HBM (no per-step upload).
 
+`--mode latency` is the ROI-sharded form of north_star's "images+proposals shard across the 8 GPUs": every rank is handed the SAME
+image and proposal table, runs the trunk, the ROI head on its 1/N of the proposals and the NMS on its 1/N of the classes
+(mpn_frcnn_test_one_sharded: two RCCL all-gathers of scored boxes); the line it prints has its own metric string (per-image
+latency, strong scaling) and is never the headline.
+
+N > 1 details: the launcher's process group is `gloo` (rendezvous, barriers and the MAX over ranks of the elapsed time — CPU
+side); the ONLY RCCL communicator a rank holds is the C ABI's mpn_comm.  Ranks pin themselves to the CPUs of their GPU's NUMA
+node; each rank rotates four different pinned images (offset by rank), so uploads are not served from a warm cache.
+MPN_BENCH_SHARE_GPU=1 (test only, stated in config.parallelism) maps every rank to device 0 and sends the record gather through
+gloo, so that `--gpus 2` exercises the launch / rank / drift-stream / reduction logic on a one-GPU box (RCCL refuses two ranks on
+one device).
+
 Prints ONE JSON line (rank 0).  Extra objects:
   "roofline"      dominant kernel group (the Winograd convolutions), fp32-MFMA bound.  `achieved` / `frac` count the FLOPs the
                   matrix pipe EXECUTES (Winograd F(2x2,3x3): 16 multiplies per 4 outputs instead of 36 => direct-conv FLOPs /
@@ -56,10 +68,12 @@ def conv_flops(cfg, h, w):
     return out
 
 
-def synthetic_inputs():
-    rng = np.random.default_rng(555)
+def synthetic_inputs(variant=0):
+    """variant 0 = SURVEY §8d's inputs (image seed 555, ROI seed 556); variants 1.. = further images / proposal sets of the same
+    distribution (the bench rotates four, so that consecutive steps do not upload and score the same bytes)"""
+    rng = np.random.default_rng(555 + 1000 * variant)
     im = rng.random((3, H, W), dtype=np.float32)
-    rng = np.random.default_rng(556)
+    rng = np.random.default_rng(556 + 1000 * variant)
     boxes = np.zeros((0, 4), np.float32)
     while boxes.shape[0] < N_ROIS:  # SURVEY §8d: centre uniform, log-uniform w,h in [16,600], clipped, area > 2
         c = rng.uniform([1, 1], [W, H], (2 * N_ROIS, 2))
@@ -291,6 +305,29 @@ def _cfg_inception_mpn(models, args):  # BASELINE configs[4]
 OTHER_CONFIGS = {"c1": _cfg_alexnet, "c3": _cfg_vgg_mpn, "c4": _cfg_resnet_mpn, "c5": _cfg_inception_mpn}
 
 
+def pin_to_gpu_numa_node(dev_index):
+    """CPU affinity of this rank = the CPUs local to its GPU (sysfs local_cpulist of the device's PCI function).  Best effort:
+    returns a short description for the JSON line, never raises."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(dev_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        base = "/sys/bus/pci/devices/" + bdf
+        node = int(open(base + "/numa_node").read().strip())
+        cpus = set()
+        for part in open(base + "/local_cpulist").read().strip().split(","):
+            if part:
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= set(os.sched_getaffinity(0))
+        if node < 0 or not cpus:
+            return "none (no NUMA node reported for %s)" % bdf
+        os.sched_setaffinity(0, cpus)
+        return "NUMA node %d of %s (%d cpus)" % (node, bdf, len(cpus))
+    except Exception as e:  # noqa: BLE001
+        return "none (%s)" % str(e).splitlines()[-1][:80]
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with no launcher: run N ranks of this script under torch.distributed.run."""
     s = socket.socket()
@@ -304,6 +341,85 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def latency_mode(args, torch, dist, models, parallel, comm, rank, world, dev, share_gpu, affinity):
+    """--mode latency: ONE image's proposals and classes sharded over the ranks (mpn_frcnn_test_one_sharded; replaces
+    ModelParallelTable.lua:195-242 for a single image).  A step = host image -> H2D -> trunk (every rank) -> ROI head on this rank's
+    1/N of the proposals -> all-gather of decoded rows -> NMS of this rank's 1/N of the classes -> all-gather of kept tables ->
+    top-100, with a device synchronisation after every step (latency, not throughput: nothing of image i+1 overlaps image i)."""
+    if share_gpu:
+        raise SystemExit("bench.py --mode latency needs one GPU per rank (RCCL refuses two ranks on one device)")
+    if comm is None:
+        raise SystemExit("bench.py --mode latency: the C-ABI RCCL communicator did not come up")
+    P = models.synthetic_params(models.VGG16_CFG, pooled=7, fc_dim=4096, n_classes=N_CLASSES, seed=557)
+    net = models.FastRCNN(P, max_h=H, max_w=W, max_rois=N_ROIS)
+    im_np, boxes_np = synthetic_inputs()
+    im_host, boxes_host = torch.from_numpy(im_np).pin_memory(), torch.from_numpy(boxes_np).pin_memory()
+    im_dev, boxes_dev = torch.empty(im_host.shape, device=dev), torch.empty(boxes_host.shape, device=dev)
+
+    def upload():
+        im_dev.copy_(im_host, non_blocking=True)
+        boxes_dev.copy_(boxes_host, non_blocking=True)
+
+    def timed(fn, with_upload=True):
+        for _ in range(args.warmup):
+            upload(); fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            if with_upload:
+                upload()
+            fn()
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt / args.steps * 1e3
+
+    ms = timed(lambda: net.test_one_sharded(comm, im_dev, boxes_dev))
+    ms_res = timed(lambda: net.test_one_sharded(comm, im_dev, boxes_dev), with_upload=False)
+    out = {"metric": "per-image latency (1000 ROIs, 600x1000 img) VGG-16 Fast R-CNN, proposals + classes of ONE image sharded over the GPUs "
+                     "[latency mode; not the headline metric]",
+           "value": round(ms, 4), "unit": "ms/image", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+           "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "VGG-16 Fast R-CNN, ONE image 600x1000 x 1000 ROIs per step for the whole job, 21 classes, NMS 0.3, top-100; host image + "
+                                  "boxes uploaded inside the step; device synchronisation after every step",
+                      "parallelism": "every rank: trunk on the whole image; ROI head on 1/%d of the proposals; RCCL all-gather of decoded rows; NMS of 1/%d of "
+                                     "the classes; RCCL all-gather of kept tables (mpn_frcnn_test_one_sharded through the C ABI); cpu affinity: %s"
+                                     % (world, world, affinity)},
+           "proposals_per_s": round(N_ROIS / (ms * 1e-3), 1), "ms_inputs_resident": round(ms_res, 4)}
+    if world == 1:
+        out["unsharded_ms"] = round(timed(lambda: net.test_one_async(im_dev, boxes_dev)), 4)  # mpn_frcnn_test_one under the same protocol
+        G = max(2, args.emulate_world)
+        rr, cr = net.shard_record_floats(N_ROIS, G)
+        rows_all = torch.empty((G, rr), dtype=torch.float32, device=dev)
+        class_all = torch.empty((G, cr), dtype=torch.float32, device=dev)
+        for r in range(G):
+            net.shard_head(im_dev, boxes_dev, r, G, out=rows_all[r])
+        for r in range(G):
+            net.shard_nms(rows_all, N_ROIS, r, G, out=class_all[r])
+
+        def rank0_share():
+            net.shard_head(im_dev, boxes_dev, 0, G, out=rows_all[0])
+            net.shard_nms(rows_all, N_ROIS, 0, G, out=class_all[0])
+            net.shard_finish(class_all, N_ROIS, G)
+        out["projected"] = {"world": G, "rank0_compute_ms": round(timed(rank0_share), 4),
+                            "what": "ONE GPU running rank 0's share of a %d-rank world (trunk + %d of %d ROIs + %d of %d classes + top-100) with the "
+                                    "other ranks' records precomputed: the two all-gathers (%.0f KB + %.0f KB in total) are NOT included — a "
+                                    "projection, not a multi-GPU measurement" % (G, -(-N_ROIS // G), N_ROIS, -(-(N_CLASSES - 1) // G), N_CLASSES - 1,
+                                                                                   rr * G * 4 / 1024.0, cr * G * 4 / 1024.0)}
+    if rank == 0:
+        print(json.dumps(out))
+        sys.stdout.flush()
+    comm.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -315,6 +431,11 @@ def main():
                     help="c2 (default) = the headline line, BASELINE configs[1].  c1 / c3 / c4 / c5 = the other BASELINE configs, each with its "
                          "own metric string (never the headline): same timed loop, whole-path rates only")
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16"], help="c4 only (c5 is bf16, the rest fp32)")
+    ap.add_argument("--mode", default="throughput", choices=["throughput", "latency"],
+                    help="throughput (default) = the headline metric, images sharded over the ranks.  latency = ONE image's proposals and classes "
+                         "sharded over the ranks (mpn_frcnn_test_one_sharded); its own metric string, never the headline")
+    ap.add_argument("--emulate-world", type=int, default=8,
+                    help="latency mode on one GPU: also time rank 0's share of a world of this size (no all-gather), as a projection")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
@@ -332,30 +453,47 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d" % (args.gpus, world))
-    if local_rank >= torch.cuda.device_count():
+    share_gpu = os.environ.get("MPN_BENCH_SHARE_GPU") == "1" and world > 1  # TEST ONLY: every rank on device 0, gather through gloo
+    dev_index = 0 if share_gpu else local_rank
+    if dev_index >= torch.cuda.device_count():
         raise SystemExit("rank %d: only %d HIP devices are visible" % (local_rank, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    affinity = pin_to_gpu_numa_node(dev_index) if (world > 1 and not share_gpu) else "not set (single rank)" if world == 1 else "not set (shared GPU)"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # bootstrap + the timing reduction only
+        # CPU-side group: rendezvous, barriers, the MAX of the elapsed time.  No RCCL communicator is created here — the only one
+        # a rank holds is the C ABI's (mpn_comm), bootstrapped by broadcasting rank 0's 128-byte id through this group.
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     # the data-path collective: mpn_gather_dets (pack kernel + ncclAllGather through the C ABI).  Should the direct RCCL
-    # communicator fail to come up on some node, the 11-KB gather goes through torch.distributed's RCCL process group
-    # instead — the bench line says which one ran; all ranks agree on the choice.
-    comm, comm_err = None, ""
-    try:
-        comm = parallel.Comm.from_torch_distributed()
-    except Exception as e:  # noqa: BLE001
-        comm_err = str(e).splitlines()[-1][:200]
+    # communicator fail to come up on some node, the 11-KB gather goes through a torch.distributed RCCL group created for
+    # that purpose instead — the bench line says which one ran; all ranks agree on the choice.
+    comm, comm_err, nccl_group = None, "", None
+    if share_gpu:
+        comm_err = "MPN_BENCH_SHARE_GPU=1"
+    else:
+        try:
+            comm = parallel.Comm.from_torch_distributed()
+        except Exception as e:  # noqa: BLE001
+            comm_err = str(e).splitlines()[-1][:200]
     if world > 1:
-        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0 and comm is not None:
             comm.close()
             comm = None
+        if comm is None and not share_gpu:
+            nccl_group = dist.new_group(backend="nccl")
     elif comm is None:
         raise SystemExit("bench.py: " + comm_err)
-    gather_via = "mpn_gather_dets (RCCL through the C ABI)" if comm is not None else "torch.distributed all_gather_into_tensor (RCCL); C-ABI communicator failed: " + comm_err
+    if comm is not None:
+        gather_via = "mpn_gather_dets (RCCL through the C ABI; the rank's only RCCL communicator)"
+    elif share_gpu:
+        gather_via = "gloo all_gather of the packed record — TEST MODE MPN_BENCH_SHARE_GPU=1: all ranks share device 0, NOT a multi-GPU measurement"
+    else:
+        gather_via = "torch.distributed all_gather_into_tensor (RCCL); C-ABI communicator failed: " + comm_err
+    if args.mode == "latency":
+        return latency_mode(args, torch, dist, models, parallel, comm, rank, world, dev, share_gpu, affinity)
 
     other = None
     if args.config != "c2":
@@ -368,8 +506,14 @@ def main():
         net = models.FastRCNN(P, max_h=H, max_w=W, max_rois=N_ROIS)
         im_np, boxes_np = synthetic_inputs()
         n_rois_cfg = N_ROIS
-    im_host = [torch.from_numpy(im_np).clone().pin_memory() for _ in range(2)]      # two pinned sets, alternated (the same synthetic image)
-    boxes_host = [torch.from_numpy(boxes_np).clone().pin_memory() for _ in range(2)]
+    # four DIFFERENT pinned (image, proposals) sets in rotation, offset by rank: no step uploads the bytes the previous step did,
+    # and no two ranks upload the same image in the same step (variant 0 = the SURVEY inputs, which the roofline / CPU legs use)
+    n_rot = 4
+    rot = [(im_np, boxes_np)] + [synthetic_inputs(v) for v in range(1, n_rot)]
+    if other is not None:
+        rot = [(i, more_boxes(b, n_rois_cfg)) for i, b in rot]
+    im_host = [torch.from_numpy(i).clone().pin_memory() for i, _ in rot]
+    boxes_host = [torch.from_numpy(b).clone().pin_memory() for _, b in rot]
     im_dev, boxes_dev = torch.from_numpy(im_np).to(dev), torch.from_numpy(boxes_np).to(dev)
     top_cap = net._dets.size(0)
     gathered = [torch.empty((world, top_cap * 6 + 1), dtype=torch.float32, device=dev) for _ in range(2)]
@@ -385,14 +529,17 @@ def main():
             with torch.cuda.stream(gstream):
                 if comm is not None:
                     comm.gather_dets(bufs[0], bufs[1], out=gathered[state["seq"] & 1])
+                elif share_gpu:  # test mode: through the CPU group (gloo), record staged on the host
+                    rec = parallel.pack_record(bufs[0], bufs[1], top_cap).cpu()
+                    gathered[state["seq"] & 1].copy_(parallel.gather_detections(rec), non_blocking=True)
                 else:
-                    parallel.gather_detections(parallel.pack_record(bufs[0], bufs[1], top_cap), out=gathered[state["seq"] & 1])
+                    parallel.gather_detections(parallel.pack_record(bufs[0], bufs[1], top_cap), group=nccl_group, out=gathered[state["seq"] & 1])
 
     def make_step(host_fed):
         def step():
             # Tester:test loop form: image i's NMS/top-k tail runs on the pipeline's side stream and overlaps image
             # i+1's trunk; its detections are stream-ordered one call later, when they are gathered.
-            b = state["seq"] & 1
+            b = (state["seq"] + rank) % n_rot
             cur = net.test_one_pipelined_host(im_host[b], boxes_host[b]) if host_fed else net.test_one_pipelined(im_dev, boxes_dev)
             gather(state["pending"])
             state["pending"] = cur
@@ -427,7 +574,7 @@ def main():
         if gc_was:
             gc.enable()
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tt = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         return dt
@@ -444,7 +591,8 @@ def main():
                    "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                    "dtype": other["dtype"], "data": "synthetic",
                    "config": {"workload": other["workload"] + "; host image + boxes uploaded inside the step",
-                              "parallelism": "image-sharded over %d RCCL rank%s, all-gather of scored boxes only via %s" % (world, "" if world == 1 else "s", gather_via)},
+                              "parallelism": "image-sharded over %d rank%s, all-gather of scored boxes only via %s; cpu affinity: %s"
+                                             % (world, "" if world == 1 else "s", gather_via, affinity)},
                    "value_inputs_resident": round(value_res, 1),
                    "roofline": {"bound": "mfma", "kernel": "whole path (no per-kernel split for this configuration)", "achieved": round(tfl, 2),
                                 "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(tfl * 1e12 / peak, 4), "traffic": None,
@@ -504,8 +652,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "VGG-16 Fast R-CNN, 1 image 600x1000 x 1000 ROIs per GPU per step, 21 classes, NMS 0.3, top-100 (BASELINE configs[1]); "
                                    "host image + boxes uploaded inside the step (pinned, copy stream, double-buffered)",
-                       "parallelism": "image-sharded over %d RCCL rank%s (one process per GPU), all-gather of scored boxes only via %s"
-                                      % (world, "" if world == 1 else "s", gather_via)},
+                       "parallelism": "image-sharded over %d rank%s (one process per GPU), all-gather of scored boxes only via %s; cpu affinity: %s; "
+                                      "4 different pinned (image, proposals) sets in rotation, offset by rank"
+                                      % (world, "" if world == 1 else "s", gather_via, affinity)},
             "value_inputs_resident": round(value_res, 1), "ms_per_step_inputs_resident": round(dt_res / args.steps * 1e3, 4),
             "whole_path": {"algorithmic_gflop_per_image": round(total_flops / 1e9, 2), "executed_gflop_per_image": round(total_exec / 1e9, 2),
                            "executed_frac_of_fp32_mfma_peak": round(value / world * (total_exec / N_ROIS) / FP32_MFMA_PEAK, 4),

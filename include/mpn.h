@@ -20,7 +20,10 @@
  *     the device that was current at creation: drive ONE handle from one thread at a time (with that device current);
  *     different handles — same or different devices — may run concurrently from different host threads and streams.
  *     Module-level calls keep their grow-on-demand scratch per (device, stream) pair, so calls on different streams
- *     or devices never share it either.
+ *     or devices never share it either — but ONE thread at a time per (device, stream): two host threads issuing
+ *     module-level calls on the same stream (the NULL stream included) would grow and use one scratch concurrently.
+ *     A host that creates streams per image releases a stream's scratch with mpn_stream_release before it destroys
+ *     the stream (tens of MB of NMS masks per entry otherwise stay until mpn_release_all_scratch / process exit).
  *   - Integer results (argmax, keep indices, counts) are bit-exact vs the reference semantics; fp32
  *     box arithmetic is evaluated without FMA contraction, in the reference's operation order.
  */
@@ -34,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MPN_VERSION 201
+#define MPN_VERSION 300
 
 typedef enum mpn_status {
   MPN_OK = 0,
@@ -49,6 +52,11 @@ int mpn_version(void);
 const char *mpn_last_error(void);
 /* Fills name[] with the device's gcnArchName; returns MPN_EHIP when no HIP device is usable. */
 int mpn_device_info(char *name, int name_len, int *cu_count, size_t *hbm_bytes);
+/* Frees the module-level scratch kept for (current device, stream) after synchronising that stream; call it before
+ * hipStreamDestroy when streams come and go.  mpn_release_all_scratch does it for every (device, stream) entry (the host
+ * must have quiesced all module-level work).  Pipeline handles are unaffected: their scratch dies with the handle. */
+int mpn_stream_release(void *stream);
+int mpn_release_all_scratch(void);
 
 /* ------------------------------------------------------------------------------------------------
  * NMS family — replaces nms.c (the reference's only native code)
@@ -358,7 +366,11 @@ int mpn_frcnn_detect(mpn_frcnn *p, const float *d_image, int H, int W, const flo
 
 /* Tester:testOne + keep_top_k: detect, per-class NMS, global top-k.
  *   d_dets [top_cap,6] {x1,y1,x2,y2,score,class}, *d_n_dets; raw per-class NMS results stay readable
- *   through mpn_frcnn_nms_results until the next call. */
+ *   through mpn_frcnn_nms_results until the next call.
+ * CONTRACT of *d_n_dets (all test_one forms, as mpn_keep_top_k's *d_n_out): the UNTRUNCATED number of survivors of the
+ * top-k rule.  utils.keep_top_k keeps every row tied at the threshold, so it can exceed top_k and even top_cap; only
+ * min(*d_n_dets, top_cap) rows of d_dets were written.  A caller must clamp before it reads rows — copy
+ * min(n, top_cap) * 6 floats — and may treat n > top_cap as "rows were dropped, enlarge top_cap". */
 int mpn_frcnn_test_one(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N, float *d_dets,
                        int top_cap, int *d_n_dets, void *stream);
 /* Throughput form for a loop over images (Tester:test, Tester_FRCNN.lua:150-157): same work, but the
@@ -404,6 +416,38 @@ int mpn_pack_det_record(const float *d_dets, const int *d_n_dets, int top_cap, f
  * d_out [world, top_cap*6 + 1]; record r belongs to the image rank r processed in this step.  Stream-ordered on
  * `stream`, no host synchronisation; every rank must call it the same number of times. */
 int mpn_gather_dets(mpn_comm *c, const float *d_dets, const int *d_n_dets, int top_cap, float *d_out, void *stream);
+/* Generic fixed-size all-gather of float records: every rank contributes n_floats from d_send, d_out is [world, n_floats]
+ * (rank order).  Stream-ordered, no host synchronisation; without an RCCL communicator (world 1) a device copy.  The calling
+ * thread's current device must be the communicator's (MPN_ESTATE otherwise; mpn_gather_dets checks the same). */
+int mpn_gather_rows(mpn_comm *c, const float *d_send, size_t n_floats, float *d_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Proposal (ROI) sharding of ONE image across the GPUs of a node — the latency mode (north_star "images+proposals
+ * shard across the 8 GPUs").  Replaces ModelParallelTable.lua:195-242 (broadcast the input to every tower GPU, run, copy back,
+ * concatenate) for a single image: every rank holds the full model and is handed the SAME image and the SAME proposal table;
+ * it runs the trunk, the ROI head on its contiguous slice of the proposals (mpn_shard_range(N, world, rank)), the per-class NMS
+ * on its contiguous slice of the foreground classes (mpn_shard_range(C-1, world, rank)), and two all-gathers of scored boxes
+ * connect the three steps.  Rows and classes are independent, so d_dets / d_n_dets and mpn_frcnn_nms_results equal the
+ * unsharded mpn_frcnn_test_one's bit for bit on every rank; iterative localisation and box voting are supported (each rank
+ * refines its own rows).  The partition contract is test_runner.lua:91-104's (every worker the same code, a disjoint share).
+ *   mpn_frcnn_shard_head   trunk + head on this rank's proposals -> d_rows_rec [mpn_frcnn_shard_rows_floats]
+ *   (exchange)             d_rows_all [world, rows_floats] = all ranks' records in rank order (mpn_gather_rows or any transport)
+ *   mpn_frcnn_shard_nms    joined tables of the whole image (kept on the handle: what detect() returns), select, NMS (+ vote)
+ *                          of this rank's classes -> d_class_rec [mpn_frcnn_shard_class_floats]
+ *   (exchange)             d_class_all [world, class_floats]
+ *   mpn_frcnn_shard_finish every class's kept table on the handle (mpn_frcnn_nms_results) + keep_top_k -> d_dets, *d_n_dets
+ * mpn_frcnn_test_one_sharded chains the five steps over an mpn_comm on `stream` (no host synchronisation in steady state).
+ * The same image size / N / world must be passed to all steps; a rank that owns no proposals (world > N) writes a zero record. */
+int mpn_shard_range(int n, int world, int rank, int *lo, int *hi); /* balanced contiguous: the first n % world ranks own one more */
+size_t mpn_frcnn_shard_rows_floats(const mpn_frcnn *p, int N, int world);
+size_t mpn_frcnn_shard_class_floats(const mpn_frcnn *p, int N, int world);
+int mpn_frcnn_shard_head(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N, int rank, int world,
+                         float *d_rows_rec, void *stream);
+int mpn_frcnn_shard_nms(mpn_frcnn *p, const float *d_rows_all, int N, int rank, int world, float *d_class_rec, void *stream);
+int mpn_frcnn_shard_finish(mpn_frcnn *p, const float *d_class_all, int N, int world, float *d_dets, int top_cap, int *d_n_dets,
+                           void *stream);
+int mpn_frcnn_test_one_sharded(mpn_frcnn *p, mpn_comm *comm, const float *d_image, int H, int W, const float *d_boxes, int N,
+                               float *d_dets, int top_cap, int *d_n_dets, void *stream);
 
 /* Per-kernel-group timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  * Tags index the arrays returned by mpn_frcnn_get_profile (accumulated ms and launch-group counts). */

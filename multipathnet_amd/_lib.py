@@ -101,6 +101,9 @@ def load(flavour=None):
     lib.mpn_pick_scale.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double]
     lib.mpn_conv3x3_workspace_bytes.restype = C.c_size_t
     lib.mpn_det_record_floats.restype = C.c_size_t
+    lib.mpn_frcnn_shard_rows_floats.restype = C.c_size_t
+    lib.mpn_frcnn_shard_class_floats.restype = C.c_size_t
+    lib.mpn_gather_rows.argtypes = [C.c_void_p, f32p, C.c_size_t, f32p, C.c_void_p]
     lib.mpn_comm_destroy.restype = None
     lib.mpn_frcnn_destroy.restype = None
     _libs[fl] = lib

@@ -156,9 +156,35 @@ extern "C" int mpn_pack_det_record(const float *d_dets, const int *d_n_dets, int
   return MPN_OK;
 }
 
+// the communicator (and its send buffer) lives on the device that was current at creation: a worker thread that forgot
+// hipSetDevice would hand RCCL cross-device buffers
+static int check_device(const mpn_comm *c, const char *who) {
+  int dev = -1;
+  MPN_CHECK_HIP(hipGetDevice(&dev));
+  if (dev != c->device) { set_error("%s: the communicator belongs to device %d but device %d is current", who, c->device, dev); return MPN_ESTATE; }
+  return MPN_OK;
+}
+
+// Generic fixed-size all-gather of float records (the exchange steps of the ROI-sharded mode, pipeline.hip): every rank
+// contributes n_floats from d_send; d_out [world, n_floats].  Without an RCCL communicator (world 1) it is a device copy.
+extern "C" int mpn_gather_rows(mpn_comm *c, const float *d_send, size_t n_floats, float *d_out, void *stream) {
+  MPN_CHECK_ARG(c && d_send && d_out && n_floats > 0);
+  hipStream_t s = as_stream(stream);
+  int rc = check_device(c, "mpn_gather_rows");
+  if (rc) return rc;
+  if (!c->comm) {
+    if (d_send != d_out) MPN_CHECK_HIP(hipMemcpyAsync(d_out, d_send, n_floats * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return MPN_OK;
+  }
+  MPN_CHECK_NCCL(g_rccl.AllGather(d_send, d_out, n_floats, kNcclFloat, c->comm, s));
+  return MPN_OK;
+}
+
 extern "C" int mpn_gather_dets(mpn_comm *c, const float *d_dets, const int *d_n_dets, int top_cap, float *d_out, void *stream) {
   MPN_CHECK_ARG(c && d_dets && d_n_dets && d_out && top_cap > 0);
   hipStream_t s = as_stream(stream);
+  int rcd = check_device(c, "mpn_gather_dets");
+  if (rcd) return rcd;
   const size_t rec = mpn_det_record_floats(top_cap);
   if (!c->comm) return mpn_pack_det_record(d_dets, d_n_dets, top_cap, d_out, stream);  // single rank without RCCL
   if (rec > c->send_floats) {

@@ -62,6 +62,43 @@ int set_max_dyn_lds(const void *fn, int bytes) {
 }
 }  // namespace mpn
 
+extern "C" int mpn_stream_release(void *stream) {
+  hipStream_t s = mpn::as_stream(stream);
+  int dev = 0;
+  MPN_CHECK_HIP(hipGetDevice(&dev));
+  mpn::Scratch *sc = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(mpn::g_reg_mu);
+    auto it = mpn::g_registry.find({dev, s});
+    if (it == mpn::g_registry.end()) return MPN_OK;
+    sc = it->second;
+    mpn::g_registry.erase(it);
+  }
+  MPN_CHECK_HIP(hipStreamSynchronize(s));
+  sc->release();
+  delete sc;
+  return MPN_OK;
+}
+
+extern "C" int mpn_release_all_scratch(void) {
+  std::map<std::pair<int, hipStream_t>, mpn::Scratch *> taken;
+  {
+    std::lock_guard<std::mutex> lk(mpn::g_reg_mu);
+    taken.swap(mpn::g_registry);
+  }
+  int cur = 0;
+  MPN_CHECK_HIP(hipGetDevice(&cur));
+  int rc = MPN_OK;
+  for (auto &kv : taken) {
+    if (hipSetDevice(kv.first.first) != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = MPN_EHIP;
+    kv.second->release();
+    delete kv.second;
+  }
+  (void)hipSetDevice(cur);
+  if (rc) mpn::set_error("mpn_release_all_scratch: a device could not be synchronised");
+  return rc;
+}
+
 extern "C" int mpn_version(void) { return MPN_VERSION; }
 extern "C" const char *mpn_last_error(void) { return mpn::g_err; }
 

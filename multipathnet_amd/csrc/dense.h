@@ -77,8 +77,14 @@ int maxpool2x2_c8p(Act in, Act out, hipStream_t s);
 // row-major [M,N] (y_rm); either may be null.
 // Mp_override: row pitch of x / y when it is not lin_mp(M) (a ROI-pooled matrix viewed as (bin, roi) rows).
 // d_res_c8 (optional, y_c8's layout): added before the ReLU; only with the direct form (>= 128 output tiles, C8 output only).
+// row_invariant: the K summation of every output row follows ONE canonical order that depends on (K, N) only — K cut into fixed
+// segments, each accumulated from zero, the segment sums added in segment order — whether the launch runs split-K (few row tiles:
+// one block per segment + the reduce kernel) or un-split (many row tiles: one block walks the segments and folds its accumulator
+// into a running total at each boundary).  A row's result is then bit-identical for ANY number of rows in the call, which is what
+// lets the ROI-sharded mode (mpn_frcnn_shard_*) equal the unsharded one exactly and makes memoryEfficientForward's chunk
+// invariance (ImageDetect.lua:126-133) hold at every size.  Used by the ROI heads (fc6 / fc7 / cls + bbox / integral heads).
 int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float *d_bpk, int N, int relu, float *d_y_c8,
-              float *d_y_rm, hipStream_t s, int Mp_override = 0, const float *d_res_c8 = nullptr);
+              float *d_y_rm, hipStream_t s, int Mp_override = 0, const float *d_res_c8 = nullptr, int row_invariant = 0);
 bool linear_c8_is_direct(int M, int N, int Mp_override = 0);  // would linear_c8 run un-split for this shape?
 // ROI max-pool reading a C8P feature map and writing the C8 matrix the fc6 GEMM consumes:
 // chunk q = cb*PH*PW + bin, row = roi.  argmax (optional) [N,C,PH,PW] int32 as the NCHW kernel.

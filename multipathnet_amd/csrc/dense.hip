@@ -1073,6 +1073,7 @@ struct GemmArgs {
   const float *bpk;
   float *y;                     // [NP/8][Mp][8]   (split: partial slabs [S][NP/8][Mp][8])
   int M, nstages, stages_per_split, relu, n_mt, n_nt, direct;
+  int seg_stages;  // un-split launch of a row-invariant GEMM: fold the accumulator into the running total every seg_stages stages (0 = never)
   int n_fast;  // tile order: 0 = all row tiles of one column tile first (the weights are the big operand: fc6), 1 = all column tiles of one
                // row tile first (the activations are: ResNet's pointwise convolutions over 10^5 pixel rows) — the big operand is streamed once
   const float *res;  // optional residual in y's layout, added before the ReLU (direct mode only; ResNet 1x1 convolutions)
@@ -1171,10 +1172,35 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
   };
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
+  // Row-invariant summation (linear_c8's row_invariant): at every canonical segment boundary the accumulator is folded into a
+  // running total and restarted from zero — total = (((0 + s_0) + s_1) + ...), the order in which splitk_reduce_kernel adds the
+  // slabs when the same GEMM runs one block per segment.  64 VALU adds per wave per boundary against >= 256 MFMAs per segment.
+  f32x16 tot[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tot[mi][ni][r] = 0.0f;
+  auto fold = [&]() {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { tot[mi][ni][r] += acc[mi][ni][r]; acc[mi][ni][r] = 0.0f; }
+  };
+  int next_fold = a.seg_stages > 0 ? st0 + a.seg_stages : 0x7fffffff;
   int st = st0;
-  if (n_more & 1) { body(st, std::true_type{}, P1{}); ++st; }
-  for (; st < st1 - 1; st += 2) { body(st, std::true_type{}, P0{}); body(st + 1, std::true_type{}, P1{}); }
+  if (n_more & 1) { body(st, std::true_type{}, P1{}); ++st; if (st == next_fold) { fold(); next_fold += a.seg_stages; } }
+  for (; st < st1 - 1; st += 2) {
+    body(st, std::true_type{}, P0{});
+    if (st + 1 == next_fold) { fold(); next_fold += a.seg_stages; }
+    body(st + 1, std::true_type{}, P1{});
+    if (st + 2 == next_fold) { fold(); next_fold += a.seg_stages; }
+  }
   body(st1 - 1, std::false_type{}, P0{});
+  fold();  // tot = 0 + acc when nothing was folded before: exact
 
   // Epilogue: every bias / residual load is issued before the first store (the empty asm is a compiler barrier for memory
   // operations).  Stores count in vmcnt on this ISA, so a load that follows a store in program order waits for the store's
@@ -1209,7 +1235,7 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float t = acc[mi][ni][g * 4 + e] + b4[mi][g][e] + r4[mi][g][ni][e];
+          float t = tot[mi][ni][g * 4 + e] + b4[mi][g][e] + r4[mi][g][ni][e];
           if (a.direct && a.relu) t = t < 0.0f ? 0.0f : t;
           v[e] = t;
         }
@@ -1261,7 +1287,7 @@ bool linear_c8_is_direct(int M, int N, int Mp_override) {
 }
 
 int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float *d_bpk, int N, int relu, float *d_y_c8,
-              float *d_y_rm, hipStream_t s, int Mp_override, const float *d_res_c8) {
+              float *d_y_rm, hipStream_t s, int Mp_override, const float *d_res_c8, int row_invariant) {
   MPN_CHECK_ARG(d_x_c8 && d_wpk && d_bpk && (d_y_c8 || d_y_rm) && M > 0 && K > 0 && N > 0);
   MPN_CHECK_ARG(Mp_override == 0 || (Mp_override >= M && Mp_override % 128 == 0));
   GemmArgs a{};
@@ -1274,14 +1300,25 @@ int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float
   // long-K, enough tiles to fill the chip: 64-k stages; otherwise 32-k stages (finer split-K granularity)
   const int kch = g_gemm_kch ? g_gemm_kch : 4;  // 64-k stages measured no faster than 32-k (tools/bench_layers.py)
   a.nstages = K64 / (8 * kch);
-  int S = 1;
+  int S = 1, inv_seg = 0;
+  a.seg_stages = 0;
   if (g_gemm_split > 0) S = g_gemm_split;
-  else if (tiles < 128) {  // too few tiles to fill 256 CUs: split K (deterministic two-pass reduce)
+  else if (row_invariant) {
+    // canonical segments from (K, N) alone: as many as fill 256 CUs when there is a single row tile, >= 4 stages (128 k) each
+    int Sc = 256 / a.n_nt;
+    if (Sc > 32) Sc = 32;
+    if (Sc < 1) Sc = 1;
+    int seg = cdiv(a.nstages, Sc);
+    if (seg < 4) seg = 4;
+    if (tiles < 128) S = cdiv(a.nstages, seg);          // one block per segment + the reduce kernel
+    else if (seg < a.nstages) a.seg_stages = seg;       // one block walks the segments, folding at the boundaries
+    inv_seg = seg;
+  } else if (tiles < 128) {  // too few tiles to fill 256 CUs: split K (deterministic two-pass reduce)
     S = 256 / tiles;
     if (S > a.nstages / 2) S = a.nstages / 2;
     if (S < 1) S = 1;
   }
-  a.stages_per_split = cdiv(a.nstages, S);
+  a.stages_per_split = (inv_seg && S > 1) ? inv_seg : cdiv(a.nstages, S);  // row-invariant: the segments ARE the canonical ones
   S = cdiv(a.nstages, a.stages_per_split);
   const bool direct = (S == 1) && d_y_c8 && !d_y_rm;
   a.direct = direct ? 1 : 0;

@@ -791,7 +791,9 @@ __global__ __launch_bounds__(64) void bbox_vote_kernel(const float *__restrict__
 }
 
 // bbox_vote for every class of an image at once (Tester_FRCNN.lua:118-124): class c votes its kept boxes against its
-// own scored boxes; the voting weights are score^pow (opt.test_bbox_voting_score_pow), pow == 1 skips powf so the
+// own scored boxes; the voting weights are score^pow (opt.test_bbox_voting_score_pow: scores:pow(p) on a clone of the
+// scored boxes, Tester_FRCNN.lua:119-121), applied ONCE per scored box while its tile is staged into LDS and evaluated as
+// THFloatTensor_pow does — C pow on the score promoted to double, rounded to float once; pow == 1 skips it, so the
 // arithmetic stays bit-identical to nms.c.  Same one-lane-per-kept-box sequential accumulation as bbox_vote_kernel.
 __global__ __launch_bounds__(64) void bbox_vote_batched_kernel(const float *__restrict__ keep, const int *__restrict__ n_keep,
                                                                const float *__restrict__ scored, const int *__restrict__ counts,
@@ -812,13 +814,16 @@ __global__ __launch_bounds__(64) void bbox_vote_batched_kernel(const float *__re
   for (int j0 = 0; j0 < m; j0 += TILE) {
     const int cnt = min(TILE, m - j0);
     __syncthreads();
-    for (int q = threadIdx.x; q < cnt * 5; q += kWave) t[q] = sb[(size_t)j0 * 5 + q];
+    for (int q = threadIdx.x; q < cnt * 5; q += kWave) {
+      float v = sb[(size_t)j0 * 5 + q];
+      if (score_pow != 1.0f && q % 5 == 4) v = (float)pow((double)v, (double)score_pow);
+      t[q] = v;
+    }
     __syncthreads();
     if (act) {
       for (int j = 0; j < cnt; ++j) {
         const float sx1 = t[5 * j], sy1 = t[5 * j + 1], sx2 = t[5 * j + 2], sy2 = t[5 * j + 3];
-        float ss = t[5 * j + 4];
-        if (score_pow != 1.0f) ss = powf(ss, score_pow);
+        const float ss = t[5 * j + 4];
         const float ov = iou_plus1(sx1, sy1, sx2, sy2, nx1, ny1, nx2, ny2);
         if (ov > thr) { a0 += sx1 * ss; a1 += sy1 * ss; a2 += sx2 * ss; a3 += sy2 * ss; a4 += ss; }
       }

@@ -113,6 +113,98 @@ __global__ void copy_cols_kernel(const float *__restrict__ src, int ld, int col0
   int m = (int)(t / ncols), c = (int)(t - (size_t)m * ncols);
   dst[t] = src[(size_t)m * ld + col0 + c];
 }
+// ---- proposal (ROI) sharding of one image (mpn_frcnn_shard_*): record pack / unpack ------------------------------------------
+// Balanced contiguous partition of n items over `world` ranks: the first n % world ranks own one item more.
+__host__ __device__ inline void shard_bounds(int n, int world, int rank, int *lo, int *hi) {
+  const int base = n / world, rem = n % world;
+  *lo = rank * base + (rank < rem ? rank : rem);
+  *hi = *lo + base + (rank < rem ? 1 : 0);
+}
+__device__ inline void shard_owner(int item, int n, int world, int *rank, int *local) {
+  const int base = n / world, rem = n % world, cut = rem * (base + 1);
+  if (item < cut) { *rank = item / (base + 1); *local = item - *rank * (base + 1); }
+  else { const int q = (item - cut) / base; *rank = rem + q; *local = item - cut - q * base; }
+}
+
+// this rank's joined score / box tables (P passes x n_local rows, pass-major) -> its row record
+// [scores: P x chunk x C][boxes: P x chunk x 4C], rows at / beyond n_local zeroed
+__global__ void shard_pack_rows_kernel(const float *__restrict__ sc, const float *__restrict__ bb, int n_local, int P, int C, int chunk,
+                                       float *__restrict__ rec) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t ns = (size_t)P * chunk * C, nb = ns * 4;
+  if (t >= ns + nb) return;
+  const bool is_box = t >= ns;
+  const size_t u = is_box ? t - ns : t;
+  const int w = is_box ? 4 * C : C;
+  const int col = (int)(u % w);
+  const size_t r = u / w;
+  const int i = (int)(r % chunk), k = (int)(r / chunk);
+  float v = 0.0f;
+  if (i < n_local) v = (is_box ? bb : sc)[((size_t)k * n_local + i) * w + col];
+  rec[t] = v;
+}
+
+// all ranks' row records [world][rec_floats] -> the image's joined tables sc [P*N, C], bb [P*N, 4C] in the unsharded row order
+__global__ void shard_unpack_rows_kernel(const float *__restrict__ all, int N, int world, int P, int C, int chunk, size_t rec_floats,
+                                         float *__restrict__ sc, float *__restrict__ bb) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t ns = (size_t)P * N * C, nb = ns * 4;
+  if (t >= ns + nb) return;
+  const bool is_box = t >= ns;
+  const size_t u = is_box ? t - ns : t;
+  const int w = is_box ? 4 * C : C;
+  const int col = (int)(u % w);
+  const size_t r = u / w;
+  const int row = (int)(r % N), k = (int)(r / N);
+  int owner, i;
+  shard_owner(row, N, world, &owner, &i);
+  const size_t plane = is_box ? (size_t)P * chunk * C : 0;
+  (is_box ? bb : sc)[u] = all[(size_t)owner * rec_floats + plane + ((size_t)k * chunk + i) * w + col];
+}
+
+// class record of one rank: [n_keep: cmax ints][keep: cmax x rows x 5][keep_idx: cmax x rows ints][voted: cmax x rows x 5 (if voting)]
+__host__ __device__ inline size_t shard_class_rec_floats(int cmax, int rows, int voting) {
+  return (size_t)cmax * (1 + (size_t)rows * (voting ? 11 : 6));
+}
+// grid (ceil(rows / 256), cmax): slot j = class c0 + j of this rank's range [c0, c1)
+__global__ void shard_pack_classes_kernel(const float *__restrict__ keep, const int *__restrict__ kidx, const int *__restrict__ n_keep,
+                                          const float *__restrict__ voted, int c0, int c1, int rows, int cmax, float *__restrict__ rec) {
+  const int j = blockIdx.y, c = c0 + j, i = blockIdx.x * blockDim.x + threadIdx.x;
+  int *rn = reinterpret_cast<int *>(rec);
+  const int n = c < c1 ? min(max(n_keep[c], 0), rows) : 0;
+  if (i == 0) rn[j] = n;
+  if (i >= n) return;
+  float *rk = rec + cmax + ((size_t)j * rows + i) * 5;
+  const float *k = keep + ((size_t)c * rows + i) * 5;
+  rk[0] = k[0]; rk[1] = k[1]; rk[2] = k[2]; rk[3] = k[3]; rk[4] = k[4];
+  reinterpret_cast<int *>(rec + cmax + (size_t)cmax * rows * 5)[(size_t)j * rows + i] = kidx[(size_t)c * rows + i];
+  if (voted) {
+    float *rv = rec + cmax + (size_t)cmax * rows * 6 + ((size_t)j * rows + i) * 5;
+    const float *v = voted + ((size_t)c * rows + i) * 5;
+    rv[0] = v[0]; rv[1] = v[1]; rv[2] = v[2]; rv[3] = v[3]; rv[4] = v[4];
+  }
+}
+// all ranks' class records -> the image's per-class tables; grid (ceil(rows / 256), n_cls)
+__global__ void shard_unpack_classes_kernel(const float *__restrict__ all, int n_cls, int world, int rows, int cmax, size_t rec_floats,
+                                            float *__restrict__ keep, int *__restrict__ kidx, int *__restrict__ n_keep,
+                                            float *__restrict__ voted) {
+  const int c = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  int owner, j;
+  shard_owner(c, n_cls, world, &owner, &j);
+  const float *rec = all + (size_t)owner * rec_floats;
+  const int n = min(max(reinterpret_cast<const int *>(rec)[j], 0), rows);
+  if (i == 0) n_keep[c] = n;
+  if (i >= n) return;
+  const float *rk = rec + cmax + ((size_t)j * rows + i) * 5;
+  float *k = keep + ((size_t)c * rows + i) * 5;
+  k[0] = rk[0]; k[1] = rk[1]; k[2] = rk[2]; k[3] = rk[3]; k[4] = rk[4];
+  kidx[(size_t)c * rows + i] = reinterpret_cast<const int *>(rec + cmax + (size_t)cmax * rows * 5)[(size_t)j * rows + i];
+  if (voted) {
+    const float *rv = rec + cmax + (size_t)cmax * rows * 6 + ((size_t)j * rows + i) * 5;
+    float *v = voted + ((size_t)c * rows + i) * 5;
+    v[0] = rv[0]; v[1] = rv[1]; v[2] = rv[2]; v[3] = rv[3]; v[4] = rv[4];
+  }
+}
 }  // namespace mpn
 
 using namespace mpn;
@@ -182,6 +274,9 @@ struct mpn_frcnn {
   hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
   bool used_pending[2] = {false, false};
   unsigned long long up_seq = 0;
+  // proposal sharding (mpn_frcnn_test_one_sharded): this rank's row / class records and the gathered ones, grown on demand
+  float *sh_buf[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t sh_bytes[4] = {0, 0, 0, 0};
   // optional per-kernel-group timing with HIP events recorded on the launch stream
   bool prof = false;
   std::vector<hipEvent_t> ev_pool;
@@ -246,6 +341,7 @@ extern "C" void mpn_frcnn_destroy(mpn_frcnn *p) {
   if (p->scaled) (void)hipFree(p->scaled);
   if (p->scale_tmp) (void)hipFree(p->scale_tmp);
   if (p->dbg) (void)hipFree(p->dbg);
+  for (int i = 0; i < 4; ++i) if (p->sh_buf[i]) (void)hipFree(p->sh_buf[i]);
   delete p;
 }
 
@@ -543,10 +639,10 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
     { ProfScope ps(p, MPN_PROF_HEADS, s);
       rc = linear_c8(p->tx, PP * Mp, T.total_feat, T.mix_w, T.mix_b, p->feat_c, 0, p->ty, nullptr, s, PP * Mp); }
     if (rc) return rc;
-    { ProfScope ps(p, MPN_PROF_FC6, s); rc = linear_c8(p->ty, N, p->K6, T.w6, T.b6, F, 1, p->tz6, nullptr, s, Mp); }
+    { ProfScope ps(p, MPN_PROF_FC6, s); rc = linear_c8(p->ty, N, p->K6, T.w6, T.b6, F, 1, p->tz6, nullptr, s, Mp, nullptr, 1); }
     if (rc) return rc;
     { ProfScope ps(p, MPN_PROF_FC7, s);
-      rc = linear_c8(p->tz6, N, F, T.w7, T.b7, F, 1, p->cat + (size_t)ti * Fcb * Mp * 8, nullptr, s, Mp); }
+      rc = linear_c8(p->tz6, N, F, T.w7, T.b7, F, 1, p->cat + (size_t)ti * Fcb * Mp * 8, nullptr, s, Mp, nullptr, 1); }
     if (rc) return rc;
     ++ti;
   }
@@ -561,8 +657,8 @@ static int run_integral_heads(mpn_frcnn *p, const float *d_boxes, int N, int H, 
   const int Fcb = lin_np(F) / 8;
   int rc;
   { ProfScope ps(p, MPN_PROF_HEADS, s);
-    rc = linear_c8(p->cat, N, n_fov * F, p->wcls, p->bcls, K * C, 0, nullptr, p->cls_rm, s, Mp);
-    if (rc == MPN_OK) rc = linear_c8(p->cat + (size_t)n_fov * Fcb * Mp * 8, N, F, p->wbbox, p->bbbox, 4 * C, 0, nullptr, p->bbox_rm, s, Mp); }
+    rc = linear_c8(p->cat, N, n_fov * F, p->wcls, p->bcls, K * C, 0, nullptr, p->cls_rm, s, Mp, nullptr, 1);
+    if (rc == MPN_OK) rc = linear_c8(p->cat + (size_t)n_fov * Fcb * Mp * 8, N, F, p->wbbox, p->bbbox, 4 * C, 0, nullptr, p->bbox_rm, s, Mp, nullptr, 1); }
   if (rc) return rc;
   ProfScope ps_post(p, MPN_PROF_POST, s);
   hipLaunchKernelGGL(integral_softmax_mean_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, p->cls_rm, N, K, C, p->scores);
@@ -657,12 +753,12 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const 
       rc = roi_pool_c8(feat, p->rois, N, c.pooled_h, c.pooled_w, c.spatial_scale, 1.0f, 0, p->x6, nullptr, s);
     } }
   if (rc) return rc;
-  { ProfScope ps(p, MPN_PROF_FC6, s); rc = linear_c8(p->x6, N, p->K6, p->w6, p->b6, F, 1, p->y6, nullptr, s); }
+  { ProfScope ps(p, MPN_PROF_FC6, s); rc = linear_c8(p->x6, N, p->K6, p->w6, p->b6, F, 1, p->y6, nullptr, s, 0, nullptr, 1); }
   if (rc) return rc;
-  { ProfScope ps(p, MPN_PROF_FC7, s); rc = linear_c8(p->y6, N, F, p->w7, p->b7, F, 1, p->y7, nullptr, s); }
+  { ProfScope ps(p, MPN_PROF_FC7, s); rc = linear_c8(p->y6, N, F, p->w7, p->b7, F, 1, p->y7, nullptr, s, 0, nullptr, 1); }
   if (rc) return rc;
   }
-  { ProfScope ps(p, MPN_PROF_HEADS, s); rc = linear_c8(p->y7, N, F, p->wh, p->bh, 5 * C, 0, nullptr, p->head, s); }
+  { ProfScope ps(p, MPN_PROF_HEADS, s); rc = linear_c8(p->y7, N, F, p->wh, p->bh, 5 * C, 0, nullptr, p->head, s, 0, nullptr, 1); }
   if (rc) return rc;
   ProfScope ps_post(p, MPN_PROF_POST, s);
   hipLaunchKernelGGL(head_softmax_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, p->head, 5 * C, N, C, p->scores);
@@ -779,6 +875,149 @@ extern "C" int mpn_frcnn_test_one(mpn_frcnn *p, const float *d_image, int H, int
   select_set(p, 0);
   p->last_rows = rows;
   return run_tail(p, rows, d_dets, top_cap, d_n_dets, s, s, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Proposal (ROI) sharding of ONE image across the GPUs of a node — the latency mode of SURVEY §8e / north_star's
+// "images+proposals shard across the 8 GPUs".  Replaces ModelParallelTable.lua:195-242 (broadcast the whole input to every tower
+// GPU, run the towers, copy their outputs back and concatenate): here every rank runs the trunk on the image (1.6 ms of replicated
+// work instead of a 5-62 MB feature broadcast over xGMI), the ROI head on ITS rows of the proposal table, the per-class NMS on
+// ITS classes; what travels is scored boxes only — one all-gather of the decoded rows ([N/G, 5C] per rank: 420 KB in total for
+// VOC, 1.6 MB for COCO) and one of the kept tables.  Rows are independent (ImageDetect.lua:126-133's chunk invariance) and
+// classes are independent (Tester_FRCNN.lua:106-125's loop), so the result is the unsharded mpn_frcnn_test_one's bit for bit.
+// The three steps take caller-provided records so that the exchange between them can be any transport; mpn_frcnn_test_one_sharded
+// chains them over an mpn_comm (RCCL all-gather, comm.hip).
+static int shard_passes(const mpn_frcnn_config &c) { return c.num_iter > 1 ? (c.use_rbox_scores ? c.num_iter - 1 : c.num_iter) : 1; }
+
+extern "C" int mpn_shard_range(int n, int world, int rank, int *lo, int *hi) {
+  MPN_CHECK_ARG(n >= 0 && world >= 1 && rank >= 0 && rank < world && lo && hi);
+  shard_bounds(n, world, rank, lo, hi);
+  return MPN_OK;
+}
+
+extern "C" size_t mpn_frcnn_shard_rows_floats(const mpn_frcnn *p, int N, int world) {
+  if (!p || N <= 0 || world < 1) return 0;
+  const int chunk = (N + world - 1) / world;
+  return (size_t)shard_passes(p->cfg) * chunk * 5 * p->cfg.n_classes;
+}
+
+extern "C" size_t mpn_frcnn_shard_class_floats(const mpn_frcnn *p, int N, int world) {
+  if (!p || N <= 0 || world < 1) return 0;
+  const int n_cls = p->cfg.n_classes - 1, cmax = (n_cls + world - 1) / world;
+  return shard_class_rec_floats(cmax, shard_passes(p->cfg) * N, p->cfg.bbox_voting);
+}
+
+extern "C" int mpn_frcnn_shard_head(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N, int rank, int world,
+                                    float *d_rows_rec, void *stream) {
+  MPN_CHECK_ARG(p != nullptr && d_boxes && d_rows_rec && N > 0 && N <= p->cfg.max_rois && world >= 1 && rank >= 0 && rank < world);
+  ScratchScope scratch_scope(&p->scratch);
+  hipStream_t s = as_stream(stream);
+  int rc = mpn_frcnn_flush(p, stream);
+  if (rc) return rc;
+  const mpn_frcnn_config &c = p->cfg;
+  const int C = c.n_classes, P = shard_passes(c), chunk = (N + world - 1) / world;
+  int lo, hi;
+  shard_bounds(N, world, rank, &lo, &hi);
+  const int n_local = hi - lo;
+  const size_t total = (size_t)P * chunk * 5 * C;
+  if (n_local == 0) {  // more ranks than proposals: nothing to score here
+    MPN_CHECK_HIP(hipMemsetAsync(d_rows_rec, 0, total * sizeof(float), s));
+    return MPN_OK;
+  }
+  int rows = n_local;
+  rc = run_detect_iter(p, d_image, H, W, d_boxes + 4 * (size_t)lo, n_local, s, &rows);
+  if (rc) return rc;
+  const float *sc = c.num_iter > 1 ? p->it_scores : p->scores, *bb = c.num_iter > 1 ? p->it_bbox : p->bbox;
+  hipLaunchKernelGGL(shard_pack_rows_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, sc, bb, n_local, P, C, chunk, d_rows_rec);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+extern "C" int mpn_frcnn_shard_nms(mpn_frcnn *p, const float *d_rows_all, int N, int rank, int world, float *d_class_rec, void *stream) {
+  MPN_CHECK_ARG(p != nullptr && d_rows_all && d_class_rec && N > 0 && N <= p->cfg.max_rois && world >= 1 && rank >= 0 && rank < world);
+  ScratchScope scratch_scope(&p->scratch);
+  hipStream_t s = as_stream(stream);
+  int rc = mpn_frcnn_flush(p, stream);
+  if (rc) return rc;
+  const mpn_frcnn_config &c = p->cfg;
+  const int C = c.n_classes, P = shard_passes(c), chunk = (N + world - 1) / world, rows = P * N;
+  // the whole image's joined tables, in the unsharded row order, where run_tail reads them
+  float *sc = c.num_iter > 1 ? p->it_scores : p->scores, *bb = c.num_iter > 1 ? p->it_bbox : p->bbox;
+  const size_t rec_floats = (size_t)P * chunk * 5 * C, total = (size_t)rows * 5 * C;
+  hipLaunchKernelGGL(shard_unpack_rows_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, d_rows_all, N, world, P, C, chunk, rec_floats, sc, bb);
+  MPN_CHECK_LAUNCH();
+  select_set(p, 0);
+  p->last_rows = rows;
+  p->last_n = N;
+  { ProfScope ps(p, MPN_PROF_SELECT, s);
+    rc = mpn_select_scored(sc, bb, rows, C, 1, c.score_thresh, p->scored, p->counts, nullptr, s); }
+  if (rc) return rc;
+  const int n_cls = C - 1, cmax = (n_cls + world - 1) / world;
+  int c0, c1;
+  shard_bounds(n_cls, world, rank, &c0, &c1);
+  if (c1 > c0) {
+    const size_t off = (size_t)c0 * rows;
+    { ProfScope ps(p, MPN_PROF_NMS, s);
+      rc = mpn_nms_batched(p->scored + off * 5, p->counts + c0, c1 - c0, rows, c.nms_thresh, p->keep + off * 5, p->keep_idx + off, p->n_keep + c0, s); }
+    if (rc) return rc;
+    if (c.bbox_voting) {
+      rc = mpn_bbox_vote_batched(p->keep + off * 5, p->n_keep + c0, p->scored + off * 5, p->counts + c0, c1 - c0, rows, c.bbox_vote_thresh,
+                                 c.bbox_vote_score_pow != 0.0f ? c.bbox_vote_score_pow : 1.0f, p->voted + off * 5, s);
+      if (rc) return rc;
+    }
+  }
+  hipLaunchKernelGGL(shard_pack_classes_kernel, dim3(cdiv(rows, 256), cmax), dim3(256), 0, s, p->keep, p->keep_idx, p->n_keep,
+                     c.bbox_voting ? p->voted : nullptr, c0, c1, rows, cmax, d_class_rec);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+extern "C" int mpn_frcnn_shard_finish(mpn_frcnn *p, const float *d_class_all, int N, int world, float *d_dets, int top_cap, int *d_n_dets,
+                                      void *stream) {
+  MPN_CHECK_ARG(p != nullptr && d_class_all && N > 0 && N <= p->cfg.max_rois && world >= 1);
+  MPN_CHECK_ARG(d_n_dets && (top_cap == 0 || d_dets) && top_cap >= 0);
+  ScratchScope scratch_scope(&p->scratch);
+  hipStream_t s = as_stream(stream);
+  const mpn_frcnn_config &c = p->cfg;
+  const int n_cls = c.n_classes - 1, cmax = (n_cls + world - 1) / world, rows = shard_passes(c) * N;
+  select_set(p, 0);
+  p->last_rows = rows;
+  hipLaunchKernelGGL(shard_unpack_classes_kernel, dim3(cdiv(rows, 256), n_cls), dim3(256), 0, s, d_class_all, n_cls, world, rows, cmax,
+                     shard_class_rec_floats(cmax, rows, c.bbox_voting), p->keep, p->keep_idx, p->n_keep, c.bbox_voting ? p->voted : nullptr);
+  MPN_CHECK_LAUNCH();
+  ProfScope ps(p, MPN_PROF_TOPK, s);
+  return mpn_keep_top_k(c.bbox_voting ? p->voted : p->keep, p->n_keep, n_cls, rows, c.top_k, p->thresh, d_dets, top_cap, d_n_dets, s);
+}
+
+static int shard_buf(mpn_frcnn *p, int i, size_t floats, hipStream_t s) {
+  const size_t need = floats * sizeof(float);
+  if (need <= p->sh_bytes[i]) return MPN_OK;
+  MPN_CHECK_HIP(hipStreamSynchronize(s));
+  if (p->sh_buf[i]) (void)hipFree(p->sh_buf[i]);
+  p->sh_buf[i] = nullptr; p->sh_bytes[i] = 0;
+  MPN_CHECK_HIP(hipMalloc(&p->sh_buf[i], need));
+  p->sh_bytes[i] = need;
+  return MPN_OK;
+}
+
+extern "C" int mpn_frcnn_test_one_sharded(mpn_frcnn *p, mpn_comm *comm, const float *d_image, int H, int W, const float *d_boxes, int N,
+                                          float *d_dets, int top_cap, int *d_n_dets, void *stream) {
+  MPN_CHECK_ARG(p != nullptr && comm != nullptr && N > 0);
+  hipStream_t s = as_stream(stream);
+  const int world = mpn_comm_world(comm), rank = mpn_comm_rank(comm);
+  MPN_CHECK_ARG(world >= 1 && rank >= 0);
+  const size_t rr = mpn_frcnn_shard_rows_floats(p, N, world), cr = mpn_frcnn_shard_class_floats(p, N, world);
+  int rc;
+  if ((rc = shard_buf(p, 0, rr, s)) || (rc = shard_buf(p, 1, rr * world, s)) || (rc = shard_buf(p, 2, cr, s)) || (rc = shard_buf(p, 3, cr * world, s))) return rc;
+  rc = mpn_frcnn_shard_head(p, d_image, H, W, d_boxes, N, rank, world, p->sh_buf[0], stream);
+  if (rc) return rc;
+  rc = mpn_gather_rows(comm, p->sh_buf[0], rr, p->sh_buf[1], stream);
+  if (rc) return rc;
+  rc = mpn_frcnn_shard_nms(p, p->sh_buf[1], N, rank, world, p->sh_buf[2], stream);
+  if (rc) return rc;
+  rc = mpn_gather_rows(comm, p->sh_buf[2], cr, p->sh_buf[3], stream);
+  if (rc) return rc;
+  return mpn_frcnn_shard_finish(p, p->sh_buf[3], N, world, d_dets, top_cap, d_n_dets, stream);
 }
 
 // Throughput form for a loop over images (Tester:test, Tester_FRCNN.lua:150-157): trunk + heads + select of

@@ -92,7 +92,8 @@ class Tester_FRCNN(object):
             kb = keep[j, : nk[j]]
             if self.test_bbox_voting:
                 sb = scored[j, : cnt[j]].clone()
-                sb[:, 4] = sb[:, 4] ** self.test_bbox_voting_score_pow
+                if self.test_bbox_voting_score_pow != 1:  # scores:pow(p) as THFloatTensor_pow: C pow in double, rounded once
+                    sb[:, 4] = sb[:, 4].double().pow(float(self.test_bbox_voting_score_pow)).float()
                 kb = utils.bbox_vote(kb.contiguous(), sb.contiguous(), self.bbox_vote_thresh)
             img_boxes.append(kb)
         torch.cuda.synchronize()

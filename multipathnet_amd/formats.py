@@ -92,9 +92,20 @@ def load_proposals(roidbfile):
             i = img2idx[v]
             b = np.asarray(dt2["boxes"][k], np.float32)
             sc = np.asarray(dt2["scores"][k], np.float32).reshape(-1) if dt2.get("scores") is not None else np.zeros(b.shape[0], np.float32)
-            out["boxes"][i] = b if out["boxes"][i] is None else np.concatenate([out["boxes"][i], b], 0)   # TableConcat
-            out["scores"][i] = sc if out["scores"][i] is None else np.concatenate([out["scores"][i], sc], 0)
+            out["boxes"][i] = _table_concat(out["boxes"][i], b)
+            out["scores"][i] = _table_concat(out["scores"][i], sc)
     return out
+
+
+def _table_concat(t1, t2):
+    """TableConcat (DataSetJSON.lua:114-122): an absent or EMPTY operand (an image without proposals in one of the merged files
+    is a 0-element tensor of no particular shape) yields the other one as float; otherwise torch.cat along dim 1."""
+    import numpy as np
+    if t1 is None or t1.size == 0:
+        return np.asarray(t2, np.float32)
+    if t2 is None or t2.size == 0:
+        return np.asarray(t1, np.float32)
+    return np.concatenate([np.asarray(t1, np.float32), np.asarray(t2, np.float32)], 0)
 
 
 def roidb_from_proposals(dt, file_names, best_number=None, min_area=0.0, allow_missing=False, device=None):

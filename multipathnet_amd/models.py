@@ -27,11 +27,20 @@ def cfg_layers(cfg):
     return cout, pool
 
 
-def synthetic_params(cfg=VGG16_CFG, pooled=7, fc_dim=4096, n_classes=21, seed=557, device="cpu", bbox_norm=True):
+HEAD_SCALES = {  # (cls_w std, cls_b std, bbox_w std, bbox_b std)
+    "init": (0.01, 0.0, 0.001, 0.0),       # model_utils.lua:106-112: the INITIALISATION of classAndBBoxLinear
+    "trained": (0.03, 1.0, 0.005, 0.1),    # magnitudes of a trained detector: class logits reach +-15, box deltas O(0.3)
+}
+
+
+def synthetic_params(cfg=VGG16_CFG, pooled=7, fc_dim=4096, n_classes=21, seed=557, device="cpu", bbox_norm=True, head_scale="init"):
     """Seeded random weights of the reference architecture (no pretrained .t7 exists offline):
     He-scaled trunk / fc so activations stay O(1) — the first conv is additionally divided by 70, the
     spread of the mean-subtracted 0..255 pixels it sees, like a trained Caffe VGG whose conv1_1 filters
-    are O(1e-2); heads as model_utils.lua:106-112 (cls N(0,0.01), bbox N(0,0.001), zero bias)."""
+    are O(1e-2); heads as model_utils.lua:106-112 (cls N(0,0.01), bbox N(0,0.001), zero bias).
+    head_scale="trained": head weights / biases at the magnitude of a trained detector instead of the initialisation
+    (the trunk and fc draws are the same for both, so the two parameter sets share every other tensor)."""
+    cls_std, cls_bstd, bbox_std, bbox_bstd = HEAD_SCALES[head_scale]
     g = torch.Generator().manual_seed(seed)
     P = {"conv_w": [], "conv_b": []}
     cin = 3
@@ -49,10 +58,11 @@ def synthetic_params(cfg=VGG16_CFG, pooled=7, fc_dim=4096, n_classes=21, seed=55
     P["fc6_b"] = (torch.randn(fc_dim, generator=g) * 0.01).to(device)
     P["fc7_w"] = (torch.randn(fc_dim, fc_dim, generator=g) * (2.0 / fc_dim) ** 0.5).to(device)
     P["fc7_b"] = (torch.randn(fc_dim, generator=g) * 0.01).to(device)
-    P["cls_w"] = (torch.randn(n_classes, fc_dim, generator=g) * 0.01).to(device)
-    P["cls_b"] = torch.zeros(n_classes, device=device)
-    P["bbox_w"] = (torch.randn(4 * n_classes, fc_dim, generator=g) * 0.001).to(device)
-    P["bbox_b"] = torch.zeros(4 * n_classes, device=device)
+    P["cls_w"] = (torch.randn(n_classes, fc_dim, generator=g) * cls_std).to(device)
+    P["bbox_w"] = (torch.randn(4 * n_classes, fc_dim, generator=g) * bbox_std).to(device)
+    # biases are drawn AFTER the weights so that "init" consumes the generator exactly as before
+    P["cls_b"] = (torch.randn(n_classes, generator=g) * cls_bstd).to(device)
+    P["bbox_b"] = (torch.randn(4 * n_classes, generator=g) * bbox_bstd).to(device)
     if bbox_norm:  # typical Fast R-CNN target statistics (train.lua:136-138 adds the module)
         P["bbox_mean"] = [0.0, 0.0, 0.0, 0.0]
         P["bbox_std"] = [0.1, 0.1, 0.2, 0.2]
@@ -676,6 +686,43 @@ class FastRCNN(object):
 
     def flush(self):
         check(self._lib.mpn_frcnn_flush(self._h, _stream()), "mpn_frcnn_flush")
+
+    # ---- proposal (ROI) sharding of one image across ranks: the latency mode (mpn_frcnn_shard_*, include/mpn.h) ----
+    def shard_record_floats(self, N, world):
+        """(floats of one rank's row record, floats of one rank's class record) for N proposals over `world` ranks."""
+        return (int(self._lib.mpn_frcnn_shard_rows_floats(self._h, int(N), int(world))),
+                int(self._lib.mpn_frcnn_shard_class_floats(self._h, int(N), int(world))))
+
+    def shard_head(self, image, boxes, rank, world, out=None):
+        """Trunk + ROI head on this rank's slice of `boxes` (the WHOLE table is passed) -> its row record."""
+        H, W = image.shape[1:]
+        N = boxes.size(0)
+        if out is None:
+            out = torch.empty(self.shard_record_floats(N, world)[0], dtype=torch.float32, device=self.device)
+        check(self._lib.mpn_frcnn_shard_head(self._h, _f(image, "image"), H, W, _f(boxes, "boxes"), N, int(rank), int(world), _f(out), _stream()),
+              "mpn_frcnn_shard_head")
+        return out
+
+    def shard_nms(self, rows_all, N, rank, world, out=None):
+        """All ranks' row records [world, rows_floats] -> this rank's class record (select + NMS (+ vote) of its classes)."""
+        if out is None:
+            out = torch.empty(self.shard_record_floats(N, world)[1], dtype=torch.float32, device=self.device)
+        check(self._lib.mpn_frcnn_shard_nms(self._h, _f(rows_all), int(N), int(rank), int(world), _f(out), _stream()), "mpn_frcnn_shard_nms")
+        return out
+
+    def shard_finish(self, class_all, N, world):
+        """All ranks' class records [world, class_floats] -> (dets, n) as test_one_async; nms_results() holds every class."""
+        check(self._lib.mpn_frcnn_shard_finish(self._h, _f(class_all), int(N), int(world), _f(self._dets), self._dets.size(0), _i(self._n_dets),
+                                               _stream()), "mpn_frcnn_shard_finish")
+        return self._dets, self._n_dets
+
+    def test_one_sharded(self, comm, image, boxes):
+        """mpn_frcnn_test_one_sharded over a parallel.Comm: every rank passes the same image and boxes and receives the
+        same (dets, n) — bit-identical to test_one_async on one GPU."""
+        H, W = image.shape[1:]
+        check(self._lib.mpn_frcnn_test_one_sharded(self._h, comm._h, _f(image, "image"), H, W, _f(boxes, "boxes"), boxes.size(0),
+                                                   _f(self._dets), self._dets.size(0), _i(self._n_dets), _stream()), "mpn_frcnn_test_one_sharded")
+        return self._dets, self._n_dets
 
     def nms_results(self):
         """Per-class NMS output of the last test_one: (keep [C-1,N,5], keep_idx [C-1,N], n_keep [C-1])."""

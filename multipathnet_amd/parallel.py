@@ -67,6 +67,14 @@ class Comm(object):
         _lib.check(self._lib.mpn_gather_dets(self._h, _f(dets), _i(n_dets), top_cap, _f(out), _stream()), "mpn_gather_dets")
         return out
 
+    def gather_rows(self, send, out=None):
+        """mpn_gather_rows: all-gather one fixed-size float record per rank -> [world, send.numel()]; stream-ordered."""
+        n = send.numel()
+        if out is None:
+            out = torch.empty((self.world, n), dtype=torch.float32, device=send.device)
+        _lib.check(self._lib.mpn_gather_rows(self._h, _f(send), n, _f(out), _stream()), "mpn_gather_rows")
+        return out
+
     def close(self):
         if self._h is not None and self._h.value:
             self._lib.mpn_comm_destroy(self._h)
@@ -81,11 +89,12 @@ def shard_indices(n_images, rank, world):
 
 
 def pack_record(dets, n_dets, top_cap):
-    """[top_cap*6 + 1] fp32 record: rows beyond n are zero, last element = count."""
+    """[top_cap*6 + 1] fp32 record: rows beyond n are zero, last element = count (mirror of pack_det_record_kernel, comm.hip)."""
     rec = torch.zeros(top_cap * 6 + 1, dtype=torch.float32, device=dets.device)
     n = (n_dets.to(dets.device).reshape(()) if isinstance(n_dets, torch.Tensor) else torch.tensor(n_dets, device=dets.device)).clamp(0, top_cap)
-    live = (torch.arange(top_cap, device=dets.device) < n).to(torch.float32).unsqueeze(1)  # no host sync: n stays on the device
-    rec[: top_cap * 6] = (dets[:top_cap] * live).reshape(-1)
+    live = (torch.arange(top_cap, device=dets.device) < n).unsqueeze(1)  # no host sync: n stays on the device
+    # SELECT zero for dead rows (as the kernel does): multiplying by 0 would let NaN / Inf garbage in them survive
+    rec[: top_cap * 6] = torch.where(live, dets[:top_cap], torch.zeros((), dtype=dets.dtype, device=dets.device)).reshape(-1)
     rec[-1] = n.to(torch.float32)
     return rec
 
@@ -117,3 +126,100 @@ def merge_by_image(gathered_per_step, world, n_images, top_cap):
             if i < n_images:
                 out[i] = unpack_record(g[r], top_cap)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Proposal (ROI) sharding of ONE image (latency mode; mpn_frcnn_shard_* in include/mpn.h): host mirrors of the partition
+# rule and of the two record layouts.  The device path is FastRCNN.test_one_sharded / shard_head / shard_nms /
+# shard_finish; these torch forms exist so that the partition / merge logic runs under gloo on CPU
+# (tests/test_dist_gloo.py) and so that the device's records can be checked element for element (tests/test_gpu_shard.py).
+# ---------------------------------------------------------------------------------------------------------------------
+def shard_range(n, world, rank):
+    """mpn_shard_range: balanced contiguous [lo, hi) — the first n % world ranks own one item more (host-only C call)."""
+    lo, hi = C.c_int(), C.c_int()
+    _lib.check(_lib.load().mpn_shard_range(int(n), int(world), int(rank), C.byref(lo), C.byref(hi)), "mpn_shard_range")
+    return lo.value, hi.value
+
+
+def shard_chunk(n, world):
+    return (n + world - 1) // world
+
+
+def pack_rows_record(scores, bbox, n_local, n_passes, chunk):
+    """scores [P*n_local, C], bbox [P*n_local, 4C] (pass-major joined tables of ONE rank) -> its row record
+    [scores: P x chunk x C | boxes: P x chunk x 4C], rows at / beyond n_local zero (mirror of shard_pack_rows_kernel)."""
+    Cc = scores.shape[1]
+    rs = torch.zeros((n_passes, chunk, Cc), dtype=torch.float32, device=scores.device)
+    rb = torch.zeros((n_passes, chunk, 4 * Cc), dtype=torch.float32, device=scores.device)
+    if n_local:
+        rs[:, :n_local] = scores.view(n_passes, n_local, Cc)
+        rb[:, :n_local] = bbox.view(n_passes, n_local, 4 * Cc)
+    return torch.cat([rs.reshape(-1), rb.reshape(-1)])
+
+
+def unpack_rows_records(rows_all, N, world, n_passes, n_classes):
+    """[world, rows_floats] -> the image's joined tables (scores [P*N, C], bbox [P*N, 4C]) in the unsharded row order
+    (mirror of shard_unpack_rows_kernel)."""
+    chunk, Cc = shard_chunk(N, world), n_classes
+    sc = torch.empty((n_passes, N, Cc), dtype=torch.float32, device=rows_all.device)
+    bb = torch.empty((n_passes, N, 4 * Cc), dtype=torch.float32, device=rows_all.device)
+    ns = n_passes * chunk * Cc
+    for r in range(world):
+        lo, hi = shard_range(N, world, r)
+        if hi > lo:
+            sc[:, lo:hi] = rows_all[r, :ns].view(n_passes, chunk, Cc)[:, : hi - lo]
+            bb[:, lo:hi] = rows_all[r, ns:].view(n_passes, chunk, 4 * Cc)[:, : hi - lo]
+    return sc.view(n_passes * N, Cc), bb.view(n_passes * N, 4 * Cc)
+
+
+def class_record_floats(n_fg_classes, world, rows, voting=False):
+    cmax = shard_chunk(n_fg_classes, world)
+    return cmax * (1 + rows * (11 if voting else 6))
+
+
+def pack_class_record(keep, keep_idx, n_keep, c0, c1, rows, cmax, voted=None):
+    """keep [n_cls, rows, 5], keep_idx [n_cls, rows] int32, n_keep [n_cls] int32 (only classes c0..c1-1 need be valid) ->
+    [n_keep: cmax ints | keep: cmax x rows x 5 | keep_idx: cmax x rows ints | voted: cmax x rows x 5] with the integers stored
+    bit for bit in float slots; rows at / beyond a class's n_keep zero (the device leaves them unwritten; nothing reads them)."""
+    dev = keep.device
+    hdr = torch.zeros(cmax, dtype=torch.int32, device=dev)
+    k = torch.zeros((cmax, rows, 5), dtype=torch.float32, device=dev)
+    ki = torch.zeros((cmax, rows), dtype=torch.int32, device=dev)
+    v = torch.zeros((cmax, rows, 5), dtype=torch.float32, device=dev) if voted is not None else None
+    for j, c in enumerate(range(c0, c1)):
+        n = int(n_keep[c])
+        hdr[j] = n
+        k[j, :n] = keep[c, :n]
+        ki[j, :n] = keep_idx[c, :n]
+        if v is not None:
+            v[j, :n] = voted[c, :n]
+    parts = [hdr.view(torch.float32), k.reshape(-1), ki.view(torch.float32).reshape(-1)]
+    if v is not None:
+        parts.append(v.reshape(-1))
+    return torch.cat(parts)
+
+
+def unpack_class_records(class_all, n_fg_classes, world, rows, voting=False):
+    """[world, class_floats] -> (keep [n_cls, rows, 5], keep_idx [n_cls, rows], n_keep [n_cls], voted or None); rows beyond
+    n_keep are zero (mirror of shard_unpack_classes_kernel)."""
+    cmax = shard_chunk(n_fg_classes, world)
+    dev = class_all.device
+    keep = torch.zeros((n_fg_classes, rows, 5), dtype=torch.float32, device=dev)
+    kidx = torch.zeros((n_fg_classes, rows), dtype=torch.int32, device=dev)
+    nk = torch.zeros(n_fg_classes, dtype=torch.int32, device=dev)
+    voted = torch.zeros_like(keep) if voting else None
+    for r in range(world):
+        c0, c1 = shard_range(n_fg_classes, world, r)
+        rec = class_all[r]
+        hdr = rec[:cmax].view(torch.int32)
+        k = rec[cmax: cmax + cmax * rows * 5].view(cmax, rows, 5)
+        ki = rec[cmax + cmax * rows * 5: cmax + cmax * rows * 6].view(torch.int32).view(cmax, rows)
+        v = rec[cmax + cmax * rows * 6:].view(cmax, rows, 5) if voting else None
+        for j, c in enumerate(range(c0, c1)):
+            n = int(hdr[j])
+            nk[c] = n
+            keep[c, :n] = k[j, :n]
+            kidx[c, :n] = ki[j, :n]
+            if voting:
+                voted[c, :n] = v[j, :n]
+    return keep, kidx, nk, voted

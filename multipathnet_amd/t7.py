@@ -108,6 +108,8 @@ class _Reader(object):
                 raise T7Error("unsupported storage class " + cls)
             n = self.long()
             nb = n * np.dtype(dt).itemsize
+            if n < 0 or self.p + nb > len(self.b):
+                raise T7Error("truncated or corrupt %s: %d elements claimed at byte %d of %d" % (cls, n, self.p, len(self.b)))
             a = np.frombuffer(self.b, dtype=dt, count=n, offset=self.p).copy()
             self.p += nb
             return a
@@ -123,6 +125,18 @@ class _Reader(object):
             if nd == 0 or st is None:
                 return np.zeros((0,), dtype=dt) if nd == 0 else np.zeros(size, dtype=dt)
             it = np.dtype(dt).itemsize
+            if not isinstance(st, np.ndarray) or st.dtype != np.dtype(dt):
+                raise T7Error("%s does not reference a storage of its own type" % cls)
+            # the view must stay inside its storage: sizes / strides / offset come unchecked from the file
+            if off < 0 or any(n < 0 for n in size) or any(q < 0 for q in stride):
+                raise T7Error("%s with negative size / stride / offset (size %s, stride %s, offset %d)" % (cls, size, stride, off + 1))
+            if all(n >= 1 for n in size):
+                last = off + sum((n - 1) * q for n, q in zip(size, stride))
+                if last >= st.shape[0]:
+                    raise T7Error("%s of size %s / stride %s / offset %d reaches element %d of a %d-element storage"
+                                  % (cls, size, stride, off + 1, last + 1, st.shape[0]))
+            else:
+                return np.zeros(size, dtype=dt)
             v = np.lib.stride_tricks.as_strided(st[off:], shape=size, strides=[s * it for s in stride], writeable=False)
             return np.ascontiguousarray(v)
         if cls == "tds.Hash":

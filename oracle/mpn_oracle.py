@@ -369,11 +369,15 @@ def detect(im, boxes, P, transformer=ROSS, target=600, max_size=1000, cfg=None, 
 
 
 def test_one(im, boxes, P, nms_thresh=0.3, score_thresh=-1.5, use_ref_nms=False, num_iter=1, use_rbox_scores=False,
-             bbox_voting=False, bbox_vote_thresh=0.5, **kw):
+             bbox_voting=False, bbox_vote_thresh=0.5, bbox_vote_score_pow=1.0, **kw):
     """Tester_FRCNN.lua:54-139: detect -> clamp the FIRST pass only (:75-78) -> for i = 2..num_iter: SelectBoxes on the previous
     pass, detect on the refined boxes (recompute_features = false: same trunk output; NOT clamped) (:82-89) ->
     opt.test_use_rbox_scores drops the first score table and the last box table (:91-97) -> joinTable -> per-class select ->
-    NMS (-> bbox_vote, :118-124; the reference passes an unset threshold field there, we take bbox_vote_thresh).
+    NMS (-> bbox_vote, :118-124; the reference passes an unset threshold field there, we take bbox_vote_thresh; the votes are
+    weighted by scores:pow(opt.test_bbox_voting_score_pow or 1) on a CLONE of the scored boxes (:119-121) — the kept boxes keep
+    their NMS scores.  THFloatTensor_pow lives in the absent TH library (PARITY UNPINNED): restated as C `pow` on the float
+    promoted to double, rounded back to float — what TH's generic `pow(*t_data, value)` does and, to the last bit except for
+    one-in-2^29 double roundings, what its later x*x / sqrt special cases give for p = 2 / 0.5).
     Returns (list over classes 1..C-1 of [K,5]), (scores, boxes) as joined."""
     scores, dec, _, _ = detect(im, boxes, P, **kw)
     dec = clamp_boxes(dec, im.shape[2], im.shape[1])
@@ -393,7 +397,11 @@ def test_one(im, boxes, P, nms_thresh=0.3, score_thresh=-1.5, use_ref_nms=False,
         sb, _ = select_scored(scores, dec, j, score_thresh)
         kept = ref_nms(sb, nms_thresh) if use_ref_nms else nms(sb, nms_thresh)
         if bbox_voting:
-            kept = (ref_bbox_vote if use_ref_nms else bbox_vote)(kept, sb, bbox_vote_thresh)
+            votes = sb
+            if bbox_vote_score_pow != 1.0:
+                votes = sb.copy()
+                votes[:, 4] = np.power(votes[:, 4].astype(np.float64), float(bbox_vote_score_pow)).astype(np.float32)
+            kept = (ref_bbox_vote if use_ref_nms else bbox_vote)(kept, votes, bbox_vote_thresh)
         out.append(kept)
     return out, (scores, dec)
 

@@ -59,6 +59,15 @@ def hooks(**settings):
                 getattr(lib, "mpn_debug_set_" + k)(HOOK_DEFAULTS[k])
 
 
+REGIME_IDS = {"distinct": 1, "ties": 2, "saturated": 3, "allequal": 4}
+
+
+def case_seed(regime, n, salt=0):
+    """A FIXED seed per (regime, n) case.  (Python's hash() of a str is randomised per process — PYTHONHASHSEED — so a
+    failure seen on the driver's box could not be reproduced from hash((regime, n)).)"""
+    return (REGIME_IDS[regime] * 1000003 + int(n) * 7919 + int(salt) * 104729 + 12345) % (2 ** 32)
+
+
 def random_scored_boxes(rng, n, regime="distinct", span=1000.0, lo=16.0, hi=400.0):
     """SURVEY §8d NMS micro-inputs: distinct random / heavy ties (1/64 quantised) / saturated (many exactly 1.0f)."""
     c = rng.uniform(0, span, (n, 2))
@@ -72,3 +81,41 @@ def random_scored_boxes(rng, n, regime="distinct", span=1000.0, lo=16.0, hi=400.
     elif regime == "allequal":
         s = np.full_like(s, 0.5)
     return np.concatenate([b, s], 1).astype(np.float32)
+
+
+def saturated_heads(P, fc7, boxes, n_classes, seed=991, lam=1.0, margin=10.0, objects_per_class=2):
+    """Head weights that make the synthetic network score like a TRAINED detector (test infrastructure; no pretrained .t7
+    exists offline).  A ridge fit of the class layer onto target logits over the image's own fc7 features `fc7` [N,F]:
+    background +margin / foreground -margin for ordinary ROIs, and for the ROIs with IoU >= 0.5 to one of a few seeded 'object'
+    boxes the object's class +margin / everything else -margin.  Result: |cls_w| rms ~ 0.09, logits within about +-margin,
+    nearly every softmax row saturated (its winner exactly 1.0f, 2*margin > 17.3 = 25 ln 2), and several ROIs per foreground
+    class tied at exactly 1.0f — the regime in which fp32 summation-order error must still land inside 1e-4 ABSOLUTE and in
+    which the NMS tie / saturated dispatch runs inside the pipeline.  Box regressor at the 'trained' magnitude.
+    Returns a copy of P with cls_w / cls_b / bbox_w / bbox_b replaced (the fit is deterministic for given fc7)."""
+    import torch
+    h = torch.as_tensor(fc7, dtype=torch.float64)
+    b = torch.as_tensor(boxes, dtype=torch.float64)
+    N, F = h.shape
+    g = torch.Generator().manual_seed(seed)
+    anchors = torch.randperm(N, generator=g)[: objects_per_class * (n_classes - 1)]
+    a = b[anchors]
+    x1 = torch.max(b[:, None, 0], a[None, :, 0]); y1 = torch.max(b[:, None, 1], a[None, :, 1])
+    x2 = torch.min(b[:, None, 2], a[None, :, 2]); y2 = torch.min(b[:, None, 3], a[None, :, 3])
+    inter = (x2 - x1).clamp(min=0) * (y2 - y1).clamp(min=0)
+    area = lambda q: (q[:, 2] - q[:, 0]) * (q[:, 3] - q[:, 1])
+    iou = inter / (area(b)[:, None] + area(a)[None, :] - inter)
+    T = torch.full((N, n_classes), -float(margin), dtype=torch.float64)
+    T[:, 0] = margin
+    for k in range(anchors.numel()):
+        m = iou[:, k] >= 0.5
+        T[m, :] = -float(margin)
+        T[m, 1 + k % (n_classes - 1)] = margin
+    ha = torch.cat([h, torch.ones(N, 1, dtype=torch.float64)], 1)  # bias column
+    U, S, Vh = torch.linalg.svd(ha, full_matrices=False)
+    Wa = (Vh.t() * (S / (S * S + lam))) @ (U.t() @ T)  # [F+1, C]
+    Q = dict(P)
+    Q["cls_w"] = Wa[:F].t().contiguous().float()
+    Q["cls_b"] = Wa[F].contiguous().float()
+    Q["bbox_w"] = torch.randn(4 * n_classes, F, generator=g) * 0.005
+    Q["bbox_b"] = torch.randn(4 * n_classes, generator=g) * 0.1
+    return Q

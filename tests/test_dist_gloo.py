@@ -83,3 +83,133 @@ def test_record_roundtrip_single_process():
     dets = torch.arange(60, dtype=torch.float32).view(10, 6)
     rec = parallel.pack_record(dets, torch.tensor([7], dtype=torch.int32), 10)
     assert rec.numel() == 61 and torch.equal(parallel.unpack_record(rec, 10), dets[:7])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Proposal (ROI) sharding of ONE image (latency mode, mpn_frcnn_shard_*): partition + the two record exchanges under gloo.
+# The per-row head is a deterministic stand-in (rows are independent — that is the property the mode rests on) and the
+# per-class NMS is the oracle's (the checker; no HIP device in this container), so what is tested is the host-visible
+# contract: mpn_shard_range's partition, the record layouts parallel.py mirrors from pipeline.hip, ragged N / classes not
+# divisible by the world size, a rank that owns nothing, and that every rank ends with the SAME full tables.
+# ---------------------------------------------------------------------------------------------------------------------
+def _standin_rows(boxes, n_classes, n_passes):
+    """joined [P*n, C] scores and [P*n, 4C] boxes of a slice: a pure function of each row's own box"""
+    outs_s, outs_b = [], []
+    for k in range(n_passes):
+        z = torch.stack([torch.sin(boxes[:, 0] * (0.37 + c) + boxes[:, 3] * 0.11 + k) for c in range(n_classes)], 1) * 3
+        outs_s.append(torch.softmax(z, 1))
+        d = torch.stack([torch.cos(boxes[:, j % 4] * (0.05 + 0.01 * c) + k) * (3 + j) for c in range(n_classes) for j in range(4)], 1)
+        outs_b.append(boxes.repeat(1, n_classes) + d)
+    return torch.cat(outs_s).float().contiguous(), torch.cat(outs_b).float().contiguous()
+
+
+def _shard_case_boxes(N, seed):
+    g = torch.Generator().manual_seed(seed)
+    c = torch.rand((N, 2), generator=g) * 200 + 20
+    wh = torch.rand((N, 2), generator=g) * 80 + 10
+    return torch.cat([c - wh / 2, c + wh / 2], 1).float()
+
+
+def _nms_tables(O, sc, bb, classes, rows, voting):
+    import numpy as np
+    n_cls = sc.shape[1] - 1
+    keep = torch.zeros((n_cls, rows, 5)); kidx = torch.zeros((n_cls, rows), dtype=torch.int32); nk = torch.zeros(n_cls, dtype=torch.int32)
+    voted = torch.zeros((n_cls, rows, 5)) if voting else None
+    for c in classes:
+        sb, src = O.select_scored(sc.numpy(), bb.numpy(), c + 1, -1.5)
+        k, ridx = O.nms(sb, 0.3, return_index=True)
+        nk[c] = k.shape[0]
+        keep[c, : k.shape[0]] = torch.from_numpy(k)
+        kidx[c, : k.shape[0]] = torch.from_numpy(np.asarray(src)[ridx].astype(np.int32))
+        if voting:
+            voted[c, : k.shape[0]] = torch.from_numpy(O.bbox_vote(k, sb, 0.5))
+    return keep, kidx, nk, voted
+
+
+def _shard_worker(rank, world, port, N, n_classes, n_passes, voting, q):
+    from multipathnet_amd import parallel
+    from oracle import mpn_oracle as O
+    O.build()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    boxes = _shard_case_boxes(N, 7)  # every rank is handed the same proposal table
+    lo, hi = parallel.shard_range(N, world, rank)
+    chunk = parallel.shard_chunk(N, world)
+    sc_l, bb_l = _standin_rows(boxes[lo:hi], n_classes, n_passes)
+    rec = parallel.pack_rows_record(sc_l, bb_l, hi - lo, n_passes, chunk)
+    rows_all = parallel.gather_detections(rec)
+    sc, bb = parallel.unpack_rows_records(rows_all, N, world, n_passes, n_classes)
+    rows = n_passes * N
+    c0, c1 = parallel.shard_range(n_classes - 1, world, rank)
+    keep, kidx, nk, voted = _nms_tables(O, sc, bb, range(c0, c1), rows, voting)
+    crec = parallel.pack_class_record(keep, kidx, nk, c0, c1, rows, parallel.shard_chunk(n_classes - 1, world), voted)
+    assert crec.numel() == parallel.class_record_floats(n_classes - 1, world, rows, voting)
+    class_all = parallel.gather_detections(crec)
+    K, KI, NK, V = parallel.unpack_class_records(class_all, n_classes - 1, world, rows, voting)
+    q.put((rank, sc.numpy().copy(), bb.numpy().copy(), K.numpy().copy(), KI.numpy().copy(), NK.numpy().copy(), None if V is None else V.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_shard_world(world, N, n_classes, n_passes, voting):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, N, n_classes, n_passes, voting, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = []
+    try:
+        for _ in range(world):
+            got.append(q.get(timeout=180))
+    except Exception:
+        got = None
+    ok = got is not None
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+            ok = False
+        elif p.exitcode != 0:
+            ok = False
+    return got if ok else None
+
+
+def test_shard_range_is_a_balanced_partition():
+    from multipathnet_amd import parallel
+    for n in (0, 1, 2, 5, 20, 37, 80, 1000, 1001):
+        for world in (1, 2, 3, 4, 8):
+            spans = [parallel.shard_range(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[r][1] == spans[r + 1][0] for r in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True) and max(sizes) <= parallel.shard_chunk(n, world)
+    assert parallel.shard_range(1000, 8, 3) == (375, 500) and parallel.shard_range(20, 8, 7) == (18, 20)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world,N,n_classes,n_passes,voting", [(2, 37, 6, 1, False), (2, 24, 4, 2, True), (3, 2, 5, 1, False)])
+def test_roi_sharded_image_equals_unsharded_under_gloo(world, N, n_classes, n_passes, voting):
+    """ragged N (37 over 2; 2 proposals over 3 ranks = a rank that owns nothing), classes not divisible by the world size (5 over 2,
+    3 over 2, 4 over 3), two localisation passes (pass-major joined rows) and the voted tables: every rank ends with the tables one
+    process computes on the whole image."""
+    import numpy as np
+    from oracle import mpn_oracle as O
+    O.build()
+    got = _run_shard_world(world, N, n_classes, n_passes, voting)
+    if got is None:
+        got = _run_shard_world(world, N, n_classes, n_passes, voting)
+    assert got is not None, "gloo run failed twice"
+    sc, bb = _standin_rows(_shard_case_boxes(N, 7), n_classes, n_passes)
+    rows = n_passes * N
+    keep, kidx, nk, voted = _nms_tables(O, sc, bb, range(n_classes - 1), rows, voting)
+    assert sorted(g[0] for g in got) == list(range(world))
+    for _, s_r, b_r, K, KI, NK, V in got:
+        assert np.array_equal(s_r, sc.numpy()) and np.array_equal(b_r, bb.numpy())
+        assert np.array_equal(NK, nk.numpy()) and np.array_equal(K, keep.numpy()) and np.array_equal(KI, kidx.numpy())
+        if voting:
+            assert np.array_equal(V, voted.numpy())
+    assert int(nk.sum()) > n_classes - 1   # the case keeps more than one box per class somewhere

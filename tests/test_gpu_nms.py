@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import hooks, random_scored_boxes
+from conftest import case_seed, hooks, random_scored_boxes
 
 pytestmark = pytest.mark.gpu
 
@@ -29,7 +29,7 @@ def nms_path(request):
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 300, 1000, 2500, 5000])
 def test_nms_bit_exact(O, dev, regime, n, nms_path):
     from multipathnet_amd import utils
-    rng = np.random.default_rng(hash((regime, n)) % 2**32)
+    rng = np.random.default_rng(case_seed(regime, n))
     sb = random_scored_boxes(rng, n, regime, span=300.0 if n <= 65 else 1000.0)
     for thr in (0.3, 0.5):
         ref, ridx = O.nms(sb, thr, return_index=True)

@@ -381,16 +381,19 @@ def test_detect_unclamped_is_imagedetect_semantics(O, dev, small):
         detect.ImageDetect(net, scale=[600], max_size=1000)   # the model's pipeline was built without getImages' rescaling
 
 
-@pytest.mark.parametrize("num_iter,rbox,voting", [(2, False, False), (2, True, False), (3, False, True), (3, True, False)])
-def test_iterative_localisation_vs_oracle(O, dev, small, num_iter, rbox, voting):
+@pytest.mark.parametrize("num_iter,rbox,voting,score_pow", [(2, False, False, 1.0), (2, True, False, 1.0), (3, False, True, 1.0),
+                                                            (3, False, True, 0.5), (3, False, True, 2.0), (1, False, True, 1.7),
+                                                            (3, True, False, 1.0)])
+def test_iterative_localisation_vs_oracle(O, dev, small, num_iter, rbox, voting, score_pow):
     """Tester_FRCNN.lua:72-100 against the ORACLE's restatement of the whole loop (first pass clamped, refinement passes not,
     SelectBoxes between passes, test_use_rbox_scores pairing): the device's joined score / box tables match it to the
     north_star tolerance, and the per-class NMS (+ voting) of the device's own rows is bit-exact — for the fused device path
-    and for the host mirror."""
+    and for the host mirror.  opt.test_bbox_voting_score_pow (Tester_FRCNN.lua:119-121) != 1: the votes are weighted by
+    score^p (double pow, rounded once — the oracle's restatement of scores:pow(p)), the kept boxes keep their NMS scores."""
     from multipathnet_amd import models, detect
     s = SMALL
     net = models.FastRCNN(small["P_torch"], cfg=s["cfg"], pooled=7, spatial_scale=s["scale"], max_h=s["H"], max_w=s["W"], max_rois=s["N"],
-                          num_iter=num_iter, use_rbox_scores=rbox, bbox_voting=voting, bbox_vote_thresh=0.5)
+                          num_iter=num_iter, use_rbox_scores=rbox, bbox_voting=voting, bbox_vote_thresh=0.5, bbox_vote_score_pow=score_pow)
     im, boxes = torch.from_numpy(small["im"]).to(dev), torch.from_numpy(small["boxes"]).to(dev)
     dets, n = net.test_one_async(im, boxes)
     torch.cuda.synchronize()
@@ -398,14 +401,14 @@ def test_iterative_localisation_vs_oracle(O, dev, small, num_iter, rbox, voting)
     rows = (num_iter - 1 if rbox else num_iter) * s["N"]
     assert keep.shape[1] == rows
     tester = detect.Tester_FRCNN(small["net"], opt={"test_num_iterative_loc": num_iter, "test_use_rbox_scores": rbox, "test_bbox_voting": voting,
-                                                    "test_bbox_voting_nms_threshold": 0.5})
+                                                    "test_bbox_voting_nms_threshold": 0.5, "test_bbox_voting_score_pow": score_pow})
     img_boxes, (output, bbox_pred) = tester.testOne(im, boxes)
     assert output.shape[0] == rows and bbox_pred.shape[0] == rows
     for j, kb in enumerate(img_boxes):
         assert np.array_equal(keep[j, : nk[j]], kb.cpu().numpy(), equal_nan=True), j
     # the oracle's whole loop on the same inputs (its own fp32 summation order => tolerance on the tables)
-    _, (osc, obb) = O.test_one(small["im"], small["boxes"], small["P"], num_iter=num_iter, use_rbox_scores=rbox, cfg=s["cfg"],
-                               target=s["H"], max_size=s["W"])
+    o_boxes, (osc, obb) = O.test_one(small["im"], small["boxes"], small["P"], num_iter=num_iter, use_rbox_scores=rbox, cfg=s["cfg"],
+                                     target=s["H"], max_size=s["W"], bbox_voting=voting, bbox_vote_thresh=0.5, bbox_vote_score_pow=score_pow)
     sc, bb = output.cpu().numpy(), bbox_pred.cpu().numpy()
     assert np.abs(sc - osc).max() < 1e-4
     assert np.abs(bb - obb).max() < 2e-3 * s["W"]   # refinement passes decode from boxes that already carry the first pass's rounding
@@ -415,13 +418,25 @@ def test_iterative_localisation_vs_oracle(O, dev, small, num_iter, rbox, voting)
         assert (bb[n_first:] < 1.0).any() or (bb[n_first:, 0::2] > s["W"]).any() or (bb[n_first:, 1::2] > s["H"]).any()
     # NMS / voting of the device's rows: bit-exact against the oracle (== compiled nms.c, tests/test_oracle_nms.py)
     per = []
+    moved = False
     for j in range(1, s["C"]):
         sb, _ = O.select_scored(sc, bb, j, -1.5)
         ref = O.nms(sb, 0.3)
         if voting:
-            ref = O.bbox_vote(ref, sb, 0.5)
+            votes = sb.copy()
+            if score_pow != 1.0:
+                votes[:, 4] = np.power(votes[:, 4].astype(np.float64), score_pow).astype(np.float32)
+                assert not np.array_equal(votes[:, 4], sb[:, 4])
+            ref = O.bbox_vote(ref, votes, 0.5)
+            if score_pow != 1.0 and ref.shape[0]:  # the exponent really changes the vote (else the case tests nothing)
+                moved = moved or not np.array_equal(ref, O.bbox_vote(O.nms(sb, 0.3), sb, 0.5))
         assert np.array_equal(keep[j - 1, : nk[j - 1]], ref, equal_nan=True)
+        # the oracle's own loop end to end (its rows differ from the device's by summation order): same number of classes, and
+        # where its rows select the same boxes the voted coordinates agree to the table tolerance
+        assert len(o_boxes) == s["C"] - 1
         per.append(ref)
+    if voting and score_pow != 1.0:
+        assert moved
     kept, _ = O.keep_top_k(per, 100)
     exp = np.concatenate([np.concatenate([k, np.full((k.shape[0], 1), j + 1, np.float32)], 1) for j, k in enumerate(kept) if k.size])
     assert np.array_equal(dets[: int(n.item())].cpu().numpy(), exp, equal_nan=True)

@@ -139,3 +139,41 @@ def test_gather_dets_two_threads_one_process(dev):
     for r in range(world):
         lib.mpn_comm_destroy(C.c_void_p(comms[r]))
     assert results == [True, True]
+
+
+def _run_bench(extra, env_extra, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update(env_extra)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]   # ONE JSON line, from rank 0 only
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_on_one_gpu_share_mode(dev):
+    """`bench.py --gpus 2` end to end on a one-GPU box — self-launch under torch.distributed.run, RANK / LOCAL_RANK /
+    WORLD_SIZE parsing, the gloo bootstrap group, the drift stream, the MAX-reduce of the elapsed time, rank-0-only printing.
+    MPN_BENCH_SHARE_GPU=1 maps both ranks to device 0 and routes the record gather through gloo (RCCL refuses two ranks on one
+    device); the line says so and is not a multi-GPU measurement."""
+    out = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"], {"MPN_BENCH_SHARE_GPU": "1"})
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 2 and out["scaling"] == "weak"
+    assert "MPN_BENCH_SHARE_GPU=1" in out["config"]["parallelism"] and "NOT a multi-GPU measurement" in out["config"]["parallelism"]
+    assert out["value"] > 0 and abs(out["value"] - 2 * 1000 * 4 / (out["ms_per_step"] * 4e-3)) < 1e-3 * out["value"]
+    assert out["roofline"]["frac"] <= 1.0
+
+
+@pytest.mark.timeout(900)
+def test_bench_latency_mode_single_rank(dev):
+    """`bench.py --mode latency` at N = 1: mpn_frcnn_test_one_sharded over a world-1 communicator, its own metric string, plus the
+    one-GPU projection of rank 0's share of an 8-rank world."""
+    out = _run_bench(["--mode", "latency", "--steps", "5", "--warmup", "2"], {})
+    assert "latency" in out["metric"] and "not the headline" in out["metric"] and out["higher_is_better"] is False and out["scaling"] == "strong"
+    assert out["unit"] == "ms/image" and 0 < out["value"] < 50 and out["unsharded_ms"] > 0
+    assert out["projected"]["world"] == 8 and 0 < out["projected"]["rank0_compute_ms"] < out["value"]

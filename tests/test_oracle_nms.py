@@ -4,7 +4,7 @@
 import numpy as np
 import pytest
 
-from conftest import random_scored_boxes
+from conftest import case_seed, random_scored_boxes
 
 
 def test_iou_known_answer(O):
@@ -29,7 +29,7 @@ def test_overlap_degenerate(O):
 def test_nms_matches_reference_c(O, regime, n, thr):
     if not O.have_ref():
         pytest.skip("oracle/_ref/libnms_ref.so not built (needs /root/reference)")
-    rng = np.random.default_rng(hash((regime, n)) % 2**32)
+    rng = np.random.default_rng(case_seed(regime, n))
     sb = random_scored_boxes(rng, n, regime, span=300.0 if n <= 65 else 1000.0)
     mine, idx = O.nms(sb, thr, return_index=True)
     ref = O.ref_nms(sb, thr)

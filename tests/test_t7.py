@@ -129,3 +129,50 @@ def test_boxes_and_results_files_and_proposal_merge():
         assert m["images"] == ["a.jpg", "b.jpg", "c.jpg"]
         assert np.array_equal(m["boxes"][1], np.concatenate([b1[1], b2[0]])) and m["scores"][1][2:].tolist() == [0, 0, 0]
         assert np.array_equal(m["boxes"][2], b2[1]) and m["scores"][2].tolist() == [0]
+
+
+def _tensor_bytes(size, stride, offset, n_storage, claim=None):
+    """a lone torch.FloatTensor record with the given (unchecked-by-the-format) geometry over an n_storage-element storage;
+    `claim` = the element count the storage header states (default n_storage)."""
+    b = _i(4) + _i(1) + _s("V 1") + _s("torch.FloatTensor")
+    b += _i(len(size)) + b"".join(_q(v) for v in size) + b"".join(_q(v) for v in stride) + _q(offset)
+    b += _i(4) + _i(2) + _s("V 1") + _s("torch.FloatStorage")
+    b += _q(n_storage if claim is None else claim) + np.arange(n_storage, dtype="<f4").tobytes()
+    return b
+
+
+def test_malformed_tensor_geometry_raises_t7error():
+    """sizes / strides / offset / storage counts come unchecked from the file; a view that leaves its storage must
+    raise T7Error instead of reading out of bounds (a 1000x1000 tensor over a 4-element storage used to load as garbage)."""
+    ok = t7.loads(_tensor_bytes([2, 2], [2, 1], 1, 4))
+    assert np.array_equal(ok, np.arange(4, dtype=np.float32).reshape(2, 2))
+    assert np.array_equal(t7.loads(_tensor_bytes([2, 3], [0, 1], 2, 4)), np.array([[1, 2, 3], [1, 2, 3]], np.float32))  # expand()ed view
+    for size, stride, off in [([1000, 1000], [1000, 1], 1), ([2, 2], [2, 1], 2), ([2, 2], [4, 1], 1), ([4], [1], 0), ([2], [-1], 2),
+                              ([-1], [1], 1), ([5], [1], 1)]:
+        with pytest.raises(t7.T7Error):
+            t7.loads(_tensor_bytes(size, stride, off, 4))
+    for claim in (-1, 5, 2 ** 40):
+        with pytest.raises(t7.T7Error):
+            t7.loads(_tensor_bytes([2], [1], 1, 4, claim=claim))
+    assert t7.loads(_tensor_bytes([0, 4], [4, 1], 1, 4)).shape == (0, 4)
+
+
+def test_proposal_merge_with_an_empty_per_image_tensor():
+    """TableConcat (DataSetJSON.lua:114-122) returns the other operand when one side is empty — an image without
+    proposals in one of the merged files is a 0-element tensor, shape (0,), which does not concatenate with (n,4)."""
+    from multipathnet_amd import formats
+    rng = np.random.default_rng(3)
+    with tempfile.TemporaryDirectory() as d:
+        f1, f2, f3 = (os.path.join(d, n) for n in ("p1.t7", "p2.t7", "p3.t7"))
+        b1 = [np.zeros((0,), np.float32), rng.random((2, 4)).astype(np.float32)]
+        s1 = [np.zeros((0,), np.float32), rng.random(2).astype(np.float32)]
+        b2 = [rng.random((3, 4)).astype(np.float32), np.zeros((0,), np.float32)]
+        s2 = [rng.random(3).astype(np.float32), np.zeros((0,), np.float32)]
+        t7.save(f1, {"boxes": b1, "scores": s1, "images": ["a.jpg", "b.jpg"]})
+        t7.save(f2, {"boxes": b2, "scores": s2, "images": ["a.jpg", "b.jpg"]})
+        t7.save(f3, {"boxes": [np.zeros((0,), np.float32)], "images": ["a.jpg"]})   # unscored AND empty
+        m = formats.load_proposals([f1, f2, f3])
+        assert np.array_equal(m["boxes"][0], b2[0]) and np.array_equal(m["scores"][0], s2[0])   # empty first, then 3 boxes, then empty
+        assert np.array_equal(m["boxes"][1], b1[1]) and np.array_equal(m["scores"][1], s1[1])
+        m2 = formats.load_proposals([f2, f1])
+        assert np.array_equal(m2["boxes"][0], b2[0]) and np.array_equal(m2["boxes"][1], b1[1])
