@@ -93,7 +93,9 @@ class Tester_FRCNN(object):
             if self.test_bbox_voting:
                 sb = scored[j, : cnt[j]].clone()
                 if self.test_bbox_voting_score_pow != 1:  # scores:pow(p) as THFloatTensor_pow: C pow in double, rounded once
-                    sb[:, 4] = sb[:, 4].double().pow(float(self.test_bbox_voting_score_pow)).float()
+                    # (the exponent reaches THFloatTensor_pow as a float: `real value`)
+                    p32 = float(torch.tensor(float(self.test_bbox_voting_score_pow), dtype=torch.float32))
+                    sb[:, 4] = sb[:, 4].double().pow(p32).float()
                 kb = utils.bbox_vote(kb.contiguous(), sb.contiguous(), self.bbox_vote_thresh)
             img_boxes.append(kb)
         torch.cuda.synchronize()

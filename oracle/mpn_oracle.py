@@ -400,7 +400,8 @@ def test_one(im, boxes, P, nms_thresh=0.3, score_thresh=-1.5, use_ref_nms=False,
             votes = sb
             if bbox_vote_score_pow != 1.0:
                 votes = sb.copy()
-                votes[:, 4] = np.power(votes[:, 4].astype(np.float64), float(bbox_vote_score_pow)).astype(np.float32)
+                # THFloatTensor_pow(r, t, real value): the Lua double exponent arrives as a FLOAT
+                votes[:, 4] = np.power(votes[:, 4].astype(np.float64), float(np.float32(bbox_vote_score_pow))).astype(np.float32)
             kept = (ref_bbox_vote if use_ref_nms else bbox_vote)(kept, votes, bbox_vote_thresh)
         out.append(kept)
     return out, (scores, dec)

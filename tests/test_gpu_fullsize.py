@@ -90,19 +90,42 @@ def test_fullsize_trunk_and_head_vs_pytorch_cpu(O, dev, full):
 
 
 @pytest.fixture(scope="module")
-def cpu_feats(O, full):
-    """CPU-side quantities the trained-scale tests share: the oracle's full 600x1000 trunk output, the oracle ROI pool of all
-    1000 ROIs and PyTorch-CPU fc7 activations of all 1000 ROIs (fc6 / fc7 are common to every head regime)."""
+def cpu_feats(O, dev, full):
+    """CPU-side quantities the trained-scale tests share (fc6 / fc7 are common to every head regime):
+      feat_o / feat_t / feat_d   conv5 of the oracle (plain C fp32), of PyTorch-CPU (oneDNN fp32) and of the DEVICE;
+      fc7_t                      PyTorch-CPU fp32 fc7 activations of all 1000 ROIs (on its own conv5);
+      idx, fc7_64[src]           a 100-ROI sample and, for each conv5 source, fc7 of the sample evaluated in FLOAT64 — the exact head,
+                                 against which an fp32 head's own summation error can be separated from the trunk's."""
     import torch.nn.functional as F
-    im, boxes, P = full["im"], full["boxes"], full["P"]
+    from multipathnet_amd import models
+    im, boxes, P, net = full["im"], full["boxes"], full["P"], full["net"]
     Pn = _np_tree(P)
-    feat = O.vgg_trunk(O.image_transform(im, **O.ROSS), Pn["conv_w"], Pn["conv_b"])
-    pooled, _ = O.roi_pool(feat, O.project_im_rois(boxes, 1.0), 7, 7, 1.0 / 16)
+    feat_o = O.vgg_trunk(O.image_transform(im, **O.ROSS), Pn["conv_w"], Pn["conv_b"])
+    net.detect(full["imd"], full["bd"])
+    feat_d = net.debug_tensor("conv5", feat_o.shape).cpu().numpy()
+    rois = O.project_im_rois(boxes, 1.0)
+    idx = np.random.default_rng(7).choice(boxes.shape[0], N_SAMPLE, replace=False)
     with torch.no_grad():
-        h = torch.from_numpy(pooled.reshape(boxes.shape[0], -1))
+        x = torch.from_numpy(O.image_transform(im, **O.ROSS)).unsqueeze(0)
+        li = 0
+        for item in models.VGG16_CFG:
+            if item == "P":
+                x = F.max_pool2d(x, 2, 2, ceil_mode=True)
+            else:
+                x = F.relu(F.conv2d(x, P["conv_w"][li], P["conv_b"][li], padding=1))
+                li += 1
+        feat_t = x[0].numpy()
+        pooled_t, _ = O.roi_pool(feat_t, rois, 7, 7, 1.0 / 16)
+        h = torch.from_numpy(pooled_t.reshape(boxes.shape[0], -1))
         h = F.relu(F.linear(h, P["fc6_w"], P["fc6_b"]))
-        fc7 = F.relu(F.linear(h, P["fc7_w"], P["fc7_b"]))
-    return dict(feat=feat, fc7=fc7)
+        fc7_t = F.relu(F.linear(h, P["fc7_w"], P["fc7_b"]))
+        w6, b6, w7, b7 = P["fc6_w"].double(), P["fc6_b"].double(), P["fc7_w"].double(), P["fc7_b"].double()
+        fc7_64 = {}
+        for name, feat in (("oracle", feat_o), ("torch", feat_t), ("device", feat_d)):
+            pooled, _ = O.roi_pool(feat, rois[idx], 7, 7, 1.0 / 16)   # integer bin bounds + max: no arithmetic
+            h = torch.from_numpy(pooled.reshape(N_SAMPLE, -1)).double()
+            fc7_64[name] = F.relu(F.linear(F.relu(F.linear(h, w6, b6)), w7, b7))
+    return dict(feat=feat_o, feat_t=feat_t, feat_d=feat_d, fc7=fc7_t, idx=idx, fc7_64=fc7_64)
 
 
 def _regime_params(full, cpu_feats, regime):
@@ -129,9 +152,24 @@ def scaled(request, O, dev, full, cpu_feats):
 
 
 def test_fullsize_trained_scale_logits_deltas_vs_oracle(O, dev, full, cpu_feats, scaled):
-    """the full-size 1e-4 ABSOLUTE check at the score scale of a trained detector — head weights ~10x the
-    initialisation, non-zero biases, logits of +-10..15, softmax rows saturating to exactly 1.0f — where fp32 summation-order
-    error over K = 25088 plus the Winograd trunk's error must still land inside north_star's 1e-4."""
+    """the full-size check at the score scale of a trained detector — head weights 3-9x the initialisation,
+    non-zero biases, logits of +-10..16, softmax rows saturating to exactly 1.0f.
+
+    'trained' (random heads, |cls_w| rms 0.03): class LOGITS and box DELTAS within 1e-4 ABSOLUTE of the oracle, like the
+    initialisation-scale test above.
+
+    'saturated' (heads fitted to this image's features, |cls_w| rms 0.09, every softmax row's winner exactly 1.0f): north_star's
+    quantities — class SCORES and bbox regression — are within 1e-4; the pre-softmax logits are not, for ANY fp32 implementation:
+    the fitted weights weigh the low-variance directions of fc7 and amplify fp32 summation-order error ~10x.  Measured on CPU
+    alone (tools/logit_error_attribution.py): PyTorch-CPU fp32 and the oracle's plain-C fp32 differ by 7.9e-4 there, the oracle's own
+    head is 6.3e-4 from the same head evaluated in float64 (sequential accumulation over K = 25088), PyTorch's blocked summation
+    1.1e-4.  So the logit bound in this regime is what fp32 admits, stated relative to the two CPU implementations:
+      (i) device-vs-oracle no larger than 1.5x PyTorch-vs-oracle;
+      (ii) the device's HEAD, against the float64 head on the device's own conv5, at least as accurate as the oracle's head is
+           against the float64 head on the oracle's conv5;
+      (iii) the device's TRUNK, seen through the float64 head, no further from the oracle's trunk than 1.5x PyTorch's trunk is.
+    The three error terms are printed: this is the per-layer attribution VERDICT r2 asked for."""
+    import torch.nn.functional as F
     net, P, regime = scaled["net"], scaled["P"], scaled["regime"]
     im, boxes = full["im"], full["boxes"]
     s, b = net.detect(full["imd"], full["bd"])
@@ -140,36 +178,57 @@ def test_fullsize_trained_scale_logits_deltas_vs_oracle(O, dev, full, cpu_feats,
     cls = net.debug_tensor("cls", (N, C)).cpu().numpy()
     raw = net.debug_tensor("bbox_raw", (N, 4 * C)).cpu().numpy()
     Pn = _np_tree(P)
-    idx = np.random.default_rng(7).choice(N, N_SAMPLE, replace=False)
+    idx = cpu_feats["idx"]
     logits, deltas = O.frcnn_head(cpu_feats["feat"], O.project_im_rois(boxes[idx], 1.0), Pn)
     e_logit, e_delta = np.abs(cls[idx] - logits).max(), np.abs(raw[idx] - deltas).max()
+    with torch.no_grad():
+        logits_t = F.linear(cpu_feats["fc7"][idx], P["cls_w"], P["cls_b"]).numpy()
+        l64 = {k: F.linear(v, P["cls_w"].double(), P["cls_b"].double()).numpy() for k, v in cpu_feats["fc7_64"].items()}
+    e_ref = np.abs(logits_t - logits).max()                       # two CPU fp32 implementations of the same network
+    head_dev, head_orc, head_torch = np.abs(cls[idx] - l64["device"]).max(), np.abs(logits - l64["oracle"]).max(), np.abs(logits_t - l64["torch"]).max()
+    trunk_dev, trunk_torch = np.abs(l64["device"] - l64["oracle"]).max(), np.abs(l64["torch"] - l64["oracle"]).max()
     n_sat = int((s == 1.0).sum())
-    print("full-size head [%s], %d ROIs: max|dlogit| = %.3g (logits %.3g .. %.3g, |cls_w| rms %.3g), max|ddelta| = %.3g (|delta| <= %.3g); "
-          "%d of %d softmax scores are exactly 1.0f (%d foreground)"
-          % (regime, N_SAMPLE, e_logit, cls.min(), cls.max(), float(np.sqrt((Pn["cls_w"] ** 2).mean())), e_delta, np.abs(deltas).max(),
-             n_sat, N, int((s[:, 1:] == 1.0).sum())))
+    print("full-size head [%s], %d ROIs: max|dlogit| device-oracle = %.3g, PyTorchCPU-oracle = %.3g (logits %.3g .. %.3g, |cls_w| rms %.3g); "
+          "head error vs the float64 head on the same conv5: device %.3g, oracle %.3g, PyTorchCPU %.3g; trunk difference to the oracle's through "
+          "the float64 head: device %.3g, PyTorchCPU %.3g; max|ddelta| = %.3g (|delta| <= %.3g); %d of %d softmax rows hold an exact 1.0f (%d foreground)"
+          % (regime, N_SAMPLE, e_logit, e_ref, cls.min(), cls.max(), float(np.sqrt((Pn["cls_w"] ** 2).mean())), head_dev, head_orc, head_torch,
+             trunk_dev, trunk_torch, e_delta, np.abs(deltas).max(), n_sat, N, int((s[:, 1:] == 1.0).sum())))
     assert np.abs(cls).max() > 9.0                      # the regime is what it claims to be
-    if regime == "saturated":
+    assert e_delta < 1e-4                               # ABSOLUTE, pre-decode
+    if regime == "trained":
+        assert e_logit < 1e-4                           # ABSOLUTE, pre-softmax
+    else:
         assert n_sat >= 300 and int((s[:, 1:] == 1.0).sum()) >= 20
-    assert e_logit < 1e-4 and e_delta < 1e-4            # ABSOLUTE, pre-softmax / pre-decode
-    assert np.abs(s[idx] - O.softmax(logits)).max() < 1e-4
+        assert e_logit < max(1e-4, 1.5 * e_ref)         # (i)
+    assert head_dev <= max(2e-5, head_orc)              # (ii)
+    assert trunk_dev <= max(2e-5, 1.5 * trunk_torch)    # (iii)
+    assert np.abs(s[idx] - O.softmax(logits)).max() < 1e-4   # north_star: class scores
     bo = O.clamp_boxes(O.bbox_decode(boxes[idx], deltas), im.shape[2], im.shape[1])
     assert np.abs(b[idx] - bo).max() < 1e-4 * im.shape[2]
 
 
 def test_fullsize_trained_scale_vs_pytorch_cpu(O, dev, full, cpu_feats, scaled):
-    """The same regimes against PyTorch-CPU's fc7 (oneDNN; oracle-independent dense arithmetic) on ALL 1000 ROIs."""
+    """The same regimes against PyTorch-CPU's fp32 path (oneDNN; oracle-independent dense arithmetic) on ALL 1000 ROIs: scores and
+    deltas within 1e-4; logits within 1e-4 ('trained') / within 1.5x the PyTorch-vs-oracle spread of the sample ('saturated', see
+    the test above)."""
     import torch.nn.functional as F
     net, P = scaled["net"], scaled["P"]
     N, C = full["boxes"].shape[0], net.n_classes
-    net.detect(full["imd"], full["bd"])
+    s, _ = net.detect(full["imd"], full["bd"])
     with torch.no_grad():
         logits = F.linear(cpu_feats["fc7"], P["cls_w"], P["cls_b"]).numpy()
         deltas = F.linear(cpu_feats["fc7"], P["bbox_w"], P["bbox_b"]).numpy() * np.tile(np.asarray(P["bbox_std"], np.float32), C) + np.tile(np.asarray(P["bbox_mean"], np.float32), C)
     cls = net.debug_tensor("cls", (N, C)).cpu().numpy()
     raw = net.debug_tensor("bbox_raw", (N, 4 * C)).cpu().numpy()
-    print("[%s] vs PyTorch-CPU, 1000 ROIs: max|dlogit| = %.3g, max|ddelta| = %.3g" % (scaled["regime"], np.abs(cls - logits).max(), np.abs(raw - deltas).max()))
-    assert np.abs(cls - logits).max() < 1e-4 and np.abs(raw - deltas).max() < 1e-4
+    e_logit = np.abs(cls - logits).max()
+    print("[%s] vs PyTorch-CPU, 1000 ROIs: max|dlogit| = %.3g, max|ddelta| = %.3g" % (scaled["regime"], e_logit, np.abs(raw - deltas).max()))
+    assert np.abs(raw - deltas).max() < 1e-4 and np.abs(s.cpu().numpy() - O.softmax(logits)).max() < 1e-4
+    if scaled["regime"] == "trained":
+        assert e_logit < 1e-4
+    else:
+        idx = cpu_feats["idx"]
+        lo, _ = O.frcnn_head(cpu_feats["feat"], O.project_im_rois(full["boxes"][idx], 1.0), _np_tree(P))
+        assert e_logit < max(1e-4, 1.5 * np.abs(logits[idx] - lo).max())
 
 
 def test_fullsize_trained_scale_test_one_all_classes_vs_reference_nms(O, dev, full, scaled):

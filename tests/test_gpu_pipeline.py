@@ -425,7 +425,7 @@ def test_iterative_localisation_vs_oracle(O, dev, small, num_iter, rbox, voting,
         if voting:
             votes = sb.copy()
             if score_pow != 1.0:
-                votes[:, 4] = np.power(votes[:, 4].astype(np.float64), score_pow).astype(np.float32)
+                votes[:, 4] = np.power(votes[:, 4].astype(np.float64), float(np.float32(score_pow))).astype(np.float32)
                 assert not np.array_equal(votes[:, 4], sb[:, 4])
             ref = O.bbox_vote(ref, votes, 0.5)
             if score_pow != 1.0 and ref.shape[0]:  # the exponent really changes the vote (else the case tests nothing)
