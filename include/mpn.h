@@ -79,6 +79,14 @@ int mpn_nms_batched(const float *d_scored, const int *d_counts, int n_cls, int m
 /* Single-class convenience (== utils.nms, utils.lua:29-33) on device buffers. */
 int mpn_nms(const float *d_scored, int m, float thr, float *d_keep, int *d_keep_idx, int *d_n_keep, void *stream);
 
+/* utils.nms_dense (utils.lua:402-462, called by demo.lua:85): the index-returning NMS — sort by score (descending), walk the
+ * sorted list, a picked box suppresses every box whose IoU with it (areas with the +1 convention, intersection clamped at 0)
+ * exceeds `overlap` (strict).  d_boxes [m,5] {x1,y1,x2,y2,score}; d_pick [m] int32 receives the picks as 1-BASED row indices
+ * in pick order (the LongTensor the Lua function returns), *d_n_pick their number.  m <= 8192.  The order among bit-equal
+ * scores is the sort's: torch.sort is TH's (unstable) quicksort and TH is absent from the reference tree — PARITY UNPINNED
+ * there; this library sorts ties by ascending index. */
+int mpn_nms_dense(const float *d_boxes, int m, float overlap, int *d_pick, int *d_n_pick, void *stream);
+
 /* Host-buffer form used by the libnms.so drop-in: H2D, kernel, D2H, synchronous.  h_keep [m,5]. */
 int mpn_nms_host(const float *h_scored, int m, float thr, float *h_keep, int *h_keep_idx, int *n_keep);
 

@@ -152,11 +152,12 @@ __device__ __forceinline__ unsigned nms_f2key(float f) {
 constexpr int kSortMax = 8192;  // 64 KiB of LDS keys
 constexpr int kTieMax = 4096;   // nms_tie_kernel: one 64-bit alive/occupancy word per lane
 constexpr int kTieLdsMask = 1024;  // full symmetric mask kept in LDS up to this many boxes (128 KiB)
-// Classes with up to this many tied adjacent pairs take the chunked scan with position replay (flag 3).  0 = never by default:
-// measured on MI355X (tools/nms_trace.py) the replay — per-pick VALU <-> SALU round trips of ~40 cycles each — costs more than
-// the slot-emulating kernel it was meant to undercut (850 k vs 320 k cycles for 1000 boxes with four tied pairs); it stays in the
-// library as a second, independent exact implementation (test path 3) until its per-pick work is vectorised.
-constexpr int kFewTies = 0;
+// Classes with up to this many tied adjacent pairs take the chunked scan with the lazy, vectorised position replay (flag 3): its
+// cost is the tie-free scan plus one batched update of the slot model per equal-score run that still has two alive members at
+// its turn.  (Round 2's eager form — head replay and death recording inside every chunk — measured 850 k cycles against the slot
+// kernel's 320 k and was not dispatched to.)  Classes with more ties keep the slot-emulating kernel, whose per-pick cost does
+// not depend on the number of ties.
+constexpr int kFewTies = 32;
 
 __global__ __launch_bounds__(1024) void nms_sort_kernel(const float *__restrict__ scored, const int *__restrict__ counts,
                                                         int m_stride, float4 *__restrict__ sbox, float *__restrict__ sscore,
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float *__restrict_
   if (tid == 0) { bad = 0; nsel = 0; hasnan = 0; }
   __syncthreads();
   if (m > kSortMax || force_mode == 1) { if (tid == 0) { flags[cls] = 2; n_sel[cls] = 0; } return; }
+  const bool dense = force_mode == 4;  // utils.nms_dense: picks follow the SORT's order (no position history), every box is pickable
   const float *src = scored + (size_t)cls * m_stride * 5;
   for (int i = tid; i < n_pad; i += blockDim.x) {
     unsigned long long k = ~0ull;
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float *__restrict_
     ob[p] = make_float4(r[0], r[1], r[2], r[3]);
     os[p] = s;
     oi[p] = i;
-    if (s > -10000000.0f) ++local_sel;  // nms.c:75: never picked otherwise; sorted => a prefix
+    if (dense || s > -10000000.0f) ++local_sel;  // nms.c:75: never picked otherwise; sorted => a prefix
   }
   atomicAdd(&nsel, local_sel);
   __syncthreads();
@@ -219,11 +221,27 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float *__restrict_
     // the host launches nms_tie_kernel only when m_stride <= kTieMax (its LDS tables are sized by m_stride): a class with
     // ties in a wider table goes to the exact sweep kernel, whatever its own count
     if (f == 1 && m_stride > kTieMax) f = 2;
+    if (dense) f = 0;
     flags[cls] = f;
     n_sel[cls] = nsel;
   }
 }
 
+// utils.nms_dense's suppression test (utils.lua:430-449), fp32 operation for operation: `c` = the picked box, `o` = the other.
+//   xx1:copy(x1):clamp(x1[c], huge) ... xx2:copy(x2):clamp(0, x2[c]); w = clamp(xx2 + (-1)*xx1 + 1, 0, huge); inter = w*h;
+//   union = area + (-1)*inter + area[c]; ol = inter / union; suppressed where ol > overlap.   THTensor_(clamp) = v<lo ? lo : (v>hi ? hi : v)
+__device__ __forceinline__ bool dense_suppresses(const float4 c, const float4 o, float overlap) {
+  const float xx1 = o.x < c.x ? c.x : o.x, yy1 = o.y < c.y ? c.y : o.y;
+  const float xx2 = o.z < 0.0f ? 0.0f : (o.z > c.z ? c.z : o.z), yy2 = o.w < 0.0f ? 0.0f : (o.w > c.w ? c.w : o.w);
+  float w = xx2 - xx1; w = w + 1.0f; w = w < 0.0f ? 0.0f : w;
+  float h = yy2 - yy1; h = h + 1.0f; h = h < 0.0f ? 0.0f : h;
+  const float inter = w * h;
+  const float ao = ((o.z - o.x) + 1.0f) * ((o.w - o.y) + 1.0f), ac = ((c.z - c.x) + 1.0f) * ((c.w - c.y) + 1.0f);
+  float uni = ao - inter; uni = uni + ac;
+  return inter / uni > overlap;
+}
+
+template <bool DENSE>
 __global__ __launch_bounds__(256) void nms_mask_kernel(const float4 *__restrict__ sbox, const int *__restrict__ n_sel,
                                                        const int *__restrict__ flags, const int *__restrict__ counts,
                                                        int m_stride, int w64, float thr,
@@ -257,8 +275,12 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float4 *__restrict_
     // overlaps me", which reads the lower triangle of that word
     if ((full || (i >> 6) == w) ? (j == i) : (j <= i)) continue;
     const float4 c = cols[jj];
-    float iou = iou_plus1(a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w);  // overlap(best, other), nms.c:92
-    if (!(iou <= thr)) bits |= 1ull << jj;
+    if constexpr (DENSE) {  // the picked box is the LOWER rank of the pair (the diagonal word's lower triangle is read as "a kept lower rank overlaps me")
+      if (j > i ? dense_suppresses(a, c, thr) : dense_suppresses(c, a, thr)) bits |= 1ull << jj;
+    } else {
+      float iou = iou_plus1(a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w);  // overlap(best, other), nms.c:92
+      if (!(iou <= thr)) bits |= 1ull << jj;
+    }
   }
   mask[((size_t)cls * m_stride + i) * w64 + w] = bits;
 }
@@ -273,7 +295,7 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
   return ((unsigned long long)hi << 32) | lo;
 }
 
-// Chunked scan, with the reference's position history replayed when the class has (a few) bit-equal scores.
+// Chunked scan, with the reference's position history replayed — lazily — when the class has (a few) bit-equal scores.
 //
 // Tie-free class (flag 0): the pick order is the rank order, a chunk of 64 ranks is resolved with wave-uniform bit
 // arithmetic on its diagonal word and the kept rows are OR-ed into the per-lane `removed` words.
@@ -281,19 +303,24 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
 // Class with a few tied pairs (flag 3): nms.c picks, among bit-equal scores, the box that sits FIRST in its array
 // (nms.c:74-81), and the array is permuted by every round — the old first element takes the picked box's place
 // (nms.c:83-85), the survivors keep their order (nms.c:91-98).  Which tied box comes first therefore depends on the whole
-// history, so the history is replayed — but cheaply, and only the part that matters:
-//   * positions ("slots") only ever matter when two alive boxes tie.  A chunk in which no alive rank has an alive-tied
-//     successor (alive & tie word == 0) is resolved exactly as in the tie-free case;
-//   * the replay of a pick needs the round's head = the alive box with the smallest slot.  A round vacates the head's slot and
-//     moves boxes only to LATER slots, so the head slot strictly increases: one pointer sweeps the slots once per class.
-//     "Alive at round i" is a comparison with the box's death round, recorded when a row is folded in; the sweep tests 64
-//     slots per ballot from a register window.  Cost per pick: a ballot, two readlanes and (if the head is not the pick)
-//     two LDS writes — instead of the slot-emulating kernel's chain of dependent LDS reads;
-//   * a chunk whose first alive ranks DO tie falls back, pick by pick, to the exact rule (min slot among the alive members
-//     of the run, rows applied one at a time) until the ambiguity is gone.
-// LDS (flag 3 only): int16 pos[rank] / occ[slot] / death[rank].  Rows are full (symmetric) for flag 3: a tied box picked
-// before a lower-ranked member of its run must still suppress it.
-constexpr short kAliveForever = 0x7fff;
+// history.  Positions ("slots") only ever matter when an equal-score run has TWO OR MORE alive members at its turn, so:
+//   * everything else is resolved exactly as in the tie-free case, and all that is recorded per pick is its round
+//     (rnd[rank], klist[round]) — no per-pick position work on the scan's critical path;
+//   * when such a run comes up, the slot model is first brought up to date for all rounds since the last update
+//     (`simulate`): a round's head is the first slot whose occupant is alive at that round; a round vacates the head's slot
+//     and moves boxes only to LATER slots, so one pointer sweeps the slots once per class, 64 slots per register window.
+//     Within a window the heads of consecutive rounds are a 64-lane fixpoint
+//         taken_l = valid_l && death_l >= t0 + popcount(taken & lanes_below_l)
+//     (a lane's round = the first pending round + the heads before it), solved with a handful of ballots; the moves of the
+//     whole batch are then two LDS scatters.  The batch is cut short where a move lands inside the window ahead of the head,
+//     or where a round's pick was itself moved earlier in the batch (its slot in LDS would be stale);
+//   * "alive at round t" is a comparison with the occupant's death round, computed on demand for the 64 window occupants:
+//     a picked box dies in its own round, a suppressed one in the round of the first pick that overlaps it = the lowest
+//     kept rank in its (symmetric, flag 3) mask row — or the earliest-picked member of that rank's equal-score run;
+//   * the run's pick is its alive member with the smallest slot (nms.c:77-80's strict '>' keeps the first maximum).
+// The algorithm was validated against the reference's compiled nms.c in a Python model first (tools/models/
+// nms_lazy_replay_model.py).  LDS (flag 3 only): int16 pos[rank] / occ[slot] / rnd[rank] / klist[round] / mv[rank].
+constexpr int kForever = 0x3fffffff;
 template <int WPL>  // 64-bit `removed` words per lane: covers m <= 4096 * WPL
 __global__ __launch_bounds__(64) void nms_scan_kernel(const float4 *__restrict__ sbox, const float *__restrict__ sscore,
                                                       const int *__restrict__ sidx, const int *__restrict__ n_sel,
@@ -301,7 +328,7 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float4 *__restrict__
                                                       const unsigned long long *__restrict__ mask, float *__restrict__ keep,
                                                       int *__restrict__ keep_idx, int *__restrict__ n_keep, int m_cap,
                                                       unsigned long long *__restrict__ trace) {
-  extern __shared__ __attribute__((aligned(16))) short lds16[];  // pos[m_cap], occ[m_cap], death[m_cap]   (flag 3)
+  extern __shared__ __attribute__((aligned(16))) short lds16[];  // pos | occ | rnd | klist | mv, m_cap each   (flag 3)
   // tools/nms_trace.py (debug flavour): s_memtime stamps of class 0's chunks -> trace[c * 8 + k]
 #define NMS_STAMP(k) do { if (MPN_ABLATE(trace != nullptr) && blockIdx.x == 0 && lane == 0 && c < 64) trace[c * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
   __shared__ unsigned long long tiew[64 * WPL];
@@ -318,75 +345,118 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float4 *__restrict__
   const unsigned long long *mk = mask + (size_t)cls * m_stride * w64;
   float *kout = keep + (size_t)cls * m_stride * 5;
   int *kidx = keep_idx ? keep_idx + (size_t)cls * m_stride : nullptr;
-  short *pos = lds16, *occ = lds16 + m_cap, *death = lds16 + 2 * m_cap;
-  unsigned long long removed[WPL], tw[WPL];
+  short *pos = lds16, *occ = lds16 + m_cap, *rnd = lds16 + 2 * m_cap, *klist = lds16 + 3 * m_cap, *mv = lds16 + 4 * m_cap;
+  unsigned long long removed[WPL], keptw[WPL];
 #pragma unroll
-  for (int h = 0; h < WPL; ++h) { removed[h] = 0; tw[h] = 0; }
+  for (int h = 0; h < WPL; ++h) { removed[h] = 0; keptw[h] = 0; }
   if (replay) {
     for (int r = lane; r < m; r += kWave) {
       const int x = si[r];
-      pos[r] = (short)x; occ[x] = (short)r; death[r] = kAliveForever;
+      pos[r] = (short)x; occ[x] = (short)r; rnd[r] = 0; mv[r] = 0;
     }
-    for (int r0 = 0; r0 < 64 * 64 * WPL && r0 < m; r0 += kWave) {  // bit r of the tie words: ranks r and r+1 are pickable and carry the same score
+    for (int r0 = 0; r0 < 64 * 64 * WPL; r0 += kWave) {  // bit r of the tie words: ranks r and r+1 are pickable and carry the same score
       const int r = r0 + lane;
       const bool tie = (r + 1 < n) && (sc[r] == sc[r + 1]);
       const unsigned long long bal = __ballot(tie);
       if (lane == 0) tiew[r0 >> 6] = bal;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < WPL; ++h) tw[h] = (lane + 64 * h) * 64 < m ? tiew[lane + 64 * h] : 0ull;
-  }
-  // replay state: slots < hp are vacated or hold dead boxes; the register window caches occ / death of slots [W0, W0 + 64)
-  int hp = 0, W0 = -64;
-  int wf = -1, wd = 0;
-  auto window_load = [&](int w0) {
-    W0 = w0;
-    const int sl = w0 + lane;
-    wf = sl < m ? (int)occ[sl] : -1;
-    wd = wf >= 0 ? (int)death[wf] : 0;
-  };
-  // one round of nms.c:74-85 on the slot model: `rank` was picked in round i (1-based)
-  // `sb` = the pick's slot.  Returns ((f - chunk_base) << 16 | sb) when the moved box f is a rank of the current chunk (whose
-  // slots the caller caches in registers), else -1.
-  auto head_step = [&](int i, int rank, int sb, int chunk_base) -> int {
-    int hs, f, fd;
-    for (;;) {
-      if (hp - W0 >= 64 || hp < W0) window_load(hp & ~63);
-      const unsigned long long cand = __ballot(wf >= 0 && wd >= i) & (~0ull << (hp - W0));
-      if (cand) {
-        const int l = __builtin_ctzll(cand);
-        hs = W0 + l;
-        f = __builtin_amdgcn_readlane(wf, l);
-        fd = __builtin_amdgcn_readlane(wd, l);
+      if (r0 + 64 >= m) {  // the remaining words are zero
+        for (int w = (r0 >> 6) + 1 + lane; w < 64 * WPL; w += kWave) tiew[w] = 0ull;
         break;
       }
-      hp = W0 + 64;
     }
-    hp = hs + 1;
-    if (f == rank) return -1;
-    // boxes[0] <-> boxes[best]: the old head takes the pick's slot
-    if (lane == 0) { occ[sb] = (short)f; pos[f] = (short)sb; }
-    if (sb - W0 < 64 && lane == sb - W0) { wf = f; wd = fd; }
-    return (chunk_base >= 0 && f >= chunk_base && f < chunk_base + 64) ? (((f - chunk_base) << 16) | sb) : -1;
-  };
+    __syncthreads();
+  }
   auto word_of = [&](int w) -> unsigned long long {  // removed word w (wave-uniform index)
     unsigned long long v = readlane64(removed[0], w & 63);
     if constexpr (WPL > 1) { if (w >= 64) v = readlane64(removed[1], w & 63); }
     return v;
   };
-  auto tie_word = [&](int w) -> unsigned long long {
-    unsigned long long v = readlane64(tw[0], w & 63);
-    if constexpr (WPL > 1) { if (w >= 64) v = readlane64(tw[1], w & 63); }
+  auto kept_word = [&](int w) -> unsigned long long {  // kept word w (wave-uniform index)
+    unsigned long long v = readlane64(keptw[0], w & 63);
+    if constexpr (WPL > 1) { if (w >= 64) v = readlane64(keptw[1], w & 63); }
     return v;
   };
-  // fold one row into `removed`, recording the death round of every box it newly removes (replay only)
-  auto record_deaths = [&](unsigned long long newly, int word, int round) {
-    while (newly) {
-      const int bit = __builtin_ctzll(newly);
-      newly &= newly - 1;
-      death[word * 64 + bit] = (short)round;
+  auto removed_bit = [&](int r) -> bool {  // per-lane rank; every lane of the wave must call it
+    const int w = r >> 6;
+    unsigned long long rw = shfl64(removed[0], w & 63);
+    if constexpr (WPL > 1) { const unsigned long long r1 = shfl64(removed[1], w & 63); if (w >= 64) rw = r1; }
+    return (rw >> (r & 63)) & 1ull;
+  };
+  // ---- the slot model, brought up to date on demand (flag 3) ----
+  int sim_done = 0, hp = 0, bid = 0;  // rounds replayed so far; slots < hp are vacated or hold dead boxes; batch stamp
+  int wf = -1, wd = -1;               // register window: occupant (rank) and its death round of slot W0 + lane
+  const int nw_kept = (n + 63) >> 6;  // picks are ranks < n
+  // death round of rank f (per lane; f < 0 -> -1): its own round if it was picked; kForever while it is alive; else the round of
+  // the first pick that overlaps it.  Every lane must call it (cross-lane reads inside).
+  auto death_of = [&](int f) -> int {
+    const int fs = f < 0 ? 0 : f;
+    const int rk = (int)rnd[fs];
+    const bool rem = removed_bit(fs);
+    int d = f < 0 ? -1 : (rk > 0 ? rk : (rem ? 0 : kForever));
+    bool need = d == 0;
+    for (int w0 = 0; w0 < nw_kept; w0 += 8) {
+      if (!__ballot(need)) break;
+      unsigned long long x[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) x[q] = (need && w0 + q < nw_kept) ? mk[(size_t)fs * w64 + w0 + q] : 0ull;  // independent loads, all in flight
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int w = w0 + q;
+        if (w < nw_kept) {  // wave-uniform
+          const unsigned long long hit = x[q] & kept_word(w);
+          if (need && hit) {
+            int bb = w * 64 + __builtin_ctzll(hit);
+            int best = (int)rnd[bb];
+            while ((tiew[bb >> 6] >> (bb & 63)) & 1ull) {  // the rest of that rank's equal-score run (its picks may be out of rank order)
+              ++bb;
+              const unsigned long long rwd = (bb >> 6) == w ? x[q] : mk[(size_t)fs * w64 + (bb >> 6)];
+              const int rb = (int)rnd[bb];
+              if (((rwd >> (bb & 63)) & 1ull) && rb > 0 && rb < best) best = rb;
+            }
+            d = best;
+            need = false;
+          }
+        }
+      }
     }
+    return d;
+  };
+  auto simulate = [&](int t1) {  // replay rounds sim_done + 1 .. t1 (all picked: klist / rnd hold them)
+    for (int guard = 0; sim_done < t1 && guard < 2 * m_cap + 1024; ++guard) {
+      __syncthreads();  // LDS writes of the previous batch / of the picks since the last call
+      const int W0 = hp & ~63, p = hp - W0;
+      { const int sl = W0 + lane; wf = sl < m ? (int)occ[sl] : -1; wd = death_of(wf); }
+      const int t0 = sim_done + 1;
+      const unsigned long long below = (1ull << lane) - 1ull;
+      const bool cand = lane >= p && wf >= 0;
+      unsigned long long taken = 0ull;
+      for (int it = 0; it < 66; ++it) {  // lane l's answer depends on lower lanes only: settles in <= 64 rounds, typically a few
+        const int rd = t0 + __popcll(taken & below);
+        const unsigned long long nt = __ballot(cand && wd >= rd && rd <= t1);
+        if (nt == taken) break;
+        taken = nt;
+      }
+      if (!taken) { hp = W0 + 64; if (hp >= m) break; continue; }  // window exhausted
+      const bool mine = (taken >> lane) & 1ull;
+      const int t = t0 + __popcll(taken & below);
+      const int pick = mine ? (int)klist[t - 1] : 0;
+      const bool move = mine && wf != pick;  // boxes[0] <-> boxes[best] (nms.c:83-85); a no-op when the head IS the pick
+      const int sb = mine ? (int)pos[pick] : 0;
+      ++bid;
+      if (move) mv[wf] = (short)bid;
+      __syncthreads();
+      const bool h1 = mine && mv[pick] == (short)bid;  // this round's pick was moved earlier in the batch: `sb` is stale
+      const unsigned long long h1m = __ballot(h1), h2m = __ballot(move && sb < W0 + 64);  // h2: the move lands inside the window
+      int cut = 64;  // commit the taken lanes below `cut`
+      if (h1m) cut = __builtin_ctzll(h1m);
+      if (h2m) { const int c2 = __builtin_ctzll(h2m) + 1; if (c2 < cut) cut = c2; }
+      unsigned long long cm = cut >= 64 ? taken : (taken & ((1ull << cut) - 1ull));
+      if (!cm) cm = taken & (~taken + 1ull);  // (cannot happen: the lowest taken lane has no earlier mover) — never stall
+      if (((cm >> lane) & 1ull) && move) { occ[sb] = (short)wf; pos[wf] = (short)sb; }
+      sim_done += __popcll(cm);
+      hp = W0 + (64 - __builtin_clzll(cm));  // one past the highest committed lane
+    }
+    __syncthreads();
   };
   int kept = 0;
   const int nchunks = (n + 63) >> 6;
@@ -399,67 +469,73 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float4 *__restrict__
     const int nv = min(64, n - base);
     const unsigned long long valid = nv == 64 ? ~0ull : ((1ull << nv) - 1ull);
     // A chunk is resolved in passes: alive ranks below the first alive rank that carries a tie bit go through the tie-free
-    // rule (bit arithmetic on the diagonal word, rows folded in a batch, heads replayed from registers); a first alive rank
-    // WITH a tie bit is resolved by the exact pick-by-pick rule; repeat until the chunk is done.
-    for (;;) {
+    // rule (bit arithmetic on the diagonal word, rows folded in a batch); a first alive rank WITH a tie bit is one pick by
+    // the exact rule; repeat until the chunk is done.
+    for (int pass = 0; pass < 130; ++pass) {
       const unsigned long long rem_c = word_of(c);
       unsigned long long alive_all = ~rem_c & valid;
       if (!alive_all) break;
-      const unsigned long long tiesel = replay ? (alive_all & tie_word(c)) : 0ull;
+      unsigned long long tcw = 0ull;
+      if (replay) tcw = tiew[c];
+      const unsigned long long tiesel = alive_all & tcw;
       const int first = __builtin_ctzll(alive_all);
       if (tiesel && __builtin_ctzll(tiesel) == first) {
-        // ---- exact rule for one pick: among the alive members of r0's equal-score run, the one sitting first in the array
+        // ---- one pick by the exact rule: among the alive members of r0's equal-score run, the one sitting first in the array
         const int r0 = base + first;
         int e = r0;  // last rank of the run = the first rank >= r0 whose tie bit is clear
         for (;;) {
-          const unsigned long long ones = tie_word(e >> 6) >> (e & 63);
+          const unsigned long long ones = tiew[e >> 6] >> (e & 63);
           const int span = 64 - (e & 63);
           const int cnt = (~ones) ? __builtin_ctzll(~ones) : 64;
           if (cnt < span) { e += cnt; break; }
           e += span;
           if (e >= n) { e = n - 1; break; }
         }
-        int bp = 0x7fffffff, br = -1;
+        // alive members: how many, and the lowest rank
+        int n_alive = 0, low = 0x7fffffff;
         for (int rr = r0; rr <= e; rr += kWave) {
           const int r = rr + lane;
-          bool ok = r <= e;
-          const int w = (ok ? r : r0) >> 6;
-          unsigned long long rw = shfl64(removed[0], w & 63);
-          if constexpr (WPL > 1) { const unsigned long long r1 = shfl64(removed[1], w & 63); if (w >= 64) rw = r1; }
-          ok = ok && !((rw >> (r & 63)) & 1ull);
-          const int p = ok ? (int)pos[r] : 0x7fffffff;
-          if (p < bp) { bp = p; br = r; }
+          const bool in = r <= e;
+          const bool ok = !removed_bit(in ? r : r0) && in;
+          n_alive += __popcll(__ballot(ok));
+          if (ok && r < low) low = r;
         }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-          const int op = __shfl_xor(bp, off), orr = __shfl_xor(br, off);
-          if (op < bp) { bp = op; br = orr; }
+        for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(low, off); if (o < low) low = o; }
+        int pick = __builtin_amdgcn_readfirstlane(low);
+        if (n_alive >= 2) {  // only now do positions matter: bring the slot model up to date, then take the smallest slot
+          simulate(kept);
+          int bp = 0x7fffffff, br = -1;
+          for (int rr = r0; rr <= e; rr += kWave) {
+            const int r = rr + lane;
+            const bool in = r <= e;
+            const bool ok = !removed_bit(in ? r : r0) && in;
+            const int pp = ok ? (int)pos[r] : 0x7fffffff;
+            if (pp < bp) { bp = pp; br = r; }
+          }
+#pragma unroll
+          for (int off = 32; off >= 1; off >>= 1) {
+            const int op = __shfl_xor(bp, off), orr = __shfl_xor(br, off);
+            if (op < bp) { bp = op; br = orr; }
+          }
+          pick = __builtin_amdgcn_readfirstlane(br);
         }
-        const int pick = __builtin_amdgcn_readfirstlane(br);
-        const int round = kept + 1;
         if (lane == 0) {
           const float4 bx = b[pick];
           float *q = kout + (size_t)kept * 5;
           q[0] = bx.x; q[1] = bx.y; q[2] = bx.z; q[3] = bx.w; q[4] = sc[pick];
           if (kidx) kidx[kept] = si[pick];
-          death[pick] = (short)round;
+          klist[kept] = (short)pick;
+          rnd[pick] = (short)(kept + 1);
         }
 #pragma unroll
         for (int h = 0; h < WPL; ++h) {
           const int w = lane + 64 * h;
           if (w < w64 && w * 64 < m) {
-            const unsigned long long row = mk[(size_t)pick * w64 + w];
-            unsigned long long newly = row & ~removed[h];
-            if (w == (pick >> 6)) newly &= ~(1ull << (pick & 63));
-            record_deaths(newly, w, round);
-            removed[h] |= row;
-            if (w == (pick >> 6)) removed[h] |= 1ull << (pick & 63);
+            removed[h] |= mk[(size_t)pick * w64 + w];
+            if (w == (pick >> 6)) { removed[h] |= 1ull << (pick & 63); keptw[h] |= 1ull << (pick & 63); }
           }
         }
-        __syncthreads();
-        window_load(hp & ~63);  // deaths changed: refresh the cached window
-        head_step(round, pick, __builtin_amdgcn_readfirstlane((int)pos[pick]), -1);
-        __syncthreads();
         ++kept;
         continue;
       }
@@ -495,19 +571,6 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float4 *__restrict__
         }
         diag_acc = __ballot((diag & keptmask) != 0ull);  // every rank of the chunk overlapped by a kept one
       }
-      if (replay) {
-        // death rounds of this chunk's ranks, all lanes at once: a picked rank dies in its own round; a suppressed one in the round of
-        // the FIRST kept rank that overlaps it — the rows are symmetric (flag 3), so that is the lowest set bit of
-        // (own row & kept ranks below it)
-        const bool was_alive = (alive_all >> lane) & 1ull;
-        const unsigned long long below = (1ull << lane) - 1ull;
-        const bool picked = (keptmask >> lane) & 1ull;
-        const unsigned long long killers = diag & keptmask & below;
-        if (was_alive && (picked || killers)) {
-          const int kr = picked ? lane : __builtin_ctzll(killers);
-          death[base + lane] = (short)(kept + __popcll(keptmask & ((1ull << kr) - 1ull)) + 1);
-        }
-      }
       // emit kept boxes in rank order
       NMS_STAMP(2);
       const bool mine = (keptmask >> lane) & 1ull;
@@ -517,86 +580,30 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float4 *__restrict__
         float *q = kout + (size_t)o * 5;
         q[0] = bx.x; q[1] = bx.y; q[2] = bx.z; q[3] = bx.w; q[4] = sc[base + lane];
         if (kidx) kidx[o] = si[base + lane];
+        if (replay) { klist[o] = (short)(base + lane); rnd[base + lane] = (short)(o + 1); }  // all the slot model will need of these rounds
       }
       // fold the kept rows into `removed`: words after this chunk, and the chunk's own word (resolved range + in-chunk kills)
       NMS_STAMP(3);
-      if (replay) {
-        unsigned long long run = removed[0];
-        int rnd = kept;
-#pragma unroll
-        for (int r = 0; r < 64; ++r) {
-          if ((keptmask >> r) & 1ull) {  // wave-uniform
-            ++rnd;
-            record_deaths(rows[r] & ~run, lane, rnd);
-            run |= rows[r];
-          }
-        }
-        removed[0] = run;
-      } else {
+      {
         unsigned long long acc = 0ull;
 #pragma unroll
         for (int r = 0; r < 64; ++r) acc |= ((keptmask >> r) & 1ull) ? rows[r] : 0ull;
         removed[0] |= acc;
       }
-      if (lane == c) removed[0] |= (valid & lim_mask) | (diag_acc & valid);
+      if (lane == c) { removed[0] |= (valid & lim_mask) | (diag_acc & valid); keptw[0] |= keptmask; }
       if constexpr (WPL > 1) {  // second word per lane (m > 4096): non-speculative, batched
         const int wsec = lane + 64;
         if (wsec < w64 && wsec > c) {
           unsigned long long km = keptmask;
-          int rnd = kept;
           while (km) {
             const int r = __builtin_ctzll(km);
             km &= km - 1;
-            ++rnd;
-            const unsigned long long row = mk[(size_t)(base + r) * w64 + wsec];
-            if (replay) record_deaths(row & ~removed[1], wsec, rnd);
-            removed[1] |= row;
+            removed[1] |= mk[(size_t)(base + r) * w64 + wsec];
           }
         }
-        if (wsec == c) removed[1] |= (valid & lim_mask) | (diag_acc & valid);
+        if (wsec == c) { removed[1] |= (valid & lim_mask) | (diag_acc & valid); keptw[1] |= keptmask; }
       }
       NMS_STAMP(4);
-      if (replay) {
-        __syncthreads();
-        window_load(hp & ~63);
-        int posr = base + lane < m ? (int)pos[base + lane] : 0;  // slots of this chunk's ranks, kept current in registers
-        // Heads of this chunk's rounds.  Eligibility masks (slot holds a box alive at the round) for 8 rounds at a time are 8
-        // independent ballots; the sweep itself is SALU; the moved box and the pick's slot are read with readlane only to feed LDS
-        // writes and a rare-path test (a move INTO the register window, or the window running out).
-        unsigned long long km = keptmask;
-        int rnd = kept;
-        while (km) {
-          unsigned long long elig[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) elig[q] = __ballot(wf >= 0 && wd >= rnd + 1 + q);
-          bool redo = false;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            if (km && !redo) {
-              const int sh = hp - W0;
-              const unsigned long long cand = sh >= 64 ? 0ull : (elig[q] & (~0ull << sh));
-              if (!cand) { redo = true; hp = W0 + 64; window_load(hp & ~63); }   // window exhausted: reload and recompute the masks
-              else {
-                const int r = __builtin_ctzll(km);
-                km &= km - 1;
-                ++rnd;
-                const int l = __builtin_ctzll(cand);
-                const int f = __builtin_amdgcn_readlane(wf, l), fd = __builtin_amdgcn_readlane(wd, l);
-                const int sb = __builtin_amdgcn_readlane(posr, r);
-                hp = W0 + l + 1;
-                // boxes[0] <-> boxes[best] (nms.c:83-85): the old head takes the pick's slot (a no-op when the head IS the pick)
-                if (lane == 0) { occ[sb] = (short)f; pos[f] = (short)sb; }
-                if (lane == f - base) posr = sb;
-                if (sb - W0 < 64) {  // rare: the move lands inside the register window -> later rounds' masks change
-                  if (lane == sb - W0) { wf = f; wd = fd; }
-                  redo = true;
-                }
-              }
-            }
-          }
-        }
-        __syncthreads();
-      }
       NMS_STAMP(5);
       kept += __popcll(keptmask);
       if (limit == 64) break;
@@ -899,7 +906,7 @@ extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n
     hipLaunchKernelGGL(nms_sort_kernel, dim3(n_cls), dim3(sort_threads), (size_t)n_pad * 8, st, d_scored, d_counts, m_stride, sbox,
                        sscore, sidx, n_sel, flags, g_nms_force_exact);
     MPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(w64, cdiv(m_stride, 256), n_cls), dim3(256), 0, st, sbox, n_sel, flags, d_counts,
+    hipLaunchKernelGGL(nms_mask_kernel<false>, dim3(w64, cdiv(m_stride, 256), n_cls), dim3(256), 0, st, sbox, n_sel, flags, d_counts,
                        m_stride, w64, thr, mask);
     MPN_CHECK_LAUNCH();
     {  // tie classes (exact slot emulation on the bitmask); both instantiations exit at once when not needed
@@ -925,9 +932,9 @@ extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n
     }
     {
       const int scap = (m_stride + 7) & ~7;
-      const size_t slds = (size_t)3 * scap * sizeof(short);
-      int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(nms_scan_kernel<1>), 3 * 4096 * 2);
-      if (rc_attr == MPN_OK) rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(nms_scan_kernel<2>), 3 * 8192 * 2);
+      const size_t slds = (size_t)5 * scap * sizeof(short);
+      int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(nms_scan_kernel<1>), 5 * 4096 * 2);
+      if (rc_attr == MPN_OK) rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(nms_scan_kernel<2>), 5 * 8192 * 2);
       if (rc_attr) return rc_attr;
       if (w64 <= 64)
         hipLaunchKernelGGL(nms_scan_kernel<1>, dim3(n_cls), dim3(kWave), slds, st, sbox, sscore, sidx, n_sel, flags, d_counts, m_stride, w64, mask,
@@ -943,6 +950,62 @@ extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n
   { int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(nms_wave_kernel), MPN_NMS_MAX_BOXES * 6 * 4); if (rc_attr) return rc_attr; }
   hipLaunchKernelGGL(nms_wave_kernel, dim3(n_cls), dim3(kWave), lds, st, d_scored, d_counts, m_stride,
                      thr, d_keep, d_keep_idx, d_n_keep, m_cap, flags, (float *)nullptr);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+__global__ void picks_to_one_based_kernel(int *__restrict__ pick, const int *__restrict__ n_pick, int m) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < min(*n_pick, m)) pick[i] += 1;
+}
+
+// utils.nms_dense (utils.lua:402-462; demo.lua:85): "another version of nms that returns indexes instead of new boxes" — sort by
+// score (descending), walk the sorted list, a picked box suppresses every box whose area-based IoU with it exceeds `overlap`.
+// The pick order is the SORT's (no swap history as in nms.c), so the sort / mask / chunked-scan kernels are reused with the dense
+// suppression rule.  torch.sort is TH's quicksort — not stable — and TH is absent from the reference tree: the order among
+// bit-equal scores is PARITY UNPINNED and defined here as ascending index.  d_pick [m] receives the 1-based indices
+// (the LongTensor the Lua function returns), *d_n_pick their number.
+extern "C" int mpn_nms_dense(const float *d_boxes, int m, float overlap, int *d_pick, int *d_n_pick, void *stream) {
+  MPN_CHECK_ARG(m >= 0 && d_n_pick != nullptr);
+  hipStream_t st = as_stream(stream);
+  if (m == 0) { MPN_CHECK_HIP(hipMemsetAsync(d_n_pick, 0, sizeof(int), st)); return MPN_OK; }
+  MPN_CHECK_ARG(d_boxes != nullptr && d_pick != nullptr);
+  if (m > kSortMax) { set_error("mpn_nms_dense: %d boxes exceed the %d this entry sorts in LDS", m, kSortMax); return MPN_EINVAL; }
+  const int w64 = (m + 63) / 64;
+  const size_t n_rows = (size_t)m;
+  const size_t need = n_rows * (sizeof(float4) + sizeof(float) + sizeof(int) + 5 * sizeof(float)) + n_rows * w64 * sizeof(unsigned long long) +
+                      2 * sizeof(int) + 256 + (size_t)64 * w64 * sizeof(unsigned long long);
+  void *ws = nullptr;
+  { int rc_ws = scratch_get(SCR_NMS, need, st, &ws); if (rc_ws) return rc_ws; }
+  char *scratch = static_cast<char *>(ws);
+  unsigned long long *mask = reinterpret_cast<unsigned long long *>(scratch);
+  float4 *sbox = reinterpret_cast<float4 *>(scratch + (((n_rows + 64) * w64 + 1) & ~(size_t)1) * sizeof(unsigned long long));
+  float *sscore = reinterpret_cast<float *>(sbox + n_rows);
+  int *sidx = reinterpret_cast<int *>(sscore + n_rows);
+  float *keep = reinterpret_cast<float *>(sidx + n_rows);
+  int *n_sel = reinterpret_cast<int *>(keep + 5 * n_rows);
+  int *flags = n_sel + 1;
+  { int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(nms_sort_kernel), kSortMax * 8); if (rc_attr) return rc_attr; }
+  int n_pad = 64;
+  while (n_pad < m) n_pad <<= 1;
+  const int sort_threads = n_pad / 2 < 64 ? 64 : (n_pad / 2 > 1024 ? 1024 : n_pad / 2);
+  hipLaunchKernelGGL(nms_sort_kernel, dim3(1), dim3(sort_threads), (size_t)n_pad * 8, st, d_boxes, (const int *)nullptr, m, sbox, sscore, sidx, n_sel, flags, 4);
+  MPN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(nms_mask_kernel<true>, dim3(w64, cdiv(m, 256), 1), dim3(256), 0, st, sbox, n_sel, flags, (const int *)nullptr, m, w64, overlap, mask);
+  MPN_CHECK_LAUNCH();
+  const int scap = (m + 7) & ~7;
+  const size_t slds = (size_t)5 * scap * sizeof(short);
+  int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(nms_scan_kernel<1>), 5 * 4096 * 2);
+  if (rc_attr == MPN_OK) rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(nms_scan_kernel<2>), 5 * 8192 * 2);
+  if (rc_attr) return rc_attr;
+  if (w64 <= 64)
+    hipLaunchKernelGGL(nms_scan_kernel<1>, dim3(1), dim3(kWave), slds, st, sbox, sscore, sidx, n_sel, flags, (const int *)nullptr, m, w64, mask, keep, d_pick,
+                       d_n_pick, scap, (unsigned long long *)nullptr);
+  else
+    hipLaunchKernelGGL(nms_scan_kernel<2>, dim3(1), dim3(kWave), slds, st, sbox, sscore, sidx, n_sel, flags, (const int *)nullptr, m, w64, mask, keep, d_pick,
+                       d_n_pick, scap, (unsigned long long *)nullptr);
+  MPN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(picks_to_one_based_kernel, dim3(cdiv(m, 256)), dim3(256), 0, st, d_pick, d_n_pick, m);
   MPN_CHECK_LAUNCH();
   return MPN_OK;
 }

@@ -1,6 +1,7 @@
 """Host-side mirror of the evaluation helpers of utils.lua (file:line relative to /root/reference).
 
   utils.nms / utils.bbox_vote   utils.lua:29-39  (FFI to nms.c -> here: wavefront kernels)
+  utils.nms_dense               utils.lua:402-462 (index-returning NMS of demo.lua)
   utils.boxoverlap              utils.lua:104-128 (same formula as nms.c:14-41)
   utils.convertFrom             utils.lua:212-248
   utils.keep_top_k              utils.lua:75-96
@@ -36,6 +37,19 @@ def nms_with_index(boxes, overlap):
         check(_lib.load().mpn_nms(_f(boxes), M, C.c_float(overlap), _f(keep), _i(idx), _i(n), _stream()), "nms")
     k = int(n.item())
     return keep[:k], idx[:k]
+
+
+def nms_dense(boxes, overlap):
+    """utils.nms_dense(boxes [M,5], overlap) (utils.lua:402-462) -> LongTensor of picked row indices, 1-BASED like the Lua
+    function's (subtract 1 to index a torch tensor), in pick order."""
+    M = boxes.size(0) if boxes.numel() else 0
+    if M == 0:
+        return torch.empty(0, dtype=torch.int64, device=boxes.device)
+    assert boxes.dim() == 2 and boxes.size(1) == 5   # utils.lua:411
+    pick = torch.empty(M, dtype=torch.int32, device=boxes.device)
+    n = torch.zeros(1, dtype=torch.int32, device=boxes.device)
+    check(_lib.load().mpn_nms_dense(_f(boxes, "boxes"), M, C.c_float(overlap), _i(pick), _i(n), _stream()), "nms_dense")
+    return pick[: int(n.item())].to(torch.int64)
 
 
 def nms_batched(scored, counts, overlap):

@@ -139,6 +139,40 @@ def nms(scored_boxes, thr, return_index=False):
     return (keep[:k].copy(), idx[:k].copy()) if return_index else keep[:k].copy()
 
 
+def nms_dense(boxes, overlap):
+    """utils.nms_dense (utils.lua:402-462): 'another version of nms that returns indexes instead of new boxes'.  Restated
+    tensor op for tensor op in float32 (boxes is a FloatTensor in demo.lua:85): sort by score descending; area = (x2-x1+1)*(y2-y1+1);
+    for every unsuppressed c in sorted order: pick I[c]; xx1 = clamp(x1, x1[c], inf) ...; w = clamp(xx2 + (-1)*xx1 + 1, 0, inf);
+    inter = w*h; union = area + (-1)*inter + area[c]; suppressed += (inter / union > overlap).  Returns the picks 1-based, as the Lua.
+    torch.sort is TH's quicksort (not stable) and TH is absent: the order among bit-equal scores is PARITY UNPINNED; restated as
+    ascending index (a stable sort)."""
+    b = _f32(boxes).reshape(-1, 5)
+    n = b.shape[0]
+    if n == 0:
+        return np.zeros(0, np.int64)
+    I = np.argsort(-b[:, 4], kind="stable")
+    bs = b[I]
+    x1, y1, x2, y2 = bs[:, 0], bs[:, 1], bs[:, 2], bs[:, 3]
+    one, zero = np.float32(1), np.float32(0)
+    area = ((x2 - x1) + one) * ((y2 - y1) + one)
+    clamp = lambda v, lo, hi: np.where(v < lo, lo, np.where(v > hi, hi, v)).astype(np.float32)   # THTensor_(clamp)
+    suppressed = np.zeros(n, bool)
+    pick = []
+    with np.errstate(all="ignore"):
+        for c in range(n):
+            if suppressed[c]:
+                continue
+            pick.append(int(I[c]) + 1)
+            xx1, yy1 = clamp(x1, x1[c], np.float32(np.inf)), clamp(y1, y1[c], np.float32(np.inf))
+            xx2, yy2 = clamp(x2, zero, x2[c]), clamp(y2, zero, y2[c])
+            w = clamp((xx2 + np.float32(-1) * xx1) + one, zero, np.float32(np.inf))
+            h = clamp((yy2 + np.float32(-1) * yy1) + one, zero, np.float32(np.inf))
+            inter = w * h
+            union = (area + np.float32(-1) * inter) + area[c]
+            suppressed |= (inter / union) > np.float32(overlap)
+    return np.asarray(pick, np.int64)
+
+
 def bbox_vote(nms_boxes, scored_boxes, thr):
     nb, sb = _f32(nms_boxes).reshape(-1, 5), _f32(scored_boxes).reshape(-1, 5)
     res = np.zeros_like(nb)

@@ -214,3 +214,41 @@ def test_nms_wider_than_the_lds_paths(O, dev, regime):
     keep, idx = utils.nms_with_index(_t(sb, dev), 0.3)
     assert np.array_equal(keep.cpu().numpy(), ref)
     assert np.array_equal(idx.cpu().numpy(), ridx)
+
+
+@pytest.mark.parametrize("regime", ["distinct", "ties", "saturated", "allequal"])
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 300, 1000, 2500, 5000])
+def test_nms_dense_bit_exact(O, dev, regime, n):
+    """utils.nms_dense (utils.lua:402-462) on the device == the oracle's op-for-op restatement: the same 1-based picks in the
+    same order, in every score regime (the order among bit-equal scores is the sort's: ascending index)."""
+    from multipathnet_amd import utils
+    rng = np.random.default_rng(case_seed(regime, n, salt=5))
+    sb = random_scored_boxes(rng, n, regime, span=300.0 if n <= 65 else 1000.0)
+    for thr in (0.3, 0.5):
+        ref = O.nms_dense(sb, thr)
+        got = utils.nms_dense(_t(sb, dev), thr)
+        assert got.dtype == torch.int64 and np.array_equal(got.cpu().numpy(), ref)
+    assert utils.nms_dense(torch.zeros((0, 5), device=dev), 0.3).numel() == 0
+
+
+@pytest.mark.parametrize("n,pairs,dups", [(300, 1, 1), (1000, 0, 1), (1000, 4, 2), (1000, 30, 0), (2500, 12, 3), (5000, 5, 5), (130, 20, 4)])
+def test_nms_few_ties_and_duplicated_boxes_bit_exact(O, dev, n, pairs, dups, nms_path):
+    """The bench image's regime: an otherwise tie-free class with a handful of bit-equal score pairs — some of them DUPLICATED
+    proposals (identical box and score, so whichever the reference picks suppresses its twin and only the reported index
+    differs).  The default dispatch sends these classes to the chunked scan with the lazy position replay (nms.hip, flag 3)."""
+    from multipathnet_amd import utils
+    rng = np.random.default_rng(case_seed("distinct", n, salt=100 + pairs * 7 + dups))
+    sb = random_scored_boxes(rng, n, "distinct", span=400.0 if n <= 300 else 1000.0)
+    for _ in range(pairs):
+        a, b = rng.choice(n, 2, replace=False)
+        sb[b, 4] = sb[a, 4]
+    for _ in range(dups):
+        a, b = rng.choice(n, 2, replace=False)
+        sb[b] = sb[a]
+    for thr in (0.3, 0.5):
+        ref, ridx = O.nms(sb, thr, return_index=True)
+        if O.have_ref():
+            assert np.array_equal(O.ref_nms(sb, thr), ref)
+        keep, idx = utils.nms_with_index(_t(sb, dev), thr)
+        assert keep.shape[0] == ref.shape[0] and np.array_equal(keep.cpu().numpy(), ref)
+        assert np.array_equal(idx.cpu().numpy(), ridx)

@@ -85,3 +85,31 @@ def test_decode_roundtrip_property(O):
     d = np.stack([(xt - xc) / w, (yt - yc) / h, np.log(wt / w), np.log(ht / h)], 1).astype(np.float32)
     out = O.bbox_decode(bbox, d)
     assert np.abs(out - tbox).max() < 1e-3
+
+
+def test_nms_dense_restatement(O):
+    """utils.nms_dense (utils.lua:402-462): hand-worked cases of the index-returning NMS demo.lua uses."""
+    assert O.nms_dense(np.zeros((0, 5), np.float32), 0.3).shape == (0,)                       # utils.lua:405-407
+    # the higher-scored of two heavily overlapping boxes is picked first and suppresses the other; a far box survives; 1-based picks
+    hb = np.array([[10, 10, 50, 50, 0.5], [12, 12, 52, 52, 0.9], [100, 100, 120, 120, 0.1]], np.float32)
+    assert O.nms_dense(hb, 0.3).tolist() == [2, 3]
+    assert O.nms_dense(hb, 0.95).tolist() == [2, 1, 3]                                       # threshold above their IoU: both stay, score order
+    # strict '>' (utils.lua:449 ol:gt(overlap)): IoU == overlap exactly does not suppress.  Two 2x1 boxes sharing one pixel column:
+    # inter = 1*... a: x 0..1, b: x 1..2, y 0..0 -> w = 1, h = 1, inter = 1, areas 2 and 2, union 3 -> IoU = 1/3
+    eq = np.array([[0, 0, 1, 0, 0.9], [1, 0, 2, 0, 0.8]], np.float32)
+    third = np.float32(1) / np.float32(3)
+    assert O.nms_dense(eq, float(third)).tolist() == [1, 2] and O.nms_dense(eq, float(np.nextafter(third, np.float32(0)))).tolist() == [1]
+    # ties: restated as ascending index (TH's quicksort order among equal scores is unpinned)
+    t = np.array([[0, 0, 10, 10, 0.5], [100, 100, 110, 110, 0.5], [200, 200, 210, 210, 0.5]], np.float32)
+    assert O.nms_dense(t, 0.3).tolist() == [1, 2, 3]
+
+
+@pytest.mark.parametrize("n", [1, 7, 64, 300, 1000])
+def test_nms_dense_agrees_with_nms_c_on_distinct_scores(O, n):
+    """With distinct scores both NMS forms walk the boxes in descending score order and differ only in how the IoU is rounded
+    (area-based vs nms.c's); on these inputs no IoU sits within an ulp of the threshold, so the picks index exactly the rows
+    nms.c keeps."""
+    sb = random_scored_boxes(np.random.default_rng(case_seed("distinct", n, salt=3)), n, "distinct", span=300.0 if n <= 64 else 1000.0)
+    picks = O.nms_dense(sb, 0.3)
+    ref, ridx = O.nms(sb, 0.3, return_index=True)
+    assert np.array_equal(picks - 1, ridx) and np.array_equal(sb[picks - 1], ref)
