@@ -255,8 +255,9 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float4 *__restrict_
   int m = counts ? counts[cls] : m_stride;
   if (m > m_stride) m = m_stride;
   const int ncol = full ? m : n;
+  const int nrow = full ? m : n;  // full: the lazy replay (nms_scan_kernel) reads the row of ANY box, pickable or not, to date its death
   const int w = blockIdx.x, rb = blockIdx.y;
-  if (w * 64 >= ncol || rb * 256 >= n) return;
+  if (w * 64 >= ncol || rb * 256 >= nrow) return;
   if (!full && rb * 256 > w * 64 + 63) return;  // strictly lower triangle: never read by the chunked scan
   const float4 *b = sbox + (size_t)cls * m_stride;
   if (threadIdx.x < 64) {
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float4 *__restrict_
   }
   __syncthreads();
   const int i = rb * 256 + threadIdx.x;
-  if (i >= n) return;
+  if (i >= nrow) return;
   const float4 a = b[i];
   unsigned long long bits = 0;
   const int jn = min(64, ncol - w * 64);
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float4 *__restrict__
     // A chunk is resolved in passes: alive ranks below the first alive rank that carries a tie bit go through the tie-free
     // rule (bit arithmetic on the diagonal word, rows folded in a batch); a first alive rank WITH a tie bit is one pick by
     // the exact rule; repeat until the chunk is done.
-    for (int pass = 0; pass < 130; ++pass) {
+    for (int pass = 0; pass < 2 * m_cap + 130; ++pass) {  // (every pass picks a box or finishes the chunk; a run's picks may lie in LATER chunks)
       const unsigned long long rem_c = word_of(c);
       unsigned long long alive_all = ~rem_c & valid;
       if (!alive_all) break;

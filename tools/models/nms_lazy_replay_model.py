@@ -32,11 +32,18 @@ def model_nms(sb, thr, stats=None):
     rank_box = sb[order]
     sc = rank_box[:, 4]
     n = int((sc > -1e7).sum())
-    over = np.zeros((m, m), bool)                                    # symmetric mask rows (flag 3: full)
-    for i in range(m):
-        for j in range(i + 1, m):
-            o = not (iou(rank_box[i], rank_box[j]) <= thr)
-            over[i, j] = over[j, i] = o
+    # symmetric mask rows (flag 3: full), nms.c:14-41 in float32, vectorised
+    f = np.float32
+    x1 = np.maximum(rank_box[:, None, 0], rank_box[None, :, 0]); y1 = np.maximum(rank_box[:, None, 1], rank_box[None, :, 1])
+    x2 = np.minimum(rank_box[:, None, 2], rank_box[None, :, 2]); y2 = np.minimum(rank_box[:, None, 3], rank_box[None, :, 3])
+    w = (x2 - x1 + f(1)).astype(f); h = (y2 - y1 + f(1)).astype(f)
+    inter = (w * h).astype(f)
+    area = ((rank_box[:, 2] - rank_box[:, 0] + f(1)).astype(f) * (rank_box[:, 3] - rank_box[:, 1] + f(1)).astype(f)).astype(f)
+    with np.errstate(all="ignore"):
+        io = (inter / ((area[:, None] + area[None, :]).astype(f) - inter).astype(f)).astype(f)
+    io = np.where((w <= 0) | (h <= 0), f(0), io)
+    over = ~(io <= f(thr))
+    np.fill_diagonal(over, False)
     tie = np.zeros(m, bool)                                          # bit r: ranks r and r+1 pickable with equal scores
     for r in range(n - 1):
         tie[r] = sc[r] == sc[r + 1]
