@@ -461,6 +461,8 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float4 *__restrict__
   };
   int kept = 0;
   const int nchunks = (n + 63) >> 6;
+  unsigned long long tr_sim = 0ull, tr_t0 = MPN_ABLATE(trace != nullptr) ? __builtin_amdgcn_s_memtime() : 0ull;  // tools/nms_trace.py
+  int tr_calls = 0;
   // the chunk's diagonal word, one row per lane, fetched a chunk ahead (its latency would otherwise sit in front of every chunk)
   unsigned long long diag_cur = (lane < n) ? mk[(size_t)lane * w64] : 0ull;
   for (int c = 0; c < nchunks; ++c) {
@@ -505,7 +507,9 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float4 *__restrict__
         for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(low, off); if (o < low) low = o; }
         int pick = __builtin_amdgcn_readfirstlane(low);
         if (n_alive >= 2) {  // only now do positions matter: bring the slot model up to date, then take the smallest slot
+          const unsigned long long ts0 = MPN_ABLATE(trace != nullptr) ? __builtin_amdgcn_s_memtime() : 0ull;
           simulate(kept);
+          if (MPN_ABLATE(trace != nullptr)) { tr_sim += __builtin_amdgcn_s_memtime() - ts0; ++tr_calls; }
           int bp = 0x7fffffff, br = -1;
           for (int rr = r0; rr <= e; rr += kWave) {
             const int r = rr + lane;
@@ -611,6 +615,9 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float4 *__restrict__
     }
   }
   if (lane == 0) n_keep[cls] = kept;
+  if (MPN_ABLATE(trace != nullptr) && blockIdx.x == 0 && lane == 0) {  // totals of class 0: [kernel cycles, cycles inside simulate(), simulate() calls, batches]
+    trace[63 * 8 + 4] = __builtin_amdgcn_s_memtime() - tr_t0; trace[63 * 8 + 5] = tr_sim; trace[63 * 8 + 6] = (unsigned long long)tr_calls; trace[63 * 8 + 7] = (unsigned long long)bid;
+  }
 }
 
 
