@@ -406,7 +406,16 @@ def latency_mode(args, torch, dist, models, parallel, comm, rank, world, dev, sh
             net.shard_head(im_dev, boxes_dev, 0, G, out=rows_all[0])
             net.shard_nms(rows_all, N_ROIS, 0, G, out=class_all[0])
             net.shard_finish(class_all, N_ROIS, G)
-        out["projected"] = {"world": G, "rank0_compute_ms": round(timed(rank0_share), 4),
+        proj_ms = timed(rank0_share)
+        net.set_profiling(True)
+        net.get_profile(reset=True)
+        for _ in range(args.steps):
+            rank0_share()
+        torch.cuda.synchronize()
+        prof = net.get_profile(reset=True)
+        net.set_profiling(False)
+        out["projected"] = {"world": G, "rank0_compute_ms": round(proj_ms, 4),
+                            "kernel_groups_ms": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]},
                             "what": "ONE GPU running rank 0's share of a %d-rank world (trunk + %d of %d ROIs + %d of %d classes + top-100) with the "
                                     "other ranks' records precomputed: the two all-gathers (%.0f KB + %.0f KB in total) are NOT included — a "
                                     "projection, not a multi-GPU measurement" % (G, -(-N_ROIS // G), N_ROIS, -(-(N_CLASSES - 1) // G), N_CLASSES - 1,
