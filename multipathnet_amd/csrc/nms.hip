@@ -395,13 +395,13 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float4 *__restrict__
     const bool rem = removed_bit(fs);
     int d = f < 0 ? -1 : (rk > 0 ? rk : (rem ? 0 : kForever));
     bool need = d == 0;
-    for (int w0 = 0; w0 < nw_kept; w0 += 8) {
+    for (int w0 = 0; w0 < nw_kept; w0 += 16) {
       if (!__ballot(need)) break;
-      unsigned long long x[8];
+      unsigned long long x[16];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) x[q] = (need && w0 + q < nw_kept) ? mk[(size_t)fs * w64 + w0 + q] : 0ull;  // independent loads, all in flight
+      for (int q = 0; q < 16; ++q) x[q] = (need && w0 + q < nw_kept) ? mk[(size_t)fs * w64 + w0 + q] : 0ull;  // independent loads, all in flight: one round trip per 1024 ranks
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < 16; ++q) {
         const int w = w0 + q;
         if (w < nw_kept) {  // wave-uniform
           const unsigned long long hit = x[q] & kept_word(w);
@@ -423,10 +423,11 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float4 *__restrict__
     return d;
   };
   auto simulate = [&](int t1) {  // replay rounds sim_done + 1 .. t1 (all picked: klist / rnd hold them)
+    int loaded = -64;  // the window in registers (death rounds are fixed for the duration of a call: every pending round is decided)
     for (int guard = 0; sim_done < t1 && guard < 2 * m_cap + 1024; ++guard) {
       __syncthreads();  // LDS writes of the previous batch / of the picks since the last call
       const int W0 = hp & ~63, p = hp - W0;
-      { const int sl = W0 + lane; wf = sl < m ? (int)occ[sl] : -1; wd = death_of(wf); }
+      if (W0 != loaded) { const int sl = W0 + lane; wf = sl < m ? (int)occ[sl] : -1; wd = death_of(wf); loaded = W0; }
       const int t0 = sim_done + 1;
       const unsigned long long below = (1ull << lane) - 1ull;
       const bool cand = lane >= p && wf >= 0;
@@ -454,6 +455,11 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float4 *__restrict__
       unsigned long long cm = cut >= 64 ? taken : (taken & ((1ull << cut) - 1ull));
       if (!cm) cm = taken & (~taken + 1ull);  // (cannot happen: the lowest taken lane has no earlier mover) — never stall
       if (((cm >> lane) & 1ull) && move) { occ[sb] = (short)wf; pos[wf] = (short)sb; }
+      if (h2m & cm) {  // the committed move that landed inside the window: its slot now holds the moved box (same window, no reload)
+        const int lc = __builtin_ctzll(h2m & cm);
+        const int f2 = __builtin_amdgcn_readlane(wf, lc), d2 = __builtin_amdgcn_readlane(wd, lc), s2 = __builtin_amdgcn_readlane(sb, lc);
+        if (lane == s2 - W0) { wf = f2; wd = d2; }
+      }
       sim_done += __popcll(cm);
       hp = W0 + (64 - __builtin_clzll(cm));  // one past the highest committed lane
     }
