@@ -148,6 +148,40 @@ function FastRCNN:testOne(im, boxes)
    end
    return img_boxes
 end
+-- The latency mode (ModelParallelTable.lua:195-242's job for ONE image): every worker passes the SAME image and proposal table with
+-- its own communicator (mpn.comm_init_all); each runs the trunk, the ROI head on its share of the proposals, the NMS of its share of
+-- the classes, and two RCCL all-gathers of scored boxes connect the steps.  Every worker returns the same img_boxes — bit for bit what
+-- testOne returns on one GPU.
+function FastRCNN:testOneSharded(comm, im, boxes)
+   local d_im, d_boxes = im:cuda():contiguous(), boxes:cuda():contiguous()
+   check(C.mpn_frcnn_test_one_sharded(self.handle, comm, d_im:data(), im:size(2), im:size(3), d_boxes:data(), boxes:size(1), self.dets:data(),
+                                      self.top_cap, ffi.cast('int *', self.n_dets:data()), stream()), 'mpn_frcnn_test_one_sharded')
+   return self:_img_boxes()
+end
+function FastRCNN:_img_boxes()
+   local keep, idx, nk, stride = ffi.new('const float *[1]'), ffi.new('const int *[1]'), ffi.new('const int *[1]'), ffi.new('int[1]')
+   check(C.mpn_frcnn_nms_results(self.handle, keep, idx, nk, stride), 'mpn_frcnn_nms_results')   -- synchronises
+   local ncls, M = self.n_classes - 1, stride[0]
+   local counts = ffi.new('int[?]', ncls)
+   ffi.C.hipMemcpy(counts, nk[0], ncls * 4, 2)
+   local img_boxes = {}
+   for j = 1, ncls do
+      local t = torch.FloatTensor(counts[j - 1], 5)
+      if counts[j - 1] > 0 then ffi.C.hipMemcpy(t:data(), keep[0] + (j - 1) * M * 5, counts[j - 1] * 5 * 4, 2) end
+      img_boxes[j] = t
+   end
+   return img_boxes
+end
+-- utils.nms_dense (utils.lua:402-462): LongTensor of 1-based picks
+function mpn.nms_dense(boxes, overlap)
+   local n = boxes:nElement() == 0 and 0 or boxes:size(1)
+   if n == 0 then return torch.LongTensor() end
+   local d = boxes:cuda():contiguous()
+   local pick, np_ = torch.CudaIntTensor(n), torch.CudaIntTensor(1)
+   check(C.mpn_nms_dense(d:data(), n, overlap, ffi.cast('int *', pick:data()), ffi.cast('int *', np_:data()), stream()), 'mpn_nms_dense')
+   local k = np_:int()[1]
+   return k > 0 and pick:narrow(1, 1, k):long() or torch.LongTensor()
+end
 -- ImageDetect:detect (ImageDetect.lua:156-193): scores [N,C], decoded (unclamped) boxes [N,4C]; recompute_features as the reference
 function FastRCNN:detect(im, boxes, recompute_features)
    local d_boxes = boxes:cuda():contiguous()
