@@ -154,10 +154,10 @@ constexpr int kTieMax = 4096;   // nms_tie_kernel: one 64-bit alive/occupancy wo
 constexpr int kTieLdsMask = 1024;  // full symmetric mask kept in LDS up to this many boxes (128 KiB)
 // Classes with up to this many tied adjacent pairs take the chunked scan with the lazy, vectorised position replay (flag 3): its
 // cost is the tie-free scan plus one batched update of the slot model per equal-score run that still has two alive members at
-// its turn.  (Round 2's eager form — head replay and death recording inside every chunk — measured 850 k cycles against the slot
+// its turn (every update re-loads register windows: the cost grows with the number of such runs).  (Round 2's eager form — head replay and death recording inside every chunk — measured 850 k cycles against the slot
 // kernel's 320 k and was not dispatched to.)  Classes with more ties keep the slot-emulating kernel, whose per-pick cost does
 // not depend on the number of ties.
-constexpr int kFewTies = 32;
+constexpr int kFewTies = 12;  // measured (tools/nms_trace.py, 1000 boxes): 4 tied pairs 189 k cycles, 16 pairs 680 k = the slot kernel's cost
 
 __global__ __launch_bounds__(1024) void nms_sort_kernel(const float *__restrict__ scored, const int *__restrict__ counts,
                                                         int m_stride, float4 *__restrict__ sbox, float *__restrict__ sscore,
