@@ -1304,8 +1304,11 @@ int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float
   a.seg_stages = 0;
   if (g_gemm_split > 0) S = g_gemm_split;
   else if (row_invariant) {
-    // canonical segments from (K, N) alone: as many as fill 256 CUs when there is a single row tile, >= 4 stages (128 k) each
-    int Sc = 256 / a.n_nt;
+    // canonical segments from (K, N) alone, >= 4 stages (128 k) each: wide layers (fc6 / fc7, >= 16 column tiles) as many as fill
+    // 256 CUs when there is a SINGLE row tile — they only ever run split when a ROI shard is small, which is when it matters —,
+    // narrow ones (the cls / bbox / integral heads, always split) as many as fill the chip at the usual 8 row tiles (1000 ROIs):
+    // finer segments would only add slab traffic (32 instead of 8 slabs cost the MultiPathNet heads +0.15 ms)
+    int Sc = 256 / (a.n_nt * (a.n_nt >= 16 ? 1 : 8));
     if (Sc > 32) Sc = 32;
     if (Sc < 1) Sc = 1;
     int seg = cdiv(a.nstages, Sc);
