@@ -350,9 +350,16 @@ def latency_mode(args, torch, dist, models, parallel, comm, rank, world, dev, sh
         raise SystemExit("bench.py --mode latency needs one GPU per rank (RCCL refuses two ranks on one device)")
     if comm is None:
         raise SystemExit("bench.py --mode latency: the C-ABI RCCL communicator did not come up")
-    P = models.synthetic_params(models.VGG16_CFG, pooled=7, fc_dim=4096, n_classes=N_CLASSES, seed=557)
-    net = models.FastRCNN(P, max_h=H, max_w=W, max_rois=N_ROIS)
     im_np, boxes_np = synthetic_inputs()
+    if args.config == "c3":  # VGG-16 MultiPathNet: 5 towers — the per-ROI head is 88 % of the image, which is what this mode shards
+        other = OTHER_CONFIGS["c3"](models, args)
+        net, n_rois, n_classes, model_name = other["net"], other["n_rois"], 81, "VGG-16 MultiPathNet (5 towers, K = 6, 81 classes)"
+        boxes_np = more_boxes(boxes_np, n_rois)
+    elif args.config == "c2":
+        P = models.synthetic_params(models.VGG16_CFG, pooled=7, fc_dim=4096, n_classes=N_CLASSES, seed=557)
+        net, n_rois, n_classes, model_name = models.FastRCNN(P, max_h=H, max_w=W, max_rois=N_ROIS), N_ROIS, N_CLASSES, "VGG-16 Fast R-CNN"
+    else:
+        raise SystemExit("bench.py --mode latency supports --config c2 (default) and c3")
     im_host, boxes_host = torch.from_numpy(im_np).pin_memory(), torch.from_numpy(boxes_np).pin_memory()
     im_dev, boxes_dev = torch.empty(im_host.shape, device=dev), torch.empty(boxes_host.shape, device=dev)
 
@@ -381,31 +388,31 @@ def latency_mode(args, torch, dist, models, parallel, comm, rank, world, dev, sh
 
     ms = timed(lambda: net.test_one_sharded(comm, im_dev, boxes_dev))
     ms_res = timed(lambda: net.test_one_sharded(comm, im_dev, boxes_dev), with_upload=False)
-    out = {"metric": "per-image latency (1000 ROIs, 600x1000 img) VGG-16 Fast R-CNN, proposals + classes of ONE image sharded over the GPUs "
-                     "[latency mode; not the headline metric]",
+    out = {"metric": "per-image latency (%d ROIs, 600x1000 img) %s, proposals + classes of ONE image sharded over the GPUs "
+                     "[latency mode; not the headline metric]" % (n_rois, model_name),
            "value": round(ms, 4), "unit": "ms/image", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
            "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "VGG-16 Fast R-CNN, ONE image 600x1000 x 1000 ROIs per step for the whole job, 21 classes, NMS 0.3, top-100; host image + "
-                                  "boxes uploaded inside the step; device synchronisation after every step",
+           "config": {"workload": "%s, ONE image 600x1000 x %d ROIs per step for the whole job, %d classes, NMS 0.3, top-100; host image + "
+                                  "boxes uploaded inside the step; device synchronisation after every step" % (model_name, n_rois, n_classes),
                       "parallelism": "every rank: trunk on the whole image; ROI head on 1/%d of the proposals; RCCL all-gather of decoded rows; NMS of 1/%d of "
                                      "the classes; RCCL all-gather of kept tables (mpn_frcnn_test_one_sharded through the C ABI); cpu affinity: %s"
                                      % (world, world, affinity)},
-           "proposals_per_s": round(N_ROIS / (ms * 1e-3), 1), "ms_inputs_resident": round(ms_res, 4)}
+           "proposals_per_s": round(n_rois / (ms * 1e-3), 1), "ms_inputs_resident": round(ms_res, 4)}
     if world == 1:
         out["unsharded_ms"] = round(timed(lambda: net.test_one_async(im_dev, boxes_dev)), 4)  # mpn_frcnn_test_one under the same protocol
         G = max(2, args.emulate_world)
-        rr, cr = net.shard_record_floats(N_ROIS, G)
+        rr, cr = net.shard_record_floats(n_rois, G)
         rows_all = torch.empty((G, rr), dtype=torch.float32, device=dev)
         class_all = torch.empty((G, cr), dtype=torch.float32, device=dev)
         for r in range(G):
             net.shard_head(im_dev, boxes_dev, r, G, out=rows_all[r])
         for r in range(G):
-            net.shard_nms(rows_all, N_ROIS, r, G, out=class_all[r])
+            net.shard_nms(rows_all, n_rois, r, G, out=class_all[r])
 
         def rank0_share():
             net.shard_head(im_dev, boxes_dev, 0, G, out=rows_all[0])
-            net.shard_nms(rows_all, N_ROIS, 0, G, out=class_all[0])
-            net.shard_finish(class_all, N_ROIS, G)
+            net.shard_nms(rows_all, n_rois, 0, G, out=class_all[0])
+            net.shard_finish(class_all, n_rois, G)
         proj_ms = timed(rank0_share)
         net.set_profiling(True)
         net.get_profile(reset=True)
@@ -418,7 +425,7 @@ def latency_mode(args, torch, dist, models, parallel, comm, rank, world, dev, sh
                             "kernel_groups_ms": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]},
                             "what": "ONE GPU running rank 0's share of a %d-rank world (trunk + %d of %d ROIs + %d of %d classes + top-100) with the "
                                     "other ranks' records precomputed: the two all-gathers (%.0f KB + %.0f KB in total) are NOT included — a "
-                                    "projection, not a multi-GPU measurement" % (G, -(-N_ROIS // G), N_ROIS, -(-(N_CLASSES - 1) // G), N_CLASSES - 1,
+                                    "projection, not a multi-GPU measurement" % (G, -(-n_rois // G), n_rois, -(-(n_classes - 1) // G), n_classes - 1,
                                                                                    rr * G * 4 / 1024.0, cr * G * 4 / 1024.0)}
     if rank == 0:
         print(json.dumps(out))

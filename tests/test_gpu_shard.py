@@ -180,3 +180,29 @@ def test_one_sharded_two_gpus(dev):
         if p.is_alive():
             p.kill()
     assert sorted(got) == [(0, True), (1, True)]
+
+
+@pytest.mark.parametrize("world", [2, 5, 8])
+def test_multipathnet_sharded_equals_unsharded_emulated(dev, world):
+    """The mode pays off most where the per-ROI head dominates: MultiPathNet (BASELINE configs[2]; 5 towers, skip pooling, integral
+    heads).  Same bar: bit-identical to the unsharded test_one — the mix / fc6 / fc7 / integral-head GEMMs are row-invariant, the
+    skip pooling and the L2 normalisation are per ROI."""
+    from multipathnet_amd import models
+    cfg = [8, 16, "P", 16, 24, "P", 32, 32, "P", 64, "P", 64]
+    H, W, N, Cn, K = 150, 250, 117, 9, 3
+    P = models.synthetic_mpnet_params(cfg, pooled=7, fc_dim=128, n_classes=Cn, n_integral=K, seed=11)
+    rng = np.random.default_rng(21)
+    im = torch.from_numpy(rng.random((3, H, W), dtype=np.float32)).to(dev)
+    boxes = torch.from_numpy(_boxes(rng, N, W, H, lo=12)).to(dev)
+    net = models.MultiPathNet(P, cfg=cfg, pooled=7, spatial_scale=1 / 16, max_h=H, max_w=W, max_rois=N)
+    sc_ref, bb_ref = net.detect(im, boxes)
+    ref_dets, keep, kidx, nk = _reference(net, im, boxes)
+    dets, n, rows_all, _ = _emulate(net, im, boxes, world)
+    from multipathnet_amd import parallel
+    sc, bb = parallel.unpack_rows_records(rows_all, N, world, 1, Cn)
+    assert torch.equal(sc, sc_ref) and torch.equal(bb, bb_ref)
+    keep2, kidx2, nk2 = net.nms_results()
+    assert torch.equal(nk2, nk) and torch.equal(dets, ref_dets)
+    for c in range(Cn - 1):
+        k = int(nk[c])
+        assert torch.equal(keep2[c, :k], keep[c, :k]) and torch.equal(kidx2[c, :k], kidx[c, :k])
