@@ -104,6 +104,12 @@ int vmax_levels_for(int H);
 int build_vmax_tables(Act feat, float *d_tables, hipStream_t s);
 int roi_pool_c8_rmq(Act feat, const float *d_tables, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset,
                     int end_adjust, float *d_x_c8, hipStream_t s, int roi_stride = 5, int Mp = 0);
+// The same on PIXEL-MAJOR tables (levels 0 .. vmax_levels_for(H), pixel_major_elems(feat) floats each; level 0 = the map): coalesced
+// 1-KiB wave loads; `normalize` fuses nn.Normalize(2)'s sum of squares into the pooling launch and applies x * (mul / norm),
+// otherwise nn.MulConstant(mul).  Pooled values bit-identical to roi_pool_c8 / roi_pool_c8_rmq.
+int build_vmax_tables_pm(Act feat, float *d_tables, hipStream_t s);
+int roi_pool_pm_rmq(Act feat, const float *d_tables_pm, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset,
+                    int end_adjust, float *d_x_c8, hipStream_t s, int roi_stride, int Mp, int normalize, float mul);
 // in-place x * (mul / sqrt(sum x^2 + 1e-10)) per ROI over n_records 8-float records of a C8 matrix
 int l2norm_scale_c8(float *d_x_c8, int n_records, int Mp, int N, float mul, hipStream_t s);
 int mul_const_c8(float *d_x_c8, int n_records, int Mp, int N, float mul, hipStream_t s);  // nn.MulConstant on the same layout

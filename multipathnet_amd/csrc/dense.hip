@@ -1926,6 +1926,140 @@ int roi_pool_pm(Act feat, const float *d_pm, const float *d_rois, int N, int PH,
   return MPN_OK;
 }
 
+// ---- the range-max-table pooling on PIXEL-MAJOR tables (MultiPathNet head, round 3) -----------------------------------------------
+// roi_pool_c8_rmq_kernel's wave is 32 different ROIs at one (channel block, bin): every load instruction touches 32 cache lines and
+// uses a quarter of each (115 us per 100 MB pooled matrix = 0.9 TB/s, a sixth of the write ceiling; 11 such pools per MultiPathNet
+// image).  Here the map and its vertical range-max levels are pixel-major ([level][y][x][C], level 0 = the map itself), a wave is ONE
+// (roi, bin) and its lanes are 256 consecutive channels — every load is one contiguous 1 KiB — the window is wave-uniform, four
+// consecutive ROIs share a block and leave as whole 128-byte lines of the mix GEMM's operand (as roi_pool_pm_kernel).  SS: the
+// block also emits this (roi, bin, 256-channel slice)'s sum of squares (a fixed shuffle tree), so nn.Normalize's reduction costs a
+// PP * C/256-term finish per ROI instead of another pass over the 100 MB matrix (l2norm_partial_kernel).  max is exact: the pooled
+// values are bit-identical to the direct and to the C8P range-max kernels.
+__global__ void vmax_level_pm_kernel(const f32x4 *__restrict__ prev, f32x4 *__restrict__ out, int H, int W, int C4, int step) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t row = (size_t)W * C4, total = (size_t)H * row;
+  if (t >= total) return;
+  const int y = (int)(t / row);
+  f32x4 a = prev[t];
+  if (y + step < H) {
+    const f32x4 b = prev[t + (size_t)step * row];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = b[e] > a[e] ? b[e] : a[e];
+  }
+  out[t] = a;
+}
+
+int build_vmax_tables_pm(Act feat, float *d_tables, hipStream_t s) {  // levels 0 .. vmax_levels_for(H), pixel_major_elems(feat) floats each
+  MPN_CHECK_ARG(feat.p && d_tables);
+  int rc = c8p_to_pixel_major(feat, d_tables, s);
+  if (rc) return rc;
+  const int L = vmax_levels_for(feat.H);
+  const size_t lvl = pixel_major_elems(feat), total = lvl / 4;
+  for (int k = 1; k <= L; ++k) {
+    hipLaunchKernelGGL(vmax_level_pm_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, reinterpret_cast<const f32x4 *>(d_tables + (size_t)(k - 1) * lvl),
+                       reinterpret_cast<f32x4 *>(d_tables + (size_t)k * lvl), feat.H, feat.W, feat.Cb() * 2, 1 << (k - 1));
+    MPN_CHECK_LAUNCH();
+  }
+  return MPN_OK;
+}
+
+template <bool SS>
+__global__ __launch_bounds__(256) void roi_pool_pm_rmq_kernel(const float *__restrict__ tab, size_t level_elems, int Cb, int H, int W,
+                                                              const float *__restrict__ rois, int roi_stride, int N, int PH, int PW, float scale,
+                                                              float coord_offset, int end_adjust, float *__restrict__ xc8, int Mp,
+                                                              float *__restrict__ ss_part) {
+  __shared__ f32x4 stage[4][64];   // [roi of the quad][lane] = 4 channels
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n0 = blockIdx.x * 4, n = n0 + wave;
+  const int bin = blockIdx.y, cq = blockIdx.z;   // cq: which 256-channel slice
+  const int ph = bin / PW, pw = bin - ph * PW;
+  const int C = Cb * 8;
+  f32x4 m = f32x4{0, 0, 0, 0};
+  if (n < N) {
+    const float *ro = rois + (size_t)roi_stride * n;
+    const int sw = (int)roundf((ro[1] - coord_offset) * scale);
+    const int sh = (int)roundf((ro[2] - coord_offset) * scale);
+    const int ew = (int)roundf((ro[3] - coord_offset) * scale) + end_adjust;
+    const int eh = (int)roundf((ro[4] - coord_offset) * scale) + end_adjust;
+    const int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
+    const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+    int hs = (int)floorf((float)ph * bh) + sh, he = (int)ceilf((float)(ph + 1) * bh) + sh;
+    int ws = (int)floorf((float)pw * bw) + sw, we = (int)ceilf((float)(pw + 1) * bw) + sw;
+    hs = min(max(hs, 0), H); he = min(max(he, 0), H);
+    ws = min(max(ws, 0), W); we = min(max(we, 0), W);
+    hs = __builtin_amdgcn_readfirstlane(hs); he = __builtin_amdgcn_readfirstlane(he);
+    ws = __builtin_amdgcn_readfirstlane(ws); we = __builtin_amdgcn_readfirstlane(we);
+    const int ch = cq * 256 + lane * 4;
+    if (he > hs && we > ws && ch < C) {
+      const int k = 31 - __clz(he - hs);  // 2^k <= he - hs < 2^(k+1)
+      const float *lvl = tab + (size_t)k * level_elems + ch;
+      const float *r0 = lvl + (size_t)hs * W * C, *r1 = lvl + (size_t)(he - (1 << k)) * W * C;
+      m = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      for (int xb = ws; xb < we; xb += 4) {  // 8 independent 1-KiB wave loads in flight; positions past the window re-read its last column
+        f32x4 a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const size_t xo = (size_t)min(xb + j, we - 1) * C;
+          a[j] = *reinterpret_cast<const f32x4 *>(r0 + xo);
+          b[j] = *reinterpret_cast<const f32x4 *>(r1 + xo);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = b[j][e] > a[j][e] ? b[j][e] : a[j][e];
+            if (v > m[e]) m[e] = v;
+          }
+      }
+    }
+  }
+  if constexpr (SS) {  // sum of squares of this (roi, bin, slice): lanes in a fixed tree (channels past C contribute +0)
+    float ss = m[0] * m[0];
+    ss += m[1] * m[1]; ss += m[2] * m[2]; ss += m[3] * m[3];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+    if (lane == 0 && n < N) ss_part[((size_t)bin * gridDim.z + cq) * N + n] = ss;
+  }
+  stage[wave][lane] = m;
+  __syncthreads();
+  // 32 channel blocks x (4 rois x 8 floats = 128 contiguous bytes): thread = (channel block, 16-byte piece of the line)
+  const int t = threadIdx.x, cbl = t >> 3, j4 = t & 7, roi = j4 >> 1, hf = j4 & 1;
+  const int cb = cq * 32 + cbl;
+  if (cb < Cb && n0 + roi < N) {
+    const f32x4 v = stage[roi][cbl * 2 + hf];
+    *reinterpret_cast<f32x4 *>(xc8 + (((size_t)cb * PH * PW + bin) * Mp + n0) * 8 + j4 * 4) = v;
+  }
+}
+
+// pool (+ optionally nn.Normalize(2) x mul, or nn.MulConstant(mul)) one map into its channel range of the mix GEMM's operand
+int roi_pool_pm_rmq(Act feat, const float *d_tables_pm, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset,
+                    int end_adjust, float *d_x_c8, hipStream_t s, int roi_stride, int Mp, int normalize, float mul) {
+  MPN_CHECK_ARG(feat.p && d_tables_pm && d_rois && d_x_c8 && N > 0 && PH > 0 && PW > 0);
+  const int mp = Mp > 0 ? Mp : lin_mp(N), Cq = cdiv(feat.Cb(), 32), PP = PH * PW;
+  const dim3 grid((unsigned)cdiv(N, 4), (unsigned)PP, (unsigned)Cq);
+  if (!normalize) {
+    hipLaunchKernelGGL(roi_pool_pm_rmq_kernel<false>, grid, dim3(256), 0, s, d_tables_pm, pixel_major_elems(feat), feat.Cb(), feat.H, feat.W, d_rois,
+                       roi_stride, N, PH, PW, scale, coord_offset, end_adjust, d_x_c8, mp, (float *)nullptr);
+    MPN_CHECK_LAUNCH();
+    return mul_const_c8(d_x_c8, feat.Cb() * PP, mp, N, mul, s);
+  }
+  const int G = PP * Cq;
+  void *ws = nullptr;
+  { int rc_ws = scratch_get(SCR_L2NORM, ((size_t)G + 1) * N * sizeof(float), s, &ws); if (rc_ws) return rc_ws; }
+  float *part = static_cast<float *>(ws), *nrm = part + (size_t)G * N;
+  hipLaunchKernelGGL(roi_pool_pm_rmq_kernel<true>, grid, dim3(256), 0, s, d_tables_pm, pixel_major_elems(feat), feat.Cb(), feat.H, feat.W, d_rois,
+                     roi_stride, N, PH, PW, scale, coord_offset, end_adjust, d_x_c8, mp, part);
+  MPN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(l2norm_finish_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, part, G, N, nrm);
+  MPN_CHECK_LAUNCH();
+  const size_t total = (size_t)feat.Cb() * PP * N * 2;
+  hipLaunchKernelGGL(l2norm_apply_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, d_x_c8, (size_t)feat.Cb() * PP, mp, N, nrm, mul);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+
 int roi_pool_c8(Act feat, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset, int end_adjust,
                 float *d_x_c8, int32_t *d_argmax, hipStream_t s, int roi_stride, int Mp) {
   MPN_CHECK_ARG(feat.p && d_rois && d_x_c8 && N > 0 && PH > 0 && PW > 0);
@@ -2103,9 +2237,23 @@ extern "C" int mpn_debug_roi_pool_rmq_mismatches(const float *d_feat_nchw, int C
   if (rc == MPN_OK) rc = roi_pool_c8_rmq(a, tab, d_rois, N, PH, PW, scale, 1.0f, 0, o2, nullptr, roi_stride, 0);
   if (rc == MPN_OK) {
     hipLaunchKernelGGL(count_diff_kernel, dim3((unsigned)cdiv_sz(oe, 256)), dim3(256), 0, nullptr, o1, o2, oe, cnt);
-    MPN_CHECK_HIP(hipMemcpy(n_mismatch, cnt, 4, hipMemcpyDeviceToHost));
+    MPN_CHECK_LAUNCH();
   }
+  // the pixel-major range-max path (round 3): also bit-identical to the direct kernel
+  float *tabpm = nullptr;
+  if (rc == MPN_OK) {
+    MPN_CHECK_HIP(hipMalloc(&tabpm, pixel_major_elems(a) * sizeof(float) * (L + 1)));
+    MPN_CHECK_HIP(hipMemset(o2, 0, oe * 4));
+    rc = build_vmax_tables_pm(a, tabpm, nullptr);
+    if (rc == MPN_OK) rc = roi_pool_pm_rmq(a, tabpm, d_rois, N, PH, PW, scale, 1.0f, 0, o2, nullptr, roi_stride, 0, 0, 1.0f);
+    if (rc == MPN_OK) {
+      hipLaunchKernelGGL(count_diff_kernel, dim3((unsigned)cdiv_sz(oe, 256)), dim3(256), 0, nullptr, o1, o2, oe, cnt);
+      MPN_CHECK_LAUNCH();
+    }
+  }
+  if (rc == MPN_OK) MPN_CHECK_HIP(hipMemcpy(n_mismatch, cnt, 4, hipMemcpyDeviceToHost));
   (void)hipFree(act); (void)hipFree(tab); (void)hipFree(o1); (void)hipFree(o2); (void)hipFree(cnt);
+  if (tabpm) (void)hipFree(tabpm);
   return rc;
 }
 

@@ -264,6 +264,7 @@ struct mpn_frcnn {
   Act tap_act[3];  // conv5, conv4, conv3 of the last trunk run
   float *vmax_tab[3] = {nullptr, nullptr, nullptr};  // vertical range-max tables of the three maps (MultiPathNet ROI pools)
   bool vmax_valid = false;                            // built for the current tap_act maps
+  bool vmax_pm = false;                               // ... in the pixel-major form
   std::vector<void *> allocs;
   Scratch scratch;  // split-K slabs, NMS masks, ... of THIS handle (bound to the calling thread by ScratchScope in every entry point)
   int device = 0;   // the handle lives on the device that was current at creation
@@ -398,7 +399,7 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
     p->act_bufs.push_back({L.out, b});
     if (mw && (l == mw->tap_conv3 || l == mw->tap_conv4 || l == n_conv - 1)) {  // range-max tables of the maps the towers pool
       const int slot = l == n_conv - 1 ? 0 : (l == mw->tap_conv4 ? 1 : 2);
-      TRY(dev_alloc(p, &p->vmax_tab[slot], (size_t)(vmax_levels_for(h) > 0 ? vmax_levels_for(h) : 1) * b, false));
+      TRY(dev_alloc(p, &p->vmax_tab[slot], (size_t)(vmax_levels_for(h) + 1) * b, false));  // levels 1..L (C8P form) or 0..L (pixel-major form)
     }
     if (L.pool) {
       h = (h + 1) / 2; w = (w + 1) / 2;
@@ -614,11 +615,13 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
   const float scales[3] = {c.spatial_scale, c.spatial_scale * 2.0f, c.spatial_scale * 4.0f};
   const float kConv345Factor[3] = {1.0f, (float)(1.0 / 30), (float)(1.0 / 200)};  // model_utils.lua:231-237 normFactor (Lua doubles -> float)
   const int Fcb = lin_np(F) / 8;
-  if (!p->vmax_valid) {  // once per trunk run; iterative localisation on the cached maps reuses them
+  const bool pm = g_roi_pool_pm != 0;  // pixel-major range-max tables + fused sum of squares (round 3); 0 = the C8P form (test hook)
+  if (!p->vmax_valid || p->vmax_pm != pm) {  // once per trunk run; iterative localisation on the cached maps reuses them
     ProfScope ps(p, MPN_PROF_ROIPOOL, s);
-    for (int m = 0; m < 3 && rc == MPN_OK; ++m) rc = build_vmax_tables(maps[m], p->vmax_tab[m], s);
+    for (int m = 0; m < 3 && rc == MPN_OK; ++m) rc = pm ? build_vmax_tables_pm(maps[m], p->vmax_tab[m], s) : build_vmax_tables(maps[m], p->vmax_tab[m], s);
     if (rc) return rc;
     p->vmax_valid = true;
+    p->vmax_pm = pm;
   }
   int ti = 0;
   for (auto &T : p->towers) {
@@ -629,9 +632,14 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
       if (!used[m]) continue;
       float *dst = p->tx + (size_t)cb_off * PP * Mp * 8;
       { ProfScope ps(p, MPN_PROF_ROIPOOL, s);
-        rc = roi_pool_c8_rmq(maps[m], p->vmax_tab[m], reg, N, c.pooled_h, c.pooled_w, scales[m], 1.0f, 0, dst, s, 20, Mp);
-        if (rc == MPN_OK) rc = p->conv345_norm ? l2norm_scale_c8(dst, maps[m].Cb() * PP, Mp, N, 1000.0f, s)
-                                               : mul_const_c8(dst, maps[m].Cb() * PP, Mp, N, kConv345Factor[m], s); }
+        if (pm) {
+          rc = roi_pool_pm_rmq(maps[m], p->vmax_tab[m], reg, N, c.pooled_h, c.pooled_w, scales[m], 1.0f, 0, dst, s, 20, Mp, p->conv345_norm ? 1 : 0,
+                               p->conv345_norm ? 1000.0f : kConv345Factor[m]);
+        } else {
+          rc = roi_pool_c8_rmq(maps[m], p->vmax_tab[m], reg, N, c.pooled_h, c.pooled_w, scales[m], 1.0f, 0, dst, s, 20, Mp);
+          if (rc == MPN_OK) rc = p->conv345_norm ? l2norm_scale_c8(dst, maps[m].Cb() * PP, Mp, N, 1000.0f, s)
+                                                 : mul_const_c8(dst, maps[m].Cb() * PP, Mp, N, kConv345Factor[m], s);
+        } }
       if (rc) return rc;
       cb_off += maps[m].Cb();
     }

@@ -258,6 +258,29 @@ def test_multipathnet_head_vs_oracle(O, dev, conv345_norm):
     assert 0 < int(n.item()) <= dets.shape[0]
 
 
+def test_multipathnet_pixel_major_pooling_equals_c8p_form(dev):
+    """Round 3: the MultiPathNet head pools from PIXEL-MAJOR range-max tables with nn.Normalize's sum of squares fused into the
+    pooling launch.  The pooled values are bit-identical to the C8P range-max kernel's (tests/test_gpu_roipool.py); the per-ROI
+    norm is summed in a different (fixed) order, so scores agree to fp32 rounding, and each form is deterministic."""
+    from multipathnet_amd import models
+    cfg = [8, 16, "P", 16, 24, "P", 32, 32, "P", 64, "P", 64]
+    H, W, N, Cn, K = 150, 250, 120, 9, 3
+    P = models.synthetic_mpnet_params(cfg, pooled=7, fc_dim=128, n_classes=Cn, n_integral=K, seed=11)
+    rng = np.random.default_rng(21)
+    im = torch.from_numpy(rng.random((3, H, W), dtype=np.float32)).to(dev)
+    boxes = torch.from_numpy(_boxes(rng, N, W, H, lo=12)).to(dev)
+    outs = []
+    for pm in (1, 0):
+        with hooks(roi_pool_pm=pm):
+            net = models.MultiPathNet(P, cfg=cfg, pooled=7, spatial_scale=1 / 16, max_h=H, max_w=W, max_rois=N)
+            s1, b1 = net.detect(im, boxes)
+            s2, b2 = net.detect(im, boxes)
+            torch.cuda.synchronize()
+            assert torch.equal(s1, s2) and torch.equal(b1, b2)
+            outs.append((s1.clone(), b1.clone()))
+    assert float((outs[0][0] - outs[1][0]).abs().max()) < 2e-6 and float((outs[0][1] - outs[1][1]).abs().max()) < 1e-3
+
+
 def test_alexnet_shaped_head_vs_oracle(O, dev):
     """BASELINE configs[0] head shape (models/alexnet.lua:23-27): ROIPooling(6,6,1/16) on a 256-channel map, fc6 9216->4096,
     300 selective-search-like ROIs, 21 classes, through the module-level C ABI, then clamp/select/NMS/top-k vs the oracle.
