@@ -1963,6 +1963,17 @@ int build_vmax_tables_pm(Act feat, float *d_tables, hipStream_t s) {  // levels 
   return MPN_OK;
 }
 
+// one wave per ROI: its G partial sums of squares (contiguous) in a fixed lane-strided + tree order -> sqrt(sum + 1e-10)
+__global__ __launch_bounds__(256) void l2norm_finish_rows_kernel(const float *__restrict__ part, int G, int N, float *__restrict__ nrm) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float ss = 0.0f;
+  for (int g = lane; g < G; g += 64) ss += part[(size_t)n * G + g];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+  if (lane == 0) nrm[n] = sqrtf(ss + 1e-10f);
+}
+
 template <bool SS>
 __global__ __launch_bounds__(256) void roi_pool_pm_rmq_kernel(const float *__restrict__ tab, size_t level_elems, int Cb, int H, int W,
                                                               const float *__restrict__ rois, int roi_stride, int N, int PH, int PW, float scale,
@@ -2019,7 +2030,7 @@ __global__ __launch_bounds__(256) void roi_pool_pm_rmq_kernel(const float *__res
     ss += m[1] * m[1]; ss += m[2] * m[2]; ss += m[3] * m[3];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
-    if (lane == 0 && n < N) ss_part[((size_t)bin * gridDim.z + cq) * N + n] = ss;
+    if (lane == 0 && n < N) ss_part[(size_t)n * (gridDim.y * gridDim.z) + bin * gridDim.z + cq] = ss;  // [roi][bin][slice]
   }
   stage[wave][lane] = m;
   __syncthreads();
@@ -2051,7 +2062,7 @@ int roi_pool_pm_rmq(Act feat, const float *d_tables_pm, const float *d_rois, int
   hipLaunchKernelGGL(roi_pool_pm_rmq_kernel<true>, grid, dim3(256), 0, s, d_tables_pm, pixel_major_elems(feat), feat.Cb(), feat.H, feat.W, d_rois,
                      roi_stride, N, PH, PW, scale, coord_offset, end_adjust, d_x_c8, mp, part);
   MPN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(l2norm_finish_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, part, G, N, nrm);
+  hipLaunchKernelGGL(l2norm_finish_rows_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, part, G, N, nrm);
   MPN_CHECK_LAUNCH();
   const size_t total = (size_t)feat.Cb() * PP * N * 2;
   hipLaunchKernelGGL(l2norm_apply_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, d_x_c8, (size_t)feat.Cb() * PP, mp, N, nrm, mul);
