@@ -252,3 +252,25 @@ def test_nms_few_ties_and_duplicated_boxes_bit_exact(O, dev, n, pairs, dups, nms
         keep, idx = utils.nms_with_index(_t(sb, dev), thr)
         assert keep.shape[0] == ref.shape[0] and np.array_equal(keep.cpu().numpy(), ref)
         assert np.array_equal(idx.cpu().numpy(), ridx)
+
+
+def test_stream_release_frees_module_level_scratch(O, dev):
+    """ADVICE r2 / VERDICT r2 #9: module-level calls keep grow-on-demand scratch per (device, stream); a host that creates streams
+    per image releases the entry with mpn_stream_release before destroying the stream.  The registry is recreated on demand."""
+    import multipathnet_amd
+    from multipathnet_amd import utils
+    lib = multipathnet_amd.load()
+    sb = _t(random_scored_boxes(np.random.default_rng(3), 500, "distinct"), dev)
+    ref = O.nms(sb.cpu().numpy(), 0.3)
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            keep = utils.nms(sb, 0.3)
+        assert np.array_equal(keep.cpu().numpy(), ref)
+        assert lib.mpn_stream_release(ctypes.c_void_p(st.cuda_stream)) == 0
+        assert lib.mpn_stream_release(ctypes.c_void_p(st.cuda_stream)) == 0   # nothing left: a no-op
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20   # three streams' NMS scratch (~10 MB each) did not accumulate
+    assert lib.mpn_release_all_scratch() == 0
+    assert np.array_equal(utils.nms(sb, 0.3).cpu().numpy(), ref)   # scratch of the default stream is rebuilt on demand
