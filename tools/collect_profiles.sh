@@ -23,6 +23,7 @@ done
 timeout 600 python $R/bench.py --config c4 --dtype bf16 --steps 6 --warmup 2 > $OUT/${TAG}_bench_c4_bf16.json 2> /tmp/bench_c4b.err
 # round 3: the ROI-sharded latency mode at N = 1 (+ the one-GPU projection of rank 0's share of an 8-rank world)
 timeout 600 python $R/bench.py --mode latency --steps 20 --warmup 5 > $OUT/${TAG}_bench_latency.json 2> /tmp/bench_lat.err
+timeout 600 python $R/bench.py --mode latency --config c3 --steps 6 --warmup 2 > $OUT/${TAG}_bench_latency_c3.json 2> /tmp/bench_lat3.err
 # NMS: per-path latency on the SURVEY 8d micro-inputs + the chunked scan's per-chunk cycle trace
 timeout 300 python $R/tools/bench_nms.py > $OUT/${TAG}_nms_paths.txt 2>&1
 timeout 300 python $R/tools/nms_trace.py > $OUT/${TAG}_nms_trace.txt 2>&1
