@@ -86,6 +86,12 @@ int maxpool2x2_c8p(Act in, Act out, hipStream_t s);
 int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float *d_bpk, int N, int relu, float *d_y_c8,
               float *d_y_rm, hipStream_t s, int Mp_override = 0, const float *d_res_c8 = nullptr, int row_invariant = 0);
 bool linear_c8_is_direct(int M, int N, int Mp_override = 0);  // would linear_c8 run un-split for this shape?
+// y = sum over up to three K segments of scale_seg[row % rs_mod] * (x_seg . w_seg) (+ b, ReLU): MultiPathNet's mix GEMM with nn.Normalize
+// of its three pooled maps applied where the accumulator is folded, instead of a read-modify-write pass over the pooled matrix.
+// Un-split launches only (linear_c8_is_direct); k_end = the K index (multiple of 32) at which segment i ends.
+struct GemmRowScale { int n_seg; int k_end[2]; const float *scale[3]; int rs_mod; };
+int linear_c8_rowscaled(const float *d_x_c8, int M, int K, const float *d_wpk, const float *d_bpk, int N, int relu, float *d_y_c8, hipStream_t s,
+                        int Mp_override, const GemmRowScale &rs);
 // ROI max-pool reading a C8P feature map and writing the C8 matrix the fc6 GEMM consumes:
 // chunk q = cb*PH*PW + bin, row = roi.  argmax (optional) [N,C,PH,PW] int32 as the NCHW kernel.
 // roi_stride: floats between consecutive rois (5; 20 selects one Foveal region out of the [4N,5] table);
@@ -108,8 +114,9 @@ int roi_pool_c8_rmq(Act feat, const float *d_tables, const float *d_rois, int N,
 // 1-KiB wave loads; `normalize` fuses nn.Normalize(2)'s sum of squares into the pooling launch and applies x * (mul / norm),
 // otherwise nn.MulConstant(mul).  Pooled values bit-identical to roi_pool_c8 / roi_pool_c8_rmq.
 int build_vmax_tables_pm(Act feat, float *d_tables, hipStream_t s);
+// d_scale_out (normalize only, [Mp]): write the per-ROI scale mul / norm there and leave the pooled matrix unscaled (the consumer applies it).
 int roi_pool_pm_rmq(Act feat, const float *d_tables_pm, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset,
-                    int end_adjust, float *d_x_c8, hipStream_t s, int roi_stride, int Mp, int normalize, float mul);
+                    int end_adjust, float *d_x_c8, hipStream_t s, int roi_stride, int Mp, int normalize, float mul, float *d_scale_out = nullptr);
 // in-place x * (mul / sqrt(sum x^2 + 1e-10)) per ROI over n_records 8-float records of a C8 matrix
 int l2norm_scale_c8(float *d_x_c8, int n_records, int Mp, int N, float mul, hipStream_t s);
 int mul_const_c8(float *d_x_c8, int n_records, int Mp, int N, float mul, hipStream_t s);  // nn.MulConstant on the same layout

@@ -1077,6 +1077,11 @@ struct GemmArgs {
   int n_fast;  // tile order: 0 = all row tiles of one column tile first (the weights are the big operand: fc6), 1 = all column tiles of one
                // row tile first (the activations are: ResNet's pointwise convolutions over 10^5 pixel rows) — the big operand is streamed once
   const float *res;  // optional residual in y's layout, added before the ReLU (direct mode only; ResNet 1x1 convolutions)
+  // K segments with a per-ROW scale each (un-split launches only; MultiPathNet's mix GEMM: nn.Normalize of the three pooled maps folded
+  // into the accumulator fold instead of a read-modify-write pass over the pooled matrix): y = sum_seg rs[seg][row % rs_mod] * (x_seg . w_seg)
+  int nsb, sb0, sb1;             // interior segment boundaries (stage indices), nsb = 0: none (seg_stages applies)
+  const float *rs0, *rs1, *rs2;  // scale vector of segment 0 / 1 / 2 (rs0 == nullptr: no scaling)
+  int rs_mod;
 };
 
 // C8 GEMM  y[NP/8][Mp][8] = x[K/8][Mp][8] . wpk[K/8][NP][8]: 128 x 128 tile per block, KCH 8-wide K chunks per LDS stage (4 -> 32 k, 32 KiB per
@@ -1126,6 +1131,18 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
+  float rsc[3][2];  // this lane's two rows' scales per K segment (fetched now: a load at a fold boundary would be an exposed round trip)
+#pragma unroll
+  for (int sg = 0; sg < 3; ++sg) { rsc[sg][0] = 1.0f; rsc[sg][1] = 1.0f; }
+  if (a.rs0) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int row = (m0 + wn * 64 + ni * 32 + l31) % a.rs_mod;
+      rsc[0][ni] = a.rs0[row];
+      if (a.rs1) rsc[1][ni] = a.rs1[row];
+      if (a.rs2) rsc[2][ni] = a.rs2[row];
+    }
+  }
   const int lane_off = l31 * 8 + half * 4;
   f32x4 af[2][2], bf[2][2];
   auto load_frags = [&](int s, int kk, int slot) {
@@ -1182,22 +1199,37 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) tot[mi][ni][r] = 0.0f;
+  int fseg = 0;  // index of the segment being accumulated
   auto fold = [&]() {
+    if (a.rs0) {  // (wave-uniform) the segment's per-row scale: tot += scale * acc
+      const float s0 = fseg == 0 ? rsc[0][0] : (fseg == 1 ? rsc[1][0] : rsc[2][0]), s1 = fseg == 0 ? rsc[0][1] : (fseg == 1 ? rsc[1][1] : rsc[2][1]);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+        for (int r = 0; r < 16; ++r) {
+          tot[mi][0][r] += s0 * acc[mi][0][r]; acc[mi][0][r] = 0.0f;
+          tot[mi][1][r] += s1 * acc[mi][1][r]; acc[mi][1][r] = 0.0f;
+        }
+    } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { tot[mi][ni][r] += acc[mi][ni][r]; acc[mi][ni][r] = 0.0f; }
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { tot[mi][ni][r] += acc[mi][ni][r]; acc[mi][ni][r] = 0.0f; }
+    }
+    ++fseg;
   };
-  int next_fold = a.seg_stages > 0 ? st0 + a.seg_stages : 0x7fffffff;
+  // fold points: explicit boundaries (sb0, sb1) or every seg_stages stages
+  int next_fold = a.nsb > 0 ? a.sb0 : (a.seg_stages > 0 ? st0 + a.seg_stages : 0x7fffffff);
+  auto advance = [&]() { next_fold = a.nsb > 0 ? (fseg < a.nsb ? a.sb1 : 0x7fffffff) : next_fold + a.seg_stages; };
   int st = st0;
-  if (n_more & 1) { body(st, std::true_type{}, P1{}); ++st; if (st == next_fold) { fold(); next_fold += a.seg_stages; } }
+  if (n_more & 1) { body(st, std::true_type{}, P1{}); ++st; if (st == next_fold) { fold(); advance(); } }
   for (; st < st1 - 1; st += 2) {
     body(st, std::true_type{}, P0{});
-    if (st + 1 == next_fold) { fold(); next_fold += a.seg_stages; }
+    if (st + 1 == next_fold) { fold(); advance(); }
     body(st + 1, std::true_type{}, P1{});
-    if (st + 2 == next_fold) { fold(); next_fold += a.seg_stages; }
+    if (st + 2 == next_fold) { fold(); advance(); }
   }
   body(st1 - 1, std::false_type{}, P0{});
   fold();  // tot = 0 + acc when nothing was folded before: exact
@@ -1286,8 +1318,24 @@ bool linear_c8_is_direct(int M, int N, int Mp_override) {
   return g_gemm_split == 0 && (Mp / 128) * (lin_np(N) / 128) >= 128;
 }
 
+static int linear_c8_impl(const float *d_x_c8, int M, int K, const float *d_wpk, const float *d_bpk, int N, int relu, float *d_y_c8,
+                          float *d_y_rm, hipStream_t s, int Mp_override, const float *d_res_c8, int row_invariant, const GemmRowScale *rs);
+
 int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float *d_bpk, int N, int relu, float *d_y_c8,
               float *d_y_rm, hipStream_t s, int Mp_override, const float *d_res_c8, int row_invariant) {
+  return linear_c8_impl(d_x_c8, M, K, d_wpk, d_bpk, N, relu, d_y_c8, d_y_rm, s, Mp_override, d_res_c8, row_invariant, nullptr);
+}
+
+int linear_c8_rowscaled(const float *d_x_c8, int M, int K, const float *d_wpk, const float *d_bpk, int N, int relu, float *d_y_c8, hipStream_t s,
+                        int Mp_override, const GemmRowScale &rs) {
+  MPN_CHECK_ARG(rs.n_seg >= 1 && rs.n_seg <= 3 && rs.rs_mod > 0 && rs.scale[0] != nullptr);
+  if (!linear_c8_is_direct(M, N, Mp_override)) { set_error("linear_c8_rowscaled: needs the un-split form (>= 128 output tiles)"); return MPN_EINVAL; }
+  for (int i = 0; i + 1 < rs.n_seg; ++i) MPN_CHECK_ARG(rs.k_end[i] > (i ? rs.k_end[i - 1] : 0) && rs.k_end[i] % 32 == 0 && rs.k_end[i] < K);
+  return linear_c8_impl(d_x_c8, M, K, d_wpk, d_bpk, N, relu, d_y_c8, nullptr, s, Mp_override, nullptr, 0, &rs);
+}
+
+static int linear_c8_impl(const float *d_x_c8, int M, int K, const float *d_wpk, const float *d_bpk, int N, int relu, float *d_y_c8,
+                          float *d_y_rm, hipStream_t s, int Mp_override, const float *d_res_c8, int row_invariant, const GemmRowScale *rs) {
   MPN_CHECK_ARG(d_x_c8 && d_wpk && d_bpk && (d_y_c8 || d_y_rm) && M > 0 && K > 0 && N > 0);
   MPN_CHECK_ARG(Mp_override == 0 || (Mp_override >= M && Mp_override % 128 == 0));
   GemmArgs a{};
@@ -1325,6 +1373,15 @@ int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float
   S = cdiv(a.nstages, a.stages_per_split);
   const bool direct = (S == 1) && d_y_c8 && !d_y_rm;
   a.direct = direct ? 1 : 0;
+  if (rs) {  // per-row-scaled K segments (checked un-split by the caller): explicit fold boundaries in stages of 8 * kch channels
+    if (!direct || kch != 4) { set_error("linear_c8_rowscaled: un-split 32-k-stage launches only"); return MPN_EINVAL; }
+    a.nsb = rs->n_seg - 1;
+    a.sb0 = rs->n_seg > 1 ? rs->k_end[0] / 32 : 0x7fffffff;
+    a.sb1 = rs->n_seg > 2 ? rs->k_end[1] / 32 : 0x7fffffff;
+    a.rs0 = rs->scale[0]; a.rs1 = rs->n_seg > 1 ? rs->scale[1] : nullptr; a.rs2 = rs->n_seg > 2 ? rs->scale[2] : nullptr;
+    a.rs_mod = rs->rs_mod;
+    a.seg_stages = 0;
+  }
   if (d_res_c8 && !direct) { set_error("linear_c8: a residual needs the direct (un-split, C8 output) form"); return MPN_EINVAL; }
   a.res = d_res_c8;
   {
@@ -2044,8 +2101,19 @@ __global__ __launch_bounds__(256) void roi_pool_pm_rmq_kernel(const float *__res
 }
 
 // pool (+ optionally nn.Normalize(2) x mul, or nn.MulConstant(mul)) one map into its channel range of the mix GEMM's operand
+// per-ROI scale mul / sqrt(sum + 1e-10) for n < N, 0 for the padding rows N .. Mp-1 (their pooled rows are zero)
+__global__ __launch_bounds__(256) void l2norm_scale_rows_kernel(const float *__restrict__ part, int G, int N, int Mp, float mul, float *__restrict__ scale) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= Mp) return;
+  float ss = 0.0f;
+  if (n < N) for (int g = lane; g < G; g += 64) ss += part[(size_t)n * G + g];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+  if (lane == 0) scale[n] = n < N ? mul / sqrtf(ss + 1e-10f) : 0.0f;
+}
+
 int roi_pool_pm_rmq(Act feat, const float *d_tables_pm, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset,
-                    int end_adjust, float *d_x_c8, hipStream_t s, int roi_stride, int Mp, int normalize, float mul) {
+                    int end_adjust, float *d_x_c8, hipStream_t s, int roi_stride, int Mp, int normalize, float mul, float *d_scale_out) {
   MPN_CHECK_ARG(feat.p && d_tables_pm && d_rois && d_x_c8 && N > 0 && PH > 0 && PW > 0);
   const int mp = Mp > 0 ? Mp : lin_mp(N), Cq = cdiv(feat.Cb(), 32), PP = PH * PW;
   const dim3 grid((unsigned)cdiv(N, 4), (unsigned)PP, (unsigned)Cq);
@@ -2062,6 +2130,11 @@ int roi_pool_pm_rmq(Act feat, const float *d_tables_pm, const float *d_rois, int
   hipLaunchKernelGGL(roi_pool_pm_rmq_kernel<true>, grid, dim3(256), 0, s, d_tables_pm, pixel_major_elems(feat), feat.Cb(), feat.H, feat.W, d_rois,
                      roi_stride, N, PH, PW, scale, coord_offset, end_adjust, d_x_c8, mp, part);
   MPN_CHECK_LAUNCH();
+  if (d_scale_out) {  // the consumer GEMM applies the scale (linear_c8_rowscaled): the pooled matrix is left as pooled
+    hipLaunchKernelGGL(l2norm_scale_rows_kernel, dim3(cdiv(mp, 4)), dim3(256), 0, s, part, G, N, mp, mul, d_scale_out);
+    MPN_CHECK_LAUNCH();
+    return MPN_OK;
+  }
   hipLaunchKernelGGL(l2norm_finish_rows_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, part, G, N, nrm);
   MPN_CHECK_LAUNCH();
   const size_t total = (size_t)feat.Cb() * PP * N * 2;
@@ -2256,7 +2329,7 @@ extern "C" int mpn_debug_roi_pool_rmq_mismatches(const float *d_feat_nchw, int C
     MPN_CHECK_HIP(hipMalloc(&tabpm, pixel_major_elems(a) * sizeof(float) * (L + 1)));
     MPN_CHECK_HIP(hipMemset(o2, 0, oe * 4));
     rc = build_vmax_tables_pm(a, tabpm, nullptr);
-    if (rc == MPN_OK) rc = roi_pool_pm_rmq(a, tabpm, d_rois, N, PH, PW, scale, 1.0f, 0, o2, nullptr, roi_stride, 0, 0, 1.0f);
+    if (rc == MPN_OK) rc = roi_pool_pm_rmq(a, tabpm, d_rois, N, PH, PW, scale, 1.0f, 0, o2, nullptr, roi_stride, 0, 0, 1.0f, nullptr);
     if (rc == MPN_OK) {
       hipLaunchKernelGGL(count_diff_kernel, dim3((unsigned)cdiv_sz(oe, 256)), dim3(256), 0, nullptr, o1, o2, oe, cnt);
       MPN_CHECK_LAUNCH();

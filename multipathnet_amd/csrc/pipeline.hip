@@ -265,6 +265,7 @@ struct mpn_frcnn {
   float *vmax_tab[3] = {nullptr, nullptr, nullptr};  // vertical range-max tables of the three maps (MultiPathNet ROI pools)
   bool vmax_valid = false;                            // built for the current tap_act maps
   bool vmax_pm = false;                               // ... in the pixel-major form
+  float *mix_scale = nullptr;                         // [3][Mp]: per-(map, ROI) nn.Normalize scales the mix GEMM applies
   std::vector<void *> allocs;
   Scratch scratch;  // split-K slabs, NMS masks, ... of THIS handle (bound to the calling thread by ScratchScope in every entry point)
   int device = 0;   // the handle lives on the device that was current at creation
@@ -307,10 +308,12 @@ struct ProfScope {
 MPN_KNOB(int, g_fuse_pool, 1);
 MPN_KNOB(int, g_first_k36, 1);  // 0: the first layer on the generic direct kernel
 MPN_KNOB(int, g_roi_pool_pm, 1);  // 0: ROI pooling straight from the C8P map (roi_pool_c8_kernel)
+MPN_KNOB(int, g_mix_fold, 1);     // 0: MultiPathNet's nn.Normalize scales applied in place (l2norm_apply) instead of inside the mix GEMM
 #ifdef MPN_DEBUG_HOOKS
 extern "C" void mpn_debug_set_fuse_pool(int v) { g_fuse_pool = v; }
 extern "C" void mpn_debug_set_first_k36(int v) { g_first_k36 = v; }
 extern "C" void mpn_debug_set_roi_pool_pm(int v) { g_roi_pool_pm = v; }
+extern "C" void mpn_debug_set_mix_fold(int v) { g_mix_fold = v; }
 #endif
 
 template <typename T>
@@ -459,6 +462,7 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
     TRY(pack_linear_weights(d_bbox_w, d_bbox_b, F, 4 * C, 1, p->wbbox, p->bbbox, nullptr));
     const size_t rows = (size_t)PP * p->Mp;
     TRY(dev_alloc(p, &p->fov, M * 20 * sizeof(float), true));
+    TRY(dev_alloc(p, &p->mix_scale, (size_t)3 * p->Mp * sizeof(float), true));
     TRY(dev_alloc(p, &p->tx, (size_t)(round_up(max_feat, 64) / 8) * rows * 8 * sizeof(float), true));
     TRY(dev_alloc(p, &p->ty, (size_t)(lin_np(c5) / 8) * rows * 8 * sizeof(float), true));
     TRY(dev_alloc(p, &p->tz6, (size_t)(lin_np(F) / 8) * p->Mp * 8 * sizeof(float), true));
@@ -623,18 +627,30 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
     p->vmax_valid = true;
     p->vmax_pm = pm;
   }
+  // nn.Normalize's per-(ROI, map) scale folded into the mix GEMM (linear_c8_rowscaled) when that GEMM runs un-split — always at
+  // BASELINE sizes; tiny test networks whose mix has < 128 output tiles keep the in-place l2norm_apply pass
+  const bool fold_scale = pm && p->conv345_norm && p->mix_scale && linear_c8_is_direct(PP * Mp, p->feat_c, PP * Mp) && g_mix_fold &&
+                          maps[0].C % 32 == 0 && maps[1].C % 32 == 0 && maps[2].C % 32 == 0;  // segment boundaries fall on 32-k stages
   int ti = 0;
   for (auto &T : p->towers) {
     const float *reg = p->fov + 5 * T.region;  // rows 4n + region of the Foveal table
     int cb_off = 0;
     const int used[3] = {1, T.use4, T.use3};
+    GemmRowScale grs{};
+    grs.rs_mod = Mp;
     for (int m = 0; m < 3; ++m) {
       if (!used[m]) continue;
       float *dst = p->tx + (size_t)cb_off * PP * Mp * 8;
       { ProfScope ps(p, MPN_PROF_ROIPOOL, s);
         if (pm) {
+          float *sc_out = fold_scale ? p->mix_scale + (size_t)grs.n_seg * p->Mp : nullptr;
           rc = roi_pool_pm_rmq(maps[m], p->vmax_tab[m], reg, N, c.pooled_h, c.pooled_w, scales[m], 1.0f, 0, dst, s, 20, Mp, p->conv345_norm ? 1 : 0,
-                               p->conv345_norm ? 1000.0f : kConv345Factor[m]);
+                               p->conv345_norm ? 1000.0f : kConv345Factor[m], sc_out);
+          if (fold_scale) {
+            grs.scale[grs.n_seg] = sc_out;
+            if (grs.n_seg < 2) grs.k_end[grs.n_seg] = (cb_off + maps[m].Cb()) * 8;
+            ++grs.n_seg;
+          }
         } else {
           rc = roi_pool_c8_rmq(maps[m], p->vmax_tab[m], reg, N, c.pooled_h, c.pooled_w, scales[m], 1.0f, 0, dst, s, 20, Mp);
           if (rc == MPN_OK) rc = p->conv345_norm ? l2norm_scale_c8(dst, maps[m].Cb() * PP, Mp, N, 1000.0f, s)
@@ -645,7 +661,8 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
     }
     // 1x1 conv mix: rows = (bin, roi), K = concat channels, N = feat_c; output layout == fc6 operand layout
     { ProfScope ps(p, MPN_PROF_HEADS, s);
-      rc = linear_c8(p->tx, PP * Mp, T.total_feat, T.mix_w, T.mix_b, p->feat_c, 0, p->ty, nullptr, s, PP * Mp); }
+      rc = fold_scale ? linear_c8_rowscaled(p->tx, PP * Mp, T.total_feat, T.mix_w, T.mix_b, p->feat_c, 0, p->ty, s, PP * Mp, grs)
+                      : linear_c8(p->tx, PP * Mp, T.total_feat, T.mix_w, T.mix_b, p->feat_c, 0, p->ty, nullptr, s, PP * Mp); }
     if (rc) return rc;
     { ProfScope ps(p, MPN_PROF_FC6, s); rc = linear_c8(p->ty, N, p->K6, T.w6, T.b6, F, 1, p->tz6, nullptr, s, Mp, nullptr, 1); }
     if (rc) return rc;

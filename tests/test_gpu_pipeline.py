@@ -281,6 +281,37 @@ def test_multipathnet_pixel_major_pooling_equals_c8p_form(dev):
     assert float((outs[0][0] - outs[1][0]).abs().max()) < 2e-6 and float((outs[0][1] - outs[1][1]).abs().max()) < 1e-3
 
 
+def test_multipathnet_mix_gemm_applies_the_normalisation(O, dev):
+    """Round 3: where the mix GEMM runs un-split (always at BASELINE sizes; here a 384-channel conv5 makes it so at 100 ROIs), nn.Normalize's
+    per-(ROI, map) scale is applied inside the GEMM — at the accumulator fold of each map's K segment (linear_c8_rowscaled) — instead of a
+    read-modify-write pass over the pooled matrix.  Against the oracle (<= 1e-4), and against the in-place form (fp32 rounding)."""
+    from multipathnet_amd import models
+    cfg = [16, 32, "P", 32, 64, "P", 64, 96, "P", 128, "P", 384]
+    H, W, N, Cn, K = 120, 200, 100, 6, 2
+    P = models.synthetic_mpnet_params(cfg, pooled=7, fc_dim=128, n_classes=Cn, n_integral=K, seed=5)
+    rng = np.random.default_rng(9)
+    im = rng.random((3, H, W), dtype=np.float32)
+    boxes = _boxes(rng, N, W, H, lo=12)
+    imd, bd = torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev)
+    outs = []
+    for fold in (1, 0):
+        with hooks(mix_fold=fold):
+            net = models.MultiPathNet(P, cfg=cfg, pooled=7, spatial_scale=1 / 16, max_h=H, max_w=W, max_rois=N)
+            s1, b1 = net.detect(imd, bd)
+            s2, b2 = net.detect(imd, bd)
+            torch.cuda.synchronize()
+            assert torch.equal(s1, s2) and torch.equal(b1, b2)
+            outs.append((s1.cpu().numpy(), b1.cpu().numpy()))
+    assert 0 < np.abs(outs[0][0] - outs[1][0]).max() < 1e-5      # two different roundings of the same arithmetic — and really two code paths
+    Pn = _np_tree(P)
+    taps = {}
+    O.vgg_trunk(O.image_transform(im, **O.ROSS), Pn["conv_w"], Pn["conv_b"], cfg, taps=taps)
+    ref_scores, deltas = O.mpnet_head([taps["conv5"], taps["conv4"], taps["conv3"]], O.project_im_rois(boxes, 1.0), Pn)
+    ref_bbox = O.clamp_boxes(O.bbox_decode(boxes, deltas), W, H)
+    for sc, bb in outs:
+        assert np.abs(sc - ref_scores).max() < 1e-4 and np.abs(bb - ref_bbox).max() < 1e-4 * W
+
+
 def test_alexnet_shaped_head_vs_oracle(O, dev):
     """BASELINE configs[0] head shape (models/alexnet.lua:23-27): ROIPooling(6,6,1/16) on a 256-channel map, fc6 9216->4096,
     300 selective-search-like ROIs, 21 classes, through the module-level C ABI, then clamp/select/NMS/top-k vs the oracle.
