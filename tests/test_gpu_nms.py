@@ -280,19 +280,20 @@ def test_stream_release_frees_module_level_scratch(O, dev):
             assert lib.mpn_stream_release(ctypes.c_void_p(st.cuda_stream)) == 0   # nothing left: a no-op
         return st
 
-    on_new_stream(True)                      # warm torch's allocator and the runtime's stream resources
-    torch.cuda.synchronize()
-    free0 = torch.cuda.mem_get_info()[0]
+    def free_now():
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()   # torch caches blocks PER STREAM: hand them back so that only this library's scratch is measured
+        return torch.cuda.mem_get_info()[0]
+
+    on_new_stream(True)                      # warm the runtime's stream resources
+    free0 = free_now()
     held = [on_new_stream(True) for _ in range(4)]
-    torch.cuda.synchronize()
-    grown_released = free0 - torch.cuda.mem_get_info()[0]
+    grown_released = free0 - free_now()
     held += [on_new_stream(False) for _ in range(4)]
-    torch.cuda.synchronize()
-    grown_kept = free0 - torch.cuda.mem_get_info()[0] - grown_released
+    grown_kept = free0 - free_now() - grown_released
     assert grown_kept > 3 * (20 << 20), grown_kept            # four unreleased entries of > 20 MB each
     assert grown_released < (20 << 20), grown_released        # four released ones: less than a single entry
     assert lib.mpn_release_all_scratch() == 0
-    torch.cuda.synchronize()
-    assert free0 - torch.cuda.mem_get_info()[0] < (24 << 20)  # everything is back
+    assert free0 - free_now() < (24 << 20)                    # everything is back
     keep, _, nk = utils.nms_batched(sb, None, 0.3)             # the default stream's scratch is rebuilt on demand
     assert np.array_equal(keep[0, : int(nk[0])].cpu().numpy(), ref[0])
