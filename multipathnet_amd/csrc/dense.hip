@@ -1090,7 +1090,10 @@ struct GemmArgs {
 // chunk's fragment loads (so the lgkmcnt(0) the compiler forces after LDS-DMA only covers loads issued 15 MFMAs
 // earlier), the next stage's DMA spread behind MFMAs 1-4 of the first chunk, and the stage barrier placed before the
 // LAST chunk's MFMAs so the next stage's first fragments are fetched under them.
-template <int KCH>
+// FOLD: the launch folds its accumulator into a running total at K-segment boundaries (row-invariant summation / per-row-scaled segments).
+// A separate instantiation because the total costs 64 more registers (264 > 256: one block per CU instead of two); launches that never
+// fold — split-K pieces, ResNet's pointwise convolutions, the un-scaled mix — keep the two-blocks-per-CU form.
+template <int KCH, bool FOLD>
 __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
   constexpr int OP_FLOATS = KCH * 128 * 8;
   constexpr int STAGE = 2 * OP_FLOATS;
@@ -1134,7 +1137,7 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
   float rsc[3][2];  // this lane's two rows' scales per K segment (fetched now: a load at a fold boundary would be an exposed round trip)
 #pragma unroll
   for (int sg = 0; sg < 3; ++sg) { rsc[sg][0] = 1.0f; rsc[sg][1] = 1.0f; }
-  if (a.rs0) {
+  if (FOLD && a.rs0) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const int row = (m0 + wn * 64 + ni * 32 + l31) % a.rs_mod;
@@ -1193,14 +1196,17 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
   // running total and restarted from zero — total = (((0 + s_0) + s_1) + ...), the order in which splitk_reduce_kernel adds the
   // slabs when the same GEMM runs one block per segment.  64 VALU adds per wave per boundary against >= 256 MFMAs per segment.
   f32x16 tot[2][2];
+  if constexpr (FOLD) {
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tot[mi][ni][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) tot[mi][ni][r] = 0.0f;
+  }
   int fseg = 0;  // index of the segment being accumulated
   auto fold = [&]() {
+    if constexpr (!FOLD) return;
     if (a.rs0) {  // (wave-uniform) the segment's per-row scale: tot += scale * acc
       const float s0 = fseg == 0 ? rsc[0][0] : (fseg == 1 ? rsc[1][0] : rsc[2][0]), s1 = fseg == 0 ? rsc[0][1] : (fseg == 1 ? rsc[1][1] : rsc[2][1]);
 #pragma unroll
@@ -1221,7 +1227,7 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
     ++fseg;
   };
   // fold points: explicit boundaries (sb0, sb1) or every seg_stages stages
-  int next_fold = a.nsb > 0 ? a.sb0 : (a.seg_stages > 0 ? st0 + a.seg_stages : 0x7fffffff);
+  int next_fold = !FOLD ? 0x7fffffff : (a.nsb > 0 ? a.sb0 : (a.seg_stages > 0 ? st0 + a.seg_stages : 0x7fffffff));
   auto advance = [&]() { next_fold = a.nsb > 0 ? (fseg < a.nsb ? a.sb1 : 0x7fffffff) : next_fold + a.seg_stages; };
   int st = st0;
   if (n_more & 1) { body(st, std::true_type{}, P1{}); ++st; if (st == next_fold) { fold(); advance(); } }
@@ -1267,7 +1273,7 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float t = tot[mi][ni][g * 4 + e] + b4[mi][g][e] + r4[mi][g][ni][e];
+          float t = (FOLD ? tot[mi][ni][g * 4 + e] : acc[mi][ni][g * 4 + e]) + b4[mi][g][e] + r4[mi][g][ni][e];
           if (a.direct && a.relu) t = t < 0.0f ? 0.0f : t;
           v[e] = t;
         }
@@ -1385,8 +1391,10 @@ static int linear_c8_impl(const float *d_x_c8, int M, int K, const float *d_wpk,
   if (d_res_c8 && !direct) { set_error("linear_c8: a residual needs the direct (un-split, C8 output) form"); return MPN_EINVAL; }
   a.res = d_res_c8;
   {
-    int rc_attr = kch == 8 ? set_max_dyn_lds(reinterpret_cast<const void *>(gemm_c8_pf_kernel<8>), 2 * 2 * 8 * 128 * 8 * 4)
-                           : set_max_dyn_lds(reinterpret_cast<const void *>(gemm_c8_pf_kernel<4>), 2 * 2 * 4 * 128 * 8 * 4);
+    int rc_attr = kch == 8 ? set_max_dyn_lds(reinterpret_cast<const void *>(gemm_c8_pf_kernel<8, false>), 2 * 2 * 8 * 128 * 8 * 4)
+                           : set_max_dyn_lds(reinterpret_cast<const void *>(gemm_c8_pf_kernel<4, false>), 2 * 2 * 4 * 128 * 8 * 4);
+    if (rc_attr == MPN_OK) rc_attr = kch == 8 ? set_max_dyn_lds(reinterpret_cast<const void *>(gemm_c8_pf_kernel<8, true>), 2 * 2 * 8 * 128 * 8 * 4)
+                                             : set_max_dyn_lds(reinterpret_cast<const void *>(gemm_c8_pf_kernel<4, true>), 2 * 2 * 4 * 128 * 8 * 4);
     if (rc_attr) return rc_attr;
   }
   if (direct) {
@@ -1398,8 +1406,14 @@ static int linear_c8_impl(const float *d_x_c8, int M, int K, const float *d_wpk,
     a.y = static_cast<float *>(ws);
   }
   dim3 grid((unsigned)tiles, (unsigned)S);
-  if (kch == 8) hipLaunchKernelGGL((gemm_c8_pf_kernel<8>), grid, dim3(256), (size_t)2 * 2 * 8 * 128 * 8 * 4, s, a);
-  else hipLaunchKernelGGL((gemm_c8_pf_kernel<4>), grid, dim3(256), (size_t)2 * 2 * 4 * 128 * 8 * 4, s, a);
+  const bool folds = a.seg_stages > 0 || a.nsb > 0 || a.rs0 != nullptr;
+  if (kch == 8) {
+    if (folds) hipLaunchKernelGGL((gemm_c8_pf_kernel<8, true>), grid, dim3(256), (size_t)2 * 2 * 8 * 128 * 8 * 4, s, a);
+    else hipLaunchKernelGGL((gemm_c8_pf_kernel<8, false>), grid, dim3(256), (size_t)2 * 2 * 8 * 128 * 8 * 4, s, a);
+  } else {
+    if (folds) hipLaunchKernelGGL((gemm_c8_pf_kernel<4, true>), grid, dim3(256), (size_t)2 * 2 * 4 * 128 * 8 * 4, s, a);
+    else hipLaunchKernelGGL((gemm_c8_pf_kernel<4, false>), grid, dim3(256), (size_t)2 * 2 * 4 * 128 * 8 * 4, s, a);
+  }
   MPN_CHECK_LAUNCH();
   if (!direct) {
     size_t total = (size_t)(a.NP / 8) * M;
