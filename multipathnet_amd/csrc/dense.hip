@@ -1258,7 +1258,9 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
       for (int ni = 0; ni < 2; ++ni) {
         const int m = m0 + wn * 64 + ni * 32 + l31;
         r4[mi][g][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.res && m < a.M) r4[mi][g][ni] = *reinterpret_cast<const f32x4 *>(a.res + ((size_t)nb8 * a.Mp + m) * 8 + half * 4);
+        if constexpr (!FOLD) {  // (a folding launch never carries a residual: 20 fewer registers)
+          if (a.res && m < a.M) r4[mi][g][ni] = *reinterpret_cast<const f32x4 *>(a.res + ((size_t)nb8 * a.Mp + m) * 8 + half * 4);
+        }
       }
     }
   asm volatile("" ::: "memory");
@@ -1407,6 +1409,7 @@ static int linear_c8_impl(const float *d_x_c8, int M, int K, const float *d_wpk,
   }
   dim3 grid((unsigned)tiles, (unsigned)S);
   const bool folds = a.seg_stages > 0 || a.nsb > 0 || a.rs0 != nullptr;
+  if (folds && a.res) { set_error("linear_c8: a residual cannot be combined with a folding (row-invariant / row-scaled) launch"); return MPN_EINVAL; }
   if (kch == 8) {
     if (folds) hipLaunchKernelGGL((gemm_c8_pf_kernel<8, true>), grid, dim3(256), (size_t)2 * 2 * 8 * 128 * 8 * 4, s, a);
     else hipLaunchKernelGGL((gemm_c8_pf_kernel<8, false>), grid, dim3(256), (size_t)2 * 2 * 8 * 128 * 8 * 4, s, a);
