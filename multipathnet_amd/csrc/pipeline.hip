@@ -265,7 +265,11 @@ struct mpn_frcnn {
   float *vmax_tab[3] = {nullptr, nullptr, nullptr};  // vertical range-max tables of the three maps (MultiPathNet ROI pools)
   bool vmax_valid = false;                            // built for the current tap_act maps
   bool vmax_pm = false;                               // ... in the pixel-major form
-  float *mix_scale = nullptr;                         // [3][Mp]: per-(map, ROI) nn.Normalize scales the mix GEMM applies
+  float *mix_scale = nullptr;                         // [2 tower parities][3][Mp]: per-(map, ROI) nn.Normalize scales the mix GEMM applies
+  // tower t + 1's skip pooling (L2 -> L1 bound, no matrix work) runs on its own stream under tower t's GEMMs (matrix-bound):
+  float *tx2 = nullptr;                               // second pooled-operand buffer (towers alternate between tx and tx2)
+  hipStream_t pool_stream = nullptr;
+  hipEvent_t ev_pool_done[2] = {nullptr, nullptr}, ev_mix_done[2] = {nullptr, nullptr}, ev_pool_go = nullptr;
   std::vector<void *> allocs;
   Scratch scratch;  // split-K slabs, NMS masks, ... of THIS handle (bound to the calling thread by ScratchScope in every entry point)
   int device = 0;   // the handle lives on the device that was current at creation
@@ -309,11 +313,13 @@ MPN_KNOB(int, g_fuse_pool, 1);
 MPN_KNOB(int, g_first_k36, 1);  // 0: the first layer on the generic direct kernel
 MPN_KNOB(int, g_roi_pool_pm, 1);  // 0: ROI pooling straight from the C8P map (roi_pool_c8_kernel)
 MPN_KNOB(int, g_mix_fold, 1);     // 0: MultiPathNet's nn.Normalize scales applied in place (l2norm_apply) instead of inside the mix GEMM
+MPN_KNOB(int, g_pool_overlap, 1); // 0: MultiPathNet's skip pooling on the launch stream instead of its own stream under the previous tower's GEMMs
 #ifdef MPN_DEBUG_HOOKS
 extern "C" void mpn_debug_set_fuse_pool(int v) { g_fuse_pool = v; }
 extern "C" void mpn_debug_set_first_k36(int v) { g_first_k36 = v; }
 extern "C" void mpn_debug_set_roi_pool_pm(int v) { g_roi_pool_pm = v; }
 extern "C" void mpn_debug_set_mix_fold(int v) { g_mix_fold = v; }
+extern "C" void mpn_debug_set_pool_overlap(int v) { g_pool_overlap = v; }
 #endif
 
 template <typename T>
@@ -336,6 +342,9 @@ extern "C" void mpn_frcnn_destroy(mpn_frcnn *p) {
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   for (int i = 0; i < 2; ++i) { if (p->ev_head[i]) (void)hipEventDestroy(p->ev_head[i]); if (p->ev_tail[i]) (void)hipEventDestroy(p->ev_tail[i]); }
   if (p->side) (void)hipStreamDestroy(p->side);
+  if (p->pool_stream) (void)hipStreamDestroy(p->pool_stream);
+  for (int i = 0; i < 2; ++i) { if (p->ev_pool_done[i]) (void)hipEventDestroy(p->ev_pool_done[i]); if (p->ev_mix_done[i]) (void)hipEventDestroy(p->ev_mix_done[i]); }
+  if (p->ev_pool_go) (void)hipEventDestroy(p->ev_pool_go);
   if (p->copy) (void)hipStreamDestroy(p->copy);
   for (int i = 0; i < 2; ++i) { if (p->ev_up[i]) (void)hipEventDestroy(p->ev_up[i]); if (p->ev_consumed[i]) (void)hipEventDestroy(p->ev_consumed[i]); }
   p->scratch.release();
@@ -462,7 +471,17 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
     TRY(pack_linear_weights(d_bbox_w, d_bbox_b, F, 4 * C, 1, p->wbbox, p->bbbox, nullptr));
     const size_t rows = (size_t)PP * p->Mp;
     TRY(dev_alloc(p, &p->fov, M * 20 * sizeof(float), true));
-    TRY(dev_alloc(p, &p->mix_scale, (size_t)3 * p->Mp * sizeof(float), true));
+    TRY(dev_alloc(p, &p->mix_scale, (size_t)2 * 3 * p->Mp * sizeof(float), true));
+    TRY(dev_alloc(p, &p->tx2, (size_t)(round_up(max_feat, 64) / 8) * rows * 8 * sizeof(float), true));
+    {
+      hipError_t e = hipStreamCreateWithFlags(&p->pool_stream, hipStreamNonBlocking);
+      for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipEventCreateWithFlags(&p->ev_pool_done[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_mix_done[i], hipEventDisableTiming);
+      }
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_pool_go, hipEventDisableTiming);
+      if (e != hipSuccess) { set_error("mpn_mpnet_create: pooling stream / events: %s", hipGetErrorString(e)); mpn_frcnn_destroy(p); return MPN_EHIP; }
+    }
     TRY(dev_alloc(p, &p->tx, (size_t)(round_up(max_feat, 64) / 8) * rows * 8 * sizeof(float), true));
     TRY(dev_alloc(p, &p->ty, (size_t)(lin_np(c5) / 8) * rows * 8 * sizeof(float), true));
     TRY(dev_alloc(p, &p->tz6, (size_t)(lin_np(F) / 8) * p->Mp * 8 * sizeof(float), true));
@@ -631,45 +650,79 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
   // BASELINE sizes; tiny test networks whose mix has < 128 output tiles keep the in-place l2norm_apply pass
   const bool fold_scale = pm && p->conv345_norm && p->mix_scale && linear_c8_is_direct(PP * Mp, p->feat_c, PP * Mp) && g_mix_fold &&
                           maps[0].C % 32 == 0 && maps[1].C % 32 == 0 && maps[2].C % 32 == 0;  // segment boundaries fall on 32-k stages
-  int ti = 0;
-  for (auto &T : p->towers) {
+  // Two streams: a tower's skip pooling is L2 -> L1 bound (no matrix work), its GEMMs are matrix-bound, and the folding GEMM leaves
+  // half of every CU's registers and 94 KB of LDS free.  Tower t's pooling therefore runs on the handle's pooling stream, into the
+  // operand buffer / scale set of parity t & 1, under tower t - 1's GEMMs on `s`; `s` waits for the pooling only where the mix GEMM
+  // starts, the pooling stream waits for the mix GEMM of tower t - 2 (the previous user of its buffers).  Every result is still
+  // ordered on `s`.  (Profiling scopes time each stream's own work; with overlap their sum exceeds the wall time.)
+  const bool overlap = pm && p->pool_stream && p->tx2 && g_pool_overlap;
+  hipStream_t ps_stream = overlap ? p->pool_stream : s;
+  if (overlap) {  // the tables, the Foveal regions and everything before them on `s`
+    MPN_CHECK_HIP(hipEventRecord(p->ev_pool_go, s));
+    MPN_CHECK_HIP(hipStreamWaitEvent(ps_stream, p->ev_pool_go, 0));
+  }
+  const int n_tow = (int)p->towers.size();
+  GemmRowScale grs_of[8];
+  auto pool_tower = [&](int t) -> int {  // pooling (+ normalisation scales) of tower t on the pooling stream
+    const mpn_frcnn::Tower &T = p->towers[t];
+    const int par = overlap ? (t & 1) : 0;
+    float *txb = par ? p->tx2 : p->tx;
     const float *reg = p->fov + 5 * T.region;  // rows 4n + region of the Foveal table
+    if (overlap && t >= 2) MPN_CHECK_HIP(hipStreamWaitEvent(ps_stream, p->ev_mix_done[par], 0));  // tower t - 2's mix GEMM has read this buffer
     int cb_off = 0;
     const int used[3] = {1, T.use4, T.use3};
-    GemmRowScale grs{};
+    GemmRowScale &grs = grs_of[t];
+    grs = GemmRowScale{};
     grs.rs_mod = Mp;
+    int rcl = MPN_OK;
     for (int m = 0; m < 3; ++m) {
       if (!used[m]) continue;
-      float *dst = p->tx + (size_t)cb_off * PP * Mp * 8;
-      { ProfScope ps(p, MPN_PROF_ROIPOOL, s);
+      float *dst = txb + (size_t)cb_off * PP * Mp * 8;
+      { ProfScope ps(p, MPN_PROF_ROIPOOL, ps_stream);
         if (pm) {
-          float *sc_out = fold_scale ? p->mix_scale + (size_t)grs.n_seg * p->Mp : nullptr;
-          rc = roi_pool_pm_rmq(maps[m], p->vmax_tab[m], reg, N, c.pooled_h, c.pooled_w, scales[m], 1.0f, 0, dst, s, 20, Mp, p->conv345_norm ? 1 : 0,
-                               p->conv345_norm ? 1000.0f : kConv345Factor[m], sc_out);
+          float *sc_out = fold_scale ? p->mix_scale + ((size_t)par * 3 + grs.n_seg) * p->Mp : nullptr;
+          rcl = roi_pool_pm_rmq(maps[m], p->vmax_tab[m], reg, N, c.pooled_h, c.pooled_w, scales[m], 1.0f, 0, dst, ps_stream, 20, Mp, p->conv345_norm ? 1 : 0,
+                                p->conv345_norm ? 1000.0f : kConv345Factor[m], sc_out);
           if (fold_scale) {
             grs.scale[grs.n_seg] = sc_out;
             if (grs.n_seg < 2) grs.k_end[grs.n_seg] = (cb_off + maps[m].Cb()) * 8;
             ++grs.n_seg;
           }
         } else {
-          rc = roi_pool_c8_rmq(maps[m], p->vmax_tab[m], reg, N, c.pooled_h, c.pooled_w, scales[m], 1.0f, 0, dst, s, 20, Mp);
-          if (rc == MPN_OK) rc = p->conv345_norm ? l2norm_scale_c8(dst, maps[m].Cb() * PP, Mp, N, 1000.0f, s)
-                                                 : mul_const_c8(dst, maps[m].Cb() * PP, Mp, N, kConv345Factor[m], s);
+          rcl = roi_pool_c8_rmq(maps[m], p->vmax_tab[m], reg, N, c.pooled_h, c.pooled_w, scales[m], 1.0f, 0, dst, ps_stream, 20, Mp);
+          if (rcl == MPN_OK) rcl = p->conv345_norm ? l2norm_scale_c8(dst, maps[m].Cb() * PP, Mp, N, 1000.0f, ps_stream)
+                                                   : mul_const_c8(dst, maps[m].Cb() * PP, Mp, N, kConv345Factor[m], ps_stream);
         } }
-      if (rc) return rc;
+      if (rcl) return rcl;
       cb_off += maps[m].Cb();
     }
+    if (overlap) MPN_CHECK_HIP(hipEventRecord(p->ev_pool_done[par], ps_stream));
+    return MPN_OK;
+  };
+  MPN_CHECK_ARG(n_tow <= 8);
+  rc = pool_tower(0);
+  if (rc) return rc;
+  for (int ti = 0; ti < n_tow; ++ti) {
+    const mpn_frcnn::Tower &T = p->towers[ti];
+    const int par = overlap ? (ti & 1) : 0;
+    const float *txb = par ? p->tx2 : p->tx;
+    if (overlap) {
+      MPN_CHECK_HIP(hipStreamWaitEvent(s, p->ev_pool_done[par], 0));
+      if (ti + 1 < n_tow) { rc = pool_tower(ti + 1); if (rc) return rc; }  // enqueued now: runs under this tower's GEMMs
+    }
+    const GemmRowScale &grs = grs_of[ti];
     // 1x1 conv mix: rows = (bin, roi), K = concat channels, N = feat_c; output layout == fc6 operand layout
     { ProfScope ps(p, MPN_PROF_HEADS, s);
-      rc = fold_scale ? linear_c8_rowscaled(p->tx, PP * Mp, T.total_feat, T.mix_w, T.mix_b, p->feat_c, 0, p->ty, s, PP * Mp, grs)
-                      : linear_c8(p->tx, PP * Mp, T.total_feat, T.mix_w, T.mix_b, p->feat_c, 0, p->ty, nullptr, s, PP * Mp); }
+      rc = fold_scale ? linear_c8_rowscaled(txb, PP * Mp, T.total_feat, T.mix_w, T.mix_b, p->feat_c, 0, p->ty, s, PP * Mp, grs)
+                      : linear_c8(txb, PP * Mp, T.total_feat, T.mix_w, T.mix_b, p->feat_c, 0, p->ty, nullptr, s, PP * Mp); }
     if (rc) return rc;
+    if (overlap) MPN_CHECK_HIP(hipEventRecord(p->ev_mix_done[par], s));
     { ProfScope ps(p, MPN_PROF_FC6, s); rc = linear_c8(p->ty, N, p->K6, T.w6, T.b6, F, 1, p->tz6, nullptr, s, Mp, nullptr, 1); }
     if (rc) return rc;
     { ProfScope ps(p, MPN_PROF_FC7, s);
       rc = linear_c8(p->tz6, N, F, T.w7, T.b7, F, 1, p->cat + (size_t)ti * Fcb * Mp * 8, nullptr, s, Mp, nullptr, 1); }
     if (rc) return rc;
-    ++ti;
+    if (!overlap && ti + 1 < n_tow) { rc = pool_tower(ti + 1); if (rc) return rc; }
   }
   return run_integral_heads(p, d_boxes, N, H, W, (int)p->towers.size() - 1, s, clamp);
 }

@@ -281,6 +281,36 @@ def test_multipathnet_pixel_major_pooling_equals_c8p_form(dev):
     assert float((outs[0][0] - outs[1][0]).abs().max()) < 2e-6 and float((outs[0][1] - outs[1][1]).abs().max()) < 1e-3
 
 
+def test_multipathnet_pooling_stream_overlap_is_invisible(dev):
+    """Round 3: tower t + 1's skip pooling runs on the handle's pooling stream under tower t's GEMMs (two operand buffers, event
+    hand-offs).  Pure scheduling: scores / boxes / detections are bit-identical to the single-stream order, call after call —
+    a missing wait between the pooling stream and the launch stream would show up here as a mismatch or as run-to-run noise."""
+    from multipathnet_amd import models
+    cfg = [16, 32, "P", 32, 64, "P", 64, 96, "P", 128, "P", 384]
+    H, W, N, Cn, K = 120, 200, 100, 6, 2
+    P = models.synthetic_mpnet_params(cfg, pooled=7, fc_dim=128, n_classes=Cn, n_integral=K, seed=5)
+    rng = np.random.default_rng(9)
+    ims = [torch.from_numpy(rng.random((3, H, W), dtype=np.float32)).to(dev) for _ in range(3)]
+    bxs = [torch.from_numpy(_boxes(rng, N - 7 * i, W, H, lo=12)).to(dev) for i in range(3)]
+    res = {}
+    for ov in (1, 0):
+        with hooks(pool_overlap=ov):
+            net = models.MultiPathNet(P, cfg=cfg, pooled=7, spatial_scale=1 / 16, max_h=H, max_w=W, max_rois=N, num_iter=2)
+            outs = []
+            for rep in range(4):
+                for im, bx in zip(ims, bxs):
+                    s1, b1 = net.detect(im, bx)
+                    d, n = net.test_one_async(im, bx)
+                    torch.cuda.synchronize()
+                    outs.append((s1.clone(), b1.clone(), d[: int(n.item())].clone()))
+            for rep in range(1, 4):
+                for i in range(3):
+                    assert all(torch.equal(x, y) for x, y in zip(outs[i], outs[3 * rep + i]))
+            res[ov] = outs[:3]
+    for a, b in zip(res[1], res[0]):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
 def test_multipathnet_mix_gemm_applies_the_normalisation(O, dev):
     """Round 3: where the mix GEMM runs un-split (always at BASELINE sizes; here a 384-channel conv5 makes it so at 100 ROIs), nn.Normalize's
     per-(ROI, map) scale is applied inside the GEMM — at the accumulator fold of each map's K segment (linear_c8_rowscaled) — instead of a
