@@ -7,6 +7,9 @@ nms_cases.npz   inputs + outputs of the reference's OWN nms.c (compiled unmodifi
                 vector of test.lua:40-52.  These pin both the C restatement and the HIP kernels.
 modules.npz     small inputs/outputs of the Lua-source-pinned modules as restated by the oracle (regression pin).
 frcnn_small.npz a tiny VGG-shaped Fast R-CNN image: inputs, weights seed and the oracle's scores / boxes.
+nms_dense.npz   (round 3; `python tests/golden/make_golden.py nms_dense` writes only this file) utils.nms_dense (utils.lua:402-462) as
+                restated by the oracle — a REGRESSION PIN of the restatement, not a reference vector (no Lua runtime exists here; the
+                order among bit-equal scores is the oracle's stable sort, unpinned against TH's quicksort).
 """
 import os
 import sys
@@ -22,7 +25,26 @@ from oracle import mpn_oracle as O  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def make_nms_dense():
+    out = {}
+    rng = np.random.default_rng(20260924)
+    i = 0
+    for regime in ("distinct", "ties", "saturated"):
+        for n in (1, 7, 64, 65, 300, 1000):
+            sb = random_scored_boxes(rng, n, regime, span=300.0 if n <= 65 else 1000.0)
+            for thr in (0.3, 0.5):
+                out["d%d_in" % i], out["d%d_thr" % i], out["d%d_pick" % i] = sb, np.float32(thr), O.nms_dense(sb, thr).astype(np.int32)
+                i += 1
+    out["n_cases"] = np.int32(i)
+    np.savez_compressed(os.path.join(HERE, "nms_dense.npz"), **out)
+
+
 def main():
+    if sys.argv[1:] == ["nms_dense"]:
+        make_nms_dense()
+        print("wrote nms_dense.npz")
+        return
+    make_nms_dense()
     assert O.have_ref(), "needs oracle/_ref/libnms_ref.so (make -C oracle ref with /root/reference present)"
     out = {}
     rng = np.random.default_rng(20260923)

@@ -71,3 +71,21 @@ def test_hip_reproduces_module_and_pipeline_goldens(dev):
     assert np.abs(bbox.cpu().numpy() - f["bbox"]).max() < 1e-4 * W
     conv5 = net.debug_tensor("conv5", f["conv5"].shape).cpu().numpy()
     assert np.abs(conv5 - f["conv5"]).max() < 1e-4 * max(1.0, np.abs(f["conv5"]).max())
+
+
+def test_oracle_reproduces_nms_dense_pins(O):
+    """utils.nms_dense: oracle-generated regression pins (tests/golden/nms_dense.npz; not reference vectors — see make_golden.py)"""
+    z = np.load(os.path.join(G, "nms_dense.npz"))
+    n = int(z["n_cases"])
+    assert n == 36
+    for i in range(n):
+        assert np.array_equal(O.nms_dense(z["d%d_in" % i], float(z["d%d_thr" % i])), z["d%d_pick" % i]), i
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_nms_dense_pins(dev):
+    from multipathnet_amd import utils
+    z = np.load(os.path.join(G, "nms_dense.npz"))
+    for i in range(int(z["n_cases"])):
+        got = utils.nms_dense(torch.from_numpy(z["d%d_in" % i]).to(dev), float(z["d%d_thr" % i]))
+        assert np.array_equal(got.cpu().numpy(), z["d%d_pick" % i]), i
