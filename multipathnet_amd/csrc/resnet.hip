@@ -1171,6 +1171,75 @@ __global__ __launch_bounds__(256) void roi_pool_c8i_bf16_sorted_kernel(const u32
   }
 }
 
+// max-pool OF the ROI-pooled map, straight from the feature map (graph heads: Inception's Mixed_7a pools its input — the ROI-pooled
+// 17 x 17 x 768 tensor, 0.9 GB for 2000 ROIs — 3 x 3 / 2; max of maxes = one max over the union of the bins' windows).  Output pixel
+// (oy, ox) covers bins [o * stride - pad, + k) clipped to the bin grid; consecutive bins touch or overlap (ceil((b + 1) h) >= floor((b + 1) h)),
+// so the union of their windows is ONE window of the map; a bin that falls outside the map is empty and holds 0 in the pooled tensor, so 0
+// joins the max when the group has one.  Bin bounds are the pooling kernel's own expressions; max is exact: the result is the two-step
+// result bit for bit (up to the sign of a zero), and the max-pool launch that re-read the pooled tensor (210 us, 5.2 TB/s) is gone.
+template <int CBG>
+__global__ __launch_bounds__(256) void roi_maxpool_c8i_bf16_sorted_kernel(const u32x4 *__restrict__ feat, int H, int W, size_t pitch_f,
+                                                                           const float *__restrict__ rois, int roi_stride, int N, int PH, int PW, float scale,
+                                                                           int k, int stride, int pad, int OH, int OW, u32x4 *__restrict__ out, size_t pitch_o) {
+  const int OP = OH * OW;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (roi, output pixel): the output row of the max-pooled batch
+  if (t >= (size_t)N * OP) return;
+  const int n = (int)(t / OP), o = (int)(t - (size_t)n * OP);
+  const int oy = o / OW, ox = o - oy * OW;
+  const float *ro = rois + (size_t)roi_stride * n;
+  const int sw = (int)roundf((ro[1] - 1.0f) * scale), sh = (int)roundf((ro[2] - 1.0f) * scale);
+  const int ew = (int)roundf((ro[3] - 1.0f) * scale), eh = (int)roundf((ro[4] - 1.0f) * scale);
+  const int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
+  const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+  bool any_empty = false;
+  int hs = 0x7fffffff, he = -1, ws = 0x7fffffff, we = -1;
+  for (int ph = max(oy * stride - pad, 0); ph < min(oy * stride - pad + k, PH); ++ph) {
+    int a = (int)floorf((float)ph * bh) + sh, b = (int)ceilf((float)(ph + 1) * bh) + sh;
+    a = min(max(a, 0), H); b = min(max(b, 0), H);
+    if (b <= a) any_empty = true; else { hs = min(hs, a); he = max(he, b); }
+  }
+  for (int pw = max(ox * stride - pad, 0); pw < min(ox * stride - pad + k, PW); ++pw) {
+    int a = (int)floorf((float)pw * bw) + sw, b = (int)ceilf((float)(pw + 1) * bw) + sw;
+    a = min(max(a, 0), W); b = min(max(b, 0), W);
+    if (b <= a) any_empty = true; else { ws = min(ws, a); we = max(we, b); }
+  }
+  const int cb0 = blockIdx.y * CBG;
+  const u32x4 *fp = feat + (size_t)cb0 * pitch_f;
+  u32x4 *op = out + (size_t)cb0 * pitch_o + t;
+  const unsigned lowest = 0x80008000u;  // int16 minimum in both halves
+  u32x4 m[CBG];
+#pragma unroll
+  for (int c = 0; c < CBG; ++c) m[c] = u32x4{lowest, lowest, lowest, lowest};
+  for (int y = hs; y < he; ++y)
+    for (int x = ws; x < we; ++x) {
+      const size_t px = (size_t)y * W + x;
+#pragma unroll
+      for (int c = 0; c < CBG; ++c) {
+        const u32x4 v = fp[(size_t)c * pitch_f + px];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned cur = m[c][e], val = v[e];
+          const i16x2 mx = __builtin_elementwise_max(__builtin_bit_cast(i16x2, cur), __builtin_bit_cast(i16x2, val));
+          m[c][e] = __builtin_bit_cast(unsigned, mx);
+        }
+      }
+    }
+#pragma unroll
+  for (int c = 0; c < CBG; ++c) {
+    u32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned cur = m[c][e];
+      if (any_empty) {  // an empty bin's 0.0 (sortable code 0) takes part in the max
+        const i16x2 mx = __builtin_elementwise_max(__builtin_bit_cast(i16x2, cur), i16x2{0, 0});
+        cur = __builtin_bit_cast(unsigned, mx);
+      }
+      r[e] = bf16x2_sortable(cur);
+    }
+    op[(size_t)c * pitch_o] = r;
+  }
+}
+
 // average pool of the bf16 maps into the fp32 C8 matrix the (fp32) head GEMM reads.  Block = one channel block x 16 maps: the
 // 16 * HW records are read as consecutive 16-byte loads (fully coalesced) into LDS as fp32, then 128 threads (map, channel) sum
 // their HW values in pixel order (the order of the plain kernel below, so the result is bit-identical to it).
@@ -1402,6 +1471,7 @@ struct GOp {
   float lrn_alpha = 0.f, lrn_beta = 0.f, lrn_k = 1.f;
   RnConv conv;
   float *pool_bias = nullptr;  // average pool only: bias (+ ReLU if relu) applied after the pool (commuted pool -> pointwise convolution)
+  bool from_rois = false;      // head graphs: a max-pool of the ROI-pooled input itself -> computed from the feature map (roi_maxpool_c8i_bf16_sorted_kernel)
 };
 struct ResNetGraph {
   // op-list mode (graph_build): branching graphs; tensor 0 = image (trunk) / ROI-pooled map (head)
@@ -1777,7 +1847,7 @@ static int graph_dims(const std::vector<GOp> &ops, std::vector<GTensor> &ts, int
   return MPN_OK;
 }
 
-MPN_KNOB(int, g_graph_fuse, 3);  // mpn_debug_set_graph_fuse: bit 0 = fuse sibling pointwise convolutions, bit 1 = commute average-pool -> pointwise convolution; 0 = run the op list as given
+MPN_KNOB(int, g_graph_fuse, 7);  // mpn_debug_set_graph_fuse: bit 0 = fuse sibling pointwise convolutions, bit 1 = commute average-pool -> pointwise convolution, bit 2 = max-pools of the ROI-pooled input computed from the feature map; 0 = run the op list as given
 static int graph_parse(ResNetGraph *g, int n_ops, const mpn_graph_op *ops_in, int n_t, const int *tc, std::vector<GOp> &out, std::vector<GTensor> &ts) {
   MPN_CHECK_ARG(n_ops > 0 && ops_in && n_t > 1 && tc);
   ts.resize(n_t);
@@ -1923,6 +1993,10 @@ int graph_build(const mpn_graph_weights *gw, int max_h, int max_w, int max_rois,
   g->g_heads.resize(n_heads);
   for (int t = 0; rc == MPN_OK && t < n_heads; ++t)
     rc = graph_parse(g, gw->n_head_ops, gw->head_ops + (size_t)t * gw->n_head_ops, gw->n_head_tensors, gw->head_tensor_c, g->g_heads[t], g->t_head);
+    if (rc == MPN_OK)
+      for (GOp &op : g->g_heads[t])
+        if (op.kind == 1 && op.src == 0 && op.src_c_off == 0 && op.cin == g->t_head[0].C && op.kh == op.kw && op.sh == op.sw && op.ph == op.pw && !op.ceil_mode)
+          op.from_rois = true;
   if (rc == MPN_OK && (g->t_trunk[0].C != 3 || g->t_head[0].C != g->t_trunk[g->feat_tensor].C)) {
     set_error("graph: tensor 0 must be the 3-channel image (trunk) / carry the feature tensor's channels (head)");
     rc = MPN_EINVAL;
@@ -1955,9 +2029,10 @@ int graph_build(const mpn_graph_weights *gw, int max_h, int max_w, int max_rois,
 }
 
 // run one op list on a batch of B maps; dims must have been propagated (graph_dims)
-static int graph_run(ResNetGraph *g, const std::vector<GOp> &ops, std::vector<GTensor> &ts, int B, hipStream_t s) {
+static int graph_run(ResNetGraph *g, const std::vector<GOp> &ops, std::vector<GTensor> &ts, int B, hipStream_t s, bool skip_from_rois = false) {
   const size_t esz = g->bf16 ? sizeof(bf16_t) : sizeof(float);
   for (const GOp &op : ops) {
+    if (skip_from_rois && op.from_rois) continue;  // already produced from the feature map (resnet_head_forward)
     GTensor src = ts[op.src];
     if (src.alias_of >= 0) {  // channel-plane view of a fused tensor (same rows, so the same pitch)
       const GTensor &par = ts[src.alias_of];
@@ -2063,6 +2138,8 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
   MPN_CHECK_ARG(g && g->feat && d_rois && d_feat_c8 && N > 0 && N <= g->max_rois && head >= 0 && head < (int)g->heads.size());
   const int Cb = (g->feat_c + 7) / 8, PH = g->pooled;
   float *const pool_dst = g->is_graph ? g->t_head[0].buf : g->hb[0];
+  const bool fuse_mp = g->is_graph && g->bf16 && (g_bf16_fast_pool & 1) && Cb % 4 == 0 && (g_graph_fuse & 4);  // max-pools of the pooled input: from the map
+  if (g->is_graph) { int rc = graph_dims(g->g_heads[head], g->t_head, PH, PH); if (rc) return rc; }
   {
     const size_t total = (size_t)N * Cb * PH * PH * 2;
     const ActI fa{g->feat, 1, g->feat_c, g->feat_h, g->feat_w}, pa{pool_dst, N, g->feat_c, PH, PH};
@@ -2083,6 +2160,17 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
       hipLaunchKernelGGL(roi_pool_c8i_bf16_sorted_kernel<4>, dim3((unsigned)cdiv_sz((size_t)N * PH * PH, 256), (unsigned)(Cb / 4)), dim3(256), 0, s,
                          reinterpret_cast<const u32x4 *>(g->feat_sorted), g->feat_h, g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale,
                          reinterpret_cast<u32x4 *>(pool_dst), pa.pitch());
+      if (fuse_mp)
+        for (const GOp &op : g->g_heads[head]) {
+          if (!op.from_rois) continue;
+          MPN_CHECK_LAUNCH();
+          const GTensor &dst = g->t_head[op.dst];
+          const ActI od{dst.buf, N, dst.C, dst.H, dst.W};
+          char *outp = reinterpret_cast<char *>(dst.buf) + (size_t)(op.dst_c_off / 8) * od.pitch() * 8 * sizeof(bf16_t);  // plane offset = the concat
+          hipLaunchKernelGGL(roi_maxpool_c8i_bf16_sorted_kernel<4>, dim3((unsigned)cdiv_sz((size_t)N * dst.H * dst.W, 256), (unsigned)(Cb / 4)), dim3(256), 0, s,
+                             reinterpret_cast<const u32x4 *>(g->feat_sorted), g->feat_h, g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale,
+                             op.kh, op.sh, op.ph, dst.H, dst.W, reinterpret_cast<u32x4 *>(outp), od.pitch());
+        }
     } else if (g->bf16)
       hipLaunchKernelGGL(roi_pool_c8i_bf16_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, reinterpret_cast<const bf16_t *>(g->feat), Cb, g->feat_h,
                          g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale, reinterpret_cast<bf16_t *>(pool_dst), pa.pitch());
@@ -2096,8 +2184,7 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
   }
   ActI cur{pool_dst, N, g->feat_c, PH, PH}, y;
   if (g->is_graph) {
-    int rc = graph_dims(g->g_heads[head], g->t_head, PH, PH);
-    if (rc == MPN_OK) rc = graph_run(g, g->g_heads[head], g->t_head, N, s);
+    int rc = graph_run(g, g->g_heads[head], g->t_head, N, s, fuse_mp);
     if (rc) return rc;
     const GTensor &o = g->t_head[g->out_tensor];
     cur = ActI{o.buf, N, o.C, o.H, o.W};

@@ -87,8 +87,8 @@ def test_inception_sibling_fusion_equivalent(dev, bf16):
     G = models.synthetic_inception_v3_params(n_classes=C, width=0.25, seed=31)
     im, boxes = _inputs(H, W, N, 21)
     out = []
-    for fuse in (3, 0, 1):
-        with hooks(graph_fuse=fuse):  # 3 = the product library
+    for fuse in (3, 0, 1, 7):
+        with hooks(graph_fuse=fuse):  # 7 = the product library (3 + the max-pool of the ROI-pooled input computed from the feature map)
             net = models.InceptionFRCNN(G, max_h=H, max_w=W, max_rois=32, top_k=10, bf16=bf16)
             s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
             out.append((s.cpu().numpy().copy(), b.cpu().numpy().copy()))
@@ -97,3 +97,6 @@ def test_inception_sibling_fusion_equivalent(dev, bf16):
     assert np.abs(out[2][1] - out[1][1]).max() < (0.25 if bf16 else 1e-3)
     assert np.abs(out[0][0] - out[1][0]).max() < (2e-3 if bf16 else 2e-5)   # + the commuted pools
     assert np.abs(out[0][1] - out[1][1]).max() < (0.5 if bf16 else 5e-3)
+    # bit 2 (bf16 only; fp32 graphs ignore it): Mixed_7a's max-pool of the ROI-pooled input taken straight from the feature map — max of
+    # maxes over the union of the bins' windows, exact: identical scores and boxes
+    assert np.array_equal(out[3][0], out[0][0]) and np.array_equal(out[3][1], out[0][1])
