@@ -1991,12 +1991,13 @@ int graph_build(const mpn_graph_weights *gw, int max_h, int max_w, int max_rois,
   const int n_heads = gw->n_heads > 1 ? gw->n_heads : 1;
   MPN_CHECK_ARG(n_heads <= 8);
   g->g_heads.resize(n_heads);
-  for (int t = 0; rc == MPN_OK && t < n_heads; ++t)
+  for (int t = 0; rc == MPN_OK && t < n_heads; ++t) {
     rc = graph_parse(g, gw->n_head_ops, gw->head_ops + (size_t)t * gw->n_head_ops, gw->n_head_tensors, gw->head_tensor_c, g->g_heads[t], g->t_head);
     if (rc == MPN_OK)
       for (GOp &op : g->g_heads[t])
         if (op.kind == 1 && op.src == 0 && op.src_c_off == 0 && op.cin == g->t_head[0].C && op.kh == op.kw && op.sh == op.sw && op.ph == op.pw && !op.ceil_mode)
           op.from_rois = true;
+  }
   if (rc == MPN_OK && (g->t_trunk[0].C != 3 || g->t_head[0].C != g->t_trunk[g->feat_tensor].C)) {
     set_error("graph: tensor 0 must be the 3-channel image (trunk) / carry the feature tensor's channels (head)");
     rc = MPN_EINVAL;
