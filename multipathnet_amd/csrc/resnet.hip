@@ -1240,95 +1240,6 @@ __global__ __launch_bounds__(256) void roi_maxpool_c8i_bf16_sorted_kernel(const 
   }
 }
 
-// ---- the same two gathers from a PIXEL-MAJOR sortable copy of the map, transposed through LDS (round 3) -------------------------------
-// The row-per-thread kernels above read 16 bytes per lane from 64 different pixels' records (C8I is channel-block-major): the fused
-// max-pool measured 295 us for a 197 MB output (floor 35 us).  Here the map is additionally kept as [pixel][Cb] 16-byte records (3.2 MB for
-// Inception's 35 x 60 x 768), a wave walks ONE output row's window with its lanes on consecutive channel blocks — a load is up to 1 KiB
-// contiguous — and a block's 16 output rows are transposed through LDS so that every channel-block plane receives 256 contiguous bytes.
-// k = 1, stride = 1, pad = 0, OH x OW = PH x PW is the plain ROI pooling.  Same bins, same max: bit-identical to the kernels above.
-__global__ void bf16_sortable_pm_kernel(const u32x4 *__restrict__ in, int Cb, size_t HW, size_t pitch, u32x4 *__restrict__ out) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (pixel, channel block)
-  if (t >= HW * (size_t)Cb) return;
-  const size_t px = t / Cb;
-  const int cb = (int)(t - px * Cb);
-  u32x4 v = in[(size_t)cb * pitch + px];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = bf16x2_sortable(v[e]);
-  out[t] = v;
-}
-
-__global__ __launch_bounds__(256) void roi_maxpool_pm_bf16_kernel(const u32x4 *__restrict__ pm, int Cb, int H, int W, const float *__restrict__ rois,
-                                                                  int roi_stride, int N, int PH, int PW, float scale, int k, int stride, int pad,
-                                                                  int OH, int OW, u32x4 *__restrict__ out, size_t pitch_o) {
-  extern __shared__ __attribute__((aligned(16))) u32x4 tile[];  // [16 rows][Cb]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int OP = OH * OW;
-  const size_t total = (size_t)N * OP, t0 = (size_t)blockIdx.x * 16;
-  const unsigned lowest = 0x80008000u;  // int16 minimum in both halves
-  for (int r = 0; r < 4; ++r) {
-    const int row = wave * 4 + r;
-    const size_t t = t0 + row;
-    if (t >= total) break;  // wave-uniform
-    const int n = (int)(t / OP), o = (int)(t - (size_t)n * OP);
-    const int oy = o / OW, ox = o - oy * OW;
-    const float *ro = rois + (size_t)roi_stride * n;
-    const int sw = (int)roundf((ro[1] - 1.0f) * scale), sh = (int)roundf((ro[2] - 1.0f) * scale);
-    const int ew = (int)roundf((ro[3] - 1.0f) * scale), eh = (int)roundf((ro[4] - 1.0f) * scale);
-    const int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
-    const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
-    bool any_empty = false;
-    int hs = 0x7fffffff, he = -1, ws = 0x7fffffff, we = -1;
-    for (int ph = max(oy * stride - pad, 0); ph < min(oy * stride - pad + k, PH); ++ph) {
-      int a = (int)floorf((float)ph * bh) + sh, b = (int)ceilf((float)(ph + 1) * bh) + sh;
-      a = min(max(a, 0), H); b = min(max(b, 0), H);
-      if (b <= a) any_empty = true; else { hs = min(hs, a); he = max(he, b); }
-    }
-    for (int pw = max(ox * stride - pad, 0); pw < min(ox * stride - pad + k, PW); ++pw) {
-      int a = (int)floorf((float)pw * bw) + sw, b = (int)ceilf((float)(pw + 1) * bw) + sw;
-      a = min(max(a, 0), W); b = min(max(b, 0), W);
-      if (b <= a) any_empty = true; else { ws = min(ws, a); we = max(we, b); }
-    }
-    for (int c0 = 0; c0 < Cb; c0 += 64) {
-      const int cb = c0 + lane;
-      u32x4 m = u32x4{lowest, lowest, lowest, lowest};
-      if (cb < Cb) {
-        for (int y = hs; y < he; ++y) {
-          const u32x4 *rowp = pm + ((size_t)y * W) * Cb + cb;
-          for (int xb = ws; xb < we; xb += 4) {  // four independent loads in flight; positions past the window re-read its last column
-            u32x4 v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = rowp[(size_t)min(xb + j, we - 1) * Cb];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const unsigned cur = m[e], val = v[j][e];
-                const i16x2 mx = __builtin_elementwise_max(__builtin_bit_cast(i16x2, cur), __builtin_bit_cast(i16x2, val));
-                m[e] = __builtin_bit_cast(unsigned, mx);
-              }
-          }
-        }
-        u32x4 res;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          unsigned cur = m[e];
-          if (any_empty) {  // an empty bin's 0.0 (sortable code 0) takes part in the max
-            const i16x2 mx = __builtin_elementwise_max(__builtin_bit_cast(i16x2, cur), i16x2{0, 0});
-            cur = __builtin_bit_cast(unsigned, mx);
-          }
-          res[e] = (he <= hs || we <= ws) && !any_empty ? 0u : bf16x2_sortable(cur);
-        }
-        tile[(size_t)row * Cb + cb] = res;
-      }
-    }
-  }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < Cb * 16; idx += 256) {
-    const int cb = idx >> 4, row = idx & 15;
-    if (t0 + row < total) out[(size_t)cb * pitch_o + t0 + row] = tile[(size_t)row * Cb + cb];
-  }
-}
-
 // average pool of the bf16 maps into the fp32 C8 matrix the (fp32) head GEMM reads.  Block = one channel block x 16 maps: the
 // 16 * HW records are read as consecutive 16-byte loads (fully coalesced) into LDS as fp32, then 128 threads (map, channel) sum
 // their HW values in pixel order (the order of the plain kernel below, so the result is bit-identical to it).
@@ -1583,7 +1494,6 @@ struct ResNetGraph {
   bf16_t *feat_sorted = nullptr; // order-preserving int16 re-coding of the cached feature map (bf16 ROI pooling), rebuilt per trunk run
   size_t feat_sorted_elems = 0;
   bool feat_sorted_valid = false;
-  bf16_t *feat_sorted_pm = nullptr;  // the same re-coding as [pixel][Cb] records (roi_maxpool_pm_bf16_kernel), rebuilt with feat_sorted
   float *splitk_ws = nullptr;    // fp32 partial slabs of split-K convolutions (bf16 graph; one stream at a time, like tb / hb)
   std::vector<void *> allocs;
 };
@@ -1646,7 +1556,7 @@ static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b
 
 MPN_KNOB(unsigned long long *, g_bf16_trace, nullptr);  // mpn_debug_set_bf16_trace (tools/dma_trace.py)
 MPN_KNOB(int, g_bf16_trace_kh, 3);
-MPN_KNOB(int, g_bf16_fast_pool, 7);       // bit 0: row-per-thread ROI pooling (bf16: on the int16-sortable map), bit 1: LDS average pooling (bf16), bit 2 (with bit 0, bf16): the ROI gathers from the pixel-major copy, transposed through LDS (0 = the plain kernels; mpn_debug_set_bf16_fast_pool)
+MPN_KNOB(int, g_bf16_fast_pool, 3);       // bit 0: row-per-thread ROI pooling (bf16: on the int16-sortable map), bit 1: LDS average pooling (bf16) (0 = the plain kernels; mpn_debug_set_bf16_fast_pool)
 MPN_KNOB(int, g_fp32_pf, 1);              // fp32 graph: conv2d_c8i_pf_kernel for 32-channel-stage layers (0 = conv2d_c8i_kernel<4>; mpn_debug_set_fp32_pf)
 MPN_KNOB(int, g_split_max_tiles, 192);     // split-K only layers with fewer 128 x 128 tiles than this (mpn_debug_set_split_max_tiles)
 MPN_KNOB(int, g_bf16_split_target, 256);  // split-K (both dtypes) aims at this many blocks (0 = never split; mpn_debug_set_bf16_split_target)
@@ -2238,26 +2148,16 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
       const size_t need = (size_t)Cb * fa.pitch() * 8;
       if (g->feat_sorted_elems < need) {  // first use (or a larger image than any before): outside the steady state
         float *q = nullptr;
-        int rc = rn_alloc(g, &q, 2 * need * sizeof(bf16_t));  // C8I form + pixel-major form
+        int rc = rn_alloc(g, &q, need * sizeof(bf16_t));
         if (rc) return rc;
-        g->feat_sorted = reinterpret_cast<bf16_t *>(q); g->feat_sorted_pm = g->feat_sorted + need; g->feat_sorted_elems = need; g->feat_sorted_valid = false;
+        g->feat_sorted = reinterpret_cast<bf16_t *>(q); g->feat_sorted_elems = need; g->feat_sorted_valid = false;
       }
-      const size_t HWf = (size_t)g->feat_h * g->feat_w;
-      const bool pm_gather = (g_bf16_fast_pool & 4) && (size_t)16 * Cb * sizeof(u32x4) <= 64 * 1024;
       if (!g->feat_sorted_valid) {
         hipLaunchKernelGGL(bf16_sortable_kernel, dim3((unsigned)cdiv_sz(need / 8, 256)), dim3(256), 0, s, reinterpret_cast<const u32x4 *>(g->feat), need / 8,
                            reinterpret_cast<u32x4 *>(g->feat_sorted));
         MPN_CHECK_LAUNCH();
-        hipLaunchKernelGGL(bf16_sortable_pm_kernel, dim3((unsigned)cdiv_sz(HWf * Cb, 256)), dim3(256), 0, s, reinterpret_cast<const u32x4 *>(g->feat), Cb, HWf,
-                           fa.pitch(), reinterpret_cast<u32x4 *>(g->feat_sorted_pm));
-        MPN_CHECK_LAUNCH();
         g->feat_sorted_valid = true;
       }
-      if (pm_gather)
-        hipLaunchKernelGGL(roi_maxpool_pm_bf16_kernel, dim3((unsigned)cdiv_sz((size_t)N * PH * PH, 16)), dim3(256), (size_t)16 * Cb * sizeof(u32x4), s,
-                           reinterpret_cast<const u32x4 *>(g->feat_sorted_pm), Cb, g->feat_h, g->feat_w, d_rois, roi_stride, N, PH, PH, spatial_scale, 1, 1, 0, PH, PH,
-                           reinterpret_cast<u32x4 *>(pool_dst), pa.pitch());
-      else
       hipLaunchKernelGGL(roi_pool_c8i_bf16_sorted_kernel<4>, dim3((unsigned)cdiv_sz((size_t)N * PH * PH, 256), (unsigned)(Cb / 4)), dim3(256), 0, s,
                          reinterpret_cast<const u32x4 *>(g->feat_sorted), g->feat_h, g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale,
                          reinterpret_cast<u32x4 *>(pool_dst), pa.pitch());
@@ -2268,11 +2168,6 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
           const GTensor &dst = g->t_head[op.dst];
           const ActI od{dst.buf, N, dst.C, dst.H, dst.W};
           char *outp = reinterpret_cast<char *>(dst.buf) + (size_t)(op.dst_c_off / 8) * od.pitch() * 8 * sizeof(bf16_t);  // plane offset = the concat
-          if (pm_gather)
-            hipLaunchKernelGGL(roi_maxpool_pm_bf16_kernel, dim3((unsigned)cdiv_sz((size_t)N * dst.H * dst.W, 16)), dim3(256), (size_t)16 * Cb * sizeof(u32x4), s,
-                               reinterpret_cast<const u32x4 *>(g->feat_sorted_pm), Cb, g->feat_h, g->feat_w, d_rois, roi_stride, N, PH, PH, spatial_scale,
-                               op.kh, op.sh, op.ph, dst.H, dst.W, reinterpret_cast<u32x4 *>(outp), od.pitch());
-          else
           hipLaunchKernelGGL(roi_maxpool_c8i_bf16_sorted_kernel<4>, dim3((unsigned)cdiv_sz((size_t)N * dst.H * dst.W, 256), (unsigned)(Cb / 4)), dim3(256), 0, s,
                              reinterpret_cast<const u32x4 *>(g->feat_sorted), g->feat_h, g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale,
                              op.kh, op.sh, op.ph, dst.H, dst.W, reinterpret_cast<u32x4 *>(outp), od.pitch());
