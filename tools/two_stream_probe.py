@@ -14,7 +14,9 @@ P = models.synthetic_params(models.VGG16_CFG, pooled=7, fc_dim=4096, n_classes=b
 nets = [models.FastRCNN(P, max_h=bench.H, max_w=bench.W, max_rois=bench.N_ROIS) for _ in range(2)]
 im_np, boxes_np = bench.synthetic_inputs()
 pins = [(torch.from_numpy(im_np).clone().pin_memory(), torch.from_numpy(boxes_np).clone().pin_memory()) for _ in range(4)]
-streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+# argv[2] = "prio": the second stream at LOWER priority, so that its image's blocks only fill what the first stream leaves idle
+prio = len(sys.argv) > 2 and sys.argv[2] == "prio"
+streams = [torch.cuda.Stream(device=dev, priority=-1 if prio else 0), torch.cuda.Stream(device=dev, priority=0)]
 
 
 def run(n_streams, host_fed=True):
