@@ -294,7 +294,8 @@ __global__ void roi_pool_c8i_kernel(const float *__restrict__ feat, int Cb, int 
 // per-thread bin arithmetic for 16 output bytes).  Same cells, same comparisons: bit-identical.
 template <int CBG>
 __global__ __launch_bounds__(256) void roi_pool_c8i_rows_kernel(const float *__restrict__ feat, int H, int W, size_t pitch_f, const float *__restrict__ rois,
-                                                                 int roi_stride, int N, int PH, int PW, float scale, float *__restrict__ out, size_t pitch_o) {
+                                                                 int roi_stride, int N, int PH, int PW, float scale, float *__restrict__ out, size_t pitch_o,
+                                                                 int fc_mp) {
   const int PP = PH * PW;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)N * PP) return;
@@ -312,7 +313,10 @@ __global__ __launch_bounds__(256) void roi_pool_c8i_rows_kernel(const float *__r
   const bool empty = (he <= hs) || (we <= ws);
   const int cb0 = blockIdx.y * CBG;
   const float *fp = feat + (size_t)cb0 * pitch_f * 8;
-  float *op = out + ((size_t)cb0 * pitch_o + t) * 8;
+  // fc_mp > 0: the (bin, roi)-row C8 matrix [Cb][PP][fc_mp][8] a fully-connected first layer reads as its GEMM operand
+  // (plane = (channel block, bin), row = roi — the VGG pipeline's fc6 layout), instead of the C8I batch of maps
+  float *op = fc_mp > 0 ? out + (((size_t)cb0 * PP + bin) * fc_mp + n) * 8 : out + ((size_t)cb0 * pitch_o + t) * 8;
+  const size_t plane_o = fc_mp > 0 ? (size_t)PP * fc_mp : pitch_o;
   const float lowest = empty ? 0.0f : -INFINITY;
   f32x4 lo[CBG], hi[CBG];
 #pragma unroll
@@ -329,8 +333,8 @@ __global__ __launch_bounds__(256) void roi_pool_c8i_rows_kernel(const float *__r
     }
 #pragma unroll
   for (int c = 0; c < CBG; ++c) {
-    *reinterpret_cast<f32x4 *>(op + (size_t)c * pitch_o * 8) = lo[c];
-    *reinterpret_cast<f32x4 *>(op + (size_t)c * pitch_o * 8 + 4) = hi[c];
+    *reinterpret_cast<f32x4 *>(op + (size_t)c * plane_o * 8) = lo[c];
+    *reinterpret_cast<f32x4 *>(op + (size_t)c * plane_o * 8 + 4) = hi[c];
   }
 }
 
@@ -1472,6 +1476,7 @@ struct GOp {
   RnConv conv;
   float *pool_bias = nullptr;  // average pool only: bias (+ ReLU if relu) applied after the pool (commuted pool -> pointwise convolution)
   bool from_rois = false;      // head graphs: a max-pool of the ROI-pooled input itself -> computed from the feature map (roi_maxpool_c8i_bf16_sorted_kernel)
+  float *fc_w = nullptr, *fc_b = nullptr;  // head graphs (fp32): a convolution over the WHOLE pooled map (AlexNet's fc6) packed for the tuned GEMM, K = (channel block, bin)
 };
 struct ResNetGraph {
   // op-list mode (graph_build): branching graphs; tensor 0 = image (trunk) / ROI-pooled map (head)
@@ -1491,6 +1496,7 @@ struct ResNetGraph {
   size_t tb_elems = 0, hb_elems = 0;
   float *feat = nullptr;         // points into tb[]: layer3 output of the last trunk run
   int feat_h = 0, feat_w = 0, last_h = -1, last_w = -1;
+  float *fc_x = nullptr;         // (bin, roi)-row ROI-pooled matrix [Cb][PP][round_up(max_rois, 128)][8] for a GOp with fc_w
   bf16_t *feat_sorted = nullptr; // order-preserving int16 re-coding of the cached feature map (bf16 ROI pooling), rebuilt per trunk run
   size_t feat_sorted_elems = 0;
   bool feat_sorted_valid = false;
@@ -1561,6 +1567,7 @@ MPN_KNOB(int, g_fp32_pf, 1);              // fp32 graph: conv2d_c8i_pf_kernel fo
 MPN_KNOB(int, g_split_max_tiles, 192);     // split-K only layers with fewer 128 x 128 tiles than this (mpn_debug_set_split_max_tiles)
 MPN_KNOB(int, g_bf16_split_target, 256);  // split-K (both dtypes) aims at this many blocks (0 = never split; mpn_debug_set_bf16_split_target)
 MPN_KNOB(int, g_bf16_dma_tn, 0);  // 0 = pick per layer; 128 / 256 = force 256 couts x that many pixels, 1256 = 128 couts x 256 pixels (mpn_debug_set_bf16_dma_tn)
+MPN_KNOB(int, g_graph_fuse, 15);  // mpn_debug_set_graph_fuse: bit 0 = fuse sibling pointwise convolutions, bit 1 = commute average-pool -> pointwise convolution, bit 2 = max-pools of the ROI-pooled input computed from the feature map, bit 3 = fully-connected head layers (whole-map / 1x1-map convolutions) on the tuned GEMM; 0 = run the op list as given
 MPN_KNOB(int, g_bf16_dma, 1);  // mpn_debug_set_bf16_dma: 0 = never, 1 = large layers, 2 = every eligible layer (tests)
 static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int relu, hipStream_t s, ActI *o, bool allow_gemm = true) {
   if (c.wpk16) {  // bf16 graph
@@ -1656,6 +1663,10 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
   a.pitch_in = in.pitch(); a.pitch_out = o->pitch();
   if (allow_gemm && c.lin_w && c.norelu_c1 == c.norelu_c0 && linear_c8_is_direct((int)in.rows(), c.Cout, (int)in.pitch()))  // same rows in and out: the tuned GEMM, residual + ReLU fused
     return linear_c8(in.p, (int)in.rows(), c.Cin, c.lin_w, c.lin_b, c.Cout, relu, out, nullptr, s, (int)in.pitch(), res);
+  // a pointwise convolution on 1x1 maps is a fully-connected layer (AlexNet's fc7): few row tiles, so the GEMM's split-K form
+  // with its row-invariant segments rather than a 128-pixel-tile convolution
+  if (allow_gemm && c.lin_w && c.norelu_c1 == c.norelu_c0 && !res && in.H == 1 && in.W == 1 && (g_graph_fuse & 8))
+    return linear_c8(in.p, (int)in.rows(), c.Cin, c.lin_w, c.lin_b, c.Cout, relu, out, nullptr, s, (int)in.pitch(), nullptr, 1);
   dim3 grid((unsigned)(((a.P + 127) / 128 + 7) / 8 * 8 * (a.CoutP / 128)));  // pixel tiles rounded up to the 8 XCDs x cout tiles (see the kernel)
   // 32-channel stages: the LDS-DMA / hand-pipelined kernel (32-bit gather offsets: the input batch must stay under 4 GiB)
   constexpr size_t PF_LDS = (size_t)2 * 2 * 4 * 128 * 8 * sizeof(float);
@@ -1847,8 +1858,8 @@ static int graph_dims(const std::vector<GOp> &ops, std::vector<GTensor> &ts, int
   return MPN_OK;
 }
 
-MPN_KNOB(int, g_graph_fuse, 7);  // mpn_debug_set_graph_fuse: bit 0 = fuse sibling pointwise convolutions, bit 1 = commute average-pool -> pointwise convolution, bit 2 = max-pools of the ROI-pooled input computed from the feature map; 0 = run the op list as given
-static int graph_parse(ResNetGraph *g, int n_ops, const mpn_graph_op *ops_in, int n_t, const int *tc, std::vector<GOp> &out, std::vector<GTensor> &ts) {
+static int graph_parse(ResNetGraph *g, int n_ops, const mpn_graph_op *ops_in, int n_t, const int *tc, std::vector<GOp> &out, std::vector<GTensor> &ts,
+                       bool head = false) {
   MPN_CHECK_ARG(n_ops > 0 && ops_in && n_t > 1 && tc);
   ts.resize(n_t);
   for (int i = 0; i < n_t; ++i) { ts[i].C = tc[i]; MPN_CHECK_ARG(tc[i] > 0); }
@@ -1976,6 +1987,23 @@ static int graph_parse(ResNetGraph *g, int n_ops, const mpn_graph_op *ops_in, in
       c.norelu_c0 = norelu_of[i].first; c.norelu_c1 = norelu_of[i].second;
       int rc = rn_pack(g, c, o.w, o.b);
       if (rc) return rc;
+      // A convolution whose window is the whole ROI-pooled map (AlexNet's fc6: alexnet.lua's View(-1) + Linear(9216, 4096)) is a
+      // fully-connected layer: with the pooled bins written as (bin, roi) rows it is ONE GEMM over K = Cin * bins on the tuned
+      // kernel (the route the VGG pipeline's fc6 takes) instead of a 36-tap convolution on three 128-ROI pixel tiles.  Needs the
+      // pooled tensor all to itself (it is then never materialised as maps).
+      if (head && !g->bf16 && (g_graph_fuse & 8) && o.src == 0 && o.src_c_off == 0 && o.cin == ts[0].C && o.kh == g->pooled && o.kw == g->pooled && o.ph == 0 &&
+          o.pw == 0 && o.dst_c_off == 0 && o.cout == ts[o.dst].C && o.cin % 32 == 0 && (o.cin * o.kh * o.kw) % 64 == 0) {
+        bool sole = true;
+        for (int j = 0; j < n_ops; ++j)
+          if (j != i && !dead[j] && fused[j].src == 0) sole = false;
+        if (sole) {
+          const int Kfc = o.cin * o.kh * o.kw;
+          rc = rn_alloc(g, &op.fc_w, lin_wpk_elems(Kfc, o.cout) * sizeof(float));
+          if (rc == MPN_OK) rc = rn_alloc(g, &op.fc_b, (size_t)lin_np(o.cout) * sizeof(float));
+          if (rc == MPN_OK) rc = pack_linear_weights(o.w, o.b, Kfc, o.cout, o.kh * o.kw, op.fc_w, op.fc_b, nullptr);
+          if (rc) return rc;
+        }
+      }
     }
     out.push_back(op);
   }
@@ -1992,7 +2020,14 @@ int graph_build(const mpn_graph_weights *gw, int max_h, int max_w, int max_rois,
   MPN_CHECK_ARG(n_heads <= 8);
   g->g_heads.resize(n_heads);
   for (int t = 0; rc == MPN_OK && t < n_heads; ++t) {
-    rc = graph_parse(g, gw->n_head_ops, gw->head_ops + (size_t)t * gw->n_head_ops, gw->n_head_tensors, gw->head_tensor_c, g->g_heads[t], g->t_head);
+    rc = graph_parse(g, gw->n_head_ops, gw->head_ops + (size_t)t * gw->n_head_ops, gw->n_head_tensors, gw->head_tensor_c, g->g_heads[t], g->t_head, true);
+    if (rc == MPN_OK)
+      for (GOp &op : g->g_heads[t])
+        if (op.fc_w && !g->fc_x) {
+          const size_t bytes = (size_t)(op.cin / 8) * pooled * pooled * round_up(max_rois, 128) * 8 * sizeof(float);
+          rc = rn_alloc(g, &g->fc_x, bytes);
+          if (rc == MPN_OK && hipMemset(g->fc_x, 0, bytes) != hipSuccess) rc = MPN_EHIP;
+        }
     if (rc == MPN_OK)
       for (GOp &op : g->g_heads[t])
         if (op.kind == 1 && op.src == 0 && op.src_c_off == 0 && op.cin == g->t_head[0].C && op.kh == op.kw && op.sh == op.sw && op.ph == op.pw && !op.ceil_mode)
@@ -2030,7 +2065,8 @@ int graph_build(const mpn_graph_weights *gw, int max_h, int max_w, int max_rois,
 }
 
 // run one op list on a batch of B maps; dims must have been propagated (graph_dims)
-static int graph_run(ResNetGraph *g, const std::vector<GOp> &ops, std::vector<GTensor> &ts, int B, hipStream_t s, bool skip_from_rois = false) {
+static int graph_run(ResNetGraph *g, const std::vector<GOp> &ops, std::vector<GTensor> &ts, int B, hipStream_t s, bool skip_from_rois = false,
+                     bool fc_gemm = false) {
   const size_t esz = g->bf16 ? sizeof(bf16_t) : sizeof(float);
   for (const GOp &op : ops) {
     if (skip_from_rois && op.from_rois) continue;  // already produced from the feature map (resnet_head_forward)
@@ -2049,7 +2085,11 @@ static int graph_run(ResNetGraph *g, const std::vector<GOp> &ops, std::vector<GT
     const ActI in{src.buf, B, src.C, src.H, src.W};
     const ActI od{dst.buf, B, dst.C, dst.H, dst.W};
     char *outp = reinterpret_cast<char *>(dst.buf) + (size_t)(op.dst_c_off / 8) * od.pitch() * 8 * esz;  // plane offset = the concat
-    if (op.kind == 0) {
+    if (op.kind == 0 && fc_gemm && op.fc_w) {  // fully connected over the (bin, roi)-row pooled matrix (resnet_head_forward wrote it): row-invariant K segments
+      int rc = linear_c8(g->fc_x, B, op.cin * op.kh * op.kw, op.fc_w, op.fc_b, op.conv.Cout, op.relu, reinterpret_cast<float *>(outp), nullptr, s, (int)od.pitch(),
+                         nullptr, 1);
+      if (rc) return rc;
+    } else if (op.kind == 0) {
       ActI o;
       // the GEMM writes whole 128-channel panels: only when this op owns them (no neighbouring branch inside the panel)
       const bool own = op.conv.Cout % 128 == 0 || (op.dst_c_off == 0 && op.conv.Cout == dst.C);
@@ -2140,6 +2180,9 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
   const int Cb = (g->feat_c + 7) / 8, PH = g->pooled;
   float *const pool_dst = g->is_graph ? g->t_head[0].buf : g->hb[0];
   const bool fuse_mp = g->is_graph && g->bf16 && (g_bf16_fast_pool & 1) && Cb % 4 == 0 && (g_graph_fuse & 4);  // max-pools of the pooled input: from the map
+  bool fc_gemm = false;  // the head starts with a fully-connected layer: pool straight into its GEMM operand
+  if (g->is_graph && !g->bf16 && g->fc_x && (g_graph_fuse & 8) && (g_bf16_fast_pool & 1) && Cb % 4 == 0)
+    for (const GOp &op : g->g_heads[head]) fc_gemm = fc_gemm || op.fc_w != nullptr;
   if (g->is_graph) { int rc = graph_dims(g->g_heads[head], g->t_head, PH, PH); if (rc) return rc; }
   {
     const size_t total = (size_t)N * Cb * PH * PH * 2;
@@ -2177,7 +2220,7 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
                          g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale, reinterpret_cast<bf16_t *>(pool_dst), pa.pitch());
     else if ((g_bf16_fast_pool & 1) && Cb % 4 == 0)
       hipLaunchKernelGGL(roi_pool_c8i_rows_kernel<4>, dim3((unsigned)cdiv_sz((size_t)N * PH * PH, 256), (unsigned)(Cb / 4)), dim3(256), 0, s, g->feat, g->feat_h,
-                         g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale, pool_dst, pa.pitch());
+                         g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale, fc_gemm ? g->fc_x : pool_dst, pa.pitch(), fc_gemm ? round_up(N, 128) : 0);
     else
       hipLaunchKernelGGL(roi_pool_c8i_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, g->feat, Cb, g->feat_h, g->feat_w, fa.pitch(), d_rois, roi_stride,
                          N, PH, PH, spatial_scale, pool_dst, pa.pitch());
@@ -2185,7 +2228,7 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
   }
   ActI cur{pool_dst, N, g->feat_c, PH, PH}, y;
   if (g->is_graph) {
-    int rc = graph_run(g, g->g_heads[head], g->t_head, N, s, fuse_mp);
+    int rc = graph_run(g, g->g_heads[head], g->t_head, N, s, fuse_mp, fc_gemm);
     if (rc) return rc;
     const GTensor &o = g->t_head[g->out_tensor];
     cur = ActI{o.buf, N, o.C, o.H, o.W};

@@ -40,6 +40,42 @@ def test_alexnet_frcnn_vs_oracle(O, dev, H, W, N, width):
         assert nk[j - 1] == ref.shape[0] and np.array_equal(keep[j - 1, : nk[j - 1]], ref)
 
 
+def test_alexnet_fc_layers_on_the_gemm_equal_the_convolution_form(dev):
+    """graph_parse bit 3: fc6 (the 6x6 convolution over the whole pooled map) and fc7 (1x1 on 1x1 maps) run on the tuned GEMM — the
+    ROI pooling writes (bin, roi) rows, K = (channel block, bin) — instead of the pixel-tile convolution kernels: the same dot
+    products in another summation order"""
+    from conftest import hooks
+    from multipathnet_amd import models
+    H, W, N = 150, 250, 40
+    G = models.synthetic_alexnet_params(n_classes=6, width=0.25, fc_dim=128, seed=3)
+    im, boxes = _inputs(H, W, N, 4)
+    out = []
+    for fuse in (7, 15):
+        with hooks(graph_fuse=fuse):
+            net = models.AlexNetFRCNN(G, max_h=H, max_w=W, max_rois=64, top_k=20)
+            s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+            out.append((s.cpu().numpy().copy(), b.cpu().numpy().copy()))
+            del net
+    assert not np.array_equal(out[0][0], out[1][0])        # really two code paths
+    assert np.abs(out[0][0] - out[1][0]).max() < 1e-6 and np.abs(out[0][1] - out[1][1]).max() < 1e-3
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_alexnet_sharded_equals_unsharded(dev, world):
+    """With fc6 / fc7 on the row-invariant GEMM the AlexNet head's rows no longer depend on the batch they are scored in: the
+    ROI-sharded latency mode (tests/test_gpu_shard.py) reproduces the unsharded detections bit for bit on this graph pipeline too"""
+    from multipathnet_amd import models
+    from test_gpu_shard import _emulate, _reference
+    H, W, N = 150, 250, 61
+    G = models.synthetic_alexnet_params(n_classes=6, width=0.25, fc_dim=128, seed=5)
+    im, boxes = _inputs(H, W, N, 6)
+    net = models.AlexNetFRCNN(G, max_h=H, max_w=W, max_rois=64, top_k=20)
+    imd, bd = torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev)
+    ref_dets, keep, kidx, nk = _reference(net, imd, bd)
+    dets, n, _, _ = _emulate(net, imd, bd, world)
+    assert n == ref_dets.size(0) and n > 0 and torch.equal(dets, ref_dets)
+
+
 def test_alexnet_fullsize_config0(O, dev):
     """configs[0] at full size: 600x1000 image, 300 ROIs, 21 classes, full-width CaffeNet (conv5 map 39 x 64 at stride 16).  The oracle
     runs the whole trunk and the head of a 60-ROI sample; logits / deltas within 1e-4 absolute."""
