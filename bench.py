@@ -9,7 +9,7 @@ by torch.distributed.run directly it reads RANK / LOCAL_RANK / WORLD_SIZE / MAST
 
 A step = one pass of the hot path over one synthetic 600x1000 image with 1000 ROIs through VGG-16 Fast R-CNN
 (BASELINE configs[1]), starting — as Tester_FRCNN.lua:64-66 / ImageDetect.lua:148-151 do — from a HOST image and HOST
-boxes: H2D upload (pinned buffers, the pipeline's copy stream, double-buffered so that it overlaps the previous image's
+boxes: H2D upload (pinned buffers, the pipeline's copy stream, three staging sets so that it overlaps the previous image's
 kernels) -> image transform -> 13 conv / 4 pool trunk -> ROI pool -> fc6/fc7 -> cls/bbox heads -> softmax / BBoxNorm /
 decode / clamp -> per-class NMS -> top-100 -> (N>1) RCCL all-gather of the scored-box record through the C ABI
 (mpn_gather_dets).  Weights are seeded random (no pretrained blobs offline).  Images shard across ranks (weak scaling, one
@@ -667,7 +667,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "VGG-16 Fast R-CNN, 1 image 600x1000 x 1000 ROIs per GPU per step, 21 classes, NMS 0.3, top-100 (BASELINE configs[1]); "
-                                   "host image + boxes uploaded inside the step (pinned, copy stream, double-buffered)",
+                                   "host image + boxes uploaded inside the step (pinned, copy stream, three staging sets)",
                        "parallelism": "image-sharded over %d rank%s (one process per GPU), all-gather of scored boxes only via %s; cpu affinity: %s; "
                                       "4 different pinned (image, proposals) sets in rotation, offset by rank"
                                       % (world, "" if world == 1 else "s", gather_via, affinity)},

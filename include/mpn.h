@@ -390,8 +390,10 @@ int mpn_frcnn_test_one_pipelined(mpn_frcnn *p, const float *d_image, int H, int 
 int mpn_frcnn_flush(mpn_frcnn *p, void *stream);
 /* The same throughput form fed from HOST buffers, as the reference's loop is (Tester_FRCNN.lua:64-66 gets a CPU image and
  * CPU boxes; ImageDetect.lua:148-151 copies them to the GPU): the upload of image i (7.2 MB + 16 KB at 600x1000 / 1000 ROIs)
- * runs on the handle's copy stream into one of two handle-owned staging sets and overlaps image i-1's kernels; `stream`
- * waits for it only where the trunk starts.  h_image / h_boxes should be pinned (hipHostMalloc / hipHostRegister /
+ * runs on the handle's copy stream into one of three handle-owned staging sets and overlaps image i-1's kernels; `stream`
+ * waits for it only where the trunk starts.  A staging set is reused once the image that filled it three calls earlier has
+ * been consumed: the call waits for that on the HOST (a copy that depends on a compute-queue event leaves the DMA engines),
+ * so the host runs at most three images ahead of the device.  h_image / h_boxes should be pinned (hipHostMalloc / hipHostRegister /
  * torch pin_memory) — pageable memory works but serialises the copy; they may be reused as soon as the call returns
  * only if pinned memory is NOT rewritten before the copy ran: alternate two host buffers like the output buffers. */
 int mpn_frcnn_test_one_pipelined_host(mpn_frcnn *p, const float *h_image, int H, int W, const float *h_boxes, int N,

@@ -273,12 +273,13 @@ struct mpn_frcnn {
   std::vector<void *> allocs;
   Scratch scratch;  // split-K slabs, NMS masks, ... of THIS handle (bound to the calling thread by ScratchScope in every entry point)
   int device = 0;   // the handle lives on the device that was current at creation
-  // host-fed throughput form (mpn_frcnn_test_one_pipelined_host): two staging sets filled by the copy stream
+  // host-fed throughput form (mpn_frcnn_test_one_pipelined_host): three staging sets filled by the copy stream
   hipStream_t copy = nullptr;
-  float *stage_img[2] = {nullptr, nullptr}, *stage_boxes[2] = {nullptr, nullptr};
-  size_t stage_cap[2] = {0, 0};
-  hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
-  bool used_pending[2] = {false, false};
+  static constexpr int kStage = 3;
+  float *stage_img[kStage] = {}, *stage_boxes[kStage] = {};
+  size_t stage_cap[kStage] = {};
+  hipEvent_t ev_up[kStage] = {}, ev_consumed[kStage] = {};
+  bool used_pending[kStage] = {};
   unsigned long long up_seq = 0;
   // proposal sharding (mpn_frcnn_test_one_sharded): this rank's row / class records and the gathered ones, grown on demand
   float *sh_buf[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -346,9 +347,9 @@ extern "C" void mpn_frcnn_destroy(mpn_frcnn *p) {
   for (int i = 0; i < 2; ++i) { if (p->ev_pool_done[i]) (void)hipEventDestroy(p->ev_pool_done[i]); if (p->ev_mix_done[i]) (void)hipEventDestroy(p->ev_mix_done[i]); }
   if (p->ev_pool_go) (void)hipEventDestroy(p->ev_pool_go);
   if (p->copy) (void)hipStreamDestroy(p->copy);
-  for (int i = 0; i < 2; ++i) { if (p->ev_up[i]) (void)hipEventDestroy(p->ev_up[i]); if (p->ev_consumed[i]) (void)hipEventDestroy(p->ev_consumed[i]); }
+  for (int i = 0; i < mpn_frcnn::kStage; ++i) { if (p->ev_up[i]) (void)hipEventDestroy(p->ev_up[i]); if (p->ev_consumed[i]) (void)hipEventDestroy(p->ev_consumed[i]); }
   p->scratch.release();
-  for (int i = 0; i < 2; ++i) if (p->stage_img[i]) (void)hipFree(p->stage_img[i]);
+  for (int i = 0; i < mpn_frcnn::kStage; ++i) if (p->stage_img[i]) (void)hipFree(p->stage_img[i]);
   for (void *q : p->allocs) (void)hipFree(q);
   resnet_free(p->rn);
   if (p->scaled) (void)hipFree(p->scaled);
@@ -1136,14 +1137,14 @@ extern "C" int mpn_frcnn_test_one_pipelined_host(mpn_frcnn *p, const float *h_im
   const size_t img_n = (size_t)3 * H * W;
   if (!p->copy) {  // first use: copy stream, events, the two box staging buffers
     MPN_CHECK_HIP(hipStreamCreateWithFlags(&p->copy, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < mpn_frcnn::kStage; ++i) {
       MPN_CHECK_HIP(hipEventCreateWithFlags(&p->ev_up[i], hipEventDisableTiming));
       MPN_CHECK_HIP(hipEventCreateWithFlags(&p->ev_consumed[i], hipEventDisableTiming));
       int rc0 = dev_alloc(p, &p->stage_boxes[i], (size_t)p->cfg.max_rois * 4 * sizeof(float), false);
       if (rc0) return rc0;
     }
   }
-  const int b = (int)(p->up_seq & 1);
+  const int b = (int)(p->up_seq % mpn_frcnn::kStage);
   if (img_n > p->stage_cap[b]) {  // image staging grows on demand (getImages may be handed images larger than max_h x max_w)
     MPN_CHECK_HIP(hipStreamSynchronize(p->copy));
     MPN_CHECK_HIP(hipStreamSynchronize(s));
@@ -1154,7 +1155,11 @@ extern "C" int mpn_frcnn_test_one_pipelined_host(mpn_frcnn *p, const float *h_im
     MPN_CHECK_HIP(hipMalloc(&p->stage_img[b], cap * sizeof(float)));
     p->stage_cap[b] = cap;
   }
-  if (p->used_pending[b]) { MPN_CHECK_HIP(hipStreamWaitEvent(p->copy, p->ev_consumed[b], 0)); p->used_pending[b] = false; }
+  // The staging set is free once the image that used it (three calls ago) has been consumed.  Waited for on the HOST, not with
+  // hipStreamWaitEvent on the copy stream: a copy that depends on a compute-queue event leaves the SDMA path (measured on AlexNet,
+  // tools/host_enqueue_probe.py: 0.99 ms / image with the stream wait, 0.86 resident), and this bounds the host's run-ahead to
+  // three images, as a queue should.
+  if (p->used_pending[b]) { MPN_CHECK_HIP(hipEventSynchronize(p->ev_consumed[b])); p->used_pending[b] = false; }
   MPN_CHECK_HIP(hipMemcpyAsync(p->stage_img[b], h_image, img_n * sizeof(float), hipMemcpyHostToDevice, p->copy));
   MPN_CHECK_HIP(hipMemcpyAsync(p->stage_boxes[b], h_boxes, (size_t)N * 4 * sizeof(float), hipMemcpyHostToDevice, p->copy));
   MPN_CHECK_HIP(hipEventRecord(p->ev_up[b], p->copy));

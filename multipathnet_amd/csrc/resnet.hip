@@ -23,6 +23,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct ActI {  // C8I batch of maps: element (b, c, y, x) at ((c/8) * pitch + (b*H + y)*W + x) * 8 + c%8
   float *p;
   int B, C, H, W;
+  const float *planar = nullptr;  // the image only: the same transformed pixels as [3][H][W] planes (the im2col first layer reads these)
   int Cb() const { return (C + 7) / 8; }
   size_t rows() const { return (size_t)B * H * W; }
   size_t pitch() const { return (rows() + 127) / 128 * 128; }  // rows per channel-block plane (a C8 matrix of `rows` rows)
@@ -244,7 +245,8 @@ __global__ void maxpool2d_c8i_kernel(const float *__restrict__ in, int Cb, int B
 
 // image transformer (modules/ImageTransformer.lua:19-33, f64 arithmetic) into a one-map C8I image (channels 3..7 zero)
 __global__ void image_transform_c8i_kernel(const float *__restrict__ in, int H, int W, int s0, int s1, int s2, double scale, double m0,
-                                           double m1, double m2, double d0, double d1, double d2, int has_std, float *__restrict__ out) {
+                                           double m1, double m2, double d0, double d1, double d2, int has_std, float *__restrict__ out,
+                                           float *__restrict__ planar) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t plane = (size_t)H * W;
   if (t >= plane) return;
@@ -254,6 +256,7 @@ __global__ void image_transform_c8i_kernel(const float *__restrict__ in, int H, 
   if (has_std) { v0 = v0 / d0; v1 = v1 / d1; v2 = v2 / d2; }
   *reinterpret_cast<f32x4 *>(out + t * 8) = f32x4{(float)v0, (float)v1, (float)v2, 0.0f};
   *reinterpret_cast<f32x4 *>(out + t * 8 + 4) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  if (planar) { planar[t] = (float)v0; planar[plane + t] = (float)v1; planar[2 * plane + t] = (float)v2; }
 }
 
 // inn.ROIPooling on a one-map C8I feature -> [N][Cb][PH][PW][8] (the batch the per-ROI head convolves); the bin arithmetic
@@ -1449,11 +1452,49 @@ __global__ void lrn_c8i_kernel(const float *__restrict__ in, int Cb, int C, size
   *reinterpret_cast<f32x4 *>(q + 4) = f32x4{o[4], o[5], o[6], o[7]};
 }
 
+// First layer (Cin = 3, fp32 graphs): im2col rows for the tuned GEMM.  One 8-channel record of the C8I image holds 3 real channels,
+// so the tap-by-tap convolution spends 8 / 3 of the matrix work on zeros (and runs the 8-channel-stage kernel); here
+// k = (ky * KW + kx) * 3 + c, zero beyond KH * KW * 3 and outside the image, written as the C8 matrix [K64 / 8][pitch][8].  It reads
+// the transformed image's [3][H][W] planes: a wave's 64 pixels are then 64 * stride floats of one row, a few cache lines per load
+// (from the C8I records each lane touched its own line: 59 us for AlexNet's conv1 instead of ~25).
+__global__ void im2col3_c8i_kernel(const float *__restrict__ img, int H, int W, int KH, int KW, int sh, int sw, int ph, int pw, int OH, int OW, int nkb,
+                                   size_t pitch_o, float *__restrict__ out) {
+  const size_t P = (size_t)OH * OW;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P * nkb) return;
+  const int kb = (int)(t / P);
+  const size_t pix = t - (size_t)kb * P;
+  const int oy = (int)(pix / OW), ox = (int)(pix - (size_t)oy * OW);
+  const int iy0 = oy * sh - ph, ix0 = ox * sw - pw;
+  // (ky, kx, c) of k = kb * 8 once, then stepped: no division per element
+  int tap = (kb * 8) / 3, c = kb * 8 - tap * 3;
+  int ky = tap / KW, kx = tap - ky * KW;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int iy = iy0 + ky, ix = ix0 + kx;
+    const bool ok = ky < KH && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    v[j] = ok ? img[((size_t)c * H + iy) * W + ix] : 0.0f;
+    if (++c == 3) { c = 0; if (++kx == KW) { kx = 0; ++ky; } }
+  }
+  float *q = out + ((size_t)kb * pitch_o + pix) * 8;
+  *reinterpret_cast<f32x4 *>(q) = f32x4{v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4 *>(q + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+// [Cout][3][KK] -> [Cout][KK * 3] (tap-major, the im2col k order)
+__global__ void permute_w3_kernel(const float *__restrict__ w, int Cout, int KK, float *__restrict__ o) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Cout * KK * 3) return;
+  const int n = t / (KK * 3), k = t - n * KK * 3, tap = k / 3, c = k - tap * 3;
+  o[t] = w[((size_t)n * 3 + c) * KK + tap];
+}
+
 struct RnConv {
   int Cin = 0, Cout = 0, K = 0, stride = 1, pad = 0;  // square form (ResNet); KH/KW/sh/sw/ph/pw below are what the kernels use
   int KH = 0, KW = 0, sh = 1, sw = 1, ph = 0, pw = 0;
   float *wpk = nullptr, *bpk = nullptr;
   float *lin_w = nullptr, *lin_b = nullptr;  // 1x1 / stride 1 with Cin % 64 == 0: also packed for the tuned GEMM (linear_c8)
+  float *col_w = nullptr, *col_b = nullptr;  // Cin == 3 (fp32): packed for the GEMM over im2col rows, k = tap * 3 + c
   bf16_t *wpk16 = nullptr;                   // bf16 graph: [tap][nch2][CoutP][8]
   int norelu_c0 = 0, norelu_c1 = 0;          // output channels [c0, c1) skip the ReLU (fused siblings with mixed activations; multiples of 8)
   float *ws = nullptr;                       // the graph's split-K workspace
@@ -1491,6 +1532,7 @@ struct ResNetGraph {
   int feat_c = 0, out_c = 0, pooled = 14, max_rois = 0;
   bool bf16 = false;             // activations / conv weights in bf16 (fp32 accumulate); the cls / bbox head GEMM stays fp32
   float *img = nullptr;          // C8I image
+  float *img_planar = nullptr;   // fp32 graphs: the transformed image as [3][H][W] planes too (im2col first layer)
   float *tb[4] = {nullptr, nullptr, nullptr, nullptr};  // trunk activations (rotating)
   float *hb[4] = {nullptr, nullptr, nullptr, nullptr};  // per-ROI head activations (rotating)
   size_t tb_elems = 0, hb_elems = 0;
@@ -1513,6 +1555,7 @@ static int rn_alloc(ResNetGraph *g, float **p, size_t bytes) {
   return MPN_OK;
 }
 
+MPN_KNOB(int, g_graph_fuse, 31);  // mpn_debug_set_graph_fuse: bit 0 = fuse sibling pointwise convolutions, bit 1 = commute average-pool -> pointwise convolution, bit 2 = max-pools of the ROI-pooled input computed from the feature map, bit 3 = fully-connected head layers (whole-map / 1x1-map convolutions) on the tuned GEMM, bit 4 = the image layer (Cin = 3) as a GEMM over im2col rows; 0 = run the op list as given
 static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b) {
   if (g->bf16) {
     const int nch2 = round_up((c.Cin + 7) / 8, 2), CoutP = round_up(c.Cout, 128), KK = c.KH * c.KW;
@@ -1549,6 +1592,18 @@ static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b
   hipLaunchKernelGGL(pack_conv_generic_kernel, dim3((unsigned)cdiv_sz(threads, 256)), dim3(256), 0, nullptr, d_w, d_b, c.Cin, c.Cout, KK, nch, CoutP,
                      c.wpk, c.bpk);
   MPN_CHECK_LAUNCH();
+  if (c.Cin == 3 && KK > 1 && (g_graph_fuse & 16)) {  // the image layer: GEMM over im2col rows
+    const int Kc = KK * 3;
+    float *perm = nullptr;
+    rc = rn_alloc(g, &perm, (size_t)c.Cout * Kc * sizeof(float));
+    if (rc == MPN_OK) rc = rn_alloc(g, &c.col_w, lin_wpk_elems(round_up(Kc, 64), c.Cout) * sizeof(float));
+    if (rc == MPN_OK) rc = rn_alloc(g, &c.col_b, (size_t)lin_np(c.Cout) * sizeof(float));
+    if (rc) return rc;
+    hipLaunchKernelGGL(permute_w3_kernel, dim3((unsigned)cdiv(c.Cout * Kc, 256)), dim3(256), 0, nullptr, d_w, c.Cout, KK, perm);
+    MPN_CHECK_LAUNCH();
+    rc = pack_linear_weights(perm, d_b, Kc, c.Cout, 1, c.col_w, c.col_b, nullptr);
+    if (rc) return rc;
+  }
   if (c.KH == 1 && c.KW == 1 && c.sh == 1 && c.sw == 1 && c.ph == 0 && c.pw == 0 && c.Cin % 64 == 0) {  // a pointwise convolution IS a GEMM over the C8I rows
     rc = rn_alloc(g, &c.lin_w, lin_wpk_elems(c.Cin, c.Cout) * sizeof(float));
     if (rc) return rc;
@@ -1567,7 +1622,6 @@ MPN_KNOB(int, g_fp32_pf, 1);              // fp32 graph: conv2d_c8i_pf_kernel fo
 MPN_KNOB(int, g_split_max_tiles, 192);     // split-K only layers with fewer 128 x 128 tiles than this (mpn_debug_set_split_max_tiles)
 MPN_KNOB(int, g_bf16_split_target, 256);  // split-K (both dtypes) aims at this many blocks (0 = never split; mpn_debug_set_bf16_split_target)
 MPN_KNOB(int, g_bf16_dma_tn, 0);  // 0 = pick per layer; 128 / 256 = force 256 couts x that many pixels, 1256 = 128 couts x 256 pixels (mpn_debug_set_bf16_dma_tn)
-MPN_KNOB(int, g_graph_fuse, 15);  // mpn_debug_set_graph_fuse: bit 0 = fuse sibling pointwise convolutions, bit 1 = commute average-pool -> pointwise convolution, bit 2 = max-pools of the ROI-pooled input computed from the feature map, bit 3 = fully-connected head layers (whole-map / 1x1-map convolutions) on the tuned GEMM; 0 = run the op list as given
 MPN_KNOB(int, g_bf16_dma, 1);  // mpn_debug_set_bf16_dma: 0 = never, 1 = large layers, 2 = every eligible layer (tests)
 static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int relu, hipStream_t s, ActI *o, bool allow_gemm = true) {
   if (c.wpk16) {  // bf16 graph
@@ -1661,6 +1715,16 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
   a.P = (long long)in.B * a.OH * a.OW;
   *o = ActI{out, in.B, c.Cout, a.OH, a.OW};
   a.pitch_in = in.pitch(); a.pitch_out = o->pitch();
+  if (allow_gemm && c.col_w && in.planar && in.B == 1 && in.C == 3 && !res && c.norelu_c1 == c.norelu_c0 && (g_graph_fuse & 16)) {
+    const int Kc = c.KH * c.KW * 3, nkb = round_up(Kc, 64) / 8;
+    const size_t need = (size_t)nkb * o->pitch() * 8 * sizeof(float);
+    void *col = nullptr;
+    { int rc_ws = scratch_get(SCR_IM2COL, need, s, &col); if (rc_ws) return rc_ws; }
+    hipLaunchKernelGGL(im2col3_c8i_kernel, dim3((unsigned)cdiv_sz((size_t)a.P * nkb, 256)), dim3(256), 0, s, in.planar, in.H, in.W, c.KH, c.KW, c.sh, c.sw, c.ph, c.pw,
+                       a.OH, a.OW, nkb, o->pitch(), static_cast<float *>(col));
+    MPN_CHECK_LAUNCH();
+    return linear_c8(static_cast<const float *>(col), (int)a.P, Kc, c.col_w, c.col_b, c.Cout, relu, out, nullptr, s, (int)o->pitch());
+  }
   if (allow_gemm && c.lin_w && c.norelu_c1 == c.norelu_c0 && linear_c8_is_direct((int)in.rows(), c.Cout, (int)in.pitch()))  // same rows in and out: the tuned GEMM, residual + ReLU fused
     return linear_c8(in.p, (int)in.rows(), c.Cin, c.lin_w, c.lin_b, c.Cout, relu, out, nullptr, s, (int)in.pitch(), res);
   // a pointwise convolution on 1x1 maps is a fully-connected layer (AlexNet's fc7): few row tiles, so the GEMM's split-K form
@@ -1673,7 +1737,7 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
   const bool pf_ok = g_fp32_pf && (size_t)in.B * in.H * in.W * 32 < ((size_t)1 << 32);
   { int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(conv2d_c8i_pf_kernel), (int)PF_LDS); if (rc_attr) return rc_attr; }
   {  // small layers: split K across blockIdx.z into fp32 slabs (as the bf16 graph does)
-    const int kc = a.nch % 4 == 0 ? 4 : 1;
+    const int kc = a.nch % 4 == 0 ? 4 : a.nch % 3 == 0 ? 3 : a.nch % 2 == 0 ? 2 : 1;  // 8-channel chunks per stage
     const int nstages = a.KH * a.KW * (a.nch / kc);
     const long long n_tiles = (a.P + 127) / 128 * (a.CoutP / 128);
     const size_t slab = (size_t)a.CoutP * o->pitch() * sizeof(float);
@@ -1686,6 +1750,8 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
       grid.z = (unsigned)splits;
       if (kc == 4 && pf_ok) hipLaunchKernelGGL(conv2d_c8i_pf_kernel, grid, dim3(256), PF_LDS, s, a);
       else if (kc == 4) hipLaunchKernelGGL((conv2d_c8i_kernel<4>), grid, dim3(256), 0, s, a);
+      else if (kc == 3) hipLaunchKernelGGL((conv2d_c8i_kernel<3>), grid, dim3(256), 0, s, a);
+      else if (kc == 2) hipLaunchKernelGGL((conv2d_c8i_kernel<2>), grid, dim3(256), 0, s, a);
       else hipLaunchKernelGGL((conv2d_c8i_kernel<1>), grid, dim3(256), 0, s, a);
       MPN_CHECK_LAUNCH();
       const size_t total = (size_t)a.Cb_out * (size_t)a.P * 2;
@@ -1697,6 +1763,8 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
   }
   if (a.nch % 4 == 0 && pf_ok) hipLaunchKernelGGL(conv2d_c8i_pf_kernel, grid, dim3(256), PF_LDS, s, a);
   else if (a.nch % 4 == 0) hipLaunchKernelGGL((conv2d_c8i_kernel<4>), grid, dim3(256), 0, s, a);
+  else if (a.nch % 3 == 0) hipLaunchKernelGGL((conv2d_c8i_kernel<3>), grid, dim3(256), 0, s, a);
+  else if (a.nch % 2 == 0) hipLaunchKernelGGL((conv2d_c8i_kernel<2>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((conv2d_c8i_kernel<1>), grid, dim3(256), 0, s, a);
   MPN_CHECK_LAUNCH();
   return MPN_OK;
@@ -1807,6 +1875,7 @@ int resnet_build(const mpn_resnet_weights *rw, int max_h, int max_w, int max_roi
   g->tb_elems = te; g->hb_elems = he;
   const size_t esz = g->bf16 ? sizeof(bf16_t) : sizeof(float);
   RTRY(rn_alloc(g, &g->img, c8i_elems(1, 16, max_h, max_w) * esz));
+  if (g->conv1.col_w) RTRY(rn_alloc(g, &g->img_planar, (size_t)3 * max_h * max_w * sizeof(float)));
   for (int i = 0; i < 4; ++i) { RTRY(rn_alloc(g, &g->tb[i], te * esz)); MPN_CHECK_HIP(hipMemset(g->tb[i], 0, te * esz)); }
   for (int i = 0; i < 4; ++i) { RTRY(rn_alloc(g, &g->hb[i], he * esz)); MPN_CHECK_HIP(hipMemset(g->hb[i], 0, he * esz)); }  // pad planes must hold finite values
 #undef RTRY
@@ -2058,6 +2127,11 @@ int graph_build(const mpn_graph_weights *gw, int max_h, int max_w, int max_rois,
   g->feat_c = g->t_trunk[g->feat_tensor].C;
   g->out_c = g->t_head[g->out_tensor].C;
   g->img = g->t_trunk[0].buf;
+  for (const GOp &op : g->g_trunk)
+    if (op.kind == 0 && op.src == 0 && op.conv.col_w && !g->img_planar) {
+      rc = rn_alloc(g, &g->img_planar, (size_t)3 * max_h * max_w * sizeof(float));
+      if (rc != MPN_OK) { resnet_free(g); return rc; }
+    }
   g->heads.resize(n_heads);
   MPN_CHECK_HIP(hipDeviceSynchronize());
   *out = g;
@@ -2082,7 +2156,8 @@ static int graph_run(ResNetGraph *g, const std::vector<GOp> &ops, std::vector<GT
       src.C = op.cin;
     }
     GTensor &dst = ts[op.dst];
-    const ActI in{src.buf, B, src.C, src.H, src.W};
+    ActI in{src.buf, B, src.C, src.H, src.W};
+    if (&ts == &g->t_trunk && op.src == 0 && op.src_c_off == 0) in.planar = g->img_planar;
     const ActI od{dst.buf, B, dst.C, dst.H, dst.W};
     char *outp = reinterpret_cast<char *>(dst.buf) + (size_t)(op.dst_c_off / 8) * od.pitch() * 8 * esz;  // plane offset = the concat
     if (op.kind == 0 && fc_gemm && op.fc_w) {  // fully connected over the (bin, roi)-row pooled matrix (resnet_head_forward wrote it): row-invariant K segments
@@ -2139,7 +2214,7 @@ int resnet_trunk_forward(ResNetGraph *g, const float *d_image, int H, int W, con
                        reinterpret_cast<bf16_t *>(g->img), (ActI{g->img, 1, 3, H, W}).pitch());
   else
     hipLaunchKernelGGL(image_transform_c8i_kernel, dim3((unsigned)cdiv_sz(plane, 256)), dim3(256), 0, s, d_image, H, W, swap[0], swap[1], swap[2], scale,
-                       mean[0], mean[1], mean[2], has_std ? std[0] : 1.0, has_std ? std[1] : 1.0, has_std ? std[2] : 1.0, has_std, g->img);
+                       mean[0], mean[1], mean[2], has_std ? std[0] : 1.0, has_std ? std[1] : 1.0, has_std ? std[2] : 1.0, has_std, g->img, g->img_planar);
   MPN_CHECK_LAUNCH();
   if (g->is_graph) {
     int rc = graph_dims(g->g_trunk, g->t_trunk, H, W);
@@ -2150,6 +2225,7 @@ int resnet_trunk_forward(ResNetGraph *g, const float *d_image, int H, int W, con
     return MPN_OK;
   }
   ActI x{g->img, 1, 3, H, W}, y;
+  x.planar = g->img_planar;
   int rc = rn_conv(g->conv1, x, g->tb[0], nullptr, 1, s, &y);
   if (rc) return rc;
   const int OH = (y.H + 2 - 3) / 2 + 1, OW = (y.W + 2 - 3) / 2 + 1;

@@ -42,22 +42,24 @@ def test_alexnet_frcnn_vs_oracle(O, dev, H, W, N, width):
 
 def test_alexnet_fc_layers_on_the_gemm_equal_the_convolution_form(dev):
     """graph_parse bit 3: fc6 (the 6x6 convolution over the whole pooled map) and fc7 (1x1 on 1x1 maps) run on the tuned GEMM — the
-    ROI pooling writes (bin, roi) rows, K = (channel block, bin) — instead of the pixel-tile convolution kernels: the same dot
-    products in another summation order"""
+    ROI pooling writes (bin, roi) rows, K = (channel block, bin) — instead of the pixel-tile convolution kernels; bit 4: conv1 (3 input
+    channels) as a GEMM over im2col rows, k = (tap, channel), instead of 121 taps of a 3-of-8-channel record: the same dot products in
+    another summation order"""
     from conftest import hooks
     from multipathnet_amd import models
     H, W, N = 150, 250, 40
     G = models.synthetic_alexnet_params(n_classes=6, width=0.25, fc_dim=128, seed=3)
     im, boxes = _inputs(H, W, N, 4)
     out = []
-    for fuse in (7, 15):
+    for fuse in (7, 15, 31):
         with hooks(graph_fuse=fuse):
             net = models.AlexNetFRCNN(G, max_h=H, max_w=W, max_rois=64, top_k=20)
             s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
             out.append((s.cpu().numpy().copy(), b.cpu().numpy().copy()))
             del net
-    assert not np.array_equal(out[0][0], out[1][0])        # really two code paths
-    assert np.abs(out[0][0] - out[1][0]).max() < 1e-6 and np.abs(out[0][1] - out[1][1]).max() < 1e-3
+    for a, b in ((0, 1), (1, 2)):
+        assert not np.array_equal(out[a][0], out[b][0])        # really two code paths
+        assert np.abs(out[a][0] - out[b][0]).max() < 1e-6 and np.abs(out[a][1] - out[b][1]).max() < 1e-3
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])

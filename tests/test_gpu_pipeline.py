@@ -537,7 +537,7 @@ def test_iterative_localisation_vs_oracle(O, dev, small, num_iter, rbox, voting,
 
 
 def test_host_fed_pipeline_equals_device_fed(dev, small):
-    """mpn_frcnn_test_one_pipelined_host (upload on the handle's copy stream into two staging sets) == the device-fed form,
+    """mpn_frcnn_test_one_pipelined_host (upload on the handle's copy stream into three staging sets) == the device-fed form,
     image after image, including a size change in the middle of the stream."""
     net = small["net"]
     rng = np.random.default_rng(7)
