@@ -1452,6 +1452,27 @@ __global__ void lrn_c8i_kernel(const float *__restrict__ in, int Cb, int C, size
   *reinterpret_cast<f32x4 *>(q + 4) = f32x4{o[4], o[5], o[6], o[7]};
 }
 
+// C8I map (B = 1) <-> C8P map (dense.h: one zero halo row / column in front, padded behind): the trunk's 3x3 / stride-1 / pad-1
+// convolutions run on dense.hip's Winograd F(2x2,3x3) kernel, which reads its halo tiles straight from the padded layout
+__global__ void c8i_to_c8p_kernel(const float *__restrict__ in, int Cb, int H, int W, size_t pitch, int Hp, int Wp, float *__restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t HW = (size_t)H * W;
+  if (t >= HW * Cb * 2) return;
+  const int h = (int)(t & 1); size_t r = t >> 1;
+  const size_t px = r % HW; const int cb = (int)(r / HW);
+  const int y = (int)(px / W), x = (int)(px - (size_t)y * W);
+  *reinterpret_cast<f32x4 *>(out + (((size_t)cb * Hp + y + 1) * Wp + x + 1) * 8 + h * 4) = *reinterpret_cast<const f32x4 *>(in + ((size_t)cb * pitch + px) * 8 + h * 4);
+}
+__global__ void c8p_to_c8i_kernel(const float *__restrict__ in, int Cb, int H, int W, int Hp, int Wp, size_t pitch, float *__restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t HW = (size_t)H * W;
+  if (t >= HW * Cb * 2) return;
+  const int h = (int)(t & 1); size_t r = t >> 1;
+  const size_t px = r % HW; const int cb = (int)(r / HW);
+  const int y = (int)(px / W), x = (int)(px - (size_t)y * W);
+  *reinterpret_cast<f32x4 *>(out + ((size_t)cb * pitch + px) * 8 + h * 4) = *reinterpret_cast<const f32x4 *>(in + (((size_t)cb * Hp + y + 1) * Wp + x + 1) * 8 + h * 4);
+}
+
 // First layer (Cin = 3, fp32 graphs): im2col rows for the tuned GEMM.  One 8-channel record of the C8I image holds 3 real channels,
 // so the tap-by-tap convolution spends 8 / 3 of the matrix work on zeros (and runs the 8-channel-stage kernel); here
 // k = (ky * KW + kx) * 3 + c, zero beyond KH * KW * 3 and outside the image, written as the C8 matrix [K64 / 8][pitch][8].  It reads
@@ -1495,6 +1516,7 @@ struct RnConv {
   float *wpk = nullptr, *bpk = nullptr;
   float *lin_w = nullptr, *lin_b = nullptr;  // 1x1 / stride 1 with Cin % 64 == 0: also packed for the tuned GEMM (linear_c8)
   float *col_w = nullptr, *col_b = nullptr;  // Cin == 3 (fp32): packed for the GEMM over im2col rows, k = tap * 3 + c
+  float *wino = nullptr;                     // graph trunks (fp32), 3x3 / stride 1 / pad 1: Winograd-transformed weights (dense.h conv3x3_c8p)
   bf16_t *wpk16 = nullptr;                   // bf16 graph: [tap][nch2][CoutP][8]
   int norelu_c0 = 0, norelu_c1 = 0;          // output channels [c0, c1) skip the ReLU (fused siblings with mixed activations; multiples of 8)
   float *ws = nullptr;                       // the graph's split-K workspace
@@ -1508,6 +1530,8 @@ struct RnBlock {
 struct GTensor {
   int C = 0, H = 0, W = 0;
   float *buf = nullptr;
+  float *c8p = nullptr;       // trunk tensors a Winograd convolution reads or writes: the same map in the C8P layout
+  int p_h = 0, p_w = 0;       // the dims c8p's zero halo is laid out for (re-zeroed when the image size changes)
   int alias_of = -1, alias_c_off = 0;  // >= 0: this tensor is channels [alias_c_off, alias_c_off + C) of tensor alias_of (fused sibling convolutions)
 };
 struct GOp {
@@ -1555,7 +1579,7 @@ static int rn_alloc(ResNetGraph *g, float **p, size_t bytes) {
   return MPN_OK;
 }
 
-MPN_KNOB(int, g_graph_fuse, 31);  // mpn_debug_set_graph_fuse: bit 0 = fuse sibling pointwise convolutions, bit 1 = commute average-pool -> pointwise convolution, bit 2 = max-pools of the ROI-pooled input computed from the feature map, bit 3 = fully-connected head layers (whole-map / 1x1-map convolutions) on the tuned GEMM, bit 4 = the image layer (Cin = 3) as a GEMM over im2col rows; 0 = run the op list as given
+MPN_KNOB(int, g_graph_fuse, 63);  // mpn_debug_set_graph_fuse: bit 0 = fuse sibling pointwise convolutions, bit 1 = commute average-pool -> pointwise convolution, bit 2 = max-pools of the ROI-pooled input computed from the feature map, bit 3 = fully-connected head layers (whole-map / 1x1-map convolutions) on the tuned GEMM, bit 4 = the image layer (Cin = 3) as a GEMM over im2col rows, bit 5 = trunk 3x3 / stride-1 convolutions on dense.hip's Winograd kernel; 0 = run the op list as given
 static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b) {
   if (g->bf16) {
     const int nch2 = round_up((c.Cin + 7) / 8, 2), CoutP = round_up(c.Cout, 128), KK = c.KH * c.KW;
@@ -2056,6 +2080,18 @@ static int graph_parse(ResNetGraph *g, int n_ops, const mpn_graph_op *ops_in, in
       c.norelu_c0 = norelu_of[i].first; c.norelu_c1 = norelu_of[i].second;
       int rc = rn_pack(g, c, o.w, o.b);
       if (rc) return rc;
+      // trunk 3x3 / stride 1 / pad 1 on whole channel blocks: dense.hip's Winograd kernel (2.25x fewer multiplies; the generic
+      // kernel is the fallback when a tensor is a fused view)
+      if (!head && !g->bf16 && (g_graph_fuse & 32) && o.kh == 3 && o.kw == 3 && o.sh == 1 && o.sw == 1 && o.ph == 1 && o.pw == 1 && o.cin % 8 == 0 &&
+          o.cout % 8 == 0 && o.cin >= 16 && ts[o.src].alias_of < 0 && ts[o.dst].alias_of < 0 && norelu_of[i].first == norelu_of[i].second) {
+        bool viewed = false;
+        for (const GTensor &t : ts) viewed = viewed || t.alias_of == o.src || t.alias_of == o.dst;
+        if (!viewed) {
+          rc = rn_alloc(g, &c.wino, conv_wino_elems(o.cin, o.cout) * sizeof(float));
+          if (rc == MPN_OK) rc = pack_conv_weights_wino(o.w, o.cin, o.cout, c.wino, nullptr);
+          if (rc) return rc;
+        }
+      }
       // A convolution whose window is the whole ROI-pooled map (AlexNet's fc6: alexnet.lua's View(-1) + Linear(9216, 4096)) is a
       // fully-connected layer: with the pooled bins written as (bin, roi) rows it is ONE GEMM over K = Cin * bins on the tuned
       // kernel (the route the VGG pipeline's fc6 takes) instead of a 36-tap convolution on three 128-ROI pixel tiles.  Needs the
@@ -2116,6 +2152,30 @@ int graph_build(const mpn_graph_weights *gw, int max_h, int max_w, int max_rois,
     rc = rn_alloc(g, &t.buf, bytes);
     if (rc == MPN_OK && hipMemset(t.buf, 0, bytes) != hipSuccess) rc = MPN_EHIP;
   }
+  // a tensor lives in ONE layout at a time: the Winograd route only where every writer of the destination takes it (a DepthConcat
+  // of a 3x3 branch with pointwise / pooled branches stays on the generic kernels)
+  for (GOp &op : g->g_trunk)
+    if (op.conv.wino)
+      for (const GOp &other : g->g_trunk)
+        if (other.dst == op.dst && !(other.kind == 0 && other.conv.wino)) { op.conv.wino = nullptr; break; }
+  for (bool again = true; again;) {  // (clearing one writer may orphan another of the same tensor)
+    again = false;
+    for (GOp &op : g->g_trunk)
+      if (op.conv.wino)
+        for (const GOp &other : g->g_trunk)
+          if (other.dst == op.dst && !(other.kind == 0 && other.conv.wino)) { op.conv.wino = nullptr; again = true; break; }
+  }
+  for (const GOp &op : g->g_trunk) {
+    if (rc != MPN_OK || !op.conv.wino) continue;
+    for (int id : {op.src, op.dst}) {
+      GTensor &t = g->t_trunk[id];
+      if (t.c8p || rc != MPN_OK) continue;
+      const size_t bytes = act_bytes(t.C, t.H, t.W);
+      rc = rn_alloc(g, &t.c8p, bytes);
+      if (rc == MPN_OK && hipMemset(t.c8p, 0, bytes) != hipSuccess) rc = MPN_EHIP;
+      t.p_h = t.H; t.p_w = t.W;
+    }
+  }
   for (size_t i = 0; rc == MPN_OK && i < g->t_head.size(); ++i) {
     GTensor &t = g->t_head[i];
     if (t.H == 0 || t.alias_of >= 0) continue;
@@ -2142,8 +2202,57 @@ int graph_build(const mpn_graph_weights *gw, int max_h, int max_w, int max_rois,
 static int graph_run(ResNetGraph *g, const std::vector<GOp> &ops, std::vector<GTensor> &ts, int B, hipStream_t s, bool skip_from_rois = false,
                      bool fc_gemm = false) {
   const size_t esz = g->bf16 ? sizeof(bf16_t) : sizeof(float);
+  // layout bookkeeping for the Winograd convolutions (trunk only): which form of each tensor holds this run's values
+  const bool trunk = &ts == &g->t_trunk;
+  std::vector<char> in_i(ts.size(), 1), in_p(ts.size(), 0);
+  auto fit_halo = [&](GTensor &t) -> int {  // the padded buffer's zero halo sits where (t.H, t.W) needs it
+    if (t.p_h == t.H && t.p_w == t.W) return MPN_OK;
+    MPN_CHECK_HIP(hipMemsetAsync(t.c8p, 0, act_bytes(t.C, t.H, t.W), s));
+    t.p_h = t.H; t.p_w = t.W;
+    return MPN_OK;
+  };
+  auto need_c8i = [&](int id) -> int {
+    if (in_i[id]) return MPN_OK;
+    GTensor &t = ts[id];
+    const ActI ti{t.buf, 1, t.C, t.H, t.W};
+    const Act tp = make_act(t.c8p, t.C, t.H, t.W);
+    hipLaunchKernelGGL(c8p_to_c8i_kernel, dim3((unsigned)cdiv_sz((size_t)t.H * t.W * ti.Cb() * 2, 256)), dim3(256), 0, s, t.c8p, ti.Cb(), t.H, t.W, tp.Hp, tp.Wp,
+                       ti.pitch(), t.buf);
+    MPN_CHECK_LAUNCH();
+    in_i[id] = 1;
+    return MPN_OK;
+  };
   for (const GOp &op : ops) {
     if (skip_from_rois && op.from_rois) continue;  // already produced from the feature map (resnet_head_forward)
+    if (trunk && B == 1 && op.kind == 0 && op.conv.wino && (g_graph_fuse & 32) && ts[op.src].c8p && ts[op.dst].c8p) {
+      GTensor &ps = ts[op.src], &pd = ts[op.dst];
+      int rc = MPN_OK;
+      if (!in_p[op.src]) {
+        rc = fit_halo(ps);
+        if (rc) return rc;
+        const ActI ti{ps.buf, 1, ps.C, ps.H, ps.W};
+        const Act tp = make_act(ps.c8p, ps.C, ps.H, ps.W);
+        hipLaunchKernelGGL(c8i_to_c8p_kernel, dim3((unsigned)cdiv_sz((size_t)ps.H * ps.W * ti.Cb() * 2, 256)), dim3(256), 0, s, ps.buf, ti.Cb(), ps.H, ps.W, ti.pitch(),
+                           tp.Hp, tp.Wp, ps.c8p);
+        MPN_CHECK_LAUNCH();
+        in_p[op.src] = 1;
+      }
+      if (!in_p[op.dst]) { rc = fit_halo(pd); if (rc) return rc; }
+      const Act fs = make_act(ps.c8p, ps.C, ps.H, ps.W), fd = make_act(pd.c8p, pd.C, pd.H, pd.W);
+      const Act ain = Act{ps.c8p + (size_t)(op.src_c_off / 8) * fs.plane(), op.cin, ps.H, ps.W, fs.Hp, fs.Wp};
+      const Act aout = Act{pd.c8p + (size_t)(op.dst_c_off / 8) * fd.plane(), op.conv.Cout, pd.H, pd.W, fd.Hp, fd.Wp};
+      rc = conv3x3_c8p(ain, nullptr, op.conv.bpk, op.conv.Cout, op.relu, aout, Act{nullptr, 0, 0, 0, 0, 0}, s, op.conv.wino);
+      if (rc) return rc;
+      in_p[op.dst] = 1; in_i[op.dst] = 0;
+      continue;
+    }
+    if (trunk) {
+      int rc = need_c8i(op.src);
+      if (rc) return rc;
+      // a plain op that writes part of a tensor whose other channels so far exist only in the padded form: bring those over first
+      if (!in_i[op.dst] && in_p[op.dst]) { rc = need_c8i(op.dst); if (rc) return rc; }
+      in_i[op.dst] = 1; in_p[op.dst] = 0;
+    }
     GTensor src = ts[op.src];
     if (src.alias_of >= 0) {  // channel-plane view of a fused tensor (same rows, so the same pitch)
       const GTensor &par = ts[src.alias_of];
@@ -2201,6 +2310,7 @@ static int graph_run(ResNetGraph *g, const std::vector<GOp> &ops, std::vector<GT
       MPN_CHECK_LAUNCH();
     }
   }
+  if (trunk) { int rc = need_c8i(g->feat_tensor); if (rc) return rc; }  // the ROI pooling reads the C8I map
   return MPN_OK;
 }
 
