@@ -18,7 +18,7 @@ done
 ls -la $OUT
 # the other BASELINE configs as bench.py lines (own metric strings, never the headline)
 for c in c1 c3 c4 c5; do
-  timeout 600 python $R/bench.py --config $c --steps 6 --warmup 2 > $OUT/${TAG}_bench_$c.json 2> /tmp/bench_$c.err
+  timeout 600 python $R/bench.py --config $c --steps $([ $c = c1 ] && echo 50 || echo 6) --warmup 2 > $OUT/${TAG}_bench_$c.json 2> /tmp/bench_$c.err
 done
 timeout 600 python $R/bench.py --config c4 --dtype bf16 --steps 6 --warmup 2 > $OUT/${TAG}_bench_c4_bf16.json 2> /tmp/bench_c4b.err
 # round 3: the ROI-sharded latency mode at N = 1 (+ the one-GPU projection of rank 0's share of an 8-rank world)
