@@ -673,7 +673,8 @@ class FastRCNN(object):
 
     def test_one_pipelined_host(self, image_pinned, boxes_pinned):
         """mpn_frcnn_test_one_pipelined_host: the same throughput form fed from (pinned) HOST tensors — the upload runs on the
-        handle's copy stream and overlaps the previous image's kernels.  Alternate two host buffers between calls."""
+        handle's copy stream and overlaps the previous image's kernels.  Alternate two host buffers between calls; the call blocks
+        the host while the device is more than three images behind."""
         H, W = image_pinned.shape[1:]
         assert not image_pinned.is_cuda and not boxes_pinned.is_cuda and image_pinned.dtype == torch.float32
         b = self._pipe_seq & 1
