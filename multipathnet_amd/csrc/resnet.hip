@@ -1129,6 +1129,26 @@ __global__ void bf16_sortable_kernel(const u32x4 *__restrict__ in, size_t n, u32
   out[t] = v;
 }
 
+// vertical range-max (sparse) table level of the sortable map: out[y] = max(prev[y], prev[y + step]) = max over rows y .. y + 2 * step - 1
+// (rows past H - 2 * step are never queried).  The fused ROI max-pool below then reads two rows per window column instead of all of them.
+__global__ void vmax_level_sorted_kernel(const u32x4 *__restrict__ prev, u32x4 *__restrict__ out, int H, int W, size_t pitch, int Cb, int step) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t HW = (size_t)H * W;
+  if (t >= HW * Cb) return;
+  const int cb = (int)(t / HW); const size_t px = t - (size_t)cb * HW;
+  const int y = (int)(px / W);
+  const u32x4 a = prev[(size_t)cb * pitch + px];
+  const u32x4 b = prev[(size_t)cb * pitch + px + (y + step < H ? (size_t)step * W : 0)];
+  u32x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned ua = a[e], ub = b[e];
+    const i16x2 mx = __builtin_elementwise_max(__builtin_bit_cast(i16x2, ua), __builtin_bit_cast(i16x2, ub));
+    r[e] = __builtin_bit_cast(unsigned, mx);
+  }
+  out[(size_t)cb * pitch + px] = r;
+}
+
 template <int CBG>  // channel blocks per thread (grid.y = Cb / CBG)
 __global__ __launch_bounds__(256) void roi_pool_c8i_bf16_sorted_kernel(const u32x4 *__restrict__ feat, int H, int W, size_t pitch_f,
                                                                         const float *__restrict__ rois, int roi_stride, int N, int PH, int PW, float scale,
@@ -1187,7 +1207,8 @@ __global__ __launch_bounds__(256) void roi_pool_c8i_bf16_sorted_kernel(const u32
 template <int CBG>
 __global__ __launch_bounds__(256) void roi_maxpool_c8i_bf16_sorted_kernel(const u32x4 *__restrict__ feat, int H, int W, size_t pitch_f,
                                                                            const float *__restrict__ rois, int roi_stride, int N, int PH, int PW, float scale,
-                                                                           int k, int stride, int pad, int OH, int OW, u32x4 *__restrict__ out, size_t pitch_o) {
+                                                                           int k, int stride, int pad, int OH, int OW, u32x4 *__restrict__ out, size_t pitch_o,
+                                                                           const u32x4 *__restrict__ tabs, size_t level_elems, int n_levels) {
   const int OP = OH * OW;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (roi, output pixel): the output row of the max-pooled batch
   if (t >= (size_t)N * OP) return;
@@ -1217,7 +1238,16 @@ __global__ __launch_bounds__(256) void roi_maxpool_c8i_bf16_sorted_kernel(const 
   u32x4 m[CBG];
 #pragma unroll
   for (int c = 0; c < CBG; ++c) m[c] = u32x4{lowest, lowest, lowest, lowest};
-  for (int y = hs; y < he; ++y)
+  // rows [hs, he) as ceil(h / 2^lv) blocks of 2^lv rows from table level lv (the last block pulled back to end at he: overlap is
+  // harmless for a max); lv = floor(log2 h) capped at the levels built -> two row reads per column for any window height
+  int lv = 0, bstep = 1;
+  if (tabs && he - hs > 1) {
+    lv = min(31 - __builtin_clz((unsigned)(he - hs)), n_levels);
+    bstep = 1 << lv;
+    if (lv > 0) fp = tabs + (size_t)(lv - 1) * level_elems + (size_t)cb0 * pitch_f;
+  }
+  for (int y0 = hs; y0 < he; y0 += bstep) {
+    const int y = min(y0, he - bstep);
     for (int x = ws; x < we; ++x) {
       const size_t px = (size_t)y * W + x;
 #pragma unroll
@@ -1231,6 +1261,7 @@ __global__ __launch_bounds__(256) void roi_maxpool_c8i_bf16_sorted_kernel(const 
         }
       }
     }
+  }
 #pragma unroll
   for (int c = 0; c < CBG; ++c) {
     u32x4 r;
@@ -1566,6 +1597,10 @@ struct ResNetGraph {
   bf16_t *feat_sorted = nullptr; // order-preserving int16 re-coding of the cached feature map (bf16 ROI pooling), rebuilt per trunk run
   size_t feat_sorted_elems = 0;
   bool feat_sorted_valid = false;
+  bf16_t *feat_vmax = nullptr;   // vertical range-max levels 1 .. feat_vmax_levels of feat_sorted (the fused ROI max-pool reads two rows per column)
+  size_t feat_vmax_elems = 0;    // elements per level
+  int feat_vmax_levels = 0;
+  bool feat_vmax_valid = false;
   float *splitk_ws = nullptr;    // fp32 partial slabs of split-K convolutions (bf16 graph; one stream at a time, like tb / hb)
   std::vector<void *> allocs;
 };
@@ -1579,7 +1614,7 @@ static int rn_alloc(ResNetGraph *g, float **p, size_t bytes) {
   return MPN_OK;
 }
 
-MPN_KNOB(int, g_graph_fuse, 63);  // mpn_debug_set_graph_fuse: bit 0 = fuse sibling pointwise convolutions, bit 1 = commute average-pool -> pointwise convolution, bit 2 = max-pools of the ROI-pooled input computed from the feature map, bit 3 = fully-connected head layers (whole-map / 1x1-map convolutions) on the tuned GEMM, bit 4 = the image layer (Cin = 3) as a GEMM over im2col rows, bit 5 = trunk 3x3 / stride-1 convolutions on dense.hip's Winograd kernel; 0 = run the op list as given
+MPN_KNOB(int, g_graph_fuse, 127);  // mpn_debug_set_graph_fuse: bit 0 = fuse sibling pointwise convolutions, bit 1 = commute average-pool -> pointwise convolution, bit 2 = max-pools of the ROI-pooled input computed from the feature map, bit 3 = fully-connected head layers (whole-map / 1x1-map convolutions) on the tuned GEMM, bit 4 = the image layer (Cin = 3) as a GEMM over im2col rows, bit 5 = trunk 3x3 / stride-1 convolutions on dense.hip's Winograd kernel, bit 6 = the fused ROI max-pool (bit 2) reads vertical range-max tables of the map; 0 = run the op list as given
 static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b) {
   if (g->bf16) {
     const int nch2 = round_up((c.Cin + 7) / 8, 2), CoutP = round_up(c.Cout, 128), KK = c.KH * c.KW;
@@ -2331,7 +2366,7 @@ int resnet_trunk_forward(ResNetGraph *g, const float *d_image, int H, int W, con
     if (rc == MPN_OK) rc = graph_run(g, g->g_trunk, g->t_trunk, 1, s);
     if (rc) return rc;
     const GTensor &f = g->t_trunk[g->feat_tensor];
-    g->feat = f.buf; g->feat_h = f.H; g->feat_w = f.W; g->last_h = H; g->last_w = W; g->feat_sorted_valid = false;
+    g->feat = f.buf; g->feat_h = f.H; g->feat_w = f.W; g->last_h = H; g->last_w = W; g->feat_sorted_valid = false; g->feat_vmax_valid = false;
     return MPN_OK;
   }
   ActI x{g->img, 1, 3, H, W}, y;
@@ -2356,7 +2391,7 @@ int resnet_trunk_forward(ResNetGraph *g, const float *d_image, int H, int W, con
     if (rc) return rc;
     cur = y;
   }
-  g->feat = cur.p; g->feat_h = cur.H; g->feat_w = cur.W; g->last_h = H; g->last_w = W; g->feat_sorted_valid = false;
+  g->feat = cur.p; g->feat_h = cur.H; g->feat_w = cur.W; g->last_h = H; g->last_w = W; g->feat_sorted_valid = false; g->feat_vmax_valid = false;
   return MPN_OK;
 }
 
@@ -2381,11 +2416,31 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
         if (rc) return rc;
         g->feat_sorted = reinterpret_cast<bf16_t *>(q); g->feat_sorted_elems = need; g->feat_sorted_valid = false;
       }
+      bool any_mp = false;
+      if (fuse_mp) for (const GOp &op : g->g_heads[head]) any_mp = any_mp || op.from_rois;
+      const int want_levels = (any_mp && (g_graph_fuse & 64) && g->feat_h > 1) ? 31 - __builtin_clz((unsigned)g->feat_h) : 0;
+      if (want_levels > 0 && (g->feat_vmax_elems < need || g->feat_vmax_levels < want_levels)) {  // outside the steady state, as above
+        float *q = nullptr;
+        int rc = rn_alloc(g, &q, need * sizeof(bf16_t) * want_levels);
+        if (rc) return rc;
+        g->feat_vmax = reinterpret_cast<bf16_t *>(q); g->feat_vmax_elems = need; g->feat_vmax_levels = want_levels; g->feat_vmax_valid = false;
+      }
       if (!g->feat_sorted_valid) {
         hipLaunchKernelGGL(bf16_sortable_kernel, dim3((unsigned)cdiv_sz(need / 8, 256)), dim3(256), 0, s, reinterpret_cast<const u32x4 *>(g->feat), need / 8,
                            reinterpret_cast<u32x4 *>(g->feat_sorted));
         MPN_CHECK_LAUNCH();
         g->feat_sorted_valid = true;
+        g->feat_vmax_valid = false;
+      }
+      if (want_levels > 0 && !g->feat_vmax_valid) {  // once per image: level l from level l - 1 (level 0 = the sortable map)
+        for (int l = 1; l <= want_levels; ++l) {
+          const u32x4 *prev = l == 1 ? reinterpret_cast<const u32x4 *>(g->feat_sorted)
+                                     : reinterpret_cast<const u32x4 *>(g->feat_vmax) + (size_t)(l - 2) * (g->feat_vmax_elems / 8);
+          hipLaunchKernelGGL(vmax_level_sorted_kernel, dim3((unsigned)cdiv_sz((size_t)g->feat_h * g->feat_w * Cb, 256)), dim3(256), 0, s, prev,
+                             reinterpret_cast<u32x4 *>(g->feat_vmax) + (size_t)(l - 1) * (g->feat_vmax_elems / 8), g->feat_h, g->feat_w, fa.pitch(), Cb, 1 << (l - 1));
+          MPN_CHECK_LAUNCH();
+        }
+        g->feat_vmax_valid = true;
       }
       hipLaunchKernelGGL(roi_pool_c8i_bf16_sorted_kernel<4>, dim3((unsigned)cdiv_sz((size_t)N * PH * PH, 256), (unsigned)(Cb / 4)), dim3(256), 0, s,
                          reinterpret_cast<const u32x4 *>(g->feat_sorted), g->feat_h, g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale,
@@ -2399,7 +2454,8 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
           char *outp = reinterpret_cast<char *>(dst.buf) + (size_t)(op.dst_c_off / 8) * od.pitch() * 8 * sizeof(bf16_t);  // plane offset = the concat
           hipLaunchKernelGGL(roi_maxpool_c8i_bf16_sorted_kernel<4>, dim3((unsigned)cdiv_sz((size_t)N * dst.H * dst.W, 256), (unsigned)(Cb / 4)), dim3(256), 0, s,
                              reinterpret_cast<const u32x4 *>(g->feat_sorted), g->feat_h, g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale,
-                             op.kh, op.sh, op.ph, dst.H, dst.W, reinterpret_cast<u32x4 *>(outp), od.pitch());
+                             op.kh, op.sh, op.ph, dst.H, dst.W, reinterpret_cast<u32x4 *>(outp), od.pitch(),
+                             want_levels > 0 ? reinterpret_cast<const u32x4 *>(g->feat_vmax) : nullptr, g->feat_vmax_elems / 8, want_levels);
         }
     } else if (g->bf16)
       hipLaunchKernelGGL(roi_pool_c8i_bf16_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, reinterpret_cast<const bf16_t *>(g->feat), Cb, g->feat_h,

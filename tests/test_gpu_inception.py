@@ -87,7 +87,7 @@ def test_inception_sibling_fusion_equivalent(dev, bf16):
     G = models.synthetic_inception_v3_params(n_classes=C, width=0.25, seed=31)
     im, boxes = _inputs(H, W, N, 21)
     out = []
-    for fuse in (3, 0, 1, 7):
+    for fuse in (3, 0, 1, 7, 71):
         with hooks(graph_fuse=fuse):  # 7 = the product library (3 + the max-pool of the ROI-pooled input computed from the feature map)
             net = models.InceptionFRCNN(G, max_h=H, max_w=W, max_rois=32, top_k=10, bf16=bf16)
             s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
@@ -100,3 +100,5 @@ def test_inception_sibling_fusion_equivalent(dev, bf16):
     # bit 2 (bf16 only; fp32 graphs ignore it): Mixed_7a's max-pool of the ROI-pooled input taken straight from the feature map — max of
     # maxes over the union of the bins' windows, exact: identical scores and boxes
     assert np.array_equal(out[3][0], out[0][0]) and np.array_equal(out[3][1], out[0][1])
+    # bit 6: the same fused max-pool reading two rows of a vertical range-max table per window column instead of every row: still a max
+    assert np.array_equal(out[4][0], out[0][0]) and np.array_equal(out[4][1], out[0][1])
