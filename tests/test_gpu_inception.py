@@ -88,7 +88,7 @@ def test_inception_sibling_fusion_equivalent(dev, bf16):
     im, boxes = _inputs(H, W, N, 21)
     out = []
     for fuse in (3, 0, 1, 7, 71):
-        with hooks(graph_fuse=fuse):  # 7 = the product library (3 + the max-pool of the ROI-pooled input computed from the feature map)
+        with hooks(graph_fuse=fuse):  # 3 / 7 / 71 = subsets of the product library's rewrites (127): 3 + the max-pool of the ROI-pooled input computed from the feature map (+ 64: from range-max tables)
             net = models.InceptionFRCNN(G, max_h=H, max_w=W, max_rois=32, top_k=10, bf16=bf16)
             s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
             out.append((s.cpu().numpy().copy(), b.cpu().numpy().copy()))
