@@ -1504,6 +1504,31 @@ __global__ void c8p_to_c8i_kernel(const float *__restrict__ in, int Cb, int H, i
   *reinterpret_cast<f32x4 *>(out + ((size_t)cb * pitch + px) * 8 + h * 4) = *reinterpret_cast<const f32x4 *>(in + (((size_t)cb * Hp + y + 1) * Wp + x + 1) * 8 + h * 4);
 }
 
+// A batch of small per-ROI maps (ResNet's layer4: 1000 x 7 x 7) as ONE padded C8P image for the Winograd kernel: a mosaic of
+// (H + 1) x (W + 1) cells, mx maps per mosaic row, map b at cell (b / mx, b % mx) with its pixels in the cell's top-left H x W and
+// the cell's last row / column left ZERO — together with the C8P halo every map is surrounded by zeros, i.e. pad 1.  The
+// converters only ever touch map pixels, so the zeros written at allocation stay (any N up to the capacity the mosaic was laid out for).
+__global__ void c8i_to_mosaic_kernel(const float *__restrict__ in, int Cb, int N, int H, int W, size_t pitch_i, int mx, int Hp, int Wp, float *__restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t rows = (size_t)N * H * W;
+  if (t >= rows * Cb * 2) return;
+  const int h = (int)(t & 1); size_t r = t >> 1;
+  const size_t row = r % rows; const int cb = (int)(r / rows);
+  const int b = (int)(row / (H * W)), px = (int)(row - (size_t)b * H * W), y = px / W, x = px - y * W;
+  const size_t my = (size_t)(b / mx) * (H + 1) + y + 1, mxx = (size_t)(b % mx) * (W + 1) + x + 1;
+  *reinterpret_cast<f32x4 *>(out + (((size_t)cb * Hp + my) * Wp + mxx) * 8 + h * 4) = *reinterpret_cast<const f32x4 *>(in + ((size_t)cb * pitch_i + row) * 8 + h * 4);
+}
+__global__ void mosaic_to_c8i_kernel(const float *__restrict__ in, int Cb, int N, int H, int W, int mx, int Hp, int Wp, size_t pitch_o, float *__restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t rows = (size_t)N * H * W;
+  if (t >= rows * Cb * 2) return;
+  const int h = (int)(t & 1); size_t r = t >> 1;
+  const size_t row = r % rows; const int cb = (int)(r / rows);
+  const int b = (int)(row / (H * W)), px = (int)(row - (size_t)b * H * W), y = px / W, x = px - y * W;
+  const size_t my = (size_t)(b / mx) * (H + 1) + y + 1, mxx = (size_t)(b % mx) * (W + 1) + x + 1;
+  *reinterpret_cast<f32x4 *>(out + ((size_t)cb * pitch_o + row) * 8 + h * 4) = *reinterpret_cast<const f32x4 *>(in + (((size_t)cb * Hp + my) * Wp + mxx) * 8 + h * 4);
+}
+
 // First layer (Cin = 3, fp32 graphs): im2col rows for the tuned GEMM.  One 8-channel record of the C8I image holds 3 real channels,
 // so the tap-by-tap convolution spends 8 / 3 of the matrix work on zeros (and runs the 8-channel-stage kernel); here
 // k = (ky * KW + kx) * 3 + c, zero beyond KH * KW * 3 and outside the image, written as the C8 matrix [K64 / 8][pitch][8].  It reads
@@ -1547,7 +1572,9 @@ struct RnConv {
   float *wpk = nullptr, *bpk = nullptr;
   float *lin_w = nullptr, *lin_b = nullptr;  // 1x1 / stride 1 with Cin % 64 == 0: also packed for the tuned GEMM (linear_c8)
   float *col_w = nullptr, *col_b = nullptr;  // Cin == 3 (fp32): packed for the GEMM over im2col rows, k = tap * 3 + c
-  float *wino = nullptr;                     // graph trunks (fp32), 3x3 / stride 1 / pad 1: Winograd-transformed weights (dense.h conv3x3_c8p)
+  float *wino = nullptr;                     // graph trunks / ResNet heads (fp32), 3x3 / stride 1 / pad 1: Winograd-transformed weights (dense.h conv3x3_c8p)
+  float *mos_in = nullptr, *mos_out = nullptr;  // ResNet heads: the mosaic images (shared by the head's eligible convolutions), laid out for
+  int mos_h = 0, mos_w = 0, mos_mx = 0, mos_rows = 0, mos_cols = 0;  //   mos_rows x mos_cols px = max_rois maps of mos_h x mos_w, mos_mx per mosaic row
   bf16_t *wpk16 = nullptr;                   // bf16 graph: [tap][nch2][CoutP][8]
   int norelu_c0 = 0, norelu_c1 = 0;          // output channels [c0, c1) skip the ReLU (fused siblings with mixed activations; multiples of 8)
   float *ws = nullptr;                       // the graph's split-K workspace
@@ -1614,7 +1641,7 @@ static int rn_alloc(ResNetGraph *g, float **p, size_t bytes) {
   return MPN_OK;
 }
 
-MPN_KNOB(int, g_graph_fuse, 127);  // mpn_debug_set_graph_fuse: bit 0 = fuse sibling pointwise convolutions, bit 1 = commute average-pool -> pointwise convolution, bit 2 = max-pools of the ROI-pooled input computed from the feature map, bit 3 = fully-connected head layers (whole-map / 1x1-map convolutions) on the tuned GEMM, bit 4 = the image layer (Cin = 3) as a GEMM over im2col rows, bit 5 = trunk 3x3 / stride-1 convolutions on dense.hip's Winograd kernel, bit 6 = the fused ROI max-pool (bit 2) reads vertical range-max tables of the map; 0 = run the op list as given
+MPN_KNOB(int, g_graph_fuse, 255);  // mpn_debug_set_graph_fuse: bit 0 = fuse sibling pointwise convolutions, bit 1 = commute average-pool -> pointwise convolution, bit 2 = max-pools of the ROI-pooled input computed from the feature map, bit 3 = fully-connected head layers (whole-map / 1x1-map convolutions) on the tuned GEMM, bit 4 = the image layer (Cin = 3) as a GEMM over im2col rows, bit 5 = trunk 3x3 / stride-1 convolutions on dense.hip's Winograd kernel, bit 6 = the fused ROI max-pool (bit 2) reads vertical range-max tables of the map, bit 7 = ResNet heads' 3x3 / stride-1 convolutions on the Winograd kernel (mosaic image of the per-ROI maps); 0 = run the op list as given
 static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b) {
   if (g->bf16) {
     const int nch2 = round_up((c.Cin + 7) / 8, 2), CoutP = round_up(c.Cout, 128), KK = c.KH * c.KW;
@@ -1774,6 +1801,23 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
   a.P = (long long)in.B * a.OH * a.OW;
   *o = ActI{out, in.B, c.Cout, a.OH, a.OW};
   a.pitch_in = in.pitch(); a.pitch_out = o->pitch();
+  if (c.wino && c.mos_in && !res && in.B > 1 && in.H == c.mos_h && in.W == c.mos_w && c.norelu_c1 == c.norelu_c0 && (g_graph_fuse & 128) &&
+      ((in.B + c.mos_mx - 1) / c.mos_mx) * (in.H + 1) <= c.mos_rows) {
+    // per-ROI 3x3 / stride-1 convolution (layer4's conv2 of blocks 2, 3): the batch as a mosaic image on the Winograd kernel
+    const int rows = ((in.B + c.mos_mx - 1) / c.mos_mx) * (in.H + 1);
+    const int Hp = act_hp(c.mos_rows), Wp = act_wp(c.mos_cols);
+    const size_t recs = (size_t)in.B * in.H * in.W;
+    hipLaunchKernelGGL(c8i_to_mosaic_kernel, dim3((unsigned)cdiv_sz(recs * in.Cb() * 2, 256)), dim3(256), 0, s, in.p, in.Cb(), in.B, in.H, in.W, in.pitch(), c.mos_mx, Hp, Wp,
+                       c.mos_in);
+    MPN_CHECK_LAUNCH();
+    const Act ain{c.mos_in, c.Cin, rows, c.mos_cols, Hp, Wp}, aout{c.mos_out, c.Cout, rows, c.mos_cols, Hp, Wp};
+    int rcw = conv3x3_c8p(ain, nullptr, c.bpk, c.Cout, relu, aout, Act{nullptr, 0, 0, 0, 0, 0}, s, c.wino);
+    if (rcw) return rcw;
+    hipLaunchKernelGGL(mosaic_to_c8i_kernel, dim3((unsigned)cdiv_sz(recs * o->Cb() * 2, 256)), dim3(256), 0, s, c.mos_out, o->Cb(), in.B, in.H, in.W, c.mos_mx, Hp, Wp,
+                       o->pitch(), out);
+    MPN_CHECK_LAUNCH();
+    return MPN_OK;
+  }
   if (allow_gemm && c.col_w && in.planar && in.B == 1 && in.C == 3 && !res && c.norelu_c1 == c.norelu_c0 && (g_graph_fuse & 16)) {
     const int Kc = c.KH * c.KW * 3, nkb = round_up(Kc, 64) / 8;
     const size_t need = (size_t)nkb * o->pitch() * 8 * sizeof(float);
@@ -1878,18 +1922,24 @@ int resnet_build(const mpn_resnet_weights *rw, int max_h, int max_w, int max_roi
   const int per_head = n_head_blocks / n_heads;
   g->heads.resize(n_heads);
   int ci = 0;
+  bool head_conv = false;  // set while the head blocks' convolutions are taken
   auto take = [&](RnConv &c) -> int {
     if (ci >= rw->n_convs) { set_error("mpn_resnet_create: block table needs more than %d convolutions", rw->n_convs); return MPN_EINVAL; }
     c.Cin = rw->cin[ci]; c.Cout = rw->cout[ci]; c.K = rw->ksize[ci]; c.stride = rw->stride[ci]; c.pad = rw->pad[ci];
     c.KH = c.KW = c.K; c.sh = c.sw = c.stride; c.ph = c.pw = c.pad;
     if (!(c.Cin > 0 && c.Cout > 0 && c.K > 0 && c.stride > 0 && c.pad >= 0 && rw->w[ci])) { set_error("mpn_resnet_create: bad convolution %d", ci); return MPN_EINVAL; }
     int r = rn_pack(g, c, rw->w[ci], rw->b ? rw->b[ci] : nullptr);
+    if (r == MPN_OK && head_conv && !g->bf16 && (g_graph_fuse & 128) && c.K == 3 && c.stride == 1 && c.pad == 1 && c.Cin % 8 == 0 && c.Cout % 8 == 0 && c.Cin >= 16) {
+      r = rn_alloc(g, &c.wino, conv_wino_elems(c.Cin, c.Cout) * sizeof(float));
+      if (r == MPN_OK) r = pack_conv_weights_wino(rw->w[ci], c.Cin, c.Cout, c.wino, nullptr);
+    }
     ++ci;
     return r;
   };
   RTRY(take(g->conv1));
   for (int b = 0; b < rw->n_blocks; ++b) {
     RnBlock blk;
+    head_conv = b >= rw->n_trunk_blocks;
     for (int k = 0; k < rw->block_n_convs[b]; ++k) { RnConv c; RTRY(take(c)); blk.convs.push_back(c); }
     blk.has_sc = rw->block_has_shortcut[b] != 0;
     if (blk.has_sc) RTRY(take(blk.sc));
@@ -1916,12 +1966,18 @@ int resnet_build(const mpn_resnet_weights *rw, int max_h, int max_w, int max_roi
   }
   g->feat_c = c;
   h = w = pooled;
+  int mos_h = 0, mos_w = 0, mos_cin = 0, mos_cout = 0;
   size_t he = c8i_elems(max_rois, c, h, w);
   for (auto &hd : g->heads) {
     int hh = h, hw = w, hc = g->feat_c;
     for (auto &blk : hd) {
       int bh = hh, bw = hw;
       for (auto &cv : blk.convs) {
+        if (cv.wino) {  // mosaic geometry of this convolution's input maps (one geometry per graph: the first eligible one's)
+          if (mos_h == 0) { mos_h = bh; mos_w = bw; }
+          if (bh == mos_h && bw == mos_w) { mos_cin = std::max(mos_cin, cv.Cin); mos_cout = std::max(mos_cout, cv.Cout); cv.mos_h = bh; cv.mos_w = bw; }
+          else cv.wino = nullptr;
+        }
         rn_shape(cv, bh, bw);
         he = std::max(he, c8i_elems(max_rois, cv.Cout, bh, bw));
         hc = cv.Cout;
@@ -1932,6 +1988,17 @@ int resnet_build(const mpn_resnet_weights *rw, int max_h, int max_w, int max_roi
     g->out_c = hc;
   }
   g->tb_elems = te; g->hb_elems = he;
+  if (mos_h > 0) {  // the two mosaic images, zeroed once (the converters never touch the zero rows / columns between the maps)
+    const int mx = std::max(1, 32 / (mos_w + 1)), rows = ((max_rois + mx - 1) / mx) * (mos_h + 1), cols = mx * (mos_w + 1);
+    float *mi = nullptr, *mo = nullptr;
+    RTRY(rn_alloc(g, &mi, act_bytes(mos_cin, rows, cols)));
+    RTRY(rn_alloc(g, &mo, act_bytes(mos_cout, rows, cols)));
+    if (hipMemset(mi, 0, act_bytes(mos_cin, rows, cols)) != hipSuccess || hipMemset(mo, 0, act_bytes(mos_cout, rows, cols)) != hipSuccess) { resnet_free(g); return MPN_EHIP; }
+    for (auto &hd : g->heads)
+      for (auto &blk : hd)
+        for (auto &cv : blk.convs)
+          if (cv.wino) { cv.mos_in = mi; cv.mos_out = mo; cv.mos_mx = mx; cv.mos_rows = rows; cv.mos_cols = cols; }
+  }
   const size_t esz = g->bf16 ? sizeof(bf16_t) : sizeof(float);
   RTRY(rn_alloc(g, &g->img, c8i_elems(1, 16, max_h, max_w) * esz));
   if (g->conv1.col_w) RTRY(rn_alloc(g, &g->img_planar, (size_t)3 * max_h * max_w * sizeof(float)));

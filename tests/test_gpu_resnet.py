@@ -49,6 +49,31 @@ def _fp32_case(O, dev, bt, blocks, width, pooled, N):
     assert torch.equal(s2, s2f)
 
 
+@pytest.mark.parametrize("bt,blocks,width,pooled,N", [("bottleneck", [1, 1, 1, 2], 16, 14, 150), ("basic", [1, 2, 1, 2], 8, 14, 37), ("bottleneck", [1, 1, 1, 3], 8, 6, 5)])
+def test_resnet_head_3x3_on_the_winograd_mosaic(dev, bt, blocks, width, pooled, N):
+    """graph_fuse bit 7: layer4's stride-1 3x3 convolutions run on the VGG pipeline's Winograd kernel over a MOSAIC image of the per-ROI maps
+    (cells of (H + 1) x (W + 1) px, the spare row / column zero = the convolution's padding) instead of the generic per-pixel-tile
+    kernel: another summation order, same result to rounding; also with fewer ROIs than the mosaic was laid out for, twice in a row"""
+    from multipathnet_amd import models
+    H, W, C = 97, 131, 6
+    R = models.synthetic_resnet_params(depth=0, n_classes=C, base_width=width, blocks=blocks, block_type=bt, seed=23)
+    im, boxes = _inputs(H, W, N, 5)
+    imd, bd = torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev)
+    out = []
+    for fuse in (127, 255):
+        with hooks(graph_fuse=fuse):
+            net = models.ResNetFRCNN(R, pooled=pooled, max_h=H, max_w=W, max_rois=max(64, N), top_k=20)
+            s, b = net.detect(imd, bd)
+            s1 = s.cpu().numpy().copy()
+            net.detect(imd, bd[: max(1, N // 3)])               # a smaller batch in between ...
+            s2, _ = net.detect(imd, bd)                         # ... leaves nothing behind in the mosaic
+            assert np.array_equal(s2.cpu().numpy(), s1)
+            out.append((s1, b.cpu().numpy().copy()))
+            del net
+    assert not np.array_equal(out[0][0], out[1][0])             # really two code paths
+    assert np.abs(out[0][0] - out[1][0]).max() < 1e-5 and np.abs(out[0][1] - out[1][1]).max() < 1e-2
+
+
 def test_resnet_test_one_pipeline(O, dev):
     """the whole Tester:testOne path (NMS, top-k, pipelined form) on the ResNet model: serial == pipelined exactly"""
     from multipathnet_amd import models
