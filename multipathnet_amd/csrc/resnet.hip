@@ -1504,6 +1504,14 @@ __global__ void c8p_to_c8i_kernel(const float *__restrict__ in, int Cb, int H, i
   *reinterpret_cast<f32x4 *>(out + ((size_t)cb * pitch + px) * 8 + h * 4) = *reinterpret_cast<const f32x4 *>(in + (((size_t)cb * Hp + y + 1) * Wp + x + 1) * 8 + h * 4);
 }
 
+// one-map C8I -> pixel-major [y][x][Cb * 8] (dense.h roi_pool_pm's operand: a pixel's channels contiguous)
+__global__ void c8i_to_pixel_major_kernel(const float *__restrict__ in, int Cb, size_t HW, size_t pitch, float *__restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= HW * Cb * 2) return;
+  const int q = (int)(t % (Cb * 2)); const size_t px = t / (Cb * 2);   // q = cb * 2 + half: consecutive lanes write consecutive 16 bytes
+  *reinterpret_cast<f32x4 *>(out + px * (size_t)Cb * 8 + q * 4) = *reinterpret_cast<const f32x4 *>(in + ((size_t)(q >> 1) * pitch + px) * 8 + (q & 1) * 4);
+}
+
 // A batch of small per-ROI maps (ResNet's layer4: 1000 x 7 x 7) as ONE padded C8P image for the Winograd kernel: a mosaic of
 // (H + 1) x (W + 1) cells, mx maps per mosaic row, map b at cell (b / mx, b % mx) with its pixels in the cell's top-left H x W and
 // the cell's last row / column left ZERO — together with the C8P halo every map is surrounded by zeros, i.e. pad 1.  The
@@ -1641,7 +1649,7 @@ static int rn_alloc(ResNetGraph *g, float **p, size_t bytes) {
   return MPN_OK;
 }
 
-MPN_KNOB(int, g_graph_fuse, 255);  // mpn_debug_set_graph_fuse: bit 0 = fuse sibling pointwise convolutions, bit 1 = commute average-pool -> pointwise convolution, bit 2 = max-pools of the ROI-pooled input computed from the feature map, bit 3 = fully-connected head layers (whole-map / 1x1-map convolutions) on the tuned GEMM, bit 4 = the image layer (Cin = 3) as a GEMM over im2col rows, bit 5 = trunk 3x3 / stride-1 convolutions on dense.hip's Winograd kernel, bit 6 = the fused ROI max-pool (bit 2) reads vertical range-max tables of the map, bit 7 = ResNet heads' 3x3 / stride-1 convolutions on the Winograd kernel (mosaic image of the per-ROI maps); 0 = run the op list as given
+MPN_KNOB(int, g_graph_fuse, 511);  // mpn_debug_set_graph_fuse: bit 0 = fuse sibling pointwise convolutions, bit 1 = commute average-pool -> pointwise convolution, bit 2 = max-pools of the ROI-pooled input computed from the feature map, bit 3 = fully-connected head layers (whole-map / 1x1-map convolutions) on the tuned GEMM, bit 4 = the image layer (Cin = 3) as a GEMM over im2col rows, bit 5 = trunk 3x3 / stride-1 convolutions on dense.hip's Winograd kernel, bit 6 = the fused ROI max-pool (bit 2) reads vertical range-max tables of the map, bit 7 = ResNet heads' 3x3 / stride-1 convolutions on the Winograd kernel (mosaic image of the per-ROI maps), bit 8 = the fully-connected operand pooled by dense.hip's pixel-major kernel; 0 = run the op list as given
 static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b) {
   if (g->bf16) {
     const int nch2 = round_up((c.Cin + 7) / 8, 2), CoutP = round_up(c.Cout, 128), KK = c.KH * c.KW;
@@ -2527,7 +2535,18 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
     } else if (g->bf16)
       hipLaunchKernelGGL(roi_pool_c8i_bf16_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, reinterpret_cast<const bf16_t *>(g->feat), Cb, g->feat_h,
                          g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale, reinterpret_cast<bf16_t *>(pool_dst), pa.pitch());
-    else if ((g_bf16_fast_pool & 1) && Cb % 4 == 0)
+    else if (fc_gemm && (g_graph_fuse & 256)) {
+      // the fully-connected operand is the VGG pipeline's (bin, roi)-row matrix: its pooling kernel too (a wave = one (roi, bin) over 256
+      // channels of a pixel-major copy of the map, four ROIs per block leaving as whole 128-byte lines) — 37 -> 12 us on AlexNet
+      void *pm = nullptr;
+      { int rc_ws = scratch_get(SCR_MISC, (size_t)g->feat_h * g->feat_w * Cb * 8 * sizeof(float), s, &pm); if (rc_ws) return rc_ws; }
+      hipLaunchKernelGGL(c8i_to_pixel_major_kernel, dim3((unsigned)cdiv_sz((size_t)g->feat_h * g->feat_w * Cb * 2, 256)), dim3(256), 0, s, g->feat, Cb,
+                         (size_t)g->feat_h * g->feat_w, fa.pitch(), static_cast<float *>(pm));
+      MPN_CHECK_LAUNCH();
+      const Act fdim{nullptr, g->feat_c, g->feat_h, g->feat_w, 0, 0};
+      int rcp = roi_pool_pm(fdim, static_cast<const float *>(pm), d_rois, N, PH, PH, spatial_scale, 1.0f, 0, g->fc_x, s, roi_stride, round_up(N, 128));
+      if (rcp) return rcp;
+    } else if ((g_bf16_fast_pool & 1) && Cb % 4 == 0)
       hipLaunchKernelGGL(roi_pool_c8i_rows_kernel<4>, dim3((unsigned)cdiv_sz((size_t)N * PH * PH, 256), (unsigned)(Cb / 4)), dim3(256), 0, s, g->feat, g->feat_h,
                          g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale, fc_gemm ? g->fc_x : pool_dst, pa.pitch(), fc_gemm ? round_up(N, 128) : 0);
     else

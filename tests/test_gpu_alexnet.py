@@ -52,7 +52,7 @@ def test_alexnet_fc_layers_on_the_gemm_equal_the_convolution_form(dev):
     G = models.synthetic_alexnet_params(n_classes=6, width=0.25, fc_dim=128, seed=3)
     im, boxes = _inputs(H, W, N, 4)
     out = []
-    for fuse in (7, 15, 31, 63):
+    for fuse in (7, 15, 31, 63, 63 + 256):
         with hooks(graph_fuse=fuse):
             net = models.AlexNetFRCNN(G, max_h=H, max_w=W, max_rois=64, top_k=20)
             s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
@@ -61,6 +61,8 @@ def test_alexnet_fc_layers_on_the_gemm_equal_the_convolution_form(dev):
     for a, b, tol in ((0, 1, 1e-6), (1, 2, 1e-6), (2, 3, 1e-5)):
         assert not np.array_equal(out[a][0], out[b][0])        # really two code paths
         assert np.abs(out[a][0] - out[b][0]).max() < tol and np.abs(out[a][1] - out[b][1]).max() < 1e3 * tol
+    # bit 8: the (bin, roi)-row operand pooled by the VGG pipeline's pixel-major kernel instead of the row-per-thread one: the same max
+    assert np.array_equal(out[4][0], out[3][0]) and np.array_equal(out[4][1], out[3][1])
 
 
 def test_alexnet_smaller_image_after_a_larger_one(dev):
