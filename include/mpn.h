@@ -468,7 +468,10 @@ enum {
 int mpn_frcnn_set_profiling(mpn_frcnn *p, int enable);
 int mpn_frcnn_get_profile(mpn_frcnn *p, double *ms, long *counts, int n_tags, int reset);
 
-/* Intermediate activations for parity tests: name in {"conv5","pooled","fc7","cls","bbox_raw"}. */
+/* Intermediate activations for parity tests: name in {"conv5","pooled","fc7","cls","bbox_raw"}; tower models (MultiPathNet, the
+ * ResNet / op-list tower forms) keep "bbox_raw", "cls_k" (the K integral classifiers' pre-softmax logits, [N, K * C] row-major) and
+ * "cat" (the towers' outputs side by side, [N, towers * fc_dim]); plain ResNet / op-list models keep "cls", "fc7" (the head's
+ * average-pooled features) and "bbox_raw". */
 int mpn_frcnn_debug_tensor(mpn_frcnn *p, const char *name, const float **d_ptr, size_t *n_elems);
 
 #ifdef __cplusplus

@@ -64,8 +64,10 @@ int image_transform_c8p(const float *d_in, int H, int W, const int *swap, double
 // out = relu?(conv3x3(in) + b); optional fused ceil-mode 2x2 max-pool writes `pooled` as well
 // (out.p may be null when only the pooled map is needed).
 // d_wino (optional): Winograd-transformed weights; used when the variant selector picks the Winograd kernel.
+// batch_invariant (Winograd only): the launch plan must not depend on the map's height — no split-K, no tail split, the 8 x 32-px block
+// geometry — so that a cell of a mosaic of per-ROI maps (resnet.hip) gets the same bits whatever the number of maps in the mosaic.
 int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int relu, Act out, Act pooled, hipStream_t s,
-                const float *d_wino = nullptr);
+                const float *d_wino = nullptr, bool batch_invariant = false);
 // first layer (<= 4 input channels): K = 9 taps x 4 channels formulation, weights [36][CoutP] (pack_conv_weights_first);
 // bias from the direct packing's d_bpk; no fused pool / split-K (the layer is bound by its output stores)
 size_t conv_first_elems(int Cout);
@@ -83,12 +85,15 @@ int maxpool2x2_c8p(Act in, Act out, hipStream_t s);
 // into a running total at each boundary).  A row's result is then bit-identical for ANY number of rows in the call, which is what
 // lets the ROI-sharded mode (mpn_frcnn_shard_*) equal the unsharded one exactly and makes memoryEfficientForward's chunk
 // invariance (ImageDetect.lua:126-133) hold at every size.  Used by the ROI heads (fc6 / fc7 / cls + bbox / integral heads).
+// row_invariant = 2: the degenerate canonical order — ONE segment, the launch never splits K whatever the row count (short-K layers
+// whose callers always bring dozens of row tiles: MultiPathNet's 1x1 mix over (bin, roi) rows, per-ROI pointwise convolutions over
+// (roi, pixel) rows); combines with a residual.
 int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float *d_bpk, int N, int relu, float *d_y_c8,
               float *d_y_rm, hipStream_t s, int Mp_override = 0, const float *d_res_c8 = nullptr, int row_invariant = 0);
 bool linear_c8_is_direct(int M, int N, int Mp_override = 0);  // would linear_c8 run un-split for this shape?
 // y = sum over up to three K segments of scale_seg[row % rs_mod] * (x_seg . w_seg) (+ b, ReLU): MultiPathNet's mix GEMM with nn.Normalize
 // of its three pooled maps applied where the accumulator is folded, instead of a read-modify-write pass over the pooled matrix.
-// Un-split launches only (linear_c8_is_direct); k_end = the K index (multiple of 32) at which segment i ends.
+// Always launched un-split (like row_invariant = 2, so a row's result does not depend on the row count); k_end = the K index (multiple of 32) at which segment i ends.
 struct GemmRowScale { int n_seg; int k_end[2]; const float *scale[3]; int rs_mod; };
 int linear_c8_rowscaled(const float *d_x_c8, int M, int K, const float *d_wpk, const float *d_bpk, int N, int relu, float *d_y_c8, hipStream_t s,
                         int Mp_override, const GemmRowScale &rs);

@@ -971,7 +971,8 @@ int conv3x3_variant_for(int Cout, bool has_wino) {
   return variant;
 }
 
-int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int relu, Act out, Act pooled, hipStream_t s, const float *d_wino) {
+int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int relu, Act out, Act pooled, hipStream_t s, const float *d_wino,
+                bool batch_invariant) {
   MPN_CHECK_ARG(in.p && (d_wpk || d_wino) && d_bpk && (out.p || pooled.p));
   ConvArgs a{};
   a.in = in.p; a.in_plane = in.plane(); a.in_Wp = in.Wp;
@@ -991,14 +992,14 @@ int conv3x3_c8p(Act in, const float *d_wpk, const float *d_bpk, int Cout, int re
     a.wpk = d_wino;
     // block geometry: 16 x 16 px or 8 x 32 px of outputs, whichever pads this map less
     const long px_sq = (long)cdiv(in.H, 16) * 16 * cdiv(in.W, 16) * 16, px_wide = (long)cdiv(in.H, 8) * 8 * cdiv(in.W, 32) * 32;
-    a.wino_tc = (g_wino_tc == 8 || g_wino_tc == 16) ? g_wino_tc : (px_wide < px_sq ? 16 : 8);
+    a.wino_tc = batch_invariant ? 16 : (g_wino_tc == 8 || g_wino_tc == 16) ? g_wino_tc : (px_wide < px_sq ? 16 : 8);
     const int tpx_h = a.wino_tc == 16 ? 8 : 16, tpx_w = a.wino_tc == 16 ? 32 : 16;
     a.tiles_x = cdiv(in.W, tpx_w);
     const int tiles_y = cdiv(in.H, tpx_h);
     a.n_ct = cdiv(Cout, 64);
     const int blocks = a.n_ct * tiles_y * a.tiles_x;
     Act geo = out.p ? out : make_act(nullptr, Cout, in.H, in.W);
-    const WinoPlan plan = wino_pick_plan(blocks, a.n_ct, a.nchunks, geo.elems() * sizeof(float));
+    const WinoPlan plan = batch_invariant ? WinoPlan{1, 0, 0, 0} : wino_pick_plan(blocks, a.n_ct, a.nchunks, geo.elems() * sizeof(float));
     a.splits = plan.splits;
     a.chunks_per_split = cdiv(a.nchunks, a.splits);
     a.splits = cdiv(a.nchunks, a.chunks_per_split);
@@ -1337,7 +1338,6 @@ int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float
 int linear_c8_rowscaled(const float *d_x_c8, int M, int K, const float *d_wpk, const float *d_bpk, int N, int relu, float *d_y_c8, hipStream_t s,
                         int Mp_override, const GemmRowScale &rs) {
   MPN_CHECK_ARG(rs.n_seg >= 1 && rs.n_seg <= 3 && rs.rs_mod > 0 && rs.scale[0] != nullptr);
-  if (!linear_c8_is_direct(M, N, Mp_override)) { set_error("linear_c8_rowscaled: needs the un-split form (>= 128 output tiles)"); return MPN_EINVAL; }
   for (int i = 0; i + 1 < rs.n_seg; ++i) MPN_CHECK_ARG(rs.k_end[i] > (i ? rs.k_end[i - 1] : 0) && rs.k_end[i] % 32 == 0 && rs.k_end[i] < K);
   return linear_c8_impl(d_x_c8, M, K, d_wpk, d_bpk, N, relu, d_y_c8, nullptr, s, Mp_override, nullptr, 0, &rs);
 }
@@ -1358,7 +1358,9 @@ static int linear_c8_impl(const float *d_x_c8, int M, int K, const float *d_wpk,
   a.nstages = K64 / (8 * kch);
   int S = 1, inv_seg = 0;
   a.seg_stages = 0;
-  if (g_gemm_split > 0) S = g_gemm_split;
+  if (rs || row_invariant == 2) S = 1;  // ONE accumulation chain whatever the row count (trivially row-invariant): short-K layers that a
+                                        // shard of any size runs with plenty of row tiles — MultiPathNet's mix, the per-ROI pointwise convolutions
+  else if (g_gemm_split > 0) S = g_gemm_split;
   else if (row_invariant) {
     // canonical segments from (K, N) alone, >= 4 stages (128 k) each: wide layers (fc6 / fc7, >= 16 column tiles) as many as fill
     // 256 CUs when there is a SINGLE row tile — they only ever run split when a ROI shard is small, which is when it matters —,

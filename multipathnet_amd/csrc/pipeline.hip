@@ -647,9 +647,11 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
     p->vmax_valid = true;
     p->vmax_pm = pm;
   }
-  // nn.Normalize's per-(ROI, map) scale folded into the mix GEMM (linear_c8_rowscaled) when that GEMM runs un-split — always at
-  // BASELINE sizes; tiny test networks whose mix has < 128 output tiles keep the in-place l2norm_apply pass
-  const bool fold_scale = pm && p->conv345_norm && p->mix_scale && linear_c8_is_direct(PP * Mp, p->feat_c, PP * Mp) && g_mix_fold &&
+  // nn.Normalize's per-(ROI, map) scale folded into the mix GEMM (linear_c8_rowscaled).  Fold or in-place l2norm_apply is decided by
+  // the network alone (channel counts), never by the ROI count, and the mix GEMM — K = the channel concat, >= 49 row tiles for any N —
+  // always runs as ONE un-split accumulation chain, so a ROI's mix output does not depend on the rows it is batched with (ADVICE r3:
+  // a 128-row shard of a feat_c <= 256 trunk used to take l2norm_apply + split-K where the full table took the fold)
+  const bool fold_scale = pm && p->conv345_norm && p->mix_scale && g_mix_fold &&
                           maps[0].C % 32 == 0 && maps[1].C % 32 == 0 && maps[2].C % 32 == 0;  // segment boundaries fall on 32-k stages
   // Two streams: a tower's skip pooling is L2 -> L1 bound (no matrix work), its GEMMs are matrix-bound, and the folding GEMM leaves
   // half of every CU's registers and 94 KB of LDS free.  Tower t's pooling therefore runs on the handle's pooling stream, into the
@@ -715,7 +717,7 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
     // 1x1 conv mix: rows = (bin, roi), K = concat channels, N = feat_c; output layout == fc6 operand layout
     { ProfScope ps(p, MPN_PROF_HEADS, s);
       rc = fold_scale ? linear_c8_rowscaled(txb, PP * Mp, T.total_feat, T.mix_w, T.mix_b, p->feat_c, 0, p->ty, s, PP * Mp, grs)
-                      : linear_c8(txb, PP * Mp, T.total_feat, T.mix_w, T.mix_b, p->feat_c, 0, p->ty, nullptr, s, PP * Mp); }
+                      : linear_c8(txb, PP * Mp, T.total_feat, T.mix_w, T.mix_b, p->feat_c, 0, p->ty, nullptr, s, PP * Mp, nullptr, 2); }
     if (rc) return rc;
     if (overlap) MPN_CHECK_HIP(hipEventRecord(p->ev_mix_done[par], s));
     { ProfScope ps(p, MPN_PROF_FC6, s); rc = linear_c8(p->ty, N, p->K6, T.w6, T.b6, F, 1, p->tz6, nullptr, s, Mp, nullptr, 1); }
@@ -1247,9 +1249,13 @@ extern "C" int mpn_frcnn_debug_tensor(mpn_frcnn *p, const char *name, const floa
   else if (nm == "fc7") n = (size_t)N * F;
   else if (nm == "cls") n = (size_t)N * C;
   else if (nm == "bbox_raw") n = (size_t)N * 4 * C;
+  else if (nm == "cls_k") n = (size_t)N * p->n_integral * C;                       // integral heads: the K classifiers' logits [N, K * C] (pre-softmax)
+  else if (nm == "cat") n = (size_t)N * (p->is_mpnet ? p->towers.size() : p->rn_region.size()) * F;  // tower outputs side by side [N, towers * F]
   else { set_error("mpn_frcnn_debug_tensor: unknown tensor '%s'", name); return MPN_EINVAL; }
-  if (p->is_mpnet && nm != "conv5" && nm != "bbox_raw") { set_error("mpn_frcnn_debug_tensor: '%s' is not kept by the MultiPathNet head", name); return MPN_EINVAL; }
-  if (p->rn && nm != "bbox_raw" && !(nm == "cls" && p->rn_region.empty())) { set_error("mpn_frcnn_debug_tensor: '%s' is not kept by the op-list / ResNet pipelines", name); return MPN_EINVAL; }
+  const bool towers = p->is_mpnet || (p->rn && !p->rn_region.empty());
+  if ((nm == "cls_k" || nm == "cat") && (!towers || lin_np(F) != F)) { set_error("mpn_frcnn_debug_tensor: '%s' needs a tower model (integral heads)", name); return MPN_EINVAL; }
+  if (p->is_mpnet && nm != "conv5" && nm != "bbox_raw" && nm != "cls_k" && nm != "cat") { set_error("mpn_frcnn_debug_tensor: '%s' is not kept by the MultiPathNet head", name); return MPN_EINVAL; }
+  if (p->rn && nm != "bbox_raw" && nm != "cls_k" && nm != "cat" && !((nm == "cls" || nm == "fc7") && p->rn_region.empty())) { set_error("mpn_frcnn_debug_tensor: '%s' is not kept by the op-list / ResNet pipelines", name); return MPN_EINVAL; }
   MPN_CHECK_HIP(hipDeviceSynchronize());
   if (n * sizeof(float) > p->dbg_bytes) {
     if (p->dbg) (void)hipFree(p->dbg);
@@ -1266,6 +1272,10 @@ extern "C" int mpn_frcnn_debug_tensor(mpn_frcnn *p, const char *name, const floa
     MPN_CHECK_LAUNCH();
   } else if (nm == "fc7") {
     rc = c8_to_rowmajor(p->y7, N, F, p->dbg, nullptr);  // rows at stride lin_mp(N), as linear_c8 wrote them
+  } else if (nm == "cls_k") {
+    MPN_CHECK_HIP(hipMemcpy(p->dbg, p->cls_rm, n * sizeof(float), hipMemcpyDeviceToDevice));
+  } else if (nm == "cat") {
+    rc = c8_to_rowmajor(p->cat, N, (int)(n / N), p->dbg, nullptr);  // towers' [F/8][Mp][8] blocks back to back == one C8 matrix of towers * F columns
   } else if (nm == "cls") {
     hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)cdiv_sz(n, 256)), dim3(256), 0, nullptr, p->head, 5 * C, 0, N, C, p->dbg);
     MPN_CHECK_LAUNCH();

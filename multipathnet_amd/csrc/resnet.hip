@@ -1717,7 +1717,15 @@ MPN_KNOB(int, g_split_max_tiles, 192);     // split-K only layers with fewer 128
 MPN_KNOB(int, g_bf16_split_target, 256);  // split-K (both dtypes) aims at this many blocks (0 = never split; mpn_debug_set_bf16_split_target)
 MPN_KNOB(int, g_bf16_dma_tn, 0);  // 0 = pick per layer; 128 / 256 = force 256 couts x that many pixels, 1256 = 128 couts x 256 pixels (mpn_debug_set_bf16_dma_tn)
 MPN_KNOB(int, g_bf16_dma, 1);  // mpn_debug_set_bf16_dma: 0 = never, 1 = large layers, 2 = every eligible layer (tests)
-static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int relu, hipStream_t s, ActI *o, bool allow_gemm = true) {
+MPN_KNOB(int, g_roi_invariant, 1);  // mpn_debug_set_roi_invariant: 0 = per-ROI layers pick kernel / split by batch size as round 3 did (tests, timing)
+// per_roi: the batch axis counts ROIs (the head of a graph model).  A ROI's result must not depend on which other ROIs share the
+// launch (memoryEfficientForward's chunked == full, ImageDetect.lua:126-133; the ROI-sharded mode == the unsharded one), so for
+// these layers everything that changes the summation ORDER is a function of the layer alone, never of in.B: no split-K (every
+// kernel family below accumulates K = (tap, channel chunk) in ONE chain per output, and the bf16 tile shapes / the small and the
+// LDS-DMA kernel share that chain bit for bit), pointwise convolutions always on the un-split GEMM, eligible 3x3 convolutions
+// always on the Winograd mosaic with a batch-independent launch plan.  Tile shapes may still follow the batch size.
+static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int relu, hipStream_t s, ActI *o, bool allow_gemm = true, bool per_roi = false) {
+  const bool inv = per_roi && g_roi_invariant;
   if (c.wpk16) {  // bf16 graph
     GConvArgsB b{};
     b.in = reinterpret_cast<const bf16_t *>(in.p); b.wpk = c.wpk16; b.res = reinterpret_cast<const bf16_t *>(res); b.bpk = c.bpk;
@@ -1776,7 +1784,7 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
       const size_t slab = (size_t)b.CoutP * o->pitch() * sizeof(float);
       int want = (int)std::min<long long>(nstages / 2, (g_bf16_split_target + nblocks - 1) / nblocks);
       if (c.ws && slab) want = (int)std::min<size_t>((size_t)want, c.ws_bytes / slab); else want = 1;
-      if (g_bf16_split_target > 0 && nblocks < g_split_max_tiles && want >= 2) {
+      if (g_bf16_split_target > 0 && !inv && nblocks < g_split_max_tiles && want >= 2) {
         b.stages_per_split = (nstages + want - 1) / want;
         const int splits = (nstages + b.stages_per_split - 1) / b.stages_per_split;
         b.part = c.ws;
@@ -1809,7 +1817,7 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
   a.P = (long long)in.B * a.OH * a.OW;
   *o = ActI{out, in.B, c.Cout, a.OH, a.OW};
   a.pitch_in = in.pitch(); a.pitch_out = o->pitch();
-  if (c.wino && c.mos_in && !res && in.B > 1 && in.H == c.mos_h && in.W == c.mos_w && c.norelu_c1 == c.norelu_c0 && (g_graph_fuse & 128) &&
+  if (c.wino && c.mos_in && !res && (inv || in.B > 1) && in.H == c.mos_h && in.W == c.mos_w && c.norelu_c1 == c.norelu_c0 && (g_graph_fuse & 128) &&
       ((in.B + c.mos_mx - 1) / c.mos_mx) * (in.H + 1) <= c.mos_rows) {
     // per-ROI 3x3 / stride-1 convolution (layer4's conv2 of blocks 2, 3): the batch as a mosaic image on the Winograd kernel
     const int rows = ((in.B + c.mos_mx - 1) / c.mos_mx) * (in.H + 1);
@@ -1819,7 +1827,7 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
                        c.mos_in);
     MPN_CHECK_LAUNCH();
     const Act ain{c.mos_in, c.Cin, rows, c.mos_cols, Hp, Wp}, aout{c.mos_out, c.Cout, rows, c.mos_cols, Hp, Wp};
-    int rcw = conv3x3_c8p(ain, nullptr, c.bpk, c.Cout, relu, aout, Act{nullptr, 0, 0, 0, 0, 0}, s, c.wino);
+    int rcw = conv3x3_c8p(ain, nullptr, c.bpk, c.Cout, relu, aout, Act{nullptr, 0, 0, 0, 0, 0}, s, c.wino, inv);
     if (rcw) return rcw;
     hipLaunchKernelGGL(mosaic_to_c8i_kernel, dim3((unsigned)cdiv_sz(recs * o->Cb() * 2, 256)), dim3(256), 0, s, c.mos_out, o->Cb(), in.B, in.H, in.W, c.mos_mx, Hp, Wp,
                        o->pitch(), out);
@@ -1836,12 +1844,13 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
     MPN_CHECK_LAUNCH();
     return linear_c8(static_cast<const float *>(col), (int)a.P, Kc, c.col_w, c.col_b, c.Cout, relu, out, nullptr, s, (int)o->pitch());
   }
-  if (allow_gemm && c.lin_w && c.norelu_c1 == c.norelu_c0 && linear_c8_is_direct((int)in.rows(), c.Cout, (int)in.pitch()))  // same rows in and out: the tuned GEMM, residual + ReLU fused
-    return linear_c8(in.p, (int)in.rows(), c.Cin, c.lin_w, c.lin_b, c.Cout, relu, out, nullptr, s, (int)in.pitch(), res);
   // a pointwise convolution on 1x1 maps is a fully-connected layer (AlexNet's fc7): few row tiles, so the GEMM's split-K form
-  // with its row-invariant segments rather than a 128-pixel-tile convolution
-  if (allow_gemm && c.lin_w && c.norelu_c1 == c.norelu_c0 && !res && in.H == 1 && in.W == 1 && (g_graph_fuse & 8))
+  // with its row-invariant segments rather than a 128-pixel-tile convolution (the un-split form folds at the same segments)
+  if (allow_gemm && c.lin_w && c.norelu_c1 == c.norelu_c0 && !res && in.H == 1 && in.W == 1 && (g_graph_fuse & 8) &&
+      (inv || !linear_c8_is_direct((int)in.rows(), c.Cout, (int)in.pitch())))
     return linear_c8(in.p, (int)in.rows(), c.Cin, c.lin_w, c.lin_b, c.Cout, relu, out, nullptr, s, (int)in.pitch(), nullptr, 1);
+  if (allow_gemm && c.lin_w && c.norelu_c1 == c.norelu_c0 && (inv || linear_c8_is_direct((int)in.rows(), c.Cout, (int)in.pitch())))  // same rows in and out: the tuned GEMM, residual + ReLU fused
+    return linear_c8(in.p, (int)in.rows(), c.Cin, c.lin_w, c.lin_b, c.Cout, relu, out, nullptr, s, (int)in.pitch(), res, inv ? 2 : 0);
   dim3 grid((unsigned)(((a.P + 127) / 128 + 7) / 8 * 8 * (a.CoutP / 128)));  // pixel tiles rounded up to the 8 XCDs x cout tiles (see the kernel)
   // 32-channel stages: the LDS-DMA / hand-pipelined kernel (32-bit gather offsets: the input batch must stay under 4 GiB)
   constexpr size_t PF_LDS = (size_t)2 * 2 * 4 * 128 * 8 * sizeof(float);
@@ -1854,7 +1863,7 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
     const size_t slab = (size_t)a.CoutP * o->pitch() * sizeof(float);
     int want = (int)std::min<long long>(nstages / 2, (g_bf16_split_target + n_tiles - 1) / n_tiles);
     if (c.ws && slab) want = (int)std::min<size_t>((size_t)want, c.ws_bytes / slab); else want = 1;
-    if (g_bf16_split_target > 0 && n_tiles < g_split_max_tiles && want >= 2) {
+    if (g_bf16_split_target > 0 && !inv && n_tiles < g_split_max_tiles && want >= 2) {
       a.stages_per_split = (nstages + want - 1) / want;
       const int splits = (nstages + a.stages_per_split - 1) / a.stages_per_split;
       a.part = c.ws;
@@ -1882,7 +1891,7 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
 }
 
 // one residual block: y = relu(conv_n(... relu(conv_1(x))) + shortcut(x)); buffers b[0..3] rotate, x may live in any of them
-static int rn_block(const RnBlock &blk, ActI x, float *const bufs[4], hipStream_t s, ActI *out) {
+static int rn_block(const RnBlock &blk, ActI x, float *const bufs[4], hipStream_t s, ActI *out, bool per_roi = false) {
   // pick three scratch buffers different from x.p
   float *free_b[3];
   int nf = 0;
@@ -1892,7 +1901,7 @@ static int rn_block(const RnBlock &blk, ActI x, float *const bufs[4], hipStream_
   ActI sc = x;
   int rc;
   if (blk.has_sc) {
-    rc = rn_conv(blk.sc, x, free_b[2], nullptr, 0, s, &sc);
+    rc = rn_conv(blk.sc, x, free_b[2], nullptr, 0, s, &sc, true, per_roi);
     if (rc) return rc;
   }
   ActI y = x;
@@ -1902,7 +1911,7 @@ static int rn_block(const RnBlock &blk, ActI x, float *const bufs[4], hipStream_
     float *dst = free_b[i & 1];
     if (dst == y.p) dst = free_b[(i & 1) ^ 1];
     ActI o;
-    rc = rn_conv(blk.convs[i], y, dst, last ? sc.p : nullptr, 1, s, &o);
+    rc = rn_conv(blk.convs[i], y, dst, last ? sc.p : nullptr, 1, s, &o, true, per_roi);
     if (rc) return rc;
     if (last) MPN_CHECK_ARG(o.C == sc.C && o.H == sc.H && o.W == sc.W);
     y = o;
@@ -2387,7 +2396,7 @@ static int graph_run(ResNetGraph *g, const std::vector<GOp> &ops, std::vector<GT
       ActI o;
       // the GEMM writes whole 128-channel panels: only when this op owns them (no neighbouring branch inside the panel)
       const bool own = op.conv.Cout % 128 == 0 || (op.dst_c_off == 0 && op.conv.Cout == dst.C);
-      int rc = rn_conv(op.conv, in, reinterpret_cast<float *>(outp), nullptr, op.relu, s, &o, own);
+      int rc = rn_conv(op.conv, in, reinterpret_cast<float *>(outp), nullptr, op.relu, s, &o, own, !trunk);
       if (rc) return rc;
     } else {
       const size_t total = (size_t)in.Cb() * B * dst.H * dst.W * 2;
@@ -2562,7 +2571,7 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
     cur = ActI{o.buf, N, o.C, o.H, o.W};
   } else
   for (auto &blk : g->heads[head]) {
-    int rc = rn_block(blk, cur, g->hb, s, &y);
+    int rc = rn_block(blk, cur, g->hb, s, &y, true);
     if (rc) return rc;
     cur = y;
   }
@@ -2584,6 +2593,7 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
 
 #ifdef MPN_DEBUG_HOOKS
 extern "C" void mpn_debug_set_bf16_dma(int v) { mpn::g_bf16_dma = v; }
+extern "C" void mpn_debug_set_roi_invariant(int v) { mpn::g_roi_invariant = v; }
 extern "C" void mpn_debug_set_bf16_dma_tn(int v) { mpn::g_bf16_dma_tn = v; }
 extern "C" void mpn_debug_set_bf16_split_target(int v) { mpn::g_bf16_split_target = v; }
 extern "C" void mpn_debug_set_bf16_fast_pool(int v) { mpn::g_bf16_fast_pool = v; }

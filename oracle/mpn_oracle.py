@@ -469,8 +469,9 @@ def conv345_combine(maps, region_rois, T, pooled=7, spatial_scale=1.0 / 16, is_n
     return np.ascontiguousarray(y.reshape(n, pooled * pooled, -1).transpose(0, 2, 1)).reshape(n, -1)  # flatten as [c5,7,7]
 
 
-def mpnet_head(maps, rois, P, pooled=7, spatial_scale=1.0 / 16):
-    """maps = [conv5, conv4, conv3] ([C,h,w] each); rois [N,5].  Returns (scores [N,C] = mean of K softmaxes, bbox deltas [N,4C])."""
+def mpnet_head(maps, rois, P, pooled=7, spatial_scale=1.0 / 16, return_raw=False):
+    """maps = [conv5, conv4, conv3] ([C,h,w] each); rois [N,5].  Returns (scores [N,C] = mean of K softmaxes, bbox deltas [N,4C])
+    (+ with return_raw the K classifiers' pre-softmax logits [N,K,C] and the towers' fc7 outputs side by side [N, towers * F])."""
     fov = foveal(rois).reshape(-1, 4, 5)
     outs = []
     for T in P["towers"]:
@@ -485,6 +486,8 @@ def mpnet_head(maps, rois, P, pooled=7, spatial_scale=1.0 / 16):
     deltas = linear(outs[-1], P["bbox_w"], P["bbox_b"])
     if P.get("bbox_mean") is not None:
         deltas = bbox_norm(deltas, P["bbox_mean"], P["bbox_std"])
+    if return_raw:
+        return scores, deltas, logits, np.concatenate(outs, 1)
     return scores, deltas
 
 
@@ -603,31 +606,37 @@ def resnet_head(feat, rois, R, pooled=14, spatial_scale=1.0 / 16, chunk=None):
     return np.concatenate(cls), np.concatenate(bbox)
 
 
-def resnet_detect(im, boxes, R, transformer=IMAGENET, target=600, max_size=1000, pooled=14, chunk=None):
-    """ImageDetect.lua:156-193 on the ResNet model (ImagenetTransformer, resnet.lua:52)"""
+def resnet_features(im, R, transformer=IMAGENET, target=600, max_size=1000):
+    """the trunk's output for an image (what ImageDetect.lua:107-111 caches): pass it back as `feat=` to the *_detect functions"""
     H, W = im.shape[1:]
     s = pick_scale(H, W, target, max_size)
     x = image_transform(im, **transformer)
     if s != 1.0:
         x = image_scale(x, int(H * s), int(W * s))
+    return resnet_trunk(x, R)
+
+
+def resnet_detect(im, boxes, R, transformer=IMAGENET, target=600, max_size=1000, pooled=14, chunk=None, feat=None):
+    """ImageDetect.lua:156-193 on the ResNet model (ImagenetTransformer, resnet.lua:52)"""
+    H, W = im.shape[1:]
+    s = pick_scale(H, W, target, max_size)
     rois = project_im_rois(boxes, s)
-    feat = resnet_trunk(x, R)
+    if feat is None:
+        feat = resnet_features(im, R, transformer, target, max_size)
     logits, deltas = resnet_head(feat, rois, R, pooled=pooled, chunk=chunk)
     dec = bbox_decode(boxes, deltas)
     return softmax(logits), dec, logits, deltas
 
 
-def resnet_mpn_detect(im, boxes, R, transformer=IMAGENET, target=600, max_size=1000, pooled=14):
+def resnet_mpn_detect(im, boxes, R, transformer=IMAGENET, target=600, max_size=1000, pooled=14, return_raw=False, feat=None):
     """MultiPathNet on a ResNet backbone (this library's extension of multipathnet.lua:64-120 to resnet.lua's graph):
     Foveal regions -> per-tower ROIPooling + layer4 copy + average pool -> concat of the classification towers ->
     K classifier clones, mean of softmaxes; the last tower feeds the box regressor.  Returns (scores, decoded boxes)."""
     H, W = im.shape[1:]
     s = pick_scale(H, W, target, max_size)
-    x = image_transform(im, **transformer)
-    if s != 1.0:
-        x = image_scale(x, int(H * s), int(W * s))
     rois = project_im_rois(boxes, s)
-    feat = resnet_trunk(x, R)
+    if feat is None:
+        feat = resnet_features(im, R, transformer, target, max_size)
     fov = foveal(rois).reshape(-1, 4, 5)
     outs = []
     for tw, rg in zip(R["head_towers"], R["head_regions"]):
@@ -643,6 +652,8 @@ def resnet_mpn_detect(im, boxes, R, transformer=IMAGENET, target=600, max_size=1
     deltas = linear(outs[-1], R["bbox_w"], R["bbox_b"])
     if R.get("bbox_mean") is not None:
         deltas = bbox_norm(deltas, R["bbox_mean"], R["bbox_std"])
+    if return_raw:  # + the K classifiers' pre-softmax logits [N, K, C], the pre-decode deltas, the towers' features [N, towers * F]
+        return scores, bbox_decode(boxes, deltas), logits, deltas, np.concatenate(outs, 1)
     return scores, bbox_decode(boxes, deltas)
 
 
@@ -696,8 +707,8 @@ def graph_run(x0, ops, tensor_c, bf16=False):
     return ts
 
 
-def graph_detect(im, boxes, G, transformer, target=600, max_size=1000, pooled=17, spatial_scale=17.0 / 299.0):
-    """ImageDetect.lua:156-193 on an op-list model (Inception-v3 Fast R-CNN)"""
+def graph_features(im, G, transformer, target=600, max_size=1000):
+    """the op-list trunk's output for an image (pass it back as `feat=` to graph_detect / graph_mpn_detect)"""
     bf = bool(G.get("bf16"))
     H, W = im.shape[1:]
     s = pick_scale(H, W, target, max_size)
@@ -706,8 +717,17 @@ def graph_detect(im, boxes, G, transformer, target=600, max_size=1000, pooled=17
         x = image_scale(x, int(H * s), int(W * s))
     if bf:
         x = bf16_round(x)
+    return graph_run(x[None], G["trunk_ops"], G["trunk_tensor_c"], bf)[G["feat_tensor"]][0]
+
+
+def graph_detect(im, boxes, G, transformer, target=600, max_size=1000, pooled=17, spatial_scale=17.0 / 299.0, feat=None):
+    """ImageDetect.lua:156-193 on an op-list model (Inception-v3 Fast R-CNN)"""
+    bf = bool(G.get("bf16"))
+    H, W = im.shape[1:]
+    s = pick_scale(H, W, target, max_size)
     rois = project_im_rois(boxes, s)
-    feat = graph_run(x[None], G["trunk_ops"], G["trunk_tensor_c"], bf)[G["feat_tensor"]][0]
+    if feat is None:
+        feat = graph_features(im, G, transformer, target, max_size)
     pooledf, _ = roi_pool(feat, rois, pooled, pooled, spatial_scale)
     y = graph_run(pooledf, G["head_ops"], G["head_tensor_c"], bf)[G["out_tensor"]]
     f = avgpool_global(y)
@@ -718,18 +738,14 @@ def graph_detect(im, boxes, G, transformer, target=600, max_size=1000, pooled=17
     return softmax(logits), bbox_decode(boxes, deltas), logits, deltas
 
 
-def graph_mpn_detect(im, boxes, G, transformer, target=600, max_size=1000, pooled=17, spatial_scale=17.0 / 299.0):
+def graph_mpn_detect(im, boxes, G, transformer, target=600, max_size=1000, pooled=17, spatial_scale=17.0 / 299.0, return_raw=False, feat=None):
     """MultiPathNet towers on an op-list backbone (this library's extension, cf. resnet_mpn_detect): returns (scores, decoded boxes)"""
     bf = bool(G.get("bf16"))
     H, W = im.shape[1:]
     s = pick_scale(H, W, target, max_size)
-    x = image_transform(im, **transformer)
-    if s != 1.0:
-        x = image_scale(x, int(H * s), int(W * s))
-    if bf:
-        x = bf16_round(x)
     rois = project_im_rois(boxes, s)
-    feat = graph_run(x[None], G["trunk_ops"], G["trunk_tensor_c"], bf)[G["feat_tensor"]][0]
+    if feat is None:
+        feat = graph_features(im, G, transformer, target, max_size)
     fov = foveal(rois).reshape(-1, 4, 5)
     outs = []
     for tw, rg in zip(G["head_towers"], G["head_regions"]):
@@ -742,6 +758,8 @@ def graph_mpn_detect(im, boxes, G, transformer, target=600, max_size=1000, poole
     deltas = linear(outs[-1], G["bbox_w"], G["bbox_b"])
     if G.get("bbox_mean") is not None:
         deltas = bbox_norm(deltas, G["bbox_mean"], G["bbox_std"])
+    if return_raw:
+        return mean_over_k(probs), bbox_decode(boxes, deltas), logits, deltas, np.concatenate(outs, 1)
     return mean_over_k(probs), bbox_decode(boxes, deltas)
 
 
