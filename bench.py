@@ -28,6 +28,10 @@ MPN_BENCH_SHARE_GPU=1 (test only, stated in config.parallelism) maps every rank 
 gloo, so that `--gpus 2` exercises the launch / rank / drift-stream / reduction logic on a one-GPU box (RCCL refuses two ranks on
 one device).
 
+After the timed K steps a `sustained` leg repeats the same host-fed step for >= 3 s (>= 800 steps) with the GPU's clock and power
+sampled beside it (sysfs hwmon of the device's PCI function, else rocm-smi): SURVEY §8(d) says "steady state", and a 70 ms timed
+region cannot show what DVFS does over a dataset-length run (Tester_FRCNN.lua:150-157).  `--sustained-seconds 0` skips it.
+
 Prints ONE JSON line (rank 0).  Extra objects:
   "roofline"      dominant kernel group (the Winograd convolutions), fp32-MFMA bound.  `achieved` / `frac` count the FLOPs the
                   matrix pipe EXECUTES (Winograd F(2x2,3x3): 16 multiplies per 4 outputs instead of 36 => direct-conv FLOPs /
@@ -179,8 +183,9 @@ def more_boxes(boxes, n):
     return np.clip(boxes[:n], 1, [W, H, W, H]).astype(np.float32)
 
 
-def _oplist_flops(ops, h, w):
-    """algorithmic convolution FLOPs of an op list (include/mpn.h mpn_graph_op) on an h x w input"""
+def _oplist_flops(ops, h, w, wino_only=False):
+    """algorithmic convolution FLOPs of an op list (include/mpn.h mpn_graph_op) on an h x w input; wino_only: only the layers an fp32
+    graph TRUNK routes to the Winograd kernel (3x3 / stride 1 / pad 1 with >= 16 input channels: resnet.hip graph_run, fuse bit 5)"""
     dims, f = {0: (h, w)}, 0.0
     for o in ops:
         sh_, sw_ = dims[o["src"]]
@@ -194,9 +199,80 @@ def _oplist_flops(ops, h, w):
         else:
             oh, ow = (sh_ + 2 * o["ph"] - o["kh"]) // o["sh"] + 1, (sw_ + 2 * o["pw"] - o["kw"]) // o["sw"] + 1
         dims.setdefault(o["dst"], (oh, ow))
-        if o["kind"] == 0:
+        if o["kind"] == 0 and (not wino_only or (o["kh"] == 3 and o["kw"] == 3 and o["sh"] == 1 and o["sw"] == 1 and o["ph"] == 1 and o["pw"] == 1 and o["cin"] >= 16)):
             f += 2.0 * o["cout"] * o["cin"] * o["kh"] * o["kw"] * oh * ow
     return f
+
+
+def _groups(**kw):
+    """kernel groups of a configuration keyed by the pipeline's profiling tag: (label, algorithmic FLOPs per image, of which on the
+    Winograd kernel).  executed = algorithmic - winograd * (1 - 16/36): what the matrix pipe multiplies (padding waste not counted)."""
+    return {tag: dict(label=label, alg=float(alg), wino=float(wino)) for tag, (label, alg, wino) in kw.items()}
+
+
+def _cpu_baseline_towers(kind, P, im, boxes, n, C, K, sample, bf16=False):
+    """cpu_baseline of the tower configurations (configs[2] / [3] / [4]) on this box's host cores: PyTorch-CPU (oneDNN; oracle/torch_ref.py —
+    conv2d / max_pool2d / avg_pool2d / linear in fp32) for the trunk on the whole image and for the towers + integral heads on a BOUNDED
+    ROI sample (rows are independent: scaled to all n ROIs), the oracle's C ROI pooling, numpy decode, and the reference's own nms.c
+    (compiled unmodified, one thread as Tester_FRCNN.lua:117 runs it) on the sample's rows per class, scaled likewise."""
+    import torch
+    from oracle import mpn_oracle as O
+    from oracle import torch_ref as T
+    from multipathnet_amd import models
+    th_n = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(th_n)
+    b = np.ascontiguousarray(boxes[:sample])
+    rois = O.project_im_rois(b, 1.0)
+    fov = O.foveal(rois).reshape(-1, 4, 5)
+
+    def run():
+        t0 = time.time()
+        if kind == "vgg":
+            taps = {}
+            T.vgg_trunk(O.image_transform(im, **O.ROSS), P, models.VGG16_CFG, taps)
+            maps = [taps["conv5"], taps["conv4"], taps["conv3"]]
+        elif kind == "resnet":
+            feat = T.resnet_trunk(O.image_transform(im, **O.IMAGENET), P, bf16)
+        else:
+            feat = T.graph_trunk(O.image_transform(im, **O.INCEPTION), P, bf16)
+        t_trunk = time.time() - t0
+        t0 = time.time()
+        fs = []
+        if kind == "vgg":
+            for Tw in P["towers"]:
+                r = np.ascontiguousarray(fov[:, Tw["region"]])
+                pools = [O.roi_pool(maps[m], r, 7, 7, (1.0 / 16) * (2 ** m))[0] if use else None for m, use in enumerate((1, Tw["use4"], Tw["use3"]))]
+                fs.append(T.mpnet_tower(pools, Tw, True))
+        elif kind == "resnet":
+            for tw, rg in zip(P["head_towers"], P["head_regions"]):
+                fs.append(T.resnet_tower(O.roi_pool(feat, np.ascontiguousarray(fov[:, rg]), 14, 14, 1.0 / 16)[0], tw, bf16))
+        else:
+            for tw, rg in zip(P["head_towers"], P["head_regions"]):
+                fs.append(T.graph_tower(O.roi_pool(feat, np.ascontiguousarray(fov[:, rg]), 17, 17, 17.0 / 299.0)[0], tw, P, bf16))
+        with torch.no_grad():
+            logits = torch.nn.functional.linear(torch.cat(fs[:-1], 1), P["cls_w"], P["cls_b"]).numpy().reshape(sample, K, C)
+            deltas = torch.nn.functional.linear(fs[-1], P["bbox_w"], P["bbox_b"]).numpy()
+        if P.get("bbox_mean") is not None:
+            deltas = O.bbox_norm(deltas, P["bbox_mean"], P["bbox_std"])
+        scores = O.mean_over_k(np.stack([O.softmax(np.ascontiguousarray(logits[:, k])) for k in range(K)]))
+        dec = O.clamp_boxes(O.bbox_decode(b, deltas), W, H)
+        t_head = time.time() - t0
+        t0 = time.time()
+        # NMS is not linear in the row count, so it is timed at FULL size: all n proposal boxes per class (the overlap structure of the
+        # real table), scored by cycling the sample's rows' scores
+        nms = O.ref_nms if O.have_ref() else O.nms
+        reps = -(-n // sample)
+        for j in range(1, C):
+            sb = np.concatenate([boxes[:n], np.tile(scores[:, j:j + 1], (reps, 1))[:n]], 1).astype(np.float32)
+            nms(sb, 0.3)
+        return t_trunk, t_head, time.time() - t0
+    run()  # cold start
+    tt, th, tn = run()
+    sc = n / float(sample)
+    total = tt + th * sc + tn
+    return {"value": round(n / total, 1), "unit": "proposals/s", "cores": th_n, "host_cores": os.cpu_count() or 1, "kind": "port", "seconds_per_image": round(total, 3),
+            "sample": "1 image 600x1000 after one warm-up pass: PyTorch-CPU fp32 trunk %.2fs + towers / heads on %d of %d ROIs scaled %.2fs + reference nms.c, %d classes x all %d "
+                      "proposal boxes (scores cycled from the sample) %.2fs" % (tt, sample, n, th * sc, C - 1, n, tn)}
 
 
 def _cfg_alexnet(models, args):  # BASELINE configs[0]
@@ -204,6 +280,10 @@ def _cfg_alexnet(models, args):  # BASELINE configs[0]
     G = models.synthetic_alexnet_params(n_classes=21, seed=557)
     net = models.AlexNetFRCNN(G, max_h=H, max_w=W, max_rois=n)
     flops = _oplist_flops(G["trunk_ops"], H, W) + n * (_oplist_flops(G["head_ops"], 6, 6) + 2.0 * 4096 * 105)
+    groups = _groups(conv_direct=("trunk (conv1 as a GEMM over im2col rows, conv2 direct, conv3-5 Winograd, pools, LRN)", _oplist_flops(G["trunk_ops"], H, W),
+                                  _oplist_flops(G["trunk_ops"], H, W, wino_only=True)),
+                     fc6=("ROI pooling + fc6 + fc7 (row-invariant GEMMs)", n * _oplist_flops(G["head_ops"], 6, 6), 0.0),
+                     heads=("cls + bbox GEMM", n * 2.0 * 4096 * 105, 0.0))
 
     def cpu(im, boxes):
         """the config's own 'CPU nn path': PyTorch-CPU conv2d(groups) / max_pool2d(ceil_mode) / local_response_norm / linear + oracle
@@ -247,7 +327,7 @@ def _cfg_alexnet(models, args):  # BASELINE configs[0]
         dt = run()
         return {"value": round(n / dt, 1), "unit": "proposals/s", "cores": min(os.cpu_count() or 1, 64), "kind": "port", "seconds_per_image": round(dt, 3),
                 "sample": "1 image 600x1000 x 300 ROIs after one warm-up image: PyTorch-CPU trunk / fc + oracle ROI pool + reference nms.c"}
-    return dict(params=G, net=net, n_rois=n, flops=flops, dtype="f32", cpu_baseline=cpu,
+    return dict(params=G, net=net, n_rois=n, flops=flops, dtype="f32", cpu_baseline=cpu, groups=groups, key="c1",
                 metric="proposals/sec (300 ROIs, 600x1000 img) AlexNet Fast R-CNN [BASELINE configs[0]; not the headline metric]",
                 workload="AlexNet / CaffeNet Fast R-CNN (models/alexnet.lua), 1 image 600x1000 x 300 ROIs per GPU per step, 21 classes")
 
@@ -258,7 +338,15 @@ def _cfg_vgg_mpn(models, args):  # BASELINE configs[2]
     net = models.MultiPathNet(P, max_h=H, max_w=W, max_rois=n)
     flops = (367.74e9 + 5 * n * 2.0 * (25088 * 4096 + 4096 * 4096) + 49 * n * 2.0 * 512 * (1280 + 1024 + 1024 + 512 + 1280)
              + n * 2.0 * (16384 * 486 + 4096 * 324))
-    return dict(params=P, net=net, n_rois=n, flops=flops, dtype="f32",
+    cf = conv_flops(models.VGG16_CFG, H, W)
+    wino = sum(f for f, v in cf if v == "conv_wino")
+    groups = _groups(conv_wino=("trunk, 12 Winograd F(2x2,3x3) layers", wino, wino), conv_direct=("conv1_1", sum(f for f, v in cf if v == "conv_direct"), 0.0),
+                     fc6=("fc6 x 5 towers", 5 * n * 2.0 * 25088 * 4096, 0.0), fc7=("fc7 x 5 towers", 5 * n * 2.0 * 4096 * 4096, 0.0),
+                     heads=("1x1 mix GEMMs x 5 + integral classifiers + box regressor", 49 * n * 2.0 * 512 * (1280 + 1024 + 1024 + 512 + 1280) + n * 2.0 * (16384 * 486 + 4096 * 324), 0.0))
+
+    def cpu(im, boxes):
+        return _cpu_baseline_towers("vgg", P, im, boxes, n, 81, 6, sample=32)
+    return dict(params=P, net=net, n_rois=n, flops=flops, dtype="f32", groups=groups, key="c3", cpu_baseline=cpu,
                 metric="proposals/sec (1000 ROIs, 600x1000 img) VGG-16 MultiPathNet [BASELINE configs[2]; not the headline metric]",
                 workload="VGG-16 MultiPathNet (4 foveal towers + box tower, conv3/4/5 skip pooling, K = 6 integral classifiers, 81 classes), 1000 ROIs")
 
@@ -269,23 +357,34 @@ def _cfg_resnet_mpn(models, args):  # BASELINE configs[3]
     R = models.synthetic_resnet_mpn_params(depth=50, n_classes=81, n_integral=6, seed=557)
     net = models.ResNetFRCNN(R, max_h=H, max_w=W, max_rois=n, bf16=bf16)
 
-    def blocks_flops(blocks, h, w):
+    def blocks_flops(blocks, h, w, wino_only=False):
         f = 0.0
         for b in blocks:
             bh, bw = h, w
-            if b["shortcut"] is not None:
+            if b["shortcut"] is not None and not wino_only:
                 ws, _, st = b["shortcut"]
                 f += 2.0 * ws.shape[0] * ws.shape[1] * ((h - 1) // st + 1) * ((w - 1) // st + 1)
             for (wt, _, st, pd) in b["convs"]:
                 k = wt.shape[2]
                 bh, bw = (bh + 2 * pd - k) // st + 1, (bw + 2 * pd - k) // st + 1
-                f += 2.0 * wt.shape[0] * wt.shape[1] * k * k * bh * bw
+                if not wino_only or (k == 3 and st == 1 and pd == 1 and wt.shape[1] >= 16):  # resnet.hip fuse bit 7: the head's 3x3 / 1 / 1 layers on the mosaic
+                    f += 2.0 * wt.shape[0] * wt.shape[1] * k * k * bh * bw
             h, w = bh, bw
         return f
     h1, w1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
     h2, w2 = (h1 + 2 - 3) // 2 + 1, (w1 + 2 - 3) // 2 + 1
-    flops = 2.0 * 64 * 3 * 49 * h1 * w1 + blocks_flops(R["trunk_blocks"], h2, w2) + n * blocks_flops(R["head_blocks"], 14, 14) * len(R["head_towers"])
-    return dict(params=R, net=net, n_rois=n, flops=flops, dtype="bf16" if bf16 else "f32",
+    n_tow = len(R["head_towers"])
+    f_trunk = 2.0 * 64 * 3 * 49 * h1 * w1 + blocks_flops(R["trunk_blocks"], h2, w2)
+    f_tow = n * blocks_flops(R["head_blocks"], 14, 14) * n_tow
+    f_heads = n * 2.0 * ((n_tow - 1) * 2048 * 6 * 81 + 2048 * 4 * 81)
+    flops = f_trunk + f_tow
+    groups = _groups(conv_direct=("trunk: conv1, max-pool, layer1-3 on the image", f_trunk, 0.0),
+                     fc6=("per-ROI towers: ROI pooling, 5 x layer4, average pool", f_tow, 0.0 if bf16 else n * blocks_flops(R["head_blocks"], 14, 14, True) * n_tow),
+                     heads=("integral classifiers + box regressor", f_heads, 0.0))
+
+    def cpu(im, boxes):
+        return _cpu_baseline_towers("resnet", R, im, boxes, n, 81, 6, sample=16, bf16=False)
+    return dict(params=R, net=net, n_rois=n, flops=flops, dtype="bf16" if bf16 else "f32", groups=groups, key="c4_bf16" if bf16 else "c4", cpu_baseline=cpu,
                 metric="proposals/sec (1000 ROIs, 600x1000 img) ResNet-50 MultiPathNet [BASELINE configs[3]; not the headline metric]",
                 workload="ResNet-50 with MultiPathNet towers (this library's extension of models/resnet.lua: 5 layer4 towers over Foveal regions, K = 6, "
                          "81 classes), 1000 ROIs, %s" % ("bf16 activations / weights, fp32 accumulate" if bf16 else "fp32"))
@@ -296,7 +395,14 @@ def _cfg_inception_mpn(models, args):  # BASELINE configs[4]
     G = models.synthetic_inception_mpn_params(n_classes=81, n_integral=6, seed=557)
     net = models.InceptionFRCNN(G, max_h=H, max_w=W, max_rois=n, bf16=True)
     flops = _oplist_flops(G["trunk_ops"], H, W) + n * _oplist_flops(G["head_ops"], 17, 17) * len(G["head_towers"])
-    return dict(params=G, net=net, n_rois=n, flops=flops, dtype="bf16",
+    n_tow = len(G["head_towers"])
+    groups = _groups(conv_direct=("trunk: stem + Mixed_5b..6e on the image", _oplist_flops(G["trunk_ops"], H, W), 0.0),
+                     fc6=("per-ROI towers: ROI pooling, 5 x Mixed_7a..7c, average pool", n * _oplist_flops(G["head_ops"], 17, 17) * n_tow, 0.0),
+                     heads=("integral classifiers + box regressor", n * 2.0 * ((n_tow - 1) * 2048 * 6 * 81 + 2048 * 4 * 81), 0.0))
+
+    def cpu(im, boxes):
+        return _cpu_baseline_towers("graph", G, im, boxes, n, 81, 6, sample=16)
+    return dict(params=G, net=net, n_rois=n, flops=flops, dtype="bf16", groups=groups, key="c5", cpu_baseline=cpu,
                 metric="proposals/sec (2000 ROIs, 600x1000 img) Inception-v3 MultiPathNet bf16 [BASELINE configs[4]; not the headline metric]",
                 workload="Inception-v3 with MultiPathNet towers (this library's extension of models/inceptionv3.lua: 5 Mixed_7a..7c towers over Foveal "
                          "regions, K = 6, 81 classes), 2000 ROIs, bf16 activations / weights, fp32 accumulate")
@@ -305,13 +411,105 @@ def _cfg_inception_mpn(models, args):  # BASELINE configs[4]
 OTHER_CONFIGS = {"c1": _cfg_alexnet, "c3": _cfg_vgg_mpn, "c4": _cfg_resnet_mpn, "c5": _cfg_inception_mpn}
 
 
+def _gpu_bdf(dev_index):
+    import torch
+    pr = torch.cuda.get_device_properties(dev_index)
+    return "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+
+
+class ClockSampler(object):
+    """GPU clock / power beside a timed leg.  Source 1: sysfs hwmon of the device's PCI function (freq1_input = sclk in Hz,
+    power1_average / power1_input in uW), read every 50 ms by a thread.  Source 2 (no readable sysfs): `rocm-smi --showclocks --showpower
+    --json` polled by the same thread (each poll is a subprocess, so a few samples per second).  Never raises; reports what it could read."""
+
+    def __init__(self, dev_index):
+        import glob
+        import threading
+        self.samples, self.source, self._stop, self._thr = [], None, threading.Event(), None
+        self._f_clk = self._f_pow = None
+        try:
+            base = "/sys/bus/pci/devices/" + _gpu_bdf(dev_index)
+            for hw in sorted(glob.glob(base + "/hwmon/hwmon*")):
+                if os.path.exists(hw + "/freq1_input"):
+                    self._f_clk = hw + "/freq1_input"
+                for name in ("power1_average", "power1_input"):
+                    if self._f_pow is None and os.path.exists(hw + "/" + name):
+                        self._f_pow = hw + "/" + name
+            if self._f_clk or self._f_pow:
+                self.source = "sysfs hwmon (%s%s)" % (os.path.basename(self._f_clk or ""), (", " + os.path.basename(self._f_pow)) if self._f_pow else "")
+        except Exception:  # noqa: BLE001
+            pass
+        self._dev = dev_index
+        self._smi = None
+        if self.source is None:
+            for exe in ("/opt/rocm/bin/rocm-smi", "rocm-smi"):
+                try:
+                    subprocess.check_output([exe, "--showclocks", "--showpower", "--json"], stderr=subprocess.DEVNULL, timeout=10)
+                    self._smi, self.source = exe, "rocm-smi --showclocks --showpower --json (subprocess polls)"
+                    break
+                except Exception:  # noqa: BLE001
+                    continue
+        self._threading = threading
+
+    def _read_sysfs(self):
+        clk = pw = None
+        try:
+            if self._f_clk:
+                clk = float(open(self._f_clk).read().strip()) / 1e6
+            if self._f_pow:
+                pw = float(open(self._f_pow).read().strip()) / 1e6
+        except Exception:  # noqa: BLE001
+            pass
+        return clk, pw
+
+    def _read_smi(self):
+        import re
+        clk = pw = None
+        try:
+            j = json.loads(subprocess.check_output([self._smi, "--showclocks", "--showpower", "--json"], stderr=subprocess.DEVNULL, timeout=10))
+            card = j.get("card%d" % self._dev) or next(iter(j.values()))
+            for k, v in card.items():
+                kl = k.lower()
+                m = re.search(r"([0-9.]+)", str(v))
+                if not m:
+                    continue
+                if "sclk" in kl and "clock" in kl and clk is None:
+                    clk = float(m.group(1))
+                if "power" in kl and ("average" in kl or "socket" in kl or "current" in kl) and pw is None:
+                    pw = float(m.group(1))
+        except Exception:  # noqa: BLE001
+            pass
+        return clk, pw
+
+    def _run(self):
+        while not self._stop.is_set():
+            self.samples.append((time.perf_counter(),) + (self._read_sysfs() if self._smi is None else self._read_smi()))
+            self._stop.wait(0.05 if self._smi is None else 0.3)
+
+    def start(self):
+        if self.source is not None:
+            self._thr = self._threading.Thread(target=self._run, daemon=True)
+            self._thr.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self._thr is not None:
+            self._thr.join(timeout=15)
+
+    def summary(self):
+        def st(vals):
+            vals = [v for v in vals if v is not None]
+            return None if not vals else {"min": round(min(vals), 1), "mean": round(sum(vals) / len(vals), 1), "max": round(max(vals), 1)}
+        return {"source": self.source or "none readable (no sysfs hwmon for the device, no rocm-smi)", "samples": len(self.samples),
+                "sclk_mhz": st([s_[1] for s_ in self.samples]), "power_w": st([s_[2] for s_ in self.samples])}
+
+
 def pin_to_gpu_numa_node(dev_index):
     """CPU affinity of this rank = the CPUs local to its GPU (sysfs local_cpulist of the device's PCI function).  Best effort:
     returns a short description for the JSON line, never raises."""
     try:
-        import torch
-        pr = torch.cuda.get_device_properties(dev_index)
-        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        bdf = _gpu_bdf(dev_index)
         base = "/sys/bus/pci/devices/" + bdf
         node = int(open(base + "/numa_node").read().strip())
         cpus = set()
@@ -450,6 +648,9 @@ def main():
     ap.add_argument("--mode", default="throughput", choices=["throughput", "latency"],
                     help="throughput (default) = the headline metric, images sharded over the ranks.  latency = ONE image's proposals and classes "
                          "sharded over the ranks (mpn_frcnn_test_one_sharded); its own metric string, never the headline")
+    ap.add_argument("--sustained-seconds", type=float, default=3.0,
+                    help="after the timed region: the same host-fed step for at least this long (and >= 800 steps at the default), clock / power "
+                         "sampled beside it -> the `sustained` object of the JSON line; 0 = skip")
     ap.add_argument("--emulate-world", type=int, default=8,
                     help="latency mode on one GPU: also time rank 0's share of a world of this size (no all-gather), as a projection")
     args = ap.parse_args()
@@ -502,7 +703,9 @@ def main():
             nccl_group = dist.new_group(backend="nccl")
     elif comm is None:
         raise SystemExit("bench.py: " + comm_err)
-    if comm is not None:
+    if world == 1:
+        gather_via = "no gather at world 1 (mpn_comm_init_rank(NULL, 1, 0) creates no RCCL communicator; nothing is exchanged)"
+    elif comm is not None:
         gather_via = "mpn_gather_dets (RCCL through the C ABI; the rank's only RCCL communicator)"
     elif share_gpu:
         gather_via = "gloo all_gather of the packed record — TEST MODE MPN_BENCH_SHARE_GPU=1: all ranks share device 0, NOT a multi-GPU measurement"
@@ -595,14 +798,80 @@ def main():
             dt = float(tt.item())
         return dt
 
+    def sustained(step, per_step_s):
+        """the same host-fed step for >= --sustained-seconds (>= 800 steps on the headline config), clock / power sampled beside it"""
+        if args.sustained_seconds <= 0:
+            return None
+        n = int(np.ceil(args.sustained_seconds / per_step_s))
+        if args.config == "c2" and args.sustained_seconds >= 3.0:
+            n = max(n, 800)
+        drain()
+        fence()
+        sampler = ClockSampler(dev_index).start()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        drain()
+        fence()
+        dts = time.perf_counter() - t0
+        sampler.stop()
+        if world > 1:
+            tt = torch.tensor([dts], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dts = float(tt.item())
+        out_s = {"steps": n, "seconds": round(dts, 3), "value": round(n * n_rois_cfg * world / dts, 1), "unit": "proposals/s",
+                 "ms_per_step": round(dts / n * 1e3, 4), "what": "host-fed steps back to back right after the timed region (same step function, "
+                 "same rotation of pinned inputs), MAX over ranks; clock / power of rank 0's GPU sampled during the leg"}
+        out_s.update(sampler.summary())
+        return out_s
+
     dt = timed(make_step(True))            # the metric: host image + boxes in, H2D inside the timed region
     dt_res = min(timed(make_step(False)) for _ in range(2))  # inputs already resident in HBM (auxiliary figure: best of two passes)
     value = args.steps * n_rois_cfg * world / dt
     value_res = args.steps * n_rois_cfg * world / dt_res
-    if other is not None:  # one of the widened configurations: whole-path rates, its own metric string
+    sus = sustained(make_step(True), dt / args.steps)
+    if sus is not None:
+        sus["vs_timed_region"] = round(sus["value"] / value, 4)
+    if other is not None:  # one of the widened configurations: its own metric string; the same objects the headline line carries
+        # profiled leg: HIP events around every kernel group of the un-pipelined call (as the headline's roofline leg)
+        net.set_profiling(True)
+        net.get_profile(reset=True)
+        for _ in range(args.steps):
+            net.test_one_async(im_dev, boxes_dev)
+        torch.cuda.synchronize()
+        prof = net.get_profile(reset=True)
+        net.set_profiling(False)
         if rank == 0:
             peak = 2500e12 if other["dtype"] == "bf16" else FP32_MFMA_PEAK
+            pk = "bf16" if other["dtype"] == "bf16" else "fp32"
             tfl = value / world * (other["flops"] / n_rois_cfg) / 1e12
+            groups = other["groups"]
+            save = 1.0 - 1.0 / WINO_MUL_RATIO
+            kernels = {}
+            for tag, (ms, cnt) in prof.items():
+                if not cnt:
+                    continue
+                per_image_ms = ms / args.steps
+                k = {"ms_per_image": round(per_image_ms, 4), "launch_groups_per_image": cnt / args.steps}
+                if tag in groups:
+                    g = groups[tag]
+                    ex = g["alg"] - g["wino"] * save
+                    k["what"] = g["label"]
+                    k["algorithmic_gflop"] = round(g["alg"] / 1e9, 2)
+                    k["executed_gflop"] = round(ex / 1e9, 2)
+                    k["executed_tflops"] = round(ex / (per_image_ms * 1e-3) / 1e12, 2)
+                    k["executed_frac_of_%s_mfma_peak" % pk] = round(ex / (per_image_ms * 1e-3) / peak, 4)
+                    k["algorithmic_equiv_frac_of_%s_mfma_peak" % pk] = round(g["alg"] / (per_image_ms * 1e-3) / peak, 4)
+                kernels[tag] = k
+            dom = max((t for t in kernels if t in groups), key=lambda t: kernels[t]["ms_per_image"])
+            tot_alg = sum(g["alg"] for g in groups.values())
+            tot_ex = sum(g["alg"] - g["wino"] * save for g in groups.values())
+            traffic, traffic_src = None, None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC passes cannot run inside the timed process: measured offline
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath)).get(other["key"])
+                if tj and dom in tj:
+                    traffic, traffic_src = tj[dom]["bytes_per_image"], tj.get("_source")
             out = {"metric": other["metric"], "value": round(value, 1), "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                    "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                    "dtype": other["dtype"], "data": "synthetic",
@@ -610,10 +879,21 @@ def main():
                               "parallelism": "image-sharded over %d rank%s, all-gather of scored boxes only via %s; cpu affinity: %s"
                                              % (world, "" if world == 1 else "s", gather_via, affinity)},
                    "value_inputs_resident": round(value_res, 1),
-                   "roofline": {"bound": "mfma", "kernel": "whole path (no per-kernel split for this configuration)", "achieved": round(tfl, 2),
-                                "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(tfl * 1e12 / peak, 4), "traffic": None,
-                                "algorithmic_gflop_per_image": round(other["flops"] / 1e9, 2),
-                                "how": "algorithmic convolution / GEMM FLOPs of one image x proposals/s / proposals per image, per GPU"}}
+                   "sustained": sus,
+                   "whole_path": {"algorithmic_gflop_per_image": round(tot_alg / 1e9, 2), "executed_gflop_per_image": round(tot_ex / 1e9, 2),
+                                  "executed_frac_of_%s_mfma_peak" % pk: round(value / world * (tot_ex / n_rois_cfg) / peak, 4),
+                                  "algorithmic_equiv_frac_of_%s_mfma_peak" % pk: round(value / world * (tot_alg / n_rois_cfg) / peak, 4),
+                                  "convolution_only_algorithmic_frac": round(tfl * 1e12 / peak, 4)},
+                   "roofline": {"bound": "mfma", "kernel": dom + ": " + groups[dom]["label"], "achieved": kernels[dom]["executed_tflops"],
+                                "peak": peak / 1e12, "unit": "TFLOP/s", "frac": kernels[dom]["executed_frac_of_%s_mfma_peak" % pk],
+                                "algorithmic_equiv_frac": kernels[dom]["algorithmic_equiv_frac_of_%s_mfma_peak" % pk],
+                                "traffic": traffic, "traffic_unit": "HBM-side bytes per IMAGE of this kernel group (FETCH_SIZE x2 + WRITE_SIZE over its launches)",
+                                "traffic_source": traffic_src,
+                                "flops_per_image": kernels[dom]["executed_gflop"] * 1e9, "ms_per_image": kernels[dom]["ms_per_image"],
+                                "how": "HIP events on the launch stream around each kernel group of the un-pipelined call, %d profiled steps after the timed "
+                                       "region; achieved / frac count the FLOPs the matrix pipe EXECUTES (layers on the Winograd kernel: direct FLOPs / 2.25), "
+                                       "algorithmic_equiv_frac the direct-convolution FLOPs" % args.steps},
+                   "kernels": kernels}
             if world == 1 and not args.no_cpu_baseline and other.get("cpu_baseline"):
                 out["cpu_baseline"] = other["cpu_baseline"](im_np, boxes_np)
             print(json.dumps(out))
@@ -672,6 +952,7 @@ def main():
                                       "4 different pinned (image, proposals) sets in rotation, offset by rank"
                                       % (world, "" if world == 1 else "s", gather_via, affinity)},
             "value_inputs_resident": round(value_res, 1), "ms_per_step_inputs_resident": round(dt_res / args.steps * 1e3, 4),
+            "sustained": sus,
             "whole_path": {"algorithmic_gflop_per_image": round(total_flops / 1e9, 2), "executed_gflop_per_image": round(total_exec / 1e9, 2),
                            "executed_frac_of_fp32_mfma_peak": round(value / world * (total_exec / N_ROIS) / FP32_MFMA_PEAK, 4),
                            "algorithmic_equiv_frac_of_fp32_mfma_peak": round(value / world * (total_flops / N_ROIS) / FP32_MFMA_PEAK, 4)},

@@ -401,6 +401,7 @@ struct GConvArgsB {
   int stages_per_split;
   unsigned long long *trace;  // tools/dma_trace.py: s_memtime stamps of wave 0 of block 0 (LDS-DMA kernel), else nullptr
   int norelu_cb0, norelu_cb1;  // channel blocks [cb0, cb1) skip the ReLU (fused sibling convolutions with mixed activations); empty by default
+  int exp;                     // LDS-DMA kernel: scheduling experiments (mpn_debug_set_bf16_exp; 0 in the product): bit 0 = s_setprio 1 over the MFMA clusters
 };
 
 // KP = chunk PAIRS (16 input channels) per LDS stage: 4 * KP MFMAs per wave between two barriers (instantiated: 1 and 2)
@@ -588,12 +589,14 @@ __device__ __forceinline__ void glds16_s(const void *base_uniform, unsigned lane
 //           loop.  The host picks per layer (rn_conv): cout counts that are not multiples of 256 (Inception's 320 / 384) take
 //           <2, 4>, and the narrow shapes also pack some grids into fuller rounds (a 512-cout layer on 49 000 pixels is 384
 //           blocks = 1.5 rounds of 256 at 256 x 256).
-template <int MI, int NI>
-__global__ __launch_bounds__(256, (MI == 4 && NI == 4) ? 1 : 2) void conv2d_c8i_bf16_dma_kernel(GConvArgsB a, int nx, int ny) {
-  static_assert((MI == 4 || MI == 2) && (NI == 4 || NI == 2) && MI + NI >= 6, "");
-  constexpr int NCH = 4, TM = 64 * MI, TN = 64 * NI;
-  constexpr int RING = (MI == 4 && NI == 4) ? 4 : 3, LOOK = RING - 1;  // stages in the ring / stages the DMA runs ahead
-  constexpr int NA = MI, NB = NI;                                 // weight- / pixel-chunk DMA items per wave per stage
+//   NCH = 8-channel chunks per stage: 4 (32 channels; the shapes above) or 8 (64 channels — half the barriers / waits / zero-fills per
+//           MFMA cycle; the stage doubles, so ONE block per CU: <4, 4, 8> two 64-KiB buffers, <4, 2, 8> / <2, 4, 8> three 48-KiB ones).
+template <int MI, int NI, int NCH = 4>
+__global__ __launch_bounds__(256, ((MI == 4 && NI == 4) || NCH == 8) ? 1 : 2) void conv2d_c8i_bf16_dma_kernel(GConvArgsB a, int nx, int ny) {
+  static_assert((MI == 4 || MI == 2) && (NI == 4 || NI == 2) && MI + NI >= 6 && (NCH == 4 || NCH == 8), "");
+  constexpr int TM = 64 * MI, TN = 64 * NI, NQ = NCH / 2;  // NQ = k-steps (16 channels) per stage
+  constexpr int RING = NCH == 8 ? ((MI == 4 && NI == 4) ? 2 : 3) : ((MI == 4 && NI == 4) ? 4 : 3), LOOK = RING - 1;  // stages in the ring / stages the DMA runs ahead
+  constexpr int NA = MI == 4 ? NCH : NCH / 2, NB = NI == 4 ? NCH : NCH / 2;  // weight- / pixel-chunk DMA items per wave per stage
   constexpr int ITEMS = NA + NB;
   constexpr unsigned OPA = NCH * TM * 16, OPBB = NCH * TN * 16, STAGEB = OPA + OPBB;  // bytes: weights / pixels / stage
   extern __shared__ __attribute__((aligned(16))) u32x4 ring[];  // [RING][A: NCH x TM rows | B: NCH x TN rows]
@@ -612,9 +615,9 @@ __global__ __launch_bounds__(256, (MI == 4 && NI == 4) ? 1 : 2) void conv2d_c8i_
   // DMA roles (one wave-load = 64 rows of one 8-channel chunk).  A 256-row operand: wave w moves rows 64 w .. 64 w + 63 of all 4
   // chunks; a 128-row operand: wave w moves rows 64 (w & 1) .. of chunks 2 (w >> 1) and 2 (w >> 1) + 1.
   const int arow = MI == 4 ? tid : (tid & 127);                  // this lane's weight row (cout) of the tile
-  const int ach0 = MI == 4 ? 0 : 2 * (wave >> 1);                // its first weight chunk
+  const int ach0 = MI == 4 ? 0 : (NCH / 2) * (wave >> 1);        // its first weight chunk
   const int prow = NI == 4 ? tid : (tid & 127);                  // this lane's pixel row of the tile
-  const int bch0 = NI == 4 ? 0 : 2 * (wave >> 1);                // its first pixel chunk
+  const int bch0 = NI == 4 ? 0 : (NCH / 2) * (wave >> 1);        // its first pixel chunk
   const long long gpix = p0 + prow;
   const bool gvalid = gpix < a.P;
   const int gb = gvalid ? (int)(gpix / OHW) : 0;
@@ -644,8 +647,14 @@ __global__ __launch_bounds__(256, (MI == 4 && NI == 4) ? 1 : 2) void conv2d_c8i_
     i_slot = (unsigned)slot * STAGEB;
     return ok;
   };
-  auto issue_a = [&](int k) { glds16_s(i_wp, a_lane, lds_a + i_slot + (unsigned)k * (TM * 16u)); i_wp += w_step; };
-  auto issue_b = [&](int k) { glds16_s(i_bp, i_blane, lds_b + i_slot + (unsigned)k * (TN * 16u)); i_bp += b_step; };
+#ifdef MPN_DEBUG_HOOKS  // timing experiments (tools/bench_conv_bf16.py; results are garbage with bits 1-4): bit 0 = s_setprio 1 over the MFMA clusters,
+  const int ex = a.exp;  // bit 1 = no pixel-gather DMA, bit 2 = no weight DMA, bit 3 = no MFMAs, bit 4 = no epilogue loads / stores,
+                         // bit 5 = no vmcnt wait / zero-fill / barrier in the K loop, bit 6 = no fragment reads in the K loop
+#else
+  constexpr int ex = 0;
+#endif
+  auto issue_a = [&](int k) { if (!(ex & 4)) glds16_s(i_wp, a_lane, lds_a + i_slot + (unsigned)k * (TM * 16u)); i_wp += w_step; };
+  auto issue_b = [&](int k) { if (!(ex & 2)) glds16_s(i_bp, i_blane, lds_b + i_slot + (unsigned)k * (TN * 16u)); i_bp += b_step; };
   auto issue_item = [&](int i) {  // weight and pixel chunks alternate while both last
     constexpr int M = NA < NB ? NA : NB;
     if (i < 2 * M) { if ((i & 1) == 0) issue_a(i >> 1); else issue_b(i >> 1); }
@@ -673,8 +682,9 @@ __global__ __launch_bounds__(256, (MI == 4 && NI == 4) ? 1 : 2) void conv2d_c8i_
   };
   auto wait_landed = [&](auto in_flight_tag) {  // all but the newest `in flight` stages' loads of this wave
     constexpr int n = decltype(in_flight_tag)::value * ITEMS;
-    static_assert(n == 0 || n == 6 || n == 8 || n == 12 || n == 16, "");
-    if constexpr (n == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    static_assert(n == 0 || n == 6 || n == 8 || n == 12 || n == 16 || n == 24, "");
+    if constexpr (n == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if constexpr (n == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if constexpr (n == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -697,6 +707,7 @@ __global__ __launch_bounds__(256, (MI == 4 && NI == 4) ? 1 : 2) void conv2d_c8i_
   bf16x8 af[2][MI], bf[2][NI];
   const int frag_row_a = half * TM + wm * (MI * 32) + l31, frag_row_b = OPA / 16 + half * TN + wn * (NI * 32) + l31;
   auto load_frags = [&](int slot, int q, int fs) {
+    if (ex & 64) return;
     const u32x4 *S = ring + (size_t)slot * (STAGEB / 16);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) af[fs][mi] = *reinterpret_cast<const bf16x8 *>(S + q * 2 * TM + frag_row_a + mi * 32);
@@ -706,19 +717,31 @@ __global__ __launch_bounds__(256, (MI == 4 && NI == 4) ? 1 : 2) void conv2d_c8i_
 
   // okn[k]: in-bounds flag of stage st + 1 + k (issued, not yet published); slots: stage st lives in ring slot st % RING
   bool okn[3] = {false, false, false};
-  const bool ok0 = issue_all(0);
-  if (nstages > 1) okn[0] = issue_all(1);
+  static_assert(LOOK >= 1 && LOOK <= 3, "");
+  const bool ok0 = issue_all(0);  // the prologue issues stages 0 .. LOOK - 1
+  if (LOOK > 1 && nstages > 1) okn[0] = issue_all(1);
   if (LOOK > 2 && nstages > 2) okn[1] = issue_all(2);
-  if (LOOK > 2 && nstages > 2) wait_landed(I2{});
-  else if (nstages > 1) wait_landed(I1{});
-  else wait_landed(I0{});
+  if constexpr (LOOK > 2) {
+    if (nstages > 2) wait_landed(I2{});
+    else if (nstages > 1) wait_landed(I1{});
+    else wait_landed(I0{});
+  } else if constexpr (LOOK > 1) {
+    if (nstages > 1) wait_landed(I1{});
+    else wait_landed(I0{});
+  } else {
+    wait_landed(I0{});
+  }
   zero_oob(0, ok0);
   __syncthreads();
   load_frags(0, 0, 0);
   int s_cur = 0;                              // slot of stage st
   int s_iss = nstages > LOOK ? LOOK : 0;      // slot of stage st + LOOK
 
+#ifdef MPN_DEBUG_HOOKS
   unsigned long long *const tr = (a.trace && blockIdx.x == 0 && tid == 0) ? a.trace + 8 : nullptr;  // [stage][q0 start, before wait, after wait, after barrier]
+#else
+  constexpr unsigned long long *tr = nullptr;  // the product kernel carries no trace branches in its K loop
+#endif
   int tr_n = 0;
   if (tr) a.trace[0] = __builtin_amdgcn_s_memtime();
   // One stage = 2 k-steps x MI NI MFMAs, hand-scheduled like gemm_c8_pf_kernel (dense.hip): VALU work from a wave does not overlap
@@ -730,31 +753,36 @@ __global__ __launch_bounds__(256, (MI == 4 && NI == 4) ? 1 : 2) void conv2d_c8i_
     constexpr bool ISSUE = decltype(issue_tag)::value;
     constexpr bool NEXT = decltype(next_tag)::value;
     const int s_nxt = next_slot(s_cur);
+    const bool prio = (ex & 1) != 0;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (q == 1 && NEXT) {
+    for (int q = 0; q < NQ; ++q) {
+      if (q == NQ - 1 && NEXT) {
         if (tr && tr_n < 96) tr[tr_n * 4 + 1] = __builtin_amdgcn_s_memtime();
-        wait_landed(in_flight_tag);
+        if (!(ex & 32)) wait_landed(in_flight_tag);
         if (tr && tr_n < 96) tr[tr_n * 4 + 2] = __builtin_amdgcn_s_memtime();
-        zero_oob(s_nxt, okn[0]);
-        __syncthreads();
+        if (!(ex & 32)) zero_oob(s_nxt, okn[0]);
+        if (!(ex & 32)) __syncthreads();
         if (tr && tr_n < 96) tr[tr_n * 4 + 3] = __builtin_amdgcn_s_memtime();
         load_frags(s_nxt, 0, 0);
       }
       if (q == 0 && tr && tr_n < 96) tr[tr_n * 4] = __builtin_amdgcn_s_memtime();
+      if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int t = 0; t < MI * NI; ++t) {
         const int mi = t / NI, ni = t % NI;
+        const int gt = q * (MI * NI) + t;  // MFMA index within the stage: the DMA items of stage st + LOOK follow MFMAs 1 .. ITEMS
         __builtin_amdgcn_sched_barrier(0);
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q][mi], bf[q][ni], acc[mi][ni], 0, 0, 0);
+        if (!(ex & 8)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q & 1][mi], bf[q & 1][ni], acc[mi][ni], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (q == 0 && t == 0) load_frags(s_cur, 1, 1);
+        if (q + 1 < NQ && t == 0) load_frags(s_cur, q + 1, (q + 1) & 1);
         if constexpr (ISSUE) {
-          if (q == 0 && t == 1) okn[LOOK - 1] = issue_begin(s_iss);
-          if (q == 0 && t >= 1 && t <= ITEMS) issue_item(t - 1);
-          if (q == 0 && t == ITEMS) issue_end();
+          static_assert(ITEMS + 1 <= (NQ - 1) * MI * NI, "the DMA issue must end before the stage barrier");
+          if (gt == 1) okn[LOOK - 1] = issue_begin(s_iss);
+          if (gt >= 1 && gt <= ITEMS) issue_item(gt - 1);
+          if (gt == ITEMS) issue_end();
         }
       }
+      if (prio) __builtin_amdgcn_s_setprio(0);
     }
     okn[0] = okn[1]; okn[1] = okn[2];
     s_cur = s_nxt; s_iss = next_slot(s_iss);
@@ -779,6 +807,15 @@ __global__ __launch_bounds__(256, (MI == 4 && NI == 4) ? 1 : 2) void conv2d_c8i_
   // bound by store INSTRUCTIONS, not bytes, so pairs of channel blocks are exchanged with v_permlane32_swap (lanes 0-31 end up
   // with the whole record of block 2p, lanes 32-63 with block 2p + 1) and written / read as 16-byte accesses.
   if (tr) a.trace[1] = __builtin_amdgcn_s_memtime();
+  if (ex & 16) {  // keep the accumulators alive without the epilogue's memory traffic
+    float sink = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) sink += acc[mi][ni][0] + acc[mi][ni][15];
+    if (sink == 1.2345e-30f) a.out[0] = (bf16_t)1;
+    return;
+  }
   const int cb0 = (cout0 + wm * (MI * 32)) / 8;
   auto swap32 = [](unsigned &lo_keeps, unsigned &hi_keeps) {  // lanes 32-63 of the first <-> lanes 0-31 of the second
     const auto r = __builtin_amdgcn_permlane32_swap(lo_keeps, hi_keeps, false, false);
@@ -1717,6 +1754,8 @@ MPN_KNOB(int, g_split_max_tiles, 192);     // split-K only layers with fewer 128
 MPN_KNOB(int, g_bf16_split_target, 256);  // split-K (both dtypes) aims at this many blocks (0 = never split; mpn_debug_set_bf16_split_target)
 MPN_KNOB(int, g_bf16_dma_tn, 0);  // 0 = pick per layer; 128 / 256 = force 256 couts x that many pixels, 1256 = 128 couts x 256 pixels (mpn_debug_set_bf16_dma_tn)
 MPN_KNOB(int, g_bf16_dma, 1);  // mpn_debug_set_bf16_dma: 0 = never, 1 = large layers, 2 = every eligible layer (tests)
+MPN_KNOB(int, g_bf16_exp, 0);   // mpn_debug_set_bf16_exp: GConvArgsB::exp (scheduling experiments of the LDS-DMA kernel)
+MPN_KNOB(int, g_bf16_nch, 4);   // mpn_debug_set_bf16_nch: 8 = 64-channel stages where Cin % 64 == 0 (one block per CU)
 MPN_KNOB(int, g_roi_invariant, 1);  // mpn_debug_set_roi_invariant: 0 = per-ROI layers pick kernel / split by batch size as round 3 did (tests, timing)
 // per_roi: the batch axis counts ROIs (the head of a graph model).  A ROI's result must not depend on which other ROIs share the
 // launch (memoryEfficientForward's chunked == full, ImageDetect.lua:126-133; the ROI-sharded mode == the unsharded one), so for
@@ -1756,17 +1795,34 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
       }
       if (best >= 0) {
         const int tm = shapes[best].tm, tn = shapes[best].tn;
-        const int ring = (tm == 256 && tn == 256) ? 4 : 3;
-        const size_t LDS = (size_t)ring * 4 * (tm + tn) * 16;  // ring depth x stage bytes (as in the kernel)
+#ifdef MPN_DEBUG_HOOKS
+        const bool nch8 = g_bf16_nch == 8 && b.nch2 % 8 == 0;
+#else
+        constexpr bool nch8 = false;  // 64-channel stages measured 12 % SLOWER (one block per CU: tools/bench_conv_bf16.py, profiles/r04_bf16_conv_ablation.txt)
+#endif
+        const int ring = nch8 ? ((tm == 256 && tn == 256) ? 2 : 3) : ((tm == 256 && tn == 256) ? 4 : 3);
+        const size_t LDS = (size_t)ring * (nch8 ? 8 : 4) * (tm + tn) * 16;  // ring depth x stage bytes (as in the kernel)
         {
           int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<4, 4>), 4 * 32768);
           if (rc_attr == MPN_OK) rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<4, 2>), 3 * 24576);
           if (rc_attr == MPN_OK) rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<2, 4>), 3 * 24576);
+#ifdef MPN_DEBUG_HOOKS
+          if (rc_attr == MPN_OK && nch8) rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<4, 4, 8>), 2 * 65536);
+          if (rc_attr == MPN_OK && nch8) rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<4, 2, 8>), 3 * 49152);
+          if (rc_attr == MPN_OK && nch8) rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<2, 4, 8>), 3 * 49152);
+#endif
           if (rc_attr) return rc_attr;
         }
         const int nx = (int)((b.P + tn - 1) / tn), ny = b.CoutP / tm;
         b.trace = (g_bf16_trace && b.KH == g_bf16_trace_kh) ? g_bf16_trace : nullptr;
+        b.exp = g_bf16_exp;
         const dim3 gridd((unsigned)(((nx + 7) / 8) * 8 * ny));
+#ifdef MPN_DEBUG_HOOKS
+        if (nch8 && tm == 256 && tn == 128) hipLaunchKernelGGL((conv2d_c8i_bf16_dma_kernel<4, 2, 8>), gridd, dim3(256), LDS, s, b, nx, ny);
+        else if (nch8 && tm == 128) hipLaunchKernelGGL((conv2d_c8i_bf16_dma_kernel<2, 4, 8>), gridd, dim3(256), LDS, s, b, nx, ny);
+        else if (nch8) hipLaunchKernelGGL((conv2d_c8i_bf16_dma_kernel<4, 4, 8>), gridd, dim3(256), LDS, s, b, nx, ny);
+        else
+#endif
         if (tm == 256 && tn == 128) hipLaunchKernelGGL((conv2d_c8i_bf16_dma_kernel<4, 2>), gridd, dim3(256), LDS, s, b, nx, ny);
         else if (tm == 128) hipLaunchKernelGGL((conv2d_c8i_bf16_dma_kernel<2, 4>), gridd, dim3(256), LDS, s, b, nx, ny);
         else hipLaunchKernelGGL((conv2d_c8i_bf16_dma_kernel<4, 4>), gridd, dim3(256), LDS, s, b, nx, ny);
@@ -2592,8 +2648,60 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
 }  // namespace mpn
 
 #ifdef MPN_DEBUG_HOOKS
+// Kernel-only timing of ONE per-ROI bf16 convolution (rn_conv, per_roi dispatch) on a batch of B maps of H x W (tools/bench_conv_bf16.py):
+// random bf16 activations / weights (zero operands clock higher), optional residual; returns the average ms of `iters` launches.
+extern "C" int mpn_debug_bench_conv_bf16(int Cin, int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int B, int H, int W, int with_res, int iters,
+                                         float *ms_out) {
+  using namespace mpn;
+  MPN_CHECK_ARG(Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && B > 0 && H > 0 && W > 0 && iters > 0 && ms_out);
+  ResNetGraph *g = new ResNetGraph();
+  g->bf16 = true;
+  RnConv c;
+  c.Cin = Cin; c.Cout = Cout; c.KH = KH; c.KW = KW; c.sh = sh; c.sw = sw; c.ph = ph; c.pw = pw; c.K = KH; c.stride = sh; c.pad = ph;
+  const size_t nw = (size_t)Cout * Cin * KH * KW;
+  std::vector<float> hw(nw);
+  unsigned x = 2463534242u;
+  for (auto &v : hw) { x = x * 1664525u + 1013904223u; v = ((x >> 8) * (1.0f / 8388608.0f) - 1.0f) * 0.05f; }
+  float *d_w = nullptr;
+  int rc = rn_alloc(g, &d_w, nw * sizeof(float));
+  if (rc == MPN_OK && hipMemcpy(d_w, hw.data(), nw * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = MPN_EHIP;
+  if (rc == MPN_OK) rc = rn_pack(g, c, d_w, nullptr);
+  const int OH = (H + 2 * ph - KH) / sh + 1, OW = (W + 2 * pw - KW) / sw + 1;
+  const size_t ie = c8i_elems(B, Cin, H, W), oe = c8i_elems(B, Cout, OH, OW);
+  float *in = nullptr, *out = nullptr, *res = nullptr;
+  if (rc == MPN_OK) rc = rn_alloc(g, &in, ie * sizeof(bf16_t));
+  if (rc == MPN_OK) rc = rn_alloc(g, &out, oe * sizeof(bf16_t));
+  if (rc == MPN_OK && with_res) rc = rn_alloc(g, &res, oe * sizeof(bf16_t));
+  if (rc == MPN_OK) {
+    std::vector<unsigned short> hi(std::max(ie, oe));
+    for (auto &v : hi) { x = x * 1664525u + 1013904223u; v = (unsigned short)(0x3c00u + ((x >> 9) & 0x3ffu) + ((x >> 31) << 15)); }  // +-[0.0078, 0.031): finite bf16
+    { const char *fill = getenv("MPN_BENCH_FILL"); if (fill && fill[0] == 'z') for (auto &v : hi) v = 0; }  // DVFS experiments: zero activations clock higher
+    if (hipMemcpy(in, hi.data(), ie * sizeof(bf16_t), hipMemcpyHostToDevice) != hipSuccess) rc = MPN_EHIP;
+    if (rc == MPN_OK && res && hipMemcpy(res, hi.data(), oe * sizeof(bf16_t), hipMemcpyHostToDevice) != hipSuccess) rc = MPN_EHIP;
+  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (rc == MPN_OK && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = MPN_EHIP;
+  const ActI ai{in, B, Cin, H, W};
+  ActI o;
+  for (int i = 0; i < 2 && rc == MPN_OK; ++i) rc = rn_conv(c, ai, out, res, 1, nullptr, &o, true, true);
+  if (rc == MPN_OK && hipDeviceSynchronize() != hipSuccess) rc = MPN_EHIP;
+  if (rc == MPN_OK) (void)hipEventRecord(e0, nullptr);
+  for (int i = 0; i < iters && rc == MPN_OK; ++i) rc = rn_conv(c, ai, out, res, 1, nullptr, &o, true, true);
+  if (rc == MPN_OK) {
+    (void)hipEventRecord(e1, nullptr);
+    float ms = 0.f;
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = MPN_EHIP;
+    *ms_out = ms / iters;
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  resnet_free(g);
+  return rc;
+}
 extern "C" void mpn_debug_set_bf16_dma(int v) { mpn::g_bf16_dma = v; }
 extern "C" void mpn_debug_set_roi_invariant(int v) { mpn::g_roi_invariant = v; }
+extern "C" void mpn_debug_set_bf16_exp(int v) { mpn::g_bf16_exp = v; }
+extern "C" void mpn_debug_set_bf16_nch(int v) { mpn::g_bf16_nch = v; }
 extern "C" void mpn_debug_set_bf16_dma_tn(int v) { mpn::g_bf16_dma_tn = v; }
 extern "C" void mpn_debug_set_bf16_split_target(int v) { mpn::g_bf16_split_target = v; }
 extern "C" void mpn_debug_set_bf16_fast_pool(int v) { mpn::g_bf16_fast_pool = v; }

@@ -71,14 +71,15 @@ def synthetic_params(cfg=VGG16_CFG, pooled=7, fc_dim=4096, n_classes=21, seed=55
     return P
 
 
-def rescale_heads(P, head_scale="trained", seed=7001):
+def rescale_heads(P, head_scale="trained", seed=7001, cls_gain=1.0):
     """A copy of ANY parameter dict of this module (VGG / MultiPathNet / ResNet / op-list, plain or tower form) whose cls / bbox head tensors
     are redrawn, same shapes, at HEAD_SCALES[head_scale] — e.g. "trained": the score scale of a trained detector (class logits of +-10 and
-    more, non-zero biases, saturating softmax rows) instead of model_utils.lua:106-112's initialisation.  Every other tensor is shared."""
+    more, non-zero biases, saturating softmax rows) instead of model_utils.lua:106-112's initialisation.  Every other tensor is shared.
+    cls_gain multiplies the class weights' std (backbones whose pooled features are small need it to reach the same logit range)."""
     cls_std, cls_bstd, bbox_std, bbox_bstd = HEAD_SCALES[head_scale]
     g = torch.Generator().manual_seed(seed)
     Q = dict(P)
-    Q["cls_w"] = torch.randn(P["cls_w"].shape, generator=g) * cls_std
+    Q["cls_w"] = torch.randn(P["cls_w"].shape, generator=g) * (cls_std * cls_gain)
     Q["bbox_w"] = torch.randn(P["bbox_w"].shape, generator=g) * bbox_std
     Q["cls_b"] = torch.randn(P["cls_b"].shape, generator=g) * cls_bstd
     Q["bbox_b"] = torch.randn(P["bbox_b"].shape, generator=g) * bbox_bstd

@@ -1,5 +1,5 @@
-"""PyTorch-CPU (oneDNN) transcriptions of the graph models — test infrastructure, the ORACLE-INDEPENDENT leg of the full-size parity
-tests: the dense arithmetic (conv2d / max_pool2d / avg_pool2d / linear, the cudnn / nn semantics the reference relies on) comes from
+"""PyTorch-CPU (oneDNN) transcriptions of the graph models — TEST INFRASTRUCTURE like the rest of oracle/ (imported by tests/ and by
+bench.py's cpu_baseline leg only, never by the product): the C-ORACLE-INDEPENDENT leg of the full-size parity tests: the dense arithmetic (conv2d / max_pool2d / avg_pool2d / linear, the cudnn / nn semantics the reference relies on) comes from
 PyTorch, not from oracle/mpn_oracle.c.  Only the ROI pooling's integer binning + max (no arithmetic) is taken from the oracle by the
 callers.  Model structure follows models/resnet.lua:28-50 (fb.resnet.torch blocks, BN folded) and models/inceptionv3.lua:27-43 (the
 op lists multipathnet_amd.models builds).

@@ -1,11 +1,11 @@
-"""tests/torch_ref.py (the PyTorch-CPU leg of the full-size graph-model parity tests) against the oracle on small networks, fp32 and
+"""oracle/torch_ref.py (the PyTorch-CPU leg of the full-size graph-model parity tests) against the oracle on small networks, fp32 and
 with the bf16 storage emulation: two independent CPU implementations of the same public definitions (models/resnet.lua:28-50,
 models/inceptionv3.lua:27-43)."""
 import numpy as np
 import pytest
 import torch
 
-import torch_ref as T
+from oracle import torch_ref as T
 
 
 def _boxes(rng, n, W, H):
