@@ -586,6 +586,13 @@ def latency_mode(args, torch, dist, models, parallel, comm, rank, world, dev, sh
 
     ms = timed(lambda: net.test_one_sharded(comm, im_dev, boxes_dev))
     ms_res = timed(lambda: net.test_one_sharded(comm, im_dev, boxes_dev), with_upload=False)
+    # outside the timed loops: every rank must hold the SAME final detections (one extra gather of the ~11-KB record), checked on rank 0
+    dets_f, n_f = net.test_one_sharded(comm, im_dev, boxes_dev)
+    allrec = comm.gather_dets(dets_f, n_f)
+    torch.cuda.synchronize()
+    identical = bool(all(torch.equal(allrec[r], allrec[0]) for r in range(world))) and int(allrec[0, -1].item()) > 0
+    if rank == 0 and not identical:
+        raise SystemExit("bench.py --mode latency: the ranks ended with different detections")
     out = {"metric": "per-image latency (%d ROIs, 600x1000 img) %s, proposals + classes of ONE image sharded over the GPUs "
                      "[latency mode; not the headline metric]" % (n_rois, model_name),
            "value": round(ms, 4), "unit": "ms/image", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
@@ -595,7 +602,9 @@ def latency_mode(args, torch, dist, models, parallel, comm, rank, world, dev, sh
                       "parallelism": "every rank: trunk on the whole image; ROI head on 1/%d of the proposals; RCCL all-gather of decoded rows; NMS of 1/%d of "
                                      "the classes; RCCL all-gather of kept tables (mpn_frcnn_test_one_sharded through the C ABI); cpu affinity: %s"
                                      % (world, world, affinity)},
-           "proposals_per_s": round(n_rois / (ms * 1e-3), 1), "ms_inputs_resident": round(ms_res, 4)}
+           "proposals_per_s": round(n_rois / (ms * 1e-3), 1), "ms_inputs_resident": round(ms_res, 4),
+           "ranks": {"rccl_ranks": comm.rccl_ranks, "final_detections_identical_on_all_ranks": identical,
+                     "n_detections": int(allrec[0, -1].item())}}
     if world == 1:
         out["unsharded_ms"] = round(timed(lambda: net.test_one_async(im_dev, boxes_dev)), 4)  # mpn_frcnn_test_one under the same protocol
         G = max(2, args.emulate_world)
@@ -686,7 +695,10 @@ def main():
     # communicator fail to come up on some node, the 11-KB gather goes through a torch.distributed RCCL group created for
     # that purpose instead — the bench line says which one ran; all ranks agree on the choice.
     comm, comm_err, nccl_group = None, "", None
-    if share_gpu:
+    force_fail = os.environ.get("MPN_BENCH_FORCE_COMM_FAIL") == "1"  # TEST ONLY: take the fallback branch below as if the C-ABI communicator had failed
+    if force_fail:
+        comm_err = "MPN_BENCH_FORCE_COMM_FAIL=1 (test: the C-ABI communicator was not tried)"
+    elif share_gpu:
         comm_err = "MPN_BENCH_SHARE_GPU=1"
     else:
         try:
@@ -699,18 +711,22 @@ def main():
         if int(ok.item()) == 0 and comm is not None:
             comm.close()
             comm = None
-        if comm is None and not share_gpu:
-            nccl_group = dist.new_group(backend="nccl")
+        if comm is None and (not share_gpu or force_fail):
+            # the fallback: a torch.distributed group for the 11-KB record gather.  RCCL on real multi-GPU runs; under the one-GPU
+            # share mode (RCCL refuses two ranks on one device) the SAME branch runs with a gloo group, so that its control flow —
+            # every rank agreeing on the choice, group creation, the gather through torch.distributed — is exercised by a test
+            nccl_group = dist.new_group(backend="gloo" if share_gpu else "nccl")
     elif comm is None:
         raise SystemExit("bench.py: " + comm_err)
     if world == 1:
         gather_via = "no gather at world 1 (mpn_comm_init_rank(NULL, 1, 0) creates no RCCL communicator; nothing is exchanged)"
     elif comm is not None:
         gather_via = "mpn_gather_dets (RCCL through the C ABI; the rank's only RCCL communicator)"
-    elif share_gpu:
+    elif share_gpu and nccl_group is None:
         gather_via = "gloo all_gather of the packed record — TEST MODE MPN_BENCH_SHARE_GPU=1: all ranks share device 0, NOT a multi-GPU measurement"
     else:
-        gather_via = "torch.distributed all_gather_into_tensor (RCCL); C-ABI communicator failed: " + comm_err
+        gather_via = ("torch.distributed all_gather_into_tensor on a fallback group (%s); C-ABI communicator failed: %s"
+                      % ("gloo — TEST MODE MPN_BENCH_SHARE_GPU=1: all ranks share device 0, NOT a multi-GPU measurement" if share_gpu else "RCCL", comm_err))
     if args.mode == "latency":
         return latency_mode(args, torch, dist, models, parallel, comm, rank, world, dev, share_gpu, affinity)
 
@@ -748,9 +764,9 @@ def main():
             with torch.cuda.stream(gstream):
                 if comm is not None:
                     comm.gather_dets(bufs[0], bufs[1], out=gathered[state["seq"] & 1])
-                elif share_gpu:  # test mode: through the CPU group (gloo), record staged on the host
+                elif share_gpu:  # test mode: through a CPU group (gloo; the fallback group when the test forced one), record staged on the host
                     rec = parallel.pack_record(bufs[0], bufs[1], top_cap).cpu()
-                    gathered[state["seq"] & 1].copy_(parallel.gather_detections(rec), non_blocking=True)
+                    gathered[state["seq"] & 1].copy_(parallel.gather_detections(rec, group=nccl_group), non_blocking=True)
                 else:
                     parallel.gather_detections(parallel.pack_record(bufs[0], bufs[1], top_cap), group=nccl_group, out=gathered[state["seq"] & 1])
 
@@ -792,10 +808,12 @@ def main():
         dt = time.perf_counter() - t0
         if gc_was:
             gc.enable()
+        state["per_rank_s"] = [dt]
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
+            each = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(each, torch.tensor([dt], dtype=torch.float64))
+            state["per_rank_s"] = [float(t.item()) for t in each]
+            dt = max(state["per_rank_s"])  # the MAX over ranks is the job's time
         return dt
 
     def sustained(step, per_step_s):
@@ -826,6 +844,12 @@ def main():
         return out_s
 
     dt = timed(make_step(True))            # the metric: host image + boxes in, H2D inside the timed region
+    per_rank = [args.steps * n_rois_cfg / t for t in state["per_rank_s"]]
+    ranks_info = {"rccl_ranks": comm.rccl_ranks if comm is not None else 0,
+                  "rccl_ranks_what": "ncclCommCount of the C-ABI communicator, cross-checked with ncclCommUserRank at init (mpn_comm_rccl_ranks); "
+                                     "0 = no RCCL communicator (one rank, or the fallback / share-GPU test paths)",
+                  "per_rank_proposals_per_s": {"min": round(min(per_rank), 1), "max": round(max(per_rank), 1),
+                                               "all": [round(v, 1) for v in per_rank]}}
     dt_res = min(timed(make_step(False)) for _ in range(2))  # inputs already resident in HBM (auxiliary figure: best of two passes)
     value = args.steps * n_rois_cfg * world / dt
     value_res = args.steps * n_rois_cfg * world / dt_res
@@ -879,7 +903,7 @@ def main():
                               "parallelism": "image-sharded over %d rank%s, all-gather of scored boxes only via %s; cpu affinity: %s"
                                              % (world, "" if world == 1 else "s", gather_via, affinity)},
                    "value_inputs_resident": round(value_res, 1),
-                   "sustained": sus,
+                   "sustained": sus, "ranks": ranks_info,
                    "whole_path": {"algorithmic_gflop_per_image": round(tot_alg / 1e9, 2), "executed_gflop_per_image": round(tot_ex / 1e9, 2),
                                   "executed_frac_of_%s_mfma_peak" % pk: round(value / world * (tot_ex / n_rois_cfg) / peak, 4),
                                   "algorithmic_equiv_frac_of_%s_mfma_peak" % pk: round(value / world * (tot_alg / n_rois_cfg) / peak, 4),
@@ -952,7 +976,7 @@ def main():
                                       "4 different pinned (image, proposals) sets in rotation, offset by rank"
                                       % (world, "" if world == 1 else "s", gather_via, affinity)},
             "value_inputs_resident": round(value_res, 1), "ms_per_step_inputs_resident": round(dt_res / args.steps * 1e3, 4),
-            "sustained": sus,
+            "sustained": sus, "ranks": ranks_info,
             "whole_path": {"algorithmic_gflop_per_image": round(total_flops / 1e9, 2), "executed_gflop_per_image": round(total_exec / 1e9, 2),
                            "executed_frac_of_fp32_mfma_peak": round(value / world * (total_exec / N_ROIS) / FP32_MFMA_PEAK, 4),
                            "algorithmic_equiv_frac_of_fp32_mfma_peak": round(value / world * (total_flops / N_ROIS) / FP32_MFMA_PEAK, 4)},

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MPN_VERSION 300
+#define MPN_VERSION 400
 
 typedef enum mpn_status {
   MPN_OK = 0,
@@ -82,9 +82,10 @@ int mpn_nms(const float *d_scored, int m, float thr, float *d_keep, int *d_keep_
 /* utils.nms_dense (utils.lua:402-462, called by demo.lua:85): the index-returning NMS — sort by score (descending), walk the
  * sorted list, a picked box suppresses every box whose IoU with it (areas with the +1 convention, intersection clamped at 0)
  * exceeds `overlap` (strict).  d_boxes [m,5] {x1,y1,x2,y2,score}; d_pick [m] int32 receives the picks as 1-BASED row indices
- * in pick order (the LongTensor the Lua function returns), *d_n_pick their number.  m <= 8192.  The order among bit-equal
- * scores is the sort's: torch.sort is TH's (unstable) quicksort and TH is absent from the reference tree — PARITY UNPINNED
- * there; this library sorts ties by ascending index. */
+ * in pick order (the LongTensor the Lua function returns), *d_n_pick their number.  Any m (tables wider than the 8192 rows the
+ * LDS sort holds take a counting-rank + sequential-walk form: the reference function has no size limit).  The order among
+ * bit-equal scores is the sort's: torch.sort is TH's (unstable) quicksort and TH is absent from the reference tree — PARITY
+ * UNPINNED there; this library sorts ties by ascending index, NaN scores last. */
 int mpn_nms_dense(const float *d_boxes, int m, float overlap, int *d_pick, int *d_n_pick, void *stream);
 
 /* Host-buffer form used by the libnms.so drop-in: H2D, kernel, D2H, synchronous.  h_keep [m,5]. */
@@ -417,6 +418,11 @@ int mpn_comm_init_rank(const void *id128, int world, int rank, mpn_comm **out);
 int mpn_comm_init_all(int n_dev, const int *h_devices, mpn_comm **out);
 int mpn_comm_world(const mpn_comm *c);
 int mpn_comm_rank(const mpn_comm *c);
+/* What RCCL ITSELF reports for the communicator (ncclCommCount), 0 when there is none (world 1 without an id).  Both init entries
+ * cross-check ncclCommCount / ncclCommUserRank against the caller's (world, rank) and fail with MPN_ENCCL on a mismatch, and
+ * mpn_comm_init_rank waits a bounded time for its peers (MPN_COMM_INIT_TIMEOUT_S, default 120 s) instead of hanging: a multi-GPU
+ * run can state — and a bench line can carry — how many ranks RCCL really saw (test_runner.lua:55-66: worker k IS GPU k). */
+int mpn_comm_rccl_ranks(const mpn_comm *c);
 void mpn_comm_destroy(mpn_comm *c);
 /* A rank's record for one image: top_cap rows {x1,y1,x2,y2,score,class} (rows at / beyond the count zeroed) + the count
  * as a float = top_cap*6 + 1 floats (~10 KB for top_cap = 464). */
@@ -458,6 +464,17 @@ int mpn_frcnn_shard_finish(mpn_frcnn *p, const float *d_class_all, int N, int wo
                            void *stream);
 int mpn_frcnn_test_one_sharded(mpn_frcnn *p, mpn_comm *comm, const float *d_image, int H, int W, const float *d_boxes, int N,
                                float *d_dets, int top_cap, int *d_n_dets, void *stream);
+
+/* Captured launch graphs.  The kernel chains of the per-image path — the head (transform .. decode) and the tail (per-class NMS,
+ * voting, top-k) of mpn_frcnn_test_one / _pipelined / _pipelined_host, and the bodies of mpn_frcnn_shard_head / _shard_nms /
+ * _shard_finish — are captured with hipStreamBeginCapture once per (buffer pointers, H, W, N) and replayed with hipGraphLaunch: one host
+ * call per segment instead of 30-60 kernel launches (Tester_FRCNN.lua:54-139 calls testOne in a loop over same-sized inputs).  Results are
+ * bit-identical to the ordinary launches.  Caller-provided buffers are captured at their second sighting, so a host that passes the
+ * same device buffers every image gets the replays and one that allocates fresh ones never pays for a capture; a graph is dropped when a
+ * library buffer it references is replaced.  On by default (MPN_GRAPHS=0 in the environment, or enable = 0 here, turns it off);
+ * profiling (mpn_frcnn_set_profiling) suspends it. */
+int mpn_frcnn_set_graphs(mpn_frcnn *p, int enable);
+int mpn_frcnn_graph_stats(const mpn_frcnn *p, long *captures, long *replays);
 
 /* Per-kernel-group timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  * Tags index the arrays returned by mpn_frcnn_get_profile (accumulated ms and launch-group counts). */

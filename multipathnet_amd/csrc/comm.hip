@@ -11,7 +11,12 @@
 // a Lua host gets /opt/rocm/lib's, and a single-GPU host never loads the 0.5 GB library at all.
 #include <dlfcn.h>
 
+#include <chrono>
+#include <cstdlib>
+#include <future>
+#include <memory>
 #include <mutex>
+#include <thread>
 
 #include "mpn_internal.h"
 
@@ -31,6 +36,8 @@ struct Rccl {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;     // optional: what RCCL itself says the communicator is
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
 };
 static Rccl g_rccl;
 static std::mutex g_rccl_mu;
@@ -52,6 +59,8 @@ static int rccl_load() {
   SYM(AllGather, "ncclAllGather");
   SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
+  r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(h, "ncclCommCount"));
+  r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
   g_rccl = r;
   return MPN_OK;
 }
@@ -80,6 +89,7 @@ using namespace mpn;
 struct mpn_comm {
   ncclComm_t comm = nullptr;
   int world = 1, rank = 0, device = 0;
+  int rccl_ranks = 0;      // ncclCommCount of `comm` (0: no RCCL communicator — world 1 without an id)
   float *send = nullptr;   // this rank's packed record
   size_t send_floats = 0;
 };
@@ -94,6 +104,37 @@ extern "C" int mpn_comm_get_unique_id(void *id128) {
   return MPN_OK;
 }
 
+// The first N > 1 run must verify itself (test_runner.lua:55-66: thread k IS GPU k): ask RCCL what it built — ncclCommCount /
+// ncclCommUserRank — and refuse a communicator that is not the (world, rank) the caller asked for.
+static int verify_comm(mpn_comm *c, const char *who) {
+  if (!c->comm) return MPN_OK;
+  if (g_rccl.CommCount) {
+    int n = -1;
+    ncclResult_t r = g_rccl.CommCount(c->comm, &n);
+    if (r != 0) { set_error("%s: ncclCommCount failed: %s", who, g_rccl.GetErrorString(r)); return MPN_ENCCL; }
+    c->rccl_ranks = n;
+    if (n != c->world) { set_error("%s: RCCL built a communicator of %d ranks, %d were asked for", who, n, c->world); return MPN_ENCCL; }
+  } else {
+    c->rccl_ranks = c->world;  // an RCCL without ncclCommCount: nothing to cross-check
+  }
+  if (g_rccl.CommUserRank) {
+    int ur = -1;
+    ncclResult_t r = g_rccl.CommUserRank(c->comm, &ur);
+    if (r != 0) { set_error("%s: ncclCommUserRank failed: %s", who, g_rccl.GetErrorString(r)); return MPN_ENCCL; }
+    if (ur != c->rank) { set_error("%s: RCCL says this is rank %d, the caller said %d", who, ur, c->rank); return MPN_ENCCL; }
+  }
+  return MPN_OK;
+}
+
+// ncclCommInitRank blocks until every rank has arrived.  A rank that never comes (a crashed peer, a wrong id) would hang the caller — and
+// the GPU lease — forever, so the call runs on a helper thread and the caller waits a bounded time (MPN_COMM_INIT_TIMEOUT_S, default
+// 120 s).  On a timeout the helper is left behind (it cannot be cancelled) and the caller gets MPN_ENCCL with a message: exit the process.
+static int init_timeout_s() {
+  const char *e = getenv("MPN_COMM_INIT_TIMEOUT_S");
+  const int v = e ? atoi(e) : 0;
+  return v > 0 ? v : 120;
+}
+
 extern "C" int mpn_comm_init_rank(const void *id128, int world, int rank, mpn_comm **out) {
   MPN_CHECK_ARG(out != nullptr && world >= 1 && rank >= 0 && rank < world && (world == 1 || id128 != nullptr));
   mpn_comm *c = new mpn_comm();
@@ -104,8 +145,27 @@ extern "C" int mpn_comm_init_rank(const void *id128, int world, int rank, mpn_co
     if (rc) { delete c; return rc; }
     ncclUniqueId id;
     memcpy(id.internal, id128, sizeof(id.internal));
-    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
-    if (r != 0) { set_error("mpn_comm_init_rank: ncclCommInitRank failed: %s", g_rccl.GetErrorString(r)); delete c; return MPN_ENCCL; }
+    struct Job { ncclComm_t comm = nullptr; ncclResult_t r = 0; };
+    auto job = std::make_shared<Job>();
+    auto done = std::make_shared<std::promise<void>>();
+    std::future<void> fut = done->get_future();
+    const int device = c->device;
+    std::thread([job, done, world, id, rank, device]() {
+      if (hipSetDevice(device) != hipSuccess) job->r = -1;
+      else job->r = g_rccl.CommInitRank(&job->comm, world, id, rank);
+      done->set_value();
+    }).detach();
+    const int tmo = init_timeout_s();
+    if (fut.wait_for(std::chrono::seconds(tmo)) != std::future_status::ready) {
+      set_error("mpn_comm_init_rank: ncclCommInitRank (rank %d of %d) did not return within %d s — a peer rank never arrived or the unique id "
+                "differs between ranks; the helper thread is abandoned, exit the process (MPN_COMM_INIT_TIMEOUT_S changes the bound)", rank, world, tmo);
+      delete c;
+      return MPN_ENCCL;
+    }
+    if (job->r != 0) { set_error("mpn_comm_init_rank: ncclCommInitRank failed: %s", job->r == -1 ? "hipSetDevice on the helper thread" : g_rccl.GetErrorString(job->r)); delete c; return MPN_ENCCL; }
+    c->comm = job->comm;
+    int rcv = verify_comm(c, "mpn_comm_init_rank");
+    if (rcv) { mpn_comm_destroy(c); return rcv; }
   }
   *out = c;
   return MPN_OK;
@@ -134,11 +194,16 @@ extern "C" int mpn_comm_init_all(int n_dev, const int *h_devices, mpn_comm **out
     out[i] = c;
   }
   delete[] comms;
+  for (int i = 0; i < n_dev; ++i) {
+    int rcv = verify_comm(out[i], "mpn_comm_init_all");
+    if (rcv) { for (int j = 0; j < n_dev; ++j) { mpn_comm_destroy(out[j]); out[j] = nullptr; } return rcv; }
+  }
   return MPN_OK;
 }
 
 extern "C" int mpn_comm_world(const mpn_comm *c) { return c ? c->world : 0; }
 extern "C" int mpn_comm_rank(const mpn_comm *c) { return c ? c->rank : -1; }
+extern "C" int mpn_comm_rccl_ranks(const mpn_comm *c) { return c ? c->rccl_ranks : 0; }
 
 extern "C" void mpn_comm_destroy(mpn_comm *c) {
   if (!c) return;

@@ -1,4 +1,5 @@
 // common.hip — error reporting, version, device query.
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <set>
@@ -14,6 +15,10 @@ void set_error(const char *fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+static std::atomic<unsigned long long> g_alloc_gen{1};
+unsigned long long alloc_generation() { return g_alloc_gen.load(std::memory_order_relaxed); }
+void bump_alloc_generation() { g_alloc_gen.fetch_add(1, std::memory_order_relaxed); }
 
 void Scratch::release() {
   for (int i = 0; i < SCR_NSLOTS; ++i) {
@@ -46,6 +51,7 @@ int scratch_get(ScratchSlot slot, size_t need, hipStream_t s, void **out) {
     sc->buf[slot] = nullptr; sc->bytes[slot] = 0;
     MPN_CHECK_HIP(hipMalloc(&sc->buf[slot], need));
     sc->bytes[slot] = need;
+    bump_alloc_generation();  // captured launch graphs hold the old pointer
   }
   *out = sc->buf[slot];
   return MPN_OK;
@@ -74,9 +80,12 @@ extern "C" int mpn_stream_release(void *stream) {
     sc = it->second;
     mpn::g_registry.erase(it);
   }
-  MPN_CHECK_HIP(hipStreamSynchronize(s));
+  // ownership was taken above: free on every path (ADVICE r3 — an early return here leaked the Scratch and its buffers).  hipFree
+  // synchronises the device itself, so a failed stream sync only changes the status that is reported.
+  const hipError_t e = hipStreamSynchronize(s);
   sc->release();
   delete sc;
+  if (e != hipSuccess) { mpn::set_error("mpn_stream_release: hipStreamSynchronize: %s (scratch freed)", hipGetErrorString(e)); return MPN_EHIP; }
   return MPN_OK;
 }
 
@@ -86,15 +95,15 @@ extern "C" int mpn_release_all_scratch(void) {
     std::lock_guard<std::mutex> lk(mpn::g_reg_mu);
     taken.swap(mpn::g_registry);
   }
-  int cur = 0;
-  MPN_CHECK_HIP(hipGetDevice(&cur));
-  int rc = MPN_OK;
+  int cur = 0, rc = MPN_OK;
+  const bool have_cur = hipGetDevice(&cur) == hipSuccess;  // no early return once the registry was taken: everything is freed below
+  if (!have_cur) rc = MPN_EHIP;
   for (auto &kv : taken) {
     if (hipSetDevice(kv.first.first) != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = MPN_EHIP;
     kv.second->release();
     delete kv.second;
   }
-  (void)hipSetDevice(cur);
+  if (have_cur) (void)hipSetDevice(cur);
   if (rc) mpn::set_error("mpn_release_all_scratch: a device could not be synchronised");
   return rc;
 }

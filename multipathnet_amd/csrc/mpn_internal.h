@@ -57,6 +57,11 @@ struct ScratchScope {
   explicit ScratchScope(Scratch *sc);
   ~ScratchScope();
 };
+// Allocation generation: bumped whenever a library-owned buffer that kernels reference is REPLACED (scratch growth, a regrown
+// per-image table).  A captured launch graph (pipeline.hip) bakes device pointers into its kernel nodes, so it is only replayed while
+// the generation it was captured under is still current.
+unsigned long long alloc_generation();
+void bump_alloc_generation();
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): function attributes are per device.
 int set_max_dyn_lds(const void *fn, int bytes);
 

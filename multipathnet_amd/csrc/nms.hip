@@ -325,10 +325,14 @@ constexpr int kForever = 0x3fffffff;
 template <int WPL>  // 64-bit `removed` words per lane: covers m <= 4096 * WPL
 __global__ __launch_bounds__(64) void nms_scan_kernel(const float4 *__restrict__ sbox, const float *__restrict__ sscore,
                                                       const int *__restrict__ sidx, const int *__restrict__ n_sel,
-                                                      const int *__restrict__ flags, const int *__restrict__ counts, int m_stride, int w64,
+                                                      int *__restrict__ flags, const int *__restrict__ counts, int m_stride, int w64,
                                                       const unsigned long long *__restrict__ mask, float *__restrict__ keep,
                                                       int *__restrict__ keep_idx, int *__restrict__ n_keep, int m_cap,
-                                                      unsigned long long *__restrict__ trace) {
+                                                      unsigned long long *__restrict__ trace, int guard_limit) {
+  // guard_limit: bound of the replay's two progress loops (0 = 2 m_cap + slack, which a correct run cannot reach).  Should a loop ever
+  // run into its bound, the class is NOT emitted truncated: its flag becomes 2 and the exact IoU-sweep kernel, launched after this one,
+  // redoes it (tests force the path with a tiny limit).
+  bool failed = false;
   extern __shared__ __attribute__((aligned(16))) short lds16[];  // pos | occ | rnd | klist | mv, m_cap each   (flag 3)
   // tools/nms_trace.py (debug flavour): s_memtime stamps of class 0's chunks -> trace[c * 8 + k]
 #define NMS_STAMP(k) do { if (MPN_ABLATE(trace != nullptr) && blockIdx.x == 0 && lane == 0 && c < 64) trace[c * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -424,7 +428,9 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float4 *__restrict__
   };
   auto simulate = [&](int t1) {  // replay rounds sim_done + 1 .. t1 (all picked: klist / rnd hold them)
     int loaded = -64;  // the window in registers (death rounds are fixed for the duration of a call: every pending round is decided)
-    for (int guard = 0; sim_done < t1 && guard < 2 * m_cap + 1024; ++guard) {
+    const int glim = guard_limit > 0 ? guard_limit : 2 * m_cap + 1024;
+    for (int guard = 0; sim_done < t1; ++guard) {
+      if (guard >= glim) { failed = true; break; }
       __syncthreads();  // LDS writes of the previous batch / of the picks since the last call
       const int W0 = hp & ~63, p = hp - W0;
       if (W0 != loaded) { const int sl = W0 + lane; wf = sl < m ? (int)occ[sl] : -1; wd = death_of(wf); loaded = W0; }
@@ -472,6 +478,7 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float4 *__restrict__
   // the chunk's diagonal word, one row per lane, fetched a chunk ahead (its latency would otherwise sit in front of every chunk)
   unsigned long long diag_cur = (lane < n) ? mk[(size_t)lane * w64] : 0ull;
   for (int c = 0; c < nchunks; ++c) {
+    if (failed) break;
     const int base = c << 6;
     const unsigned long long diag = diag_cur;
     if (c + 1 < nchunks) diag_cur = (base + 64 + lane < n) ? mk[(size_t)(base + 64 + lane) * w64 + (c + 1)] : 0ull;
@@ -480,7 +487,9 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float4 *__restrict__
     // A chunk is resolved in passes: alive ranks below the first alive rank that carries a tie bit go through the tie-free
     // rule (bit arithmetic on the diagonal word, rows folded in a batch); a first alive rank WITH a tie bit is one pick by
     // the exact rule; repeat until the chunk is done.
-    for (int pass = 0; pass < 2 * m_cap + 130; ++pass) {  // (every pass picks a box or finishes the chunk; a run's picks may lie in LATER chunks)
+    const int plim = guard_limit > 0 ? guard_limit : 2 * m_cap + 130;
+    for (int pass = 0;; ++pass) {  // (every pass picks a box or finishes the chunk; a run's picks may lie in LATER chunks)
+      if (pass >= plim || failed) { failed = true; break; }
       const unsigned long long rem_c = word_of(c);
       unsigned long long alive_all = ~rem_c & valid;
       if (!alive_all) break;
@@ -619,6 +628,10 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float4 *__restrict__
       kept += __popcll(keptmask);
       if (limit == 64) break;
     }
+  }
+  if (failed) {  // a progress bound was hit: hand the class to the exact sweep (nms_wave_kernel checks flags[cls] == 2)
+    if (lane == 0) flags[cls] = 2;
+    return;
   }
   if (lane == 0) n_keep[cls] = kept;
   if (MPN_ABLATE(trace != nullptr) && blockIdx.x == 0 && lane == 0) {  // totals of class 0: [kernel cycles, cycles inside simulate(), simulate() calls, batches]
@@ -868,9 +881,11 @@ using namespace mpn;
 
 MPN_KNOB(int, g_nms_force_exact, 0);  // test hook: 1 = always the exact IoU-sweep kernel, 2 = always the tie (slot-emulation) kernel, 3 = always the replaying scan
 MPN_KNOB(unsigned long long *, g_nms_trace, nullptr);
+MPN_KNOB(int, g_nms_guard_limit, 0);  // test hook (mpn_debug_set_nms_guard_limit): bound of the replaying scan's progress loops (0 = the real one)
 #ifdef MPN_DEBUG_HOOKS
 extern "C" void mpn_debug_set_nms_force_exact(int v) { g_nms_force_exact = v; }
 extern "C" void mpn_debug_set_nms_trace(void *p) { g_nms_trace = static_cast<unsigned long long *>(p); }
+extern "C" void mpn_debug_set_nms_guard_limit(int v) { g_nms_guard_limit = v; }
 #endif
 
 extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n_cls, int m_stride, float thr,
@@ -952,10 +967,10 @@ extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n
       if (rc_attr) return rc_attr;
       if (w64 <= 64)
         hipLaunchKernelGGL(nms_scan_kernel<1>, dim3(n_cls), dim3(kWave), slds, st, sbox, sscore, sidx, n_sel, flags, d_counts, m_stride, w64, mask,
-                           d_keep, d_keep_idx, d_n_keep, scap, g_nms_trace);
+                           d_keep, d_keep_idx, d_n_keep, scap, g_nms_trace, g_nms_guard_limit);
       else
         hipLaunchKernelGGL(nms_scan_kernel<2>, dim3(n_cls), dim3(kWave), slds, st, sbox, sscore, sidx, n_sel, flags, d_counts, m_stride, w64, mask,
-                           d_keep, d_keep_idx, d_n_keep, scap, g_nms_trace);
+                           d_keep, d_keep_idx, d_n_keep, scap, g_nms_trace, g_nms_guard_limit);
       MPN_CHECK_LAUNCH();
     }
   }
@@ -973,6 +988,55 @@ __global__ void picks_to_one_based_kernel(int *__restrict__ pick, const int *__r
   if (i < min(*n_pick, m)) pick[i] += 1;
 }
 
+// ---- utils.nms_dense beyond the LDS sort (m > kSortMax): the reference function has no size limit -----------------------
+// Rank by counting: box i's position in (score descending, index ascending) order = the number of boxes whose 64-bit key — the one
+// nms_sort_kernel sorts — is smaller; keys are unique (they carry the index), so the ranks are a permutation.  O(m^2) key compares from
+// LDS tiles; exactly the order of the LDS bitonic sort.
+__global__ __launch_bounds__(256) void dense_rank_scatter_kernel(const float *__restrict__ scored, int m, float4 *__restrict__ sbox, int *__restrict__ sidx) {
+  __shared__ unsigned long long tile[1024];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  unsigned long long mine = ~0ull;
+  if (i < m) mine = ((unsigned long long)(~nms_f2key(scored[5 * (size_t)i + 4])) << 32) | (unsigned)i;
+  int rank = 0;
+  for (int j0 = 0; j0 < m; j0 += 1024) {
+    for (int t = threadIdx.x; t < 1024; t += 256) {
+      const int j = j0 + t;
+      tile[t] = j < m ? (((unsigned long long)(~nms_f2key(scored[5 * (size_t)j + 4])) << 32) | (unsigned)j) : ~0ull;
+    }
+    __syncthreads();
+    const int n = min(1024, m - j0);
+    for (int t = 0; t < n; ++t) rank += tile[t] < mine ? 1 : 0;
+    __syncthreads();
+  }
+  if (i < m) {
+    const float *r = scored + 5 * (size_t)i;
+    sbox[rank] = make_float4(r[0], r[1], r[2], r[3]);
+    sidx[rank] = i;
+  }
+}
+
+// The walk of utils.lua:416-460 itself on the sorted table, one block: rank i, if still alive, is picked and suppresses every later
+// alive rank whose dense overlap with it exceeds `overlap`.  One barrier per PICK (a dead rank writes nothing).  alive: m bytes, all 1.
+__global__ __launch_bounds__(1024) void nms_dense_sweep_kernel(const float4 *__restrict__ sbox, const int *__restrict__ sidx, int m, float overlap,
+                                                               unsigned char *__restrict__ alive, int *__restrict__ pick, int *__restrict__ n_pick) {
+  int np = 0;
+  for (int i = 0; i < m; ++i) {
+    if (!alive[i]) continue;  // uniform: written before the last barrier
+    const float4 c = sbox[i];
+    if (threadIdx.x == 0) pick[np] = sidx[i];
+    ++np;
+    for (int j = i + 1 + (int)threadIdx.x; j < m; j += 1024)
+      if (alive[j] && dense_suppresses(c, sbox[j], overlap)) alive[j] = 0;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *n_pick = np;
+}
+
+MPN_KNOB(int, g_nms_dense_sweep, 0);  // test hook (mpn_debug_set_nms_dense_sweep): 1 = always the counting-rank + sweep form
+#ifdef MPN_DEBUG_HOOKS
+extern "C" void mpn_debug_set_nms_dense_sweep(int v) { g_nms_dense_sweep = v; }
+#endif
+
 // utils.nms_dense (utils.lua:402-462; demo.lua:85): "another version of nms that returns indexes instead of new boxes" — sort by
 // score (descending), walk the sorted list, a picked box suppresses every box whose area-based IoU with it exceeds `overlap`.
 // The pick order is the SORT's (no swap history as in nms.c), so the sort / mask / chunked-scan kernels are reused with the dense
@@ -984,7 +1048,22 @@ extern "C" int mpn_nms_dense(const float *d_boxes, int m, float overlap, int *d_
   hipStream_t st = as_stream(stream);
   if (m == 0) { MPN_CHECK_HIP(hipMemsetAsync(d_n_pick, 0, sizeof(int), st)); return MPN_OK; }
   MPN_CHECK_ARG(d_boxes != nullptr && d_pick != nullptr);
-  if (m > kSortMax) { set_error("mpn_nms_dense: %d boxes exceed the %d this entry sorts in LDS", m, kSortMax); return MPN_EINVAL; }
+  if (m > kSortMax || g_nms_dense_sweep) {  // wider than the LDS sort: rank by counting, then the exact sequential walk (no size limit)
+    const size_t need_s = (size_t)m * (sizeof(float4) + sizeof(int) + 1) + 64;
+    void *ws_s = nullptr;
+    { int rc_ws = scratch_get(SCR_NMS, need_s, st, &ws_s); if (rc_ws) return rc_ws; }
+    float4 *sb = static_cast<float4 *>(ws_s);
+    int *si = reinterpret_cast<int *>(sb + m);
+    unsigned char *alive = reinterpret_cast<unsigned char *>(si + m);
+    MPN_CHECK_HIP(hipMemsetAsync(alive, 1, (size_t)m, st));
+    hipLaunchKernelGGL(dense_rank_scatter_kernel, dim3(cdiv(m, 256)), dim3(256), 0, st, d_boxes, m, sb, si);
+    MPN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nms_dense_sweep_kernel, dim3(1), dim3(1024), 0, st, sb, si, m, overlap, alive, d_pick, d_n_pick);
+    MPN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(picks_to_one_based_kernel, dim3(cdiv(m, 256)), dim3(256), 0, st, d_pick, d_n_pick, m);
+    MPN_CHECK_LAUNCH();
+    return MPN_OK;
+  }
   const int w64 = (m + 63) / 64;
   const size_t n_rows = (size_t)m;
   const size_t need = n_rows * (sizeof(float4) + sizeof(float) + sizeof(int) + 5 * sizeof(float)) + n_rows * w64 * sizeof(unsigned long long) +
@@ -1014,10 +1093,10 @@ extern "C" int mpn_nms_dense(const float *d_boxes, int m, float overlap, int *d_
   if (rc_attr) return rc_attr;
   if (w64 <= 64)
     hipLaunchKernelGGL(nms_scan_kernel<1>, dim3(1), dim3(kWave), slds, st, sbox, sscore, sidx, n_sel, flags, (const int *)nullptr, m, w64, mask, keep, d_pick,
-                       d_n_pick, scap, (unsigned long long *)nullptr);
+                       d_n_pick, scap, (unsigned long long *)nullptr, 0);
   else
     hipLaunchKernelGGL(nms_scan_kernel<2>, dim3(1), dim3(kWave), slds, st, sbox, sscore, sidx, n_sel, flags, (const int *)nullptr, m, w64, mask, keep, d_pick,
-                       d_n_pick, scap, (unsigned long long *)nullptr);
+                       d_n_pick, scap, (unsigned long long *)nullptr, 0);
   MPN_CHECK_LAUNCH();
   hipLaunchKernelGGL(picks_to_one_based_kernel, dim3(cdiv(m, 256)), dim3(256), 0, st, d_pick, d_n_pick, m);
   MPN_CHECK_LAUNCH();

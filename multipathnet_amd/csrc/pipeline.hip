@@ -8,7 +8,10 @@
 // allocated at create time.  The reference's 500-ROI chunking (ImageDetect.lua:116-124) is not
 // needed: all ROIs go through each GEMM at once (rows are independent, results identical), so the
 // fc weights stream from HBM once per image instead of twice.
+#include <cstdlib>
+#include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "dense.h"
@@ -284,6 +287,25 @@ struct mpn_frcnn {
   // proposal sharding (mpn_frcnn_test_one_sharded): this rank's row / class records and the gathered ones, grown on demand
   float *sh_buf[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t sh_bytes[4] = {0, 0, 0, 0};
+  // ---- captured launch graphs (round 4): the kernel chain of a SEGMENT of the per-image path — the head (transform .. decode, the
+  // iterative-localisation passes) or the tail (per-class NMS, voting, top-k) — is captured once per (pointers, shape) with
+  // hipStreamBeginCapture on the handle's capture stream and replayed with hipGraphLaunch on the caller's stream: one host call instead
+  // of 30-60 launches.  A segment is replayed only when (a) the previous execution of that segment kind on this handle had the same
+  // shape — the host-side state a real run leaves (cached-feature flags, sizes) is then exactly what it would be — (b) no library buffer
+  // was replaced since the capture (alloc_generation), (c) profiling is off.  Everything between the segments (cross-stream events,
+  // the select kernel, uploads) stays ordinary stream work, so the pipelined forms keep their overlap.
+  struct GraphKey {
+    int kind; const void *a, *b, *c, *d; int i0, i1, i2, i3;
+    bool operator<(const GraphKey &o) const {
+      return std::tie(kind, a, b, c, d, i0, i1, i2, i3) < std::tie(o.kind, o.a, o.b, o.c, o.d, o.i0, o.i1, o.i2, o.i3);
+    }
+  };
+  struct GraphEntry { hipGraphExec_t exec = nullptr; unsigned long long gen = 0; bool failed = false; int seen = 0; };
+  std::map<GraphKey, GraphEntry> graphs;
+  int graphs_on = 1;                 // mpn_frcnn_set_graphs / MPN_GRAPHS
+  hipStream_t cap_stream = nullptr;  // capture happens here (the caller's stream may be the legacy NULL stream, which cannot capture)
+  int seg_shape[4][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}, {-1, -1, -1, -1}, {-1, -1, -1, -1}};  // shape of the last execution per segment kind
+  long graph_replays = 0, graph_captures = 0;
   // optional per-kernel-group timing with HIP events recorded on the launch stream
   bool prof = false;
   std::vector<hipEvent_t> ev_pool;
@@ -340,6 +362,8 @@ static int dev_alloc(mpn_frcnn *p, T **ptr, size_t bytes, bool zero) {
 extern "C" void mpn_frcnn_destroy(mpn_frcnn *p) {
   if (!p) return;
   (void)hipDeviceSynchronize();
+  for (auto &kv : p->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+  if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   for (int i = 0; i < 2; ++i) { if (p->ev_head[i]) (void)hipEventDestroy(p->ev_head[i]); if (p->ev_tail[i]) (void)hipEventDestroy(p->ev_tail[i]); }
   if (p->side) (void)hipStreamDestroy(p->side);
@@ -373,6 +397,14 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
   MPN_CHECK_ARG(cfg->top_k > 0);
   mpn_frcnn *p = new mpn_frcnn();
   p->cfg = *cfg;
+  {  // captured launch graphs: on in the product library; off by default in the debug flavour, whose hooks change the dispatch between
+     // calls on one handle (a graph would replay the old choice); MPN_GRAPHS=0 / 1 overrides, mpn_frcnn_set_graphs sets it per handle
+#ifdef MPN_DEBUG_HOOKS
+    p->graphs_on = 0;
+#endif
+    const char *e = getenv("MPN_GRAPHS");
+    if (e && (e[0] == '0' || e[0] == '1')) p->graphs_on = e[0] == '1';
+  }
   if (hipGetDevice(&p->device) != hipSuccess) { delete p; set_error("mpn_frcnn_create: no current HIP device"); return MPN_EHIP; }
   p->scratch.device = p->device;
   ScratchScope scratch_scope(&p->scratch);
@@ -757,6 +789,7 @@ static int run_integral_heads(mpn_frcnn *p, const float *d_boxes, int N, int H, 
 static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const float *d_boxes, int N, hipStream_t s, int clamp = 1) {
   const mpn_frcnn_config &c = p->cfg;
   MPN_CHECK_ARG(p && d_boxes);
+  p->seg_shape[0][0] = -1;  // SEG_HEAD: the host-side state a captured head graph relies on is being rewritten (run_segment re-stamps it after its body)
   MPN_CHECK_ARG(H0 > 0 && W0 > 0 && N > 0 && N <= c.max_rois);
   // getImages (ImageDetect.lua:34-43): s = target/min side, capped so that round(s*max side) <= max_size; the image is
   // resampled to (long)(H*s) x (long)(W*s).  scale_target == 0 keeps the image as it is (s = 1).
@@ -780,6 +813,7 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const 
         MPN_CHECK_HIP(hipStreamSynchronize(s));
         if (need > p->scaled_bytes) { if (p->scaled) (void)hipFree(p->scaled); p->scaled = nullptr; p->scaled_bytes = 0; MPN_CHECK_HIP(hipMalloc(&p->scaled, need)); p->scaled_bytes = need; }
         if (need_t > p->scale_tmp_bytes) { if (p->scale_tmp) (void)hipFree(p->scale_tmp); p->scale_tmp = nullptr; p->scale_tmp_bytes = 0; MPN_CHECK_HIP(hipMalloc(&p->scale_tmp, need_t)); p->scale_tmp_bytes = need_t; }
+        bump_alloc_generation();
       }
       rc = mpn_image_scale(d_image, 3, H0, W0, H, W, p->scale_tmp, p->scaled, s);
       if (rc) return rc;
@@ -873,6 +907,58 @@ static void select_set(mpn_frcnn *p, int b) {
   p->voted = p->voted_b[b];
 }
 
+// ---- captured launch graphs (see mpn_frcnn::GraphKey) --------------------------------------------------------------------------
+enum { SEG_HEAD = 0, SEG_TAIL = 1, SEG_SHARD_NMS = 2, SEG_SHARD_FIN = 3 };
+constexpr size_t kMaxGraphs = 64;  // per handle: a caller that passes fresh pointers on every call must not grow the cache without bound
+
+// Runs body(stream) — a pure chain of stream work plus host-side bookkeeping — for segment `kind`, or replays its captured graph.
+// stable_ptrs: the key's pointers are library-owned (staging sets): capture at the first sighting; caller-provided pointers are captured
+// at their second sighting (a caller that hands in fresh buffers every call never pays for a capture).
+template <class F>
+static int run_segment(mpn_frcnn *p, int kind, const mpn_frcnn::GraphKey &key, const int (&shape)[4], bool stable_ptrs, hipStream_t s, F &&body) {
+  int *last = p->seg_shape[kind];
+  const bool same_shape = memcmp(last, shape, sizeof(shape)) == 0;
+  auto direct = [&]() -> int {
+    const int rc = body(s);
+    memcpy(last, shape, sizeof(shape));
+    if (rc) last[0] = -2;  // a failed run leaves no state to rely on
+    return rc;
+  };
+  if (!p->graphs_on || p->prof) return direct();
+  auto it = p->graphs.find(key);
+  if (it == p->graphs.end()) {
+    if (p->graphs.size() >= kMaxGraphs) return direct();
+    it = p->graphs.emplace(key, mpn_frcnn::GraphEntry()).first;
+  }
+  mpn_frcnn::GraphEntry &e = it->second;
+  if (e.exec && e.gen != alloc_generation()) { (void)hipGraphExecDestroy(e.exec); e.exec = nullptr; }  // a library buffer was replaced since
+  if (e.exec && same_shape) {
+    MPN_CHECK_HIP(hipGraphLaunch(e.exec, s));
+    ++p->graph_replays;
+    return MPN_OK;
+  }
+  ++e.seen;
+  if (!same_shape || e.failed || (!stable_ptrs && e.seen < 2)) return direct();  // the warm-up run for this shape / this key
+  if (!p->cap_stream && hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); e.failed = true; return direct(); }
+  if (hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); e.failed = true; return direct(); }
+  const int rc_body = body(p->cap_stream);  // host bookkeeping happens, the stream work is recorded instead of executed
+  hipGraph_t g = nullptr;
+  const hipError_t ec = hipStreamEndCapture(p->cap_stream, &g);
+  hipGraphExec_t ex = nullptr;
+  if (rc_body == MPN_OK && ec == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess && ex) {
+    (void)hipGraphDestroy(g);
+    e.exec = ex; e.gen = alloc_generation();
+    ++p->graph_captures;
+    memcpy(last, shape, sizeof(shape));
+    MPN_CHECK_HIP(hipGraphLaunch(e.exec, s));
+    return MPN_OK;
+  }
+  if (g) (void)hipGraphDestroy(g);
+  (void)hipGetLastError();
+  e.failed = true;     // this chain cannot be captured here: never try again, run it as ordinary launches
+  return direct();
+}
+
 // Tester_FRCNN.lua:106-125 + keep_top_k: per class j=1..C-1 select (score > thresh) -> NMS -> top-k, on stream `t`
 static int run_tail(mpn_frcnn *p, int N, float *d_dets, int top_cap, int *d_n_dets, hipStream_t sel_stream, hipStream_t t,
                     hipEvent_t after_select) {
@@ -888,18 +974,23 @@ static int run_tail(mpn_frcnn *p, int N, float *d_dets, int top_cap, int *d_n_de
     MPN_CHECK_HIP(hipEventRecord(after_select, sel_stream));
     MPN_CHECK_HIP(hipStreamWaitEvent(t, after_select, 0));
   }
-  { ProfScope ps(p, MPN_PROF_NMS, t);
-    rc = mpn_nms_batched(p->scored, p->counts, C - 1, N, c.nms_thresh, p->keep, p->keep_idx, p->n_keep, t); }
-  if (rc) return rc;
-  const float *final_tables = p->keep;
-  if (c.bbox_voting) {  // Tester_FRCNN.lua:118-124
-    rc = mpn_bbox_vote_batched(p->keep, p->n_keep, p->scored, p->counts, C - 1, N, c.bbox_vote_thresh,
-                               c.bbox_vote_score_pow != 0.0f ? c.bbox_vote_score_pow : 1.0f, p->voted, t);
-    if (rc) return rc;
-    final_tables = p->voted;
-  }
-  ProfScope ps(p, MPN_PROF_TOPK, t);
-  return mpn_keep_top_k(final_tables, p->n_keep, C - 1, N, c.top_k, p->thresh, d_dets, top_cap, d_n_dets, t);
+  const mpn_frcnn::GraphKey key{SEG_TAIL, d_dets, d_n_dets, p->scored, nullptr, N, top_cap, 0, 0};  // p->scored names the buffer set
+  const int shape[4] = {N, top_cap, c.bbox_voting ? 1 : 0, 0};
+  return run_segment(p, SEG_TAIL, key, shape, false, t, [&](hipStream_t q) -> int {
+    int r;
+    { ProfScope ps(p, MPN_PROF_NMS, q);
+      r = mpn_nms_batched(p->scored, p->counts, C - 1, N, c.nms_thresh, p->keep, p->keep_idx, p->n_keep, q); }
+    if (r) return r;
+    const float *final_tables = p->keep;
+    if (c.bbox_voting) {  // Tester_FRCNN.lua:118-124
+      r = mpn_bbox_vote_batched(p->keep, p->n_keep, p->scored, p->counts, C - 1, N, c.bbox_vote_thresh,
+                                c.bbox_vote_score_pow != 0.0f ? c.bbox_vote_score_pow : 1.0f, p->voted, q);
+      if (r) return r;
+      final_tables = p->voted;
+    }
+    ProfScope ps(p, MPN_PROF_TOPK, q);
+    return mpn_keep_top_k(final_tables, p->n_keep, C - 1, N, c.top_k, p->thresh, d_dets, top_cap, d_n_dets, q);
+  });
 }
 
 // Tester_FRCNN.lua:72-100: detect (clamped, :75-78); for i = 2..num_iter: SelectBoxes on the previous pass -> detect on the refined
@@ -927,6 +1018,26 @@ static int run_detect_iter(mpn_frcnn *p, const float *d_image, int H, int W, con
   return MPN_OK;
 }
 
+// the head segment: run_detect_iter as a captured graph when it starts from an image (the cached-features form keeps host-side
+// checks of what is cached and always runs as ordinary launches)
+static int run_head(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N, hipStream_t s, int *n_rows, bool stable_ptrs) {
+  if (!d_image || !d_boxes || N <= 0 || N > p->cfg.max_rois) {
+    const int rc = run_detect_iter(p, d_image, H, W, d_boxes, N, s, n_rows);
+    p->seg_shape[SEG_HEAD][0] = -1;
+    return rc;
+  }
+  const mpn_frcnn_config &c = p->cfg;
+  *n_rows = c.num_iter > 1 ? (c.use_rbox_scores ? c.num_iter - 1 : c.num_iter) * N : N;
+  const mpn_frcnn::GraphKey key{SEG_HEAD, d_image, d_boxes, nullptr, nullptr, H, W, N, 0};
+  const int shape[4] = {H, W, N, 1};
+  const int rc = run_segment(p, SEG_HEAD, key, shape, stable_ptrs, s, [&](hipStream_t q) -> int {
+    int rows = 0;
+    return run_detect_iter(p, d_image, H, W, d_boxes, N, q, &rows);
+  });
+  if (rc == MPN_OK) p->last_n = N;  // (a replay runs no host code)
+  return rc;
+}
+
 static int join_tail(mpn_frcnn *p, int b, hipStream_t s) {
   if (p->tail_pending[b]) {
     MPN_CHECK_HIP(hipStreamWaitEvent(s, p->ev_tail[b], 0));
@@ -951,7 +1062,7 @@ extern "C" int mpn_frcnn_test_one(mpn_frcnn *p, const float *d_image, int H, int
   int rc = mpn_frcnn_flush(p, stream);  // a pipelined predecessor may still own a buffer set
   if (rc) return rc;
   int rows = N;
-  rc = run_detect_iter(p, d_image, H, W, d_boxes, N, s, &rows);
+  rc = run_head(p, d_image, H, W, d_boxes, N, s, &rows, false);
   if (rc) return rc;
   select_set(p, 0);
   p->last_rows = rows;
@@ -1006,7 +1117,7 @@ extern "C" int mpn_frcnn_shard_head(mpn_frcnn *p, const float *d_image, int H, i
     return MPN_OK;
   }
   int rows = n_local;
-  rc = run_detect_iter(p, d_image, H, W, d_boxes + 4 * (size_t)lo, n_local, s, &rows);
+  rc = run_head(p, d_image, H, W, d_boxes + 4 * (size_t)lo, n_local, s, &rows, false);
   if (rc) return rc;
   const float *sc = c.num_iter > 1 ? p->it_scores : p->scores, *bb = c.num_iter > 1 ? p->it_bbox : p->bbox;
   hipLaunchKernelGGL(shard_pack_rows_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, sc, bb, n_local, P, C, chunk, d_rows_rec);
@@ -1025,32 +1136,38 @@ extern "C" int mpn_frcnn_shard_nms(mpn_frcnn *p, const float *d_rows_all, int N,
   // the whole image's joined tables, in the unsharded row order, where run_tail reads them
   float *sc = c.num_iter > 1 ? p->it_scores : p->scores, *bb = c.num_iter > 1 ? p->it_bbox : p->bbox;
   const size_t rec_floats = (size_t)P * chunk * 5 * C, total = (size_t)rows * 5 * C;
-  hipLaunchKernelGGL(shard_unpack_rows_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, d_rows_all, N, world, P, C, chunk, rec_floats, sc, bb);
-  MPN_CHECK_LAUNCH();
   select_set(p, 0);
   p->last_rows = rows;
   p->last_n = N;
-  { ProfScope ps(p, MPN_PROF_SELECT, s);
-    rc = mpn_select_scored(sc, bb, rows, C, 1, c.score_thresh, p->scored, p->counts, nullptr, s); }
-  if (rc) return rc;
+  p->seg_shape[SEG_HEAD][0] = -1;  // the joined tables of the WHOLE image replace this rank's own rows
   const int n_cls = C - 1, cmax = (n_cls + world - 1) / world;
   int c0, c1;
   shard_bounds(n_cls, world, rank, &c0, &c1);
-  if (c1 > c0) {
-    const size_t off = (size_t)c0 * rows;
-    { ProfScope ps(p, MPN_PROF_NMS, s);
-      rc = mpn_nms_batched(p->scored + off * 5, p->counts + c0, c1 - c0, rows, c.nms_thresh, p->keep + off * 5, p->keep_idx + off, p->n_keep + c0, s); }
-    if (rc) return rc;
-    if (c.bbox_voting) {
-      rc = mpn_bbox_vote_batched(p->keep + off * 5, p->n_keep + c0, p->scored + off * 5, p->counts + c0, c1 - c0, rows, c.bbox_vote_thresh,
-                                 c.bbox_vote_score_pow != 0.0f ? c.bbox_vote_score_pow : 1.0f, p->voted + off * 5, s);
-      if (rc) return rc;
+  const mpn_frcnn::GraphKey key{SEG_SHARD_NMS, d_rows_all, d_class_rec, nullptr, nullptr, N, rank, world, 0};
+  const int shape[4] = {N, rank, world, c.bbox_voting ? 1 : 0};
+  return run_segment(p, SEG_SHARD_NMS, key, shape, false, s, [&](hipStream_t q) -> int {
+    hipLaunchKernelGGL(shard_unpack_rows_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, q, d_rows_all, N, world, P, C, chunk, rec_floats, sc, bb);
+    MPN_CHECK_LAUNCH();
+    int r;
+    { ProfScope ps(p, MPN_PROF_SELECT, q);
+      r = mpn_select_scored(sc, bb, rows, C, 1, c.score_thresh, p->scored, p->counts, nullptr, q); }
+    if (r) return r;
+    if (c1 > c0) {
+      const size_t off = (size_t)c0 * rows;
+      { ProfScope ps(p, MPN_PROF_NMS, q);
+        r = mpn_nms_batched(p->scored + off * 5, p->counts + c0, c1 - c0, rows, c.nms_thresh, p->keep + off * 5, p->keep_idx + off, p->n_keep + c0, q); }
+      if (r) return r;
+      if (c.bbox_voting) {
+        r = mpn_bbox_vote_batched(p->keep + off * 5, p->n_keep + c0, p->scored + off * 5, p->counts + c0, c1 - c0, rows, c.bbox_vote_thresh,
+                                  c.bbox_vote_score_pow != 0.0f ? c.bbox_vote_score_pow : 1.0f, p->voted + off * 5, q);
+        if (r) return r;
+      }
     }
-  }
-  hipLaunchKernelGGL(shard_pack_classes_kernel, dim3(cdiv(rows, 256), cmax), dim3(256), 0, s, p->keep, p->keep_idx, p->n_keep,
-                     c.bbox_voting ? p->voted : nullptr, c0, c1, rows, cmax, d_class_rec);
-  MPN_CHECK_LAUNCH();
-  return MPN_OK;
+    hipLaunchKernelGGL(shard_pack_classes_kernel, dim3(cdiv(rows, 256), cmax), dim3(256), 0, q, p->keep, p->keep_idx, p->n_keep,
+                       c.bbox_voting ? p->voted : nullptr, c0, c1, rows, cmax, d_class_rec);
+    MPN_CHECK_LAUNCH();
+    return MPN_OK;
+  });
 }
 
 extern "C" int mpn_frcnn_shard_finish(mpn_frcnn *p, const float *d_class_all, int N, int world, float *d_dets, int top_cap, int *d_n_dets,
@@ -1063,11 +1180,15 @@ extern "C" int mpn_frcnn_shard_finish(mpn_frcnn *p, const float *d_class_all, in
   const int n_cls = c.n_classes - 1, cmax = (n_cls + world - 1) / world, rows = shard_passes(c) * N;
   select_set(p, 0);
   p->last_rows = rows;
-  hipLaunchKernelGGL(shard_unpack_classes_kernel, dim3(cdiv(rows, 256), n_cls), dim3(256), 0, s, d_class_all, n_cls, world, rows, cmax,
-                     shard_class_rec_floats(cmax, rows, c.bbox_voting), p->keep, p->keep_idx, p->n_keep, c.bbox_voting ? p->voted : nullptr);
-  MPN_CHECK_LAUNCH();
-  ProfScope ps(p, MPN_PROF_TOPK, s);
-  return mpn_keep_top_k(c.bbox_voting ? p->voted : p->keep, p->n_keep, n_cls, rows, c.top_k, p->thresh, d_dets, top_cap, d_n_dets, s);
+  const mpn_frcnn::GraphKey key{SEG_SHARD_FIN, d_class_all, d_dets, d_n_dets, nullptr, N, world, top_cap, 0};
+  const int shape[4] = {N, world, top_cap, c.bbox_voting ? 1 : 0};
+  return run_segment(p, SEG_SHARD_FIN, key, shape, false, s, [&](hipStream_t q) -> int {
+    hipLaunchKernelGGL(shard_unpack_classes_kernel, dim3(cdiv(rows, 256), n_cls), dim3(256), 0, q, d_class_all, n_cls, world, rows, cmax,
+                       shard_class_rec_floats(cmax, rows, c.bbox_voting), p->keep, p->keep_idx, p->n_keep, c.bbox_voting ? p->voted : nullptr);
+    MPN_CHECK_LAUNCH();
+    ProfScope ps(p, MPN_PROF_TOPK, q);
+    return mpn_keep_top_k(c.bbox_voting ? p->voted : p->keep, p->n_keep, n_cls, rows, c.top_k, p->thresh, d_dets, top_cap, d_n_dets, q);
+  });
 }
 
 static int shard_buf(mpn_frcnn *p, int i, size_t floats, hipStream_t s) {
@@ -1078,6 +1199,7 @@ static int shard_buf(mpn_frcnn *p, int i, size_t floats, hipStream_t s) {
   p->sh_buf[i] = nullptr; p->sh_bytes[i] = 0;
   MPN_CHECK_HIP(hipMalloc(&p->sh_buf[i], need));
   p->sh_bytes[i] = need;
+  bump_alloc_generation();
   return MPN_OK;
 }
 
@@ -1105,8 +1227,8 @@ extern "C" int mpn_frcnn_test_one_sharded(mpn_frcnn *p, mpn_comm *comm, const fl
 // image i on `stream`; NMS + top-k of image i on the pipeline's high-priority side stream, overlapping image
 // i+1's MFMA kernels (they are latency-bound on ~20 CUs).  d_dets / d_n_dets of call i are ordered on `stream`
 // only after call i+1 returns or after mpn_frcnn_flush(); the caller alternates two output buffers.
-extern "C" int mpn_frcnn_test_one_pipelined(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N,
-                                            float *d_dets, int top_cap, int *d_n_dets, void *stream) {
+static int pipelined_impl(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N, float *d_dets, int top_cap, int *d_n_dets,
+                          void *stream, bool stable_ptrs) {
   MPN_CHECK_ARG(p != nullptr && d_n_dets && (top_cap == 0 || d_dets) && top_cap >= 0);
   ScratchScope scratch_scope(&p->scratch);
   hipStream_t s = as_stream(stream);
@@ -1114,7 +1236,7 @@ extern "C" int mpn_frcnn_test_one_pipelined(mpn_frcnn *p, const float *d_image, 
   int rc = join_tail(p, b, s);  // buffer set b was last used two calls ago
   if (rc) return rc;
   int rows = N;
-  rc = run_detect_iter(p, d_image, H, W, d_boxes, N, s, &rows);
+  rc = run_head(p, d_image, H, W, d_boxes, N, s, &rows, stable_ptrs);
   if (rc) return rc;
   select_set(p, b);
   p->last_rows = rows;
@@ -1125,6 +1247,11 @@ extern "C" int mpn_frcnn_test_one_pipelined(mpn_frcnn *p, const float *d_image, 
   rc = join_tail(p, b ^ 1, s);  // the previous image's detections become visible to `stream` here
   p->seq++;
   return rc;
+}
+
+extern "C" int mpn_frcnn_test_one_pipelined(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N,
+                                            float *d_dets, int top_cap, int *d_n_dets, void *stream) {
+  return pipelined_impl(p, d_image, H, W, d_boxes, N, d_dets, top_cap, d_n_dets, stream, false);
 }
 
 // Host-fed throughput form: the reference's loop hands testOne a CPU image and CPU boxes (Tester_FRCNN.lua:64-66) and
@@ -1156,6 +1283,7 @@ extern "C" int mpn_frcnn_test_one_pipelined_host(mpn_frcnn *p, const float *h_im
     if (cap < img_n) cap = img_n;
     MPN_CHECK_HIP(hipMalloc(&p->stage_img[b], cap * sizeof(float)));
     p->stage_cap[b] = cap;
+    bump_alloc_generation();
   }
   // The staging set is free once the image that used it (three calls ago) has been consumed.  Waited for on the HOST, not with
   // hipStreamWaitEvent on the copy stream: a copy that depends on a compute-queue event leaves the SDMA path (measured on AlexNet,
@@ -1166,7 +1294,7 @@ extern "C" int mpn_frcnn_test_one_pipelined_host(mpn_frcnn *p, const float *h_im
   MPN_CHECK_HIP(hipMemcpyAsync(p->stage_boxes[b], h_boxes, (size_t)N * 4 * sizeof(float), hipMemcpyHostToDevice, p->copy));
   MPN_CHECK_HIP(hipEventRecord(p->ev_up[b], p->copy));
   MPN_CHECK_HIP(hipStreamWaitEvent(s, p->ev_up[b], 0));
-  int rc = mpn_frcnn_test_one_pipelined(p, p->stage_img[b], H, W, p->stage_boxes[b], N, d_dets, top_cap, d_n_dets, stream);
+  int rc = pipelined_impl(p, p->stage_img[b], H, W, p->stage_boxes[b], N, d_dets, top_cap, d_n_dets, stream, true);  // staging sets: stable pointers
   if (rc) return rc;
   // the image is consumed by the trunk's first kernel and the boxes by the decode kernel: both are behind this point of `stream`
   MPN_CHECK_HIP(hipEventRecord(p->ev_consumed[b], s));
@@ -1199,6 +1327,19 @@ extern "C" int mpn_graph_create(const mpn_frcnn_config *cfg, const mpn_graph_wei
                                 const float *d_bbox_w, const float *d_bbox_b, mpn_frcnn **out) {
   MPN_CHECK_ARG(gw != nullptr);
   return create_impl(cfg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_cls_w, d_cls_b, d_bbox_w, d_bbox_b, nullptr, out, nullptr, gw);
+}
+
+extern "C" int mpn_frcnn_set_graphs(mpn_frcnn *p, int enable) {
+  MPN_CHECK_ARG(p != nullptr);
+  p->graphs_on = enable ? 1 : 0;
+  return MPN_OK;
+}
+
+extern "C" int mpn_frcnn_graph_stats(const mpn_frcnn *p, long *captures, long *replays) {
+  MPN_CHECK_ARG(p != nullptr);
+  if (captures) *captures = p->graph_captures;
+  if (replays) *replays = p->graph_replays;
+  return MPN_OK;
 }
 
 extern "C" int mpn_frcnn_set_profiling(mpn_frcnn *p, int enable) {

@@ -1686,6 +1686,19 @@ static int rn_alloc(ResNetGraph *g, float **p, size_t bytes) {
   return MPN_OK;
 }
 
+// a buffer that grows with the image size (outside the steady state): the old block is released (hipFree waits for the device, so
+// kernels still reading it have finished) instead of staying on g->allocs until the handle dies
+static int rn_regrow(ResNetGraph *g, float **p, size_t bytes) {
+  if (*p) {
+    auto it = std::find(g->allocs.begin(), g->allocs.end(), static_cast<void *>(*p));
+    if (it != g->allocs.end()) g->allocs.erase(it);
+    MPN_CHECK_HIP(hipFree(*p));
+    *p = nullptr;
+    bump_alloc_generation();  // captured launch graphs (pipeline.hip) hold the old pointer
+  }
+  return rn_alloc(g, p, bytes);
+}
+
 MPN_KNOB(int, g_graph_fuse, 511);  // mpn_debug_set_graph_fuse: bit 0 = fuse sibling pointwise convolutions, bit 1 = commute average-pool -> pointwise convolution, bit 2 = max-pools of the ROI-pooled input computed from the feature map, bit 3 = fully-connected head layers (whole-map / 1x1-map convolutions) on the tuned GEMM, bit 4 = the image layer (Cin = 3) as a GEMM over im2col rows, bit 5 = trunk 3x3 / stride-1 convolutions on dense.hip's Winograd kernel, bit 6 = the fused ROI max-pool (bit 2) reads vertical range-max tables of the map, bit 7 = ResNet heads' 3x3 / stride-1 convolutions on the Winograd kernel (mosaic image of the per-ROI maps), bit 8 = the fully-connected operand pooled by dense.hip's pixel-major kernel; 0 = run the op list as given
 static int rn_pack(ResNetGraph *g, RnConv &c, const float *d_w, const float *d_b) {
   if (g->bf16) {
@@ -1755,7 +1768,9 @@ MPN_KNOB(int, g_bf16_split_target, 256);  // split-K (both dtypes) aims at this 
 MPN_KNOB(int, g_bf16_dma_tn, 0);  // 0 = pick per layer; 128 / 256 = force 256 couts x that many pixels, 1256 = 128 couts x 256 pixels (mpn_debug_set_bf16_dma_tn)
 MPN_KNOB(int, g_bf16_dma, 1);  // mpn_debug_set_bf16_dma: 0 = never, 1 = large layers, 2 = every eligible layer (tests)
 MPN_KNOB(int, g_bf16_exp, 0);   // mpn_debug_set_bf16_exp: GConvArgsB::exp (scheduling experiments of the LDS-DMA kernel)
-MPN_KNOB(int, g_bf16_nch, 4);   // mpn_debug_set_bf16_nch: 8 = 64-channel stages where Cin % 64 == 0 (one block per CU)
+#ifdef MPN_DEBUG_HOOKS
+MPN_KNOB(int, g_bf16_nch, 4);   // mpn_debug_set_bf16_nch: 8 = 64-channel stages where Cin % 64 == 0 (one block per CU; measured slower, debug flavour only)
+#endif
 MPN_KNOB(int, g_roi_invariant, 1);  // mpn_debug_set_roi_invariant: 0 = per-ROI layers pick kernel / split by batch size as round 3 did (tests, timing)
 // per_roi: the batch axis counts ROIs (the head of a graph model).  A ROI's result must not depend on which other ROIs share the
 // launch (memoryEfficientForward's chunked == full, ImageDetect.lua:126-133; the ROI-sharded mode == the unsharded one), so for
@@ -2551,8 +2566,9 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
     if (g->bf16 && (g_bf16_fast_pool & 1) && Cb % 4 == 0) {
       const size_t need = (size_t)Cb * fa.pitch() * 8;
       if (g->feat_sorted_elems < need) {  // first use (or a larger image than any before): outside the steady state
-        float *q = nullptr;
-        int rc = rn_alloc(g, &q, need * sizeof(bf16_t));
+        float *q = reinterpret_cast<float *>(g->feat_sorted);
+        g->feat_sorted = nullptr; g->feat_sorted_elems = 0;
+        int rc = rn_regrow(g, &q, need * sizeof(bf16_t));
         if (rc) return rc;
         g->feat_sorted = reinterpret_cast<bf16_t *>(q); g->feat_sorted_elems = need; g->feat_sorted_valid = false;
       }
@@ -2560,8 +2576,9 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
       if (fuse_mp) for (const GOp &op : g->g_heads[head]) any_mp = any_mp || op.from_rois;
       const int want_levels = (any_mp && (g_graph_fuse & 64) && g->feat_h > 1) ? 31 - __builtin_clz((unsigned)g->feat_h) : 0;
       if (want_levels > 0 && (g->feat_vmax_elems < need || g->feat_vmax_levels < want_levels)) {  // outside the steady state, as above
-        float *q = nullptr;
-        int rc = rn_alloc(g, &q, need * sizeof(bf16_t) * want_levels);
+        float *q = reinterpret_cast<float *>(g->feat_vmax);
+        g->feat_vmax = nullptr; g->feat_vmax_elems = 0; g->feat_vmax_levels = 0;
+        int rc = rn_regrow(g, &q, need * sizeof(bf16_t) * want_levels);
         if (rc) return rc;
         g->feat_vmax = reinterpret_cast<bf16_t *>(q); g->feat_vmax_elems = need; g->feat_vmax_levels = want_levels; g->feat_vmax_valid = false;
       }

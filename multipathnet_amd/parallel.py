@@ -56,6 +56,11 @@ class Comm(object):
         _lib.check(lib.mpn_comm_init_rank(idbuf if world > 1 else None, world, rank, C.byref(h)), "mpn_comm_init_rank")
         return cls(h, world, rank, lib)
 
+    @property
+    def rccl_ranks(self):
+        """the rank count RCCL itself reports for this communicator (ncclCommCount); 0 = no RCCL communicator (world 1 without an id)"""
+        return int(self._lib.mpn_comm_rccl_ranks(self._h)) if self._h is not None and self._h.value else 0
+
     def record_floats(self, top_cap):
         return int(self._lib.mpn_det_record_floats(int(top_cap)))
 

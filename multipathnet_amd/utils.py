@@ -41,7 +41,8 @@ def nms_with_index(boxes, overlap):
 
 def nms_dense(boxes, overlap):
     """utils.nms_dense(boxes [M,5], overlap) (utils.lua:402-462) -> LongTensor of picked row indices, 1-BASED like the Lua
-    function's (subtract 1 to index a torch tensor), in pick order."""
+    function's (subtract 1 to index a torch tensor), in pick order.  Any table width (beyond 8192 rows: a counting-rank + sequential-walk
+    form).  Order among bit-equal scores: ascending index; NaN scores sort last (TH's quicksort order is unpinned, TH absent)."""
     M = boxes.size(0) if boxes.numel() else 0
     if M == 0:
         return torch.empty(0, dtype=torch.int64, device=boxes.device)

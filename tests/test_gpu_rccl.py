@@ -167,6 +167,63 @@ def test_bench_two_ranks_on_one_gpu_share_mode(dev):
     assert "MPN_BENCH_SHARE_GPU=1" in out["config"]["parallelism"] and "NOT a multi-GPU measurement" in out["config"]["parallelism"]
     assert out["value"] > 0 and abs(out["value"] - 2 * 1000 * 4 / (out["ms_per_step"] * 4e-3)) < 1e-3 * out["value"]
     assert out["roofline"]["frac"] <= 1.0
+    assert out["ranks"]["rccl_ranks"] == 0 and len(out["ranks"]["per_rank_proposals_per_s"]["all"]) == 2
+    assert out["sustained"]["steps"] >= 800 and out["sustained"]["seconds"] >= 2.0   # the steady-state leg runs under two ranks too
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_fallback_group_branch(dev):
+    """bench.py's fallback — a torch.distributed group for the record gather when the C-ABI communicator does not come
+    up — had never executed.  MPN_BENCH_FORCE_COMM_FAIL=1 sends every rank down that branch (the ranks agree on it through the MIN
+    all-reduce, the group is created, the gather runs through torch.distributed); on a one-GPU box the group is gloo (RCCL refuses two
+    ranks on one device), on a multi-GPU node the same branch creates the RCCL group.  The line says which ran, carries the per-rank
+    rates and rccl_ranks = 0."""
+    out = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--sustained-seconds", "0"],
+                     {"MPN_BENCH_SHARE_GPU": "1", "MPN_BENCH_FORCE_COMM_FAIL": "1"})
+    par = out["config"]["parallelism"]
+    assert "fallback group" in par and "MPN_BENCH_FORCE_COMM_FAIL=1" in par and "NOT a multi-GPU measurement" in par
+    assert out["ranks"]["rccl_ranks"] == 0 and len(out["ranks"]["per_rank_proposals_per_s"]["all"]) == 2
+    assert out["ranks"]["per_rank_proposals_per_s"]["min"] * 2 <= out["value"] * 1.001  # the job's rate is bounded by its slowest rank
+    assert out["sustained"] is None
+
+
+def test_comm_reports_what_rccl_built(dev):
+    """mpn_comm_rccl_ranks: ncclCommCount of the communicator (cross-checked against the caller's world / rank at init); 0 without RCCL"""
+    from multipathnet_amd import parallel
+    c0, c1 = parallel.Comm.single(use_rccl=False), parallel.Comm.single(use_rccl=True)
+    try:
+        assert c0.rccl_ranks == 0 and c1.rccl_ranks == 1
+    finally:
+        c0.close(); c1.close()
+
+
+@pytest.mark.timeout(300)
+def test_comm_init_is_bounded_in_time(dev):
+    """a peer that never arrives must not hang the caller (and the GPU lease): ncclCommInitRank runs on a helper thread and
+    mpn_comm_init_rank gives up after MPN_COMM_INIT_TIMEOUT_S with MPN_ENCCL and a message.  Run in a child process: the abandoned
+    helper thread stays blocked inside RCCL until the process exits."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import ctypes as C, sys, time; sys.path.insert(0, %r)\n"
+            "import torch, multipathnet_amd\n"
+            "torch.cuda.set_device(0); lib = multipathnet_amd.load()\n"
+            "idb = (C.c_char * 128)(); assert lib.mpn_comm_get_unique_id(idb) == 0\n"
+            "h = C.c_void_p(); t0 = time.time()\n"
+            "rc = lib.mpn_comm_init_rank(idb, 2, 0, C.byref(h))   # rank 1 never comes\n"
+            "lib.mpn_last_error.restype = C.c_char_p\n"
+            "print('RC', rc, round(time.time() - t0, 1), lib.mpn_last_error().decode()); sys.stdout.flush()\n"
+            "import os; os._exit(0)\n") % root
+    env = dict(os.environ, MPN_COMM_INIT_TIMEOUT_S="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    out = r.stdout.decode()
+    line = [ln for ln in out.splitlines() if ln.startswith("RC ")]
+    assert line, (out[-1000:], r.stderr.decode()[-1000:])
+    _, rc, secs, msg = line[0].split(" ", 3)
+    assert int(rc) != 0 and 3.0 <= float(secs) <= 60.0 and "did not return within 4 s" in msg
+    assert time.time() - t0 < 200
 
 
 @pytest.mark.timeout(900)
@@ -177,3 +234,4 @@ def test_bench_latency_mode_single_rank(dev):
     assert "latency" in out["metric"] and "not the headline" in out["metric"] and out["higher_is_better"] is False and out["scaling"] == "strong"
     assert out["unit"] == "ms/image" and 0 < out["value"] < 50 and out["unsharded_ms"] > 0
     assert out["projected"]["world"] == 8 and 0 < out["projected"]["rank0_compute_ms"] < out["value"]
+    assert out["ranks"]["final_detections_identical_on_all_ranks"] is True and out["ranks"]["n_detections"] > 0
