@@ -471,8 +471,10 @@ int mpn_frcnn_test_one_sharded(mpn_frcnn *p, mpn_comm *comm, const float *d_imag
  * call per segment instead of 30-60 kernel launches (Tester_FRCNN.lua:54-139 calls testOne in a loop over same-sized inputs).  Results are
  * bit-identical to the ordinary launches.  Caller-provided buffers are captured at their second sighting, so a host that passes the
  * same device buffers every image gets the replays and one that allocates fresh ones never pays for a capture; a graph is dropped when a
- * library buffer it references is replaced.  On by default (MPN_GRAPHS=0 in the environment, or enable = 0 here, turns it off);
- * profiling (mpn_frcnn_set_profiling) suspends it. */
+ * library buffer it references is replaced.  OFF by default — opt in with enable = 1 here or MPN_GRAPHS=1 in the environment: measured
+ * on MI355X the host's enqueue time per image drops 6.5x (AlexNet 484 -> 74 us) while the device-side timeline, and so the proposals/s
+ * of a device-bound loop, does not improve (-0.5 %): it frees the host thread, it does not speed up the GPU.  Profiling
+ * (mpn_frcnn_set_profiling) suspends it. */
 int mpn_frcnn_set_graphs(mpn_frcnn *p, int enable);
 int mpn_frcnn_graph_stats(const mpn_frcnn *p, long *captures, long *replays);
 

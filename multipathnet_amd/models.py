@@ -757,6 +757,16 @@ class FastRCNN(object):
         hip.hipMemcpy(C.c_void_p(n.data_ptr()), np_, C.c_size_t(n.numel() * 4), 3)
         return keep, idx, n
 
+    def set_graphs(self, on):
+        """captured launch graphs (mpn_frcnn_set_graphs): replay the per-image kernel chains with hipGraphLaunch (default on)"""
+        check(self._lib.mpn_frcnn_set_graphs(self._h, int(bool(on))), "set_graphs")
+
+    def graph_stats(self):
+        """(captures, replays) of this handle's launch graphs"""
+        c, r = C.c_long(), C.c_long()
+        check(self._lib.mpn_frcnn_graph_stats(self._h, C.byref(c), C.byref(r)), "graph_stats")
+        return int(c.value), int(r.value)
+
     PROF_TAGS = ["transform", "conv_wino", "conv_direct", "pool", "roi_pool", "fc6", "fc7", "heads", "post", "select", "nms", "topk"]
 
     def set_profiling(self, on):

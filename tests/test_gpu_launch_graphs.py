@@ -1,0 +1,191 @@
+"""Captured launch graphs (include/mpn.h mpn_frcnn_set_graphs; pipeline.hip run_segment): the per-image kernel chains replayed with
+hipGraphLaunch must give the records the ordinary launches give, BIT FOR BIT, through every way the host can interleave calls —
+repeats, changing shapes and buffers, cached-feature detects in between, the pipelined host-fed form, the sharded steps, towers whose
+pooling forks onto a second stream, bf16 graph models.  The loop the reference runs is Tester:test -> testOne per image
+(Tester_FRCNN.lua:54-139,150-157)."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_pipeline import SMALL, _boxes
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(**kw):
+    from multipathnet_amd import models
+    s = SMALL
+    P = models.synthetic_params(s["cfg"], pooled=7, fc_dim=s["fc"], n_classes=s["C"], seed=557)
+    return models.FastRCNN(P, cfg=s["cfg"], pooled=7, spatial_scale=s["scale"], max_h=s["H"], max_w=s["W"], max_rois=s["N"], **kw)
+
+
+def _on(net):
+    net.set_graphs(True)   # opt-in (off by default: a host-CPU saving, not a device speed-up)
+    return net
+
+
+def _run(net, im, bx):
+    d, n = net.test_one_async(im, bx)
+    torch.cuda.synchronize()
+    return d[: int(n.item())].clone()
+
+
+def test_replayed_records_equal_ordinary_launches_through_interleavings(dev):
+    s = SMALL
+    rng = np.random.default_rng(3)
+    ims = [torch.from_numpy(rng.random((3, s["H"], s["W"]), dtype=np.float32)).to(dev), torch.from_numpy(rng.random((3, s["H"] - 11, s["W"] - 20), dtype=np.float32)).to(dev)]
+    bxs = [torch.from_numpy(_boxes(np.random.default_rng(5), 200, s["W"], s["H"])).to(dev),
+           torch.from_numpy(_boxes(np.random.default_rng(6), 77, s["W"] - 20, s["H"] - 11)).to(dev)]
+    ref_net = _net()
+    ref_net.set_graphs(False)
+    net = _on(_net())
+    assert net.graph_stats() == (0, 0)
+    ref = [_run(ref_net, ims[i], bxs[i]) for i in range(2)]
+    assert ref_net.graph_stats() == (0, 0)
+    # A A A A B B B A B A A : captures at the second sighting of each key, replays afterwards, a shape change in between runs ordinary launches
+    for step, i in enumerate([0, 0, 0, 0, 1, 1, 1, 0, 1, 0, 0]):
+        assert torch.equal(_run(net, ims[i], bxs[i]), ref[i]), step
+    cap, rep = net.graph_stats()
+    assert cap >= 4 and rep >= 4          # head + tail for both shapes; several replays
+    # a cached-features detect on other boxes between two replays (rewrites the head's host-side state): the next test_one is still right
+    _run(ref_net, ims[0], bxs[0])
+    sc, bb = net.detect(ims[0], bxs[0][:50].contiguous(), recompute_features=False)
+    sc_r, bb_r = ref_net.detect(ims[0], bxs[0][:50].contiguous(), recompute_features=False)
+    assert torch.equal(sc, sc_r) and torch.equal(bb, bb_r)
+    for _ in range(3):
+        assert torch.equal(_run(net, ims[0], bxs[0]), ref[0])
+    # contents change, pointers do not: the graph reads the buffers, not a snapshot
+    ims[0].mul_(0.5)
+    want = _run(ref_net, ims[0], bxs[0])
+    assert not torch.equal(want, ref[0]) and torch.equal(_run(net, ims[0], bxs[0]), want)
+    # profiling suspends the replays and the numbers still agree
+    net.set_profiling(True)
+    assert torch.equal(_run(net, ims[0], bxs[0]), want)
+    net.set_profiling(False)
+    assert torch.equal(_run(net, ims[0], bxs[0]), want)
+
+
+@pytest.mark.parametrize("kind", ["iter2vote", "mpnet", "resnet_bf16", "alexnet"])
+def test_replays_on_the_other_pipelines(dev, kind):
+    """iterative localisation + voting (device-to-device copies and the voting kernel inside the graph), MultiPathNet (the towers' pooling
+    forks onto the handle's pooling stream inside the capture), a bf16 ResNet and the op-list AlexNet"""
+    from multipathnet_amd import models
+    rng = np.random.default_rng(11)
+    if kind == "iter2vote":
+        s = SMALL
+        H, W, N = s["H"], s["W"], 150
+        mk = lambda: _net(num_iter=2, bbox_voting=True, bbox_vote_thresh=0.5, bbox_vote_score_pow=0.5)
+    elif kind == "mpnet":
+        cfg = [8, 16, "P", 16, 24, "P", 32, 32, "P", 64, "P", 64]
+        H, W, N = 150, 250, 117
+        P = models.synthetic_mpnet_params(cfg, pooled=7, fc_dim=128, n_classes=9, n_integral=3, seed=11)
+        mk = lambda: models.MultiPathNet(P, cfg=cfg, pooled=7, spatial_scale=1 / 16, max_h=H, max_w=W, max_rois=N)
+    elif kind == "resnet_bf16":
+        H, W, N = 120, 160, 50
+        R = models.synthetic_resnet_params(depth=0, n_classes=5, base_width=8, blocks=[1, 1, 1, 2], block_type="bottleneck", seed=3)
+        mk = lambda: models.ResNetFRCNN(R, max_h=H, max_w=W, max_rois=64, top_k=10, bf16=True)
+    else:
+        H, W, N = 160, 208, 40
+        G = models.synthetic_alexnet_params(n_classes=6, seed=5, width=0.25, fc_dim=256)
+        mk = lambda: models.AlexNetFRCNN(G, max_h=H, max_w=W, max_rois=64, top_k=10)
+    im = torch.from_numpy(rng.random((3, H, W), dtype=np.float32)).to(dev)
+    bx = torch.from_numpy(_boxes(rng, N, W, H, lo=12)).to(dev)
+    ref_net, net = mk(), _on(mk())
+    ref_net.set_graphs(False)
+    ref = _run(ref_net, im, bx)
+    assert ref.shape[0] > 0
+    for _ in range(5):
+        assert torch.equal(_run(net, im, bx), ref)
+    cap, rep = net.graph_stats()
+    assert cap >= 2 and rep >= 4
+    keep_r, kidx_r, nk_r = ref_net.nms_results()
+    keep, kidx, nk = net.nms_results()
+    assert torch.equal(nk, nk_r)
+    for c in range(nk.numel()):
+        k = int(nk[c])
+        assert torch.equal(keep[c, :k], keep_r[c, :k]) and torch.equal(kidx[c, :k], kidx_r[c, :k])
+
+
+def test_sharded_steps_replay(dev):
+    """mpn_frcnn_shard_head / _shard_nms / _shard_finish as graphs.  A rank's handle sees ONE (rank, world) — that is the steady state the
+    replays are for — so: all ranks' records once (emulated on a second handle), then rank 1's three steps for six rounds on its own
+    handle, writing its records in place: detections equal the unsharded ones every round, and from the third round on the steps are replays."""
+    s = SMALL
+    rng = np.random.default_rng(8)
+    im = torch.from_numpy(rng.random((3, s["H"], s["W"]), dtype=np.float32)).to(dev)
+    bx = torch.from_numpy(_boxes(rng, 200, s["W"], s["H"])).to(dev)
+    ref_net, net = _net(), _on(_net())
+    ref_net.set_graphs(False)
+    ref = _run(ref_net, im, bx)
+    world = 3
+    rr, cr = net.shard_record_floats(200, world)
+    rows_all = torch.empty((world, rr), dtype=torch.float32, device=dev)
+    class_all = torch.empty((world, cr), dtype=torch.float32, device=dev)
+    for r in range(world):
+        ref_net.shard_head(im, bx, r, world, out=rows_all[r])
+    for r in range(world):
+        ref_net.shard_nms(rows_all, 200, r, world, out=class_all[r])
+    for rnd in range(6):
+        rows_all[1].zero_(); class_all[1].zero_()      # rank 1's records are recomputed in place every round
+        net.shard_head(im, bx, 1, world, out=rows_all[1])
+        net.shard_nms(rows_all, 200, 1, world, out=class_all[1])
+        d, n = net.shard_finish(class_all, 200, world)
+        torch.cuda.synchronize()
+        assert torch.equal(d[: int(n.item())], ref), rnd
+    cap, rep = net.graph_stats()
+    assert cap >= 3 and rep >= 9
+
+
+def test_fresh_buffers_every_call_never_capture(dev):
+    """a host that allocates new device buffers for every image gets ordinary launches (no capture cost, a bounded cache)"""
+    s = SMALL
+    rng = np.random.default_rng(9)
+    net = _on(_net())
+    im0 = rng.random((3, s["H"], s["W"]), dtype=np.float32)
+    bx0 = _boxes(rng, 100, s["W"], s["H"])
+    keepalive, ref = [], None
+    for _ in range(80):
+        im, bx = torch.from_numpy(im0).to(dev), torch.from_numpy(bx0).to(dev)
+        keepalive += [im, bx]          # distinct addresses
+        out = _run(net, im, bx)
+        ref = out if ref is None else ref
+        assert torch.equal(out, ref)
+    cap, _ = net.graph_stats()
+    assert cap <= 2                     # only the tail (the handle's own output buffers repeat); never the head
+
+
+def test_pipelined_host_fed_form_replays(dev):
+    """what bench.py times (mpn_frcnn_test_one_pipelined_host: uploads on the copy stream into three staging sets, the NMS / top-k tail on
+    the side stream) with the head of every staging set and the tail of both buffer sets replayed as graphs: 16 steps over three
+    different images without a host sync == the serial records"""
+    import ctypes as C
+    from multipathnet_amd._lib import check, f32p
+    from multipathnet_amd.nn import _f, _i, _stream
+    s = SMALL
+    rng = np.random.default_rng(99)
+    ims = [rng.random((3, s["H"], s["W"]), dtype=np.float32) for _ in range(3)]
+    bxs = [_boxes(np.random.default_rng(40 + i), 180, s["W"], s["H"]) for i in range(3)]
+    ref_net = _net()
+    ref = [_run(ref_net, torch.from_numpy(im).to(dev), torch.from_numpy(bx).to(dev)) for im, bx in zip(ims, bxs)]
+    net = _on(_net())
+    pin = [(torch.from_numpy(im).pin_memory(), torch.from_numpy(bx).pin_memory()) for im, bx in zip(ims, bxs)]
+    steps = 16
+    pair = [(torch.zeros_like(net._dets), torch.zeros_like(net._n_dets)) for _ in range(2)]   # the caller alternates two output buffers
+    got = []
+    for t in range(steps):
+        i, bx = pin[t % 3]
+        d, n = pair[t & 1]
+        check(net._lib.mpn_frcnn_test_one_pipelined_host(net._h, C.cast(i.data_ptr(), f32p), s["H"], s["W"], C.cast(bx.data_ptr(), f32p), bx.size(0),
+                                                         _f(d), d.size(0), _i(n), _stream()), "pipelined_host")
+        if t >= 1:  # call t makes call t-1's record visible on the stream
+            dp, np_ = pair[(t - 1) & 1]
+            got.append((t - 1, dp.clone(), np_.clone()))
+    net.flush()
+    dp, np_ = pair[(steps - 1) & 1]
+    got.append((steps - 1, dp.clone(), np_.clone()))
+    torch.cuda.synchronize()
+    for t, d, n in got:
+        assert torch.equal(d[: int(n.item())], ref[t % 3]), t
+    cap, rep = net.graph_stats()
+    # three staging sets' heads + two buffer sets' tails (+ one re-capture: a staging set allocated after the first capture drops that graph)
+    assert cap in (5, 6) and rep >= 2 * steps - 14
