@@ -894,8 +894,8 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC passes cannot run inside the timed process: measured offline
             if os.path.exists(tpath):
                 tj = json.load(open(tpath)).get(other["key"])
-                if tj and dom in tj:
-                    traffic, traffic_src = tj[dom]["bytes_per_image"], tj.get("_source")
+                if tj and "dominant" in tj:
+                    traffic, traffic_src = tj["dominant"], tj.get("_source")
             out = {"metric": other["metric"], "value": round(value, 1), "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                    "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                    "dtype": other["dtype"], "data": "synthetic",
@@ -911,7 +911,8 @@ def main():
                    "roofline": {"bound": "mfma", "kernel": dom + ": " + groups[dom]["label"], "achieved": kernels[dom]["executed_tflops"],
                                 "peak": peak / 1e12, "unit": "TFLOP/s", "frac": kernels[dom]["executed_frac_of_%s_mfma_peak" % pk],
                                 "algorithmic_equiv_frac": kernels[dom]["algorithmic_equiv_frac_of_%s_mfma_peak" % pk],
-                                "traffic": traffic, "traffic_unit": "HBM-side bytes per IMAGE of this kernel group (FETCH_SIZE x2 + WRITE_SIZE over its launches)",
+                                "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_kernel": traffic,
+                                "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE) of the group's dominant kernel by name, averaged over its launches",
                                 "traffic_source": traffic_src,
                                 "flops_per_image": kernels[dom]["executed_gflop"] * 1e9, "ms_per_image": kernels[dom]["ms_per_image"],
                                 "how": "HIP events on the launch stream around each kernel group of the un-pipelined call, %d profiled steps after the timed "

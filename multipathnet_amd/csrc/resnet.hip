@@ -647,7 +647,7 @@ __global__ __launch_bounds__(256, ((MI == 4 && NI == 4) || NCH == 8) ? 1 : 2) vo
     i_slot = (unsigned)slot * STAGEB;
     return ok;
   };
-#ifdef MPN_DEBUG_HOOKS  // timing experiments (tools/bench_conv_bf16.py; results are garbage with bits 1-4): bit 0 = s_setprio 1 over the MFMA clusters,
+#ifdef MPN_BF16_ABLATE  // timing experiments (make FLAGS+=-DMPN_BF16_ABLATE; tools/bench_conv_bf16.py; garbage results with bits 1-6; the branches cost the K loop ~13 %, so they are in NO default build): bit 0 = s_setprio 1 over the MFMA clusters,
   const int ex = a.exp;  // bit 1 = no pixel-gather DMA, bit 2 = no weight DMA, bit 3 = no MFMAs, bit 4 = no epilogue loads / stores,
                          // bit 5 = no vmcnt wait / zero-fill / barrier in the K loop, bit 6 = no fragment reads in the K loop
 #else
@@ -883,6 +883,236 @@ __global__ __launch_bounds__(256, ((MI == 4 && NI == 4) || NCH == 8) ? 1 : 2) vo
     }
   }
   if (tr) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); a.trace[2] = __builtin_amdgcn_s_memtime(); a.trace[3] = (unsigned long long)nstages; }
+}
+
+// ---- round 4: weights through LDS, PIXELS STRAIGHT INTO REGISTERS ("B-direct") ---------------------------------------------------
+// What the LDS-DMA kernel above pays for, measured layer by layer with its operands knocked out (tools/bench_conv_bf16.py,
+// profiles/r04_bf16_conv_ablation.txt): the pixel gather costs 16-19 % of a tower's convolution time (the weights 1 %: they are
+// cache-hot), the stage barrier + fragment reads 17 %, the epilogue 5-9 %; a bare MFMA stream of its wave tile reaches 1.43 PFLOP/s
+// against the 1.74 the matrix pipe sustains on random bf16 data (tools/probes/mfma_bf16_peak.cpp: power-capped).  The gather is slow
+// because it is coupled: its data passes through a 2-3-stage LDS ring (72 KiB of the 80 a block may use with two blocks per CU — no
+// room to run further ahead), and every wave waits at the stage barrier for the slowest wave's pixels.
+// This kernel uncouples it.  Block = 128 couts x 256 pixels, the four waves side by side along the PIXEL axis: wave w owns all 128
+// couts (MI = 4) of pixels 64 w .. 64 w + 63 (NI = 2).  The MFMA B fragment of a wave is then private to it — lane (l31, half) needs
+// the 16-byte record of pixel l31, chunk 2 q + half: ONE buffer_load_dwordx4 per lane per fragment, coalesced (32 consecutive records),
+// straight into the VGPRs the MFMA reads, no LDS, no zero-fill pass (a tap outside the map is an out-of-range buffer offset: the
+// hardware returns zeros), no barrier.  The fragments of the next 2 DS - 1 k-steps (DS = 3-4 stages, 48-64 VGPRs) are in flight while
+// the current one is multiplied: twice the lookahead of the ring, per wave.  Only the weights (8 KiB per stage, shared by the four
+// waves) go through LDS, register-staged (two records per thread per stage) into a 3-slot ring with one barrier per stage.  Every
+// load is a compiler-visible builtin: hipcc computes the vmcnt of every wait from program order, which sched_barrier pins.
+// K order = (tap, chunk pair) in one accumulation chain per output, the same MFMA instruction and operand layout as the kernels
+// above: results are bit-identical to theirs (tests/test_gpu_resnet.py forces either).
+template <int DS>
+__global__ __launch_bounds__(256, 2) void conv2d_c8i_bf16_bdir_kernel(GConvArgsB a, int nx, int ny) {
+  constexpr int MI = 4, NI = 2, TM = 128, TN = 256, RA = 3, RB = 2 * DS;  // RB: B-fragment ring, in k-steps
+  __shared__ __attribute__((aligned(16))) u32x4 lds_a[RA][4 * TM];        // [slot][chunk][cout row] 16-byte records
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+  const int ty = kq % ny, tx = (kq / ny) * 8 + xcd;  // a pixel tile's cout tiles back to back on one XCD
+  if (tx >= nx) return;
+  const long long p0 = (long long)tx * TN + wave * (NI * 32);
+  const int cout0 = ty * TM;
+  const int OHW = a.OH * a.OW;
+  const int spt = a.nch2 / 4;
+  const int nstages = a.KH * a.KW * spt;
+  constexpr unsigned OOB = 0x7ffffff0u;  // >= num_records of either descriptor (the host checks both tensors stay below 2 GiB)
+  const unsigned plane_b = (unsigned)(a.pitch_in * 16);
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(a.in), 0, (int)((size_t)a.nch2 * a.pitch_in * 16), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(a.wpk), 0, (int)((size_t)nstages * 4 * a.CoutP * 16), 0x00020000);
+
+  // this lane's two pixels (one per B fragment)
+  int iy0[NI], ix0[NI];
+  unsigned map_off[NI];
+  bool pv[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const long long gpix = p0 + ni * 32 + l31;
+    pv[ni] = gpix < a.P;
+    const int gb = pv[ni] ? (int)(gpix / OHW) : 0;
+    const int grem = pv[ni] ? (int)(gpix - (long long)gb * OHW) : 0;
+    const int goy = grem / a.OW, gox = grem - goy * a.OW;
+    iy0[ni] = goy * a.sh - a.ph; ix0[ni] = gox * a.sw - a.pw;
+    map_off[ni] = (unsigned)gb * (unsigned)(a.H * a.W);
+  }
+  // B issue cursor: stage, tap, channel group; per-lane byte offsets of the tap's pixel (+ this half-wave's chunk plane)
+  int b_st = 0, b_cg = 0, b_kx = 0, b_ky = 0;
+  unsigned voff[NI];
+  auto b_offsets = [&]() {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int iy = iy0[ni] + b_ky, ix = ix0[ni] + b_kx;
+      const bool ok = pv[ni] && b_st < nstages && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      voff[ni] = ok ? (map_off[ni] + (unsigned)(iy * a.W + ix)) * 16u + (unsigned)half * plane_b : OOB;
+    }
+  };
+  b_offsets();
+  bf16x8 bq[RB][NI];
+  auto b_issue = [&](int q, int slot) {  // fragments of k-step q of stage b_st
+    const unsigned soff = (unsigned)(b_cg * 4 + 2 * q) * plane_b;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[ni], soff, 0);
+      bq[slot][ni] = __builtin_bit_cast(bf16x8, v);
+    }
+  };
+  auto b_advance = [&]() {
+    ++b_st;
+    if (++b_cg == spt) {
+      b_cg = 0;
+      if (++b_kx == a.KW) { b_kx = 0; ++b_ky; }
+      b_offsets();
+    } else if (b_st == nstages) {
+      b_offsets();  // past the last stage (the loop runs whole groups of DS stages): zeros
+    }
+  };
+  // A (weights): thread = row tid & 127 of chunks (tid >> 7) and (tid >> 7) + 2 of a stage; a stage past the last is an
+  // out-of-range offset of the weight descriptor -> zeros
+  const unsigned a_row = (unsigned)(cout0 + (tid & 127)) * 16u, a_ch = (unsigned)(tid >> 7);
+  const unsigned w_chunk = (unsigned)a.CoutP * 16u;
+  u32x4 a_stage[2];
+  auto a_load = [&](int st) {
+    const unsigned base = (unsigned)st * 4u * w_chunk;  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned off = st < nstages ? a_row + (a_ch + 2u * i) * w_chunk : OOB;
+      a_stage[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, base, 0);
+    }
+  };
+  auto a_store = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) lds_a[slot][(a_ch + 2 * i) * TM + (tid & 127)] = a_stage[i];
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+  bf16x8 af[2][MI];
+  auto a_frags = [&](int slot, int q, int fs) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) af[fs][mi] = *reinterpret_cast<const bf16x8 *>(&lds_a[slot][(2 * q + half) * TM + mi * 32 + l31]);
+  };
+
+  // prologue: weights of stage 0 in LDS, of stage 1 in the staging registers; pixel fragments of k-steps 0 .. RB - 2 in flight
+  a_load(0);
+#pragma unroll
+  for (int t = 0; t < RB - 1; ++t) {
+    b_issue(t & 1, t);
+    if (t & 1) b_advance();
+  }
+  a_store(0);
+  a_load(1);
+  __syncthreads();
+  a_frags(0, 0, 0);
+
+  int a_slot = 0;  // LDS slot of the stage being multiplied
+  const int ngroups = (nstages + DS - 1) / DS;
+  for (int g = 0; g < ngroups; ++g) {
+#pragma unroll
+    for (int j = 0; j < DS; ++j) {
+      const int st = g * DS + j;
+      const int s_nxt = a_slot + 1 == RA ? 0 : a_slot + 1;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int t = 2 * j + q;                         // k-step within the group = its ring slot (static)
+        const int t_iss = (t + RB - 1) % RB;             // slot freed by the previous k-step: k-step t + RB - 1 goes there
+        // issue side: the pixel fragments RB - 1 k-steps ahead (cursor parity: the prologue left it at k-step RB - 1 = odd)
+        b_issue((q + 1) & 1, t_iss);
+        if (((q + 1) & 1) == 1) b_advance();
+        if (q == 0) {  // weights: stage st + 1 from the staging registers into its slot (last read two stages ago), stage st + 2 into the registers
+          a_store(s_nxt);
+          a_load(st + 2);
+        }
+        if (q == 1) {  // the stage barrier sits before the last k-step's MFMAs (their operands are in registers already)
+          __syncthreads();
+          a_frags(s_nxt, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < MI * NI; ++m) {
+          const int mi = m / NI, ni = m % NI;
+          __builtin_amdgcn_sched_barrier(0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q][mi], bq[t][ni], acc[mi][ni], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (q == 0 && m == 0) a_frags(a_slot, 1, 1);
+        }
+      }
+      a_slot = s_nxt;
+    }
+  }
+
+  // epilogue: as the LDS-DMA kernel's (loads of channel group mi + 1 before the stores of group mi; 16-byte accesses through
+  // v_permlane32_swap), for this wave's 128 couts x 64 pixels
+  const int cb0 = cout0 / 8;
+  auto swap32 = [](unsigned &lo_keeps, unsigned &hi_keeps) {
+    const auto r = __builtin_amdgcn_permlane32_swap(lo_keeps, hi_keeps, false, false);
+    lo_keeps = r[0]; hi_keeps = r[1];
+  };
+  f32x4 bias[2][4];
+  u32x4 rr[2][NI][2];
+  auto preload = [&](int mi, int buf) {
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int cb = cb0 + mi * 4 + gq;
+      bias[buf][gq] = cb < a.Cb_out ? *reinterpret_cast<const f32x4 *>(a.bpk + cb * 8 + half * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (a.res) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const long long pix = p0 + ni * 32 + l31;
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          const int cb = cb0 + mi * 4 + gp * 2 + half;
+          rr[buf][ni][gp] = (pix < a.P && cb < a.Cb_out) ? *reinterpret_cast<const u32x4 *>(a.res + ((size_t)cb * a.pitch_out + (size_t)pix) * 8)
+                                                         : u32x4{0u, 0u, 0u, 0u};
+        }
+      }
+    }
+  };
+  preload(0, 0);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int buf = mi & 1;
+    if (mi + 1 < MI) preload(mi + 1, buf ^ 1);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const long long pix = p0 + ni * 32 + l31;
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        f32x4 va, vb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          va[e] = acc[mi][ni][(gp * 2) * 4 + e] + bias[buf][gp * 2][e];
+          vb[e] = acc[mi][ni][(gp * 2 + 1) * 4 + e] + bias[buf][gp * 2 + 1][e];
+        }
+        if (a.res) {
+          unsigned r0 = rr[buf][ni][gp][0], r1 = rr[buf][ni][gp][1], r2 = rr[buf][ni][gp][2], r3 = rr[buf][ni][gp][3];
+          swap32(r0, r2);
+          swap32(r1, r3);
+          va[0] += bf2f((bf16_t)(r0 & 0xffffu)); va[1] += bf2f((bf16_t)(r0 >> 16));
+          va[2] += bf2f((bf16_t)(r1 & 0xffffu)); va[3] += bf2f((bf16_t)(r1 >> 16));
+          vb[0] += bf2f((bf16_t)(r2 & 0xffffu)); vb[1] += bf2f((bf16_t)(r2 >> 16));
+          vb[2] += bf2f((bf16_t)(r3 & 0xffffu)); vb[3] += bf2f((bf16_t)(r3 >> 16));
+        }
+        {
+          const int cba = cb0 + mi * 4 + gp * 2;
+          const bool rla = a.relu && !(cba >= a.norelu_cb0 && cba < a.norelu_cb1), rlb = a.relu && !(cba + 1 >= a.norelu_cb0 && cba + 1 < a.norelu_cb1);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { va[e] = (rla && va[e] < 0.0f) ? 0.0f : va[e]; vb[e] = (rlb && vb[e] < 0.0f) ? 0.0f : vb[e]; }
+        }
+        unsigned ax = (unsigned)f2bf(va[0]) | ((unsigned)f2bf(va[1]) << 16), ay = (unsigned)f2bf(va[2]) | ((unsigned)f2bf(va[3]) << 16);
+        unsigned bx = (unsigned)f2bf(vb[0]) | ((unsigned)f2bf(vb[1]) << 16), by = (unsigned)f2bf(vb[2]) | ((unsigned)f2bf(vb[3]) << 16);
+        swap32(ax, bx);
+        swap32(ay, by);
+        const int cb = cb0 + mi * 4 + gp * 2 + half;
+        if (pix < a.P && cb < a.Cb_out) *reinterpret_cast<u32x4 *>(a.out + ((size_t)cb * a.pitch_out + (size_t)pix) * 8) = u32x4{ax, ay, bx, by};
+      }
+    }
+  }
 }
 
 // ---- fp32 generic convolution, LDS-DMA + hand-pipelined form (32-channel stages) ------------------------------------------
@@ -1771,6 +2001,7 @@ MPN_KNOB(int, g_bf16_exp, 0);   // mpn_debug_set_bf16_exp: GConvArgsB::exp (sche
 #ifdef MPN_DEBUG_HOOKS
 MPN_KNOB(int, g_bf16_nch, 4);   // mpn_debug_set_bf16_nch: 8 = 64-channel stages where Cin % 64 == 0 (one block per CU; measured slower, debug flavour only)
 #endif
+MPN_KNOB(int, g_bf16_bdir, 1);  // mpn_debug_set_bf16_bdir: 1 = conv2d_c8i_bf16_bdir_kernel for the large layers it measured faster on (all but strided pointwise ones), 0 = never (the LDS-DMA kernel), 2 = every eligible large layer
 MPN_KNOB(int, g_roi_invariant, 1);  // mpn_debug_set_roi_invariant: 0 = per-ROI layers pick kernel / split by batch size as round 3 did (tests, timing)
 // per_roi: the batch axis counts ROIs (the head of a graph model).  A ROI's result must not depend on which other ROIs share the
 // launch (memoryEfficientForward's chunked == full, ImageDetect.lua:126-133; the ROI-sharded mode == the unsharded one), so for
@@ -1793,6 +2024,23 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
     b.P = (long long)in.B * b.OH * b.OW;
     *o = ActI{out, in.B, c.Cout, b.OH, b.OW};
     b.pitch_in = in.pitch(); b.pitch_out = o->pitch();
+    // round 4: the B-direct kernel (128 couts x 256 pixels; pixels straight into registers), where both tensors fit a 2-GiB descriptor
+    // Where it measured faster, layer by layer against the LDS-DMA kernel on the per-ROI layers of configs[3] / [4] (tools/bench_conv_bf16.py,
+    // profiles/r04_bf16_conv_bdirect.txt): convolutions with spatial taps at stride 1 (every pixel record is re-read once per tap, from
+    // the CU's own cache: 1x3 / 3x1 -17 %, 3x3 -21 %, 1x7 / 7x1 -10 %), strided 3x3 with >= 512 input channels (-4 %), and pointwise
+    // layers with Cin >= 2 Cout (2048 -> 512: -9 %).  NOT on pointwise layers with many output channels (512 -> 2048 + residual: +9 %:
+    // its 128-cout tile re-reads the pixel tile twice as often as the 256-cout LDS-DMA shape), nor on strided pointwise layers
+    // (every second record of a row: half-used cache lines per fragment load, +26 %).  A rule of the layer alone, never of the batch.
+    const bool pointwise = b.KH == 1 && b.KW == 1, strided = b.sh > 1 || b.sw > 1;
+    const bool bdir_wins = pointwise ? (!strided && c.Cin >= 2 * c.Cout) : (!strided || c.Cin >= 512);
+    if (g_bf16_bdir && (g_bf16_bdir == 2 || bdir_wins) && g_bf16_dma && b.nch2 % 4 == 0 && b.P >= (g_bf16_dma == 2 ? 1 : 256 * 128) &&
+        (size_t)b.nch2 * b.pitch_in * 16 < ((size_t)1 << 31) && (size_t)b.KH * b.KW * b.nch2 * b.CoutP * 16 < ((size_t)1 << 31)) {
+      const int nx = (int)((b.P + 255) / 256), ny = b.CoutP / 128;
+      const dim3 gridd((unsigned)(((nx + 7) / 8) * 8 * ny));
+      hipLaunchKernelGGL((conv2d_c8i_bf16_bdir_kernel<3>), gridd, dim3(256), 0, s, b, nx, ny);
+      MPN_CHECK_LAUNCH();
+      return MPN_OK;
+    }
     // large layers: the LDS-DMA kernel (32-channel stages, 32-bit record offsets); tile shape per layer
     if (g_bf16_dma && b.nch2 % 4 == 0 && b.P >= (g_bf16_dma == 2 ? 1 : 256 * 128) && (size_t)in.B * in.H * in.W * 16 < ((size_t)1 << 32)) {
       // cost of a shape = block-rounds over the 256 CUs x work per block (the two 3-ring shapes run two blocks per CU at half speed
@@ -2667,8 +2915,18 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
 #ifdef MPN_DEBUG_HOOKS
 // Kernel-only timing of ONE per-ROI bf16 convolution (rn_conv, per_roi dispatch) on a batch of B maps of H x W (tools/bench_conv_bf16.py):
 // random bf16 activations / weights (zero operands clock higher), optional residual; returns the average ms of `iters` launches.
+namespace mpn {
+__global__ void checksum_u16_kernel(const unsigned short *__restrict__ p, size_t n, unsigned long long *__restrict__ acc) {
+  unsigned long long local = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    local += (unsigned long long)p[i] * (unsigned long long)(i % 65521u + 1u);
+  atomicAdd(acc, local);
+}
+}  // namespace mpn
+// checksum_out (optional): a position-weighted 64-bit checksum of the (zero-initialised, then written) output tensor — equal checksums
+// under two kernel choices = the same bits
 extern "C" int mpn_debug_bench_conv_bf16(int Cin, int Cout, int KH, int KW, int sh, int sw, int ph, int pw, int B, int H, int W, int with_res, int iters,
-                                         float *ms_out) {
+                                         float *ms_out, unsigned long long *checksum_out) {
   using namespace mpn;
   MPN_CHECK_ARG(Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && B > 0 && H > 0 && W > 0 && iters > 0 && ms_out);
   ResNetGraph *g = new ResNetGraph();
@@ -2702,6 +2960,16 @@ extern "C" int mpn_debug_bench_conv_bf16(int Cin, int Cout, int KH, int KW, int 
   ActI o;
   for (int i = 0; i < 2 && rc == MPN_OK; ++i) rc = rn_conv(c, ai, out, res, 1, nullptr, &o, true, true);
   if (rc == MPN_OK && hipDeviceSynchronize() != hipSuccess) rc = MPN_EHIP;
+  if (rc == MPN_OK && checksum_out) {
+    unsigned long long *d_acc = nullptr;
+    if (hipMalloc(&d_acc, 8) != hipSuccess || hipMemset(d_acc, 0, 8) != hipSuccess || hipMemset(out, 0, oe * sizeof(bf16_t)) != hipSuccess) rc = MPN_EHIP;
+    if (rc == MPN_OK) rc = rn_conv(c, ai, out, res, 1, nullptr, &o, true, true);
+    if (rc == MPN_OK) {
+      hipLaunchKernelGGL(checksum_u16_kernel, dim3(2048), dim3(256), 0, nullptr, reinterpret_cast<const unsigned short *>(out), oe, d_acc);
+      if (hipMemcpy(checksum_out, d_acc, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = MPN_EHIP;
+    }
+    if (d_acc) (void)hipFree(d_acc);
+  }
   if (rc == MPN_OK) (void)hipEventRecord(e0, nullptr);
   for (int i = 0; i < iters && rc == MPN_OK; ++i) rc = rn_conv(c, ai, out, res, 1, nullptr, &o, true, true);
   if (rc == MPN_OK) {
@@ -2718,6 +2986,7 @@ extern "C" int mpn_debug_bench_conv_bf16(int Cin, int Cout, int KH, int KW, int 
 extern "C" void mpn_debug_set_bf16_dma(int v) { mpn::g_bf16_dma = v; }
 extern "C" void mpn_debug_set_roi_invariant(int v) { mpn::g_roi_invariant = v; }
 extern "C" void mpn_debug_set_bf16_exp(int v) { mpn::g_bf16_exp = v; }
+extern "C" void mpn_debug_set_bf16_bdir(int v) { mpn::g_bf16_bdir = v; }
 extern "C" void mpn_debug_set_bf16_nch(int v) { mpn::g_bf16_nch = v; }
 extern "C" void mpn_debug_set_bf16_dma_tn(int v) { mpn::g_bf16_dma_tn = v; }
 extern "C" void mpn_debug_set_bf16_split_target(int v) { mpn::g_bf16_split_target = v; }

@@ -56,7 +56,7 @@ def test_inception_multipathnet_extension_vs_oracle(O, dev):
     assert np.abs(b.cpu().numpy() - O.clamp_boxes(bo, W, H)).max() < 0.5
 
 
-@pytest.mark.parametrize("tn", [0, 1256, 256])
+@pytest.mark.parametrize("tn", [0, 1256, 256, -1])
 def test_inception_bf16_lds_dma_kernel_forced(O, dev, tn):
     """the LDS-DMA convolution kernel forced onto every eligible layer of a quarter-width Inception-v3 (by default only layers
     with >= 32768 output pixels use it): 1x7 / 7x1 / 1x3 / 3x1 taps, stride-2 reductions, DepthConcat slices as outputs, cout
@@ -66,7 +66,8 @@ def test_inception_bf16_lds_dma_kernel_forced(O, dev, tn):
     G = models.synthetic_inception_v3_params(n_classes=C, width=0.25, seed=29)
     Gn = dict(models.graph_params_numpy(G), bf16=True)
     im, boxes = _inputs(H, W, N, 18)
-    with hooks(bf16_dma=2, bf16_dma_tn=tn):
+    # tn = -1: the B-direct kernel (round 4) forced onto every eligible layer instead of the LDS-DMA one
+    with hooks(bf16_dma=2, bf16_dma_tn=max(tn, 0), bf16_bdir=2 if tn < 0 else 0):
         net = models.InceptionFRCNN(G, max_h=H, max_w=W, max_rois=32, top_k=10, bf16=True)
         s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
         s = s.cpu().numpy()

@@ -146,8 +146,30 @@ def test_resnet_bf16_vs_bf16_oracle_and_fp32(O, dev, bt, blocks, width, dma, tn)
     the fp32 oracle they agree to bf16 precision.  width 64 exercises the 32-channel-per-stage kernel variant (widths 16: 16-channel);
     dma=2 forces the 256-cout LDS-DMA kernel onto every eligible layer (by default only layers with >= 32768 output pixels), tn its
     tile shape (0 = picked per layer, 128 / 256 = 256 couts x that many pixels, 1256 = 128 couts x 256 pixels)."""
-    with hooks(bf16_dma=dma, bf16_dma_tn=tn):
+    with hooks(bf16_dma=dma, bf16_dma_tn=tn, bf16_bdir=0):   # (the B-direct kernel that large layers take by default: next test)
         _bf16_case(O, dev, bt, blocks, width)
+
+
+@pytest.mark.parametrize("bt,blocks,width", [("bottleneck", [1, 1, 1, 1], 64), ("basic", [1, 1, 1, 2], 64)])
+def test_resnet_bf16_b_direct_kernel_forced_and_bit_identical(O, dev, bt, blocks, width):
+    """conv2d_c8i_bf16_bdir_kernel (round 4: weights through LDS, the pixel fragments straight into registers by buffer loads whose
+    out-of-range offsets stand for the zero padding) forced onto every eligible layer — 1x1, 3x3 with padding, stride 2, residual
+    epilogue, ragged pixel tiles: parity with the same-roundings oracle, and the SAME BITS as the LDS-DMA kernel (one accumulation
+    chain per output in the same K order) — which is what lets either kernel serve a ROI batch of any size."""
+    from multipathnet_amd import models
+    outs = []
+    for bdir in (2, 0):
+        with hooks(bf16_dma=2, bf16_bdir=bdir):
+            if bdir == 2:
+                _bf16_case(O, dev, bt, blocks, width)
+            H, W, N, C = 97, 131, 37, 6
+            R = models.synthetic_resnet_params(depth=0, n_classes=C, base_width=width, blocks=blocks, block_type=bt, seed=23)
+            im, boxes = _inputs(H, W, N, 6)
+            net = models.ResNetFRCNN(R, max_h=H, max_w=W, max_rois=64, top_k=20, bf16=True)
+            s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+            outs.append((s.clone(), b.clone()))
+            del net
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 def _bf16_case(O, dev, bt, blocks, width):

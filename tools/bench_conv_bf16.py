@@ -38,17 +38,18 @@ for name, layers in (("inception", INC), ("resnet", RES)):
     tot_ms = tot_f = 0.0
     for (nm, ci, co, kh, kw, sh, sw, ph, pw, B, H, W, res, cnt) in layers:
         ms = C.c_float()
-        rc = lib.mpn_debug_bench_conv_bf16(ci, co, kh, kw, sh, sw, ph, pw, B, H, W, res, 10, C.byref(ms))
+        ck = C.c_ulonglong()
+        rc = lib.mpn_debug_bench_conv_bf16(ci, co, kh, kw, sh, sw, ph, pw, B, H, W, res, 10, C.byref(ms), C.byref(ck))
         assert rc == 0, (nm, rc)
         clk = ""
         if CLK:
             smp = bench.ClockSampler(0).start()
-            rc = lib.mpn_debug_bench_conv_bf16(ci, co, kh, kw, sh, sw, ph, pw, B, H, W, res, max(10, int(400.0 / ms.value)), C.byref(ms))
+            rc = lib.mpn_debug_bench_conv_bf16(ci, co, kh, kw, sh, sw, ph, pw, B, H, W, res, max(10, int(400.0 / ms.value)), C.byref(ms), None)
             smp.stop()
             sm = smp.summary()
             clk = "  sclk %s MHz  power %s W" % ((sm["sclk_mhz"] or {}).get("mean"), (sm["power_w"] or {}).get("mean"))
         oh, ow = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
         fl = 2.0 * B * oh * ow * ci * kh * kw * co
-        print("%-40s %8.1f us  %7.1f TFLOP/s  %.3f of 2.5 PF   (x%d per tower)%s" % (nm, ms.value * 1e3, fl / ms.value / 1e9, fl / ms.value / 1e9 / 2500.0, cnt, clk))
+        print("%-40s %8.1f us  %7.1f TFLOP/s  %.3f of 2.5 PF   (x%d per tower)  ck %016x%s" % (nm, ms.value * 1e3, fl / ms.value / 1e9, fl / ms.value / 1e9 / 2500.0, cnt, ck.value, clk))
         tot_ms += ms.value * cnt; tot_f += fl * cnt
     print("%s tower convolutions: %.3f ms, %.2f TFLOP -> %.1f TFLOP/s = %.3f of 2.5 PF" % (name, tot_ms, tot_f / 1e12, tot_f / tot_ms / 1e9, tot_f / tot_ms / 1e9 / 2500.0))

@@ -6,6 +6,10 @@ import numpy as np, torch
 import bench
 from multipathnet_amd import models
 import multipathnet_amd
+if os.environ.get("MPN_HOOKS"):  # A/B on the debug flavour: MPN_FLAVOUR=debug MPN_HOOKS="bf16_bdir=0 bf16_dma_tn=256" python tools/...
+    for kv in os.environ["MPN_HOOKS"].split():
+        k, v = kv.split("=")
+        getattr(multipathnet_amd.load(), "mpn_debug_set_" + k)(int(v))
 if os.environ.get("MPN_SPLIT_MAX_TILES"):  # A/B: split-K only layers with fewer 128 x 128 tiles than this
     multipathnet_amd.load().mpn_debug_set_split_max_tiles(int(os.environ["MPN_SPLIT_MAX_TILES"]))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000

@@ -6,6 +6,10 @@ import torch
 import bench
 from multipathnet_amd import models
 import multipathnet_amd
+if os.environ.get("MPN_HOOKS"):  # A/B on the debug flavour: MPN_FLAVOUR=debug MPN_HOOKS="bf16_bdir=0 bf16_dma_tn=256" python tools/...
+    for kv in os.environ["MPN_HOOKS"].split():
+        k, v = kv.split("=")
+        getattr(multipathnet_amd.load(), "mpn_debug_set_" + k)(int(v))
 if os.environ.get("MPN_BF16_DMA"):  # A/B: 0 = never use the LDS-DMA bf16 convolution, 1 = large layers (default), 2 = every eligible layer
     multipathnet_amd.load().mpn_debug_set_bf16_dma(int(os.environ["MPN_BF16_DMA"]))
 if os.environ.get("MPN_DMA_TN"):  # A/B: pixel-tile width of the bf16 LDS-DMA convolution kernel (128 / 256; 0 = per layer)
