@@ -1115,6 +1115,241 @@ __global__ __launch_bounds__(256, 2) void conv2d_c8i_bf16_bdir_kernel(GConvArgsB
   }
 }
 
+#ifdef MPN_DEBUG_HOOKS  // measured no faster than the compiler-counted form (4.73-4.78 vs 4.73 ms per Inception tower): kept in the debug flavour only
+// Second form of the same kernel: every memory operation of the K loop is issued by inline asm and counted by hand.  Why: vmcnt retires
+// IN ORDER, so in the form above the wait for a stage's weight registers (loaded one stage earlier) also waits for every pixel fragment
+// issued before them — the pixel lookahead the ring was built for is cut from 2 DS - 1 k-steps to about three.  Here the weights go
+// global -> LDS by LDS-DMA (no staging registers, no ds_write) into a SIX-slot ring, issued four stages ahead: by the time a stage's
+// weights are waited for (vmcnt(18), before the stage barrier) every older pixel fragment has long been consumed, so the wait costs the
+// pixel stream nothing.  Every k-step issues exactly [fragment, fragment, weight piece]; a fragment pair is therefore followed by
+// 3 (RB - 1) + 1 operations when its k-step comes up: s_waitcnt vmcnt(3 RB - 2), with the fragment registers as in/out operands of the
+// wait statement so that no MFMA is scheduled above it.  Past the last stage the fragment loads are out-of-range offsets (zeros) and the
+// weight pieces re-load stage 0 (finite values x 0).
+template <int DS>
+__global__ __launch_bounds__(256, 2) void conv2d_c8i_bf16_bdir2_kernel(GConvArgsB a, int nx, int ny) {
+  constexpr int MI = 4, NI = 2, TM = 128, TN = 256, RA = 6, LA = 4, RB = 2 * DS;  // RA / LA: weight ring slots / stages of weight lookahead; RB: fragment ring (k-steps)
+  __shared__ __attribute__((aligned(16))) u32x4 lds_a[RA][4 * TM];                // [slot][chunk][cout row] 16-byte records
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+  const int ty = kq % ny, tx = (kq / ny) * 8 + xcd;  // a pixel tile's cout tiles back to back on one XCD
+  if (tx >= nx) return;
+  const long long p0 = (long long)tx * TN + wave * (NI * 32);
+  const int cout0 = ty * TM;
+  const int OHW = a.OH * a.OW;
+  const int spt = a.nch2 / 4;
+  const int nstages = a.KH * a.KW * spt;
+  constexpr unsigned OOB = 0x7ffffff0u;  // >= num_records of either descriptor (the host checks both tensors stay below 2 GiB)
+  const unsigned plane_b = (unsigned)(a.pitch_in * 16);
+  u32x4 rs_in;  // raw buffer descriptor of the input tensor in four SGPRs: base, stride 0, num_records (bytes), flags
+  {
+    const unsigned long long base = (unsigned long long)a.in;
+    rs_in[0] = __builtin_amdgcn_readfirstlane((unsigned)base);
+    rs_in[1] = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32) & 0xffffu);
+    rs_in[2] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)a.nch2 * a.pitch_in * 16));
+    rs_in[3] = __builtin_amdgcn_readfirstlane(0x00020000u);
+  }
+
+  // this lane's two pixels (one per B fragment)
+  int iy0[NI], ix0[NI];
+  unsigned map_off[NI];
+  bool pv[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const long long gpix = p0 + ni * 32 + l31;
+    pv[ni] = gpix < a.P;
+    const int gb = pv[ni] ? (int)(gpix / OHW) : 0;
+    const int grem = pv[ni] ? (int)(gpix - (long long)gb * OHW) : 0;
+    const int goy = grem / a.OW, gox = grem - goy * a.OW;
+    iy0[ni] = goy * a.sh - a.ph; ix0[ni] = gox * a.sw - a.pw;
+    map_off[ni] = (unsigned)gb * (unsigned)(a.H * a.W);
+  }
+  // B issue cursor: stage, tap, channel group; per-lane byte offsets of the tap's pixel (+ this half-wave's chunk plane)
+  int b_st = 0, b_cg = 0, b_kx = 0, b_ky = 0;
+  unsigned voff[NI];
+  auto b_offsets = [&]() {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int iy = iy0[ni] + b_ky, ix = ix0[ni] + b_kx;
+      const bool ok = pv[ni] && b_st < nstages && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      voff[ni] = ok ? (map_off[ni] + (unsigned)(iy * a.W + ix)) * 16u + (unsigned)half * plane_b : OOB;
+    }
+  };
+  b_offsets();
+  bf16x8 bq[RB][NI];
+  auto b_issue = [&](int q, int slot) {  // fragments of k-step q of stage b_st (destinations unprotected until the counted wait)
+    const unsigned soff = (unsigned)(b_cg * 4 + 2 * q) * plane_b;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(bq[slot][ni]) : "v"(voff[ni]), "s"(rs_in), "s"(soff) : "memory");
+  };
+  auto b_advance = [&]() {
+    ++b_st;
+    if (++b_cg == spt) {
+      b_cg = 0;
+      if (++b_kx == a.KW) { b_kx = 0; ++b_ky; }
+      b_offsets();
+    } else if (b_st == nstages) {
+      b_offsets();  // past the last stage (the loop runs whole groups of DS stages): zeros
+    }
+  };
+  // A (weights) by LDS-DMA: a stage is 4 chunks x 128 rows = 8 wave-loads of 1 KiB; wave w moves pieces w (k-step 0) and w + 4 (k-step 1):
+  // piece p = rows 64 (p & 1) .. of chunk p >> 1.  Stage st + LA goes to slot (st + LA) % RA while stage st is multiplied.
+  const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) const u32x4 *)&lds_a[0][0]);
+  const unsigned a_lane = (unsigned)lane * 16u;
+  const size_t w_chunk = (size_t)a.CoutP * 16;
+  const char *const w_base = reinterpret_cast<const char *>(a.wpk) + (size_t)cout0 * 16;
+  int a_st = 0, a_slot_iss = 0;  // issue cursor: stage, its ring slot
+  auto a_issue = [&](int half_piece) {  // half_piece 0 / 1 = this wave's first / second piece of stage a_st
+    const int p = wave + 4 * half_piece;
+    const int st_src = a_st < nstages ? a_st : 0;  // past the end: any finite weights (their pixel fragments are zeros)
+    const char *src = w_base + ((size_t)st_src * 4 + (p >> 1)) * w_chunk + (size_t)(p & 1) * 1024;
+    glds16_s(src, a_lane, lds0 + (unsigned)a_slot_iss * (4u * TM * 16u) + (unsigned)((p >> 1) * TM + (p & 1) * 64) * 16u);
+  };
+  auto a_advance = [&]() { ++a_st; a_slot_iss = a_slot_iss + 1 == RA ? 0 : a_slot_iss + 1; };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+  bf16x8 af[2][MI];
+  auto a_frags = [&](int slot, int q, int fs) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) af[fs][mi] = *reinterpret_cast<const bf16x8 *>(&lds_a[slot][(2 * q + half) * TM + mi * 32 + l31]);
+  };
+
+  // prologue: weight stages 0 .. LA - 1 and the pixel fragments of k-steps 0 .. RB - 2 in flight, then ONE full drain (every later
+  // wait is counted against the steady [fragment, fragment, weight piece] pattern, which starts after this point)
+#pragma unroll
+  for (int i = 0; i < LA; ++i) { a_issue(0); a_issue(1); a_advance(); }
+#pragma unroll
+  for (int t = 0; t < RB - 1; ++t) {
+    b_issue(t & 1, t);
+    if (t & 1) b_advance();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  a_frags(0, 0, 0);
+
+  int a_slot = 0;  // LDS slot of the stage being multiplied
+  const int ngroups = (nstages + DS - 1) / DS;
+  for (int g = 0; g < ngroups; ++g) {
+#pragma unroll
+    for (int j = 0; j < DS; ++j) {
+      const int s_nxt = a_slot + 1 == RA ? 0 : a_slot + 1;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int t = 2 * j + q;                         // k-step within the group = its ring slot (static)
+        const int t_iss = (t + RB - 1) % RB;             // slot freed by the previous k-step: k-step t + RB - 1 goes there
+        // issue side, exactly three operations per k-step: the two pixel fragments RB - 1 k-steps ahead, one weight piece LA stages ahead
+        b_issue((q + 1) & 1, t_iss);
+        if (((q + 1) & 1) == 1) b_advance();
+        a_issue(q);
+        if (q == 1) a_advance();
+        if (q == 1) {  // the stage barrier sits before the last k-step's MFMAs (their operands are in registers already)
+          // the next stage's weight pieces were issued LA - 1 stages ago: 3 operations per k-step since, this k-step's included
+          static_assert(LA == 4, "the counted wait below assumes the weight pieces of stage st + 1 were issued during stage st - 3");
+          asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+          __syncthreads();
+          a_frags(s_nxt, 0, 0);
+        }
+        // this k-step's fragments: issued RB - 1 k-steps ago, followed since by 1 + 3 (RB - 2) + 3 operations
+        {
+          constexpr int NW = 3 * RB - 2;
+          static_assert(NW == 16 || NW == 22, "");
+          if constexpr (NW == 16) asm volatile("s_waitcnt vmcnt(16)" : "+v"(bq[t][0]), "+v"(bq[t][1]) :: "memory");
+          else asm volatile("s_waitcnt vmcnt(22)" : "+v"(bq[t][0]), "+v"(bq[t][1]) :: "memory");
+        }
+#pragma unroll
+        for (int m = 0; m < MI * NI; ++m) {
+          const int mi = m / NI, ni = m % NI;
+          __builtin_amdgcn_sched_barrier(0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q][mi], bq[t][ni], acc[mi][ni], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (q == 0 && m == 0) a_frags(a_slot, 1, 1);
+        }
+      }
+      a_slot = s_nxt;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the look-ahead loads past the last stage (zeros / stage-0 weights): nothing may land after the wave has gone
+
+  // epilogue: as the LDS-DMA kernel's (loads of channel group mi + 1 before the stores of group mi; 16-byte accesses through
+  // v_permlane32_swap), for this wave's 128 couts x 64 pixels
+  const int cb0 = cout0 / 8;
+  auto swap32 = [](unsigned &lo_keeps, unsigned &hi_keeps) {
+    const auto r = __builtin_amdgcn_permlane32_swap(lo_keeps, hi_keeps, false, false);
+    lo_keeps = r[0]; hi_keeps = r[1];
+  };
+  f32x4 bias[2][4];
+  u32x4 rr[2][NI][2];
+  auto preload = [&](int mi, int buf) {
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int cb = cb0 + mi * 4 + gq;
+      bias[buf][gq] = cb < a.Cb_out ? *reinterpret_cast<const f32x4 *>(a.bpk + cb * 8 + half * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (a.res) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const long long pix = p0 + ni * 32 + l31;
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          const int cb = cb0 + mi * 4 + gp * 2 + half;
+          rr[buf][ni][gp] = (pix < a.P && cb < a.Cb_out) ? *reinterpret_cast<const u32x4 *>(a.res + ((size_t)cb * a.pitch_out + (size_t)pix) * 8)
+                                                         : u32x4{0u, 0u, 0u, 0u};
+        }
+      }
+    }
+  };
+  preload(0, 0);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int buf = mi & 1;
+    if (mi + 1 < MI) preload(mi + 1, buf ^ 1);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const long long pix = p0 + ni * 32 + l31;
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        f32x4 va, vb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          va[e] = acc[mi][ni][(gp * 2) * 4 + e] + bias[buf][gp * 2][e];
+          vb[e] = acc[mi][ni][(gp * 2 + 1) * 4 + e] + bias[buf][gp * 2 + 1][e];
+        }
+        if (a.res) {
+          unsigned r0 = rr[buf][ni][gp][0], r1 = rr[buf][ni][gp][1], r2 = rr[buf][ni][gp][2], r3 = rr[buf][ni][gp][3];
+          swap32(r0, r2);
+          swap32(r1, r3);
+          va[0] += bf2f((bf16_t)(r0 & 0xffffu)); va[1] += bf2f((bf16_t)(r0 >> 16));
+          va[2] += bf2f((bf16_t)(r1 & 0xffffu)); va[3] += bf2f((bf16_t)(r1 >> 16));
+          vb[0] += bf2f((bf16_t)(r2 & 0xffffu)); vb[1] += bf2f((bf16_t)(r2 >> 16));
+          vb[2] += bf2f((bf16_t)(r3 & 0xffffu)); vb[3] += bf2f((bf16_t)(r3 >> 16));
+        }
+        {
+          const int cba = cb0 + mi * 4 + gp * 2;
+          const bool rla = a.relu && !(cba >= a.norelu_cb0 && cba < a.norelu_cb1), rlb = a.relu && !(cba + 1 >= a.norelu_cb0 && cba + 1 < a.norelu_cb1);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { va[e] = (rla && va[e] < 0.0f) ? 0.0f : va[e]; vb[e] = (rlb && vb[e] < 0.0f) ? 0.0f : vb[e]; }
+        }
+        unsigned ax = (unsigned)f2bf(va[0]) | ((unsigned)f2bf(va[1]) << 16), ay = (unsigned)f2bf(va[2]) | ((unsigned)f2bf(va[3]) << 16);
+        unsigned bx = (unsigned)f2bf(vb[0]) | ((unsigned)f2bf(vb[1]) << 16), by = (unsigned)f2bf(vb[2]) | ((unsigned)f2bf(vb[3]) << 16);
+        swap32(ax, bx);
+        swap32(ay, by);
+        const int cb = cb0 + mi * 4 + gp * 2 + half;
+        if (pix < a.P && cb < a.Cb_out) *reinterpret_cast<u32x4 *>(a.out + ((size_t)cb * a.pitch_out + (size_t)pix) * 8) = u32x4{ax, ay, bx, by};
+      }
+    }
+  }
+}
+
+#endif  // MPN_DEBUG_HOOKS (conv2d_c8i_bf16_bdir2_kernel)
+
 // ---- fp32 generic convolution, LDS-DMA + hand-pipelined form (32-channel stages) ------------------------------------------
 // Same tile and arithmetic as conv2d_c8i_kernel<4> (128 couts x 128 pixels, 4 waves of 64 x 64, fp32 MFMA, stage = 32 input
 // channels of one tap, two stages in LDS), but built like dense.hip's gemm_c8_pf_kernel: both operands go global -> LDS through
@@ -2002,6 +2237,9 @@ MPN_KNOB(int, g_bf16_exp, 0);   // mpn_debug_set_bf16_exp: GConvArgsB::exp (sche
 MPN_KNOB(int, g_bf16_nch, 4);   // mpn_debug_set_bf16_nch: 8 = 64-channel stages where Cin % 64 == 0 (one block per CU; measured slower, debug flavour only)
 #endif
 MPN_KNOB(int, g_bf16_bdir, 1);  // mpn_debug_set_bf16_bdir: 1 = conv2d_c8i_bf16_bdir_kernel for the large layers it measured faster on (all but strided pointwise ones), 0 = never (the LDS-DMA kernel), 2 = every eligible large layer
+#ifdef MPN_DEBUG_HOOKS
+MPN_KNOB(int, g_bf16_bdir_ver, 1);  // mpn_debug_set_bf16_bdir_ver: 1 = compiler-counted form <3>, 2 / 3 = hand-counted form <3> / <4> (debug flavour only)
+#endif
 MPN_KNOB(int, g_roi_invariant, 1);  // mpn_debug_set_roi_invariant: 0 = per-ROI layers pick kernel / split by batch size as round 3 did (tests, timing)
 // per_roi: the batch axis counts ROIs (the head of a graph model).  A ROI's result must not depend on which other ROIs share the
 // launch (memoryEfficientForward's chunked == full, ImageDetect.lua:126-133; the ROI-sharded mode == the unsharded one), so for
@@ -2037,6 +2275,11 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
         (size_t)b.nch2 * b.pitch_in * 16 < ((size_t)1 << 31) && (size_t)b.KH * b.KW * b.nch2 * b.CoutP * 16 < ((size_t)1 << 31)) {
       const int nx = (int)((b.P + 255) / 256), ny = b.CoutP / 128;
       const dim3 gridd((unsigned)(((nx + 7) / 8) * 8 * ny));
+#ifdef MPN_DEBUG_HOOKS
+      if (g_bf16_bdir_ver == 2) hipLaunchKernelGGL((conv2d_c8i_bf16_bdir2_kernel<3>), gridd, dim3(256), 0, s, b, nx, ny);
+      else if (g_bf16_bdir_ver == 3) hipLaunchKernelGGL((conv2d_c8i_bf16_bdir2_kernel<4>), gridd, dim3(256), 0, s, b, nx, ny);
+      else
+#endif
       hipLaunchKernelGGL((conv2d_c8i_bf16_bdir_kernel<3>), gridd, dim3(256), 0, s, b, nx, ny);
       MPN_CHECK_LAUNCH();
       return MPN_OK;
@@ -2987,6 +3230,7 @@ extern "C" void mpn_debug_set_bf16_dma(int v) { mpn::g_bf16_dma = v; }
 extern "C" void mpn_debug_set_roi_invariant(int v) { mpn::g_roi_invariant = v; }
 extern "C" void mpn_debug_set_bf16_exp(int v) { mpn::g_bf16_exp = v; }
 extern "C" void mpn_debug_set_bf16_bdir(int v) { mpn::g_bf16_bdir = v; }
+extern "C" void mpn_debug_set_bf16_bdir_ver(int v) { mpn::g_bf16_bdir_ver = v; }
 extern "C" void mpn_debug_set_bf16_nch(int v) { mpn::g_bf16_nch = v; }
 extern "C" void mpn_debug_set_bf16_dma_tn(int v) { mpn::g_bf16_dma_tn = v; }
 extern "C" void mpn_debug_set_bf16_split_target(int v) { mpn::g_bf16_split_target = v; }
