@@ -192,6 +192,17 @@ function FastRCNN:detect(im, boxes, recompute_features)
                             bbox:data(), 0, stream()), 'mpn_frcnn_detect')
    return scores, bbox
 end
+-- Captured launch graphs (off by default): the handle replays its kernel sequences with hipGraphLaunch while the caller keeps passing the
+-- same device buffers and shapes.  Frees the host thread (one enqueue instead of ~100 per image); the GPU's timeline is unchanged.
+function FastRCNN:setGraphs(on)
+   check(C.mpn_frcnn_set_graphs(self.handle, on and 1 or 0), 'mpn_frcnn_set_graphs')
+   return self
+end
+function FastRCNN:graphStats()
+   local cap, rep = ffi.new('long[1]'), ffi.new('long[1]')
+   check(C.mpn_frcnn_graph_stats(self.handle, cap, rep), 'mpn_frcnn_graph_stats')
+   return tonumber(cap[0]), tonumber(rep[0])
+end
 mpn.FastRCNN = FastRCNN
 
 -- Scored-box gather over RCCL (replaces test_runner.lua:91-104's per-thread result hand-back) -------------------------------------
@@ -202,6 +213,8 @@ function mpn.comm_init_all(n)
    check(C.mpn_comm_init_all(n, nil, comms), 'mpn_comm_init_all')
    return comms
 end
+-- what RCCL itself says the communicator spans (ncclCommCount, checked against ncclCommUserRank at init); 0 = no RCCL communicator
+function mpn.comm_rccl_ranks(comm) return C.mpn_comm_rccl_ranks(comm) end
 function mpn.gather(comm, dets, n_dets, out)  -- out: CudaTensor [world, top_cap*6 + 1]
    check(C.mpn_gather_dets(comm, dets:data(), ffi.cast('const int *', n_dets:data()), dets:size(1), out:data(), stream()), 'mpn_gather_dets')
    return out
