@@ -902,16 +902,16 @@ __global__ __launch_bounds__(256, ((MI == 4 && NI == 4) || NCH == 8) ? 1 : 2) vo
 // load is a compiler-visible builtin: hipcc computes the vmcnt of every wait from program order, which sched_barrier pins.
 // K order = (tap, chunk pair) in one accumulation chain per output, the same MFMA instruction and operand layout as the kernels
 // above: results are bit-identical to theirs (tests/test_gpu_resnet.py forces either).
-template <int DS>
-__global__ __launch_bounds__(256, 2) void conv2d_c8i_bf16_bdir_kernel(GConvArgsB a, int nx, int ny) {
-  constexpr int MI = 4, NI = 2, TM = 128, TN = 256, RA = 3, RB = 2 * DS;  // RB: B-fragment ring, in k-steps
-  __shared__ __attribute__((aligned(16))) u32x4 lds_a[RA][4 * TM];        // [slot][chunk][cout row] 16-byte records
+// ABL (timing experiments, -DMPN_BF16_ABLATE builds only; garbage results): bit 0 no pixel loads, 1 no weight loads / LDS stores,
+// 2 no stage barrier, 3 no MFMAs (operands still waited for), 4 no epilogue, 5 pixel loads all from one resident 1-KiB window
+// MI = 32-cout sub-tiles the block multiplies: 4, or 2 for a ragged last cout tile with <= 64 valid couts (192- / 320- / 1344-cout
+// layers: their last tile no longer multiplies 64 rows of zero weights)
+template <int DS, int ABL, int MI>
+__device__ __forceinline__ void bdir_body(const GConvArgsB &a, u32x4 (*lds_a)[4 * 128], const int tx, const int ty) {
+  constexpr int NI = 2, TM = 128, TN = 256, RA = 3, RB = 2 * DS;  // RB: B-fragment ring, in k-steps
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
-  const int ty = kq % ny, tx = (kq / ny) * 8 + xcd;  // a pixel tile's cout tiles back to back on one XCD
-  if (tx >= nx) return;
   const long long p0 = (long long)tx * TN + wave * (NI * 32);
   const int cout0 = ty * TM;
   const int OHW = a.OH * a.OW;
@@ -945,12 +945,29 @@ __global__ __launch_bounds__(256, 2) void conv2d_c8i_bf16_bdir_kernel(GConvArgsB
       const int iy = iy0[ni] + b_ky, ix = ix0[ni] + b_kx;
       const bool ok = pv[ni] && b_st < nstages && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
       voff[ni] = ok ? (map_off[ni] + (unsigned)(iy * a.W + ix)) * 16u + (unsigned)half * plane_b : OOB;
+      if constexpr ((ABL & 32) != 0) voff[ni] = (unsigned)(l31 * 16 + ni * 512);
     }
   };
   b_offsets();
   bf16x8 bq[RB][NI];
+  if constexpr ((ABL & 1) != 0) {
+#pragma unroll
+    for (int t = 0; t < RB; ++t)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bq[t][ni] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)lane, 0x3f803f80u, (unsigned)t, 0x3f803f80u});
+  }
   auto b_issue = [&](int q, int slot) {  // fragments of k-step q of stage b_st
-    const unsigned soff = (unsigned)(b_cg * 4 + 2 * q) * plane_b;
+    unsigned soff = (unsigned)(b_cg * 4 + 2 * q) * plane_b;
+    if constexpr ((ABL & 32) != 0) soff = 0;
+    if constexpr ((ABL & 1) != 0) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(bq[slot][ni]));
+      return;
+    }
+    if constexpr ((ABL & 192) == 192) {  // decoupled experiment: the previous load into this slot is consumed only now
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) asm volatile("" :: "v"(bq[slot][ni]));
+    }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[ni], soff, 0);
@@ -973,6 +990,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_c8i_bf16_bdir_kernel(GConvArgsB
   const unsigned w_chunk = (unsigned)a.CoutP * 16u;
   u32x4 a_stage[2];
   auto a_load = [&](int st) {
+    if constexpr ((ABL & 2) != 0) return;
     const unsigned base = (unsigned)st * 4u * w_chunk;  // wave-uniform
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -981,10 +999,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_c8i_bf16_bdir_kernel(GConvArgsB
     }
   };
   auto a_store = [&](int slot) {
+    if constexpr ((ABL & 2) != 0) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) lds_a[slot][(a_ch + 2 * i) * TM + (tid & 127)] = a_stage[i];
   };
 
+  bf16x8 bconst = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u ^ (unsigned)lane, 0x3f813f82u, 0x3f833f84u, 0x3f853f86u + (unsigned)lane});
+  asm volatile("" : "+v"(bconst));
   f32x16 acc[MI][NI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -1029,13 +1050,18 @@ __global__ __launch_bounds__(256, 2) void conv2d_c8i_bf16_bdir_kernel(GConvArgsB
           a_load(st + 2);
         }
         if (q == 1) {  // the stage barrier sits before the last k-step's MFMAs (their operands are in registers already)
-          __syncthreads();
+          if constexpr ((ABL & 4) == 0) __syncthreads();
           a_frags(s_nxt, 0, 0);
         }
 #pragma unroll
         for (int m = 0; m < MI * NI; ++m) {
           const int mi = m / NI, ni = m % NI;
           __builtin_amdgcn_sched_barrier(0);
+          if constexpr ((ABL & 8) != 0) asm volatile("" :: "v"(af[q][mi]), "v"(bq[t][ni]));
+          else if constexpr ((ABL & 64) != 0) {  // MFMAs on a constant pixel fragment: the loads run beside them without feeding them
+            if constexpr ((ABL & 128) == 0) { if (mi == 0) asm volatile("" :: "v"(bq[t][ni])); }
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q][mi], bconst, acc[mi][ni], 0, 0, 0);
+          } else
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q][mi], bq[t][ni], acc[mi][ni], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           if (q == 0 && m == 0) a_frags(a_slot, 1, 1);
@@ -1045,6 +1071,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_c8i_bf16_bdir_kernel(GConvArgsB
     }
   }
 
+  if constexpr ((ABL & 16) != 0) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) asm volatile("" :: "v"(acc[mi][ni]));
+    return;
+  }
   // epilogue: as the LDS-DMA kernel's (loads of channel group mi + 1 before the stores of group mi; 16-byte accesses through
   // v_permlane32_swap), for this wave's 128 couts x 64 pixels
   const int cb0 = cout0 / 8;
@@ -1114,6 +1147,253 @@ __global__ __launch_bounds__(256, 2) void conv2d_c8i_bf16_bdir_kernel(GConvArgsB
     }
   }
 }
+
+template <int DS, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void conv2d_c8i_bf16_bdir_kernel(GConvArgsB a, int nx, int ny) {
+  __shared__ __attribute__((aligned(16))) u32x4 lds_a[(ABL & 8) ? 9 : 3][4 * 128];  // [slot][chunk][cout row] 16-byte records (no-MFMA timing variant: padded so that still two blocks fit a CU)
+  const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+  const int ty = kq % ny, tx = (kq / ny) * 8 + xcd;  // a pixel tile's cout tiles back to back on one XCD
+  if (tx >= nx) return;
+  if (a.Cb_out * 8 - ty * 128 > 64) bdir_body<DS, ABL, 4>(a, lds_a, tx, ty);
+  else bdir_body<DS, ABL, 2>(a, lds_a, tx, ty);
+}
+
+#ifdef MPN_DEBUG_HOOKS  // measured 12 % SLOWER than the 4-wave kernel above: debug flavour only (profiles/r04_bf16_conv_bdir_ablation.txt)
+// ---- round 4, an experiment that did not pay: B-direct with 256 couts per block ("bdir8") ---------------------------------------
+// Knock-out timing of the kernel above (tools/bench_conv_bf16.py bf16_bdir_abl=..., profiles/r04_bf16_conv_bdir_ablation.txt), per
+// Inception tower, sustained: MFMAs alone 1.84-2.28 ms, the loads alone 2.47, everything 4.12 — the matrix stream and the vector-memory
+// stream add up instead of overlapping, and pixel loads that all HIT the CU's vector cache still cost half of what the real ones do.
+// Hypothesis tested here: fewer bytes per FLOP.  256 couts per block, eight waves side by side along the PIXEL axis, each owning ALL
+// 256 couts (MI = 8) of 32 pixels (NI = 1): a pixel fragment feeds eight MFMAs instead of four (16 KiB weights + 16 KiB pixels per
+// 4.2 MFLOP stage against 8 + 16 per 2.1).  One block per CU (two waves per SIMD as before), 128 accumulator registers; the weight
+// fragments are single-buffered and ROLL (fragment mi of the next k-step is read right behind the MFMA that consumed fragment mi of
+// this one); pixel ring of 2 DS k-steps (DS = 4, 6, 8 instantiated: 220-252 VGPRs, no spill).  Bit-identical to the kernels above.
+// Result: slower on every 384- / 1344-cout layer (its MFMA stream with one LDS read per MFMA runs at 3.26 vs 2.78 ms per tower even
+// with no loads at all), a deeper ring changes nothing (4.69 / 4.70 / 4.75 ms for 8 / 12 / 16 k-steps in flight): neither bytes per
+// FLOP nor lookahead is what keeps the two streams from overlapping.  Kept for the record and for tools/bench_conv_bf16.py.
+// MI = the block's valid 32-cout sub-tiles rounded up to even (compile-time: the kernel dispatches once per block)
+template <int DS, int MI, int ABL>
+__device__ __forceinline__ void bdir8_body(const GConvArgsB &a, u32x4 (*lds_a)[4 * 256], const int tx, const int ty) {
+  constexpr int TM = 256, TN = 256, RA = 3, RB = 2 * DS;  // RB: pixel-fragment ring, in k-steps
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const long long p0 = (long long)tx * TN + wave * 32;
+  const int cout0 = ty * TM;
+  const int OHW = a.OH * a.OW;
+  const int spt = a.nch2 / 4;
+  const int nstages = a.KH * a.KW * spt;
+  constexpr unsigned OOB = 0x7ffffff0u;
+  const unsigned plane_b = (unsigned)(a.pitch_in * 16);
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(a.in), 0, (int)((size_t)a.nch2 * a.pitch_in * 16), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(a.wpk), 0, (int)((size_t)nstages * 4 * a.CoutP * 16), 0x00020000);
+
+  // this lane's pixel
+  int iy0, ix0;
+  unsigned map_off;
+  bool pv;
+  {
+    const long long gpix = p0 + l31;
+    pv = gpix < a.P;
+    const int gb = pv ? (int)(gpix / OHW) : 0;
+    const int grem = pv ? (int)(gpix - (long long)gb * OHW) : 0;
+    const int goy = grem / a.OW, gox = grem - goy * a.OW;
+    iy0 = goy * a.sh - a.ph; ix0 = gox * a.sw - a.pw;
+    map_off = (unsigned)gb * (unsigned)(a.H * a.W);
+  }
+  int b_st = 0, b_cg = 0, b_kx = 0, b_ky = 0;
+  unsigned voff;
+  auto b_offsets = [&]() {
+    const int iy = iy0 + b_ky, ix = ix0 + b_kx;
+    const bool ok = pv && b_st < nstages && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    voff = ok ? (map_off + (unsigned)(iy * a.W + ix)) * 16u + (unsigned)half * plane_b : OOB;
+    if constexpr ((ABL & 32) != 0) voff = (unsigned)(l31 * 16);
+  };
+  b_offsets();
+  bf16x8 bq[RB];
+  if constexpr ((ABL & 1) != 0) {
+#pragma unroll
+    for (int t = 0; t < RB; ++t) bq[t] = __builtin_bit_cast(bf16x8, u32x4{(unsigned)lane, 0x3f803f80u, (unsigned)t, 0x3f803f80u});
+  }
+  auto b_issue = [&](int q, int slot) {  // the fragment of k-step q of stage b_st
+    unsigned soff = (unsigned)(b_cg * 4 + 2 * q) * plane_b;
+    if constexpr ((ABL & 32) != 0) soff = 0;
+    if constexpr ((ABL & 1) != 0) {
+      asm volatile("" : "+v"(bq[slot]));
+      return;
+    }
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, soff, 0);
+    bq[slot] = __builtin_bit_cast(bf16x8, v);
+  };
+  auto b_advance = [&]() {
+    ++b_st;
+    if (++b_cg == spt) {
+      b_cg = 0;
+      if (++b_kx == a.KW) { b_kx = 0; ++b_ky; }
+      b_offsets();
+    } else if (b_st == nstages) {
+      b_offsets();  // past the last stage: zeros
+    }
+  };
+  // A (weights): thread = row tid & 255 of chunks (tid >> 8) and (tid >> 8) + 2 of a stage; rows past the padded cout count and
+  // stages past the last are out-of-range offsets -> zeros
+  const bool a_ok = cout0 + (tid & 255) < a.CoutP;
+  const unsigned a_row = (unsigned)(cout0 + (tid & 255)) * 16u, a_ch = (unsigned)(tid >> 8);
+  const unsigned w_chunk = (unsigned)a.CoutP * 16u;
+  u32x4 a_stage[2];
+  auto a_load = [&](int st) {
+    if constexpr ((ABL & 2) != 0) return;
+    const unsigned base = (unsigned)st * 4u * w_chunk;  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned off = (a_ok && st < nstages) ? a_row + (a_ch + 2u * i) * w_chunk : OOB;
+      a_stage[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, base, 0);
+    }
+  };
+  auto a_store = [&](int slot) {
+    if constexpr ((ABL & 2) != 0) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) lds_a[slot][(a_ch + 2 * i) * TM + (tid & 255)] = a_stage[i];
+  };
+
+  f32x16 acc[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mi][r] = 0.0f;
+  bf16x8 af[MI];
+  auto a_frag = [&](int slot, int q, int mi) { af[mi] = *reinterpret_cast<const bf16x8 *>(&lds_a[slot][(2 * q + half) * TM + mi * 32 + l31]); };
+
+  // prologue: weights of stage 0 in LDS, of stage 1 in the staging registers; pixel fragments of k-steps 0 .. RB - 2 in flight
+  a_load(0);
+#pragma unroll
+  for (int t = 0; t < RB - 1; ++t) {
+    b_issue(t & 1, t);
+    if (t & 1) b_advance();
+  }
+  a_store(0);
+  a_load(1);
+  __syncthreads();
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) a_frag(0, 0, mi);
+
+  int a_slot = 0;  // LDS slot of the stage being multiplied
+  bool more = true;
+  for (int g = 0; more; ++g) {
+#pragma unroll
+    for (int j = 0; j < DS; ++j) {
+      const int st = g * DS + j;
+      if (st >= nstages) { more = false; break; }
+      const int s_nxt = a_slot + 1 == RA ? 0 : a_slot + 1;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int t = 2 * j + q;              // k-step within the group = its ring slot (static)
+        const int t_iss = (t + RB - 1) % RB;  // the slot the previous k-step freed: k-step t + RB - 1 goes there
+        b_issue((q + 1) & 1, t_iss);
+        if (((q + 1) & 1) == 1) b_advance();
+        if (q == 0) {  // weights: stage st + 1 from the staging registers into its slot (last read two stages ago), stage st + 2 into the registers
+          a_store(s_nxt);
+          a_load(st + 2);
+        }
+        if (q == 1) {  // the stage barrier: from here on the rolling reads fetch stage st + 1's fragments
+          if constexpr ((ABL & 4) == 0) __syncthreads();
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr ((ABL & 8) != 0) asm volatile("" :: "v"(af[mi]), "v"(bq[t]));
+          else
+          acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bq[t], acc[mi], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (q == 0) a_frag(a_slot, 1, mi); else a_frag(s_nxt, 0, mi);
+        }
+      }
+      a_slot = s_nxt;
+    }
+  }
+
+  if constexpr ((ABL & 16) != 0) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) asm volatile("" :: "v"(acc[mi]));
+    return;
+  }
+  // epilogue: as the kernels above (loads of channel group mi + 1 before the stores of group mi; 16-byte accesses through
+  // v_permlane32_swap), for this wave's 256 couts x 32 pixels
+  const int cb0 = cout0 / 8;
+  auto swap32 = [](unsigned &lo_keeps, unsigned &hi_keeps) {
+    const auto r = __builtin_amdgcn_permlane32_swap(lo_keeps, hi_keeps, false, false);
+    lo_keeps = r[0]; hi_keeps = r[1];
+  };
+  const long long pix = p0 + l31;
+  f32x4 bias[2][4];
+  u32x4 rr[2][2];
+  auto preload = [&](int mi, int buf) {
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int cb = cb0 + mi * 4 + gq;
+      bias[buf][gq] = cb < a.Cb_out ? *reinterpret_cast<const f32x4 *>(a.bpk + cb * 8 + half * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (a.res) {
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        const int cb = cb0 + mi * 4 + gp * 2 + half;
+        rr[buf][gp] = (pix < a.P && cb < a.Cb_out) ? *reinterpret_cast<const u32x4 *>(a.res + ((size_t)cb * a.pitch_out + (size_t)pix) * 8)
+                                                   : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  };
+  preload(0, 0);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int buf = mi & 1;
+    if (mi + 1 < MI) preload(mi + 1, buf ^ 1);
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+      f32x4 va, vb;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        va[e] = acc[mi][(gp * 2) * 4 + e] + bias[buf][gp * 2][e];
+        vb[e] = acc[mi][(gp * 2 + 1) * 4 + e] + bias[buf][gp * 2 + 1][e];
+      }
+      if (a.res) {
+        unsigned r0 = rr[buf][gp][0], r1 = rr[buf][gp][1], r2 = rr[buf][gp][2], r3 = rr[buf][gp][3];
+        swap32(r0, r2);
+        swap32(r1, r3);
+        va[0] += bf2f((bf16_t)(r0 & 0xffffu)); va[1] += bf2f((bf16_t)(r0 >> 16));
+        va[2] += bf2f((bf16_t)(r1 & 0xffffu)); va[3] += bf2f((bf16_t)(r1 >> 16));
+        vb[0] += bf2f((bf16_t)(r2 & 0xffffu)); vb[1] += bf2f((bf16_t)(r2 >> 16));
+        vb[2] += bf2f((bf16_t)(r3 & 0xffffu)); vb[3] += bf2f((bf16_t)(r3 >> 16));
+      }
+      {
+        const int cba = cb0 + mi * 4 + gp * 2;
+        const bool rla = a.relu && !(cba >= a.norelu_cb0 && cba < a.norelu_cb1), rlb = a.relu && !(cba + 1 >= a.norelu_cb0 && cba + 1 < a.norelu_cb1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { va[e] = (rla && va[e] < 0.0f) ? 0.0f : va[e]; vb[e] = (rlb && vb[e] < 0.0f) ? 0.0f : vb[e]; }
+      }
+      unsigned ax = (unsigned)f2bf(va[0]) | ((unsigned)f2bf(va[1]) << 16), ay = (unsigned)f2bf(va[2]) | ((unsigned)f2bf(va[3]) << 16);
+      unsigned bx = (unsigned)f2bf(vb[0]) | ((unsigned)f2bf(vb[1]) << 16), by = (unsigned)f2bf(vb[2]) | ((unsigned)f2bf(vb[3]) << 16);
+      swap32(ax, bx);
+      swap32(ay, by);
+      const int cb = cb0 + mi * 4 + gp * 2 + half;
+      if (pix < a.P && cb < a.Cb_out) *reinterpret_cast<u32x4 *>(a.out + ((size_t)cb * a.pitch_out + (size_t)pix) * 8) = u32x4{ax, ay, bx, by};
+    }
+  }
+}
+
+template <int DS, int ABL = 0>
+__global__ __launch_bounds__(512, 1) void conv2d_c8i_bf16_bdir8_kernel(GConvArgsB a, int nx, int ny) {
+  __shared__ __attribute__((aligned(16))) u32x4 lds_a[3][4 * 256];  // [slot][chunk][cout row] 16-byte records
+  const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+  const int ty = kq % ny, tx = (kq / ny) * 8 + xcd;  // a pixel tile's cout tiles back to back on one XCD
+  if (tx >= nx) return;
+  const int mi_cnt = (a.Cb_out * 8 - ty * 256 + 31) / 32;  // valid 32-cout sub-tiles of this block (block-uniform)
+  if (mi_cnt > 6) bdir8_body<DS, 8, ABL>(a, lds_a, tx, ty);
+  else if (mi_cnt > 4) bdir8_body<DS, 6, ABL>(a, lds_a, tx, ty);
+  else if (mi_cnt > 2) bdir8_body<DS, 4, ABL>(a, lds_a, tx, ty);
+  else bdir8_body<DS, 2, ABL>(a, lds_a, tx, ty);
+}
+
+#endif  // MPN_DEBUG_HOOKS (bdir8)
 
 #ifdef MPN_DEBUG_HOOKS  // measured no faster than the compiler-counted form (4.73-4.78 vs 4.73 ms per Inception tower): kept in the debug flavour only
 // Second form of the same kernel: every memory operation of the K loop is issued by inline asm and counted by hand.  Why: vmcnt retires
@@ -2238,6 +2518,7 @@ MPN_KNOB(int, g_bf16_nch, 4);   // mpn_debug_set_bf16_nch: 8 = 64-channel stages
 #endif
 MPN_KNOB(int, g_bf16_bdir, 1);  // mpn_debug_set_bf16_bdir: 1 = conv2d_c8i_bf16_bdir_kernel for the large layers it measured faster on (all but strided pointwise ones), 0 = never (the LDS-DMA kernel), 2 = every eligible large layer
 #ifdef MPN_DEBUG_HOOKS
+MPN_KNOB(int, g_bf16_bdir_abl, 0);  // mpn_debug_set_bf16_bdir_abl: the B-direct kernel's ABL knock-outs (only in -DMPN_BF16_ABLATE builds)
 MPN_KNOB(int, g_bf16_bdir_ver, 1);  // mpn_debug_set_bf16_bdir_ver: 1 = compiler-counted form <3>, 2 / 3 = hand-counted form <3> / <4> (debug flavour only)
 #endif
 MPN_KNOB(int, g_roi_invariant, 1);  // mpn_debug_set_roi_invariant: 0 = per-ROI layers pick kernel / split by batch size as round 3 did (tests, timing)
@@ -2276,9 +2557,31 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
       const int nx = (int)((b.P + 255) / 256), ny = b.CoutP / 128;
       const dim3 gridd((unsigned)(((nx + 7) / 8) * 8 * ny));
 #ifdef MPN_DEBUG_HOOKS
+      if (g_bf16_bdir_ver == 8) {
+        const int ny8 = (b.CoutP + 255) / 256;
+        const dim3 grid8((unsigned)(((nx + 7) / 8) * 8 * ny8));
+#ifdef MPN_BF16_ABLATE
+#define MPN_BDIR8_ABL(v) if (g_bf16_bdir_abl == v) hipLaunchKernelGGL((conv2d_c8i_bf16_bdir8_kernel<4, v>), grid8, dim3(512), 0, s, b, nx, ny8); else
+        MPN_BDIR8_ABL(1) MPN_BDIR8_ABL(2) MPN_BDIR8_ABL(8) MPN_BDIR8_ABL(16) MPN_BDIR8_ABL(32) MPN_BDIR8_ABL(7) MPN_BDIR8_ABL(23) MPN_BDIR8_ABL(24)
+#undef MPN_BDIR8_ABL
+#endif
+        if (g_bf16_bdir_abl == 1000) hipLaunchKernelGGL((conv2d_c8i_bf16_bdir8_kernel<8>), grid8, dim3(512), 0, s, b, nx, ny8);
+        else if (g_bf16_bdir_abl == 1001) hipLaunchKernelGGL((conv2d_c8i_bf16_bdir8_kernel<6>), grid8, dim3(512), 0, s, b, nx, ny8);
+        else
+        hipLaunchKernelGGL((conv2d_c8i_bf16_bdir8_kernel<4>), grid8, dim3(512), 0, s, b, nx, ny8);
+        MPN_CHECK_LAUNCH();
+        return MPN_OK;
+      }
+#endif
+#ifdef MPN_DEBUG_HOOKS
       if (g_bf16_bdir_ver == 2) hipLaunchKernelGGL((conv2d_c8i_bf16_bdir2_kernel<3>), gridd, dim3(256), 0, s, b, nx, ny);
       else if (g_bf16_bdir_ver == 3) hipLaunchKernelGGL((conv2d_c8i_bf16_bdir2_kernel<4>), gridd, dim3(256), 0, s, b, nx, ny);
       else
+#ifdef MPN_BF16_ABLATE
+#define MPN_BDIR_ABL(v) if (g_bf16_bdir_abl == v) hipLaunchKernelGGL((conv2d_c8i_bf16_bdir_kernel<3, v>), gridd, dim3(256), 0, s, b, nx, ny); else
+      MPN_BDIR_ABL(1) MPN_BDIR_ABL(2) MPN_BDIR_ABL(4) MPN_BDIR_ABL(8) MPN_BDIR_ABL(16) MPN_BDIR_ABL(32) MPN_BDIR_ABL(7) MPN_BDIR_ABL(23) MPN_BDIR_ABL(6) MPN_BDIR_ABL(24) MPN_BDIR_ABL(36) MPN_BDIR_ABL(64) MPN_BDIR_ABL(192) MPN_BDIR_ABL(194) MPN_BDIR_ABL(198) MPN_BDIR_ABL(70)
+#undef MPN_BDIR_ABL
+#endif
 #endif
       hipLaunchKernelGGL((conv2d_c8i_bf16_bdir_kernel<3>), gridd, dim3(256), 0, s, b, nx, ny);
       MPN_CHECK_LAUNCH();
@@ -3231,6 +3534,7 @@ extern "C" void mpn_debug_set_roi_invariant(int v) { mpn::g_roi_invariant = v; }
 extern "C" void mpn_debug_set_bf16_exp(int v) { mpn::g_bf16_exp = v; }
 extern "C" void mpn_debug_set_bf16_bdir(int v) { mpn::g_bf16_bdir = v; }
 extern "C" void mpn_debug_set_bf16_bdir_ver(int v) { mpn::g_bf16_bdir_ver = v; }
+extern "C" void mpn_debug_set_bf16_bdir_abl(int v) { mpn::g_bf16_bdir_abl = v; }
 extern "C" void mpn_debug_set_bf16_nch(int v) { mpn::g_bf16_nch = v; }
 extern "C" void mpn_debug_set_bf16_dma_tn(int v) { mpn::g_bf16_dma_tn = v; }
 extern "C" void mpn_debug_set_bf16_split_target(int v) { mpn::g_bf16_split_target = v; }

@@ -158,9 +158,9 @@ def test_resnet_bf16_b_direct_kernel_forced_and_bit_identical(O, dev, bt, blocks
     chain per output in the same K order) — which is what lets either kernel serve a ROI batch of any size."""
     from multipathnet_amd import models
     outs = []
-    for bdir in (2, 0):
-        with hooks(bf16_dma=2, bf16_bdir=bdir):
-            if bdir == 2:
+    for bdir, ver in ((2, 1), (0, 1), (2, 8)):   # ver 8: the 8-wave / 256-cout form (debug flavour only: measured slower, kept for the record)
+        with hooks(bf16_dma=2, bf16_bdir=bdir, bf16_bdir_ver=ver):
+            if bdir == 2 and ver == 1:
                 _bf16_case(O, dev, bt, blocks, width)
             H, W, N, C = 97, 131, 37, 6
             R = models.synthetic_resnet_params(depth=0, n_classes=C, base_width=width, blocks=blocks, block_type=bt, seed=23)
@@ -169,7 +169,8 @@ def test_resnet_bf16_b_direct_kernel_forced_and_bit_identical(O, dev, bt, blocks
             s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
             outs.append((s.clone(), b.clone()))
             del net
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1])
 
 
 def _bf16_case(O, dev, bt, blocks, width):

@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/g17
+for v in 0 1 2 4 8 16 32 7 23 6 24 36; do
+  echo "=== variant: bf16_bdir=2 bf16_bdir_abl=$v"
+  timeout 200 python tools/bench_conv_bf16.py all bf16_bdir=2 bf16_bdir_abl=$v 2>&1 | grep -v amdgpu.ids
+done > gpurun_out/g17/abl.txt
+tail -5 gpurun_out/g17/abl.txt
