@@ -906,10 +906,11 @@ __global__ __launch_bounds__(256, ((MI == 4 && NI == 4) || NCH == 8) ? 1 : 2) vo
 // 2 no stage barrier, 3 no MFMAs (operands still waited for), 4 no epilogue, 5 pixel loads all from one resident 1-KiB window
 // MI = 32-cout sub-tiles the block multiplies: 4, or 2 for a ragged last cout tile with <= 64 valid couts (192- / 320- / 1344-cout
 // layers: their last tile no longer multiplies 64 rows of zero weights)
-template <int DS, int ABL, int MI>
-__device__ __forceinline__ void bdir_body(const GConvArgsB &a, u32x4 (*lds_a)[4 * 128], const int tx, const int ty) {
+// PP = 1: the ping-pong form (conv2d_c8i_bf16_bdpp_kernel below): the block holds TWO such 4-wave groups, tid / wave are group-local
+template <int DS, int ABL, int MI, int PP = 0>
+__device__ __forceinline__ void bdir_body(const GConvArgsB &a, u32x4 (*lds_a)[4 * 128], const int tx, const int ty, const int grp = 0) {
   constexpr int NI = 2, TM = 128, TN = 256, RA = 3, RB = 2 * DS;  // RB: B-fragment ring, in k-steps
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x & 255, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const long long p0 = (long long)tx * TN + wave * (NI * 32);
@@ -974,6 +975,11 @@ __device__ __forceinline__ void bdir_body(const GConvArgsB &a, u32x4 (*lds_a)[4 
       bq[slot][ni] = __builtin_bit_cast(bf16x8, v);
     }
   };
+  auto b_issue1 = [&](int q, int slot, int ni) {  // one fragment load (the fine-grained schedule deals them between the MFMAs)
+    const unsigned soff = (unsigned)(b_cg * 4 + 2 * q) * plane_b;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[ni], soff, 0);
+    bq[slot][ni] = __builtin_bit_cast(bf16x8, v);
+  };
   auto b_advance = [&]() {
     ++b_st;
     if (++b_cg == spt) {
@@ -998,6 +1004,11 @@ __device__ __forceinline__ void bdir_body(const GConvArgsB &a, u32x4 (*lds_a)[4 
       a_stage[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, base, 0);
     }
   };
+  auto a_load1 = [&](int st, int i) {
+    const unsigned base = (unsigned)st * 4u * w_chunk;  // wave-uniform
+    const unsigned off = st < nstages ? a_row + (a_ch + 2u * i) * w_chunk : OOB;
+    a_stage[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, base, 0);
+  };
   auto a_store = [&](int slot) {
     if constexpr ((ABL & 2) != 0) return;
 #pragma unroll
@@ -1019,6 +1030,69 @@ __device__ __forceinline__ void bdir_body(const GConvArgsB &a, u32x4 (*lds_a)[4 
     for (int mi = 0; mi < MI; ++mi) af[fs][mi] = *reinterpret_cast<const bf16x8 *>(&lds_a[slot][(2 * q + half) * TM + mi * 32 + l31]);
   };
 
+  if constexpr (PP != 0) {
+    // ---- ping-pong form.  The two groups of the block alternate, one block barrier per phase: while this group multiplies a stage
+    // (phase M: 16 MFMAs back to back, nothing else), the other group — its waves share the SIMDs one to one — does everything that is
+    // not an MFMA for its next stages (phase P: weight registers -> LDS, next weight loads, fragment ds_reads, the pixel loads DS
+    // stages ahead, their address arithmetic), and vice versa.  Group 1 runs one phase behind group 0.
+    auto phase_barrier = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // prologue (both groups at once): weights of stages 0 and 1 in LDS, of stage 2 in the staging registers; the pixel fragments of
+    // stages 0 .. DS - 1 (the whole ring) in flight; the fragments of stage 0 in registers
+    a_load(0);
+#pragma unroll
+    for (int t = 0; t < RB; ++t) {
+      b_issue(t & 1, t);
+      if (t & 1) b_advance();
+    }
+    a_store(0);
+    a_load(1);
+    a_store(1);
+    a_load(2);
+    phase_barrier();
+    a_frags(0, 0, 0);
+    a_frags(0, 1, 1);
+    if (grp == 1) phase_barrier();
+    int slot1 = 1, slot2 = 2;  // LDS slots of stages st + 1 and st + 2
+    bool more = true;
+    for (int g = 0; more; ++g) {
+#pragma unroll
+      for (int j = 0; j < DS; ++j) {
+        const int st = g * DS + j;
+        if (st >= nstages) { more = false; break; }
+        // phase M
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int m = 0; m < MI * NI; ++m) {
+            const int mi = m / NI, ni = m % NI;
+            __builtin_amdgcn_sched_barrier(0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q][mi], bq[2 * j + q][ni], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        __builtin_amdgcn_s_setprio(0);
+        phase_barrier();
+        // phase P
+        if (st + 1 < nstages) {
+          a_frags(slot1, 0, 0);
+          a_frags(slot1, 1, 1);
+          a_store(slot2);
+          a_load(st + 3);
+          b_issue(0, 2 * j);
+          b_issue(1, 2 * j + 1);
+          b_advance();
+        }
+        phase_barrier();
+        const int s0 = slot1 == 0 ? 2 : slot1 - 1;  // the slot of stage st: free for stage st + 3
+        slot1 = slot2; slot2 = s0;
+      }
+    }
+    if (grp == 0) phase_barrier();
+  } else {
   // prologue: weights of stage 0 in LDS, of stage 1 in the staging registers; pixel fragments of k-steps 0 .. RB - 2 in flight
   a_load(0);
 #pragma unroll
@@ -1043,11 +1117,19 @@ __device__ __forceinline__ void bdir_body(const GConvArgsB &a, u32x4 (*lds_a)[4 
         const int t = 2 * j + q;                         // k-step within the group = its ring slot (static)
         const int t_iss = (t + RB - 1) % RB;             // slot freed by the previous k-step: k-step t + RB - 1 goes there
         // issue side: the pixel fragments RB - 1 k-steps ahead (cursor parity: the prologue left it at k-step RB - 1 = odd)
-        b_issue((q + 1) & 1, t_iss);
-        if (((q + 1) & 1) == 1) b_advance();
+        constexpr bool FINE = (ABL & 0x1ff) == 0 || (ABL & 512) != 0;  // (the knock-out experiments keep the clumped schedule they were measured on)
+        // FINE: every load of the k-step is issued BETWEEN its MFMAs, two MFMAs apart, instead of in a clump ahead of them.  Measured
+        // on a bare loop (tools/probes/vmem_path_bw.cpp: 3 x 1-KiB loads per 8 MFMAs, L2-resident): clumped 0.97 PFLOP/s, one load
+        // every 2-3 MFMAs 1.48 — a clump from all eight waves of the CU at once backs up the vector-memory issue path and the waves
+        // stand at their loads instead of their MFMAs.
+        constexpr int T = MI * NI;
+        constexpr int PB0 = T == 8 ? 1 : 0, PB1 = T == 8 ? 3 : 1, PA0 = T == 8 ? 5 : 2, PA1 = T == 8 ? 6 : 3;  // the MFMA each load follows
+        if constexpr (!FINE) {
+          b_issue((q + 1) & 1, t_iss);
+          if (((q + 1) & 1) == 1) b_advance();
+        }
         if (q == 0) {  // weights: stage st + 1 from the staging registers into its slot (last read two stages ago), stage st + 2 into the registers
-          a_store(s_nxt);
-          a_load(st + 2);
+          if constexpr (!FINE) { a_store(s_nxt); a_load(st + 2); }
         }
         if (q == 1) {  // the stage barrier sits before the last k-step's MFMAs (their operands are in registers already)
           if constexpr ((ABL & 4) == 0) __syncthreads();
@@ -1056,6 +1138,12 @@ __device__ __forceinline__ void bdir_body(const GConvArgsB &a, u32x4 (*lds_a)[4 
 #pragma unroll
         for (int m = 0; m < MI * NI; ++m) {
           const int mi = m / NI, ni = m % NI;
+          if constexpr (FINE) {
+            if (m == PB0 + 1) b_issue1((q + 1) & 1, t_iss, 0);
+            if (m == PB1 + 1) { b_issue1((q + 1) & 1, t_iss, 1); if (((q + 1) & 1) == 1) b_advance(); if (q == 0) a_store(s_nxt); }
+            if (q == 0 && m == PA0 + 1) a_load1(st + 2, 0);
+            if (q == 0 && m == PA1 + 1 && PA1 + 1 < T) a_load1(st + 2, 1);
+          }
           __builtin_amdgcn_sched_barrier(0);
           if constexpr ((ABL & 8) != 0) asm volatile("" :: "v"(af[q][mi]), "v"(bq[t][ni]));
           else if constexpr ((ABL & 64) != 0) {  // MFMAs on a constant pixel fragment: the loads run beside them without feeding them
@@ -1065,11 +1153,13 @@ __device__ __forceinline__ void bdir_body(const GConvArgsB &a, u32x4 (*lds_a)[4 
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[q][mi], bq[t][ni], acc[mi][ni], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           if (q == 0 && m == 0) a_frags(a_slot, 1, 1);
+          if constexpr (FINE) { if (q == 0 && m == T - 1 && PA1 + 1 >= T) a_load1(st + 2, 1); }
         }
       }
       a_slot = s_nxt;
     }
   }
+  }  // PP
 
   if constexpr ((ABL & 16) != 0) {
 #pragma unroll
@@ -1157,6 +1247,30 @@ __global__ __launch_bounds__(256, 2) void conv2d_c8i_bf16_bdir_kernel(GConvArgsB
   if (a.Cb_out * 8 - ty * 128 > 64) bdir_body<DS, ABL, 4>(a, lds_a, tx, ty);
   else bdir_body<DS, ABL, 2>(a, lds_a, tx, ty);
 }
+
+#ifdef MPN_DEBUG_HOOKS  // measured 13 % SLOWER than two free-running blocks per CU: debug flavour only (profiles/r04_bf16_conv_bdir_ablation.txt, F)
+// The ping-pong form: 512 threads = two 4-wave groups, each a B-direct block of its own (own tile, own weight ring), phase-locked
+// by the block barrier so that one group's MFMA phase always runs beside the other group's memory phase (bdir_body<.., PP = 1>).
+// Tiles: virtual block v = 2 * (blockIdx.x >> 3) + group on XCD blockIdx.x & 7 — the two groups normally hold neighbouring cout
+// tiles of ONE pixel tile (the second group's pixel loads hit the lines the first group just fetched).
+// Result: bit-identical, 4.65 vs 4.11 ms per Inception tower at a HIGHER clock (2.35 vs 2.2 GHz: the matrix pipe idles more) — a
+// phase lasts as long as the memory path needs for a stage's 24 KiB, not as long as its 16 MFMAs: the vector-memory path
+// (~30 B / clock / CU measured with the loads alone) is the limit, and lock-stepping the groups only adds the barrier skew.
+template <int DS>
+__global__ __launch_bounds__(512, 1) void conv2d_c8i_bf16_bdpp_kernel(GConvArgsB a, int nx, int ny) {
+  __shared__ __attribute__((aligned(16))) u32x4 lds_a[2][3][4 * 128];  // [group][slot][chunk][cout row] 16-byte records
+  const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  const int xcd = blockIdx.x & 7, kq = (int)(blockIdx.x >> 3) * 2 + grp;
+  const int ty = kq % ny, tx = (kq / ny) * 8 + xcd;
+  if (tx >= nx) {  // this group has no tile: keep the other group's barrier count
+    const int nb = 2 + 2 * (a.KH * a.KW * (a.nch2 / 4));
+    for (int i = 0; i < nb; ++i) __syncthreads();
+    return;
+  }
+  if (a.Cb_out * 8 - ty * 128 > 64) bdir_body<DS, 0, 4, 1>(a, lds_a[grp], tx, ty, grp);
+  else bdir_body<DS, 0, 2, 1>(a, lds_a[grp], tx, ty, grp);
+}
+#endif  // MPN_DEBUG_HOOKS (ping-pong form)
 
 #ifdef MPN_DEBUG_HOOKS  // measured 12 % SLOWER than the 4-wave kernel above: debug flavour only (profiles/r04_bf16_conv_bdir_ablation.txt)
 // ---- round 4, an experiment that did not pay: B-direct with 256 couts per block ("bdir8") ---------------------------------------
@@ -2557,6 +2671,13 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
       const int nx = (int)((b.P + 255) / 256), ny = b.CoutP / 128;
       const dim3 gridd((unsigned)(((nx + 7) / 8) * 8 * ny));
 #ifdef MPN_DEBUG_HOOKS
+      if (g_bf16_bdir_ver == 9) {
+        const int nxq = (nx + 7) / 8;
+        const dim3 gridp((unsigned)(8 * ((nxq * ny + 1) / 2)));
+        hipLaunchKernelGGL((conv2d_c8i_bf16_bdpp_kernel<3>), gridp, dim3(512), 0, s, b, nx, ny);
+        MPN_CHECK_LAUNCH();
+        return MPN_OK;
+      }
       if (g_bf16_bdir_ver == 8) {
         const int ny8 = (b.CoutP + 255) / 256;
         const dim3 grid8((unsigned)(((nx + 7) / 8) * 8 * ny8));
@@ -2579,7 +2700,7 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
       else
 #ifdef MPN_BF16_ABLATE
 #define MPN_BDIR_ABL(v) if (g_bf16_bdir_abl == v) hipLaunchKernelGGL((conv2d_c8i_bf16_bdir_kernel<3, v>), gridd, dim3(256), 0, s, b, nx, ny); else
-      MPN_BDIR_ABL(1) MPN_BDIR_ABL(2) MPN_BDIR_ABL(4) MPN_BDIR_ABL(8) MPN_BDIR_ABL(16) MPN_BDIR_ABL(32) MPN_BDIR_ABL(7) MPN_BDIR_ABL(23) MPN_BDIR_ABL(6) MPN_BDIR_ABL(24) MPN_BDIR_ABL(36) MPN_BDIR_ABL(64) MPN_BDIR_ABL(192) MPN_BDIR_ABL(194) MPN_BDIR_ABL(198) MPN_BDIR_ABL(70)
+      MPN_BDIR_ABL(1) MPN_BDIR_ABL(2) MPN_BDIR_ABL(4) MPN_BDIR_ABL(8) MPN_BDIR_ABL(16) MPN_BDIR_ABL(32) MPN_BDIR_ABL(7) MPN_BDIR_ABL(23) MPN_BDIR_ABL(6) MPN_BDIR_ABL(24) MPN_BDIR_ABL(36) MPN_BDIR_ABL(64) MPN_BDIR_ABL(192) MPN_BDIR_ABL(194) MPN_BDIR_ABL(198) MPN_BDIR_ABL(70) MPN_BDIR_ABL(256)
 #undef MPN_BDIR_ABL
 #endif
 #endif
