@@ -65,6 +65,17 @@ __global__ __launch_bounds__(256, 2) void k(const u32x4* __restrict__ src, unsig
 #pragma unroll
             for (int t = 0; t < (j < 2 ? 3 : 2) && MF; ++t) mfma1(j * 3 + t);
           }
+        } else if (SCH == 4) {  // 2 loads per 8 MFMAs, dealt (a 256 x 256 LDS-shared tile's 7.6 KiB per MFLOP)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            load1(g * 3 + j);
+#pragma unroll
+            for (int t = 0; t < 4 && MF; ++t) mfma1(j * 4 + t);
+          }
+        } else if (SCH == 5) {  // 1 load per 8 MFMAs
+          load1(g * 3);
+#pragma unroll
+          for (int t = 0; t < MF; ++t) mfma1(t);
         } else {
 #pragma unroll
           for (int j = 0; j < 3; ++j) load1(g * 3 + j);
@@ -98,7 +109,7 @@ template <int MF, int KIND, int SCH = 0> void run(const u32x4* src, size_t windo
     (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     if (rep == 0) { iters = (int)(iters * 400.0 / ms) + 1; continue; }
-    const double bytes = KIND ? (double)blocks * 4 * iters * 12 * 1024.0 : 0.0;
+    const double bytes = KIND ? (double)blocks * 4 * iters * (SCH == 4 ? 8 : SCH == 5 ? 4 : 12) * 1024.0 : 0.0;
     const double fl = (double)blocks * 4 * iters * 4 * MF * 2.0 * 32 * 32 * 16;
     const char* kn[] = {"no loads", "-> VGPR", "-> LDS (DMA)", "ds_read_b128"};
     printf("%-24s %-13s sched %d MFMAs %d: %7.1f GB/s per CU %6.2f TB/s  MFMA %7.1f TFLOP/s   sclk %4.0f MHz  %4.0f W   -> %5.1f B/clk/CU, matrix pipe %3.0f %% busy\n", what, kn[KIND], SCH, MF,
@@ -133,4 +144,9 @@ int main() {
   // schedules (L2-resident window): 0 = 3 loads then 8 MFMAs, 1 = a load every 2-3 MFMAs, 2 = schedule 0 with s_setprio 1 over the MFMAs, 3 = 12 loads then 32 MFMAs
   run<8, 1, 1>(src, (size_t)2 << 20, out, ops, "L2 (2 MiB)"); run<8, 1, 2>(src, (size_t)2 << 20, out, ops, "L2 (2 MiB)"); run<8, 1, 3>(src, (size_t)2 << 20, out, ops, "L2 (2 MiB)");
   run<8, 2, 1>(src, (size_t)2 << 20, out, ops, "L2 (2 MiB)"); run<8, 2, 2>(src, (size_t)2 << 20, out, ops, "L2 (2 MiB)"); run<8, 2, 3>(src, (size_t)2 << 20, out, ops, "L2 (2 MiB)");
+  // fewer bytes per FLOP, dealt: 4 = 2 loads per 8 MFMAs (7.6 KiB / MFLOP), 5 = 1 load per 8 MFMAs (3.8)
+  run<8, 1, 4>(src, (size_t)2 << 20, out, ops, "L2 (2 MiB)"); run<8, 2, 4>(src, (size_t)2 << 20, out, ops, "L2 (2 MiB)");
+  run<8, 1, 5>(src, (size_t)2 << 20, out, ops, "L2 (2 MiB)"); run<8, 2, 5>(src, (size_t)2 << 20, out, ops, "L2 (2 MiB)");
+  run<8, 1, 1>(src, (size_t)16 << 20, out, ops, "L2 of 8 XCDs (16 MiB)"); run<8, 1, 4>(src, (size_t)16 << 20, out, ops, "L2 of 8 XCDs (16 MiB)");
+  run<8, 1, 1>(src, (size_t)64 << 20, out, ops, "Infinity Cache (64 MiB)"); run<8, 1, 4>(src, (size_t)64 << 20, out, ops, "Infinity Cache (64 MiB)");
 }
