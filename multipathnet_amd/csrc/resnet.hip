@@ -368,11 +368,20 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round to nearest even (finite inputs)
-  unsigned u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// fp32 -> bf16, round to nearest even: gfx950's own conversion (v_cvt_pk_bf16_f32, two values per instruction).  Every kernel of this
+// file rounds through these two helpers, so kernels that share a K order stay bit-identical to each other.  (The bit-arithmetic form
+// — add 0x7fff + lsb, shift — costs 4-5 VALU instructions per value; at 128 accumulators per lane that was 10-20 % of a convolution
+// launch: VALU work never overlaps the wave's MFMAs on this chip.)
+typedef __bf16 hwbf16x2 __attribute__((ext_vector_type(2)));
+typedef float cvtf32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {  // bits 0-15 = bf16(lo), bits 16-31 = bf16(hi)
+  const cvtf32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hwbf16x2));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf16x2(f, 0.0f) & 0xffffu); }
+// ReLU switched by a wave-uniform flag, one v_med3_f32: clamp(v, lo, +inf) with lo = 0 (ReLU) or -inf (none)
+__device__ __forceinline__ float relu_lo(bool on) { return on ? 0.0f : -__builtin_inff(); }
+__device__ __forceinline__ float clamp_lo(float v, float lo) { return __builtin_amdgcn_fmed3f(v, lo, __builtin_inff()); }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
 
 // packed bf16 weights: [tap][nch2][CoutP][8], nch2 = Cin chunks rounded up to even
@@ -870,11 +879,12 @@ __global__ __launch_bounds__(256, ((MI == 4 && NI == 4) || NCH == 8) ? 1 : 2) vo
         {
           const int cba = cb0 + mi * 4 + gp * 2;  // va: block cba, vb: block cba + 1
           const bool rla = a.relu && !(cba >= a.norelu_cb0 && cba < a.norelu_cb1), rlb = a.relu && !(cba + 1 >= a.norelu_cb0 && cba + 1 < a.norelu_cb1);
+          const float loa = relu_lo(rla), lob = relu_lo(rlb);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { va[e] = (rla && va[e] < 0.0f) ? 0.0f : va[e]; vb[e] = (rlb && vb[e] < 0.0f) ? 0.0f : vb[e]; }
+          for (int e = 0; e < 4; ++e) { va[e] = clamp_lo(va[e], loa); vb[e] = clamp_lo(vb[e], lob); }
         }
-        unsigned ax = (unsigned)f2bf(va[0]) | ((unsigned)f2bf(va[1]) << 16), ay = (unsigned)f2bf(va[2]) | ((unsigned)f2bf(va[3]) << 16);
-        unsigned bx = (unsigned)f2bf(vb[0]) | ((unsigned)f2bf(vb[1]) << 16), by = (unsigned)f2bf(vb[2]) | ((unsigned)f2bf(vb[3]) << 16);
+        unsigned ax = pack_bf16x2(va[0], va[1]), ay = pack_bf16x2(va[2], va[3]);
+        unsigned bx = pack_bf16x2(vb[0], vb[1]), by = pack_bf16x2(vb[2], vb[3]);
         swap32(ax, bx);
         swap32(ay, by);
         const int cb = cb0 + mi * 4 + gp * 2 + half;
@@ -1224,11 +1234,12 @@ __device__ __forceinline__ void bdir_body(const GConvArgsB &a, u32x4 (*lds_a)[4 
         {
           const int cba = cb0 + mi * 4 + gp * 2;
           const bool rla = a.relu && !(cba >= a.norelu_cb0 && cba < a.norelu_cb1), rlb = a.relu && !(cba + 1 >= a.norelu_cb0 && cba + 1 < a.norelu_cb1);
+          const float loa = relu_lo(rla), lob = relu_lo(rlb);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { va[e] = (rla && va[e] < 0.0f) ? 0.0f : va[e]; vb[e] = (rlb && vb[e] < 0.0f) ? 0.0f : vb[e]; }
+          for (int e = 0; e < 4; ++e) { va[e] = clamp_lo(va[e], loa); vb[e] = clamp_lo(vb[e], lob); }
         }
-        unsigned ax = (unsigned)f2bf(va[0]) | ((unsigned)f2bf(va[1]) << 16), ay = (unsigned)f2bf(va[2]) | ((unsigned)f2bf(va[3]) << 16);
-        unsigned bx = (unsigned)f2bf(vb[0]) | ((unsigned)f2bf(vb[1]) << 16), by = (unsigned)f2bf(vb[2]) | ((unsigned)f2bf(vb[3]) << 16);
+        unsigned ax = pack_bf16x2(va[0], va[1]), ay = pack_bf16x2(va[2], va[3]);
+        unsigned bx = pack_bf16x2(vb[0], vb[1]), by = pack_bf16x2(vb[2], vb[3]);
         swap32(ax, bx);
         swap32(ay, by);
         const int cb = cb0 + mi * 4 + gp * 2 + half;
@@ -1481,11 +1492,12 @@ __device__ __forceinline__ void bdir8_body(const GConvArgsB &a, u32x4 (*lds_a)[4
       {
         const int cba = cb0 + mi * 4 + gp * 2;
         const bool rla = a.relu && !(cba >= a.norelu_cb0 && cba < a.norelu_cb1), rlb = a.relu && !(cba + 1 >= a.norelu_cb0 && cba + 1 < a.norelu_cb1);
+        const float loa = relu_lo(rla), lob = relu_lo(rlb);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { va[e] = (rla && va[e] < 0.0f) ? 0.0f : va[e]; vb[e] = (rlb && vb[e] < 0.0f) ? 0.0f : vb[e]; }
+        for (int e = 0; e < 4; ++e) { va[e] = clamp_lo(va[e], loa); vb[e] = clamp_lo(vb[e], lob); }
       }
-      unsigned ax = (unsigned)f2bf(va[0]) | ((unsigned)f2bf(va[1]) << 16), ay = (unsigned)f2bf(va[2]) | ((unsigned)f2bf(va[3]) << 16);
-      unsigned bx = (unsigned)f2bf(vb[0]) | ((unsigned)f2bf(vb[1]) << 16), by = (unsigned)f2bf(vb[2]) | ((unsigned)f2bf(vb[3]) << 16);
+      unsigned ax = pack_bf16x2(va[0], va[1]), ay = pack_bf16x2(va[2], va[3]);
+      unsigned bx = pack_bf16x2(vb[0], vb[1]), by = pack_bf16x2(vb[2], vb[3]);
       swap32(ax, bx);
       swap32(ay, by);
       const int cb = cb0 + mi * 4 + gp * 2 + half;
@@ -1728,11 +1740,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_c8i_bf16_bdir2_kernel(GConvArgs
         {
           const int cba = cb0 + mi * 4 + gp * 2;
           const bool rla = a.relu && !(cba >= a.norelu_cb0 && cba < a.norelu_cb1), rlb = a.relu && !(cba + 1 >= a.norelu_cb0 && cba + 1 < a.norelu_cb1);
+          const float loa = relu_lo(rla), lob = relu_lo(rlb);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { va[e] = (rla && va[e] < 0.0f) ? 0.0f : va[e]; vb[e] = (rlb && vb[e] < 0.0f) ? 0.0f : vb[e]; }
+          for (int e = 0; e < 4; ++e) { va[e] = clamp_lo(va[e], loa); vb[e] = clamp_lo(vb[e], lob); }
         }
-        unsigned ax = (unsigned)f2bf(va[0]) | ((unsigned)f2bf(va[1]) << 16), ay = (unsigned)f2bf(va[2]) | ((unsigned)f2bf(va[3]) << 16);
-        unsigned bx = (unsigned)f2bf(vb[0]) | ((unsigned)f2bf(vb[1]) << 16), by = (unsigned)f2bf(vb[2]) | ((unsigned)f2bf(vb[3]) << 16);
+        unsigned ax = pack_bf16x2(va[0], va[1]), ay = pack_bf16x2(va[2], va[3]);
+        unsigned bx = pack_bf16x2(vb[0], vb[1]), by = pack_bf16x2(vb[2], vb[3]);
         swap32(ax, bx);
         swap32(ay, by);
         const int cb = cb0 + mi * 4 + gp * 2 + half;
@@ -1951,7 +1964,7 @@ __global__ void maxpool2d_c8i_bf16_kernel(const bf16_t *__restrict__ in, int Cb,
     }
   u32x4 o;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = (unsigned)f2bf(m[2 * e]) | ((unsigned)f2bf(m[2 * e + 1]) << 16);
+  for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(m[2 * e], m[2 * e + 1]);
   reinterpret_cast<u32x4 *>(out)[cb * pitch_out + ((size_t)b * OH + oy) * OW + ox] = o;
 }
 
@@ -2291,7 +2304,7 @@ __global__ void avgpool2d_c8i_bf16_kernel(const bf16_t *__restrict__ in, int Cb,
   }
   u32x4 o;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = (unsigned)f2bf(acc[2 * e]) | ((unsigned)f2bf(acc[2 * e + 1]) << 16);
+  for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(acc[2 * e], acc[2 * e + 1]);
   reinterpret_cast<u32x4 *>(out)[cb * pitch_out + ((size_t)b * OH + oy) * OW + ox] = o;
 }
 
@@ -2332,7 +2345,7 @@ __global__ __launch_bounds__(256) void avgpool2d_c8i_bf16_small_kernel(const bf1
   }
   u32x4 o;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = (unsigned)f2bf(acc[2 * e]) | ((unsigned)f2bf(acc[2 * e + 1]) << 16);
+  for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(acc[2 * e], acc[2 * e + 1]);
   reinterpret_cast<u32x4 *>(out)[(size_t)cb * pitch_out + (size_t)b0 * HW + t] = o;
 }
 
