@@ -600,19 +600,25 @@ __device__ __forceinline__ void glds16_s(const void *base_uniform, unsigned lane
 //           blocks = 1.5 rounds of 256 at 256 x 256).
 //   NCH = 8-channel chunks per stage: 4 (32 channels; the shapes above) or 8 (64 channels — half the barriers / waits / zero-fills per
 //           MFMA cycle; the stage doubles, so ONE block per CU: <4, 4, 8> two 64-KiB buffers, <4, 2, 8> / <2, 4, 8> three 48-KiB ones).
-template <int MI, int NI, int NCH = 4>
-__global__ __launch_bounds__(256, ((MI == 4 && NI == 4) || NCH == 8) ? 1 : 2) void conv2d_c8i_bf16_dma_kernel(GConvArgsB a, int nx, int ny) {
-  static_assert((MI == 4 || MI == 2) && (NI == 4 || NI == 2) && MI + NI >= 6 && (NCH == 4 || NCH == 8), "");
-  constexpr int TM = 64 * MI, TN = 64 * NI, NQ = NCH / 2;  // NQ = k-steps (16 channels) per stage
-  constexpr int RING = NCH == 8 ? ((MI == 4 && NI == 4) ? 2 : 3) : ((MI == 4 && NI == 4) ? 4 : 3), LOOK = RING - 1;  // stages in the ring / stages the DMA runs ahead
-  constexpr int NA = MI == 4 ? NCH : NCH / 2, NB = NI == 4 ? NCH : NCH / 2;  // weight- / pixel-chunk DMA items per wave per stage
+//   WN = waves along the pixel axis (2 along the cout axis always).  WN = 4 (round 4, <4, 2, 4, 4>, debug flavour): EIGHT waves share a 256 x 256 tile, each
+//           128 couts x 64 pixels — the bytes per FLOP of <4, 4> (7.6 KiB of operands per MFLOP through the vector-memory path instead of 11.4) with two waves
+//           per SIMD and 128 accumulator registers instead of one wave with 256; 4-deep ring (128 KiB), one block per CU, four DMA items per wave per stage,
+//           dealt one every second MFMA.  Bit-identical; measured no faster than the per-layer pick on configs[3]'s layers (1.5 block rounds).
+template <int MI, int NI, int NCH = 4, int WN = 2>
+__global__ __launch_bounds__(128 * WN, ((MI == 4 && NI == 4) || NCH == 8 || WN == 4) ? 1 : 2) void conv2d_c8i_bf16_dma_kernel(GConvArgsB a, int nx, int ny) {
+  static_assert((MI == 4 || MI == 2) && (NI == 4 || NI == 2) && MI + NI >= 6 && (NCH == 4 || NCH == 8) && (WN == 2 || (WN == 4 && MI == 4 && NI == 2 && NCH == 4)), "");
+  constexpr int NT = 128 * WN;                                 // threads
+  constexpr int TM = 64 * MI, TN = 32 * NI * WN, NQ = NCH / 2;  // NQ = k-steps (16 channels) per stage
+  constexpr bool BIG = (MI == 4 && NI == 4) || WN == 4;         // 256 x 256 tiles
+  constexpr int RING = NCH == 8 ? (BIG ? 2 : 3) : (BIG ? 4 : 3), LOOK = RING - 1;  // stages in the ring / stages the DMA runs ahead
+  constexpr int NA = NCH * TM / NT, NB = NCH * TN / NT;  // weight- / pixel-chunk DMA items per wave per stage (a wave-load = 64 rows of one chunk)
   constexpr int ITEMS = NA + NB;
   constexpr unsigned OPA = NCH * TM * 16, OPBB = NCH * TN * 16, STAGEB = OPA + OPBB;  // bytes: weights / pixels / stage
   extern __shared__ __attribute__((aligned(16))) u32x4 ring[];  // [RING][A: NCH x TM rows | B: NCH x TN rows]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   // block -> tile: a pixel tile's ny cout tiles run back to back on ONE XCD (blocks are dealt to the 8 XCDs round-robin), so the
   // gathered pixels are fetched into one L2 once
   const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
@@ -623,10 +629,11 @@ __global__ __launch_bounds__(256, ((MI == 4 && NI == 4) || NCH == 8) ? 1 : 2) vo
   const int OHW = a.OH * a.OW;
   // DMA roles (one wave-load = 64 rows of one 8-channel chunk).  A 256-row operand: wave w moves rows 64 w .. 64 w + 63 of all 4
   // chunks; a 128-row operand: wave w moves rows 64 (w & 1) .. of chunks 2 (w >> 1) and 2 (w >> 1) + 1.
-  const int arow = MI == 4 ? tid : (tid & 127);                  // this lane's weight row (cout) of the tile
-  const int ach0 = MI == 4 ? 0 : (NCH / 2) * (wave >> 1);        // its first weight chunk
-  const int prow = NI == 4 ? tid : (tid & 127);                  // this lane's pixel row of the tile
-  const int bch0 = NI == 4 ? 0 : (NCH / 2) * (wave >> 1);        // its first pixel chunk
+  constexpr int WA = TM / 64, WB = TN / 64;                      // waves per chunk of either operand (a wave-load = 64 rows of one chunk)
+  const int arow = (wave % WA) * 64 + lane;                      // this lane's weight row (cout) of the tile
+  const int ach0 = NA * (wave / WA);                             // its first weight chunk (wave-uniform)
+  const int prow = (wave % WB) * 64 + lane;                      // this lane's pixel row of the tile
+  const int bch0 = NB * (wave / WB);                             // its first pixel chunk (wave-uniform)
   const long long gpix = p0 + prow;
   const bool gvalid = gpix < a.P;
   const int gb = gvalid ? (int)(gpix / OHW) : 0;
@@ -635,8 +642,8 @@ __global__ __launch_bounds__(256, ((MI == 4 && NI == 4) || NCH == 8) ? 1 : 2) vo
   const int iy0 = goy * a.sh - a.ph, ix0 = gox * a.sw - a.pw;
   const unsigned map_off = (unsigned)gb * (unsigned)(a.H * a.W);  // records
   const unsigned ring0 = (unsigned)(size_t)((__attribute__((address_space(3))) const u32x4 *)ring);
-  const unsigned lds_a = ring0 + (unsigned)ach0 * (TM * 16u) + (unsigned)(MI == 4 ? wave : (wave & 1)) * 1024u;
-  const unsigned lds_b = ring0 + OPA + (unsigned)bch0 * (TN * 16u) + (unsigned)(NI == 4 ? wave : (wave & 1)) * 1024u;
+  const unsigned lds_a = ring0 + (unsigned)ach0 * (TM * 16u) + (unsigned)(wave % WA) * 1024u;
+  const unsigned lds_b = ring0 + OPA + (unsigned)bch0 * (TN * 16u) + (unsigned)(wave % WB) * 1024u;
   const unsigned a_lane = (unsigned)arow * 16u;
   const int spt = a.nch2 / NCH;
   const int nstages = a.KH * a.KW * spt;
@@ -691,8 +698,9 @@ __global__ __launch_bounds__(256, ((MI == 4 && NI == 4) || NCH == 8) ? 1 : 2) vo
   };
   auto wait_landed = [&](auto in_flight_tag) {  // all but the newest `in flight` stages' loads of this wave
     constexpr int n = decltype(in_flight_tag)::value * ITEMS;
-    static_assert(n == 0 || n == 6 || n == 8 || n == 12 || n == 16 || n == 24, "");
-    if constexpr (n == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    static_assert(n == 0 || n == 4 || n == 6 || n == 8 || n == 12 || n == 16 || n == 24, "");
+    if constexpr (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (n == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
     else if constexpr (n == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if constexpr (n == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -787,8 +795,13 @@ __global__ __launch_bounds__(256, ((MI == 4 && NI == 4) || NCH == 8) ? 1 : 2) vo
         if constexpr (ISSUE) {
           static_assert(ITEMS + 1 <= (NQ - 1) * MI * NI, "the DMA issue must end before the stage barrier");
           if (gt == 1) okn[LOOK - 1] = issue_begin(s_iss);
-          if (gt >= 1 && gt <= ITEMS) issue_item(gt - 1);
-          if (gt == ITEMS) issue_end();
+          if constexpr (WN == 4) {  // dealt: one DMA item every second MFMA of k-step 0 (tools/probes/vmem_path_bw.cpp: clumps cost the matrix pipe)
+            if ((gt & 1) == 1 && (gt >> 1) < ITEMS) issue_item(gt >> 1);
+            if (gt == 2 * ITEMS - 1) issue_end();
+          } else {
+            if (gt >= 1 && gt <= ITEMS) issue_item(gt - 1);
+            if (gt == ITEMS) issue_end();
+          }
         }
       }
       if (prio) __builtin_amdgcn_s_setprio(0);
@@ -2727,11 +2740,17 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
       // each: the same count); 256-cout tiles need whole 256-row weight tiles
       struct Shape { int tm, tn; };
       const Shape shapes[3] = {{256, 128}, {128, 256}, {256, 256}};  // ties go to the earlier entry
+#ifdef MPN_DEBUG_HOOKS
+      const bool w8 = g_bf16_dma_tn == 2256 && b.CoutP % 256 == 0;  // (hook) the 8-wave 256 x 256 shape: bit-identical, measured no faster than the per-layer pick (ResNet towers 1.95 vs 1.89 ms: 1.5 block rounds on 49 000 pixels), debug flavour only
+#else
+      constexpr bool w8 = false;
+#endif
       int best = -1; long long best_cost = 0;
       for (int i = 0; i < 3; ++i) {
         const Shape &sh = shapes[i];
         if (sh.tm == 256 && b.CoutP % 256 != 0) continue;
-        if (g_bf16_dma_tn && !(sh.tn == g_bf16_dma_tn % 1000 && sh.tm == (g_bf16_dma_tn >= 1000 ? 128 : 256))) continue;
+        if (w8 && !(sh.tm == 256 && sh.tn == 256)) continue;
+        if (!w8 && g_bf16_dma_tn && !(sh.tn == g_bf16_dma_tn % 1000 && sh.tm == (g_bf16_dma_tn >= 1000 ? 128 : 256))) continue;
         const long long nb = (b.P + sh.tn - 1) / sh.tn * (b.CoutP / sh.tm);
         const long long cost = (nb + 255) / 256 * sh.tm * sh.tn;
         if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
@@ -2747,6 +2766,9 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
         const size_t LDS = (size_t)ring * (nch8 ? 8 : 4) * (tm + tn) * 16;  // ring depth x stage bytes (as in the kernel)
         {
           int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<4, 4>), 4 * 32768);
+#ifdef MPN_DEBUG_HOOKS
+          if (rc_attr == MPN_OK) rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<4, 2, 4, 4>), 4 * 32768);
+#endif
           if (rc_attr == MPN_OK) rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<4, 2>), 3 * 24576);
           if (rc_attr == MPN_OK) rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(conv2d_c8i_bf16_dma_kernel<2, 4>), 3 * 24576);
 #ifdef MPN_DEBUG_HOOKS
@@ -2764,6 +2786,10 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
         if (nch8 && tm == 256 && tn == 128) hipLaunchKernelGGL((conv2d_c8i_bf16_dma_kernel<4, 2, 8>), gridd, dim3(256), LDS, s, b, nx, ny);
         else if (nch8 && tm == 128) hipLaunchKernelGGL((conv2d_c8i_bf16_dma_kernel<2, 4, 8>), gridd, dim3(256), LDS, s, b, nx, ny);
         else if (nch8) hipLaunchKernelGGL((conv2d_c8i_bf16_dma_kernel<4, 4, 8>), gridd, dim3(256), LDS, s, b, nx, ny);
+        else
+#endif
+#ifdef MPN_DEBUG_HOOKS
+        if (w8) hipLaunchKernelGGL((conv2d_c8i_bf16_dma_kernel<4, 2, 4, 4>), gridd, dim3(512), LDS, s, b, nx, ny);
         else
 #endif
         if (tm == 256 && tn == 128) hipLaunchKernelGGL((conv2d_c8i_bf16_dma_kernel<4, 2>), gridd, dim3(256), LDS, s, b, nx, ny);

@@ -139,13 +139,15 @@ def test_resnet_iterative_localisation_and_voting_run(dev):
 @pytest.mark.parametrize("bt,blocks,width,dma,tn", [("bottleneck", [1, 1, 1, 1], 16, 1, 0), ("basic", [1, 1, 1, 2], 16, 1, 0), ("bottleneck", [1, 1, 1, 1], 64, 1, 0),
                                                     ("bottleneck", [1, 1, 1, 1], 64, 2, 256), ("basic", [1, 1, 1, 2], 64, 2, 256),
                                                     ("bottleneck", [1, 1, 1, 1], 64, 2, 128), ("basic", [1, 1, 1, 2], 64, 2, 128),
-                                                    ("bottleneck", [1, 1, 1, 1], 64, 2, 1256), ("basic", [1, 1, 1, 2], 64, 2, 1256)])
+                                                    ("bottleneck", [1, 1, 1, 1], 64, 2, 1256), ("basic", [1, 1, 1, 2], 64, 2, 1256),
+                                                    ("bottleneck", [1, 1, 1, 1], 64, 2, 2256), ("basic", [1, 1, 1, 2], 64, 2, 2256)])
 def test_resnet_bf16_vs_bf16_oracle_and_fp32(O, dev, bt, blocks, width, dma, tn):
     """bf16 graph (bf16 activations / weights, fp32 accumulate): against the oracle run with the same roundings (weights, the
     transformed image and every layer output rounded to bf16) the scores agree to bf16 accumulation-order noise; against
     the fp32 oracle they agree to bf16 precision.  width 64 exercises the 32-channel-per-stage kernel variant (widths 16: 16-channel);
     dma=2 forces the 256-cout LDS-DMA kernel onto every eligible layer (by default only layers with >= 32768 output pixels), tn its
-    tile shape (0 = picked per layer, 128 / 256 = 256 couts x that many pixels, 1256 = 128 couts x 256 pixels)."""
+    tile shape (0 = picked per layer, 128 / 256 = 256 couts x that many pixels, 1256 = 128 couts x 256 pixels, 2256 = the eight-wave 256 x 256
+    shape of the debug flavour, where the cout count is a multiple of 256)."""
     with hooks(bf16_dma=dma, bf16_dma_tn=tn, bf16_bdir=0):   # (the B-direct kernel that large layers take by default: next test)
         _bf16_case(O, dev, bt, blocks, width)
 
