@@ -671,7 +671,12 @@ def main():
     import multipathnet_amd
     from multipathnet_amd import models, parallel
 
-    multipathnet_amd.load()
+    lib = multipathnet_amd.load()
+    if os.environ.get("MPN_HOOKS"):  # A/B TIMING ONLY, debug flavour: MPN_FLAVOUR=debug MPN_HOOKS="tower_lanes=0" python bench.py ... (printed to stderr; never the product)
+        for kv in os.environ["MPN_HOOKS"].split():
+            k, v = kv.split("=")
+            getattr(lib, "mpn_debug_set_" + k)(int(v))
+        sys.stderr.write("bench.py: DEBUG-FLAVOUR HOOKS %s — an A/B run, not a product measurement\n" % os.environ["MPN_HOOKS"])
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
     rank = int(os.environ.get("RANK", "0"))
