@@ -852,7 +852,7 @@ def main():
     per_rank = [args.steps * n_rois_cfg / t for t in state["per_rank_s"]]
     ranks_info = {"rccl_ranks": comm.rccl_ranks if comm is not None else 0,
                   "rccl_ranks_what": "ncclCommCount of the C-ABI communicator, cross-checked with ncclCommUserRank at init (mpn_comm_rccl_ranks); "
-                                     "0 = no RCCL communicator (one rank, or the fallback / share-GPU test paths)",
+                                     "0 = no RCCL communicator (one rank, or the fallback / share-GPU test paths); -1 = this RCCL has no ncclCommCount: unverified",
                   "per_rank_proposals_per_s": {"min": round(min(per_rank), 1), "max": round(max(per_rank), 1),
                                                "all": [round(v, 1) for v in per_rank]}}
     dt_res = min(timed(make_step(False)) for _ in range(2))  # inputs already resident in HBM (auxiliary figure: best of two passes)

@@ -418,7 +418,8 @@ int mpn_comm_init_rank(const void *id128, int world, int rank, mpn_comm **out);
 int mpn_comm_init_all(int n_dev, const int *h_devices, mpn_comm **out);
 int mpn_comm_world(const mpn_comm *c);
 int mpn_comm_rank(const mpn_comm *c);
-/* What RCCL ITSELF reports for the communicator (ncclCommCount), 0 when there is none (world 1 without an id).  Both init entries
+/* What RCCL ITSELF reports for the communicator (ncclCommCount), 0 when there is none (world 1 without an id), -1 when the loaded RCCL
+ * has no ncclCommCount symbol (nothing was cross-checked: UNVERIFIED, never the caller's own world size).  Both init entries
  * cross-check ncclCommCount / ncclCommUserRank against the caller's (world, rank) and fail with MPN_ENCCL on a mismatch, and
  * mpn_comm_init_rank waits a bounded time for its peers (MPN_COMM_INIT_TIMEOUT_S, default 120 s) instead of hanging: a multi-GPU
  * run can state — and a bench line can carry — how many ranks RCCL really saw (test_runner.lua:55-66: worker k IS GPU k). */

@@ -89,7 +89,7 @@ using namespace mpn;
 struct mpn_comm {
   ncclComm_t comm = nullptr;
   int world = 1, rank = 0, device = 0;
-  int rccl_ranks = 0;      // ncclCommCount of `comm` (0: no RCCL communicator — world 1 without an id)
+  int rccl_ranks = 0;      // ncclCommCount of `comm` (0: no RCCL communicator — world 1 without an id; -1: the RCCL has no ncclCommCount, unverified)
   float *send = nullptr;   // this rank's packed record
   size_t send_floats = 0;
 };
@@ -115,7 +115,7 @@ static int verify_comm(mpn_comm *c, const char *who) {
     c->rccl_ranks = n;
     if (n != c->world) { set_error("%s: RCCL built a communicator of %d ranks, %d were asked for", who, n, c->world); return MPN_ENCCL; }
   } else {
-    c->rccl_ranks = c->world;  // an RCCL without ncclCommCount: nothing to cross-check
+    c->rccl_ranks = -1;  // an RCCL without ncclCommCount: nothing was cross-checked — reported as -1 (unverified), never as the world size
   }
   if (g_rccl.CommUserRank) {
     int ur = -1;

@@ -9,6 +9,7 @@
 // needed: all ROIs go through each GEMM at once (rows are independent, results identical), so the
 // fc weights stream from HBM once per image instead of twice.
 #include <cstdlib>
+#include <iterator>
 #include <map>
 #include <string>
 #include <tuple>
@@ -300,8 +301,13 @@ struct mpn_frcnn {
       return std::tie(kind, a, b, c, d, i0, i1, i2, i3) < std::tie(o.kind, o.a, o.b, o.c, o.d, o.i0, o.i1, o.i2, o.i3);
     }
   };
-  struct GraphEntry { hipGraphExec_t exec = nullptr; unsigned long long gen = 0; bool failed = false; int seen = 0; };
+  struct GraphEntry { hipGraphExec_t exec = nullptr; unsigned long long gen = 0, last_use = 0; bool failed = false; int seen = 0; };
+  unsigned long long graph_clock = 0;
   std::map<GraphKey, GraphEntry> graphs;
+  // the last caller-pointer key seen ONCE per segment kind: such a key enters `graphs` only at its second consecutive sighting, so a host
+  // that hands in fresh buffers every call never occupies the cache
+  GraphKey unseen[4] = {};
+  bool unseen_valid[4] = {false, false, false, false};
   int graphs_on = 0;                 // mpn_frcnn_set_graphs / MPN_GRAPHS (opt-in: see create_impl)
   hipStream_t cap_stream = nullptr;  // capture happens here (the caller's stream may be the legacy NULL stream, which cannot capture)
   int seg_shape[4][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}, {-1, -1, -1, -1}, {-1, -1, -1, -1}};  // shape of the last execution per segment kind
@@ -810,9 +816,9 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const 
       const size_t need = (size_t)3 * H * W * sizeof(float), need_t = (size_t)3 * H0 * W * sizeof(float);
       if (need > p->scaled_bytes || need_t > p->scale_tmp_bytes) {
         MPN_CHECK_HIP(hipStreamSynchronize(s));
+        bump_alloc_generation();  // BEFORE the frees: a hipMalloc that fails below must not leave captured graphs holding a freed pointer
         if (need > p->scaled_bytes) { if (p->scaled) (void)hipFree(p->scaled); p->scaled = nullptr; p->scaled_bytes = 0; MPN_CHECK_HIP(hipMalloc(&p->scaled, need)); p->scaled_bytes = need; }
         if (need_t > p->scale_tmp_bytes) { if (p->scale_tmp) (void)hipFree(p->scale_tmp); p->scale_tmp = nullptr; p->scale_tmp_bytes = 0; MPN_CHECK_HIP(hipMalloc(&p->scale_tmp, need_t)); p->scale_tmp_bytes = need_t; }
-        bump_alloc_generation();
       }
       rc = mpn_image_scale(d_image, 3, H0, W0, H, W, p->scale_tmp, p->scaled, s);
       if (rc) return rc;
@@ -925,11 +931,29 @@ static int run_segment(mpn_frcnn *p, int kind, const mpn_frcnn::GraphKey &key, c
   };
   if (!p->graphs_on || p->prof) return direct();
   auto it = p->graphs.find(key);
+  int seen_before = 0;
   if (it == p->graphs.end()) {
-    if (p->graphs.size() >= kMaxGraphs) return direct();
+    if (!stable_ptrs) {  // first sighting of caller-provided pointers: remember the key in the side slot only
+      const mpn_frcnn::GraphKey &u = p->unseen[kind];
+      const bool again = p->unseen_valid[kind] && !(u < key) && !(key < u);
+      if (!again) { p->unseen[kind] = key; p->unseen_valid[kind] = true; return direct(); }
+      p->unseen_valid[kind] = false;
+      seen_before = 1;
+    }
+    if (p->graphs.size() >= kMaxGraphs) {  // full: drop the entries that hold no executable graph (failed / never captured) before giving up
+      for (auto j = p->graphs.begin(); j != p->graphs.end();) j = j->second.exec ? std::next(j) : p->graphs.erase(j);
+      if (p->graphs.size() >= kMaxGraphs) {  // all live: evict the least recently used one
+        auto lru = p->graphs.begin();
+        for (auto j = p->graphs.begin(); j != p->graphs.end(); ++j) if (j->second.last_use < lru->second.last_use) lru = j;
+        (void)hipGraphExecDestroy(lru->second.exec);
+        p->graphs.erase(lru);
+      }
+    }
     it = p->graphs.emplace(key, mpn_frcnn::GraphEntry()).first;
+    it->second.seen = seen_before;
   }
   mpn_frcnn::GraphEntry &e = it->second;
+  e.last_use = ++p->graph_clock;
   if (e.exec && e.gen != alloc_generation()) { (void)hipGraphExecDestroy(e.exec); e.exec = nullptr; }  // a library buffer was replaced since
   if (e.exec && same_shape) {
     MPN_CHECK_HIP(hipGraphLaunch(e.exec, s));
@@ -1193,11 +1217,11 @@ static int shard_buf(mpn_frcnn *p, int i, size_t floats, hipStream_t s) {
   const size_t need = floats * sizeof(float);
   if (need <= p->sh_bytes[i]) return MPN_OK;
   MPN_CHECK_HIP(hipStreamSynchronize(s));
+  bump_alloc_generation();  // before the free: see run_detect's regrow
   if (p->sh_buf[i]) (void)hipFree(p->sh_buf[i]);
   p->sh_buf[i] = nullptr; p->sh_bytes[i] = 0;
   MPN_CHECK_HIP(hipMalloc(&p->sh_buf[i], need));
   p->sh_bytes[i] = need;
-  bump_alloc_generation();
   return MPN_OK;
 }
 
@@ -1275,13 +1299,13 @@ extern "C" int mpn_frcnn_test_one_pipelined_host(mpn_frcnn *p, const float *h_im
   if (img_n > p->stage_cap[b]) {  // image staging grows on demand (getImages may be handed images larger than max_h x max_w)
     MPN_CHECK_HIP(hipStreamSynchronize(p->copy));
     MPN_CHECK_HIP(hipStreamSynchronize(s));
+    bump_alloc_generation();  // before the free: see run_detect's regrow
     if (p->stage_img[b]) (void)hipFree(p->stage_img[b]);
     p->stage_img[b] = nullptr; p->stage_cap[b] = 0;
     size_t cap = (size_t)3 * p->cfg.max_h * p->cfg.max_w;
     if (cap < img_n) cap = img_n;
     MPN_CHECK_HIP(hipMalloc(&p->stage_img[b], cap * sizeof(float)));
     p->stage_cap[b] = cap;
-    bump_alloc_generation();
   }
   // The staging set is free once the image that used it (three calls ago) has been consumed.  Waited for on the HOST, not with
   // hipStreamWaitEvent on the copy stream: a copy that depends on a compute-queue event leaves the SDMA path (measured on AlexNet,

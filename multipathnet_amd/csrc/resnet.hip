@@ -2842,7 +2842,12 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
   a.P = (long long)in.B * a.OH * a.OW;
   *o = ActI{out, in.B, c.Cout, a.OH, a.OW};
   a.pitch_in = in.pitch(); a.pitch_out = o->pitch();
-  if (c.wino && c.mos_in && !res && (inv || in.B > 1) && in.H == c.mos_h && in.W == c.mos_w && c.norelu_c1 == c.norelu_c0 && (g_graph_fuse & 128) &&
+  // Row invariance on the mosaic: the F(2x2,3x3) kernel's rounding depends on a pixel's position inside its 2x2 output tile, and ROI b
+  // sits at ((b / mx) * (H + 1) + 1, (b % mx) * (W + 1) + 1) — the same tile phase for every b only when both cell pitches are EVEN
+  // (7x7 maps: pitch 8).  Even map sizes (pooled 16 -> 8x8 maps, pitch 9) would make a row depend on its index in the batch: those take
+  // the generic kernel whenever rows must not depend on the batch (inv).
+  const bool mos_phase_ok = ((in.H + 1) % 2 == 0) && ((in.W + 1) % 2 == 0);
+  if (c.wino && c.mos_in && !res && (inv || in.B > 1) && (!inv || mos_phase_ok) && in.H == c.mos_h && in.W == c.mos_w && c.norelu_c1 == c.norelu_c0 && (g_graph_fuse & 128) &&
       ((in.B + c.mos_mx - 1) / c.mos_mx) * (in.H + 1) <= c.mos_rows) {
     // per-ROI 3x3 / stride-1 convolution (layer4's conv2 of blocks 2, 3): the batch as a mosaic image on the Winograd kernel
     const int rows = ((in.B + c.mos_mx - 1) / c.mos_mx) * (in.H + 1);

@@ -758,7 +758,8 @@ class FastRCNN(object):
         return keep, idx, n
 
     def set_graphs(self, on):
-        """captured launch graphs (mpn_frcnn_set_graphs): replay the per-image kernel chains with hipGraphLaunch (default on)"""
+        """captured launch graphs (mpn_frcnn_set_graphs): replay the per-image kernel chains with hipGraphLaunch.
+        Default OFF (opt-in: MPN_GRAPHS=1 in the environment or set_graphs(True); include/mpn.h)"""
         check(self._lib.mpn_frcnn_set_graphs(self._h, int(bool(on))), "set_graphs")
 
     def graph_stats(self):
