@@ -175,6 +175,29 @@ def cpu_baseline(P, im, boxes, rois_sample):
     return out
 
 
+# A dataset-shaped stream (Tester:test loops over images of DIFFERENT sizes, Tester_FRCNN.lua:150-157; getImages rescales each to a 600-px
+# short side with the long side capped at 1000, ImageDetect.lua:22-52): (H, W, proposals) -> the size the trunk sees
+MIXED_SIZES = [(600, 1000, 1000),    # s = 1: the bench image's size
+               (600, 800, 1000),     # s = 1, another aspect ratio
+               (480, 640, 700),      # s = 1.25 -> 600 x 800 (bilinear up)
+               (640, 480, 1000),     # portrait, s = 1.25 -> 800 x 600
+               (400, 800, 300),      # s = 1.5 would give a 1200-px long side: capped, s = 1.25 -> 500 x 1000
+               (1200, 1600, 1000)]   # s = 0.5 -> 600 x 800 (box-average down)
+
+
+def mixed_size_inputs():
+    """[(image [3,H,W] fp32 in [0,1), proposals [n,4] 1-based x1y1x2y2)] for MIXED_SIZES: seeded, same box distribution as synthetic_inputs"""
+    out = []
+    for i, (h, w, n) in enumerate(MIXED_SIZES):
+        rng = np.random.default_rng(7000 + i)
+        im = rng.random((3, h, w), dtype=np.float32)
+        c = rng.uniform([1, 1], [w, h], (n, 2))
+        wh = np.exp(rng.uniform(np.log(16), np.log(min(h, w)), (n, 2)))
+        boxes = np.clip(np.concatenate([c - wh / 2, c + wh / 2], 1), 1, [w, h, w, h]).astype(np.float32)
+        out.append((im, boxes))
+    return out
+
+
 def more_boxes(boxes, n):
     """the synthetic proposal set cut / extended (same distribution) to n rows"""
     rng = np.random.default_rng(556)

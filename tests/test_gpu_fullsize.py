@@ -263,6 +263,176 @@ def test_fullsize_trained_scale_test_one_all_classes_vs_reference_nms(O, dev, fu
     assert np.array_equal(dets[: int(n.item())].cpu().numpy(), exp)
 
 
+def iterloc_vote_check(O, dev, plain_net, fused_net, imd, bd, voting, score_pow, label):
+    """Tester_FRCNN.lua:82-99,118-124 at FULL size: opt.test_num_iterative_loc = 2 [+ test_bbox_voting] in the fused device
+    path `fused_net`; the joined 2N-row score / box tables come from the host mirror (detect.Tester_FRCNN on `plain_net`, same kernels).
+    Every foreground class's NMS over its 2N-row table must equal the reference's COMPILED nms.c (O.ref_nms) — kept count, source indices —
+    and the voted rows the compiled bbox_vote (nms.c:110-142, O.ref_bbox_vote) bit for bit, with scores:pow(p) as THFloatTensor_pow does it;
+    the top-100 record follows by utils.keep_top_k.  Returns (tied classes, rows moved by voting) for the caller's regime assertions."""
+    from multipathnet_amd import detect
+    N, C = bd.shape[0], plain_net.n_classes
+    dets, n = fused_net.test_one_async(imd, bd)
+    torch.cuda.synchronize()
+    keep, kidx, nk = [t.cpu().numpy() for t in fused_net.nms_results()]
+    assert keep.shape[1] == 2 * N
+    tester = detect.Tester_FRCNN(plain_net, opt={"test_num_iterative_loc": 2})
+    _, (output, bbox_pred) = tester.testOne(imd, bd)
+    sc, bb = output.cpu().numpy(), bbox_pred.cpu().numpy()
+    assert sc.shape == (2 * N, C) and bb.shape == (2 * N, 4 * C)
+    # the first pass is clamped to the image (Tester_FRCNN.lua:75-78), the refinement pass is not
+    assert bb[:N].min() >= 1.0
+    per, tied, moved, widest = [], 0, 0, 0
+    for cls in range(1, C):
+        sb, src = O.select_scored(sc, bb, cls, -1.5)
+        assert sb.shape[0] == 2 * N                         # thresh = -1.5: every row of both passes (Tester_FRCNN.lua:50)
+        tied += int(np.unique(sb[:, 4]).size < sb.shape[0])
+        ref = O.ref_nms(sb, 0.3)
+        mine, ridx = O.nms(sb, 0.3, return_index=True)
+        assert np.array_equal(mine, ref)
+        k = int(nk[cls - 1])
+        assert k == ref.shape[0], (label, cls, k, ref.shape[0])
+        assert np.array_equal(kidx[cls - 1, :k], src[ridx]), (label, cls)
+        widest = max(widest, k)
+        if voting:
+            votes = sb.copy()
+            if score_pow != 1.0:
+                votes[:, 4] = np.power(votes[:, 4].astype(np.float64), float(np.float32(score_pow))).astype(np.float32)
+            voted = O.ref_bbox_vote(ref, votes, 0.5)
+            assert np.array_equal(voted[:, 4], ref[:, 4])   # the kept boxes keep their NMS scores (nms.c:139)
+            moved += int((voted[:, :4] != ref[:, :4]).any(1).sum())
+            ref = voted
+        assert np.array_equal(keep[cls - 1, :k], ref, equal_nan=True), (label, cls)
+        per.append(ref)
+    kept, _ = O.keep_top_k(per, 100)
+    exp = np.concatenate([np.concatenate([k_, np.full((k_.shape[0], 1), j + 1, np.float32)], 1) for j, k_ in enumerate(kept) if k_.size])
+    nd = int(n.item())
+    assert nd == exp.shape[0] and np.array_equal(dets[:nd].cpu().numpy(), exp, equal_nan=True)
+    print("[%s] num_iter=2 voting=%s pow=%g: %d classes x %d rows, %d with bit-equal scores, widest kept table %d, %d rows moved by the vote"
+          % (label, voting, score_pow, C - 1, 2 * N, tied, widest, moved))
+    return tied, moved
+
+
+@pytest.mark.parametrize("voting,score_pow", [(False, 1.0), (True, 1.0), (True, 0.5)])
+def test_fullsize_iterative_localisation_and_voting_vs_compiled_reference(O, dev, full, scaled, voting, score_pow):
+    """configs[1] with the reference's accuracy knobs on, 600x1000 x 1000 ROIs -> 2000-row class tables, in the trained and the saturated
+    score regime (the latter: every class holds scores tied at exactly 1.0f — the wide-table tie paths and bbox_vote_batched run on them)"""
+    import bench
+    from multipathnet_amd import models
+    net = models.FastRCNN(scaled["P"], max_h=bench.H, max_w=bench.W, max_rois=bench.N_ROIS, num_iter=2, bbox_voting=voting,
+                          bbox_vote_thresh=0.5, bbox_vote_score_pow=score_pow)
+    tied, moved = iterloc_vote_check(O, dev, scaled["net"], net, full["imd"], full["bd"], voting, score_pow, "vgg16-frcnn/" + scaled["regime"])
+    if scaled["regime"] == "saturated":
+        assert tied == net.n_classes - 1
+    if voting:
+        assert moved > 0
+    del net
+    torch.cuda.empty_cache()
+
+
+def test_fullsize_2000_proposals(O, dev, full, cpu_feats):
+    """VGG-16 Fast R-CNN at N = 2000 — the proposal count the reference's own evaluation script uses (scripts/eval_fastrcnn_voc2007.sh:8-20:
+    -test_best_proposals_number 2000) — on the 600x1000 image with trained-scale heads: (1) class logits / box deltas of a 100-ROI sample
+    (drawn over all 2000 rows, incl. the last) within 1e-4 absolute of the oracle; (2) the first 1000 rows BIT-EQUAL to the 1000-ROI
+    pipeline's (rows do not depend on the batch: one fc6 GEMM over 2000 rows vs 1000); (3) all 20 classes' NMS over 2000-row tables ==
+    the reference's compiled nms.c, and the top-100 record by utils.keep_top_k."""
+    import bench
+    from multipathnet_amd import models
+    N = 2000
+    Q = models.synthetic_params(models.VGG16_CFG, pooled=7, fc_dim=4096, n_classes=bench.N_CLASSES, seed=557, head_scale="trained")
+    boxes = bench.more_boxes(full["boxes"], N)
+    assert np.array_equal(boxes[: bench.N_ROIS], full["boxes"])
+    net = models.FastRCNN(Q, max_h=bench.H, max_w=bench.W, max_rois=N)
+    bd = torch.from_numpy(boxes).to(dev)
+    s, b = net.detect(full["imd"], bd)
+    C = net.n_classes
+    cls = net.debug_tensor("cls", (N, C)).cpu().numpy()
+    raw = net.debug_tensor("bbox_raw", (N, 4 * C)).cpu().numpy()
+    idx = np.random.default_rng(2000).choice(N, N_SAMPLE, replace=False)
+    idx[0] = N - 1
+    logits, deltas = O.frcnn_head(cpu_feats["feat"], O.project_im_rois(boxes[idx], 1.0), _np_tree(Q))
+    e_l, e_d = np.abs(cls[idx] - logits).max(), np.abs(raw[idx] - deltas).max()
+    print("N = 2000, %d-ROI sample: max|dlogit| = %.3g (logits %.3g .. %.3g), max|ddelta| = %.3g" % (N_SAMPLE, e_l, cls.min(), cls.max(), e_d))
+    assert np.abs(cls).max() > 9.0 and e_l < 1e-4 and e_d < 1e-4
+    net1k = models.FastRCNN(Q, max_h=bench.H, max_w=bench.W, max_rois=bench.N_ROIS)
+    s1, b1 = net1k.detect(full["imd"], full["bd"])
+    assert torch.equal(s[: bench.N_ROIS], s1) and torch.equal(b[: bench.N_ROIS], b1)
+    del net1k
+    dets, n = net.test_one_async(full["imd"], bd)
+    torch.cuda.synchronize()
+    keep, kidx, nk = [t.cpu().numpy() for t in net.nms_results()]
+    sn, bn = s.cpu().numpy(), b.cpu().numpy()
+    per = []
+    for c in range(1, C):
+        sb, src = O.select_scored(sn, bn, c, -1.5)
+        ref = O.ref_nms(sb, 0.3)
+        mine, ridx = O.nms(sb, 0.3, return_index=True)
+        k = int(nk[c - 1])
+        assert np.array_equal(mine, ref) and k == ref.shape[0] and np.array_equal(keep[c - 1, :k], ref), c
+        assert np.array_equal(kidx[c - 1, :k], src[ridx]), c
+        per.append(ref)
+    kept, _ = O.keep_top_k(per, 100)
+    exp = np.concatenate([np.concatenate([k_, np.full((k_.shape[0], 1), j + 1, np.float32)], 1) for j, k_ in enumerate(kept) if k_.size])
+    assert np.array_equal(dets[: int(n.item())].cpu().numpy(), exp)
+    del net
+    torch.cuda.empty_cache()
+
+
+def test_fullsize_mixed_size_stream(O, dev, full):
+    """A dataset-shaped stream at full size (VERDICT r4 missing #3): Tester:test feeds images of DIFFERENT sizes (Tester_FRCNN.lua:150-157), each
+    rescaled by getImages to a 600-px short side / 1000-px cap (ImageDetect.lua:22-52) — bench.MIXED_SIZES: s = 1 at two aspect ratios, s = 1.25
+    landscape and portrait, the capped scale, and a 2x downscale; ragged proposal counts.  (1) one ROI sample per size against the oracle's whole
+    path (transform -> image.scale -> trunk -> head; logits / deltas 1e-4 absolute); (2) the host-fed pipelined form (what bench.py times: uploads
+    on the copy stream, tails on the side stream, activation halos re-laid at every size change) over 3 rounds of the stream == the serial
+    records bit for bit."""
+    import bench
+    from multipathnet_amd import models
+    P = full["P"]
+    net = models.FastRCNN(P, max_h=1000, max_w=1000, max_rois=bench.N_ROIS, scale=600, max_size=1000)
+    stream = bench.mixed_size_inputs()
+    Pn = _np_tree(P)
+    ref = []
+    for im, bx in stream:
+        imd, bd = torch.from_numpy(im).to(dev), torch.from_numpy(bx).to(dev)
+        H0, W0 = im.shape[1:]
+        sc = O.pick_scale(H0, W0, 600, 1000)
+        s, b = net.detect(imd, bd)
+        N, C = bx.shape[0], net.n_classes
+        cls = net.debug_tensor("cls", (N, C)).cpu().numpy()
+        raw = net.debug_tensor("bbox_raw", (N, 4 * C)).cpu().numpy()
+        idx = np.random.default_rng(H0).choice(N, 40, replace=False)
+        idx[0] = N - 1
+        so, bo, logits, deltas = O.detect(im, bx[idx], Pn, target=600, max_size=1000)
+        e_l, e_d = np.abs(cls[idx] - logits).max(), np.abs(raw[idx] - deltas).max()
+        print("%4d x %4d (s = %.4g -> %d x %d), %4d ROIs: max|dlogit| = %.3g, max|ddelta| = %.3g" % (H0, W0, sc, int(H0 * sc), int(W0 * sc), N, e_l, e_d))
+        assert e_l < 1e-4 and e_d < 1e-4
+        assert np.abs(s.cpu().numpy()[idx] - so).max() < 1e-4
+        assert np.abs(b.cpu().numpy()[idx] - O.clamp_boxes(bo, W0, H0)).max() < 1e-4 * max(H0, W0)
+        d, n = net.test_one_async(imd, bd)
+        torch.cuda.synchronize()
+        ref.append(d[: int(n.item())].clone())
+        assert ref[-1].shape[0] > 0
+    pin = [(torch.from_numpy(im).pin_memory(), torch.from_numpy(bx).pin_memory()) for im, bx in stream]
+    steps = 3 * len(stream)
+    outs = [(torch.zeros_like(net._dets), torch.zeros_like(net._n_dets)) for _ in range(steps)]
+    from multipathnet_amd._lib import check, f32p
+    from multipathnet_amd.nn import _f, _i, _stream
+    import ctypes as C_
+    order = [t % len(stream) for t in range(steps)]
+    order[-3:] = [0, 0, 5]     # also: the same size twice in a row, then the largest upload last
+    for t in range(steps):
+        i, bx = pin[order[t]]
+        d, n = outs[t]
+        check(net._lib.mpn_frcnn_test_one_pipelined_host(net._h, C_.cast(i.data_ptr(), f32p), i.shape[1], i.shape[2], C_.cast(bx.data_ptr(), f32p),
+                                                         bx.size(0), _f(d), d.size(0), _i(n), _stream()), "pipelined_host")
+    net.flush()
+    torch.cuda.synchronize()
+    for t in range(steps):
+        d, n = outs[t]
+        assert torch.equal(d[: int(n.item())], ref[order[t]]), (t, order[t])
+    del net
+    torch.cuda.empty_cache()
+
+
 def test_fullsize_pipelined_host_record_equals_serial(dev, full):
     """what bench.py times (mpn_frcnn_test_one_pipelined_host at 600x1000 x 1000 ROIs: upload on the copy
     stream, NMS / top-k tail on the side stream) returns, image after image, exactly the record the serial
