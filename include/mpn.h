@@ -199,6 +199,13 @@ int mpn_select_scored(const float *d_scores, const float *d_bbox, int N, int C, 
  * knows rows were dropped (utils.keep_top_k itself never truncates). */
 int mpn_keep_top_k(const float *d_keep, const int *d_n_keep, int n_cls, int m_stride, int k, float *d_thresh,
                    float *d_out, int max_out, int *d_n_out, void *stream);
+/* The same on tables whose rows are in NON-INCREASING score order inside every class — what mpn_nms_batched emits (each greedy round picks the
+ * largest remaining score, nms.c:74-81) and what mpn_bbox_vote_batched keeps (voted rows carry their NMS scores, nms.c:139).  Only the first
+ * min(k, n_c) rows of each class can reach the k-th largest score and a class's survivors are a prefix of it, so the kernel stages
+ * n_cls * k keys instead of every kept row.  Same outputs, bit for bit, as mpn_keep_top_k ON SUCH TABLES; on unsorted tables use
+ * mpn_keep_top_k.  The test_one forms of the pipeline call this one. */
+int mpn_keep_top_k_sorted(const float *d_keep, const int *d_n_keep, int n_cls, int m_stride, int k, float *d_thresh,
+                          float *d_out, int max_out, int *d_n_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Wire formats either side of the path

@@ -407,6 +407,163 @@ __global__ __launch_bounds__(1024) void keep_top_k_kernel(const float *__restric
   if (tid == 0) *n_out = all;  // the UNTRUNCATED survivor count: > max_out tells the caller rows were dropped
 }
 
+// keep_top_k on tables whose rows are in NON-INCREASING score order inside every class — what NMS emits (each round picks the largest
+// remaining score) and what bbox_vote keeps (nms.c:139: the voted rows keep their NMS scores).  The k-th largest score over all classes is
+// then the k-th largest among the FIRST min(k, n_c) rows of each class, and the survivors of a class are a prefix of it: the kernel
+// stages n_cls x k keys (8 000 for 80 classes, whatever the tables' height — the general kernel above stages every kept row: 100 k keys
+// at 80 x 2000, three quarters of them re-read from HBM by every radix pass: 184 us on BASELINE configs[4]) and never touches the rest,
+// except for a class whose whole staged prefix survives (ties at the threshold run past row k: its tail is walked 64 rows at a time).
+__global__ __launch_bounds__(1024) void keep_top_k_sorted_kernel(const float *__restrict__ keep, const int *__restrict__ n_keep, int n_cls, int m_stride,
+                                                                 int k, float *__restrict__ thresh_out, float *__restrict__ out, int max_out,
+                                                                 int *__restrict__ n_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned topk_keys[];  // [n_cls][kk]: slot (c, j) valid iff j < cls_n[c]
+  __shared__ int cls_n[kTopkMaxCls];
+  __shared__ int cls_off[kTopkMaxCls + 1];  // survivors per class, then their exclusive prefix sum
+  __shared__ unsigned hist[256];
+  __shared__ unsigned sel_bin, sel_rank;
+  __shared__ unsigned wave_lo[16], wave_hi[16];
+  __shared__ int total_rows;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
+  const int kk = min(k, m_stride);
+  if (tid == 0) total_rows = 0;
+  __syncthreads();
+  {
+    int part = 0;
+    for (int c = tid; c < n_cls; c += blockDim.x) {
+      int v = min(n_keep[c], m_stride);
+      if (v < 0) v = 0;
+      cls_n[c] = v;
+      part += v;
+    }
+    if (part) atomicAdd(&total_rows, part);
+  }
+  __syncthreads();
+  const int total = total_rows;
+  if (total == 0) {
+    if (tid == 0) { *thresh_out = 0.0f; *n_out = 0; }  // utils.lua:77-79
+    return;
+  }
+  const int n_slot = n_cls * kk;
+  unsigned mn = 0xffffffffu, mx = 0u;
+  for (int base = tid; base < n_slot; base += 8 * (int)blockDim.x) {  // 8 independent gathers in flight per thread
+    unsigned kv[8];
+    bool ok[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * (int)blockDim.x;
+      const int c = i < n_slot ? i / kk : 0, j = i - c * kk;
+      ok[u] = i < n_slot && j < cls_n[c];
+      kv[u] = ok[u] ? f2key(keep[((size_t)c * m_stride + j) * 5 + 4]) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * (int)blockDim.x;
+      if (i < n_slot) topk_keys[i] = kv[u];
+      if (ok[u]) { mn = min(mn, kv[u]); mx = max(mx, kv[u]); }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    mn = min(mn, (unsigned)__shfl_xor((int)mn, off));
+    mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
+  }
+  if (lane == 0) { wave_lo[wid] = mn; wave_hi[wid] = mx; }
+  if (tid == 0) sel_rank = (unsigned)max(min(total, k), 1);
+  __syncthreads();
+  unsigned lo = 0xffffffffu, hi = 0u;
+  for (int w = 0; w < nw; ++w) { lo = min(lo, wave_lo[w]); hi = max(hi, wave_hi[w]); }
+  // radix select on digits of the keys' own range (as keep_top_k_kernel)
+  while (hi > lo) {
+    const unsigned width = hi - lo;
+    const int nb = 32 - __clz((int)width);
+    const int shift = nb > 8 ? nb - 8 : 0;
+    for (int b = tid; b < 256; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    for (int i = tid; i < n_slot; i += blockDim.x) {
+      const int c = i / kk, j = i - c * kk;
+      const unsigned key = topk_keys[i];
+      if (j < cls_n[c] && key >= lo && key <= hi) atomicAdd(&hist[(key - lo) >> shift], 1u);
+    }
+    __syncthreads();
+    if (wid == 0) {  // the bin that holds the rank: suffix sums over the 256 bins, 4 bins per lane (lane 0 = bins 252..255)
+      const int b0 = 252 - 4 * lane;
+      const unsigned h3 = hist[b0 + 3], h2 = hist[b0 + 2], h1 = hist[b0 + 1], h0 = hist[b0];
+      const unsigned mine = h0 + h1 + h2 + h3;
+      unsigned incl = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+      }
+      const unsigned before = incl - mine;
+      const unsigned rank = sel_rank;
+      const bool hit = before < rank && incl >= rank;
+      const unsigned long long hm = __ballot(hit);
+      if (hm && lane == __builtin_ctzll(hm)) {
+        unsigned acc = before;
+        int b = b0 + 3;
+        if (acc + h3 < rank) { acc += h3; b = b0 + 2; if (acc + h2 < rank) { acc += h2; b = b0 + 1; if (acc + h1 < rank) { acc += h1; b = b0; } } }
+        sel_rank = rank - acc;
+        sel_bin = (unsigned)b;
+      }
+    }
+    __syncthreads();
+    lo += sel_bin << shift;
+    hi = min(hi, lo + ((1u << shift) - 1u));
+    __syncthreads();  // every thread has read sel_bin before the next pass rewrites it
+  }
+  const unsigned thr_key = lo;
+  if (tid == 0) *thresh_out = key2f(thr_key);
+  // survivors of class c = a prefix: counted in the staged keys, continued in the table only when the whole staged prefix survives
+  for (int c = wid; c < n_cls; c += nw) {
+    const int nc = cls_n[c], staged = min(kk, nc);
+    int len = 0;
+    for (int j0 = 0; j0 < staged; j0 += 64) {
+      const int j = j0 + lane;
+      len += __popcll(__ballot(j < staged && topk_keys[c * kk + j] >= thr_key));
+    }
+    if (len == staged && nc > staged) {
+      for (int j0 = staged; j0 < nc; j0 += 64) {
+        const int j = j0 + lane;
+        const bool take = j < nc && f2key(keep[((size_t)c * m_stride + j) * 5 + 4]) >= thr_key;
+        const unsigned long long tk = __ballot(take);
+        const unsigned long long valid = nc - j0 >= 64 ? ~0ull : ((1ull << (nc - j0)) - 1ull);
+        if (tk == valid) { len += __popcll(tk); continue; }
+        len += __builtin_ctzll(~tk);  // non-increasing scores: the survivors end at the first row below the threshold
+        break;
+      }
+    }
+    if (lane == 0) cls_off[c] = len;
+  }
+  __syncthreads();
+  if (wid == 0) {  // exclusive prefix sum of the survivor counts, 64 classes per step
+    int run = 0;
+    for (int c0 = 0; c0 < n_cls; c0 += 64) {
+      const int c = c0 + lane;
+      const int v = c < n_cls ? cls_off[c] : 0;
+      int incl = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+      }
+      const int tot = __shfl(incl, 63);
+      if (c < n_cls) cls_off[c] = run + incl - v;
+      run += tot;
+    }
+    if (lane == 0) cls_off[n_cls] = run;
+  }
+  __syncthreads();
+  const int all = cls_off[n_cls];
+  for (int o = tid; o < min(all, max_out); o += blockDim.x) {
+    const int c = topk_class_of(cls_off, n_cls, o);
+    const float *row = keep + ((size_t)c * m_stride + (o - cls_off[c])) * 5;
+    float *q = out + 6 * (size_t)o;
+    q[0] = row[0]; q[1] = row[1]; q[2] = row[2]; q[3] = row[3]; q[4] = row[4]; q[5] = (float)(c + 1);
+  }
+  if (tid == 0) *n_out = all;  // the UNTRUNCATED survivor count
+}
+
 // image.scale(src, W2, H2) 'bilinear' (external `image` rock, ImageDetect.lua:41; parity unpinned — see mpn.h):
 // one output sample of a 1-D resample; `sstride` walks the source line.
 __device__ __forceinline__ float scale_sample(const float *__restrict__ src, long sstride, long slen, long dlen, long d) {
@@ -650,6 +807,22 @@ extern "C" int mpn_keep_top_k(const float *d_keep, const int *d_n_keep, int n_cl
   { int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(keep_top_k_kernel), kTopkLdsKeys * 4 + 32 + kTopkCand * 4); if (rc_attr) return rc_attr; }
   hipLaunchKernelGGL(keep_top_k_kernel, dim3(1), dim3(1024), nkeys * 4 + 32 + kTopkCand * 4, as_stream(stream), d_keep, d_n_keep, n_cls, m_stride, k,
                      d_thresh, d_out, max_out, d_n_out);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+extern "C" int mpn_keep_top_k_sorted(const float *d_keep, const int *d_n_keep, int n_cls, int m_stride, int k, float *d_thresh,
+                                     float *d_out, int max_out, int *d_n_out, void *stream) {
+  MPN_CHECK_ARG(n_cls >= 0 && m_stride >= 0 && k > 0 && max_out >= 0);
+  MPN_CHECK_ARG(d_thresh && d_n_out && (max_out == 0 || d_out));
+  MPN_CHECK_ARG(n_cls == 0 || (d_keep && d_n_keep));
+  MPN_CHECK_ARG(n_cls <= kTopkMaxCls);
+  const size_t slots = (size_t)n_cls * (size_t)(k < m_stride ? k : m_stride);
+  if (slots > (size_t)kTopkLdsKeys || slots == 0)  // more candidates than the LDS stage holds: the general kernel is as good
+    return mpn_keep_top_k(d_keep, d_n_keep, n_cls, m_stride, k, d_thresh, d_out, max_out, d_n_out, stream);
+  { int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(keep_top_k_sorted_kernel), kTopkLdsKeys * 4); if (rc_attr) return rc_attr; }
+  hipLaunchKernelGGL(keep_top_k_sorted_kernel, dim3(1), dim3(1024), slots * 4, as_stream(stream), d_keep, d_n_keep, n_cls, m_stride, k, d_thresh, d_out,
+                     max_out, d_n_out);
   MPN_CHECK_LAUNCH();
   return MPN_OK;
 }

@@ -35,7 +35,11 @@ static std::mutex g_reg_mu;
 static std::map<std::pair<int, hipStream_t>, Scratch *> g_registry;   // module-level calls: one Scratch per (device, stream)
 static std::set<std::pair<const void *, int>> g_attr_done;            // (kernel, device) pairs whose LDS limit is raised
 
-int scratch_get(ScratchSlot slot, size_t need, hipStream_t s, void **out) {
+static int scratch_get_impl(ScratchSlot slot, size_t need, hipStream_t s, void **out, bool zero);
+int scratch_get(ScratchSlot slot, size_t need, hipStream_t s, void **out) { return scratch_get_impl(slot, need, s, out, false); }
+int scratch_get_zeroed(ScratchSlot slot, size_t need, hipStream_t s, void **out) { return scratch_get_impl(slot, need, s, out, true); }
+
+static int scratch_get_impl(ScratchSlot slot, size_t need, hipStream_t s, void **out, bool zero) {
   Scratch *sc = t_scratch;
   if (!sc) {
     int dev = 0;
@@ -47,11 +51,12 @@ int scratch_get(ScratchSlot slot, size_t need, hipStream_t s, void **out) {
   }
   if (need > sc->bytes[slot]) {  // grows monotonically; steady state allocates nothing
     MPN_CHECK_HIP(hipStreamSynchronize(s));
+    bump_alloc_generation();  // captured launch graphs hold the old pointer (bumped BEFORE the free: a failing hipMalloc must not leave them replayable)
     if (sc->buf[slot]) (void)hipFree(sc->buf[slot]);
     sc->buf[slot] = nullptr; sc->bytes[slot] = 0;
     MPN_CHECK_HIP(hipMalloc(&sc->buf[slot], need));
     sc->bytes[slot] = need;
-    bump_alloc_generation();  // captured launch graphs hold the old pointer
+    if (zero) MPN_CHECK_HIP(hipMemsetAsync(sc->buf[slot], 0, need, s));
   }
   *out = sc->buf[slot];
   return MPN_OK;

@@ -42,7 +42,7 @@ constexpr int kWave = 64;
 // with a mutex.  Work on a stream is ordered, so one Scratch per stream of work is race-free; two handles, two host
 // threads or two devices never share a buffer (the reference host runs one worker thread per GPU in ONE process,
 // test_runner.lua:55-66).
-enum ScratchSlot { SCR_CONV_SPLITK = 0, SCR_GEMM_SPLITK, SCR_L2NORM, SCR_NMS, SCR_LINEAR_PACK, SCR_GRAPH_SPLITK, SCR_MISC, SCR_IM2COL, SCR_NSLOTS };
+enum ScratchSlot { SCR_CONV_SPLITK = 0, SCR_GEMM_SPLITK, SCR_L2NORM, SCR_NMS, SCR_LINEAR_PACK, SCR_GRAPH_SPLITK, SCR_MISC, SCR_IM2COL, SCR_NMS_CNT, SCR_NSLOTS };
 struct Scratch {
   int device = -1;
   void *buf[SCR_NSLOTS] = {};
@@ -52,6 +52,8 @@ struct Scratch {
 // The current thread's Scratch for `s`: the ScratchScope override if one is active, else the registry entry of
 // (current device, s).  Returns a buffer of at least `need` bytes in *out (grown by sync(s) + free + malloc).
 int scratch_get(ScratchSlot slot, size_t need, hipStream_t s, void **out);
+// the same, and the buffer is zero-filled (on `s`) whenever it is (re)allocated: self-resetting device counters live here
+int scratch_get_zeroed(ScratchSlot slot, size_t need, hipStream_t s, void **out);
 struct ScratchScope {
   Scratch *prev;
   explicit ScratchScope(Scratch *sc);

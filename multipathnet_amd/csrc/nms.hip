@@ -879,13 +879,288 @@ __global__ void boxoverlap_kernel(const float *__restrict__ a, int n, float bx1,
 
 using namespace mpn;
 
+
+// =================================================================================================
+// Fused NMS for class tables of up to kFusedMax rows (round 5): ONE launch instead of the sort -> mask -> tie -> scan -> wave chain.
+//
+// grid = (S slices, n_cls classes), 1 block per CU (the greedy phase keeps the class's whole suppression mask in LDS):
+//   1. every block of a class sorts the class's keys in LDS (score desc, index asc; bitonic) — the S copies of the sort run in
+//      parallel and give the same order, which is what lets the mask be split without a second launch;
+//   2. slice s computes rows s, s + S, ... of the suppression mask — one wavefront per 64-bit word: lane j evaluates
+//      IoU(rank i, rank 64 w + j) exactly as nms.c:14-41 (the row box is an LDS broadcast, the 64 column boxes one
+//      conflict-free ds_read_b128 each), a ballot is the word — and writes them to HBM scratch;
+//   3. the LAST block of the class to finish (device-scope counter, release / acquire fences) pulls the mask into LDS and one
+//      wavefront runs the greedy selection:
+//        tie-free class: picks follow the rank order; a chunk of 64 ranks is resolved with scalar bit arithmetic on its diagonal
+//          words, then the kept rows are OR-ed into the per-lane alive words (LDS reads, all in flight);
+//        class with bit-equal scores: the reference's pick depends on its array history (nms.c:74-98: FIRST maximum in array order;
+//          the old first element takes the picked box's slot; survivors keep their order).  Simulated exactly, O(1) LDS words per
+//          round, with two bitsets — alive by RANK (register word per lane) and alive by POSITION (slot in the reference's array;
+//          LDS words) — plus pos[rank] / owner[slot]: a run's pick is its alive member with the smallest slot, the head is the
+//          first set bit of the position bitset, a suppressed rank clears the bit of the slot it occupies.  (Python model against
+//          the compiled nms.c: tools/models/nms_fused_model.py.)
+//   4. the whole block writes the kept rows / source indices in pick order.
+// Classes with NaN scores are flagged (flags[c] = 2) for the exact IoU-sweep kernel launched behind this one.
+constexpr int kFusedMax = 1024;
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(v, off); v = o < v ? o : v; }
+  return v;
+}
+
+__global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict__ scored, const int *__restrict__ counts, int m_stride, float thr,
+                                                         float *__restrict__ keep, int *__restrict__ keep_idx, int *__restrict__ n_keep,
+                                                         unsigned long long *gmask, unsigned int *cnt, int *__restrict__ flags, int cap_w,
+                                                         int mask_bytes) {
+  typedef unsigned long long u64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
+  __shared__ int sh_hasnan, sh_nsel, sh_ties, sh_last, sh_kept;
+  const int cls = blockIdx.y, slice = blockIdx.x, S = gridDim.x, tid = threadIdx.x, nt = blockDim.x;
+  const int lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
+  int m = counts ? counts[cls] : m_stride;
+  if (m > m_stride) m = m_stride;
+  if (m <= 0) {
+    if (slice == 0 && tid == 0) { n_keep[cls] = 0; flags[cls] = 5; }
+    return;
+  }
+  const int W = (m + 63) >> 6, cap = W * 64, cap_s = cap_w * 64;
+  int n_pad = 64;
+  while (n_pad < m) n_pad <<= 1;
+  u64 *LM = reinterpret_cast<u64 *>(fused_lds);                             // sort keys, later the class's mask [m][W]
+  float4 *box = reinterpret_cast<float4 *>(fused_lds + mask_bytes);          // sorted boxes [cap_s]; later klist | pos | owner (u16 [cap_s] each)
+  unsigned short *sid = reinterpret_cast<unsigned short *>(fused_lds + mask_bytes + (size_t)cap_s * 16);  // source row of rank r
+  unsigned short *fw = sid + cap_s;                                          // first mask word of row r that is computed
+  u64 *EQ = reinterpret_cast<u64 *>(fw + cap_s);                             // bit r: ranks r and r + 1 carry the same score   [16 words]
+  u64 *APW = EQ + 16;                                                        // alive by position                                   [16 words]
+  u64 *keys = LM;
+  const float *src = scored + (size_t)cls * m_stride * 5;
+  if (tid == 0) { sh_hasnan = 0; sh_nsel = 0; sh_ties = 0; sh_kept = 0; }
+  if (tid < 16) EQ[tid] = 0ull;
+  __syncthreads();
+  // ---- 1. keys + bitonic sort
+  for (int i = tid; i < n_pad; i += nt) {
+    u64 k = ~0ull;
+    if (i < m) {
+      const float sc = src[5 * (size_t)i + 4];
+      if (sc != sc) sh_hasnan = 1;
+      unsigned u = __float_as_uint(sc);
+      if ((u << 1) == 0u) u = 0u;   // -0.0f and 0.0f are EQUAL for nms.c:77's '>': one key, so that the array order decides between them
+      k = ((u64)(~nms_f2key(__uint_as_float(u))) << 32) | (unsigned)i;
+    }
+    keys[i] = k;
+  }
+  __syncthreads();
+  if (sh_hasnan) {  // the exact sweep kernel reproduces the reference's behaviour on NaN scores
+    if (slice == 0 && tid == 0) flags[cls] = 2;
+    return;
+  }
+  for (int k = 2; k <= n_pad; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < n_pad / 2; t += nt) {
+        const int lo = (t / j) * 2 * j + (t % j), hi = lo + j;
+        const bool up = ((lo & k) == 0);
+        const u64 a = keys[lo], b = keys[hi];
+        if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+      }
+      __syncthreads();
+    }
+  // ---- sorted boxes, source rows, equal-score bits, the pickable prefix (nms.c:75: scores <= -1e7 are never picked)
+  for (int r = tid; r < cap; r += nt) {  // cap and nt are multiples of 64: whole wavefronts
+    const bool valid = r < m;
+    const u64 k = valid ? keys[r] : ~0ull;
+    const int i = (int)(unsigned)k;
+    const bool e = (r + 1 < m) && ((unsigned)(keys[r + 1] >> 32) == (unsigned)(k >> 32));
+    bool sel = false;
+    if (valid) {
+      const float *q = src + 5 * (size_t)i;
+      box[r] = make_float4(q[0], q[1], q[2], q[3]);
+      sid[r] = (unsigned short)i;
+      sel = q[4] > -10000000.0f;
+    }
+    const u64 be = __ballot(e), bs = __ballot(sel);
+    if (lane == 0) {
+      EQ[r >> 6] = be;
+      if (be) sh_ties = 1;
+      if (bs) atomicAdd(&sh_nsel, __popcll(bs));
+    }
+  }
+  __syncthreads();
+  const bool has_ties = sh_ties != 0;
+  const int n_sel = sh_nsel;
+  // first mask word a row needs: picks inside an equal-score run may come in any rank order, so a row must cover its run from the
+  // run's first rank; a rank outside any run only ever suppresses later ranks
+  for (int r = tid; r < m; r += nt) {
+    int rs = r;
+    if (has_ties) {
+      while (rs > 0) {
+        const int w = (rs - 1) >> 6, b = (rs - 1) & 63;
+        const u64 zeros = ~EQ[w] & (b == 63 ? ~0ull : ((1ull << (b + 1)) - 1ull));  // ranks q <= rs - 1 in this word with score[q] != score[q + 1]
+        if (zeros) { rs = 64 * w + (63 - __builtin_clzll(zeros)) + 1; break; }
+        rs = 64 * w;
+      }
+    }
+    fw[r] = (unsigned short)(rs >> 6);
+  }
+  __syncthreads();
+  // ---- 2. this slice's rows of the suppression mask: one wavefront per word
+  {
+    u64 *G = gmask + (size_t)cls * m_stride * cap_w;
+    const int nrows = (m - slice + S - 1) / S;  // rows slice, slice + S, ...
+    for (int it = wave; it < nrows * W; it += nwaves) {
+      const int q = it / W, w = it - q * W;
+      const int i = slice + q * S;
+      if (w < (int)fw[i]) continue;
+      const int col = 64 * w + lane;
+      const float4 a = box[i];
+      bool bit = false;
+      if (col < m && col != i) {
+        const float4 c = box[col];
+        bit = !(iou_plus1(a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w) <= thr);  // nms.c:93 keeps `iou <= threshold`
+      }
+      const u64 word = __ballot(bit);
+      if (lane == 0) G[(size_t)i * cap_w + w] = word;
+    }
+  }
+  // ---- 3. the last block of the class to arrive runs the selection
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned old = atomicAdd(&cnt[cls], 1u);
+    const int last = old == (unsigned)(S - 1);
+    if (last) cnt[cls] = 0u;  // ready for the next launch
+    sh_last = last;
+  }
+  __syncthreads();
+  if (!sh_last) return;
+  __threadfence();
+  {
+    const u64 *G = gmask + (size_t)cls * m_stride * cap_w;
+    for (int idx = tid; idx < m * W; idx += nt) {
+      const int i = idx / W, w = idx - i * W;
+      LM[idx] = (w >= (int)fw[i]) ? __hip_atomic_load(G + (size_t)i * cap_w + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    }
+  }
+  unsigned short *klist = reinterpret_cast<unsigned short *>(box), *pos = klist + cap_s, *owner = pos + cap_s;
+  if (has_ties) {
+    for (int r = tid; r < m; r += nt) { const int x = sid[r]; pos[r] = (unsigned short)x; owner[x] = (unsigned short)r; }
+    if (tid < 16) APW[tid] = 64 * tid >= m ? 0ull : (m - 64 * tid >= 64 ? ~0ull : ((1ull << (m - 64 * tid)) - 1ull));
+  }
+  __syncthreads();
+  if (wave == 0) {
+    int kept = 0;
+    u64 aw = 0ull;  // lane l: alive ranks 64 l .. 64 l + 63
+    {
+      const int lim = has_ties ? m : n_sel;  // tie-free: the unpickable suffix never matters
+      const int lo = 64 * lane;
+      if (lo < lim) aw = lim - lo >= 64 ? ~0ull : ((1ull << (lim - lo)) - 1ull);
+    }
+    if (!has_ties) {
+      for (int c = 0; c < W; ++c) {
+        const u64 cur = readlane64(aw, c);
+        if (!cur) continue;
+        const int r = 64 * c + lane;
+        const u64 D = r < m ? LM[r * W + c] : 0ull;  // lane j: the chunk's own columns of rank 64 c + j
+        u64 alive = cur, kw = 0ull;
+        while (alive) {
+          const int j = __builtin_ctzll(alive);
+          kw |= 1ull << j;
+          alive &= ~readlane64(D, j);
+          alive &= ~(1ull << j);
+        }
+        if ((kw >> lane) & 1ull) klist[kept + __popcll(kw & ((1ull << lane) - 1ull))] = (unsigned short)r;
+        kept += __popcll(kw);
+        if (lane > c && lane < W) {
+          u64 rem = 0ull, k = kw;
+          while (k) {
+            const int j = __builtin_ctzll(k);
+            k &= k - 1ull;
+            rem |= LM[(64 * c + j) * W + lane];
+          }
+          aw &= ~rem;
+        }
+      }
+    } else {
+      for (;;) {
+        const u64 nz = __ballot(aw != 0ull);
+        if (!nz) break;
+        const int w0 = __builtin_ctzll(nz);
+        const u64 word0 = readlane64(aw, w0);
+        const int r0 = 64 * w0 + __builtin_ctzll(word0);
+        if (r0 >= n_sel) break;  // only unpickable rows are left
+        int b = r0;
+        const u64 eq0 = EQ[w0];
+        if ((eq0 >> (r0 & 63)) & 1ull) {  // an equal-score run: its alive member with the smallest slot
+          int w = w0;
+          u64 x = ~eq0 & (~0ull << (r0 & 63));
+          while (!x) { ++w; x = ~EQ[w]; }  // bit m - 1 is never set: terminates inside the table
+          const int e = 64 * w + __builtin_ctzll(x);  // last rank of the run
+          int best = 0x7fffffff;
+          for (int ww = w0; ww <= (e >> 6); ++ww) {
+            const u64 a = readlane64(aw, ww);
+            const int r = 64 * ww + lane;
+            const bool in = r >= r0 && r <= e && ((a >> lane) & 1ull);
+            const int p = in ? (int)pos[r] : 0x7fffffff;
+            best = p < best ? p : best;
+          }
+          best = wave_min_i32(best);
+          b = __builtin_amdgcn_readfirstlane((int)owner[best]);
+        }
+        // nms.c:83-85: boxes[0] <-> boxes[best] — the head (first alive slot) takes the pick's slot, the pick leaves the array
+        const u64 apw = lane < 16 ? APW[lane] : 0ull;
+        const u64 nzp = __ballot(apw != 0ull);
+        const int pw = __builtin_ctzll(nzp);
+        const u64 pword = readlane64(apw, pw);
+        const int pf = 64 * pw + __builtin_ctzll(pword);
+        const int pb = __builtin_amdgcn_readfirstlane((int)pos[b]);
+        const int f = __builtin_amdgcn_readfirstlane((int)owner[pf]);
+        if (lane == 0) {
+          APW[pw] = pword & ~(1ull << (pf & 63));  // pf == pb: the pick WAS the head; else the head's old slot empties and it lives on in slot pb
+          if (pf != pb) { owner[pb] = (unsigned short)f; pos[f] = (unsigned short)pb; }
+          klist[kept] = (unsigned short)b;
+        }
+        ++kept;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // lane 0's slot update before the lanes' reads below (LDS is in order per wave)
+        // nms.c:91-98: the survivors keep `iou <= threshold`
+        const u64 row = lane < W ? LM[b * W + lane] : 0ull;
+        if (lane == (b >> 6)) aw &= ~(1ull << (b & 63));
+        u64 newly = row & aw;
+        aw &= ~row;
+        while (newly) {
+          const int j = __builtin_ctzll(newly);
+          newly &= newly - 1ull;
+          const int p = (int)pos[64 * lane + j];
+          atomicAnd(&APW[p >> 6], ~(1ull << (p & 63)));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      }
+    }
+    if (lane == 0) sh_kept = kept;
+  }
+  __syncthreads();
+  // ---- 4. kept rows in pick order
+  const int K = sh_kept;
+  float *kout = keep + (size_t)cls * m_stride * 5;
+  for (int t = tid; t < K * 5; t += nt) {
+    const int k = t / 5, fcol = t - 5 * k;
+    kout[t] = src[5 * (size_t)sid[klist[k]] + fcol];
+  }
+  if (keep_idx) {
+    int *kidx = keep_idx + (size_t)cls * m_stride;
+    for (int k = tid; k < K; k += nt) kidx[k] = (int)sid[klist[k]];
+  }
+  if (tid == 0) { n_keep[cls] = K; flags[cls] = 5; }
+}
+
 MPN_KNOB(int, g_nms_force_exact, 0);  // test hook: 1 = always the exact IoU-sweep kernel, 2 = always the tie (slot-emulation) kernel, 3 = always the replaying scan
 MPN_KNOB(unsigned long long *, g_nms_trace, nullptr);
 MPN_KNOB(int, g_nms_guard_limit, 0);  // test hook (mpn_debug_set_nms_guard_limit): bound of the replaying scan's progress loops (0 = the real one)
+MPN_KNOB(int, g_nms_fused, 1);  // test hook (mpn_debug_set_nms_fused): 0 = the round-2..4 launch chain also for tables of <= kFusedMax rows
 #ifdef MPN_DEBUG_HOOKS
 extern "C" void mpn_debug_set_nms_force_exact(int v) { g_nms_force_exact = v; }
 extern "C" void mpn_debug_set_nms_trace(void *p) { g_nms_trace = static_cast<unsigned long long *>(p); }
 extern "C" void mpn_debug_set_nms_guard_limit(int v) { g_nms_guard_limit = v; }
+extern "C" void mpn_debug_set_nms_fused(int v) { g_nms_fused = v; }
 #endif
 
 extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n_cls, int m_stride, float thr,
@@ -906,6 +1181,35 @@ extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n
     if (rc_ws) return rc_ws;
     hipLaunchKernelGGL(nms_wave_kernel, dim3(n_cls), dim3(kWave), 0, st, d_scored, d_counts, m_stride, thr, d_keep, d_keep_idx, d_n_keep, m_cap,
                        (const int *)nullptr, static_cast<float *>(ws));
+    MPN_CHECK_LAUNCH();
+    return MPN_OK;
+  }
+  if (m_stride <= kFusedMax && g_nms_fused && g_nms_force_exact == 0) {  // one launch: nms_fused_kernel (+ the sweep kernel behind it for NaN classes)
+    const int cap_w = (m_stride + 63) / 64, cap_s = cap_w * 64;
+    int n_pad = 64;
+    while (n_pad < m_stride) n_pad <<= 1;
+    size_t mask_bytes = (size_t)cap_s * cap_w * 8;
+    if (mask_bytes < (size_t)n_pad * 8) mask_bytes = (size_t)n_pad * 8;
+    const size_t lds = mask_bytes + (size_t)cap_s * 16 + (size_t)cap_s * 4 + 256;
+    int S = 256 / n_cls;  // one block per CU (the mask lives in LDS): at most one wave of blocks over the 256 CUs
+    if (S > 16) S = 16;
+    if (S > cdiv(m_stride, 32)) S = cdiv(m_stride, 32);
+    if (S < 1) S = 1;
+    const int nt = n_pad < 256 ? 256 : (n_pad > 1024 ? 1024 : n_pad);
+    const size_t gm_bytes = ((size_t)n_cls * m_stride * cap_w * 8 + 255) & ~(size_t)255;
+    void *ws = nullptr, *wc = nullptr;
+    int rc_ws = scratch_get(SCR_NMS, gm_bytes + (size_t)n_cls * sizeof(int), st, &ws);
+    if (rc_ws == MPN_OK) rc_ws = scratch_get_zeroed(SCR_NMS_CNT, ((size_t)n_cls * sizeof(unsigned) + 4095) & ~(size_t)4095, st, &wc);
+    if (rc_ws) return rc_ws;
+    int *fl = reinterpret_cast<int *>(static_cast<char *>(ws) + gm_bytes);
+    { int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(nms_fused_kernel), 160 * 1024 - 64); if (rc_attr) return rc_attr; }
+    hipLaunchKernelGGL(nms_fused_kernel, dim3(S, n_cls), dim3(nt), lds, st, d_scored, d_counts, m_stride, thr, d_keep, d_keep_idx, d_n_keep,
+                       static_cast<unsigned long long *>(ws), static_cast<unsigned int *>(wc), fl, cap_w, (int)mask_bytes);
+    MPN_CHECK_LAUNCH();
+    const int m_cap_w = (m_stride + 3) & ~3;
+    { int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(nms_wave_kernel), MPN_NMS_MAX_BOXES * 6 * 4); if (rc_attr) return rc_attr; }
+    hipLaunchKernelGGL(nms_wave_kernel, dim3(n_cls), dim3(kWave), (size_t)m_cap_w * 6 * sizeof(float), st, d_scored, d_counts, m_stride, thr, d_keep, d_keep_idx,
+                       d_n_keep, m_cap_w, fl, (float *)nullptr);
     MPN_CHECK_LAUNCH();
     return MPN_OK;
   }
@@ -1108,11 +1412,49 @@ extern "C" int mpn_nms(const float *d_scored, int m, float thr, float *d_keep, i
   return mpn_nms_batched(d_scored, nullptr, 1, m, thr, d_keep, d_keep_idx, d_n_keep, stream);
 }
 
+// The libnms.so drop-in's small tables (Tester_FRCNN.lua:117 hands utils.nms a few hundred rows per class): no device allocation, no
+// hipMemcpy — the table is staged in a per-thread pinned, device-mapped buffer which the fused kernel reads and writes directly over the
+// host link (6 KB in, <= 7 KB out), so a call is memcpy + one launch + one stream sync + memcpy.  The buffer (45 KB) is allocated once per
+// host thread and deliberately never freed: the HIP runtime may already be gone when thread-local destructors run at process exit.
+namespace {
+struct HostNmsStage { void *pin = nullptr; void *dptr = nullptr; int device = -1; };
+thread_local HostNmsStage t_host_nms;
+constexpr size_t kHostNmsBytes = (size_t)kFusedMax * (5 + 5 + 1) * 4 + 256;
+}  // namespace
+
+static int nms_host_small(const float *h_scored, int m, float thr, float *h_keep, int *h_keep_idx, int *n_keep) {
+  int dev = 0;
+  MPN_CHECK_HIP(hipGetDevice(&dev));
+  HostNmsStage &t = t_host_nms;
+  if (!t.pin || t.device != dev) {  // (a thread that switches devices re-stages; the old buffer stays with its device)
+    void *p = nullptr, *d = nullptr;
+    MPN_CHECK_HIP(hipHostMalloc(&p, kHostNmsBytes, hipHostMallocPortable | hipHostMallocMapped));
+    if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(p); set_error("mpn_nms_host: the pinned stage is not device-mapped"); return MPN_EHIP; }
+    t.pin = p; t.dptr = d; t.device = dev;
+  }
+  float *in = static_cast<float *>(t.pin), *out = in + 5 * (size_t)kFusedMax;
+  int *idx = reinterpret_cast<int *>(out + 5 * (size_t)kFusedMax), *n = idx + kFusedMax;
+  const ptrdiff_t delta = static_cast<char *>(t.dptr) - static_cast<char *>(t.pin);
+  auto dp = [&](void *h) { return static_cast<void *>(static_cast<char *>(h) + delta); };
+  memcpy(in, h_scored, sizeof(float) * 5 * (size_t)m);
+  *n = 0;
+  int rc = mpn_nms_batched(static_cast<float *>(dp(in)), nullptr, 1, m, thr, static_cast<float *>(dp(out)), static_cast<int *>(dp(idx)), static_cast<int *>(dp(n)), nullptr);
+  if (rc) return rc;
+  MPN_CHECK_HIP(hipStreamSynchronize(nullptr));
+  const int k = *n;
+  if (k < 0 || k > m) { set_error("mpn_nms_host: kept count %d out of range", k); return MPN_EHIP; }
+  *n_keep = k;
+  memcpy(h_keep, out, sizeof(float) * 5 * (size_t)k);
+  if (h_keep_idx) memcpy(h_keep_idx, idx, sizeof(int) * (size_t)k);
+  return MPN_OK;
+}
+
 extern "C" int mpn_nms_host(const float *h_scored, int m, float thr, float *h_keep, int *h_keep_idx, int *n_keep) {
   MPN_CHECK_ARG(m >= 0 && n_keep != nullptr);
   *n_keep = 0;
   if (m == 0) return MPN_OK;
   MPN_CHECK_ARG(h_scored != nullptr && h_keep != nullptr);
+  if (m <= kFusedMax && g_nms_fused && g_nms_force_exact == 0) return nms_host_small(h_scored, m, thr, h_keep, h_keep_idx, n_keep);
   float *d_in = nullptr, *d_keep = nullptr;
   int *d_idx = nullptr, *d_n = nullptr;
   size_t bytes = sizeof(float) * 5 * (size_t)m;

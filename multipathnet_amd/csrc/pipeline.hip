@@ -1012,7 +1012,7 @@ static int run_tail(mpn_frcnn *p, int N, float *d_dets, int top_cap, int *d_n_de
       final_tables = p->voted;
     }
     ProfScope ps(p, MPN_PROF_TOPK, q);
-    return mpn_keep_top_k(final_tables, p->n_keep, C - 1, N, c.top_k, p->thresh, d_dets, top_cap, d_n_dets, q);
+    return mpn_keep_top_k_sorted(final_tables, p->n_keep, C - 1, N, c.top_k, p->thresh, d_dets, top_cap, d_n_dets, q);  // NMS / voted tables: scores non-increasing per class
   });
 }
 
@@ -1209,7 +1209,7 @@ extern "C" int mpn_frcnn_shard_finish(mpn_frcnn *p, const float *d_class_all, in
                        shard_class_rec_floats(cmax, rows, c.bbox_voting), p->keep, p->keep_idx, p->n_keep, c.bbox_voting ? p->voted : nullptr);
     MPN_CHECK_LAUNCH();
     ProfScope ps(p, MPN_PROF_TOPK, q);
-    return mpn_keep_top_k(c.bbox_voting ? p->voted : p->keep, p->n_keep, n_cls, rows, c.top_k, p->thresh, d_dets, top_cap, d_n_dets, q);
+    return mpn_keep_top_k_sorted(c.bbox_voting ? p->voted : p->keep, p->n_keep, n_cls, rows, c.top_k, p->thresh, d_dets, top_cap, d_n_dets, q);
   });
 }
 

@@ -134,3 +134,52 @@ def test_select_scored_and_keep_top_k(O, dev):
         assert tg == t
         for a, b in zip(got, ref):
             assert np.array_equal(a.cpu().numpy().reshape(-1, 5), b.reshape(-1, 5))
+
+
+@pytest.mark.parametrize("n_cls,M,k", [(20, 1000, 100), (80, 2000, 100), (80, 2000, 1), (5, 64, 100), (3, 50, 5000), (400, 30, 100), (1, 1000, 100)])
+def test_keep_top_k_sorted_equals_general(O, dev, n_cls, M, k):
+    """mpn_keep_top_k_sorted (tables in non-increasing score order per class, as NMS / bbox_vote leave them: only n_cls * k keys are staged)
+    == mpn_keep_top_k == utils.keep_top_k's rule (utils.lua:75-96), bit for bit: threshold, untruncated count, rows in class-major pick order.
+    Cases: distinct scores; scores quantised to 1/50 (ties AT the threshold, kept); one class holding hundreds of rows tied at the top score
+    (its survivors run far past row k: the tail walk); empty classes; all classes empty."""
+    from multipathnet_amd import _lib, nn
+    rng = np.random.default_rng(n_cls * 7 + M + k)
+    lib = _lib.load()
+    for case in ("distinct", "quantised", "plateau", "empty"):
+        counts = rng.integers(0, M + 1, n_cls)
+        counts[rng.integers(0, n_cls)] = M
+        if n_cls > 2:
+            counts[1] = 0
+        if case == "empty":
+            counts[:] = 0
+        per = []
+        for c in range(n_cls):
+            sc = rng.random(counts[c]).astype(np.float32)
+            if case == "quantised":
+                sc = (np.round(sc * 50) / 50).astype(np.float32)
+            if case == "plateau" and c == 0 and counts[c] > 3:
+                sc[: max(3, counts[c] * 2 // 3)] = np.float32(2.0)
+            sc = np.sort(sc)[::-1]
+            per.append(np.concatenate([rng.random((counts[c], 4)).astype(np.float32), sc[:, None]], 1).astype(np.float32))
+        d_keep = torch.zeros((n_cls, M, 5), device=dev)
+        for c, t in enumerate(per):
+            if t.size:
+                d_keep[c, : t.shape[0]] = _t(t, dev)
+        d_n = torch.tensor(counts, dtype=torch.int32, device=dev)
+        cap = int(counts.sum()) + 1
+        res = []
+        for fn in (lib.mpn_keep_top_k, lib.mpn_keep_top_k_sorted):
+            out = torch.full((cap, 6), -1.0, device=dev)
+            thr = torch.full((1,), -5.0, device=dev)
+            n_out = torch.full((1,), -5, dtype=torch.int32, device=dev)
+            _lib.check(fn(nn._f(d_keep), nn._i(d_n), n_cls, M, k, nn._f(thr), nn._f(out), cap, nn._i(n_out), None))
+            torch.cuda.synchronize()
+            res.append((float(thr.item()), int(n_out.item()), out.cpu().numpy()))
+        assert res[0][0] == res[1][0] and res[0][1] == res[1][1], (case, res[0][:2], res[1][:2])
+        assert np.array_equal(res[0][2], res[1][2]), case
+        ref, t = O.keep_top_k(per, k)
+        n_ref = sum(r.shape[0] for r in ref)
+        assert res[1][1] == n_ref and (n_ref == 0 or res[1][0] == t)
+        if n_ref:
+            exp = np.concatenate([np.concatenate([r, np.full((r.shape[0], 1), j + 1, np.float32)], 1) for j, r in enumerate(ref) if r.size])
+            assert np.array_equal(res[1][2][:n_ref], exp), case

@@ -16,12 +16,14 @@ def _t(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=["auto", "sweepkernel", "tiekernel", "replayscan"])
+@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["auto", "sweepkernel", "tiekernel", "replayscan", "chain"])
 def nms_path(request):
-    """0 = default dispatch (chunked bitmask scan — with the position replay for classes with a few tied pairs —, the slot-emulating
-    tie kernel for classes with many bit-equal scores, the IoU-sweep kernel for NaN / oversize); 1 = IoU-sweep kernel only; 2 = tie
-    kernel wherever it applies; 3 = the replaying scan for every class, however many ties it has (its pick-by-pick rule)"""
-    with hooks(nms_force_exact=request.param):  # 0 = the product library's own dispatch
+    """0 = default dispatch: tables of <= 1024 rows on the one-launch fused kernel (round 5: sort + sliced mask + in-LDS greedy selection
+    with the exact position rule), wider ones on the launch chain (chunked bitmask scan — with the position replay for classes with a few
+    tied pairs —, the slot-emulating tie kernel for classes with many bit-equal scores, the IoU-sweep kernel for NaN / oversize);
+    1 = IoU-sweep kernel only; 2 = tie kernel wherever it applies; 3 = the replaying scan for every class, however many ties it has (its
+    pick-by-pick rule); 4 = the launch chain's own dispatch at every size (the fused kernel switched off)"""
+    with hooks(nms_force_exact=request.param % 4, nms_fused=0 if request.param == 4 else 1):  # 0 = the product library's own dispatch
         yield request.param
 
 
@@ -289,9 +291,84 @@ def test_nms_lazy_replay_fuzz_vs_reference(O, dev, seed):
         ref = O.ref_nms(sb, thr) if O.have_ref() else O.nms(sb, thr)
         mine, ridx = O.nms(sb, thr, return_index=True)
         assert np.array_equal(mine, ref)
+        for fused in ((1, 0) if n <= 1024 else (1,)):   # tables of <= 1024 rows default to the fused kernel: the replay is kept covered there too
+            with hooks(nms_fused=fused):
+                keep, idx = utils.nms_with_index(_t(sb, dev), thr)
+            assert keep.shape[0] == ref.shape[0] and np.array_equal(keep.cpu().numpy(), ref), (seed, n, thr, fused)
+            assert np.array_equal(idx.cpu().numpy(), ridx)
+
+
+@pytest.mark.parametrize("regime", ["distinct", "ties", "saturated", "allequal"])
+@pytest.mark.parametrize("n", [127, 128, 129, 511, 512, 513, 960, 1023, 1024])
+def test_nms_fused_kernel_sizes(O, dev, regime, n):
+    """the one-launch fused kernel (tables of <= 1024 rows) at word / sort-width boundaries, in every score regime, against the reference's
+    compiled nms.c: kept rows, order, source indices"""
+    from multipathnet_amd import utils
+    rng = np.random.default_rng(case_seed(regime, n, salt=55))
+    sb = random_scored_boxes(rng, n, regime)
+    for thr in (0.3, 0.7):
+        ref = O.ref_nms(sb, thr) if O.have_ref() else O.nms(sb, thr)
+        mine, ridx = O.nms(sb, thr, return_index=True)
+        assert np.array_equal(mine, ref)
         keep, idx = utils.nms_with_index(_t(sb, dev), thr)
-        assert keep.shape[0] == ref.shape[0] and np.array_equal(keep.cpu().numpy(), ref), (seed, n, thr)
+        assert keep.shape[0] == ref.shape[0] and np.array_equal(keep.cpu().numpy(), ref), (regime, n, thr)
         assert np.array_equal(idx.cpu().numpy(), ridx)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_nms_fused_kernel_fuzz_vs_reference(O, dev, seed):
+    """randomized tie structure for the fused kernel's position rule (nms.c:74-98): scores quantised to a random number of levels (2 .. 300:
+    from two giant equal-score runs to mostly-distinct scores with a few pairs), random sizes <= 1024, dense and sparse box layouts,
+    duplicated proposals — against the reference's compiled nms.c, bit for bit"""
+    from multipathnet_amd import utils
+    rng = np.random.default_rng(70000 + seed)
+    n = int(rng.integers(2, 1025))
+    sb = random_scored_boxes(rng, n, "distinct", span=float(rng.choice([150.0, 400.0, 1000.0, 3000.0])), lo=float(rng.choice([8.0, 16.0, 60.0])))
+    levels = int(rng.choice([2, 3, 5, 17, 64, 300]))
+    frac = float(rng.choice([0.1, 0.5, 1.0]))                 # share of the rows whose score is quantised
+    q = rng.random(n) < frac
+    sb[q, 4] = (np.round(sb[q, 4] * levels) / levels).astype(np.float32)
+    for _ in range(int(rng.integers(0, 6))):
+        a, b = rng.choice(n, 2, replace=False)
+        sb[b] = sb[a]
+    for thr in (0.3, 0.55):
+        ref = O.ref_nms(sb, thr) if O.have_ref() else O.nms(sb, thr)
+        mine, ridx = O.nms(sb, thr, return_index=True)
+        assert np.array_equal(mine, ref)
+        keep, idx = utils.nms_with_index(_t(sb, dev), thr)
+        assert keep.shape[0] == ref.shape[0] and np.array_equal(keep.cpu().numpy(), ref), (seed, n, levels, thr)
+        assert np.array_equal(idx.cpu().numpy(), ridx)
+
+
+@pytest.mark.parametrize("n_cls,M", [(1, 1000), (20, 1000), (80, 1000), (300, 257), (7, 64), (20, 40)])
+def test_nms_fused_kernel_batched_slices(O, dev, n_cls, M):
+    """the fused kernel's launch shapes: 16 / 12 / 3 / 1 mask slices per class (grid = slices x classes, the last block of a class to finish
+    runs its selection; the arrival counters reset themselves), ragged counts incl. 0 and M, every third class tied / saturated, a class of
+    unpickable rows (nms.c:75), signed zeros among zero scores, and a class with a NaN score (-> the exact sweep kernel behind it); twice in
+    a row on the same scratch"""
+    from multipathnet_amd import utils
+    rng = np.random.default_rng(n_cls * 1000 + M)
+    counts = rng.integers(0, M + 1, n_cls).astype(np.int32)
+    counts[0] = M
+    if n_cls > 2:
+        counts[1] = 0
+    sb = np.stack([random_scored_boxes(rng, M, ["distinct", "ties", "saturated"][c % 3]) for c in range(n_cls)])
+    if n_cls >= 7:
+        sb[3, ::3, 4] = -2e7                      # never picked
+        sb[4, ::5, 4] = 0.0
+        sb[4, 1::5, 4] = -0.0                     # equal to 0.0 for the reference's '>'
+        sb[5, M // 2, 4] = np.nan
+        counts[3:6] = M
+    for rep in range(2):
+        keep, idx, nk = utils.nms_batched(_t(sb, dev), _t(counts, dev), 0.3)
+        keep, idx, nk = keep.cpu().numpy(), idx.cpu().numpy(), nk.cpu().numpy()
+        for c in range(n_cls):
+            t = sb[c, :counts[c]]
+            ref, ridx = O.nms(t, 0.3, return_index=True)
+            if O.have_ref() and not (n_cls >= 7 and c in (3, 5)):   # unpickable rows / NaN: the compiled reference runs into best = -1 (UB)
+                assert np.array_equal(O.ref_nms(t, 0.3), ref, equal_nan=True), c
+            assert nk[c] == ref.shape[0], (rep, c)
+            assert np.array_equal(keep[c, :nk[c]], ref, equal_nan=True) and np.array_equal(idx[c, :nk[c]], ridx), (rep, c)
 
 
 def test_nms_replay_progress_bound_falls_back_to_the_exact_sweep(O, dev):

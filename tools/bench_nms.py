@@ -23,10 +23,11 @@ for regime in ("distinct", "fewties", "ties", "saturated"):
             k = rng.choice(M, 8, replace=False)
             sb[c, k[:4], 4] = sb[c, k[4:], 4]
     d = torch.from_numpy(sb).to(dev)
-    for mode, name in ((0, "auto"), (3, "replay-scan"), (2, "tie-kernel"), (1, "sweep-kernel")):
+    for mode, name in ((0, "auto"), (4, "chain-auto"), (3, "replay-scan"), (2, "tie-kernel"), (1, "sweep-kernel")):
         if only_modes and mode not in only_modes:
             continue
-        lib.mpn_debug_set_nms_force_exact(mode)
+        lib.mpn_debug_set_nms_force_exact(mode % 4)
+        lib.mpn_debug_set_nms_fused(0 if mode == 4 else 1)   # auto = the fused one-launch kernel for tables of <= 1024 rows (round 5); chain-auto = rounds 2-4
         with _lib.debug_hooks():
           for _ in range(2):
             keep, idx, nk = utils.nms_batched(d, None, 0.3)
@@ -40,3 +41,4 @@ for regime in ("distinct", "fewties", "ties", "saturated"):
         torch.cuda.synchronize()
         print("%-9s M=%d %-12s %8.1f us/call (20 classes, %.1f us/class if serial)  kept/class mean %.0f" % (regime, M, name, e0.elapsed_time(e1) / 5 * 1e3, e0.elapsed_time(e1) / 5 * 1e3 / n_cls, nk.float().mean().item()))
 lib.mpn_debug_set_nms_force_exact(0)
+lib.mpn_debug_set_nms_fused(1)
