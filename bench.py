@@ -142,7 +142,8 @@ def cpu_baseline(P, im, boxes, rois_sample):
     ncpu = os.cpu_count() or 1
     out = {"unit": "proposals/s", "kind": "port",
            "what": "PyTorch-CPU (oneDNN) conv2d / max_pool2d(ceil_mode) / linear + oracle C ROI pool + numpy decode + "
-                   + ("the reference's own nms.c (compiled unmodified, 1 thread)" if O.have_ref() else "oracle NMS port")}
+                   + ("the reference's own nms.c (compiled unmodified, 1 thread)" if O.have_ref() else "oracle NMS port")
+                   + "; `value` is the BEST OF {16, 64} oneDNN threads (chosen after measuring both: `by_threads`), `cores` = the winner"}
     # several thread counts (oneDNN on one 600x1000 image does not scale to every core of a big host: 256 threads measured 9 s for
     # the trunk where 1 thread takes 2 s); the best one is the baseline, `cores` = the threads it used
     cpu_path_torch(P, im, boxes, min(ncpu, 16), 16)  # cold-start warm-up
@@ -350,9 +351,87 @@ def _cfg_alexnet(models, args):  # BASELINE configs[0]
         dt = run()
         return {"value": round(n / dt, 1), "unit": "proposals/s", "cores": min(os.cpu_count() or 1, 64), "kind": "port", "seconds_per_image": round(dt, 3),
                 "sample": "1 image 600x1000 x 300 ROIs after one warm-up image: PyTorch-CPU trunk / fc + oracle ROI pool + reference nms.c"}
-    return dict(params=G, net=net, n_rois=n, flops=flops, dtype="f32", cpu_baseline=cpu, groups=groups, key="c1",
+    alg_bytes = (_oplist_bytes(G["trunk_ops"], H, W, 1, 4, G["trunk_tensor_c"]) + 4.0 * n * 256 * 36 + _oplist_bytes(G["head_ops"], 6, 6, n, 4, G["head_tensor_c"])
+                 + 4.0 * (4096 * 105 + n * 105))
+    return dict(params=G, net=net, n_rois=n, flops=flops, dtype="f32", cpu_baseline=cpu, groups=groups, key="c1", alg_bytes=alg_bytes,
                 metric="proposals/sec (300 ROIs, 600x1000 img) AlexNet Fast R-CNN [BASELINE configs[0]; not the headline metric]",
                 workload="AlexNet / CaffeNet Fast R-CNN (models/alexnet.lua), 1 image 600x1000 x 300 ROIs per GPU per step, 21 classes")
+
+
+def _cfg_vgg_frcnn_n(models, args):  # the HEADLINE model at another proposal count: `--config c2 --rois 2000` (auxiliary line, never the headline)
+    n = int(args.rois)
+    P = models.synthetic_params(models.VGG16_CFG, pooled=7, fc_dim=4096, n_classes=N_CLASSES, seed=557)
+    net = models.FastRCNN(P, max_h=H, max_w=W, max_rois=n)
+    cf = conv_flops(models.VGG16_CFG, H, W)
+    wino = sum(f for f, v in cf if v == "conv_wino")
+    head = 2.0 * (25088 * 4096 + 4096 * 4096 + 4096 * 5 * N_CLASSES)
+    groups = _groups(conv_wino=("trunk, 12 Winograd F(2x2,3x3) layers", wino, wino), conv_direct=("conv1_1", sum(f for f, v in cf if v == "conv_direct"), 0.0),
+                     fc6=("fc6", n * 2.0 * 25088 * 4096, 0.0), fc7=("fc7", n * 2.0 * 4096 * 4096, 0.0), heads=("cls + bbox GEMM", n * 2.0 * 4096 * 5 * N_CLASSES, 0.0))
+    # compulsory HBM bytes of one image, every layer reading its input and writing its output once (fp32), weights once
+    trunk_b = _vgg_trunk_bytes(models.VGG16_CFG, H, W)
+    head_b = 4.0 * (n * 25088 * 2 + 25088 * 4096 + n * 4096 * 2 + 4096 * 4096 + n * 4096 * 2 + 4096 * 5 * N_CLASSES + n * 5 * N_CLASSES)
+    return dict(params=P, net=net, n_rois=n, flops=sum(f for f, _ in cf) + n * head, dtype="f32", groups=groups, key="c2_n%d" % n, cpu_baseline=None,
+                alg_bytes=trunk_b + head_b,
+                metric="proposals/sec (%d ROIs, 600x1000 img) VGG-16 Fast R-CNN [the headline model at the proposal count of scripts/eval_fastrcnn_voc2007.sh; "
+                       "auxiliary line, not the headline metric]" % n,
+                workload="VGG-16 Fast R-CNN, 1 image 600x1000 x %d ROIs per GPU per step, 21 classes, NMS 0.3, top-100" % n)
+
+
+def _vgg_trunk_bytes(cfg, h, w):
+    """fp32 bytes a VGG trunk must move when every layer reads its input map and writes its output map once (a fused ceil-mode pool writes
+    the pooled map only) and reads its weights once"""
+    b, cin, li = 0.0, 3, 0
+    items = list(cfg)
+    for i, item in enumerate(items):
+        if item == "P":
+            continue
+        pooled = i + 1 < len(items) and items[i + 1] == "P"
+        oh, ow = ((h + 1) // 2, (w + 1) // 2) if pooled else (h, w)
+        b += 4.0 * (cin * h * w + item * oh * ow + item * cin * 9 + item)
+        cin, h, w = item, oh, ow
+    return b
+
+
+def _oplist_bytes(ops, h, w, batch, esz, tensor_c=None):
+    """HBM bytes of an op list (include/mpn.h mpn_graph_op) on `batch` maps of h x w.  tensor_c = None: the LAYER-WISE count — every op reads
+    its input channels and writes its output channels once (element size esz), convolutions read their weights once per launch.  tensor_c =
+    the list's tensor channel counts: the TENSOR-LEVEL floor — every tensor of the list is written once and read once (however many ops
+    consume it: an Inception block's four branches share one read of their input), weights once."""
+    if tensor_c is not None:
+        dims, wb = {0: (h, w)}, 0.0
+        for o in ops:
+            sh_, sw_ = dims[o["src"]]
+            if o["kind"] == 3:
+                oh, ow = sh_, sw_
+            elif o["kind"] == 1 and o.get("ceil"):
+                def cs2(x, k, s_, p_):
+                    r = -(-(x + 2 * p_ - k) // s_) + 1
+                    return r - 1 if (p_ > 0 and (r - 1) * s_ >= x + p_) else r
+                oh, ow = cs2(sh_, o["kh"], o["sh"], o["ph"]), cs2(sw_, o["kw"], o["sw"], o["pw"])
+            else:
+                oh, ow = (sh_ + 2 * o["ph"] - o["kh"]) // o["sh"] + 1, (sw_ + 2 * o["pw"] - o["kw"]) // o["sw"] + 1
+            dims.setdefault(o["dst"], (oh, ow))
+            if o["kind"] == 0:
+                wb += esz * o["cout"] * o["cin"] * o["kh"] * o["kw"]
+        return wb + sum(batch * esz * tensor_c[t] * hh * ww * (1.0 if t == 0 else 2.0) for t, (hh, ww) in dims.items())
+    dims, b = {0: (h, w)}, 0.0
+    for o in ops:
+        sh_, sw_ = dims[o["src"]]
+        if o["kind"] == 3:
+            oh, ow = sh_, sw_
+        elif o["kind"] == 1 and o.get("ceil"):
+            def cs(x, k, s, p):
+                r = -(-(x + 2 * p - k) // s) + 1
+                return r - 1 if (p > 0 and (r - 1) * s >= x + p) else r
+            oh, ow = cs(sh_, o["kh"], o["sh"], o["ph"]), cs(sw_, o["kw"], o["sw"], o["pw"])
+        else:
+            oh, ow = (sh_ + 2 * o["ph"] - o["kh"]) // o["sh"] + 1, (sw_ + 2 * o["pw"] - o["kw"]) // o["sw"] + 1
+        dims.setdefault(o["dst"], (oh, ow))
+        cout = o["cout"] if o["kind"] == 0 else o["cin"]
+        b += batch * esz * (o["cin"] * sh_ * sw_ + cout * oh * ow)
+        if o["kind"] == 0:
+            b += esz * o["cout"] * o["cin"] * o["kh"] * o["kw"]
+    return b
 
 
 def _cfg_vgg_mpn(models, args):  # BASELINE configs[2]
@@ -369,7 +448,11 @@ def _cfg_vgg_mpn(models, args):  # BASELINE configs[2]
 
     def cpu(im, boxes):
         return _cpu_baseline_towers("vgg", P, im, boxes, n, 81, 6, sample=32)
-    return dict(params=P, net=net, n_rois=n, flops=flops, dtype="f32", groups=groups, key="c3", cpu_baseline=cpu,
+    tow_c = (1280, 1024, 1024, 512, 1280)
+    alg_bytes = (_vgg_trunk_bytes(models.VGG16_CFG, H, W)
+                 + sum(4.0 * (n * 49 * c * 2 + c * 512 + n * 25088 * 2 + 25088 * 4096 + n * 4096 * 2 + 4096 * 4096 + n * 4096) for c in tow_c)
+                 + 4.0 * (16384 * 486 + 4096 * 324 + n * 20480 + n * (486 + 324)))
+    return dict(params=P, net=net, n_rois=n, flops=flops, dtype="f32", groups=groups, key="c3", cpu_baseline=cpu, alg_bytes=alg_bytes,
                 metric="proposals/sec (1000 ROIs, 600x1000 img) VGG-16 MultiPathNet [BASELINE configs[2]; not the headline metric]",
                 workload="VGG-16 MultiPathNet (4 foveal towers + box tower, conv3/4/5 skip pooling, K = 6 integral classifiers, 81 classes), 1000 ROIs")
 
@@ -394,9 +477,49 @@ def _cfg_resnet_mpn(models, args):  # BASELINE configs[3]
                     f += 2.0 * wt.shape[0] * wt.shape[1] * k * k * bh * bw
             h, w = bh, bw
         return f
+    def blocks_bytes(blocks, h, w, batch, esz, floor=False):
+        """floor = False, LAYER-WISE: every convolution reads its input and writes its output once (+ weights once per launch), the residual operand
+        is read once.  floor = True, TENSOR-LEVEL: every tensor a block produces is written once and read once (the block input's two consumers —
+        first convolution and shortcut — share one read), weights once."""
+        b = 0.0
+        if floor:
+            for blk in blocks:
+                bh, bw = h, w
+                if blk["shortcut"] is not None:
+                    ws, _, st = blk["shortcut"]
+                    b += batch * esz * 2.0 * ws.shape[0] * ((h - 1) // st + 1) * ((w - 1) // st + 1) + esz * ws.numel()
+                for (wt, _, st, pd) in blk["convs"]:
+                    k = wt.shape[2]
+                    bh, bw = (bh + 2 * pd - k) // st + 1, (bw + 2 * pd - k) // st + 1
+                    b += batch * esz * 2.0 * wt.shape[0] * bh * bw + esz * wt.numel()
+                h, w = bh, bw
+            return b
+        for blk in blocks:
+            bh, bw = h, w
+            cin0 = blk["convs"][0][0].shape[1]
+            if blk["shortcut"] is not None:
+                ws, _, st = blk["shortcut"]
+                b += batch * esz * (ws.shape[1] * h * w + ws.shape[0] * ((h - 1) // st + 1) * ((w - 1) // st + 1)) + esz * ws.numel()
+            cout_last = blk["convs"][-1][0].shape[0]
+            for (wt, _, st, pd) in blk["convs"]:
+                k = wt.shape[2]
+                oh, ow = (bh + 2 * pd - k) // st + 1, (bw + 2 * pd - k) // st + 1
+                b += batch * esz * (wt.shape[1] * bh * bw + wt.shape[0] * oh * ow) + esz * wt.numel()
+                bh, bw = oh, ow
+            b += batch * esz * cout_last * bh * bw   # the residual read by the block's last convolution
+            h, w = bh, bw
+        return b
     h1, w1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
     h2, w2 = (h1 + 2 - 3) // 2 + 1, (w1 + 2 - 3) // 2 + 1
     n_tow = len(R["head_towers"])
+    esz = 2 if bf16 else 4
+    c_feat = R["head_blocks"][0]["convs"][0][0].shape[1]
+    tail4 = 4.0 * ((n_tow - 1) * 2048 * 6 * 81 + 2048 * 4 * 81 + n * n_tow * 2048)
+    stem4 = 4.0 * 3 * H * W + esz * (64 * h1 * w1 * 2 + 64 * h2 * w2 * 2)
+    alg_bytes = (stem4 + blocks_bytes(R["trunk_blocks"], h2, w2, 1, esz, True)
+                 + n_tow * (esz * 2.0 * n * c_feat * 196 + blocks_bytes(R["head_blocks"], 14, 14, n, esz, True) + 4.0 * n * 2048) + tail4)
+    layerwise_bytes = (stem4 + blocks_bytes(R["trunk_blocks"], h2, w2, 1, esz)
+                       + n_tow * (esz * n * c_feat * 196 + blocks_bytes(R["head_blocks"], 14, 14, n, esz) + 4.0 * n * 2048) + tail4)
     f_trunk = 2.0 * 64 * 3 * 49 * h1 * w1 + blocks_flops(R["trunk_blocks"], h2, w2)
     f_tow = n * blocks_flops(R["head_blocks"], 14, 14) * n_tow
     f_heads = n * 2.0 * ((n_tow - 1) * 2048 * 6 * 81 + 2048 * 4 * 81)
@@ -407,7 +530,7 @@ def _cfg_resnet_mpn(models, args):  # BASELINE configs[3]
 
     def cpu(im, boxes):
         return _cpu_baseline_towers("resnet", R, im, boxes, n, 81, 6, sample=16, bf16=False)
-    return dict(params=R, net=net, n_rois=n, flops=flops, dtype="bf16" if bf16 else "f32", groups=groups, key="c4_bf16" if bf16 else "c4", cpu_baseline=cpu,
+    return dict(params=R, net=net, n_rois=n, flops=flops, dtype="bf16" if bf16 else "f32", groups=groups, key="c4_bf16" if bf16 else "c4", cpu_baseline=cpu, alg_bytes=alg_bytes, layerwise_bytes=layerwise_bytes,
                 metric="proposals/sec (1000 ROIs, 600x1000 img) ResNet-50 MultiPathNet [BASELINE configs[3]; not the headline metric]",
                 workload="ResNet-50 with MultiPathNet towers (this library's extension of models/resnet.lua: 5 layer4 towers over Foveal regions, K = 6, "
                          "81 classes), 1000 ROIs, %s" % ("bf16 activations / weights, fp32 accumulate" if bf16 else "fp32"))
@@ -425,7 +548,15 @@ def _cfg_inception_mpn(models, args):  # BASELINE configs[4]
 
     def cpu(im, boxes):
         return _cpu_baseline_towers("graph", G, im, boxes, n, 81, 6, sample=16)
-    return dict(params=G, net=net, n_rois=n, flops=flops, dtype="bf16", groups=groups, key="c5", cpu_baseline=cpu,
+    c_feat5 = G["trunk_tensor_c"][G["feat_tensor"]]
+    c_out5 = G["bbox_w"].shape[1]
+    tail5 = 4.0 * ((n_tow - 1) * c_out5 * 6 * 81 + c_out5 * 4 * 81 + n * n_tow * c_out5)
+    # tensor-level floor: every tensor written once and read once (the ROI-pooled tensor = tensor 0 of the head list: + its one write), weights once
+    alg_bytes = (4.0 * 3 * H * W + _oplist_bytes(G["trunk_ops"], H, W, 1, 2, G["trunk_tensor_c"])
+                 + n_tow * (2.0 * n * c_feat5 * 289 + _oplist_bytes(G["head_ops"], 17, 17, n, 2, G["head_tensor_c"]) + 4.0 * n * c_out5) + tail5)
+    layerwise_bytes = (4.0 * 3 * H * W + _oplist_bytes(G["trunk_ops"], H, W, 1, 2)
+                       + n_tow * (2.0 * n * c_feat5 * 289 + _oplist_bytes(G["head_ops"], 17, 17, n, 2) + 4.0 * n * c_out5) + tail5)
+    return dict(params=G, net=net, n_rois=n, flops=flops, dtype="bf16", groups=groups, key="c5", cpu_baseline=cpu, alg_bytes=alg_bytes, layerwise_bytes=layerwise_bytes,
                 metric="proposals/sec (2000 ROIs, 600x1000 img) Inception-v3 MultiPathNet bf16 [BASELINE configs[4]; not the headline metric]",
                 workload="Inception-v3 with MultiPathNet towers (this library's extension of models/inceptionv3.lua: 5 Mixed_7a..7c towers over Foveal "
                          "regions, K = 6, 81 classes), 2000 ROIs, bf16 activations / weights, fp32 accumulate")
@@ -567,9 +698,7 @@ def latency_mode(args, torch, dist, models, parallel, comm, rank, world, dev, sh
     ModelParallelTable.lua:195-242 for a single image).  A step = host image -> H2D -> trunk (every rank) -> ROI head on this rank's
     1/N of the proposals -> all-gather of decoded rows -> NMS of this rank's 1/N of the classes -> all-gather of kept tables ->
     top-100, with a device synchronisation after every step (latency, not throughput: nothing of image i+1 overlaps image i)."""
-    if share_gpu:
-        raise SystemExit("bench.py --mode latency needs one GPU per rank (RCCL refuses two ranks on one device)")
-    if comm is None:
+    if comm is None and not share_gpu:
         raise SystemExit("bench.py --mode latency: the C-ABI RCCL communicator did not come up")
     im_np, boxes_np = synthetic_inputs()
     if args.config == "c3":  # VGG-16 MultiPathNet: 5 towers — the per-ROI head is 88 % of the image, which is what this mode shards
@@ -607,11 +736,38 @@ def latency_mode(args, torch, dist, models, parallel, comm, rank, world, dev, sh
             dt = float(tt.item())
         return dt / args.steps * 1e3
 
-    ms = timed(lambda: net.test_one_sharded(comm, im_dev, boxes_dev))
-    ms_res = timed(lambda: net.test_one_sharded(comm, im_dev, boxes_dev), with_upload=False)
+    if share_gpu:
+        # TEST MODE (MPN_BENCH_SHARE_GPU=1): every rank on device 0 — RCCL refuses two ranks on one device, so the two all-gathers of
+        # mpn_frcnn_test_one_sharded go through the gloo group, records staged on the host; the three device phases are the C ABI's own
+        # (mpn_frcnn_shard_head / _nms / _finish).  Exercises the launcher, the sharding arithmetic and the reductions at this world size.
+        rr, cr = net.shard_record_floats(n_rois, world)
+
+        def gather_rows(mine, n_floats):
+            parts = [torch.empty(n_floats, dtype=torch.float32) for _ in range(world)]
+            dist.all_gather(parts, mine.detach().cpu().contiguous())
+            return torch.stack(parts).to(dev)
+
+        def sharded():
+            rows = net.shard_head(im_dev, boxes_dev, rank, world)
+            rows_all = gather_rows(rows, rr)
+            crec = net.shard_nms(rows_all, n_rois, rank, world)
+            class_all = gather_rows(crec, cr)
+            return net.shard_finish(class_all, n_rois, world)
+
+        def gather_final(d, n):
+            rec = parallel.pack_record(d, n, d.size(0)).cpu()
+            return parallel.gather_detections(rec).to(dev)
+    else:
+        def sharded():
+            return net.test_one_sharded(comm, im_dev, boxes_dev)
+
+        def gather_final(d, n):
+            return comm.gather_dets(d, n)
+    ms = timed(sharded)
+    ms_res = timed(sharded, with_upload=False)
     # outside the timed loops: every rank must hold the SAME final detections (one extra gather of the ~11-KB record), checked on rank 0
-    dets_f, n_f = net.test_one_sharded(comm, im_dev, boxes_dev)
-    allrec = comm.gather_dets(dets_f, n_f)
+    dets_f, n_f = sharded()
+    allrec = gather_final(dets_f, n_f)
     torch.cuda.synchronize()
     identical = bool(all(torch.equal(allrec[r], allrec[0]) for r in range(world))) and int(allrec[0, -1].item()) > 0
     if rank == 0 and not identical:
@@ -622,11 +778,13 @@ def latency_mode(args, torch, dist, models, parallel, comm, rank, world, dev, sh
            "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "%s, ONE image 600x1000 x %d ROIs per step for the whole job, %d classes, NMS 0.3, top-100; host image + "
                                   "boxes uploaded inside the step; device synchronisation after every step" % (model_name, n_rois, n_classes),
-                      "parallelism": "every rank: trunk on the whole image; ROI head on 1/%d of the proposals; RCCL all-gather of decoded rows; NMS of 1/%d of "
-                                     "the classes; RCCL all-gather of kept tables (mpn_frcnn_test_one_sharded through the C ABI); cpu affinity: %s"
-                                     % (world, world, affinity)},
+                      "parallelism": ("every rank: trunk on the whole image; ROI head on 1/%d of the proposals; RCCL all-gather of decoded rows; NMS of 1/%d of "
+                                      "the classes; RCCL all-gather of kept tables (mpn_frcnn_test_one_sharded through the C ABI); cpu affinity: %s"
+                                      % (world, world, affinity))
+                                     + ("; TEST MODE MPN_BENCH_SHARE_GPU=1: all ranks share device 0 and both all-gathers go through gloo (host-staged) — NOT a "
+                                        "multi-GPU measurement" if share_gpu else "")},
            "proposals_per_s": round(n_rois / (ms * 1e-3), 1), "ms_inputs_resident": round(ms_res, 4),
-           "ranks": {"rccl_ranks": comm.rccl_ranks, "final_detections_identical_on_all_ranks": identical,
+           "ranks": {"rccl_ranks": comm.rccl_ranks if comm is not None else 0, "final_detections_identical_on_all_ranks": identical,
                      "n_detections": int(allrec[0, -1].item())}}
     if world == 1:
         out["unsharded_ms"] = round(timed(lambda: net.test_one_async(im_dev, boxes_dev)), 4)  # mpn_frcnn_test_one under the same protocol
@@ -660,10 +818,89 @@ def latency_mode(args, torch, dist, models, parallel, comm, rank, world, dev, sh
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
-    comm.close()
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def power_sensitivity(torch, models, P, im_dev, boxes_dev, dev_index, prof):
+    """VERDICT r4 weak #8 / task 6a: fc6 (M = 1000, K = 25088, N = 4096; 205.5 GFLOP) ALONE, issued back to back for ~1 s, (a) on the operand the
+    pipeline hands it (ROI-pooled post-ReLU conv5 features, the model's fc6 weights) and (b) on dense random operands, clock and power sampled
+    beside each — next to the same GEMM's time INSIDE the pipeline (HIP events of the profiled leg), where it follows the trunk's phases.  The
+    back-to-back legs run in the DEBUG flavour of the library (same sources and kernels; mpn_debug_bench_fc6 / mpn_debug_bench_linear)."""
+    import ctypes as C
+    from multipathnet_amd import _lib
+    out = {"what": "fc6 alone, back to back, ~1 s per leg (debug-flavour library, same kernel: gemm_c8_pf_kernel); in_pipeline = the profiled leg's fc6 group",
+           "gflop": round(2.0 * N_ROIS * 25088 * 4096 / 1e9, 2)}
+    try:
+        fl = 2.0 * N_ROIS * 25088 * 4096
+        if prof.get("fc6", (0, 0))[1]:
+            ms_in = prof["fc6"][0] / prof["fc6"][1]
+            out["in_pipeline"] = {"us": round(ms_in * 1e3, 1), "frac_of_fp32_mfma_peak": round(fl / (ms_in * 1e-3) / FP32_MFMA_PEAK, 4)}
+        with _lib.debug_hooks() as dlib:
+            netd = models.FastRCNN(P, max_h=H, max_w=W, max_rois=N_ROIS)
+            netd.detect(im_dev, boxes_dev)
+            torch.cuda.synchronize()
+            ms = C.c_float()
+            legs = (("pipeline_operand", lambda it: dlib.mpn_debug_bench_fc6(netd._h, it, C.byref(ms))),
+                    ("dense_random_operand", lambda it: dlib.mpn_debug_bench_linear(N_ROIS, 25088, 4096, it, C.byref(ms))))
+            for name, fn in legs:
+                _lib.check(fn(20), name)
+                iters = max(50, int(1.0 / max(ms.value * 1e-3, 1e-4)))
+                sampler = ClockSampler(dev_index).start()
+                _lib.check(fn(iters), name)
+                sampler.stop()
+                leg = {"us": round(ms.value * 1e3, 1), "iters": iters, "frac_of_fp32_mfma_peak": round(fl / (ms.value * 1e-3) / FP32_MFMA_PEAK, 4)}
+                leg.update(sampler.summary())
+                out[name] = leg
+            del netd
+        torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001  (an auxiliary leg never takes the headline line down)
+        out["error"] = str(e).splitlines()[-1][:200]
+    return out
+
+
+def mixed_sizes_leg(torch, dist, models, P, dev, dev_index, world, rank, seconds):
+    """VERDICT r4 task 6d: a sustained leg over a dataset-shaped stream — bench.MIXED_SIZES, six (image size, proposal count) pairs in rotation,
+    each image rescaled ON THE DEVICE by getImages' rule (600-px short side, 1000-px cap: s = 1, 1.25, 0.5 ...), host-fed through
+    mpn_frcnn_test_one_pipelined_host like the headline step.  Every size change re-lays the activation halos.  Its own key, never the metric."""
+    stream = mixed_size_inputs()
+    net = models.FastRCNN(P, max_h=1000, max_w=1000, max_rois=N_ROIS, scale=600, max_size=1000)
+    pin = [(torch.from_numpy(i).pin_memory(), torch.from_numpy(b).pin_memory()) for i, b in stream]
+    n_rois = [b.shape[0] for _, b in stream]
+
+    def run(n_steps, start=0):
+        for t in range(n_steps):
+            i, b = pin[(start + t + rank) % len(pin)]
+            net.test_one_pipelined_host(i, b)
+        net.flush()
+        torch.cuda.synchronize()
+    run(2 * len(pin))
+    t0 = time.perf_counter()
+    run(len(pin))
+    per_round = time.perf_counter() - t0
+    rounds = max(3, int(np.ceil(seconds / per_round)))
+    if world > 1:
+        dist.barrier()
+    sampler = ClockSampler(dev_index).start()
+    t0 = time.perf_counter()
+    run(rounds * len(pin))
+    dt = time.perf_counter() - t0
+    sampler.stop()
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    out = {"what": "host-fed pipelined steps over MIXED_SIZES in rotation (a size change at EVERY step), getImages' rescale on the device; MAX over ranks",
+           "sizes": ["%dx%d x %d ROIs" % (h, w, n) for h, w, n in MIXED_SIZES], "images": rounds * len(pin), "seconds": round(dt, 3),
+           "images_per_s": round(world * rounds * len(pin) / dt, 2), "value": round(world * rounds * sum(n_rois) / dt, 1), "unit": "proposals/s",
+           "ms_per_image": round(dt / (rounds * len(pin)) * 1e3, 4)}
+    out.update(sampler.summary())
+    del net
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -677,6 +914,13 @@ def main():
                     help="c2 (default) = the headline line, BASELINE configs[1].  c1 / c3 / c4 / c5 = the other BASELINE configs, each with its "
                          "own metric string (never the headline): same timed loop, whole-path rates only")
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16"], help="c4 only (c5 is bf16, the rest fp32)")
+    ap.add_argument("--rois", type=int, default=N_ROIS,
+                    help="c2 only: another proposal count for the headline model (e.g. 2000, scripts/eval_fastrcnn_voc2007.sh) -> an AUXILIARY line with its "
+                         "own metric string; the default (1000) is the headline")
+    ap.add_argument("--mixed-sizes", action="store_true",
+                    help="c2 only: after the headline legs, a sustained leg over a dataset-shaped stream of DIFFERENT image sizes (bench.MIXED_SIZES, getImages' "
+                         "rescale on the device) -> the `mixed_sizes` object; never the headline")
+    ap.add_argument("--no-power-sensitivity", action="store_true", help="c2 only: skip the `power_sensitivity` leg (fc6 alone, back to back; debug-flavour library)")
     ap.add_argument("--mode", default="throughput", choices=["throughput", "latency"],
                     help="throughput (default) = the headline metric, images sharded over the ranks.  latency = ONE image's proposals and classes "
                          "sharded over the ranks (mpn_frcnn_test_one_sharded); its own metric string, never the headline")
@@ -759,8 +1003,8 @@ def main():
         return latency_mode(args, torch, dist, models, parallel, comm, rank, world, dev, share_gpu, affinity)
 
     other = None
-    if args.config != "c2":
-        other = OTHER_CONFIGS[args.config](models, args)
+    if args.config != "c2" or args.rois != N_ROIS:
+        other = _cfg_vgg_frcnn_n(models, args) if args.config == "c2" else OTHER_CONFIGS[args.config](models, args)
         P, net, n_rois_cfg = other["params"], other["net"], other["n_rois"]
         im_np, boxes_np = synthetic_inputs()
         boxes_np = more_boxes(boxes_np, n_rois_cfg)
@@ -918,7 +1162,7 @@ def main():
             dom = max((t for t in kernels if t in groups), key=lambda t: kernels[t]["ms_per_image"])
             tot_alg = sum(g["alg"] for g in groups.values())
             tot_ex = sum(g["alg"] - g["wino"] * save for g in groups.values())
-            traffic, traffic_src = None, None
+            traffic, traffic_src, tj = None, None, None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC passes cannot run inside the timed process: measured offline
             if os.path.exists(tpath):
                 tj = json.load(open(tpath)).get(other["key"])
@@ -939,6 +1183,13 @@ def main():
                    "roofline": {"bound": "mfma", "kernel": dom + ": " + groups[dom]["label"], "achieved": kernels[dom]["executed_tflops"],
                                 "peak": peak / 1e12, "unit": "TFLOP/s", "frac": kernels[dom]["executed_frac_of_%s_mfma_peak" % pk],
                                 "algorithmic_equiv_frac": kernels[dom]["algorithmic_equiv_frac_of_%s_mfma_peak" % pk],
+                                "algorithmic_bytes_per_image": other.get("alg_bytes"),
+                                "algorithmic_bytes_what": "the TENSOR-LEVEL floor for ONE image: every tensor of the path (activations in the config's dtype, the "
+                                                          "ROI-pooled tensors included) written once and read once however many layers consume it, weights once per "
+                                                          "launch; layerwise_bytes_per_image (graph configs) = every LAYER reading its input and writing its output once",
+                                "layerwise_bytes_per_image": other.get("layerwise_bytes"),
+                                "traffic_bytes_per_image_all_kernels": tj.get("all_kernels_bytes_per_image") if tj else None,
+                                "traffic_over_algorithmic": round(tj["all_kernels_bytes_per_image"] / other["alg_bytes"], 2) if (tj and tj.get("all_kernels_bytes_per_image") and other.get("alg_bytes")) else None,
                                 "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_kernel": traffic,
                                 "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE) of the group's dominant kernel by name, averaged over its launches",
                                 "traffic_source": traffic_src,
@@ -966,6 +1217,14 @@ def main():
     torch.cuda.synchronize()
     prof = net.get_profile(reset=True)
     net.set_profiling(False)
+
+    # ---- auxiliary legs of the headline config (never the metric): fc6's sensitivity to clock / operand, and a mixed-size stream
+    power_sens = None
+    if world == 1 and not args.no_power_sensitivity:
+        power_sens = power_sensitivity(torch, models, P, im_dev, boxes_dev, dev_index, prof)
+    mixed = None
+    if args.mixed_sizes:
+        mixed = mixed_sizes_leg(torch, dist, models, P, dev, dev_index, world, rank, max(args.sustained_seconds, 1.0))
 
     if rank == 0:
         cf = conv_flops(models.VGG16_CFG, H, W)
@@ -1030,6 +1289,10 @@ def main():
                 out["roofline"]["traffic"] = tj[dom]["bytes_per_launch"]
                 out["roofline"]["traffic_unit"] = "HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)"
                 out["roofline"]["traffic_source"] = tj.get("_source")
+        if power_sens is not None:
+            out["power_sensitivity"] = power_sens
+        if mixed is not None:
+            out["mixed_sizes"] = mixed
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(P, im_np, boxes_np, args.cpu_rois)
         print(json.dumps(out))

@@ -900,7 +900,7 @@ using namespace mpn;
 //          first set bit of the position bitset, a suppressed rank clears the bit of the slot it occupies.  (Python model against
 //          the compiled nms.c: tools/models/nms_fused_model.py.)
 //   4. the whole block writes the kept rows / source indices in pick order.
-// Classes with NaN scores are flagged (flags[c] = 2) for the exact IoU-sweep kernel launched behind this one.
+// A NaN score is never picked by nms.c:77's '>' : such rows sort with the unpickable ones (scores <= -1e7, nms.c:75).
 constexpr int kFusedMax = 1024;
 
 __device__ __forceinline__ int wave_min_i32(int v) {
@@ -911,17 +911,16 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 
 __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict__ scored, const int *__restrict__ counts, int m_stride, float thr,
                                                          float *__restrict__ keep, int *__restrict__ keep_idx, int *__restrict__ n_keep,
-                                                         unsigned long long *gmask, unsigned int *cnt, int *__restrict__ flags, int cap_w,
-                                                         int mask_bytes) {
+                                                         unsigned long long *gmask, unsigned int *cnt, int cap_w, int mask_bytes) {
   typedef unsigned long long u64;
   extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
-  __shared__ int sh_hasnan, sh_nsel, sh_ties, sh_last, sh_kept;
+  __shared__ int sh_nsel, sh_ties, sh_last, sh_kept;
   const int cls = blockIdx.y, slice = blockIdx.x, S = gridDim.x, tid = threadIdx.x, nt = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
   int m = counts ? counts[cls] : m_stride;
   if (m > m_stride) m = m_stride;
   if (m <= 0) {
-    if (slice == 0 && tid == 0) { n_keep[cls] = 0; flags[cls] = 5; }
+    if (slice == 0 && tid == 0) n_keep[cls] = 0;
     return;
   }
   const int W = (m + 63) >> 6, cap = W * 64, cap_s = cap_w * 64;
@@ -935,7 +934,7 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
   u64 *APW = EQ + 16;                                                        // alive by position                                   [16 words]
   u64 *keys = LM;
   const float *src = scored + (size_t)cls * m_stride * 5;
-  if (tid == 0) { sh_hasnan = 0; sh_nsel = 0; sh_ties = 0; sh_kept = 0; }
+  if (tid == 0) { sh_nsel = 0; sh_ties = 0; sh_kept = 0; }
   if (tid < 16) EQ[tid] = 0ull;
   __syncthreads();
   // ---- 1. keys + bitonic sort
@@ -943,18 +942,14 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
     u64 k = ~0ull;
     if (i < m) {
       const float sc = src[5 * (size_t)i + 4];
-      if (sc != sc) sh_hasnan = 1;
       unsigned u = __float_as_uint(sc);
-      if ((u << 1) == 0u) u = 0u;   // -0.0f and 0.0f are EQUAL for nms.c:77's '>': one key, so that the array order decides between them
+      if ((u << 1) == 0u) u = 0u;          // -0.0f and 0.0f are EQUAL for nms.c:77's '>': one key, so that the array order decides between them
+      if (sc != sc) u = 0xff800000u;       // a NaN score is never picked (nms.c:77: `NaN > bestS` is false): it sorts with the unpickable rows, as -inf
       k = ((u64)(~nms_f2key(__uint_as_float(u))) << 32) | (unsigned)i;
     }
     keys[i] = k;
   }
   __syncthreads();
-  if (sh_hasnan) {  // the exact sweep kernel reproduces the reference's behaviour on NaN scores
-    if (slice == 0 && tid == 0) flags[cls] = 2;
-    return;
-  }
   for (int k = 2; k <= n_pad; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int t = tid; t < n_pad / 2; t += nt) {
@@ -976,7 +971,7 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
       const float *q = src + 5 * (size_t)i;
       box[r] = make_float4(q[0], q[1], q[2], q[3]);
       sid[r] = (unsigned short)i;
-      sel = q[4] > -10000000.0f;
+      sel = q[4] > -10000000.0f;  // (false for NaN)
     }
     const u64 be = __ballot(e), bs = __ballot(sel);
     if (lane == 0) {
@@ -1023,17 +1018,18 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
     }
   }
   // ---- 3. the last block of the class to arrive runs the selection
-  __threadfence();
+  // ONE release / acquire per block (the barrier makes the block's mask words happen-before thread 0's release; a device-scope fence in
+  // every wave — buffer_wbl2 x 16 waves x 240 blocks — measured 250 us of a 440-us launch).  The mask words are read back below with
+  // device-scope atomic loads (sc1: past the non-coherent L2 lines of another XCD).
   __syncthreads();
   if (tid == 0) {
-    const unsigned old = atomicAdd(&cnt[cls], 1u);
+    const unsigned old = __hip_atomic_fetch_add(&cnt[cls], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     const int last = old == (unsigned)(S - 1);
     if (last) cnt[cls] = 0u;  // ready for the next launch
     sh_last = last;
   }
   __syncthreads();
   if (!sh_last) return;
-  __threadfence();
   {
     const u64 *G = gmask + (size_t)cls * m_stride * cap_w;
     for (int idx = tid; idx < m * W; idx += nt) {
@@ -1070,12 +1066,16 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
         }
         if ((kw >> lane) & 1ull) klist[kept + __popcll(kw & ((1ull << lane) - 1ull))] = (unsigned short)r;
         kept += __popcll(kw);
-        if (lane > c && lane < W) {
+        if (lane > c && lane < W) {  // four independent ds_reads in flight per trip
           u64 rem = 0ull, k = kw;
+          const u64 *col = LM + 64 * c * W + lane;
           while (k) {
-            const int j = __builtin_ctzll(k);
-            k &= k - 1ull;
-            rem |= LM[(64 * c + j) * W + lane];
+            const int j0 = __builtin_ctzll(k); k &= k - 1ull;
+            const int j1 = k ? __builtin_ctzll(k) : j0; k &= k - 1ull;
+            const int j2 = k ? __builtin_ctzll(k) : j0; k &= k - 1ull;
+            const int j3 = k ? __builtin_ctzll(k) : j0; k &= k - 1ull;
+            const u64 v0 = col[j0 * W], v1 = col[j1 * W], v2 = col[j2 * W], v3 = col[j3 * W];
+            rem |= (v0 | v1) | (v2 | v3);
           }
           aw &= ~rem;
         }
@@ -1088,8 +1088,12 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
         const u64 word0 = readlane64(aw, w0);
         const int r0 = 64 * w0 + __builtin_ctzll(word0);
         if (r0 >= n_sel) break;  // only unpickable rows are left
-        int b = r0;
+        // one LDS round trip: the run bit, the position words and — speculatively, for the common pick b = r0 — its slot and mask row
         const u64 eq0 = EQ[w0];
+        const u64 apw = lane < 16 ? APW[lane] : 0ull;
+        int pb = (int)pos[r0];
+        u64 row = lane < W ? LM[r0 * W + lane] : 0ull;
+        int b = r0;
         if ((eq0 >> (r0 & 63)) & 1ull) {  // an equal-score run: its alive member with the smallest slot
           int w = w0;
           u64 x = ~eq0 & (~0ull << (r0 & 63));
@@ -1101,28 +1105,43 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
             const int r = 64 * ww + lane;
             const bool in = r >= r0 && r <= e && ((a >> lane) & 1ull);
             const int p = in ? (int)pos[r] : 0x7fffffff;
-            best = p < best ? p : best;
+            u64 mb = __ballot(in);
+            if (__popcll(mb) <= 6) {  // a few members: scalar minimum over their lanes
+              while (mb) {
+                const int l = __builtin_ctzll(mb);
+                mb &= mb - 1ull;
+                const int q = __builtin_amdgcn_readlane(p, l);
+                best = q < best ? q : best;
+              }
+            } else {
+              const int q = wave_min_i32(p);
+              best = q < best ? q : best;
+            }
           }
-          best = wave_min_i32(best);
-          b = __builtin_amdgcn_readfirstlane((int)owner[best]);
+          best = __builtin_amdgcn_readfirstlane(best);
+          if (best != __builtin_amdgcn_readfirstlane(pb)) {
+            pb = best;  // the pick's slot IS the minimum found
+            b = __builtin_amdgcn_readfirstlane((int)owner[best]);
+            row = lane < W ? LM[b * W + lane] : 0ull;
+          }
         }
+        pb = __builtin_amdgcn_readfirstlane(pb);
         // nms.c:83-85: boxes[0] <-> boxes[best] — the head (first alive slot) takes the pick's slot, the pick leaves the array
-        const u64 apw = lane < 16 ? APW[lane] : 0ull;
         const u64 nzp = __ballot(apw != 0ull);
         const int pw = __builtin_ctzll(nzp);
         const u64 pword = readlane64(apw, pw);
         const int pf = 64 * pw + __builtin_ctzll(pword);
-        const int pb = __builtin_amdgcn_readfirstlane((int)pos[b]);
-        const int f = __builtin_amdgcn_readfirstlane((int)owner[pf]);
+        if (pf != pb) {  // (pf == pb: the pick WAS the head)
+          const int f = __builtin_amdgcn_readfirstlane((int)owner[pf]);
+          if (lane == 0) { owner[pb] = (unsigned short)f; pos[f] = (unsigned short)pb; }
+        }
         if (lane == 0) {
-          APW[pw] = pword & ~(1ull << (pf & 63));  // pf == pb: the pick WAS the head; else the head's old slot empties and it lives on in slot pb
-          if (pf != pb) { owner[pb] = (unsigned short)f; pos[f] = (unsigned short)pb; }
+          APW[pw] = pword & ~(1ull << (pf & 63));  // the head's old slot empties (when it was not the pick it lives on in slot pb, whose bit stays set)
           klist[kept] = (unsigned short)b;
         }
         ++kept;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // lane 0's slot update before the lanes' reads below (LDS is in order per wave)
         // nms.c:91-98: the survivors keep `iou <= threshold`
-        const u64 row = lane < W ? LM[b * W + lane] : 0ull;
         if (lane == (b >> 6)) aw &= ~(1ull << (b & 63));
         u64 newly = row & aw;
         aw &= ~row;
@@ -1149,7 +1168,7 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
     int *kidx = keep_idx + (size_t)cls * m_stride;
     for (int k = tid; k < K; k += nt) kidx[k] = (int)sid[klist[k]];
   }
-  if (tid == 0) { n_keep[cls] = K; flags[cls] = 5; }
+  if (tid == 0) n_keep[cls] = K;
 }
 
 MPN_KNOB(int, g_nms_force_exact, 0);  // test hook: 1 = always the exact IoU-sweep kernel, 2 = always the tie (slot-emulation) kernel, 3 = always the replaying scan
@@ -1184,7 +1203,7 @@ extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n
     MPN_CHECK_LAUNCH();
     return MPN_OK;
   }
-  if (m_stride <= kFusedMax && g_nms_fused && g_nms_force_exact == 0) {  // one launch: nms_fused_kernel (+ the sweep kernel behind it for NaN classes)
+  if (m_stride <= kFusedMax && g_nms_fused && g_nms_force_exact == 0) {  // one launch: nms_fused_kernel
     const int cap_w = (m_stride + 63) / 64, cap_s = cap_w * 64;
     int n_pad = 64;
     while (n_pad < m_stride) n_pad <<= 1;
@@ -1198,18 +1217,12 @@ extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n
     const int nt = n_pad < 256 ? 256 : (n_pad > 1024 ? 1024 : n_pad);
     const size_t gm_bytes = ((size_t)n_cls * m_stride * cap_w * 8 + 255) & ~(size_t)255;
     void *ws = nullptr, *wc = nullptr;
-    int rc_ws = scratch_get(SCR_NMS, gm_bytes + (size_t)n_cls * sizeof(int), st, &ws);
+    int rc_ws = scratch_get(SCR_NMS, gm_bytes, st, &ws);
     if (rc_ws == MPN_OK) rc_ws = scratch_get_zeroed(SCR_NMS_CNT, ((size_t)n_cls * sizeof(unsigned) + 4095) & ~(size_t)4095, st, &wc);
     if (rc_ws) return rc_ws;
-    int *fl = reinterpret_cast<int *>(static_cast<char *>(ws) + gm_bytes);
     { int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(nms_fused_kernel), 160 * 1024 - 64); if (rc_attr) return rc_attr; }
     hipLaunchKernelGGL(nms_fused_kernel, dim3(S, n_cls), dim3(nt), lds, st, d_scored, d_counts, m_stride, thr, d_keep, d_keep_idx, d_n_keep,
-                       static_cast<unsigned long long *>(ws), static_cast<unsigned int *>(wc), fl, cap_w, (int)mask_bytes);
-    MPN_CHECK_LAUNCH();
-    const int m_cap_w = (m_stride + 3) & ~3;
-    { int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(nms_wave_kernel), MPN_NMS_MAX_BOXES * 6 * 4); if (rc_attr) return rc_attr; }
-    hipLaunchKernelGGL(nms_wave_kernel, dim3(n_cls), dim3(kWave), (size_t)m_cap_w * 6 * sizeof(float), st, d_scored, d_counts, m_stride, thr, d_keep, d_keep_idx,
-                       d_n_keep, m_cap_w, fl, (float *)nullptr);
+                       static_cast<unsigned long long *>(ws), static_cast<unsigned int *>(wc), cap_w, (int)mask_bytes);
     MPN_CHECK_LAUNCH();
     return MPN_OK;
   }

@@ -1398,6 +1398,32 @@ extern "C" int mpn_frcnn_nms_results(mpn_frcnn *p, const float **d_keep, const i
   return MPN_OK;
 }
 
+#ifdef MPN_DEBUG_HOOKS
+// bench.py's `power_sensitivity` leg (debug flavour only): fc6 of the VGG Fast R-CNN pipeline issued `iters` times BACK TO BACK on the
+// operand the last detect() left in HBM (the ROI-pooled, post-ReLU conv5 features and the handle's own fc6 weights) — the same GEMM that
+// mpn_debug_bench_linear times on dense random operands.  Inside the pipeline fc6 follows the trunk's phases and runs at a higher clock.
+extern "C" int mpn_debug_bench_fc6(mpn_frcnn *p, int iters, float *ms_out) {
+  MPN_CHECK_ARG(p && iters > 0 && ms_out);
+  if (p->rn || p->is_mpnet || p->last_n <= 0) { set_error("mpn_debug_bench_fc6: needs a VGG Fast R-CNN handle after a detect()"); return MPN_ESTATE; }
+  ScratchScope scratch_scope(&p->scratch);
+  const int N = p->last_n, F = p->cfg.fc_dim;
+  hipEvent_t e0, e1;
+  MPN_CHECK_HIP(hipEventCreate(&e0)); MPN_CHECK_HIP(hipEventCreate(&e1));
+  int rc = MPN_OK;
+  for (int i = 0; i < 2 && rc == MPN_OK; ++i) rc = linear_c8(p->x6, N, p->K6, p->w6, p->b6, F, 1, p->y6, nullptr, nullptr, 0, nullptr, 1);
+  MPN_CHECK_HIP(hipDeviceSynchronize());
+  MPN_CHECK_HIP(hipEventRecord(e0, nullptr));
+  for (int i = 0; i < iters && rc == MPN_OK; ++i) rc = linear_c8(p->x6, N, p->K6, p->w6, p->b6, F, 1, p->y6, nullptr, nullptr, 0, nullptr, 1);
+  MPN_CHECK_HIP(hipEventRecord(e1, nullptr));
+  MPN_CHECK_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  MPN_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = ms / iters;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return rc;
+}
+#endif
+
 extern "C" int mpn_frcnn_debug_tensor(mpn_frcnn *p, const char *name, const float **d_ptr, size_t *n_elems) {
   MPN_CHECK_ARG(p && name && d_ptr && n_elems);
   if (p->last_n <= 0 || (!p->rn && p->last_h <= 0)) { set_error("mpn_frcnn_debug_tensor: run detect first"); return MPN_ESTATE; }

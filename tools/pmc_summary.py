@@ -21,7 +21,11 @@ for key, c in sorted(acc.items(), key=lambda kv: -kv[1].get("_dur_us", 0)):
     n = cnt[key]
     g = c.get("GRBM_GUI_ACTIVE", 0) / n / 8.0  # the counter is reported per XCD (8 rows per dispatch): average them
     line = "%-58s grid=%-8s n=%-3d" % (key[0], key[1], n)
-    if c["_dur_us"]: line += " dur=%8.1fus clk=%5.0fMHz" % (c["_dur_us"] / n, g / (c["_dur_us"] / n))
+    if c["_dur_us"]:
+        line += " dur=%8.1fus" % (c["_dur_us"] / n)
+        # effective clock = GRBM_GUI_ACTIVE / duration: only meaningful where that counter was collected (the SQ pass, not the FETCH / WRITE
+        # passes) and where the launch is long enough for the ratio not to be dominated by the counter's start / stop skew (>= 20 us)
+        if g and c["_dur_us"] / n >= 20.0: line += " clk=%5.0fMHz" % (g / (c["_dur_us"] / n))
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and g: line += " mfma_util=%5.1f%%" % (100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / n / (g * 1024))
     for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
         if k in c and c.get("SQ_WAVE_CYCLES"): line += " %s=%4.1f%%" % (k[3:], 100 * c[k] / c["SQ_WAVE_CYCLES"])
