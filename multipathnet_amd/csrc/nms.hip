@@ -884,24 +884,32 @@ using namespace mpn;
 // Fused NMS for class tables of up to kFusedMax rows (round 5): ONE launch instead of the sort -> mask -> tie -> scan -> wave chain.
 //
 // grid = (S slices, n_cls classes), 1 block per CU (the greedy phase keeps the class's whole suppression mask in LDS):
-//   1. every block of a class sorts the class's keys in LDS (score desc, index asc; bitonic) — the S copies of the sort run in
-//      parallel and give the same order, which is what lets the mask be split without a second launch;
-//   2. slice s computes rows s, s + S, ... of the suppression mask — one wavefront per 64-bit word: lane j evaluates
-//      IoU(rank i, rank 64 w + j) exactly as nms.c:14-41 (the row box is an LDS broadcast, the 64 column boxes one
-//      conflict-free ds_read_b128 each), a ballot is the word — and writes them to HBM scratch;
-//   3. the LAST block of the class to finish (device-scope counter, release / acquire fences) pulls the mask into LDS and one
-//      wavefront runs the greedy selection:
-//        tie-free class: picks follow the rank order; a chunk of 64 ranks is resolved with scalar bit arithmetic on its diagonal
-//          words, then the kept rows are OR-ed into the per-lane alive words (LDS reads, all in flight);
+//   1. every block of a class sorts the class's keys (score desc, index asc): one key per thread, a bitonic network whose strides below 64
+//      are wave shuffles and whose larger strides go through LDS — the S copies of the sort run in parallel and give the same order,
+//      which is what lets the mask be split without a second launch;
+//   2. slice s computes rows s, s + S, ... of the suppression mask — one wavefront per row, two 64-bit words per trip: lane j evaluates
+//      IoU(rank i, rank 64 w + j) exactly as nms.c:14-41 (the row box is an LDS broadcast, the 64 column boxes one conflict-free
+//      ds_read_b128 each), a ballot is the word — and writes them THROUGH to memory (device-scope stores: nothing is left dirty in
+//      this XCD's L2, so no cache write-back stands between the slices and the block that consumes them);
+//   3. the LAST block of the class to finish (device-scope counter) pulls the mask into LDS and one wavefront runs the greedy selection:
+//        tie-free class: picks follow the rank order; a chunk of 64 ranks is resolved as a 64-lane fixpoint on its diagonal words
+//          (lane j is kept iff it is alive and no KEPT lower lane overlaps it: a handful of ballots), then the kept rows are OR-ed
+//          into the per-lane alive words (LDS reads, four in flight);
 //        class with bit-equal scores: the reference's pick depends on its array history (nms.c:74-98: FIRST maximum in array order;
-//          the old first element takes the picked box's slot; survivors keep their order).  Simulated exactly, O(1) LDS words per
-//          round, with two bitsets — alive by RANK (register word per lane) and alive by POSITION (slot in the reference's array;
-//          LDS words) — plus pos[rank] / owner[slot]: a run's pick is its alive member with the smallest slot, the head is the
-//          first set bit of the position bitset, a suppressed rank clears the bit of the slot it occupies.  (Python model against
-//          the compiled nms.c: tools/models/nms_fused_model.py.)
+//          the old first element takes the picked box's slot; survivors keep their order).  Simulated exactly with two bitsets kept in
+//          registers — alive by RANK and occupied by POSITION (slot in the reference's array; dead occupants are dropped lazily, when
+//          they surface as the head) — plus pos[rank] / owner[slot] in LDS: a run's pick is its alive member with the smallest slot
+//          (the run's slots are cached in registers while the run lasts), the head is the first occupied slot whose owner is alive.
+//          One LDS round trip per pick.  (Python model against the compiled nms.c: tools/models/nms_fused_model.py.)
 //   4. the whole block writes the kept rows / source indices in pick order.
 // A NaN score is never picked by nms.c:77's '>' : such rows sort with the unpickable ones (scores <= -1e7, nms.c:75).
 constexpr int kFusedMax = 1024;
+#ifdef MPN_DEBUG_HOOKS
+__device__ unsigned long long g_fused_trace[16];  // s_memtime stamps of class 0's LAST block at the phase boundaries (tools/nms_fused_trace.py)
+#define FUSED_STAMP(i) do { if (cls == 0 && tid == 0) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FUSED_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ int wave_min_i32(int v) {
 #pragma unroll
@@ -911,55 +919,63 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 
 __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict__ scored, const int *__restrict__ counts, int m_stride, float thr,
                                                          float *__restrict__ keep, int *__restrict__ keep_idx, int *__restrict__ n_keep,
-                                                         unsigned long long *gmask, unsigned int *cnt, int cap_w, int mask_bytes) {
+                                                         unsigned long long *gmask, unsigned int *cnt, int lw, int mask_bytes) {
+  // lw = log2 of the mask's row pitch in 64-bit words (a power of two >= ceil(m_stride / 64)), in HBM and in LDS; blockDim.x = the sort
+  // width = the power of two >= max(64, m_stride)
   typedef unsigned long long u64;
   extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
   __shared__ int sh_nsel, sh_ties, sh_last, sh_kept;
   const int cls = blockIdx.y, slice = blockIdx.x, S = gridDim.x, tid = threadIdx.x, nt = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
+#ifdef MPN_DEBUG_HOOKS
+  unsigned long long stamp[12] = {};
+#endif
+  FUSED_STAMP(0);
   int m = counts ? counts[cls] : m_stride;
   if (m > m_stride) m = m_stride;
   if (m <= 0) {
     if (slice == 0 && tid == 0) n_keep[cls] = 0;
     return;
   }
-  const int W = (m + 63) >> 6, cap = W * 64, cap_s = cap_w * 64;
-  int n_pad = 64;
-  while (n_pad < m) n_pad <<= 1;
-  u64 *LM = reinterpret_cast<u64 *>(fused_lds);                             // sort keys, later the class's mask [m][W]
+  const int W = (m + 63) >> 6, cap = W * 64, Wp = 1 << lw, cap_s = nt;
+  u64 *LM = reinterpret_cast<u64 *>(fused_lds);                             // sort exchange buffer [nt], later the class's mask [m][Wp]
   float4 *box = reinterpret_cast<float4 *>(fused_lds + mask_bytes);          // sorted boxes [cap_s]; later klist | pos | owner (u16 [cap_s] each)
   unsigned short *sid = reinterpret_cast<unsigned short *>(fused_lds + mask_bytes + (size_t)cap_s * 16);  // source row of rank r
   unsigned short *fw = sid + cap_s;                                          // first mask word of row r that is computed
   u64 *EQ = reinterpret_cast<u64 *>(fw + cap_s);                             // bit r: ranks r and r + 1 carry the same score   [16 words]
-  u64 *APW = EQ + 16;                                                        // alive by position                                   [16 words]
   u64 *keys = LM;
   const float *src = scored + (size_t)cls * m_stride * 5;
   if (tid == 0) { sh_nsel = 0; sh_ties = 0; sh_kept = 0; }
   if (tid < 16) EQ[tid] = 0ull;
-  __syncthreads();
-  // ---- 1. keys + bitonic sort
-  for (int i = tid; i < n_pad; i += nt) {
-    u64 k = ~0ull;
-    if (i < m) {
-      const float sc = src[5 * (size_t)i + 4];
-      unsigned u = __float_as_uint(sc);
-      if ((u << 1) == 0u) u = 0u;          // -0.0f and 0.0f are EQUAL for nms.c:77's '>': one key, so that the array order decides between them
-      if (sc != sc) u = 0xff800000u;       // a NaN score is never picked (nms.c:77: `NaN > bestS` is false): it sorts with the unpickable rows, as -inf
-      k = ((u64)(~nms_f2key(__uint_as_float(u))) << 32) | (unsigned)i;
-    }
-    keys[i] = k;
+  // ---- 1. one key per thread
+  u64 key = ~0ull;
+  if (tid < m) {
+    const float sc = src[5 * (size_t)tid + 4];
+    unsigned u = __float_as_uint(sc);
+    if ((u << 1) == 0u) u = 0u;          // -0.0f and 0.0f are EQUAL for nms.c:77's '>': one key, so that the array order decides between them
+    if (sc != sc) u = 0xff800000u;       // a NaN score is never picked (nms.c:77: `NaN > bestS` is false): it sorts with the unpickable rows, as -inf
+    key = ((u64)(~nms_f2key(__uint_as_float(u))) << 32) | (unsigned)tid;
   }
-  __syncthreads();
-  for (int k = 2; k <= n_pad; k <<= 1)
+  FUSED_STAMP(1);
+  for (int k = 2; k <= nt; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < n_pad / 2; t += nt) {
-        const int lo = (t / j) * 2 * j + (t % j), hi = lo + j;
-        const bool up = ((lo & k) == 0);
-        const u64 a = keys[lo], b = keys[hi];
-        if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+      u64 other;
+      if (j >= 64) {  // block-uniform
+        __syncthreads();
+        keys[tid] = key;
+        __syncthreads();
+        other = keys[tid ^ j];
+      } else {
+        other = shfl64(key, lane ^ j);
       }
-      __syncthreads();
+      const bool take_min = ((tid & j) == 0) == ((tid & k) == 0);  // the lower index of an ascending pair, or the upper one of a descending pair
+      const bool smaller = other < key;
+      key = (smaller == take_min) ? other : key;
     }
+  __syncthreads();
+  keys[tid] = key;
+  __syncthreads();
+  FUSED_STAMP(2);
   // ---- sorted boxes, source rows, equal-score bits, the pickable prefix (nms.c:75: scores <= -1e7 are never picked)
   for (int r = tid; r < cap; r += nt) {  // cap and nt are multiples of 64: whole wavefronts
     const bool valid = r < m;
@@ -998,51 +1014,61 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
     fw[r] = (unsigned short)(rs >> 6);
   }
   __syncthreads();
-  // ---- 2. this slice's rows of the suppression mask: one wavefront per word
+  FUSED_STAMP(3);
+  // ---- 2. this slice's rows of the suppression mask: one wavefront per row, two words per trip (two independent IoU chains per lane)
   {
-    u64 *G = gmask + (size_t)cls * m_stride * cap_w;
-    const int nrows = (m - slice + S - 1) / S;  // rows slice, slice + S, ...
-    for (int it = wave; it < nrows * W; it += nwaves) {
-      const int q = it / W, w = it - q * W;
-      const int i = slice + q * S;
-      if (w < (int)fw[i]) continue;
-      const int col = 64 * w + lane;
+    u64 *G = gmask + (((size_t)cls * m_stride) << lw);
+    for (int i = slice + wave * S; i < m; i += nwaves * S) {
       const float4 a = box[i];
-      bool bit = false;
-      if (col < m && col != i) {
-        const float4 c = box[col];
-        bit = !(iou_plus1(a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w) <= thr);  // nms.c:93 keeps `iou <= threshold`
+      for (int w = fw[i]; w < W; w += 2) {
+        const int c0 = 64 * w + lane, c1 = c0 + 64;
+        bool b0 = false, b1 = false;
+        if (c0 < m && c0 != i) {
+          const float4 c = box[c0];
+          b0 = !(iou_plus1(a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w) <= thr);  // nms.c:93 keeps `iou <= threshold`
+        }
+        if (c1 < m && c1 != i) {
+          const float4 c = box[c1];
+          b1 = !(iou_plus1(a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w) <= thr);
+        }
+        const u64 w0 = __ballot(b0), w1 = __ballot(b1);
+        if (lane == 0) {
+          __hip_atomic_store(G + ((size_t)i << lw) + w, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (w + 1 < W) __hip_atomic_store(G + ((size_t)i << lw) + w + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
-      const u64 word = __ballot(bit);
-      if (lane == 0) G[(size_t)i * cap_w + w] = word;
     }
   }
-  // ---- 3. the last block of the class to arrive runs the selection
-  // ONE release / acquire per block (the barrier makes the block's mask words happen-before thread 0's release; a device-scope fence in
-  // every wave — buffer_wbl2 x 16 waves x 240 blocks — measured 250 us of a 440-us launch).  The mask words are read back below with
-  // device-scope atomic loads (sc1: past the non-coherent L2 lines of another XCD).
+  FUSED_STAMP(4);
+  // ---- 3. the last block of the class to arrive runs the selection.  The mask words were stored and are loaded with device-scope
+  // (write-through / cache-bypassing) accesses; every wave waits for its stores to complete, the barrier collects the waves, thread 0
+  // counts the block in.  (A device-scope release fence instead — buffer_wbl2 — measured 20-35 us per block at 1000 rows, and queues
+  // behind the other blocks' write-backs.)
+  __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (tid == 0) {
-    const unsigned old = __hip_atomic_fetch_add(&cnt[cls], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned old = __hip_atomic_fetch_add(&cnt[cls], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = old == (unsigned)(S - 1);
-    if (last) cnt[cls] = 0u;  // ready for the next launch
+    if (last) __hip_atomic_store(&cnt[cls], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
     sh_last = last;
   }
   __syncthreads();
   if (!sh_last) return;
+  FUSED_STAMP(5);
   {
-    const u64 *G = gmask + (size_t)cls * m_stride * cap_w;
-    for (int idx = tid; idx < m * W; idx += nt) {
-      const int i = idx / W, w = idx - i * W;
-      LM[idx] = (w >= (int)fw[i]) ? __hip_atomic_load(G + (size_t)i * cap_w + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    const u64 *G = gmask + (((size_t)cls * m_stride) << lw);
+    const int total = m << lw;
+#pragma unroll 4
+    for (int idx = tid; idx < total; idx += nt) {
+      const int i = idx >> lw, w = idx & (Wp - 1);
+      LM[idx] = (w >= (int)fw[i] && w < W) ? __hip_atomic_load(G + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     }
   }
   unsigned short *klist = reinterpret_cast<unsigned short *>(box), *pos = klist + cap_s, *owner = pos + cap_s;
-  if (has_ties) {
+  if (has_ties)
     for (int r = tid; r < m; r += nt) { const int x = sid[r]; pos[r] = (unsigned short)x; owner[x] = (unsigned short)r; }
-    if (tid < 16) APW[tid] = 64 * tid >= m ? 0ull : (m - 64 * tid >= 64 ? ~0ull : ((1ull << (m - 64 * tid)) - 1ull));
-  }
   __syncthreads();
+  FUSED_STAMP(6);
   if (wave == 0) {
     int kept = 0;
     u64 aw = 0ull;  // lane l: alive ranks 64 l .. 64 l + 63
@@ -1056,31 +1082,35 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
         const u64 cur = readlane64(aw, c);
         if (!cur) continue;
         const int r = 64 * c + lane;
-        const u64 D = r < m ? LM[r * W + c] : 0ull;  // lane j: the chunk's own columns of rank 64 c + j
-        u64 alive = cur, kw = 0ull;
-        while (alive) {
-          const int j = __builtin_ctzll(alive);
-          kw |= 1ull << j;
-          alive &= ~readlane64(D, j);
-          alive &= ~(1ull << j);
+        const u64 D = r < m ? LM[(r << lw) + c] : 0ull;       // lane j: the chunk's own columns of rank 64 c + j
+        const u64 T = D & ((1ull << lane) - 1ull);              // the lower lanes that overlap me (IoU is symmetric, bit for bit)
+        const bool al = (cur >> lane) & 1ull;
+        u64 kw = cur;
+        for (int it = 0; it < 66; ++it) {  // lane j is final once the lanes below it are: <= 64 rounds, typically 2-4
+          const u64 nk = __ballot(al && !(T & kw));
+          if (nk == kw) break;
+          kw = nk;
         }
         if ((kw >> lane) & 1ull) klist[kept + __popcll(kw & ((1ull << lane) - 1ull))] = (unsigned short)r;
         kept += __popcll(kw);
         if (lane > c && lane < W) {  // four independent ds_reads in flight per trip
           u64 rem = 0ull, k = kw;
-          const u64 *col = LM + 64 * c * W + lane;
+          const u64 *col = LM + ((64 * c) << lw) + lane;
           while (k) {
             const int j0 = __builtin_ctzll(k); k &= k - 1ull;
             const int j1 = k ? __builtin_ctzll(k) : j0; k &= k - 1ull;
             const int j2 = k ? __builtin_ctzll(k) : j0; k &= k - 1ull;
             const int j3 = k ? __builtin_ctzll(k) : j0; k &= k - 1ull;
-            const u64 v0 = col[j0 * W], v1 = col[j1 * W], v2 = col[j2 * W], v3 = col[j3 * W];
+            const u64 v0 = col[j0 << lw], v1 = col[j1 << lw], v2 = col[j2 << lw], v3 = col[j3 << lw];
             rem |= (v0 | v1) | (v2 | v3);
           }
           aw &= ~rem;
         }
       }
     } else {
+      const u64 eqw = lane < 16 ? EQ[lane] : 0ull;                                                        // lane l: EQ word l
+      u64 apw = 64 * lane >= m ? 0ull : (m - 64 * lane >= 64 ? ~0ull : ((1ull << (m - 64 * lane)) - 1ull)); // lane l: occupied slots 64 l ..
+      int run_s = 0, run_e = -1, mp = 0x7fffffff;  // the cached equal-score run [run_s, run_e] (<= 64 members): lane j holds pos[run_s + j]
       for (;;) {
         const u64 nz = __ballot(aw != 0ull);
         if (!nz) break;
@@ -1088,25 +1118,27 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
         const u64 word0 = readlane64(aw, w0);
         const int r0 = 64 * w0 + __builtin_ctzll(word0);
         if (r0 >= n_sel) break;  // only unpickable rows are left
-        // one LDS round trip: the run bit, the position words and — speculatively, for the common pick b = r0 — its slot and mask row
-        const u64 eq0 = EQ[w0];
-        const u64 apw = lane < 16 ? APW[lane] : 0ull;
-        int pb = (int)pos[r0];
-        u64 row = lane < W ? LM[r0 * W + lane] : 0ull;
-        int b = r0;
-        if ((eq0 >> (r0 & 63)) & 1ull) {  // an equal-score run: its alive member with the smallest slot
+        // ---- the pick: r0, or — inside an equal-score run — the run's alive member that sits first in the reference's array
+        int b = r0, pb = -1;
+        const u64 eq0 = readlane64(eqw, w0);
+        if ((eq0 >> (r0 & 63)) & 1ull) {
           int w = w0;
           u64 x = ~eq0 & (~0ull << (r0 & 63));
-          while (!x) { ++w; x = ~EQ[w]; }  // bit m - 1 is never set: terminates inside the table
-          const int e = 64 * w + __builtin_ctzll(x);  // last rank of the run
-          int best = 0x7fffffff;
-          for (int ww = w0; ww <= (e >> 6); ++ww) {
-            const u64 a = readlane64(aw, ww);
-            const int r = 64 * ww + lane;
-            const bool in = r >= r0 && r <= e && ((a >> lane) & 1ull);
-            const int p = in ? (int)pos[r] : 0x7fffffff;
+          while (!x) { ++w; x = ~readlane64(eqw, w); }  // bit m - 1 is never set: terminates inside the table
+          const int e = 64 * w + __builtin_ctzll(x);    // last rank of the run; its members below r0 are dead
+          if (e - r0 < 64) {
+            if (e != run_e) {  // a new run: its members' slots into registers (one LDS round trip per run)
+              run_s = r0; run_e = e;
+              mp = (run_s + lane <= e) ? (int)pos[run_s + lane] : 0x7fffffff;
+            }
+            const int r = run_s + lane;
+            const int wa = run_s >> 6;
+            const u64 a0 = readlane64(aw, wa), a1 = readlane64(aw, wa + 1 < 16 ? wa + 1 : 15);
+            const bool in = r <= run_e && ((((r >> 6) == wa ? a0 : a1) >> (r & 63)) & 1ull);
+            const int p = in ? mp : 0x7fffffff;
             u64 mb = __ballot(in);
-            if (__popcll(mb) <= 6) {  // a few members: scalar minimum over their lanes
+            int best = 0x7fffffff;
+            if (__popcll(mb) <= 8) {  // a few members: scalar minimum over their lanes
               while (mb) {
                 const int l = __builtin_ctzll(mb);
                 mb &= mb - 1ull;
@@ -1114,49 +1146,58 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
                 best = q < best ? q : best;
               }
             } else {
-              const int q = wave_min_i32(p);
-              best = q < best ? q : best;
+              best = __builtin_amdgcn_readfirstlane(wave_min_i32(p));
             }
-          }
-          best = __builtin_amdgcn_readfirstlane(best);
-          if (best != __builtin_amdgcn_readfirstlane(pb)) {
-            pb = best;  // the pick's slot IS the minimum found
+            const u64 hit = __ballot(in && p == best);
+            b = run_s + __builtin_ctzll(hit);
+            pb = best;
+          } else {  // a run of more than 64 members (saturated scores): its alive members' slots straight from LDS
+            int best = 0x7fffffff;
+            for (int ww = w0; ww <= (e >> 6); ++ww) {
+              const u64 a = readlane64(aw, ww);
+              const int r = 64 * ww + lane;
+              const bool in = r >= r0 && r <= e && ((a >> lane) & 1ull);
+              const int p = in ? (int)pos[r] : 0x7fffffff;
+              best = p < best ? p : best;
+            }
+            best = __builtin_amdgcn_readfirstlane(wave_min_i32(best));
             b = __builtin_amdgcn_readfirstlane((int)owner[best]);
-            row = lane < W ? LM[b * W + lane] : 0ull;
+            pb = best;
           }
         }
-        pb = __builtin_amdgcn_readfirstlane(pb);
-        // nms.c:83-85: boxes[0] <-> boxes[best] — the head (first alive slot) takes the pick's slot, the pick leaves the array
-        const u64 nzp = __ballot(apw != 0ull);
-        const int pw = __builtin_ctzll(nzp);
-        const u64 pword = readlane64(apw, pw);
-        const int pf = 64 * pw + __builtin_ctzll(pword);
-        if (pf != pb) {  // (pf == pb: the pick WAS the head)
-          const int f = __builtin_amdgcn_readfirstlane((int)owner[pf]);
-          if (lane == 0) { owner[pb] = (unsigned short)f; pos[f] = (unsigned short)pb; }
+        // ---- one LDS round trip: the pick's mask row, its slot, and the owner of the first occupied slot (the head candidate)
+        const u64 row = lane < W ? LM[(b << lw) + lane] : 0ull;
+        int pbv = pb < 0 ? (int)pos[b] : pb;
+        int pw, pf, f;
+        u64 pword;
+        for (;;) {  // nms.c:83-85's boxes[0]: the first occupied slot whose owner is still alive (dead owners are dropped here, lazily)
+          const u64 nzp = __ballot(apw != 0ull);
+          pw = __builtin_ctzll(nzp);
+          pword = readlane64(apw, pw);
+          pf = 64 * pw + __builtin_ctzll(pword);
+          f = __builtin_amdgcn_readfirstlane((int)owner[pf]);
+          if ((readlane64(aw, f >> 6) >> (f & 63)) & 1ull) break;
+          if (lane == pw) apw &= ~(1ull << (pf & 63));
         }
-        if (lane == 0) {
-          APW[pw] = pword & ~(1ull << (pf & 63));  // the head's old slot empties (when it was not the pick it lives on in slot pb, whose bit stays set)
-          klist[kept] = (unsigned short)b;
+        pbv = __builtin_amdgcn_readfirstlane(pbv);
+        // nms.c:83-85: boxes[0] <-> boxes[best] — the head takes the pick's slot (which stays occupied), the pick leaves the array
+        if (lane == pw) apw &= ~(1ull << (pf & 63));
+        if (pf != pbv) {
+          if (lane == 0) { owner[pbv] = (unsigned short)f; pos[f] = (unsigned short)pbv; }
+          if (f >= run_s && f <= run_e && lane == f - run_s) mp = pbv;  // the head is a member of the cached run
         }
+        if (lane == 0) klist[kept] = (unsigned short)b;
         ++kept;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // lane 0's slot update before the lanes' reads below (LDS is in order per wave)
         // nms.c:91-98: the survivors keep `iou <= threshold`
         if (lane == (b >> 6)) aw &= ~(1ull << (b & 63));
-        u64 newly = row & aw;
         aw &= ~row;
-        while (newly) {
-          const int j = __builtin_ctzll(newly);
-          newly &= newly - 1ull;
-          const int p = (int)pos[64 * lane + j];
-          atomicAnd(&APW[p >> 6], ~(1ull << (p & 63)));
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // lane 0's slot update before the next round's reads (LDS is in order per wave)
       }
     }
     if (lane == 0) sh_kept = kept;
   }
   __syncthreads();
+  FUSED_STAMP(7);
   // ---- 4. kept rows in pick order
   const int K = sh_kept;
   float *kout = keep + (size_t)cls * m_stride * 5;
@@ -1169,17 +1210,28 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
     for (int k = tid; k < K; k += nt) kidx[k] = (int)sid[klist[k]];
   }
   if (tid == 0) n_keep[cls] = K;
+#ifdef MPN_DEBUG_HOOKS
+  FUSED_STAMP(8);
+  if (cls == 0 && tid == 0) { for (int i = 0; i < 9; ++i) g_fused_trace[i] = stamp[i]; g_fused_trace[9] = (unsigned long long)K; g_fused_trace[10] = (unsigned long long)sh_ties; }
+#endif
 }
 
 MPN_KNOB(int, g_nms_force_exact, 0);  // test hook: 1 = always the exact IoU-sweep kernel, 2 = always the tie (slot-emulation) kernel, 3 = always the replaying scan
 MPN_KNOB(unsigned long long *, g_nms_trace, nullptr);
 MPN_KNOB(int, g_nms_guard_limit, 0);  // test hook (mpn_debug_set_nms_guard_limit): bound of the replaying scan's progress loops (0 = the real one)
+MPN_KNOB(int, g_nms_fused_slices, 0);  // test / timing hook: mask slices per class of the fused kernel (0 = fill the GPU once)
 MPN_KNOB(int, g_nms_fused, 1);  // test hook (mpn_debug_set_nms_fused): 0 = the round-2..4 launch chain also for tables of <= kFusedMax rows
 #ifdef MPN_DEBUG_HOOKS
 extern "C" void mpn_debug_set_nms_force_exact(int v) { g_nms_force_exact = v; }
 extern "C" void mpn_debug_set_nms_trace(void *p) { g_nms_trace = static_cast<unsigned long long *>(p); }
 extern "C" void mpn_debug_set_nms_guard_limit(int v) { g_nms_guard_limit = v; }
 extern "C" void mpn_debug_set_nms_fused(int v) { g_nms_fused = v; }
+extern "C" void mpn_debug_set_nms_fused_slices(int v) { g_nms_fused_slices = v; }
+extern "C" int mpn_debug_get_nms_fused_trace(unsigned long long *h_out16) {
+  MPN_CHECK_ARG(h_out16);
+  MPN_CHECK_HIP(hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(g_fused_trace), 16 * sizeof(unsigned long long)));
+  return MPN_OK;
+}
 #endif
 
 extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n_cls, int m_stride, float thr,
@@ -1204,25 +1256,27 @@ extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n
     return MPN_OK;
   }
   if (m_stride <= kFusedMax && g_nms_fused && g_nms_force_exact == 0) {  // one launch: nms_fused_kernel
-    const int cap_w = (m_stride + 63) / 64, cap_s = cap_w * 64;
-    int n_pad = 64;
-    while (n_pad < m_stride) n_pad <<= 1;
-    size_t mask_bytes = (size_t)cap_s * cap_w * 8;
-    if (mask_bytes < (size_t)n_pad * 8) mask_bytes = (size_t)n_pad * 8;
-    const size_t lds = mask_bytes + (size_t)cap_s * 16 + (size_t)cap_s * 4 + 256;
-    int S = 256 / n_cls;  // one block per CU (the mask lives in LDS): at most one wave of blocks over the 256 CUs
+    const int cap_w = (m_stride + 63) / 64;
+    int lw = 0;
+    while ((1 << lw) < cap_w) ++lw;
+    int nt = 64;
+    while (nt < m_stride) nt <<= 1;                              // one sort key per thread
+    size_t mask_bytes = ((size_t)m_stride << lw) * 8;            // the mask [m][1 << lw] in LDS ...
+    if (mask_bytes < (size_t)nt * 8) mask_bytes = (size_t)nt * 8;  // ... aliasing the sort's exchange buffer
+    mask_bytes = (mask_bytes + 15) & ~(size_t)15;
+    const size_t lds = mask_bytes + (size_t)nt * 16 + (size_t)nt * 4 + 128;
+    int S = g_nms_fused_slices > 0 ? g_nms_fused_slices : 256 / n_cls;  // one block per CU (the mask lives in LDS): at most one wave of blocks over the 256 CUs
     if (S > 16) S = 16;
     if (S > cdiv(m_stride, 32)) S = cdiv(m_stride, 32);
     if (S < 1) S = 1;
-    const int nt = n_pad < 256 ? 256 : (n_pad > 1024 ? 1024 : n_pad);
-    const size_t gm_bytes = ((size_t)n_cls * m_stride * cap_w * 8 + 255) & ~(size_t)255;
+    const size_t gm_bytes = ((((size_t)n_cls * m_stride) << lw) * 8 + 255) & ~(size_t)255;
     void *ws = nullptr, *wc = nullptr;
     int rc_ws = scratch_get(SCR_NMS, gm_bytes, st, &ws);
     if (rc_ws == MPN_OK) rc_ws = scratch_get_zeroed(SCR_NMS_CNT, ((size_t)n_cls * sizeof(unsigned) + 4095) & ~(size_t)4095, st, &wc);
     if (rc_ws) return rc_ws;
     { int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(nms_fused_kernel), 160 * 1024 - 64); if (rc_attr) return rc_attr; }
     hipLaunchKernelGGL(nms_fused_kernel, dim3(S, n_cls), dim3(nt), lds, st, d_scored, d_counts, m_stride, thr, d_keep, d_keep_idx, d_n_keep,
-                       static_cast<unsigned long long *>(ws), static_cast<unsigned int *>(wc), cap_w, (int)mask_bytes);
+                       static_cast<unsigned long long *>(ws), static_cast<unsigned int *>(wc), lw, (int)mask_bytes);
     MPN_CHECK_LAUNCH();
     return MPN_OK;
   }

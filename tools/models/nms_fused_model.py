@@ -79,6 +79,72 @@ def fused(sb, thr):
     return sb[[sid[r] for r in kept]], [sid[r] for r in kept]
 
 
+def fused_v2(sb, thr):
+    """the kernel's SECOND form (what ships): occupied-by-position bits dropped LAZILY (a dead owner is skipped when it surfaces as the head),
+    the current run's slots cached (`mp`) and patched when the head that moves is a member — same picks as fused()"""
+    sb = np.asarray(sb, np.float32)
+    m = sb.shape[0]
+    s = sb[:, 4].copy()
+    s[s == 0] = 0.0
+    s[np.isnan(s)] = -np.inf
+    order = sorted(range(m), key=lambda i: (-float(s[i]), i))
+    sid = order
+    n_sel = sum(1 for i in range(m) if s[i] > -1e7)
+    eq = [r + 1 < m and s[sid[r]] == s[sid[r + 1]] for r in range(m)]
+    if not any(eq):
+        return fused(sb, thr)
+    with np.errstate(all="ignore"):
+        sup = [[(c != r) and not (iou(sb[sid[r]], sb[sid[c]]) <= np.float32(thr)) for c in range(m)] for r in range(m)]
+    alive = [True] * m
+    pos = list(sid)
+    owner = [0] * m
+    for r in range(m):
+        owner[sid[r]] = r
+    occ = [True] * m
+    run_s, run_e, mp = 0, -1, {}
+    kept = []
+    while True:
+        r0 = next((r for r in range(m) if alive[r]), None)
+        if r0 is None or r0 >= n_sel:
+            break
+        b, pb = r0, None
+        if eq[r0]:
+            e = r0
+            while eq[e]:
+                e += 1
+            if e - r0 < 64:
+                if e != run_e:
+                    run_s, run_e = r0, e
+                    mp = {r: pos[r] for r in range(run_s, e + 1)}
+                best = min(mp[r] for r in range(run_s, run_e + 1) if alive[r])
+                b = next(r for r in range(run_s, run_e + 1) if alive[r] and mp[r] == best)
+                pb = best
+            else:
+                best = min(pos[r] for r in range(r0, e + 1) if alive[r])
+                b, pb = owner[best], best
+        if pb is None:
+            pb = pos[b]
+        while True:
+            pf = next(p for p in range(m) if occ[p])
+            f = owner[pf]
+            if alive[f]:
+                break
+            occ[pf] = False
+        occ[pf] = False
+        if pf != pb:
+            owner[pb] = f
+            pos[f] = pb
+            occ[pb] = True
+            if run_s <= f <= run_e:
+                mp[f] = pb
+        kept.append(b)
+        alive[b] = False
+        for c in range(m):
+            if alive[c] and sup[b][c]:
+                alive[c] = False
+    return sb[[sid[r] for r in kept]], [sid[r] for r in kept]
+
+
 def main():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import random_scored_boxes
@@ -86,7 +152,7 @@ def main():
     O.build()
     n_cases = 0
     for regime in ("distinct", "ties", "saturated", "allequal"):
-        for m in (1, 2, 3, 17, 64, 65, 130, 200):
+        for m in (1, 2, 3, 17, 64, 65, 130, 200, 300):
             for seed in range(4):
                 rng = np.random.default_rng(seed * 1000 + m)
                 sb = random_scored_boxes(rng, m, regime, span=300.0, lo=16.0, hi=200.0)
@@ -97,8 +163,9 @@ def main():
                 if unpick:                              # rows nms.c:75 never picks (with them the compiled reference runs into best = -1: UB;
                     sb[rng.integers(0, m, 3), 4] = -2e7  # the oracle's restatement defines the behaviour: stop)
                 ref = O.nms(sb, 0.3) if unpick else O.ref_nms(sb, 0.3)
-                got, _ = fused(sb, 0.3)
-                assert np.array_equal(got, ref), (regime, m, seed)
+                for fn in (fused, fused_v2):
+                    got, _ = fn(sb, 0.3)
+                    assert np.array_equal(got, ref), (fn.__name__, regime, m, seed)
                 n_cases += 1
     print("nms_fused_model: %d cases == compiled nms.c" % n_cases)
 

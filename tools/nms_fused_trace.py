@@ -1,0 +1,31 @@
+"""s_memtime phase trace of nms_fused_kernel (debug flavour): class 0's last block.  python tools/nms_fused_trace.py [M] [n_cls]"""
+import ctypes as C, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import multipathnet_amd
+from multipathnet_amd import utils, _lib
+from conftest import random_scored_boxes
+lib = _lib.load("debug")
+dev = torch.device("cuda:0")
+Ms = [int(sys.argv[1])] if len(sys.argv) > 1 else [300, 1000]
+n_cls_list = [int(sys.argv[2])] if len(sys.argv) > 2 else [1, 20]
+names = ["keys", "sort", "gather + eq + fw", "mask slice", "arrive", "mask -> LDS", "greedy selection", "write rows"]
+for M in Ms:
+    for n_cls in n_cls_list:
+        for regime in ("distinct", "ties", "saturated"):
+            rng = np.random.default_rng(0)
+            sb = np.stack([random_scored_boxes(rng, M, regime) for _ in range(n_cls)])
+            d = torch.from_numpy(sb).to(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with _lib.debug_hooks():
+                for _ in range(3):
+                    e0.record()
+                    keep, idx, nk = utils.nms_batched(d, None, 0.3)
+                    e1.record(); torch.cuda.synchronize()
+            tr = (C.c_ulonglong * 16)()
+            lib.mpn_debug_get_nms_fused_trace(tr)
+            t = [int(x) for x in tr]
+            tot = t[8] - t[0]
+            print("M=%d x %d classes, %-9s: kept %d (ties flag %d), %.1f us by events; class 0's last block %d shader cycles:" % (M, n_cls, regime, t[9], t[10], e0.elapsed_time(e1) * 1e3, tot))
+            print("   " + "  ".join("%s %d" % (names[i], t[i + 1] - t[i]) for i in range(8)) + ("   | %.0f cycles / pick" % ((t[7] - t[6]) / max(1, t[9]))))
