@@ -903,7 +903,8 @@ using namespace mpn;
 //          One LDS round trip per pick.  (Python model against the compiled nms.c: tools/models/nms_fused_model.py.)
 //   4. the whole block writes the kept rows / source indices in pick order.
 // A NaN score is never picked by nms.c:77's '>' : such rows sort with the unpickable ones (scores <= -1e7, nms.c:75).
-constexpr int kFusedMax = 1024;
+constexpr int kFusedMax = 1024;         // what the kernel can take (its mask must fit one CU's LDS)
+constexpr int kFusedDispatchMax = 384;  // what mpn_nms_batched sends to it (see there)
 #ifdef MPN_DEBUG_HOOKS
 __device__ unsigned long long g_fused_trace[16];  // s_memtime stamps of class 0's LAST block at the phase boundaries (tools/nms_fused_trace.py)
 #define FUSED_STAMP(i) do { if (cls == 0 && tid == 0) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -1220,7 +1221,7 @@ MPN_KNOB(int, g_nms_force_exact, 0);  // test hook: 1 = always the exact IoU-swe
 MPN_KNOB(unsigned long long *, g_nms_trace, nullptr);
 MPN_KNOB(int, g_nms_guard_limit, 0);  // test hook (mpn_debug_set_nms_guard_limit): bound of the replaying scan's progress loops (0 = the real one)
 MPN_KNOB(int, g_nms_fused_slices, 0);  // test / timing hook: mask slices per class of the fused kernel (0 = fill the GPU once)
-MPN_KNOB(int, g_nms_fused, 1);  // test hook (mpn_debug_set_nms_fused): 0 = the round-2..4 launch chain also for tables of <= kFusedMax rows
+MPN_KNOB(int, g_nms_fused, 1);  // test hook (mpn_debug_set_nms_fused): 0 = the launch chain at every size; 2 = the fused kernel for every table of <= kFusedMax rows
 #ifdef MPN_DEBUG_HOOKS
 extern "C" void mpn_debug_set_nms_force_exact(int v) { g_nms_force_exact = v; }
 extern "C" void mpn_debug_set_nms_trace(void *p) { g_nms_trace = static_cast<unsigned long long *>(p); }
@@ -1255,7 +1256,13 @@ extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n
     MPN_CHECK_LAUNCH();
     return MPN_OK;
   }
-  if (m_stride <= kFusedMax && g_nms_fused && g_nms_force_exact == 0) {  // one launch: nms_fused_kernel
+  // Dispatch (measured, profiles/r05_nms_paths.txt): the fused kernel's greedy phase is ONE wavefront, which issues an instruction every ~4
+  // cycles — 70 cycles per pick on a tie-free class (64-lane fixpoint chunks), 1 700 per pick once the class holds ANY bit-equal pair (the
+  // exact position rule, pick by pick).  Up to kFusedDispatchMax rows that is as fast as or faster than the launch chain in every score
+  // regime (300 rows x 20 classes: 30 vs 60 us tie-free, 199 vs 247 us tied); at 1000 rows a class with a handful of tied pairs — every
+  // class of a real 1000-proposal image — costs 500 us against the chain's lazily-replayed 216, so wider tables keep the chain.
+  // (mpn_debug_set_nms_fused(2) sends every table of <= kFusedMax rows to the fused kernel: tests and timing.)
+  if (m_stride <= (g_nms_fused == 2 ? kFusedMax : kFusedDispatchMax) && g_nms_fused && g_nms_force_exact == 0) {  // one launch: nms_fused_kernel
     const int cap_w = (m_stride + 63) / 64;
     int lw = 0;
     while ((1 << lw) < cap_w) ++lw;
@@ -1521,7 +1528,7 @@ extern "C" int mpn_nms_host(const float *h_scored, int m, float thr, float *h_ke
   *n_keep = 0;
   if (m == 0) return MPN_OK;
   MPN_CHECK_ARG(h_scored != nullptr && h_keep != nullptr);
-  if (m <= kFusedMax && g_nms_fused && g_nms_force_exact == 0) return nms_host_small(h_scored, m, thr, h_keep, h_keep_idx, n_keep);
+  if (m <= (g_nms_fused == 2 ? kFusedMax : kFusedDispatchMax) && g_nms_fused && g_nms_force_exact == 0) return nms_host_small(h_scored, m, thr, h_keep, h_keep_idx, n_keep);
   float *d_in = nullptr, *d_keep = nullptr;
   int *d_idx = nullptr, *d_n = nullptr;
   size_t bytes = sizeof(float) * 5 * (size_t)m;

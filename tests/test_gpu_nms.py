@@ -23,7 +23,7 @@ def nms_path(request):
     tied pairs —, the slot-emulating tie kernel for classes with many bit-equal scores, the IoU-sweep kernel for NaN / oversize);
     1 = IoU-sweep kernel only; 2 = tie kernel wherever it applies; 3 = the replaying scan for every class, however many ties it has (its
     pick-by-pick rule); 4 = the launch chain's own dispatch at every size (the fused kernel switched off)"""
-    with hooks(nms_force_exact=request.param % 4, nms_fused=0 if request.param == 4 else 1):  # 0 = the product library's own dispatch
+    with hooks(nms_force_exact=request.param % 4, nms_fused=0 if request.param == 4 else 1):  # 0 = the product library's own dispatch (fused up to 384 rows)
         yield request.param
 
 
@@ -291,7 +291,7 @@ def test_nms_lazy_replay_fuzz_vs_reference(O, dev, seed):
         ref = O.ref_nms(sb, thr) if O.have_ref() else O.nms(sb, thr)
         mine, ridx = O.nms(sb, thr, return_index=True)
         assert np.array_equal(mine, ref)
-        for fused in ((1, 0) if n <= 1024 else (1,)):   # tables of <= 1024 rows default to the fused kernel: the replay is kept covered there too
+        for fused in ((2, 1, 0) if n <= 1024 else (1,)):   # <= 1024 rows: the fused kernel forced (2), the product dispatch (1: fused up to 384 rows), the chain (0)
             with hooks(nms_fused=fused):
                 keep, idx = utils.nms_with_index(_t(sb, dev), thr)
             assert keep.shape[0] == ref.shape[0] and np.array_equal(keep.cpu().numpy(), ref), (seed, n, thr, fused)
@@ -310,7 +310,8 @@ def test_nms_fused_kernel_sizes(O, dev, regime, n):
         ref = O.ref_nms(sb, thr) if O.have_ref() else O.nms(sb, thr)
         mine, ridx = O.nms(sb, thr, return_index=True)
         assert np.array_equal(mine, ref)
-        keep, idx = utils.nms_with_index(_t(sb, dev), thr)
+        with hooks(nms_fused=2):   # the fused kernel at every size it can take (the product dispatch stops at 384 rows)
+            keep, idx = utils.nms_with_index(_t(sb, dev), thr)
         assert keep.shape[0] == ref.shape[0] and np.array_equal(keep.cpu().numpy(), ref), (regime, n, thr)
         assert np.array_equal(idx.cpu().numpy(), ridx)
 
@@ -335,7 +336,8 @@ def test_nms_fused_kernel_fuzz_vs_reference(O, dev, seed):
         ref = O.ref_nms(sb, thr) if O.have_ref() else O.nms(sb, thr)
         mine, ridx = O.nms(sb, thr, return_index=True)
         assert np.array_equal(mine, ref)
-        keep, idx = utils.nms_with_index(_t(sb, dev), thr)
+        with hooks(nms_fused=2):
+            keep, idx = utils.nms_with_index(_t(sb, dev), thr)
         assert keep.shape[0] == ref.shape[0] and np.array_equal(keep.cpu().numpy(), ref), (seed, n, levels, thr)
         assert np.array_equal(idx.cpu().numpy(), ridx)
 
@@ -360,7 +362,8 @@ def test_nms_fused_kernel_batched_slices(O, dev, n_cls, M):
         sb[5, M // 2, 4] = np.nan
         counts[3:6] = M
     for rep in range(2):
-        keep, idx, nk = utils.nms_batched(_t(sb, dev), _t(counts, dev), 0.3)
+        with hooks(nms_fused=2):
+            keep, idx, nk = utils.nms_batched(_t(sb, dev), _t(counts, dev), 0.3)
         keep, idx, nk = keep.cpu().numpy(), idx.cpu().numpy(), nk.cpu().numpy()
         for c in range(n_cls):
             t = sb[c, :counts[c]]

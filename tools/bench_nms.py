@@ -23,11 +23,11 @@ for regime in ("distinct", "fewties", "ties", "saturated"):
             k = rng.choice(M, 8, replace=False)
             sb[c, k[:4], 4] = sb[c, k[4:], 4]
     d = torch.from_numpy(sb).to(dev)
-    for mode, name in ((0, "auto"), (4, "chain-auto"), (3, "replay-scan"), (2, "tie-kernel"), (1, "sweep-kernel")):
+    for mode, name in ((0, "auto"), (5, "fused"), (4, "chain-auto"), (3, "replay-scan"), (2, "tie-kernel"), (1, "sweep-kernel")):
         if only_modes and mode not in only_modes:
             continue
-        lib.mpn_debug_set_nms_force_exact(mode % 4)
-        lib.mpn_debug_set_nms_fused(0 if mode == 4 else 1)   # auto = the fused one-launch kernel for tables of <= 1024 rows (round 5); chain-auto = rounds 2-4
+        lib.mpn_debug_set_nms_force_exact(0 if mode == 5 else mode % 4)
+        lib.mpn_debug_set_nms_fused(0 if mode == 4 else 2 if mode == 5 else 1)   # auto = the fused one-launch kernel for tables of <= 1024 rows (round 5); chain-auto = rounds 2-4
         with _lib.debug_hooks():
           for _ in range(2):
             keep, idx, nk = utils.nms_batched(d, None, 0.3)

@@ -7,6 +7,7 @@ import multipathnet_amd
 from multipathnet_amd import utils, _lib
 from conftest import random_scored_boxes
 lib = _lib.load("debug")
+lib.mpn_debug_set_nms_fused(2)   # the fused kernel at every size it can take (the product dispatch stops at 384 rows)
 dev = torch.device("cuda:0")
 Ms = [int(sys.argv[1])] if len(sys.argv) > 1 else [300, 1000]
 n_cls_list = [int(sys.argv[2])] if len(sys.argv) > 2 else [1, 20]
