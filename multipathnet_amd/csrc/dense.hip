@@ -625,7 +625,9 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(ConvArgs a) {
   for (int k = 0; k < 16; ++k)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
-  dma_wait_all();
+  // ABL bit 7 (round 5, timing only, garbage results): the prologue's DMA round trip is NOT waited for — what a persistent launch that
+  // prefetched the next tile's first chunk under the previous tile's epilogue could hide at the very best (tools/ablate_wino_prologue.py)
+  if constexpr ((ABL & 128) == 0) dma_wait_all();
   __syncthreads();
   tf_load(b0);
   tf_rows();
@@ -825,6 +827,8 @@ static int launch_conv_wino(const ConvArgs &a, int tiles_y, hipStream_t s) {
     case 23: return launch_conv_wino_t<23>(a, tiles_y, s);
     case 31: return launch_conv_wino_t<31>(a, tiles_y, s);
     case 64: return launch_conv_wino_t<64>(a, tiles_y, s);
+    case 128: return launch_conv_wino_t<128>(a, tiles_y, s);
+    case 136: return launch_conv_wino_t<136>(a, tiles_y, s);
     default: break;
   }
 #endif
