@@ -304,10 +304,13 @@ struct mpn_frcnn {
   struct GraphEntry { hipGraphExec_t exec = nullptr; unsigned long long gen = 0, last_use = 0; bool failed = false; int seen = 0; };
   unsigned long long graph_clock = 0;
   std::map<GraphKey, GraphEntry> graphs;
-  // the last caller-pointer key seen ONCE per segment kind: such a key enters `graphs` only at its second consecutive sighting, so a host
-  // that hands in fresh buffers every call never occupies the cache
-  GraphKey unseen[4] = {};
-  bool unseen_valid[4] = {false, false, false, false};
+  // the last few caller-pointer keys seen ONCE, per segment kind (a small ring: the pipelined forms alternate two output buffer sets, a host
+  // may rotate a handful): such a key enters `graphs` only at its second sighting while still in the ring, so a host that hands in fresh
+  // buffers every call never occupies the cache
+  static constexpr int kUnseen = 8;
+  GraphKey unseen[4][kUnseen] = {};
+  bool unseen_valid[4][kUnseen] = {};
+  int unseen_next[4] = {0, 0, 0, 0};
   int graphs_on = 0;                 // mpn_frcnn_set_graphs / MPN_GRAPHS (opt-in: see create_impl)
   hipStream_t cap_stream = nullptr;  // capture happens here (the caller's stream may be the legacy NULL stream, which cannot capture)
   int seg_shape[4][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}, {-1, -1, -1, -1}, {-1, -1, -1, -1}};  // shape of the last execution per segment kind
@@ -933,11 +936,19 @@ static int run_segment(mpn_frcnn *p, int kind, const mpn_frcnn::GraphKey &key, c
   auto it = p->graphs.find(key);
   int seen_before = 0;
   if (it == p->graphs.end()) {
-    if (!stable_ptrs) {  // first sighting of caller-provided pointers: remember the key in the side slot only
-      const mpn_frcnn::GraphKey &u = p->unseen[kind];
-      const bool again = p->unseen_valid[kind] && !(u < key) && !(key < u);
-      if (!again) { p->unseen[kind] = key; p->unseen_valid[kind] = true; return direct(); }
-      p->unseen_valid[kind] = false;
+    if (!stable_ptrs) {  // first sighting of caller-provided pointers: remember the key in the side ring only
+      int hit = -1;
+      for (int q = 0; q < mpn_frcnn::kUnseen; ++q) {
+        const mpn_frcnn::GraphKey &u = p->unseen[kind][q];
+        if (p->unseen_valid[kind][q] && !(u < key) && !(key < u)) { hit = q; break; }
+      }
+      if (hit < 0) {
+        const int q = p->unseen_next[kind];
+        p->unseen[kind][q] = key; p->unseen_valid[kind][q] = true;
+        p->unseen_next[kind] = (q + 1) % mpn_frcnn::kUnseen;
+        return direct();
+      }
+      p->unseen_valid[kind][hit] = false;
       seen_before = 1;
     }
     if (p->graphs.size() >= kMaxGraphs) {  // full: drop the entries that hold no executable graph (failed / never captured) before giving up
