@@ -862,13 +862,14 @@ def power_sensitivity(torch, models, P, im_dev, boxes_dev, dev_index, prof):
     return out
 
 
-def mixed_sizes_leg(torch, dist, models, P, dev, dev_index, world, rank, seconds):
+def mixed_sizes_leg(torch, dist, models, P, dev, dev_index, world, rank, seconds, pin=None):
     """VERDICT r4 task 6d: a sustained leg over a dataset-shaped stream — bench.MIXED_SIZES, six (image size, proposal count) pairs in rotation,
     each image rescaled ON THE DEVICE by getImages' rule (600-px short side, 1000-px cap: s = 1, 1.25, 0.5 ...), host-fed through
     mpn_frcnn_test_one_pipelined_host like the headline step.  Every size change re-lays the activation halos.  Its own key, never the metric."""
     stream = mixed_size_inputs()
     net = models.FastRCNN(P, max_h=1000, max_w=1000, max_rois=N_ROIS, scale=600, max_size=1000)
-    pin = [(torch.from_numpy(i).pin_memory(), torch.from_numpy(b).pin_memory()) for i, b in stream]
+    if pin is None:
+        pin = [(torch.from_numpy(i).pin_memory(), torch.from_numpy(b).pin_memory()) for i, b in stream]
     n_rois = [b.shape[0] for _, b in stream]
 
     def run(n_steps, start=0):
@@ -957,7 +958,10 @@ def main():
         raise SystemExit("rank %d: only %d HIP devices are visible" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    affinity = pin_to_gpu_numa_node(dev_index) if (world > 1 and not share_gpu) else "not set (single rank)" if world == 1 else "not set (shared GPU)"
+    if world == 1 and os.environ.get("MPN_BENCH_AFFINITY") == "1":
+        affinity = pin_to_gpu_numa_node(dev_index)
+    else:
+        affinity = pin_to_gpu_numa_node(dev_index) if (world > 1 and not share_gpu) else "not set (single rank)" if world == 1 else "not set (shared GPU)"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # CPU-side group: rendezvous, barriers, the MAX of the elapsed time.  No RCCL communicator is created here — the only one
@@ -1002,6 +1006,8 @@ def main():
     if args.mode == "latency":
         return latency_mode(args, torch, dist, models, parallel, comm, rank, world, dev, share_gpu, affinity)
 
+    # the mixed-size leg's pinned host inputs are staged NOW, like the headline's: (diagnostic: MPN_BENCH_MIXED_PIN_LATE=1 stages them when the leg starts)
+    mixed_pin = [(torch.from_numpy(i).pin_memory(), torch.from_numpy(b).pin_memory()) for i, b in mixed_size_inputs()] if args.mixed_sizes else None
     other = None
     if args.config != "c2" or args.rois != N_ROIS:
         other = _cfg_vgg_frcnn_n(models, args) if args.config == "c2" else OTHER_CONFIGS[args.config](models, args)
@@ -1224,7 +1230,8 @@ def main():
         power_sens = power_sensitivity(torch, models, P, im_dev, boxes_dev, dev_index, prof)
     mixed = None
     if args.mixed_sizes:
-        mixed = mixed_sizes_leg(torch, dist, models, P, dev, dev_index, world, rank, max(args.sustained_seconds, 1.0))
+        mixed = mixed_sizes_leg(torch, dist, models, P, dev, dev_index, world, rank, max(args.sustained_seconds, 1.0),
+                                pin=mixed_pin if os.environ.get("MPN_BENCH_MIXED_PIN_LATE") != "1" else None)
 
     if rank == 0:
         cf = conv_flops(models.VGG16_CFG, H, W)

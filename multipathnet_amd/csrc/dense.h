@@ -75,6 +75,11 @@ int pack_conv_weights_first(const float *d_w, int Cin, int Cout, float *d_w36, h
 int conv3x3_first_c8p(Act in, const float *d_w36, const float *d_bpk, int Cout, int relu, Act out, hipStream_t s);
 int conv3x3_variant_for(int Cout, bool has_wino = false);  // 7 = Winograd, 1 = direct 128 couts x 4 rows x 32 cols tile, 2 = direct 64 x 8 x 32
 int maxpool2x2_c8p(Act in, Act out, hipStream_t s);
+// zero the halo (everything of each plane outside the H x W interior) of n C8P activations, one launch per kHaloMax of them
+constexpr int kHaloMax = 24;
+struct HaloDesc { float *p; int H, W, Hp, Wp; };
+struct HaloTable { int n; size_t total; size_t first[kHaloMax]; HaloDesc d[kHaloMax]; };
+int c8p_zero_halos(const Act *acts, int n, hipStream_t s);
 // y = relu?(x W^T + b).  x: C8 matrix [K8/8][Mp][8]; y: C8 matrix [NP/8][Mp][8] (y_c8) and/or
 // row-major [M,N] (y_rm); either may be null.
 // Mp_override: row pitch of x / y when it is not lin_mp(M) (a ROI-pooled matrix viewed as (bin, roi) rows).

@@ -1627,6 +1627,60 @@ int image_transform_c8p(const float *d_in, int H, int W, const int *swap, double
   return MPN_OK;
 }
 
+// Re-lays the zero halo of up to kHaloMax C8P activations for a new image size in ONE launch: every record of a plane that is not one of the
+// H x W interior pixels (row 0, rows H + 1 .. Hp - 1, column 0, columns W + 1 .. Wp - 1).  The interior is rewritten by the producing layer
+// before anything reads it; the halo is what the 3x3 padding and the ragged tile edges read.  (Round 5: this replaces one hipMemsetAsync of
+// the WHOLE allocation per activation — 19 runtime blits, ~1 GB at a 1000 x 1000 cap — which cost a mixed-size stream 0.2 ms per size change
+// stand-alone and 1.9 ms inside bench.py, where the blits' cross-queue synchronisation went through more hardware queues.)
+__global__ void c8p_zero_halos_kernel(HaloTable t) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= t.total) return;
+  int k = 0;
+#pragma unroll 1
+  while (k + 1 < t.n && g >= t.first[k + 1]) ++k;
+  const HaloDesc d = t.d[k];
+  size_t r = g - t.first[k];          // half-record index inside activation k
+  const int half = (int)(r & 1); r >>= 1;
+  const size_t per_plane = (size_t)d.Wp * (d.Hp - d.H) + (size_t)d.H * (d.Wp - d.W);
+  const int cb = (int)(r / per_plane);
+  size_t h = r - (size_t)cb * per_plane;
+  int row, col;
+  const size_t full_rows = (size_t)d.Wp * (d.Hp - d.H);   // row 0 and rows H + 1 .. Hp - 1, whole
+  if (h < full_rows) {
+    const int ri = (int)(h / d.Wp);
+    col = (int)(h - (size_t)ri * d.Wp);
+    row = ri == 0 ? 0 : d.H + ri;
+  } else {
+    h -= full_rows;
+    const int wd = d.Wp - d.W;                           // column 0 and columns W + 1 .. Wp - 1 of rows 1 .. H
+    const int ri = (int)(h / wd), ci = (int)(h - (size_t)ri * wd);
+    row = 1 + ri;
+    col = ci == 0 ? 0 : d.W + ci;
+  }
+  *reinterpret_cast<f32x4 *>(d.p + (((size_t)cb * d.Hp + row) * d.Wp + col) * 8 + half * 4) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+}
+
+int c8p_zero_halos(const Act *acts, int n, hipStream_t s) {
+  MPN_CHECK_ARG(acts && n >= 0);
+  for (int i0 = 0; i0 < n; i0 += kHaloMax) {
+    HaloTable t{};
+    t.n = n - i0 < kHaloMax ? n - i0 : kHaloMax;
+    size_t tot = 0;
+    for (int k = 0; k < t.n; ++k) {
+      const Act &a = acts[i0 + k];
+      MPN_CHECK_ARG(a.p && a.H > 0 && a.W > 0 && a.Hp > a.H && a.Wp > a.W);
+      t.d[k] = HaloDesc{a.p, a.H, a.W, a.Hp, a.Wp};
+      t.first[k] = tot;
+      tot += ((size_t)a.Wp * (a.Hp - a.H) + (size_t)a.H * (a.Wp - a.W)) * a.Cb() * 2;
+    }
+    t.total = tot;
+    if (!tot) continue;
+    hipLaunchKernelGGL(c8p_zero_halos_kernel, dim3((unsigned)cdiv_sz(tot, 256)), dim3(256), 0, s, t);
+    MPN_CHECK_LAUNCH();
+  }
+  return MPN_OK;
+}
+
 __global__ void maxpool2x2_c8p_kernel(const float *__restrict__ in, int H, int W, int Hp, int Wp, int Cb, float *__restrict__ out,
                                       int Ho, int Wo, int Hpo, int Wpo) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

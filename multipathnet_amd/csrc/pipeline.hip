@@ -346,12 +346,14 @@ MPN_KNOB(int, g_first_k36, 1);  // 0: the first layer on the generic direct kern
 MPN_KNOB(int, g_roi_pool_pm, 1);  // 0: ROI pooling straight from the C8P map (roi_pool_c8_kernel)
 MPN_KNOB(int, g_mix_fold, 1);     // 0: MultiPathNet's nn.Normalize scales applied in place (l2norm_apply) instead of inside the mix GEMM
 MPN_KNOB(int, g_pool_overlap, 1); // 0: MultiPathNet's skip pooling on the launch stream instead of its own stream under the previous tower's GEMMs
+MPN_KNOB(int, g_halo_memset, 0);  // 1: a size change clears every activation buffer whole (rounds 1-4) instead of re-laying the halos only
 #ifdef MPN_DEBUG_HOOKS
 extern "C" void mpn_debug_set_fuse_pool(int v) { g_fuse_pool = v; }
 extern "C" void mpn_debug_set_first_k36(int v) { g_first_k36 = v; }
 extern "C" void mpn_debug_set_roi_pool_pm(int v) { g_roi_pool_pm = v; }
 extern "C" void mpn_debug_set_mix_fold(int v) { g_mix_fold = v; }
 extern "C" void mpn_debug_set_pool_overlap(int v) { g_pool_overlap = v; }
+extern "C" void mpn_debug_set_halo_memset(int v) { g_halo_memset = v; }
 #endif
 
 template <typename T>
@@ -622,8 +624,20 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
 
 static int run_trunk(mpn_frcnn *p, const float *d_image, int H, int W, hipStream_t s, Act *feat_out) {
   const mpn_frcnn_config &c = p->cfg;
-  if (H != p->last_h || W != p->last_w) {  // halo positions move with the image size: re-zero once
-    for (auto &b : p->act_bufs) MPN_CHECK_HIP(hipMemsetAsync(b.first, 0, b.second, s));
+  if (H != p->last_h || W != p->last_w) {  // halo positions move with the image size: re-lay the zero halo of every activation, once
+    if (g_halo_memset) {
+      for (auto &b : p->act_bufs) MPN_CHECK_HIP(hipMemsetAsync(b.first, 0, b.second, s));
+    } else {
+      std::vector<Act> acts;
+      acts.push_back(make_act(p->img_c8p, 3, H, W));
+      int hh = H, ww = W;
+      for (auto &L : p->conv) {
+        if (L.out) acts.push_back(make_act(L.out, L.Cout, hh, ww));
+        if (L.pool) { hh = (hh + 1) / 2; ww = (ww + 1) / 2; if (L.pooled) acts.push_back(make_act(L.pooled, L.Cout, hh, ww)); }
+      }
+      int rc_h = c8p_zero_halos(acts.data(), (int)acts.size(), s);
+      if (rc_h) return rc_h;
+    }
     p->last_h = H; p->last_w = W;
   }
   Act cur = make_act(p->img_c8p, 3, H, W);

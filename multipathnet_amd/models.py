@@ -646,11 +646,16 @@ class FastRCNN(object):
         self._n_dets2 = [torch.zeros_like(self._n_dets) for _ in range(2)]
         self._pipe_seq = 0
 
+    def close(self):
+        """mpn_frcnn_destroy now (streams, events, buffers) instead of at garbage collection: a process holds a few HIP hardware queues, and
+        the copy / side streams of an idle handle still occupy them"""
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.mpn_frcnn_destroy(self._h)
+            self._h = C.c_void_p()
+
     def __del__(self):
         try:
-            if getattr(self, "_h", None) and self._h.value:
-                self._lib.mpn_frcnn_destroy(self._h)
-                self._h = C.c_void_p()
+            self.close()
         except Exception:
             pass
 

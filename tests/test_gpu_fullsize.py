@@ -431,6 +431,25 @@ def test_fullsize_mixed_size_stream(O, dev, full):
         assert torch.equal(d[: int(n.item())], ref[order[t]]), (t, order[t])
     del net
     torch.cuda.empty_cache()
+    # a size change re-lays only the HALOS of the activations (c8p_zero_halos_kernel, round 5); clearing every buffer whole, as rounds 1-4
+    # did (debug hook), must give the same records — in an order in which every size follows a LARGER and a smaller one
+    from conftest import hooks
+    with hooks(halo_memset=1):
+        net2 = models.FastRCNN(P, max_h=1000, max_w=1000, max_rois=bench.N_ROIS, scale=600, max_size=1000)
+        for i in (5, 0, 4, 3, 2, 1, 0, 5, 3):
+            im, bx = stream[i]
+            d, n = net2.test_one_async(torch.from_numpy(im).to(dev), torch.from_numpy(bx).to(dev))
+            torch.cuda.synchronize()
+            assert torch.equal(d[: int(n.item())], ref[i]), i
+        del net2
+    net3 = models.FastRCNN(P, max_h=1000, max_w=1000, max_rois=bench.N_ROIS, scale=600, max_size=1000)
+    for i in (5, 0, 4, 3, 2, 1, 0, 5, 3):
+        im, bx = stream[i]
+        d, n = net3.test_one_async(torch.from_numpy(im).to(dev), torch.from_numpy(bx).to(dev))
+        torch.cuda.synchronize()
+        assert torch.equal(d[: int(n.item())], ref[i]), i
+    del net3
+    torch.cuda.empty_cache()
 
 
 def test_fullsize_pipelined_host_record_equals_serial(dev, full):
