@@ -608,7 +608,13 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
   {
     int lo = 0, hi = 0;
     hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, hi);
+    // The side stream (NMS / top-k tail under the next image's trunk) has the DEFAULT priority since round 5.  Rounds 1-4 created it with
+    // the highest one; what that bought the headline is nothing measurable (3.457-3.476 ms either way, six alternating runs), and what it can
+    // cost is large: a priority stream lands in a different hardware-queue class, and depending on which queue HIP's round-robin hands it,
+    // EVERY dispatch of the launch queue took 30-50 us longer while the two queues were both active — a mixed-size stream inside bench.py ran
+    // at 4.59 ms per image with the highest priority, 4.05 with the lowest, 3.12 with the default (profiles/r05_mixed_sizes_timeline.txt).
+    (void)lo; (void)hi;
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
       e = hipEventCreateWithFlags(&p->ev_head[i], hipEventDisableTiming);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_tail[i], hipEventDisableTiming);
@@ -1338,9 +1344,22 @@ extern "C" int mpn_frcnn_test_one_pipelined_host(mpn_frcnn *p, const float *h_im
   // three images, as a queue should.
   if (p->used_pending[b]) { MPN_CHECK_HIP(hipEventSynchronize(p->ev_consumed[b])); p->used_pending[b] = false; }
   MPN_CHECK_HIP(hipMemcpyAsync(p->stage_img[b], h_image, img_n * sizeof(float), hipMemcpyHostToDevice, p->copy));
-  MPN_CHECK_HIP(hipMemcpyAsync(p->stage_boxes[b], h_boxes, (size_t)N * 4 * sizeof(float), hipMemcpyHostToDevice, p->copy));
+  // The proposal table is 16 KB: the runtime copies anything that small with a shader blit (__amd_rocclr_copyBuffer), i.e. a KERNEL on the
+  // copy stream's hardware queue.  A third compute queue active beside the launch stream's and the side stream's cost a mixed-size stream
+  // 30-50 us on EVERY dispatch of the launch queue (profiles/r05_mixed_sizes_timeline.txt: 4.56 vs 3.10 ms per image, depending only on
+  // which hardware queues HIP's round-robin handed the three streams).  From PINNED host memory the table is therefore copied on the
+  // launch stream itself (in order in front of this image's head, which is the only reader); the image stays on the copy stream, where the
+  // DMA engine moves it.  Pageable host memory keeps the copy stream (an async copy from it may block the host on the stream it is issued to).
+  bool boxes_pinned = false;
+  {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, h_boxes) == hipSuccess) boxes_pinned = at.type == hipMemoryTypeHost;
+    else (void)hipGetLastError();
+  }
+  if (!boxes_pinned) MPN_CHECK_HIP(hipMemcpyAsync(p->stage_boxes[b], h_boxes, (size_t)N * 4 * sizeof(float), hipMemcpyHostToDevice, p->copy));
   MPN_CHECK_HIP(hipEventRecord(p->ev_up[b], p->copy));
   MPN_CHECK_HIP(hipStreamWaitEvent(s, p->ev_up[b], 0));
+  if (boxes_pinned) MPN_CHECK_HIP(hipMemcpyAsync(p->stage_boxes[b], h_boxes, (size_t)N * 4 * sizeof(float), hipMemcpyHostToDevice, s));
   int rc = pipelined_impl(p, p->stage_img[b], H, W, p->stage_boxes[b], N, d_dets, top_cap, d_n_dets, stream, true);  // staging sets: stable pointers
   if (rc) return rc;
   // the image is consumed by the trunk's first kernel and the boxes by the decode kernel: both are behind this point of `stream`
