@@ -1344,22 +1344,11 @@ extern "C" int mpn_frcnn_test_one_pipelined_host(mpn_frcnn *p, const float *h_im
   // three images, as a queue should.
   if (p->used_pending[b]) { MPN_CHECK_HIP(hipEventSynchronize(p->ev_consumed[b])); p->used_pending[b] = false; }
   MPN_CHECK_HIP(hipMemcpyAsync(p->stage_img[b], h_image, img_n * sizeof(float), hipMemcpyHostToDevice, p->copy));
-  // The proposal table is 16 KB: the runtime copies anything that small with a shader blit (__amd_rocclr_copyBuffer), i.e. a KERNEL on the
-  // copy stream's hardware queue.  A third compute queue active beside the launch stream's and the side stream's cost a mixed-size stream
-  // 30-50 us on EVERY dispatch of the launch queue (profiles/r05_mixed_sizes_timeline.txt: 4.56 vs 3.10 ms per image, depending only on
-  // which hardware queues HIP's round-robin handed the three streams).  From PINNED host memory the table is therefore copied on the
-  // launch stream itself (in order in front of this image's head, which is the only reader); the image stays on the copy stream, where the
-  // DMA engine moves it.  Pageable host memory keeps the copy stream (an async copy from it may block the host on the stream it is issued to).
-  bool boxes_pinned = false;
-  {
-    hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, h_boxes) == hipSuccess) boxes_pinned = at.type == hipMemoryTypeHost;
-    else (void)hipGetLastError();
-  }
-  if (!boxes_pinned) MPN_CHECK_HIP(hipMemcpyAsync(p->stage_boxes[b], h_boxes, (size_t)N * 4 * sizeof(float), hipMemcpyHostToDevice, p->copy));
+  // (Round 5 tried the proposal table's copy on the launch stream instead — small copies are shader blits, i.e. a kernel on the copy stream's
+  // hardware queue — and took it back: a 32-KB table there stalls the launch stream for 0.25 ms per image, 5.40 -> 5.65 ms at 2000 proposals.)
+  MPN_CHECK_HIP(hipMemcpyAsync(p->stage_boxes[b], h_boxes, (size_t)N * 4 * sizeof(float), hipMemcpyHostToDevice, p->copy));
   MPN_CHECK_HIP(hipEventRecord(p->ev_up[b], p->copy));
   MPN_CHECK_HIP(hipStreamWaitEvent(s, p->ev_up[b], 0));
-  if (boxes_pinned) MPN_CHECK_HIP(hipMemcpyAsync(p->stage_boxes[b], h_boxes, (size_t)N * 4 * sizeof(float), hipMemcpyHostToDevice, s));
   int rc = pipelined_impl(p, p->stage_img[b], H, W, p->stage_boxes[b], N, d_dets, top_cap, d_n_dets, stream, true);  // staging sets: stable pointers
   if (rc) return rc;
   // the image is consumed by the trunk's first kernel and the boxes by the decode kernel: both are behind this point of `stream`

@@ -113,3 +113,28 @@ def test_nms_dense_agrees_with_nms_c_on_distinct_scores(O, n):
     picks = O.nms_dense(sb, 0.3)
     ref, ridx = O.nms(sb, 0.3, return_index=True)
     assert np.array_equal(picks - 1, ridx) and np.array_equal(sb[picks - 1], ref)
+
+
+def test_fused_kernel_model_matches_the_compiled_reference(O):
+    """tools/models/nms_fused_model.py is the algorithm csrc/nms.hip's nms_fused_kernel runs for classes with bit-equal scores (alive-by-rank
+    and occupied-by-slot bitsets, pos / owner, lazily dropped dead slots, the run's cached slots): both of its forms must reproduce the
+    reference's compiled nms.c pick for pick (nms.c:74-98) — on CPU, so that the rule the kernel implements stays pinned without a GPU."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("nms_fused_model", os.path.join(root, "tools", "models", "nms_fused_model.py"))
+    mdl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mdl)
+    from conftest import random_scored_boxes
+    n = 0
+    for regime in ("distinct", "ties", "saturated", "allequal"):
+        for m in (1, 2, 17, 65, 90):
+            rng = np.random.default_rng(m * 31 + len(regime))
+            sb = random_scored_boxes(rng, m, regime, span=200.0, lo=16.0, hi=150.0)
+            ref = O.ref_nms(sb, 0.3) if O.have_ref() else O.nms(sb, 0.3)
+            for fn in (mdl.fused, mdl.fused_v2):
+                got, idx = fn(sb, 0.3)
+                assert np.array_equal(got, ref), (fn.__name__, regime, m)
+                assert np.array_equal(sb[idx], ref)
+            n += 1
+    assert n == 20
