@@ -66,6 +66,10 @@ unsigned long long alloc_generation();
 void bump_alloc_generation();
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): function attributes are per device.
 int set_max_dyn_lds(const void *fn, int bytes);
+// mpn_nms_batched for a call that runs on a side stream UNDER other work (the pipelined forms' tail under the next image's trunk): keeps the
+// launch chain for tables whose fused-kernel blocks (150 KB of LDS each) would displace that work (nms.hip: nms_batched_core)
+int nms_batched_under_trunk(const float *d_scored, const int *d_counts, int n_cls, int m_stride, float thr, float *d_keep, int *d_keep_idx,
+                            int *d_n_keep, hipStream_t stream);
 
 // ---- tuning knobs ---------------------------------------------------------------------------------------------
 // Test / timing hooks (forced kernel variants, split factors, ablations, traces) exist only in the DEBUG flavour of

@@ -904,11 +904,14 @@ using namespace mpn;
 //   4. the whole block writes the kept rows / source indices in pick order.
 // A NaN score is never picked by nms.c:77's '>' : such rows sort with the unpickable ones (scores <= -1e7, nms.c:75).
 constexpr int kFusedMax = 1024;         // what the kernel can take (its mask must fit one CU's LDS)
-constexpr int kFusedDispatchMax = 384;  // what mpn_nms_batched sends to it (see there)
+constexpr int kFusedDispatchMax = 384;  // ... and what it is sent when the call runs UNDER other work (nms_batched_core)
 #ifdef MPN_DEBUG_HOOKS
 __device__ unsigned long long g_fused_trace[16];  // s_memtime stamps of class 0's LAST block at the phase boundaries (tools/nms_fused_trace.py)
 #define FUSED_STAMP(i) do { if (cls == 0 && tid == 0) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long g_fused_wall[4096 * 2];  // wall_clock64 (100 MHz, one counter for the whole GPU) at every block's entry and exit
+#define FUSED_WALL(k) do { if (tid == 0 && blockIdx.y * gridDim.x + blockIdx.x < 4096) g_fused_wall[(blockIdx.y * gridDim.x + blockIdx.x) * 2 + (k)] = wall_clock64(); } while (0)
 #else
+#define FUSED_WALL(k) do { } while (0)
 #define FUSED_STAMP(i) do { } while (0)
 #endif
 
@@ -918,20 +921,229 @@ __device__ __forceinline__ int wave_min_i32(int v) {
   return v;
 }
 
+// The chunked scan with the LAZY position replay (nms_scan_kernel's flag-3 algorithm, see the comment above it) on the fused kernel's
+// LDS-resident mask: one wavefront of the class's last block, the mask rows of ALL boxes full and symmetric (fw = 0), every row read an LDS
+// read.  Returns the number of picks (their ranks in klist[0 ..), or -1 if a progress bound was hit (the caller then runs the pick-by-pick
+// path, which needs no bound).  n = pickable ranks, m = rows; tiew[w] bit r: ranks r and r + 1 are pickable and carry the same score.
+#define FUSED_WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")  /* one wavefront: LDS is in order, this pins the compiler */
+__device__ __forceinline__ int fused_replay_select(const unsigned long long *LM, const int lw, const int W, const int m, const int n,
+                                                   const unsigned long long *tiew, short *lds16, const int m_cap, const unsigned short *sid,
+                                                   const int lane) {
+  typedef unsigned long long u64;
+  bool failed = false;
+  short *pos = lds16, *occ = lds16 + m_cap, *rnd = lds16 + 2 * m_cap, *klist = lds16 + 3 * m_cap, *mv = lds16 + 4 * m_cap;
+  u64 removed = 0ull, keptw = 0ull;  // lane l: ranks 64 l .. 64 l + 63 (m <= 1024: one word per lane)
+  for (int r = lane; r < m; r += kWave) {
+    const int x = sid[r];
+    pos[r] = (short)x; occ[x] = (short)r; rnd[r] = 0; mv[r] = 0;
+  }
+  FUSED_WAVE_SYNC();
+  auto word_of = [&](int w) -> u64 { return readlane64(removed, w & 63); };
+  auto kept_word = [&](int w) -> u64 { return readlane64(keptw, w & 63); };
+  auto removed_bit = [&](int r) -> bool {  // per-lane rank; every lane of the wave must call it
+    const u64 rw = shfl64(removed, (r >> 6) & 63);
+    return (rw >> (r & 63)) & 1ull;
+  };
+  int sim_done = 0, hp = 0, bid = 0;
+  int wf = -1, wd = -1;
+  const int nw_kept = (n + 63) >> 6;
+  auto death_of = [&](int f) -> int {
+    const int fs = f < 0 ? 0 : f;
+    const int rk = (int)rnd[fs];
+    const bool rem = removed_bit(fs);
+    int d = f < 0 ? -1 : (rk > 0 ? rk : (rem ? 0 : kForever));
+    bool need = d == 0;
+    if (__ballot(need)) {
+      u64 x[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) x[q] = (need && q < nw_kept) ? LM[(fs << lw) + q] : 0ull;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        if (q < nw_kept) {  // wave-uniform
+          const u64 hit = x[q] & kept_word(q);
+          if (need && hit) {
+            int bb = q * 64 + __builtin_ctzll(hit);
+            int best = (int)rnd[bb];
+            while ((tiew[bb >> 6] >> (bb & 63)) & 1ull) {  // the rest of that rank's equal-score run (its picks may be out of rank order)
+              ++bb;
+              const u64 rwd = (bb >> 6) == q ? x[q] : LM[(fs << lw) + (bb >> 6)];
+              const int rb = (int)rnd[bb];
+              if (((rwd >> (bb & 63)) & 1ull) && rb > 0 && rb < best) best = rb;
+            }
+            d = best;
+            need = false;
+          }
+        }
+      }
+    }
+    return d;
+  };
+  auto simulate = [&](int t1) {  // replay rounds sim_done + 1 .. t1 (all picked: klist / rnd hold them)
+    int loaded = -64;
+    const int glim = 2 * m_cap + 1024;
+    for (int guard = 0; sim_done < t1; ++guard) {
+      if (guard >= glim) { failed = true; break; }
+      FUSED_WAVE_SYNC();
+      const int W0 = hp & ~63, p = hp - W0;
+      if (W0 != loaded) { const int sl = W0 + lane; wf = sl < m ? (int)occ[sl] : -1; wd = death_of(wf); loaded = W0; }
+      const int t0 = sim_done + 1;
+      const u64 below = (1ull << lane) - 1ull;
+      const bool cand = lane >= p && wf >= 0;
+      u64 taken = 0ull;
+      for (int it = 0; it < 66; ++it) {
+        const int rd = t0 + __popcll(taken & below);
+        const u64 nt = __ballot(cand && wd >= rd && rd <= t1);
+        if (nt == taken) break;
+        taken = nt;
+      }
+      if (!taken) { hp = W0 + 64; if (hp >= m) break; continue; }
+      const bool mine = (taken >> lane) & 1ull;
+      const int t = t0 + __popcll(taken & below);
+      const int pick = mine ? (int)klist[t - 1] : 0;
+      const bool move = mine && wf != pick;
+      const int sb = mine ? (int)pos[pick] : 0;
+      ++bid;
+      if (move) mv[wf] = (short)bid;
+      FUSED_WAVE_SYNC();
+      const bool h1 = mine && mv[pick] == (short)bid;
+      const u64 h1m = __ballot(h1), h2m = __ballot(move && sb < W0 + 64);
+      int cut = 64;
+      if (h1m) cut = __builtin_ctzll(h1m);
+      if (h2m) { const int c2 = __builtin_ctzll(h2m) + 1; if (c2 < cut) cut = c2; }
+      u64 cm = cut >= 64 ? taken : (taken & ((1ull << cut) - 1ull));
+      if (!cm) cm = taken & (~taken + 1ull);
+      if (((cm >> lane) & 1ull) && move) { occ[sb] = (short)wf; pos[wf] = (short)sb; }
+      if (h2m & cm) {
+        const int lc = __builtin_ctzll(h2m & cm);
+        const int f2 = __builtin_amdgcn_readlane(wf, lc), d2 = __builtin_amdgcn_readlane(wd, lc), s2 = __builtin_amdgcn_readlane(sb, lc);
+        if (lane == s2 - W0) { wf = f2; wd = d2; }
+      }
+      sim_done += __popcll(cm);
+      hp = W0 + (64 - __builtin_clzll(cm));
+    }
+    FUSED_WAVE_SYNC();
+  };
+  int kept = 0;
+  const int nchunks = (n + 63) >> 6;
+  for (int c = 0; c < nchunks; ++c) {
+    if (failed) break;
+    const int base = c << 6;
+    const u64 diag = (base + lane < n) ? LM[((base + lane) << lw) + c] : 0ull;
+    const int nv = min(64, n - base);
+    const u64 valid = nv == 64 ? ~0ull : ((1ull << nv) - 1ull);
+    const int plim = 2 * m_cap + 130;
+    for (int pass = 0;; ++pass) {
+      if (pass >= plim || failed) { failed = true; break; }
+      const u64 rem_c = word_of(c);
+      const u64 alive_all = ~rem_c & valid;
+      if (!alive_all) break;
+      const u64 tcw = tiew[c];
+      const u64 tiesel = alive_all & tcw;
+      const int first = __builtin_ctzll(alive_all);
+      if (tiesel && __builtin_ctzll(tiesel) == first) {
+        // ---- one pick by the exact rule: among the alive members of r0's equal-score run, the one sitting first in the array
+        const int r0 = base + first;
+        int e = r0;
+        for (;;) {
+          const u64 ones = tiew[e >> 6] >> (e & 63);
+          const int span = 64 - (e & 63);
+          const int cnt = (~ones) ? __builtin_ctzll(~ones) : 64;
+          if (cnt < span) { e += cnt; break; }
+          e += span;
+          if (e >= n) { e = n - 1; break; }
+        }
+        int n_alive = 0, low = 0x7fffffff;
+        for (int rr = r0; rr <= e; rr += kWave) {
+          const int r = rr + lane;
+          const bool in = r <= e;
+          const bool ok = !removed_bit(in ? r : r0) && in;
+          n_alive += __popcll(__ballot(ok));
+          if (ok && r < low) low = r;
+        }
+        low = wave_min_i32(low);
+        int pick = __builtin_amdgcn_readfirstlane(low);
+        if (n_alive >= 2) {  // only now do positions matter: bring the slot model up to date, then take the smallest slot
+          simulate(kept);
+          int bp = 0x7fffffff, br = -1;
+          for (int rr = r0; rr <= e; rr += kWave) {
+            const int r = rr + lane;
+            const bool in = r <= e;
+            const bool ok = !removed_bit(in ? r : r0) && in;
+            const int pp = ok ? (int)pos[r] : 0x7fffffff;
+            if (pp < bp) { bp = pp; br = r; }
+          }
+#pragma unroll
+          for (int off = 32; off >= 1; off >>= 1) {
+            const int op = __shfl_xor(bp, off), orr = __shfl_xor(br, off);
+            if (op < bp) { bp = op; br = orr; }
+          }
+          pick = __builtin_amdgcn_readfirstlane(br);
+        }
+        if (lane == 0) { klist[kept] = (short)pick; rnd[pick] = (short)(kept + 1); }
+        if (lane < W) {
+          removed |= LM[(pick << lw) + lane];
+          if (lane == (pick >> 6)) { removed |= 1ull << (pick & 63); keptw |= 1ull << (pick & 63); }
+        }
+        ++kept;
+        FUSED_WAVE_SYNC();
+        continue;
+      }
+      // ---- tie-free rule for the alive ranks below `limit`
+      const int limit = tiesel ? __builtin_ctzll(tiesel) : 64;
+      const u64 lim_mask = limit == 64 ? ~0ull : ((1ull << limit) - 1ull);
+      u64 keptmask, diag_acc;
+      {
+        const u64 alive0 = alive_all & lim_mask;
+        const u64 lower = diag & ((1ull << lane) - 1ull);
+        const bool alive_l = (alive0 >> lane) & 1ull;
+        keptmask = alive0;
+        for (int it = 0; it < 66; ++it) {
+          const u64 kn = __ballot(alive_l && !(lower & keptmask));
+          if (kn == keptmask) break;
+          keptmask = kn;
+        }
+        diag_acc = __ballot((diag & keptmask) != 0ull);  // every rank of the chunk overlapped by a kept one
+      }
+      if ((keptmask >> lane) & 1ull) {
+        const int o = kept + __popcll(keptmask & ((1ull << lane) - 1ull));
+        klist[o] = (short)(base + lane); rnd[base + lane] = (short)(o + 1);
+      }
+      if (lane > c && lane < W) {  // fold the kept rows into `removed`: four independent ds_reads in flight per trip
+        u64 acc = 0ull, k = keptmask;
+        const u64 *col = LM + (base << lw) + lane;
+        while (k) {
+          const int j0 = __builtin_ctzll(k); k &= k - 1ull;
+          const int j1 = k ? __builtin_ctzll(k) : j0; k &= k - 1ull;
+          const int j2 = k ? __builtin_ctzll(k) : j0; k &= k - 1ull;
+          const int j3 = k ? __builtin_ctzll(k) : j0; k &= k - 1ull;
+          acc |= (col[j0 << lw] | col[j1 << lw]) | (col[j2 << lw] | col[j3 << lw]);
+        }
+        removed |= acc;
+      }
+      if (lane == c) { removed |= (valid & lim_mask) | (diag_acc & valid); keptw |= keptmask; }
+      kept += __popcll(keptmask);
+      FUSED_WAVE_SYNC();
+      if (limit == 64) break;
+    }
+  }
+  return failed ? -1 : kept;
+}
+
 __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict__ scored, const int *__restrict__ counts, int m_stride, float thr,
                                                          float *__restrict__ keep, int *__restrict__ keep_idx, int *__restrict__ n_keep,
-                                                         unsigned long long *gmask, unsigned int *cnt, int lw, int mask_bytes) {
+                                                         unsigned long long *gmask, unsigned int *cnt, int lw, int mask_bytes, int replay_on) {
   // lw = log2 of the mask's row pitch in 64-bit words (a power of two >= ceil(m_stride / 64)), in HBM and in LDS; blockDim.x = the sort
   // width = the power of two >= max(64, m_stride)
   typedef unsigned long long u64;
   extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
-  __shared__ int sh_nsel, sh_ties, sh_last, sh_kept;
+  __shared__ int sh_nsel, sh_last, sh_kept, sh_bad;
   const int cls = blockIdx.y, slice = blockIdx.x, S = gridDim.x, tid = threadIdx.x, nt = blockDim.x;
   const int lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
 #ifdef MPN_DEBUG_HOOKS
   unsigned long long stamp[12] = {};
 #endif
   FUSED_STAMP(0);
+  FUSED_WALL(0);
   int m = counts ? counts[cls] : m_stride;
   if (m > m_stride) m = m_stride;
   if (m <= 0) {
@@ -944,9 +1156,10 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
   unsigned short *sid = reinterpret_cast<unsigned short *>(fused_lds + mask_bytes + (size_t)cap_s * 16);  // source row of rank r
   unsigned short *fw = sid + cap_s;                                          // first mask word of row r that is computed
   u64 *EQ = reinterpret_cast<u64 *>(fw + cap_s);                             // bit r: ranks r and r + 1 carry the same score   [16 words]
+  u64 *TW = EQ + 16;                                                         // the same among PICKABLE ranks only (the replay's tie words) [16 words]
   u64 *keys = LM;
   const float *src = scored + (size_t)cls * m_stride * 5;
-  if (tid == 0) { sh_nsel = 0; sh_ties = 0; sh_kept = 0; }
+  if (tid == 0) { sh_nsel = 0; sh_kept = 0; sh_bad = 0; }
   if (tid < 16) EQ[tid] = 0ull;
   // ---- 1. one key per thread
   u64 key = ~0ull;
@@ -993,18 +1206,28 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
     const u64 be = __ballot(e), bs = __ballot(sel);
     if (lane == 0) {
       EQ[r >> 6] = be;
-      if (be) sh_ties = 1;
       if (bs) atomicAdd(&sh_nsel, __popcll(bs));
     }
   }
   __syncthreads();
-  const bool has_ties = sh_ties != 0;
   const int n_sel = sh_nsel;
+  if (tid < 16) {  // tied pairs among the PICKABLE ranks (unpickable rows are never picked: their ties never matter)
+    const int lim = n_sel - 1 - 64 * tid;  // bits r with r + 1 < n_sel
+    const u64 tw = lim <= 0 ? 0ull : (EQ[tid] & (lim >= 64 ? ~0ull : ((1ull << lim) - 1ull)));
+    TW[tid] = tw;
+    if (tw) atomicAdd(&sh_bad, __popcll(tw));
+  }
+  __syncthreads();
+  // mode 0: no tied pickable pair — picks follow the rank order; mode 3: a few tied pairs — the chunked scan with the lazy position replay
+  // (needs the rows of ALL boxes full and symmetric); mode 1: many — the exact rule pick by pick
+  const int bad = sh_bad;
+  const int mode = bad == 0 ? 0 : (bad <= kFewTies && replay_on ? 3 : 1);
+  const bool has_ties = mode != 0;
   // first mask word a row needs: picks inside an equal-score run may come in any rank order, so a row must cover its run from the
   // run's first rank; a rank outside any run only ever suppresses later ranks
   for (int r = tid; r < m; r += nt) {
-    int rs = r;
-    if (has_ties) {
+    int rs = mode == 3 ? 0 : r;
+    if (mode == 1) {
       while (rs > 0) {
         const int w = (rs - 1) >> 6, b = (rs - 1) & 63;
         const u64 zeros = ~EQ[w] & (b == 63 ? ~0ull : ((1ull << (b + 1)) - 1ull));  // ranks q <= rs - 1 in this word with score[q] != score[q + 1]
@@ -1054,7 +1277,7 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
     sh_last = last;
   }
   __syncthreads();
-  if (!sh_last) return;
+  if (!sh_last) { FUSED_WALL(1); return; }
   FUSED_STAMP(5);
   {
     const u64 *G = gmask + (((size_t)cls * m_stride) << lw);
@@ -1066,11 +1289,26 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
     }
   }
   unsigned short *klist = reinterpret_cast<unsigned short *>(box), *pos = klist + cap_s, *owner = pos + cap_s;
-  if (has_ties)
+  if (mode == 1)
     for (int r = tid; r < m; r += nt) { const int x = sid[r]; pos[r] = (unsigned short)x; owner[x] = (unsigned short)r; }
   __syncthreads();
   FUSED_STAMP(6);
-  if (wave == 0) {
+  const unsigned short *kl = klist;  // the pick list the output phase reads
+  int run_mode = mode;
+  if (wave == 0 && mode == 3) {  // the lazy replay on the LDS mask; its arrays (pos | occ | rnd | klist | mv, cap each) live where the boxes were
+    short *l16 = reinterpret_cast<short *>(box);
+    const int k3 = fused_replay_select(LM, lw, W, m, n_sel, TW, l16, cap, sid, lane);
+    if (k3 >= 0) {
+      if (lane == 0) sh_kept = k3;
+      run_mode = -1;  // done
+    } else {  // (a progress bound was hit: cannot happen in a correct run) — redo the class pick by pick
+      for (int r = lane; r < m; r += kWave) { const int x = sid[r]; pos[r] = (unsigned short)x; owner[x] = (unsigned short)r; }
+      FUSED_WAVE_SYNC();
+      run_mode = 1;
+    }
+  }
+  if (mode == 3) kl = reinterpret_cast<const unsigned short *>(box) + 3 * cap;
+  if (wave == 0 && run_mode >= 0) {
     int kept = 0;
     u64 aw = 0ull;  // lane l: alive ranks 64 l .. 64 l + 63
     {
@@ -1078,7 +1316,7 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
       const int lo = 64 * lane;
       if (lo < lim) aw = lim - lo >= 64 ? ~0ull : ((1ull << (lim - lo)) - 1ull);
     }
-    if (!has_ties) {
+    if (run_mode == 0) {
       for (int c = 0; c < W; ++c) {
         const u64 cur = readlane64(aw, c);
         if (!cur) continue;
@@ -1195,31 +1433,34 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // lane 0's slot update before the next round's reads (LDS is in order per wave)
       }
     }
-    if (lane == 0) sh_kept = kept;
+    if (lane == 0) { sh_kept = kept; if (mode == 3) sh_last = 2; }  // (2: the replay gave up, the picks are in the kernel's own list)
   }
   __syncthreads();
+  if (sh_last == 2) kl = klist;
   FUSED_STAMP(7);
   // ---- 4. kept rows in pick order
   const int K = sh_kept;
   float *kout = keep + (size_t)cls * m_stride * 5;
   for (int t = tid; t < K * 5; t += nt) {
     const int k = t / 5, fcol = t - 5 * k;
-    kout[t] = src[5 * (size_t)sid[klist[k]] + fcol];
+    kout[t] = src[5 * (size_t)sid[kl[k]] + fcol];
   }
   if (keep_idx) {
     int *kidx = keep_idx + (size_t)cls * m_stride;
-    for (int k = tid; k < K; k += nt) kidx[k] = (int)sid[klist[k]];
+    for (int k = tid; k < K; k += nt) kidx[k] = (int)sid[kl[k]];
   }
   if (tid == 0) n_keep[cls] = K;
 #ifdef MPN_DEBUG_HOOKS
   FUSED_STAMP(8);
-  if (cls == 0 && tid == 0) { for (int i = 0; i < 9; ++i) g_fused_trace[i] = stamp[i]; g_fused_trace[9] = (unsigned long long)K; g_fused_trace[10] = (unsigned long long)sh_ties; }
+  FUSED_WALL(1);
+  if (cls == 0 && tid == 0) { for (int i = 0; i < 9; ++i) g_fused_trace[i] = stamp[i]; g_fused_trace[9] = (unsigned long long)K; g_fused_trace[10] = (unsigned long long)sh_bad; }
 #endif
 }
 
 MPN_KNOB(int, g_nms_force_exact, 0);  // test hook: 1 = always the exact IoU-sweep kernel, 2 = always the tie (slot-emulation) kernel, 3 = always the replaying scan
 MPN_KNOB(unsigned long long *, g_nms_trace, nullptr);
 MPN_KNOB(int, g_nms_guard_limit, 0);  // test hook (mpn_debug_set_nms_guard_limit): bound of the replaying scan's progress loops (0 = the real one)
+MPN_KNOB(int, g_nms_fused_replay, 1);  // test hook: 0 = classes with a few tied pairs take the fused kernel's pick-by-pick path instead of the lazy replay
 MPN_KNOB(int, g_nms_fused_slices, 0);  // test / timing hook: mask slices per class of the fused kernel (0 = fill the GPU once)
 MPN_KNOB(int, g_nms_fused, 1);  // test hook (mpn_debug_set_nms_fused): 0 = the launch chain at every size; 2 = the fused kernel for every table of <= kFusedMax rows
 #ifdef MPN_DEBUG_HOOKS
@@ -1228,6 +1469,12 @@ extern "C" void mpn_debug_set_nms_trace(void *p) { g_nms_trace = static_cast<uns
 extern "C" void mpn_debug_set_nms_guard_limit(int v) { g_nms_guard_limit = v; }
 extern "C" void mpn_debug_set_nms_fused(int v) { g_nms_fused = v; }
 extern "C" void mpn_debug_set_nms_fused_slices(int v) { g_nms_fused_slices = v; }
+extern "C" void mpn_debug_set_nms_fused_replay(int v) { g_nms_fused_replay = v; }
+extern "C" int mpn_debug_get_nms_fused_wall(unsigned long long *h_out, int n_blocks) {  // [n_blocks][2]: entry, exit (10 ns ticks)
+  MPN_CHECK_ARG(h_out && n_blocks >= 0 && n_blocks <= 4096);
+  MPN_CHECK_HIP(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_fused_wall), (size_t)n_blocks * 2 * sizeof(unsigned long long)));
+  return MPN_OK;
+}
 extern "C" int mpn_debug_get_nms_fused_trace(unsigned long long *h_out16) {
   MPN_CHECK_ARG(h_out16);
   MPN_CHECK_HIP(hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(g_fused_trace), 16 * sizeof(unsigned long long)));
@@ -1235,8 +1482,22 @@ extern "C" int mpn_debug_get_nms_fused_trace(unsigned long long *h_out16) {
 }
 #endif
 
+static int nms_batched_core(const float *d_scored, const int *d_counts, int n_cls, int m_stride, float thr, float *d_keep, int *d_keep_idx,
+                            int *d_n_keep, void *stream, bool under_other_work);
 extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n_cls, int m_stride, float thr,
                                float *d_keep, int *d_keep_idx, int *d_n_keep, void *stream) {
+  return nms_batched_core(d_scored, d_counts, n_cls, m_stride, thr, d_keep, d_keep_idx, d_n_keep, stream, false);
+}
+namespace mpn {
+// the pipelined forms' tail: NMS on a side stream UNDER the next image's trunk (mpn_internal.h)
+int nms_batched_under_trunk(const float *d_scored, const int *d_counts, int n_cls, int m_stride, float thr, float *d_keep, int *d_keep_idx,
+                            int *d_n_keep, hipStream_t stream) {
+  return nms_batched_core(d_scored, d_counts, n_cls, m_stride, thr, d_keep, d_keep_idx, d_n_keep, stream, true);
+}
+}  // namespace mpn
+
+static int nms_batched_core(const float *d_scored, const int *d_counts, int n_cls, int m_stride, float thr, float *d_keep, int *d_keep_idx,
+                            int *d_n_keep, void *stream, bool under_other_work) {
   MPN_CHECK_ARG(n_cls >= 0 && m_stride >= 0);
   MPN_CHECK_ARG(d_n_keep != nullptr);
   if (n_cls == 0) return MPN_OK;
@@ -1256,13 +1517,15 @@ extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n
     MPN_CHECK_LAUNCH();
     return MPN_OK;
   }
-  // Dispatch (measured, profiles/r05_nms_paths.txt): the fused kernel's greedy phase is ONE wavefront, which issues an instruction every ~4
-  // cycles — 70 cycles per pick on a tie-free class (64-lane fixpoint chunks), 1 700 per pick once the class holds ANY bit-equal pair (the
-  // exact position rule, pick by pick).  Up to kFusedDispatchMax rows that is as fast as or faster than the launch chain in every score
-  // regime (300 rows x 20 classes: 30 vs 60 us tie-free, 199 vs 247 us tied); at 1000 rows a class with a handful of tied pairs — every
-  // class of a real 1000-proposal image — costs 500 us against the chain's lazily-replayed 216, so wider tables keep the chain.
-  // (mpn_debug_set_nms_fused(2) sends every table of <= kFusedMax rows to the fused kernel: tests and timing.)
-  if (m_stride <= (g_nms_fused == 2 ? kFusedMax : kFusedDispatchMax) && g_nms_fused && g_nms_force_exact == 0) {  // one launch: nms_fused_kernel
+  // Dispatch (measured, profiles/r05_nms_paths.txt).  The fused kernel takes every table of <= kFusedMax rows when the call has the GPU to
+  // itself (module-level calls, the un-pipelined test_one, the latency mode, libnms.so): one launch, the mask in LDS, tie-free classes 70
+  // cycles per pick, classes with a few tied pairs the lazy position replay on LDS rows, classes full of ties 1 700 cycles per pick.  Its
+  // blocks hold 150 KB of LDS each, though: UNDER the next image's trunk (the pipelined forms' side stream) 240 of them displace the trunk's
+  // one-block-per-CU launches, where the chain's small kernels slip in beside them — there tables above kFusedDispatchMax rows keep the chain
+  // (the headline's 1000-row tables: 280.8 k proposals/s with the fused kernel under the trunk, 289-291 k with the chain).
+  // (mpn_debug_set_nms_fused: 0 = the chain at every size, 2 = the fused kernel wherever it can run.)
+  const int fused_limit = g_nms_fused == 2 ? kFusedMax : (under_other_work ? kFusedDispatchMax : kFusedMax);
+  if (m_stride <= fused_limit && g_nms_fused && g_nms_force_exact == 0) {  // one launch: nms_fused_kernel
     const int cap_w = (m_stride + 63) / 64;
     int lw = 0;
     while ((1 << lw) < cap_w) ++lw;
@@ -1271,7 +1534,7 @@ extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n
     size_t mask_bytes = ((size_t)m_stride << lw) * 8;            // the mask [m][1 << lw] in LDS ...
     if (mask_bytes < (size_t)nt * 8) mask_bytes = (size_t)nt * 8;  // ... aliasing the sort's exchange buffer
     mask_bytes = (mask_bytes + 15) & ~(size_t)15;
-    const size_t lds = mask_bytes + (size_t)nt * 16 + (size_t)nt * 4 + 128;
+    const size_t lds = mask_bytes + (size_t)nt * 16 + (size_t)nt * 4 + 256;
     int S = g_nms_fused_slices > 0 ? g_nms_fused_slices : 256 / n_cls;  // one block per CU (the mask lives in LDS): at most one wave of blocks over the 256 CUs
     if (S > 16) S = 16;
     if (S > cdiv(m_stride, 32)) S = cdiv(m_stride, 32);
@@ -1283,7 +1546,7 @@ extern "C" int mpn_nms_batched(const float *d_scored, const int *d_counts, int n
     if (rc_ws) return rc_ws;
     { int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(nms_fused_kernel), 160 * 1024 - 64); if (rc_attr) return rc_attr; }
     hipLaunchKernelGGL(nms_fused_kernel, dim3(S, n_cls), dim3(nt), lds, st, d_scored, d_counts, m_stride, thr, d_keep, d_keep_idx, d_n_keep,
-                       static_cast<unsigned long long *>(ws), static_cast<unsigned int *>(wc), lw, (int)mask_bytes);
+                       static_cast<unsigned long long *>(ws), static_cast<unsigned int *>(wc), lw, (int)mask_bytes, (int)g_nms_fused_replay);
     MPN_CHECK_LAUNCH();
     return MPN_OK;
   }
@@ -1528,7 +1791,7 @@ extern "C" int mpn_nms_host(const float *h_scored, int m, float thr, float *h_ke
   *n_keep = 0;
   if (m == 0) return MPN_OK;
   MPN_CHECK_ARG(h_scored != nullptr && h_keep != nullptr);
-  if (m <= (g_nms_fused == 2 ? kFusedMax : kFusedDispatchMax) && g_nms_fused && g_nms_force_exact == 0) return nms_host_small(h_scored, m, thr, h_keep, h_keep_idx, n_keep);
+  if (m <= kFusedMax && g_nms_fused && g_nms_force_exact == 0) return nms_host_small(h_scored, m, thr, h_keep, h_keep_idx, n_keep);
   float *d_in = nullptr, *d_keep = nullptr;
   int *d_idx = nullptr, *d_n = nullptr;
   size_t bytes = sizeof(float) * 5 * (size_t)m;

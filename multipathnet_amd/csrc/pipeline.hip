@@ -1033,7 +1033,8 @@ static int run_tail(mpn_frcnn *p, int N, float *d_dets, int top_cap, int *d_n_de
   return run_segment(p, SEG_TAIL, key, shape, false, t, [&](hipStream_t q) -> int {
     int r;
     { ProfScope ps(p, MPN_PROF_NMS, q);
-      r = mpn_nms_batched(p->scored, p->counts, C - 1, N, c.nms_thresh, p->keep, p->keep_idx, p->n_keep, q); }
+      r = after_select ? nms_batched_under_trunk(p->scored, p->counts, C - 1, N, c.nms_thresh, p->keep, p->keep_idx, p->n_keep, q)
+                       : mpn_nms_batched(p->scored, p->counts, C - 1, N, c.nms_thresh, p->keep, p->keep_idx, p->n_keep, q); }
     if (r) return r;
     const float *final_tables = p->keep;
     if (c.bbox_voting) {  // Tester_FRCNN.lua:118-124

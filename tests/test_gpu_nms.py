@@ -291,10 +291,12 @@ def test_nms_lazy_replay_fuzz_vs_reference(O, dev, seed):
         ref = O.ref_nms(sb, thr) if O.have_ref() else O.nms(sb, thr)
         mine, ridx = O.nms(sb, thr, return_index=True)
         assert np.array_equal(mine, ref)
-        for fused in ((2, 1, 0) if n <= 1024 else (1,)):   # <= 1024 rows: the fused kernel forced (2), the product dispatch (1: fused up to 384 rows), the chain (0)
-            with hooks(nms_fused=fused):
+        # <= 1024 rows: the product dispatch (fused kernel, its lazy replay on the LDS mask for these 1..12 tied pairs), the same kernel with
+        # the replay switched off (its per-round position rule), and the launch chain (its own replaying scan)
+        for fused, replay in (((1, 1), (1, 0), (0, 1)) if n <= 1024 else ((1, 1),)):
+            with hooks(nms_fused=fused, nms_fused_replay=replay):
                 keep, idx = utils.nms_with_index(_t(sb, dev), thr)
-            assert keep.shape[0] == ref.shape[0] and np.array_equal(keep.cpu().numpy(), ref), (seed, n, thr, fused)
+            assert keep.shape[0] == ref.shape[0] and np.array_equal(keep.cpu().numpy(), ref), (seed, n, thr, fused, replay)
             assert np.array_equal(idx.cpu().numpy(), ridx)
 
 

@@ -14,6 +14,7 @@ n_cls, M = 20, int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 only_regimes = sys.argv[2].split(",") if len(sys.argv) > 2 else None   # e.g. fewties
 only_modes = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else None   # e.g. 0,3
 from multipathnet_amd import _lib
+lib.mpn_debug_set_nms_fused_replay(int(os.environ.get("MPN_FUSED_REPLAY", "1")))   # 0: the fused kernel's per-round tie path for every tied class
 for regime in ("distinct", "fewties", "ties", "saturated"):
     if only_regimes and regime not in only_regimes:
         continue
@@ -42,3 +43,4 @@ for regime in ("distinct", "fewties", "ties", "saturated"):
         print("%-9s M=%d %-12s %8.1f us/call (20 classes, %.1f us/class if serial)  kept/class mean %.0f" % (regime, M, name, e0.elapsed_time(e1) / 5 * 1e3, e0.elapsed_time(e1) / 5 * 1e3 / n_cls, nk.float().mean().item()))
 lib.mpn_debug_set_nms_force_exact(0)
 lib.mpn_debug_set_nms_fused(1)
+lib.mpn_debug_set_nms_fused_replay(1)

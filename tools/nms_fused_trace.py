@@ -7,7 +7,7 @@ import multipathnet_amd
 from multipathnet_amd import utils, _lib
 from conftest import random_scored_boxes
 lib = _lib.load("debug")
-lib.mpn_debug_set_nms_fused(2)   # the fused kernel at every size it can take (the product dispatch stops at 384 rows)
+lib.mpn_debug_set_nms_fused(2)   # the fused kernel at every size it can take
 dev = torch.device("cuda:0")
 Ms = [int(sys.argv[1])] if len(sys.argv) > 1 else [300, 1000]
 n_cls_list = [int(sys.argv[2])] if len(sys.argv) > 2 else [1, 20]
@@ -30,3 +30,17 @@ for M in Ms:
             tot = t[8] - t[0]
             print("M=%d x %d classes, %-9s: kept %d (ties flag %d), %.1f us by events; class 0's last block %d shader cycles:" % (M, n_cls, regime, t[9], t[10], e0.elapsed_time(e1) * 1e3, tot))
             print("   " + "  ".join("%s %d" % (names[i], t[i + 1] - t[i]) for i in range(8)) + ("   | %.0f cycles / pick" % ((t[7] - t[6]) / max(1, t[9]))))
+            S = min(16, max(1, 256 // n_cls), (M + 31) // 32)
+            nb = min(4096, S * n_cls)
+            w = (C.c_ulonglong * (2 * nb))()
+            lib.mpn_debug_get_nms_fused_wall(w, nb)
+            w = np.array(list(w), dtype=np.int64).reshape(nb, 2)
+            t0 = w[:, 0].min()
+            st, en = (w[:, 0] - t0) / 100.0, (w[:, 1] - t0) / 100.0
+            sel = en.reshape(n_cls, -1).max(axis=1)      # the selecting block of each class ends last
+            print("   wall clock (us after the first block's entry), %d blocks: entries min/median/max %.1f/%.1f/%.1f   exits of the non-selecting blocks median %.1f   "
+                  "selecting blocks' exits min/median/max %.1f/%.1f/%.1f" % (nb, st.min(), np.median(st), st.max(), np.median(en), sel.min(), np.median(sel), sel.max()))
+            slow = [c for c in range(n_cls) if sel[c] > 1.3 * np.median(sel)]
+            for c in slow[:6]:
+                sc = np.sort(sb[c, :, 4])
+                print("      class %d: exit %.1f us, kept %d, %d bit-equal adjacent score pairs, selecting slice %d" % (c, sel[c], int(nk[c]), int((sc[1:] == sc[:-1]).sum()), int(en.reshape(n_cls, -1)[c].argmax())))
