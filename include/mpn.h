@@ -70,8 +70,9 @@ int mpn_release_all_scratch(void);
  *   d_n_keep    [n_cls]               number kept
  * Greedy selection, IoU with the +1 convention (nms.c:14-41), suppression when IoU > thr,
  * tie-breaking among bit-equal scores identical to nms.c:74-98 (swap + stable partition history).
- * Tables of up to 384 rows per class take ONE launch (sort, suppression mask sliced over the GPU, greedy selection with the exact position
- * rule in one CU's LDS); tables up to MPN_NMS_MAX_BOXES rows a chain of launches (bitonic sort -> suppression bitmask -> wave scan);
+ * Tables of up to 1024 rows per class take ONE launch (sort, suppression mask sliced over the GPU, greedy selection with the exact position
+ * rule in one CU's LDS); tables up to MPN_NMS_MAX_BOXES rows a chain of launches (bitonic sort -> suppression bitmask -> wave scan; also
+ * what the pipelined mpn_frcnn_* forms run above 384 rows, their NMS sharing the GPU with the next image's trunk);
  * wider tables are accepted too (nms.c has no size limit) and take the exact sweep kernel on HBM-resident arrays. */
 #define MPN_NMS_MAX_BOXES 6144
 int mpn_nms_batched(const float *d_scored, const int *d_counts, int n_cls, int m_stride, float thr, float *d_keep,
@@ -89,7 +90,7 @@ int mpn_nms(const float *d_scored, int m, float thr, float *d_keep, int *d_keep_
  * UNPINNED there; this library sorts ties by ascending index, NaN scores last. */
 int mpn_nms_dense(const float *d_boxes, int m, float overlap, int *d_pick, int *d_n_pick, void *stream);
 
-/* Host-buffer form used by the libnms.so drop-in, synchronous.  h_keep [m,5].  Tables of up to 384 rows are staged in a per-thread pinned,
+/* Host-buffer form used by the libnms.so drop-in, synchronous.  h_keep [m,5].  Tables of up to 1024 rows are staged in a per-thread pinned,
  * device-mapped buffer that the kernel reads and writes directly (no device allocation, no hipMemcpy: one launch + one stream sync);
  * wider ones go H2D -> kernels -> D2H. */
 int mpn_nms_host(const float *h_scored, int m, float thr, float *h_keep, int *h_keep_idx, int *n_keep);

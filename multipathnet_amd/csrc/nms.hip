@@ -910,8 +910,17 @@ __device__ unsigned long long g_fused_trace[16];  // s_memtime stamps of class 0
 #define FUSED_STAMP(i) do { if (cls == 0 && tid == 0) stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
 __device__ unsigned long long g_fused_wall[4096 * 2];  // wall_clock64 (100 MHz, one counter for the whole GPU) at every block's entry and exit
 #define FUSED_WALL(k) do { if (tid == 0 && blockIdx.y * gridDim.x + blockIdx.x < 4096) g_fused_wall[(blockIdx.y * gridDim.x + blockIdx.x) * 2 + (k)] = wall_clock64(); } while (0)
+__device__ unsigned long long g_fused_sim[8];  // class 0: cycles inside the replay's simulate(), calls, batches
+#define FUSED_SIM_T0() const unsigned long long sim_t0 = __builtin_amdgcn_s_memtime(); const int bid0 = bid
+#define FUSED_SIM_T1() do { if (blockIdx.y == 0 && lane == 0) { g_fused_sim[0] += __builtin_amdgcn_s_memtime() - sim_t0; g_fused_sim[1] += 1; g_fused_sim[2] += (unsigned long long)(bid - bid0); } } while (0)
+#define FUSED_SIM_ACC(i, t_from) do { if (blockIdx.y == 0 && lane == 0) g_fused_sim[i] += __builtin_amdgcn_s_memtime() - (t_from); } while (0)
+#define FUSED_SIM_MARK(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
 #else
+#define FUSED_SIM_ACC(i, t_from) do { } while (0)
+#define FUSED_SIM_MARK(v) do { } while (0)
 #define FUSED_WALL(k) do { } while (0)
+#define FUSED_SIM_T0() do { } while (0)
+#define FUSED_SIM_T1() do { } while (0)
 #define FUSED_STAMP(i) do { } while (0)
 #endif
 
@@ -925,6 +934,9 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // LDS-resident mask: one wavefront of the class's last block, the mask rows of ALL boxes full and symmetric (fw = 0), every row read an LDS
 // read.  Returns the number of picks (their ranks in klist[0 ..), or -1 if a progress bound was hit (the caller then runs the pick-by-pick
 // path, which needs no bound).  n = pickable ranks, m = rows; tiew[w] bit r: ranks r and r + 1 are pickable and carry the same score.
+// lds16: pos | occ | rnd | klist | mv (m_cap shorts each), then 384 bytes of round-space scratch (simulate()).
+// Measured (tools/nms_fused_trace.py, 1000 rows, the last two kept boxes tied = 651 rounds to replay): 41 batches, ~120 k cycles, a third
+// of it the 16 death_of() calls (64 lanes read 64 different mask rows: the rows start on the same LDS banks).
 #define FUSED_WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")  /* one wavefront: LDS is in order, this pins the compiler */
 __device__ __forceinline__ int fused_replay_select(const unsigned long long *LM, const int lw, const int W, const int m, const int n,
                                                    const unsigned long long *tiew, short *lds16, const int m_cap, const unsigned short *sid,
@@ -945,81 +957,123 @@ __device__ __forceinline__ int fused_replay_select(const unsigned long long *LM,
     return (rw >> (r & 63)) & 1ull;
   };
   int sim_done = 0, hp = 0, bid = 0;
-  int wf = -1, wd = -1;
   const int nw_kept = (n + 63) >> 6;
   auto death_of = [&](int f) -> int {
     const int fs = f < 0 ? 0 : f;
     const int rk = (int)rnd[fs];
     const bool rem = removed_bit(fs);
     int d = f < 0 ? -1 : (rk > 0 ? rk : (rem ? 0 : kForever));
-    bool need = d == 0;
+    const bool need = d == 0;  // suppressed: by the kept rank picked first among those that overlap it
     if (__ballot(need)) {
       u64 x[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) x[q] = (need && q < nw_kept) ? LM[(fs << lw) + q] : 0ull;
+      int bb = -1;  // the first kept RANK that overlaps fs: branch-free over the words (a divergent body per word cost 4 200 cycles a call)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
+      for (int q = 15; q >= 0; --q) {
         if (q < nw_kept) {  // wave-uniform
           const u64 hit = x[q] & kept_word(q);
-          if (need && hit) {
-            int bb = q * 64 + __builtin_ctzll(hit);
-            int best = (int)rnd[bb];
-            while ((tiew[bb >> 6] >> (bb & 63)) & 1ull) {  // the rest of that rank's equal-score run (its picks may be out of rank order)
-              ++bb;
-              const u64 rwd = (bb >> 6) == q ? x[q] : LM[(fs << lw) + (bb >> 6)];
-              const int rb = (int)rnd[bb];
-              if (((rwd >> (bb & 63)) & 1ull) && rb > 0 && rb < best) best = rb;
-            }
-            d = best;
-            need = false;
+          if (hit) bb = q * 64 + __builtin_ctzll(hit);
+        }
+      }
+      const bool found = need && bb >= 0;
+      const int b0 = found ? bb : 0;
+      int best = (int)rnd[b0];
+      const bool in_run = found && ((tiew[b0 >> 6] >> (b0 & 63)) & 1ull);
+      if (__ballot(in_run)) {  // rare: the rest of that rank's equal-score run (its picks may be out of rank order)
+        if (in_run) {
+          int b = b0;
+          while ((tiew[b >> 6] >> (b & 63)) & 1ull) {
+            ++b;
+            const u64 rwd = LM[(fs << lw) + (b >> 6)];
+            const int rb = (int)rnd[b];
+            if (((rwd >> (b & 63)) & 1ull) && rb > 0 && rb < best) best = rb;
           }
         }
       }
+      if (found) d = best;
     }
     return d;
   };
-  auto simulate = [&](int t1) {  // replay rounds sim_done + 1 .. t1 (all picked: klist / rnd hold them)
-    int loaded = -64;
+  // Replay of rounds sim_done + 1 .. t1 (all picked: klist / rnd hold them), one 64-slot window per batch.  Unlike nms_scan_kernel's
+  // replay, a move that lands INSIDE the window does not end the batch (at 1000 rows that cut a batch every 6.5 rounds: 100 batches of
+  // ~1 750 cycles): the window's rounds are laid out in "round space" first — lane j: the pick of round t0 + j, its slot, and through
+  // inb[] the window lane that slot is, i.e. where round j's head will land — and the 64-lane fixpoint then runs over (taken, occupant,
+  // death) together: the head of round j is the j-th taken lane (Rr[j], written by that lane), lane x's occupant is the head of the round
+  // landing on it if that head sits below x.  Lanes settle from the bottom up.  Only a pick that was itself moved earlier in the batch
+  // (its slot in pos[] is stale) still ends one.  (tools/models/nms_lazy_replay_model.py: simulate_v2, against the compiled nms.c.)
+  int *Rr = reinterpret_cast<int *>(lds16 + 5 * m_cap);  // [64] lane << 22 | rank << 12 | min(death, 4095)
+  short *inb = lds16 + 5 * m_cap + 128;                  // [64]
+  auto simulate = [&](int t1) {
+    int loaded = -64, f0 = -1, d0 = -1;
     const int glim = 2 * m_cap + 1024;
+    const u64 below = (1ull << lane) - 1ull;
     for (int guard = 0; sim_done < t1; ++guard) {
       if (guard >= glim) { failed = true; break; }
       FUSED_WAVE_SYNC();
       const int W0 = hp & ~63, p = hp - W0;
-      if (W0 != loaded) { const int sl = W0 + lane; wf = sl < m ? (int)occ[sl] : -1; wd = death_of(wf); loaded = W0; }
+      if (W0 != loaded) {
+        FUSED_SIM_MARK(td);
+        const int sl = W0 + lane;
+        f0 = sl < m ? (int)occ[sl] : -1;
+        d0 = death_of(f0);
+        if (d0 > 4095) d0 = 4095;  // rounds are <= 1024: "alive at round t" tests keep their answers
+        loaded = W0;
+        FUSED_SIM_ACC(3, td);
+      }
+      FUSED_SIM_MARK(tp);
       const int t0 = sim_done + 1;
-      const u64 below = (1ull << lane) - 1ull;
-      const bool cand = lane >= p && wf >= 0;
+      const int tj = t0 + lane;
+      const int pk = tj <= t1 ? (int)klist[tj - 1] : -1;
+      const int sbj = pk >= 0 ? (int)pos[pk] : -1;
+      inb[lane] = (short)-1;
+      FUSED_WAVE_SYNC();
+      if (sbj >= W0 && sbj < W0 + 64) inb[sbj - W0] = (short)lane;  // distinct boxes sit in distinct slots
+      FUSED_WAVE_SYNC();
+      const int jr = (int)inb[lane];
+      FUSED_SIM_ACC(4, tp);
+      FUSED_SIM_MARK(tf);
       u64 taken = 0ull;
-      for (int it = 0; it < 66; ++it) {
-        const int rd = t0 + __popcll(taken & below);
-        const u64 nt = __ballot(cand && wd >= rd && rd <= t1);
-        if (nt == taken) break;
+      int f = f0, d = d0;
+      bool settled = false;
+      for (int it = 0; it < 70; ++it) {
+        const int k = __popcll(taken & below), cnt = __popcll(taken);
+        if ((taken >> lane) & 1ull) Rr[k] = (lane << 22) | (f << 12) | d;
+        FUSED_WAVE_SYNC();
+        int nf = f0, nd = d0;
+        if (jr >= 0 && jr < cnt) {
+          const int v = Rr[jr];
+          if ((v >> 22) < lane) { nf = (v >> 12) & 1023; nd = v & 4095; }
+        }
+        FUSED_WAVE_SYNC();
+        const int rd = t0 + k;
+        const u64 nt = __ballot(lane >= p && nf >= 0 && nd >= rd && rd <= t1);
+        const u64 chg = __ballot(nf != f || nd != d);
+        f = nf; d = nd;
+        if (nt == taken && !chg) { settled = true; break; }
         taken = nt;
       }
-      if (!taken) { hp = W0 + 64; if (hp >= m) break; continue; }
-      const bool mine = (taken >> lane) & 1ull;
-      const int t = t0 + __popcll(taken & below);
-      const int pick = mine ? (int)klist[t - 1] : 0;
-      const bool move = mine && wf != pick;
-      const int sb = mine ? (int)pos[pick] : 0;
+      if (!settled) { failed = true; break; }
+      FUSED_SIM_ACC(5, tf);
+      FUSED_SIM_MARK(tc);
+      const int cnt = __popcll(taken);
+      if (cnt == 0) { hp = W0 + 64; if (hp >= m) { failed = true; break; } continue; }
+      const bool live = lane < cnt;                       // round space: round t0 + lane was played in this window
+      const int hv = live ? Rr[lane] : 0;
+      const int hl = hv >> 22, hf = (hv >> 12) & 1023;
+      const bool move = live && hf != pk;
       ++bid;
-      if (move) mv[wf] = (short)bid;
+      if (move) mv[hf] = (short)bid;
       FUSED_WAVE_SYNC();
-      const bool h1 = mine && mv[pick] == (short)bid;
-      const u64 h1m = __ballot(h1), h2m = __ballot(move && sb < W0 + 64);
-      int cut = 64;
-      if (h1m) cut = __builtin_ctzll(h1m);
-      if (h2m) { const int c2 = __builtin_ctzll(h2m) + 1; if (c2 < cut) cut = c2; }
-      u64 cm = cut >= 64 ? taken : (taken & ((1ull << cut) - 1ull));
-      if (!cm) cm = taken & (~taken + 1ull);
-      if (((cm >> lane) & 1ull) && move) { occ[sb] = (short)wf; pos[wf] = (short)sb; }
-      if (h2m & cm) {
-        const int lc = __builtin_ctzll(h2m & cm);
-        const int f2 = __builtin_amdgcn_readlane(wf, lc), d2 = __builtin_amdgcn_readlane(wd, lc), s2 = __builtin_amdgcn_readlane(sb, lc);
-        if (lane == s2 - W0) { wf = f2; wd = d2; }
-      }
-      sim_done += __popcll(cm);
-      hp = W0 + (64 - __builtin_clzll(cm));
+      const u64 h1m = __ballot(live && mv[live ? pk : 0] == (short)bid);
+      const int cut = h1m ? __builtin_ctzll(h1m) : cnt;   // >= 1: nothing has been moved before the batch's first round
+      if (cut <= 0) { failed = true; break; }
+      if (lane < cut && move) { occ[sbj] = (short)hf; pos[hf] = (short)sbj; }
+      sim_done += cut;
+      if (jr >= 0 && jr < cut) { f0 = f; d0 = d; }        // the window registers follow the committed landings
+      hp = (cut == cnt && sim_done < t1) ? W0 + 64        // every lane above the last head is dead on arrival
+                                         : W0 + __builtin_amdgcn_readlane(hl, cut - 1) + 1;
+      FUSED_SIM_ACC(6, tc);
     }
     FUSED_WAVE_SYNC();
   };
@@ -1063,7 +1117,9 @@ __device__ __forceinline__ int fused_replay_select(const unsigned long long *LM,
         low = wave_min_i32(low);
         int pick = __builtin_amdgcn_readfirstlane(low);
         if (n_alive >= 2) {  // only now do positions matter: bring the slot model up to date, then take the smallest slot
+          FUSED_SIM_T0();
           simulate(kept);
+          FUSED_SIM_T1();
           int bp = 0x7fffffff, br = -1;
           for (int rr = r0; rr <= e; rr += kWave) {
             const int r = rr + lane;
@@ -1453,7 +1509,12 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
 #ifdef MPN_DEBUG_HOOKS
   FUSED_STAMP(8);
   FUSED_WALL(1);
-  if (cls == 0 && tid == 0) { for (int i = 0; i < 9; ++i) g_fused_trace[i] = stamp[i]; g_fused_trace[9] = (unsigned long long)K; g_fused_trace[10] = (unsigned long long)sh_bad; }
+  if (cls == 0 && tid == 0) {
+    for (int i = 0; i < 9; ++i) g_fused_trace[i] = stamp[i];
+    g_fused_trace[9] = (unsigned long long)K; g_fused_trace[10] = (unsigned long long)sh_bad;
+    for (int i = 0; i < 3; ++i) g_fused_trace[11 + i] = g_fused_sim[i];
+    for (int i = 0; i < 8; ++i) { g_fused_wall[8000 + i] = g_fused_sim[i]; g_fused_sim[i] = 0ull; }
+  }
 #endif
 }
 

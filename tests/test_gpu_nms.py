@@ -23,7 +23,7 @@ def nms_path(request):
     tied pairs —, the slot-emulating tie kernel for classes with many bit-equal scores, the IoU-sweep kernel for NaN / oversize);
     1 = IoU-sweep kernel only; 2 = tie kernel wherever it applies; 3 = the replaying scan for every class, however many ties it has (its
     pick-by-pick rule); 4 = the launch chain's own dispatch at every size (the fused kernel switched off)"""
-    with hooks(nms_force_exact=request.param % 4, nms_fused=0 if request.param == 4 else 1):  # 0 = the product library's own dispatch (fused up to 384 rows)
+    with hooks(nms_force_exact=request.param % 4, nms_fused=0 if request.param == 4 else 1):  # 0 = the product library's own dispatch (fused up to 1024 rows)
         yield request.param
 
 
@@ -312,7 +312,7 @@ def test_nms_fused_kernel_sizes(O, dev, regime, n):
         ref = O.ref_nms(sb, thr) if O.have_ref() else O.nms(sb, thr)
         mine, ridx = O.nms(sb, thr, return_index=True)
         assert np.array_equal(mine, ref)
-        with hooks(nms_fused=2):   # the fused kernel at every size it can take (the product dispatch stops at 384 rows)
+        with hooks(nms_fused=2):   # the fused kernel wherever it can run (what the product dispatch does for a call like this one; 2 = also under the pipelined trunk)
             keep, idx = utils.nms_with_index(_t(sb, dev), thr)
         assert keep.shape[0] == ref.shape[0] and np.array_equal(keep.cpu().numpy(), ref), (regime, n, thr)
         assert np.array_equal(idx.cpu().numpy(), ridx)

@@ -25,7 +25,7 @@ def iou(a, b):
     return np.float32(inter / np.float32(np.float32(aa + ab) - inter))
 
 
-def model_nms(sb, thr, stats=None):
+def model_nms(sb, thr, stats=None, V2=False):
     sb = np.asarray(sb, np.float32)
     m = sb.shape[0]
     order = sorted(range(m), key=lambda i: (-sb[i, 4], i))          # (score desc, index asc) = nms_sort_kernel
@@ -123,6 +123,88 @@ def model_nms(sb, thr, stats=None):
             if last is None:               # first taken lane already hazardous (cannot happen: moved is empty) -> defensive
                 raise AssertionError("empty commit")
 
+    def simulate_v2():
+        """round 5 (nms_fused_kernel's replay): a move that lands INSIDE the window no longer cuts the batch.  The 64 rounds a window can
+        hold are preloaded in 'round space' (lane j: the pick of round t0 + j, its slot, the window lane that slot is — the landing lane of
+        round j's head); the fixpoint then iterates over (taken, occupant, death) together: the head of round j is the j-th taken lane, lane
+        X's occupant is the head of the round landing on it if that head sits below X.  Only a pick that was itself moved earlier in the
+        batch (stale slot) still cuts."""
+        t1 = len(kept)
+        if sim["done"] >= t1:
+            return
+        d = deaths()
+        if stats is not None:
+            stats["sims"] = stats.get("sims", 0) + 1
+        while sim["done"] < t1:
+            W0 = sim["hp"] & ~63
+            p = sim["hp"] - W0
+            f0 = [int(occ[W0 + l]) if W0 + l < m else -1 for l in range(64)]
+            d0 = [int(d[f0[l]]) if f0[l] >= 0 else -1 for l in range(64)]
+            t0 = sim["done"] + 1
+            pk = [kept[t0 + j - 1] if t0 + j <= t1 else -1 for j in range(64)]
+            sbj = [int(pos[pk[j]]) if pk[j] >= 0 else -1 for j in range(64)]
+            jr = [-1] * 64
+            for j in range(64):
+                if pk[j] >= 0 and W0 <= sbj[j] < W0 + 64:
+                    assert jr[sbj[j] - W0] < 0
+                    jr[sbj[j] - W0] = j
+            taken = [False] * 64
+            f, dd = list(f0), list(d0)
+            for it in range(70):
+                k = [sum(1 for q in range(l) if taken[q]) for l in range(64)]
+                cnt = sum(taken)
+                R = [None] * 64
+                for l in range(64):
+                    if taken[l]:
+                        R[k[l]] = (l, f[l], dd[l])
+                nf, nd = list(f0), list(d0)
+                for x in range(64):
+                    j = jr[x]
+                    if j >= 0 and j < cnt and R[j][0] < x:
+                        nf[x], nd[x] = R[j][1], R[j][2]
+                nt = [l >= p and nf[l] >= 0 and nd[l] >= t0 + k[l] and t0 + k[l] <= t1 for l in range(64)]
+                if nt == taken and nf == f and nd == dd:
+                    break
+                taken, f, dd = nt, nf, nd
+            else:
+                raise AssertionError("fixpoint did not settle")
+            if stats is not None:
+                stats["batches"] = stats.get("batches", 0) + 1
+                stats["iters"] = stats.get("iters", 0) + it + 1
+            k = [sum(1 for q in range(l) if taken[q]) for l in range(64)]
+            cnt = sum(taken)
+            if cnt == 0:
+                sim["hp"] = W0 + 64
+                assert sim["hp"] < m + 64, "ran out of slots with rounds pending"
+                continue
+            R = [None] * 64
+            for l in range(64):
+                if taken[l]:
+                    R[k[l]] = (l, f[l], dd[l])
+            moved = set(R[j][1] for j in range(cnt) if R[j][1] != pk[j])
+            cut = cnt
+            for j in range(cnt):
+                if pk[j] in moved:      # stale slot: the pick was a head (and moved) earlier in this batch
+                    cut = j
+                    if stats is not None:
+                        stats["h1"] = stats.get("h1", 0) + 1
+                    break
+            assert cut > 0
+            for j in range(cut):
+                hl, hf, hd = R[j]
+                if hf != pk[j]:
+                    assert sbj[j] > W0 + hl
+                    occ[sbj[j]] = hf
+                    pos[hf] = sbj[j]
+            sim["done"] += cut
+            if cut == cnt and sim["done"] < t1:
+                sim["hp"] = W0 + 64       # every lane above the last head is dead on arrival
+            else:
+                sim["hp"] = W0 + R[cut - 1][0] + 1
+
+    if V2:
+        simulate = simulate_v2
+
     def pick_rank(r, by_rule=False):
         t = len(kept) + 1
         kept.append(r)
@@ -200,8 +282,9 @@ if __name__ == "__main__":
                     if O.have_ref():
                         assert np.array_equal(O.ref_nms(sb, thr), ref)
                     st = {}
-                    k, i = model_nms(sb, thr, st)
-                    assert np.array_equal(k, ref) and np.array_equal(i, ridx), (regime, n, rep, thr)
+                    for v2 in (False, True):
+                        k, i = model_nms(sb, thr, st, V2=v2)
+                        assert np.array_equal(k, ref) and np.array_equal(i, ridx), (regime, n, rep, thr, v2)
                     tot += 1
         print(regime, "ok")
     print("model == nms.c on", tot, "cases")

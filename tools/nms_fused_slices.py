@@ -7,7 +7,7 @@ import multipathnet_amd
 from multipathnet_amd import utils, _lib
 from conftest import random_scored_boxes
 lib = _lib.load("debug")
-lib.mpn_debug_set_nms_fused(2)   # the fused kernel at every size it can take (the product dispatch stops at 384 rows)
+lib.mpn_debug_set_nms_fused(2)   # the fused kernel at every size it can take 
 dev = torch.device("cuda:0")
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 for n_cls in ([int(sys.argv[2])] if len(sys.argv) > 2 else [1, 4, 20, 80]):
