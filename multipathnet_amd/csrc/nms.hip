@@ -940,7 +940,7 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 #define FUSED_WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")  /* one wavefront: LDS is in order, this pins the compiler */
 __device__ __forceinline__ int fused_replay_select(const unsigned long long *LM, const int lw, const int W, const int m, const int n,
                                                    const unsigned long long *tiew, short *lds16, const int m_cap, const unsigned short *sid,
-                                                   const int lane) {
+                                                   const int lane, const bool give_up_midway) {
   typedef unsigned long long u64;
   bool failed = false;
   short *pos = lds16, *occ = lds16 + m_cap, *rnd = lds16 + 2 * m_cap, *klist = lds16 + 3 * m_cap, *mv = lds16 + 4 * m_cap;
@@ -1080,6 +1080,7 @@ __device__ __forceinline__ int fused_replay_select(const unsigned long long *LM,
   int kept = 0;
   const int nchunks = (n + 63) >> 6;
   for (int c = 0; c < nchunks; ++c) {
+    if (give_up_midway && c == (nchunks >> 1)) failed = true;  // test hook (replay_on == 2): the caller's redo from a half-used state
     if (failed) break;
     const int base = c << 6;
     const u64 diag = (base + lane < n) ? LM[((base + lane) << lw) + c] : 0ull;
@@ -1277,7 +1278,11 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
   // mode 0: no tied pickable pair — picks follow the rank order; mode 3: a few tied pairs — the chunked scan with the lazy position replay
   // (needs the rows of ALL boxes full and symmetric); mode 1: many — the exact rule pick by pick
   const int bad = sh_bad;
-  const int mode = bad == 0 ? 0 : (bad <= kFewTies && replay_on ? 3 : 1);
+  // The replay pays per tied pair (one simulate() call of >= 1 batch + a window's death search: ~5 k cycles), the pick-by-pick path per
+  // pick (1 200-2 400 cycles): measured crossover at ~m / 10 pairs (tools/bench_nms.py ties30 / ties100: 1000 rows 207 vs 371 us at 30
+  // pairs, 355 vs 387 at 100; 300 rows 140 vs 144 at 30, 339 vs 165 at 100).
+  const int few = replay_on > 2 ? replay_on : max(kFewTies, m / 12);  // (test / tuning hook: > 2 = the threshold itself)
+  const int mode = bad == 0 ? 0 : (bad <= few && replay_on ? 3 : 1);
   const bool has_ties = mode != 0;
   // first mask word a row needs: picks inside an equal-score run may come in any rank order, so a row must cover its run from the
   // run's first rank; a rank outside any run only ever suppresses later ranks
@@ -1353,7 +1358,7 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
   int run_mode = mode;
   if (wave == 0 && mode == 3) {  // the lazy replay on the LDS mask; its arrays (pos | occ | rnd | klist | mv, cap each) live where the boxes were
     short *l16 = reinterpret_cast<short *>(box);
-    const int k3 = fused_replay_select(LM, lw, W, m, n_sel, TW, l16, cap, sid, lane);
+    const int k3 = fused_replay_select(LM, lw, W, m, n_sel, TW, l16, cap, sid, lane, replay_on == 2);
     if (k3 >= 0) {
       if (lane == 0) sh_kept = k3;
       run_mode = -1;  // done
@@ -1521,7 +1526,7 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
 MPN_KNOB(int, g_nms_force_exact, 0);  // test hook: 1 = always the exact IoU-sweep kernel, 2 = always the tie (slot-emulation) kernel, 3 = always the replaying scan
 MPN_KNOB(unsigned long long *, g_nms_trace, nullptr);
 MPN_KNOB(int, g_nms_guard_limit, 0);  // test hook (mpn_debug_set_nms_guard_limit): bound of the replaying scan's progress loops (0 = the real one)
-MPN_KNOB(int, g_nms_fused_replay, 1);  // test hook: 0 = classes with a few tied pairs take the fused kernel's pick-by-pick path instead of the lazy replay
+MPN_KNOB(int, g_nms_fused_replay, 1);  // test hook: 0 = classes with a few tied pairs take the fused kernel's pick-by-pick path instead of the lazy replay; 2 = the replay gives up half way (its progress bounds cannot be reached otherwise) and the class is redone pick by pick
 MPN_KNOB(int, g_nms_fused_slices, 0);  // test / timing hook: mask slices per class of the fused kernel (0 = fill the GPU once)
 MPN_KNOB(int, g_nms_fused, 1);  // test hook (mpn_debug_set_nms_fused): 0 = the launch chain at every size; 2 = the fused kernel for every table of <= kFusedMax rows
 #ifdef MPN_DEBUG_HOOKS

@@ -236,7 +236,9 @@ def test_nms_dense_bit_exact(O, dev, regime, n):
     assert utils.nms_dense(torch.zeros((0, 5), device=dev), 0.3).numel() == 0
 
 
-@pytest.mark.parametrize("n,pairs,dups", [(300, 1, 1), (1000, 0, 1), (1000, 4, 2), (1000, 30, 0), (2500, 12, 3), (5000, 5, 5), (130, 20, 4)])
+# (the fused kernel replays up to max(12, m / 12) tied pairs: 1000 rows 83, 300 rows 25 — cases on both sides of it)
+@pytest.mark.parametrize("n,pairs,dups", [(300, 1, 1), (1000, 0, 1), (1000, 4, 2), (1000, 30, 0), (2500, 12, 3), (5000, 5, 5), (130, 20, 4),
+                                          (1000, 60, 3), (1000, 81, 2), (1000, 90, 0), (300, 22, 2), (300, 40, 0), (1024, 85, 0)])
 def test_nms_few_ties_and_duplicated_boxes_bit_exact(O, dev, n, pairs, dups, nms_path):
     """The bench image's regime: an otherwise tie-free class with a handful of bit-equal score pairs — some of them DUPLICATED
     proposals (identical box and score, so whichever the reference picks suppresses its twin and only the reported index
@@ -293,7 +295,8 @@ def test_nms_lazy_replay_fuzz_vs_reference(O, dev, seed):
         assert np.array_equal(mine, ref)
         # <= 1024 rows: the product dispatch (fused kernel, its lazy replay on the LDS mask for these 1..12 tied pairs), the same kernel with
         # the replay switched off (its per-round position rule), and the launch chain (its own replaying scan)
-        for fused, replay in (((1, 1), (1, 0), (0, 1)) if n <= 1024 else ((1, 1),)):
+        # ... and with the replay giving up half way (replay 2: the redo from a half-used state that a progress bound would trigger)
+        for fused, replay in (((1, 1), (1, 0), (1, 2), (0, 1)) if n <= 1024 else ((1, 1),)):
             with hooks(nms_fused=fused, nms_fused_replay=replay):
                 keep, idx = utils.nms_with_index(_t(sb, dev), thr)
             assert keep.shape[0] == ref.shape[0] and np.array_equal(keep.cpu().numpy(), ref), (seed, n, thr, fused, replay)

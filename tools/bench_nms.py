@@ -15,10 +15,15 @@ only_regimes = sys.argv[2].split(",") if len(sys.argv) > 2 else None   # e.g. fe
 only_modes = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else None   # e.g. 0,3
 from multipathnet_amd import _lib
 lib.mpn_debug_set_nms_fused_replay(int(os.environ.get("MPN_FUSED_REPLAY", "1")))   # 0: the fused kernel's per-round tie path for every tied class
-for regime in ("distinct", "fewties", "ties", "saturated"):
+for regime in ("distinct", "fewties", "ties30", "ties100", "ties", "saturated"):
     if only_regimes and regime not in only_regimes:
         continue
-    sb = np.stack([random_scored_boxes(rng, M, "distinct" if regime == "fewties" else regime) for _ in range(n_cls)])
+    sb = np.stack([random_scored_boxes(rng, M, "distinct" if regime in ("fewties", "ties30", "ties100") else regime) for _ in range(n_cls)])
+    if regime in ("ties30", "ties100"):  # 30 / 100 bit-equal pairs per class
+        npairs = int(regime[4:])
+        for c in range(n_cls):
+            k = rng.choice(M, 2 * npairs, replace=False)
+            sb[c, k[:npairs], 4] = sb[c, k[npairs:], 4]
     if regime == "fewties":  # what real softmax scores look like: a handful of bit-equal pairs per class
         for c in range(n_cls):
             k = rng.choice(M, 8, replace=False)
