@@ -1077,7 +1077,7 @@ __device__ __forceinline__ int fused_replay_select(const unsigned long long *LM,
     }
     FUSED_WAVE_SYNC();
   };
-  int kept = 0;
+  int kept = 0, sim_run_e = -1;
   const int nchunks = (n + 63) >> 6;
   for (int c = 0; c < nchunks; ++c) {
     if (give_up_midway && c == (nchunks >> 1)) failed = true;  // test hook (replay_on == 2): the caller's redo from a half-used state
@@ -1118,9 +1118,14 @@ __device__ __forceinline__ int fused_replay_select(const unsigned long long *LM,
         low = wave_min_i32(low);
         int pick = __builtin_amdgcn_readfirstlane(low);
         if (n_alive >= 2) {  // only now do positions matter: bring the slot model up to date, then take the smallest slot
-          FUSED_SIM_T0();
-          simulate(kept);
-          FUSED_SIM_T1();
+          // ... once per RUN: while a run is being picked its members' slots cannot change — the head that moves in a round is either a
+          // non-member (a lower score sitting earlier in the array) or the pick itself (nms_lazy_replay_model.py, V2)
+          if (e != sim_run_e) {
+            FUSED_SIM_T0();
+            simulate(kept);
+            FUSED_SIM_T1();
+            sim_run_e = e;
+          }
           int bp = 0x7fffffff, br = -1;
           for (int rr = r0; rr <= e; rr += kWave) {
             const int r = rr + lane;

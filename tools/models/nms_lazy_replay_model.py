@@ -245,8 +245,15 @@ def model_nms(sb, thr, stats=None, V2=False):
                 if limit is None:
                     break
                 continue   # the picks above may have removed members of the run: look again
-            # exact rule for one pick: the alive member of the run sitting first in the array
-            simulate()
+            # exact rule for one pick: the alive member of the run sitting first in the array.  While a run is being picked its members'
+            # slots cannot change — the head that moves in a round is either a non-member (a lower score sitting earlier in the array) or
+            # the pick itself — so the slot model is brought up to date once per RUN (V2), not once per pick.
+            run_id = max(run)
+            while run_id < n - 1 and tie[run_id]:
+                run_id += 1
+            if not (V2 and sim.get("run") == run_id):
+                simulate()
+                sim["run"] = run_id
             best = min(run, key=lambda q: pos[q])
             if stats is not None:
                 stats["exact"] = stats.get("exact", 0) + 1
