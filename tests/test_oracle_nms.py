@@ -138,3 +138,39 @@ def test_fused_kernel_model_matches_the_compiled_reference(O):
                 assert np.array_equal(sb[idx], ref)
             n += 1
     assert n == 20
+
+
+def test_lazy_replay_model_matches_the_compiled_reference(O):
+    """tools/models/nms_lazy_replay_model.py is the chunked scan with the lazy position replay — nms_scan_kernel's form (V2=False: a move
+    landing inside the 64-slot window ends the batch, the slot model is brought up to date before every exact-rule pick) and
+    nms_fused_kernel's (V2=True: round-space batches that resolve such landings inside the fixpoint, once per equal-score RUN).  Both must
+    reproduce the reference's compiled nms.c pick for pick, incl. on tables with long runs (where the once-per-run invariant is exercised)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("nms_lazy_replay_model", os.path.join(root, "tools", "models", "nms_lazy_replay_model.py"))
+    mdl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mdl)
+    from conftest import random_scored_boxes
+    n = 0
+    for seed in range(12):
+        rng = np.random.default_rng(4200 + seed)
+        m = int(rng.choice([5, 64, 65, 97, 130, 200]))
+        sb = random_scored_boxes(rng, m, "distinct", span=float(rng.choice([150.0, 300.0])), lo=16.0, hi=150.0)
+        if seed % 3 == 0:       # a few tied pairs and a duplicated proposal
+            for _ in range(3):
+                a, b = rng.choice(m, 2, replace=False)
+                sb[b, 4] = sb[a, 4]
+            a, b = rng.choice(m, 2, replace=False)
+            sb[b] = sb[a]
+        else:                   # scores on a few levels: runs of many equal scores
+            levels = int(rng.choice([2, 5, 17]))
+            sb[:, 4] = (np.round(sb[:, 4] * levels) / levels).astype(np.float32)
+        ref = O.ref_nms(sb, 0.3) if O.have_ref() else O.nms(sb, 0.3)
+        for v2 in (False, True):
+            st = {}
+            got, idx = mdl.model_nms(sb, 0.3, st, V2=v2)
+            assert np.array_equal(got, ref), (seed, m, v2)
+            assert np.array_equal(sb[idx], ref)
+        n += 1
+    assert n == 12
