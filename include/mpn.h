@@ -396,7 +396,11 @@ int mpn_frcnn_test_one(mpn_frcnn *p, const float *d_image, int H, int W, const f
 /* Throughput form for a loop over images (Tester:test, Tester_FRCNN.lua:150-157): same work, but the
  * latency-bound NMS + top-k tail of image i runs on an internal high-priority stream and overlaps image
  * i+1's trunk.  d_dets / d_n_dets of call i are ordered on `stream` only after call i+1 (on the same
- * handle) or mpn_frcnn_flush(); alternate two output buffers between consecutive calls. */
+ * handle) or mpn_frcnn_flush(); alternate two output buffers between consecutive calls.  For the plain Fast R-CNN head
+ * (one localisation pass) the class / box GEMM, softmax, decode and select of image i run on that internal stream as well
+ * (51 us of kernels that leave most of the GPU idle, now under image i+1's first layers); what they read is kept per
+ * buffer set inside the handle — d_image and d_boxes are consumed on `stream` before the call's work there ends, exactly as
+ * in the un-pipelined form. */
 int mpn_frcnn_test_one_pipelined(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N,
                                  float *d_dets, int top_cap, int *d_n_dets, void *stream);
 int mpn_frcnn_flush(mpn_frcnn *p, void *stream);

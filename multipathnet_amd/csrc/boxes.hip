@@ -24,13 +24,14 @@ __global__ void image_transform_kernel(const float *__restrict__ in, size_t plan
 }
 
 // ImageDetect.lua:66-70
-__global__ void project_rois_kernel(const float *__restrict__ boxes, int n, float s, float *__restrict__ rois) {
+__global__ void project_rois_kernel(const float *__restrict__ boxes, int n, float s, float *__restrict__ rois, float *__restrict__ boxes_copy) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   rois[5 * i] = 1.0f;
 #pragma unroll
   for (int f = 0; f < 4; ++f) {
     float v = boxes[4 * i + f];
+    if (boxes_copy) boxes_copy[4 * i + f] = v;  // the pipelined forms keep the caller's boxes per buffer set (deferred decode)
     v = v + (-1.0f);
     v = v * s;
     v = v + 1.0f;
@@ -697,10 +698,22 @@ extern "C" int mpn_project_im_rois(const float *d_boxes, int n, double scale, fl
   if (n == 0) return MPN_OK;
   MPN_CHECK_ARG(d_boxes && d_rois);
   hipLaunchKernelGGL(project_rois_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), d_boxes, n, (float)scale,
-                     d_rois);
+                     d_rois, static_cast<float *>(nullptr));
   MPN_CHECK_LAUNCH();
   return MPN_OK;
 }
+
+namespace mpn {
+// mpn_project_im_rois + a verbatim copy of the boxes [n,4] (pipeline.hip: the deferred heads decode from it on the side stream)
+int project_im_rois_copy(const float *d_boxes, int n, double scale, float *d_rois, float *d_boxes_copy, hipStream_t s) {
+  MPN_CHECK_ARG(n >= 0 && scale > 0.0);
+  if (n == 0) return MPN_OK;
+  MPN_CHECK_ARG(d_boxes && d_rois && d_boxes_copy);
+  hipLaunchKernelGGL(project_rois_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, d_boxes, n, (float)scale, d_rois, d_boxes_copy);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+}  // namespace mpn
 
 extern "C" int mpn_foveal_forward(const float *d_rois, int N, float *d_out, void *stream) {
   MPN_CHECK_ARG(N >= 0);

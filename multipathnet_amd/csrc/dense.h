@@ -96,6 +96,13 @@ int c8p_zero_halos(const Act *acts, int n, hipStream_t s);
 int linear_c8(const float *d_x_c8, int M, int K, const float *d_wpk, const float *d_bpk, int N, int relu, float *d_y_c8,
               float *d_y_rm, hipStream_t s, int Mp_override = 0, const float *d_res_c8 = nullptr, int row_invariant = 0);
 bool linear_c8_is_direct(int M, int N, int Mp_override = 0);  // would linear_c8 run un-split for this shape?
+// The scratch slot a split-K linear_c8 of this thread keeps its partial sums in.  A launch that runs on a SECOND stream of the same handle
+// beside the launch stream's GEMMs (the pipelined forms' deferred heads) takes SCR_GEMM_SPLITK_SIDE for its duration.
+struct SplitkSlotScope {
+  explicit SplitkSlotScope(ScratchSlot slot);
+  ~SplitkSlotScope();
+  ScratchSlot prev;
+};
 // y = sum over up to three K segments of scale_seg[row % rs_mod] * (x_seg . w_seg) (+ b, ReLU): MultiPathNet's mix GEMM with nn.Normalize
 // of its three pooled maps applied where the accumulator is folded, instead of a read-modify-write pass over the pooled matrix.
 // Always launched un-split (like row_invariant = 2, so a row's result does not depend on the row count); k_end = the K index (multiple of 32) at which segment i ends.

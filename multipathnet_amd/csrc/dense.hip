@@ -1326,6 +1326,10 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ part, int S, int 
 MPN_KNOB(int, g_gemm_kch, 0);       // test/bench hook: force 4 or 8 K chunks per stage
 MPN_KNOB(int, g_gemm_split, 0);  // test/bench hook: force a split-K factor
 
+static thread_local ScratchSlot t_gemm_splitk_slot = SCR_GEMM_SPLITK;
+SplitkSlotScope::SplitkSlotScope(ScratchSlot slot) : prev(t_gemm_splitk_slot) { t_gemm_splitk_slot = slot; }
+SplitkSlotScope::~SplitkSlotScope() { t_gemm_splitk_slot = prev; }
+
 bool linear_c8_is_direct(int M, int N, int Mp_override) {
   const int Mp = Mp_override ? Mp_override : lin_mp(M);
   return g_gemm_split == 0 && (Mp / 128) * (lin_np(N) / 128) >= 128;
@@ -1410,7 +1414,7 @@ static int linear_c8_impl(const float *d_x_c8, int M, int K, const float *d_wpk,
   } else {
     size_t need = (size_t)S * (a.NP / 8) * a.Mp * 8 * sizeof(float);
     void *ws = nullptr;
-    { int rc_ws = scratch_get(SCR_GEMM_SPLITK, need, s, &ws); if (rc_ws) return rc_ws; }
+    { int rc_ws = scratch_get(t_gemm_splitk_slot, need, s, &ws); if (rc_ws) return rc_ws; }
     a.y = static_cast<float *>(ws);
   }
   dim3 grid((unsigned)tiles, (unsigned)S);

@@ -42,7 +42,7 @@ constexpr int kWave = 64;
 // with a mutex.  Work on a stream is ordered, so one Scratch per stream of work is race-free; two handles, two host
 // threads or two devices never share a buffer (the reference host runs one worker thread per GPU in ONE process,
 // test_runner.lua:55-66).
-enum ScratchSlot { SCR_CONV_SPLITK = 0, SCR_GEMM_SPLITK, SCR_L2NORM, SCR_NMS, SCR_LINEAR_PACK, SCR_GRAPH_SPLITK, SCR_MISC, SCR_IM2COL, SCR_NMS_CNT, SCR_NSLOTS };
+enum ScratchSlot { SCR_CONV_SPLITK = 0, SCR_GEMM_SPLITK, SCR_L2NORM, SCR_NMS, SCR_LINEAR_PACK, SCR_GRAPH_SPLITK, SCR_MISC, SCR_IM2COL, SCR_NMS_CNT, SCR_GEMM_SPLITK_SIDE, SCR_NSLOTS };
 struct Scratch {
   int device = -1;
   void *buf[SCR_NSLOTS] = {};
@@ -66,6 +66,7 @@ unsigned long long alloc_generation();
 void bump_alloc_generation();
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): function attributes are per device.
 int set_max_dyn_lds(const void *fn, int bytes);
+int project_im_rois_copy(const float *d_boxes, int n, double scale, float *d_rois, float *d_boxes_copy, hipStream_t s);  // boxes.hip
 // mpn_nms_batched for a call that runs on a side stream UNDER other work (the pipelined forms' tail under the next image's trunk): keeps the
 // launch chain for tables whose fused-kernel blocks (150 KB of LDS each) would displace that work (nms.hip: nms_batched_core)
 int nms_batched_under_trunk(const float *d_scored, const int *d_counts, int n_cls, int m_stride, float thr, float *d_keep, int *d_keep_idx,

@@ -248,6 +248,13 @@ struct mpn_frcnn {
   float *scored = nullptr, *keep = nullptr, *thresh = nullptr;   // set of the most recent call
   int *counts = nullptr, *keep_idx = nullptr, *n_keep = nullptr;
   hipStream_t side = nullptr;           // high-priority stream for the latency-bound NMS / top-k tail
+  // Deferred heads (pipelined forms of the plain Fast R-CNN head): cls / bbox GEMM + softmax + decode + select of image i run on `side`
+  // too, under image i + 1's first trunk layers — they are 51 us of kernels that leave most of the GPU idle.  What they read is held per
+  // buffer set: fc7's output (y7_b) and a copy of the caller's boxes (boxes_b); join_tail(b) orders their reuse two calls later.
+  hipStream_t defer_stream = nullptr;   // non-null while run_detect is to hand the heads over to it
+  int defer_set = 0;
+  float *y7_b[2] = {nullptr, nullptr}, *boxes_b[2] = {nullptr, nullptr}, *y7_last = nullptr;  // y7_last: where the last head left fc7's output
+  hipEvent_t ev_fc7 = nullptr;
   hipEvent_t ev_head[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
   bool tail_pending[2] = {false, false};
   unsigned long long seq = 0;
@@ -346,6 +353,14 @@ MPN_KNOB(int, g_first_k36, 1);  // 0: the first layer on the generic direct kern
 MPN_KNOB(int, g_roi_pool_pm, 1);  // 0: ROI pooling straight from the C8P map (roi_pool_c8_kernel)
 MPN_KNOB(int, g_mix_fold, 1);     // 0: MultiPathNet's nn.Normalize scales applied in place (l2norm_apply) instead of inside the mix GEMM
 MPN_KNOB(int, g_pool_overlap, 1); // 0: MultiPathNet's skip pooling on the launch stream instead of its own stream under the previous tower's GEMMs
+MPN_KNOB(int, g_defer_heads, 1);  // 0: the pipelined forms keep heads / softmax / decode / select on the launch stream (rounds 1-5a); 2 (test): the
+                                  // side stream is held back 1 ms before the heads, so that the launch stream runs far ahead of it
+#ifdef MPN_DEBUG_HOOKS
+__global__ void side_stream_delay_kernel(long long ticks) {  // wall_clock64: 100 MHz
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+#endif
 MPN_KNOB(int, g_halo_memset, 0);  // 1: a size change clears every activation buffer whole (rounds 1-4) instead of re-laying the halos only
 #ifdef MPN_DEBUG_HOOKS
 extern "C" void mpn_debug_set_fuse_pool(int v) { g_fuse_pool = v; }
@@ -354,6 +369,7 @@ extern "C" void mpn_debug_set_roi_pool_pm(int v) { g_roi_pool_pm = v; }
 extern "C" void mpn_debug_set_mix_fold(int v) { g_mix_fold = v; }
 extern "C" void mpn_debug_set_pool_overlap(int v) { g_pool_overlap = v; }
 extern "C" void mpn_debug_set_halo_memset(int v) { g_halo_memset = v; }
+extern "C" void mpn_debug_set_defer_heads(int v) { g_defer_heads = v; }
 #endif
 
 template <typename T>
@@ -377,6 +393,7 @@ extern "C" void mpn_frcnn_destroy(mpn_frcnn *p) {
   if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
   for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
   for (int i = 0; i < 2; ++i) { if (p->ev_head[i]) (void)hipEventDestroy(p->ev_head[i]); if (p->ev_tail[i]) (void)hipEventDestroy(p->ev_tail[i]); }
+  if (p->ev_fc7) (void)hipEventDestroy(p->ev_fc7);
   if (p->side) (void)hipStreamDestroy(p->side);
   if (p->pool_stream) (void)hipStreamDestroy(p->pool_stream);
   for (int i = 0; i < 2; ++i) { if (p->ev_pool_done[i]) (void)hipEventDestroy(p->ev_pool_done[i]); if (p->ev_mix_done[i]) (void)hipEventDestroy(p->ev_mix_done[i]); }
@@ -860,7 +877,8 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const 
     feat = p->tap_act[0];
   }
   if (rc) return rc;
-  rc = mpn_project_im_rois(d_boxes, N, sc, p->rois, s);
+  const bool defer_heads = p->defer_stream && !p->rn && !p->is_mpnet;  // the pipelined forms of the plain VGG head (pipelined_impl)
+  rc = defer_heads ? project_im_rois_copy(d_boxes, N, sc, p->rois, p->boxes_b[p->defer_set], s) : mpn_project_im_rois(d_boxes, N, sc, p->rois, s);
   if (rc) return rc;
   // decode uses the ORIGINAL boxes and clamps to the ORIGINAL image (ImageDetect.lua:183-185, Tester_FRCNN.lua:75-78)
   H = H0; W = W0;
@@ -883,6 +901,11 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const 
     p->last_n = N;
     return rc;
   }
+  // the pipelined forms of the plain VGG head hand the heads over to the side stream after fc7 (mpn_frcnn::defer_stream)
+  hipStream_t hs = defer_heads ? p->defer_stream : s;
+  float *y7 = hs != s ? p->y7_b[p->defer_set] : p->y7;
+  p->y7_last = y7;
+  const float *dec_boxes = d_boxes;
   if (p->rn) {  // resnet.lua:40-48: ROIPooling(14,14) -> layer4 -> average pool -> View; lands in y7 as the heads' operand
     ProfScope ps(p, MPN_PROF_FC6, s);
     rc = resnet_head_forward(p->rn, 0, p->rois, 5, N, c.spatial_scale, p->y7, lin_mp(N), s);
@@ -898,16 +921,26 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const 
   if (rc) return rc;
   { ProfScope ps(p, MPN_PROF_FC6, s); rc = linear_c8(p->x6, N, p->K6, p->w6, p->b6, F, 1, p->y6, nullptr, s, 0, nullptr, 1); }
   if (rc) return rc;
-  { ProfScope ps(p, MPN_PROF_FC7, s); rc = linear_c8(p->y6, N, F, p->w7, p->b7, F, 1, p->y7, nullptr, s, 0, nullptr, 1); }
+  { ProfScope ps(p, MPN_PROF_FC7, s); rc = linear_c8(p->y6, N, F, p->w7, p->b7, F, 1, y7, nullptr, s, 0, nullptr, 1); }
   if (rc) return rc;
   }
-  { ProfScope ps(p, MPN_PROF_HEADS, s); rc = linear_c8(p->y7, N, F, p->wh, p->bh, 5 * C, 0, nullptr, p->head, s, 0, nullptr, 1); }
+  if (hs != s) {  // hand over: the side stream continues from here (its work on this buffer set is ordered by ev_tail[set])
+    MPN_CHECK_HIP(hipEventRecord(p->ev_fc7, s));
+    MPN_CHECK_HIP(hipStreamWaitEvent(hs, p->ev_fc7, 0));
+    dec_boxes = p->boxes_b[p->defer_set];
+#ifdef MPN_DEBUG_HOOKS
+    if (g_defer_heads == 2) hipLaunchKernelGGL(side_stream_delay_kernel, dim3(1), dim3(64), 0, hs, 100000ll);
+#endif
+  }
+  { ProfScope ps(p, MPN_PROF_HEADS, hs);
+    SplitkSlotScope sk(hs != s ? SCR_GEMM_SPLITK_SIDE : SCR_GEMM_SPLITK);  // its partial sums must not share a buffer with fc6 / fc7 of the next image
+    rc = linear_c8(y7, N, F, p->wh, p->bh, 5 * C, 0, nullptr, p->head, hs, 0, nullptr, 1); }
   if (rc) return rc;
-  ProfScope ps_post(p, MPN_PROF_POST, s);
-  hipLaunchKernelGGL(head_softmax_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, p->head, 5 * C, N, C, p->scores);
+  ProfScope ps_post(p, MPN_PROF_POST, hs);
+  hipLaunchKernelGGL(head_softmax_kernel, dim3(cdiv(N, 4)), dim3(256), 0, hs, p->head, 5 * C, N, C, p->scores);
   MPN_CHECK_LAUNCH();
   const bool norm = c.bbox_std[0] != 0.0f;
-  hipLaunchKernelGGL(head_decode_kernel, dim3((unsigned)cdiv_sz((size_t)N * C, 256)), dim3(256), 0, s, p->head, 5 * C, C, N, C, d_boxes,
+  hipLaunchKernelGGL(head_decode_kernel, dim3((unsigned)cdiv_sz((size_t)N * C, 256)), dim3(256), 0, hs, p->head, 5 * C, C, N, C, dec_boxes,
                      norm ? 1 : 0, c.bbox_mean[0], c.bbox_mean[1], c.bbox_mean[2], c.bbox_mean[3], c.bbox_std[0], c.bbox_std[1],
                      c.bbox_std[2], c.bbox_std[3], clamp, (float)W, (float)H, p->bbox_raw, p->bbox);
   MPN_CHECK_LAUNCH();
@@ -919,7 +952,7 @@ extern "C" int mpn_frcnn_detect(mpn_frcnn *p, const float *d_image, int H, int W
                                 float *d_scores, float *d_bbox, int clamp, void *stream) {
   MPN_CHECK_ARG(p != nullptr);
   ScratchScope scratch_scope(&p->scratch);
-  if (d_image == nullptr) { int rcf = mpn_frcnn_flush(p, stream); if (rcf) return rcf; }
+  { int rcf = mpn_frcnn_flush(p, stream); if (rcf) return rcf; }  // a pipelined predecessor's side-stream work may still use the head buffers
   hipStream_t s = as_stream(stream);
   int rc = run_detect(p, d_image, H, W, d_boxes, N, s, clamp ? 1 : 0);
   if (rc) return rc;
@@ -1290,11 +1323,24 @@ static int pipelined_impl(mpn_frcnn *p, const float *d_image, int H, int W, cons
   int rc = join_tail(p, b, s);  // buffer set b was last used two calls ago
   if (rc) return rc;
   int rows = N;
+  // heads + softmax + decode + select on the side stream too (plain VGG head, one localisation pass, no captured graphs, not profiling)
+  const bool defer = g_defer_heads && !p->is_mpnet && !p->rn && p->cfg.num_iter == 1 && !p->graphs_on && !p->prof && d_image && d_boxes;
+  if (defer) {
+    if (!p->y7_b[1]) {
+      p->y7_b[0] = p->y7;
+      int rca = dev_alloc(p, &p->y7_b[1], (size_t)(lin_np(p->cfg.fc_dim) / 8) * p->Mp * 8 * sizeof(float), true);
+      for (int i = 0; i < 2 && !rca; ++i) rca = dev_alloc(p, &p->boxes_b[i], (size_t)p->cfg.max_rois * 4 * sizeof(float), false);
+      if (rca) return rca;
+      MPN_CHECK_HIP(hipEventCreateWithFlags(&p->ev_fc7, hipEventDisableTiming));
+    }
+    p->defer_stream = p->side; p->defer_set = b;
+  }
   rc = run_head(p, d_image, H, W, d_boxes, N, s, &rows, stable_ptrs);
+  p->defer_stream = nullptr;
   if (rc) return rc;
   select_set(p, b);
   p->last_rows = rows;
-  rc = run_tail(p, rows, d_dets, top_cap, d_n_dets, s, p->side, p->ev_head[b]);
+  rc = run_tail(p, rows, d_dets, top_cap, d_n_dets, defer ? p->side : s, p->side, p->ev_head[b]);
   if (rc) return rc;
   MPN_CHECK_HIP(hipEventRecord(p->ev_tail[b], p->side));
   p->tail_pending[b] = true;
@@ -1494,7 +1540,7 @@ extern "C" int mpn_frcnn_debug_tensor(mpn_frcnn *p, const char *name, const floa
     hipLaunchKernelGGL(unpack_pooled_kernel, dim3((unsigned)cdiv_sz(n, 256)), dim3(256), 0, nullptr, p->x6, N, p->feat_c, PP, lin_mp(N), p->dbg);
     MPN_CHECK_LAUNCH();
   } else if (nm == "fc7") {
-    rc = c8_to_rowmajor(p->y7, N, F, p->dbg, nullptr);  // rows at stride lin_mp(N), as linear_c8 wrote them
+    rc = c8_to_rowmajor(p->y7_last ? p->y7_last : p->y7, N, F, p->dbg, nullptr);  // rows at stride lin_mp(N), as linear_c8 wrote them
   } else if (nm == "cls_k") {
     MPN_CHECK_HIP(hipMemcpy(p->dbg, p->cls_rm, n * sizeof(float), hipMemcpyDeviceToDevice));
   } else if (nm == "cat") {

@@ -660,3 +660,45 @@ def test_roi_pool_pixel_major_is_bit_identical(dev, small):
         b_s, b_b = net0.detect(im, bx)
         b_p = net0.debug_tensor("pooled", small["pooled"].shape).clone()
     assert torch.equal(a_p, b_p) and torch.equal(a_s, b_s) and torch.equal(a_b, b_b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("defer", [0, 2], ids=["launch-stream-heads", "side-stream-held-back"])
+def test_deferred_heads_hazards(dev, small, defer):
+    """Round 5: the pipelined forms of the plain Fast R-CNN head hand cls / bbox GEMM + softmax + decode + select over to the side stream
+    after fc7 (they then run under the next image's first trunk layers).  What they read lives per buffer set (fc7's output, a copy of the
+    caller's boxes, a split-K scratch of their own).  defer = 2 holds the side stream back 1 ms before every image's heads, so that the
+    launch stream is a whole image ahead — its next fc6 / fc7 (split-K at this size), its next boxes upload, its next ROI projection all
+    run BEFORE the previous image's heads: a missing guard shows as a wrong record.  defer = 0 is the previous form.  60 host-fed images of
+    three sizes, every record against the serial form's, bit for bit."""
+    from multipathnet_amd import models
+    rng = np.random.default_rng(23)
+    s = SMALL
+    shapes = [(s["H"], s["W"], s["N"]), (120, 200, 150), (s["H"], s["W"], 64)]
+    ims = [rng.random((3, h, w), dtype=np.float32) for h, w, _ in shapes]
+    bxs = [_boxes(rng, n, w, h) for h, w, n in shapes]
+    ref = []
+    for im, b in zip(ims, bxs):   # the serial form on the product library
+        d, n = small["net"].test_one_async(torch.from_numpy(im).to(dev), torch.from_numpy(b).to(dev))
+        torch.cuda.synchronize()
+        ref.append(d[: int(n.item())].clone())
+    pin = [(torch.from_numpy(im).pin_memory(), torch.from_numpy(b).pin_memory()) for im, b in zip(ims, bxs)]
+    with hooks(defer_heads=defer):   # the knob lives in the debug flavour: a handle of its own
+        net = models.FastRCNN(small["P_torch"], cfg=s["cfg"], pooled=7, spatial_scale=s["scale"], max_h=s["H"], max_w=s["W"], max_rois=s["N"])
+        steps, snap_d, snap_n, prev = 60, [], [], None
+        for t_ in range(steps):
+            cur = net.test_one_pipelined_host(*pin[t_ % 3])
+            if prev is not None:
+                snap_d.append(prev[0].clone()); snap_n.append(prev[1].clone())
+            prev = cur
+        net.flush()
+        snap_d.append(prev[0].clone()); snap_n.append(prev[1].clone())
+        torch.cuda.synchronize()
+        # the un-pipelined entries stay correct straight after pipelined use (they join the side stream first)
+        d, n = net.test_one_async(torch.from_numpy(ims[1]).to(dev), torch.from_numpy(bxs[1]).to(dev))
+        torch.cuda.synchronize()
+        assert torch.equal(d[: int(n.item())], ref[1])
+    for t_ in range(steps):
+        n = int(snap_n[t_].item())
+        assert n == ref[t_ % 3].shape[0], t_
+        assert torch.equal(snap_d[t_][:n], ref[t_ % 3]), t_
