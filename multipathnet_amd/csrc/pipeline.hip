@@ -252,6 +252,7 @@ struct mpn_frcnn {
   // too, under image i + 1's first trunk layers — they are 51 us of kernels that leave most of the GPU idle.  What they read is held per
   // buffer set: fc7's output (y7_b) and a copy of the caller's boxes (boxes_b); join_tail(b) orders their reuse two calls later.
   hipStream_t defer_stream = nullptr;   // non-null while run_detect is to hand the heads over to it
+  bool was_deferred = false;            // the previous pipelined call handed its heads over
   int defer_set = 0;
   float *y7_b[2] = {nullptr, nullptr}, *boxes_b[2] = {nullptr, nullptr}, *y7_last = nullptr;  // y7_last: where the last head left fc7's output
   hipEvent_t ev_fc7 = nullptr;
@@ -1334,7 +1335,11 @@ static int pipelined_impl(mpn_frcnn *p, const float *d_image, int H, int W, cons
       MPN_CHECK_HIP(hipEventCreateWithFlags(&p->ev_fc7, hipEventDisableTiming));
     }
     p->defer_stream = p->side; p->defer_set = b;
+  } else if (p->was_deferred) {  // the form changed under us (graphs / profiling switched on): the side stream may still read y7_b[0] == y7
+    rc = mpn_frcnn_flush(p, stream);
+    if (rc) return rc;
   }
+  p->was_deferred = defer;
   rc = run_head(p, d_image, H, W, d_boxes, N, s, &rows, stable_ptrs);
   p->defer_stream = nullptr;
   if (rc) return rc;
