@@ -394,7 +394,7 @@ int mpn_frcnn_detect(mpn_frcnn *p, const float *d_image, int H, int W, const flo
 int mpn_frcnn_test_one(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N, float *d_dets,
                        int top_cap, int *d_n_dets, void *stream);
 /* Throughput form for a loop over images (Tester:test, Tester_FRCNN.lua:150-157): same work, but the
- * latency-bound NMS + top-k tail of image i runs on an internal high-priority stream and overlaps image
+ * latency-bound NMS + top-k tail of image i runs on an internal side stream (default priority) and overlaps image
  * i+1's trunk.  d_dets / d_n_dets of call i are ordered on `stream` only after call i+1 (on the same
  * handle) or mpn_frcnn_flush(); alternate two output buffers between consecutive calls.  For the plain Fast R-CNN head
  * (one localisation pass) the class / box GEMM, softmax, decode and select of image i run on that internal stream as well

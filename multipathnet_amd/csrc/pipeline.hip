@@ -247,7 +247,7 @@ struct mpn_frcnn {
   int *counts_b[2] = {nullptr, nullptr}, *keep_idx_b[2] = {nullptr, nullptr}, *n_keep_b[2] = {nullptr, nullptr};
   float *scored = nullptr, *keep = nullptr, *thresh = nullptr;   // set of the most recent call
   int *counts = nullptr, *keep_idx = nullptr, *n_keep = nullptr;
-  hipStream_t side = nullptr;           // high-priority stream for the latency-bound NMS / top-k tail
+  hipStream_t side = nullptr;           // side stream (default priority: see create) for the heads and the NMS / top-k tail of the pipelined forms
   // Deferred heads (pipelined forms of the plain Fast R-CNN head): cls / bbox GEMM + softmax + decode + select of image i run on `side`
   // too, under image i + 1's first trunk layers — they are 51 us of kernels that leave most of the GPU idle.  What they read is held per
   // buffer set: fc7's output (y7_b) and a copy of the caller's boxes (boxes_b); join_tail(b) orders their reuse two calls later.
@@ -1312,7 +1312,7 @@ extern "C" int mpn_frcnn_test_one_sharded(mpn_frcnn *p, mpn_comm *comm, const fl
 }
 
 // Throughput form for a loop over images (Tester:test, Tester_FRCNN.lua:150-157): trunk + heads + select of
-// image i on `stream`; NMS + top-k of image i on the pipeline's high-priority side stream, overlapping image
+// image i on `stream`; NMS + top-k of image i on the pipeline's side stream, overlapping image
 // i+1's MFMA kernels (they are latency-bound on ~20 CUs).  d_dets / d_n_dets of call i are ordered on `stream`
 // only after call i+1 returns or after mpn_frcnn_flush(); the caller alternates two output buffers.
 static int pipelined_impl(mpn_frcnn *p, const float *d_image, int H, int W, const float *d_boxes, int N, float *d_dets, int top_cap, int *d_n_dets,
