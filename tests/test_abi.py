@@ -31,7 +31,7 @@ def test_product_library_has_no_test_hooks():
     plus the hooks."""
     so = os.path.join(ROOT, "multipathnet_amd", "libmpn_hip.so")
     dbg = os.path.join(ROOT, "multipathnet_amd", "libmpn_hip_dbg.so")
-    sym = subprocess.check_output(["nm", "-D", "--defined-only", so]).decode()
+    sym = subprocess.check_output(["nm", "--defined-only", so]).decode()  # the full symbol table: kernels are not exported (mpn.map)
     assert "mpn_debug" not in sym
     # conv3x3_wino_kernel<ABL, TC>: only ABL = 0 (no timing-experiment switches) ships; TC = 8 / 16 are the two block geometries
     assert not re.search(r"conv3x3_wino_kernelILi[1-9]", sym), "ablation instantiations of the Winograd kernel in the product build"
@@ -44,6 +44,20 @@ def test_product_library_has_no_test_hooks():
     for f in ("dense.hip", "nms.hip", "resnet.hip", "boxes.hip", "pipeline.hip"):
         txt = open(os.path.join(ROOT, "multipathnet_amd", "csrc", f)).read()
         assert not re.search(r"^\s*static\s+(float|char|void)\s*\*\s*\w+\s*=\s*nullptr", txt, flags=re.M), f
+
+
+def test_libraries_export_the_header_and_nothing_else():
+    """VERDICT r5 item 6: `nm -D` of either flavour shows the C ABI (mpn_*) only — no mangled mpn:: internals, no kernel stubs
+    (csrc/mpn.map).  A Lua host that also loads another HIP library cannot collide with ours."""
+    declared = set(_declared("mpn.h"))
+    for name, hooks in (("libmpn_hip.so", False), ("libmpn_hip_dbg.so", True)):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "multipathnet_amd", name)]).decode()
+        syms = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+        assert syms, name
+        assert not [x for x in syms if x.startswith("_Z")], (name, [x for x in syms if x.startswith("_Z")][:5])
+        extra = sorted(x for x in syms if x not in declared and not (hooks and x.startswith("mpn_debug_")))
+        assert not extra, (name, extra[:8])
+        assert declared <= set(syms), (name, sorted(declared - set(syms))[:8])
 
 
 def test_libnms_dropin_exports():
