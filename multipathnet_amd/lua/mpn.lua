@@ -85,6 +85,30 @@ mpn.ROIPooling, mpn.Foveal, mpn.ContextRegion = ROIPooling, Foveal, Context
 -- model = nn.Sequential{ ParallelTable{features, Identity}, inn.ROIPooling, nn.View, classifier, ConcatTable{cls, bbox[+BBoxNorm]} }
 -- opt: n_classes, max_h, max_w, max_rois, nms_thresh, num_iter, bbox_voting, ... (Tester_FRCNN.lua:20-51 fields)
 local FastRCNN = torch.class('mpn.FastRCNN')
+local function is_conv(m) local tn = torch.typename(m); return tn == 'cudnn.SpatialConvolution' or tn == 'nn.SpatialConvolution' end
+-- What wraps the reference's sub-networks: utils.makeDataParallel (model_utils.lua:15-29) returns nn.Sequential():add(module) at nGPU = 1 and
+-- an nn.DataParallelTable of per-GPU clones otherwise; nn.NoBackprop (modules/NoBackprop.lua) is a one-child container;
+-- utils.disableFeatureBackprop (model_utils.lua:96-103) moves the first layers into NoBackprop(nn.Sequential) at position 1.
+-- replica(m): m without its outer wrappers, and ONE replica of it (the clones hold the same values) — so that findModules / listModules below
+-- see every layer once, whatever nGPU was.  (Module:findModules returns the receiver itself first when it matches: never index its result to
+-- "get inside" a wrapper.)
+local function replica(m)
+   while m.modules do
+      local tn = torch.typename(m)
+      if tn == 'nn.DataParallelTable' or tn == 'nn.NoBackprop' then m = m.modules[1]
+      elseif tn == 'nn.Sequential' and #m.modules == 1 and m.modules[1].modules then m = m.modules[1]
+      else break end
+   end
+   return m
+end
+-- conv_sequential(m): the nn.Sequential at or under m, in listModules' pre-order, whose FIRST module is a convolution — the container that holds
+-- conv1 (ResNet's stem, inside disableFeatureBackprop's NoBackprop) / conv1_1 .. (VGG's skip_features)
+local function conv_sequential(m)
+   for _, s in ipairs(replica(m):listModules()) do
+      if torch.typename(s) == 'nn.Sequential' and s.modules[1] and is_conv(s.modules[1]) then return s end
+   end
+   error('no nn.Sequential that starts with a convolution under ' .. torch.typename(m))
+end
 local function convs_of(features)  -- 3x3 convolutions in execution order + "a 2x2 max-pool follows" flags
    local convs, pool = {}, {}
    for _, m in ipairs(features:listModules()) do
@@ -132,7 +156,7 @@ local function finish(self, h, cfg, keep)
    self.dets, self.n_dets = torch.CudaTensor(self.top_cap, 6), torch.CudaIntTensor(1)
 end
 function FastRCNN:__init(model, opt)
-   local features, roipool = model:get(1):get(1), model:get(2)
+   local features, roipool = replica(model:get(1):get(1)), model:get(2)
    local lin = model:get(4):findModules('nn.Linear')             -- fc6, fc7
    local cls_w, cls_b, bbox, bnorm = heads_of(model:get(5))
    local convs, pool = convs_of(features)
@@ -161,11 +185,12 @@ end
 --   (4) ConcatTable{Narrow, Narrow}   (5) classAndBBoxLinear [utils.integral: K classifier clones]   [(6) ModeSwitch] }
 function mpn.MultiPathNet(model, opt)
    local self = setmetatable({}, {__index = FastRCNN})
-   local skip = model:get(1):get(1)
+   local skip = replica(model:get(1):get(1))                      -- NoBackprop(makeDataParallel(skip_features)) -> skip_features itself
    local conv_list, pool = convs_of(skip)                         -- listModules walks features 1-16, then conv4, then conv5: execution order
    local n = #conv_list
    local n3 = 0                                                    -- convolutions among skip_features' own first 16 layers = conv1_1 .. conv3_3
-   local top = skip:findModules('nn.Sequential')[1] or skip
+   local top = conv_sequential(skip)                               -- multipathnet.lua:34-57: 16 layers, ConcatTable{conv4, Identity}, ParallelTable, FlattenTable
+   assert(#top.modules >= 17 and torch.typename(top:get(17)) == 'nn.ConcatTable', 'not models/multipathnet.lua\'s skip_features')
    for i = 1, 16 do local tn = torch.typename(top:get(i)); if tn == 'cudnn.SpatialConvolution' or tn == 'nn.SpatialConvolution' then n3 = n3 + 1 end end
    local n4 = n3
    for _, m in ipairs(top:get(17):get(1):listModules()) do local tn = torch.typename(m); if tn == 'cudnn.SpatialConvolution' or tn == 'nn.SpatialConvolution' then n4 = n4 + 1 end end
@@ -219,14 +244,13 @@ local function folded(conv, affine, keep)
    keep[#keep + 1], keep[#keep + 2] = w, b
    return w, b
 end
-local function is_conv(m) local tn = torch.typename(m); return tn == 'cudnn.SpatialConvolution' or tn == 'nn.SpatialConvolution' end
 local function is_affine(m) local tn = torch.typename(m); return tn == 'inn.ConstAffine' or tn == 'nn.SpatialBatchNormalization' or tn == 'cudnn.SpatialBatchNormalization' end
 
 -- models/resnet.lua:24-50: net:get(1..7) on the image, inn.ROIPooling(14,14,1/16), net:get(8..10) = layer4 + average pool + View per ROI.
 -- fb.resnet.torch blocks: Sequential{ ConcatTable{ Sequential{conv, bn, relu, ...conv, bn}, shortcut (Identity | Sequential{conv, bn}) }, CAddTable, ReLU }
 function mpn.ResNet(model, opt)
    local self = setmetatable({}, {__index = FastRCNN})
-   local features, roipool, classifier = model:get(1):get(1), model:get(2), model:get(3)
+   local features, roipool, classifier = replica(model:get(1):get(1)), model:get(2), replica(model:get(3))
    local cls_w, cls_b, bbox, bnorm = heads_of(model:get(4))
    local keep = {cls_w, cls_b}
    local W, B, cin, co, ks, st, pd, bn, bs = {}, {}, {}, {}, {}, {}, {}, {}, {}
@@ -250,8 +274,8 @@ function mpn.ResNet(model, opt)
          bn[#bn + 1], bs[#bs + 1] = nc, has
       end
    end
-   local stem = features:findModules('nn.Sequential')[1] or features
-   add_conv(stem.modules, 1)                                       -- conv1 7x7/2 (+ its BatchNorm)
+   local stem = conv_sequential(features)                          -- resnet.lua:33: conv1 sits inside disableFeatureBackprop(features, 5)'s NoBackprop
+   add_conv(stem.modules, 1)                                       -- conv1 7x7/2 (+ its BatchNorm unless inn.utils.foldBatchNorm folded it, resnet.lua:34)
    add_blocks(features)
    local n_trunk = #bn
    add_blocks(classifier)
@@ -346,7 +370,7 @@ local function graph_ops(root, c0, keep, pooled)
          op.dst = new_tensor(c)
          ops[#ops + 1] = op
          return op.dst, h
-      elseif m.modules and #m.modules == 1 then                    -- NoBackprop / DataParallelTable wrappers
+      elseif tn == 'nn.DataParallelTable' or (m.modules and #m.modules == 1) then   -- NoBackprop / makeDataParallel wrappers: one replica
          return walk(m.modules[1], src, h)
       end
       return src, h                                                 -- View, Dropout, Identity, Contiguous, a ReLU that follows a pooling layer
@@ -367,7 +391,7 @@ end
 -- opt.transformer: {scale, mean, std, swap} (default: fbcoco.ImageTransformer({1,1,1}, nil, 2), inceptionv3.lua:52; pass mpn.ROSS for alexnet.lua)
 function mpn.Graph(model, opt)
    local self = setmetatable({}, {__index = FastRCNN})
-   local features, roipool, classifier = model:get(1):get(1), model:get(2), model:get(3)
+   local features, roipool, classifier = replica(model:get(1):get(1)), model:get(2), replica(model:get(3))
    -- (grouped convolutions — alexnet.lua's conv2 / conv4 / conv5 — must be split into one convolution per group by the caller: op.src_c_off)
    local cls_w, cls_b, bbox, bnorm = heads_of(model:get(#model.modules))
    local keep = {cls_w, cls_b}

@@ -155,3 +155,144 @@ def test_model_weight_structs_used_by_the_lua_constructors_exist():
     # top_cap is derived from the configuration, not a literal, and the per-class table read-back exists once
     assert "cfg.top_k * 4 + 64" in lua and "464" not in lua
     assert lua.count("function FastRCNN:_img_boxes") == 1 and lua.count("C.mpn_frcnn_nms_results") == 1
+
+
+# ---- the constructors' walkers on module trees shaped like the reference's, nGPU = 1 and nGPU > 1 -------------------------
+# No Lua runtime exists in the image, so the walkers cannot be EXECUTED; what runs here is a Python transcription of mpn.lua's two helpers
+# (replica, conv_sequential) over mock nn modules with Torch7's container semantics (Module:listModules = pre-order incl. the receiver;
+# Module:findModules returns the receiver first when it matches — the trap the round-5 code fell into), on trees built the way
+# models/{vgg,resnet,multipathnet}.lua + model_utils.lua:15-29,96-103 build them.  The test also pins the Lua text to the transcription: the
+# helpers exist with the transcribed rules, every constructor goes through replica(), nothing indexes findModules('nn.Sequential').
+class _M:
+    def __init__(self, tn, *mods, container=None):
+        self.tn = tn
+        self.modules = list(mods) if (mods or container) else None
+
+    def list_modules(self):
+        out = [self]
+        for m in self.modules or []:
+            out += m.list_modules()
+        return out
+
+    def find_modules(self, tn):
+        return [m for m in self.list_modules() if m.tn == tn]
+
+
+def _seq(*mods):
+    return _M("nn.Sequential", *mods, container=True)
+
+
+def _is_conv(m):
+    return m.tn in ("cudnn.SpatialConvolution", "nn.SpatialConvolution")
+
+
+def _replica(m):
+    while m.modules is not None:
+        if m.tn in ("nn.DataParallelTable", "nn.NoBackprop"):
+            m = m.modules[0]
+        elif m.tn == "nn.Sequential" and len(m.modules) == 1 and m.modules[0].modules is not None:
+            m = m.modules[0]
+        else:
+            break
+    return m
+
+
+def _conv_sequential(m):
+    for s in _replica(m).list_modules():
+        if s.tn == "nn.Sequential" and s.modules and _is_conv(s.modules[0]):
+            return s
+    raise AssertionError("no Sequential starting with a convolution")
+
+
+def _make_data_parallel(module_factory, n_gpu):   # model_utils.lua:15-29
+    if n_gpu > 1:
+        return _M("nn.DataParallelTable", *[module_factory() for _ in range(n_gpu)], container=True)
+    return _seq(module_factory())
+
+
+def _disable_feature_backprop(features, max_layer):   # model_utils.lua:96-103
+    head = _seq(*features.modules[:max_layer])
+    features.modules = [_M("nn.NoBackprop", head, container=True)] + features.modules[max_layer:]
+
+
+def _vgg_features():
+    cfg = [64, 64, "P", 128, 128, "P", 256, 256, 256, "P", 512, 512, 512, "P", 512, 512, 512]
+    mods = []
+    for c in cfg:
+        mods += [_M("nn.SpatialMaxPooling")] if c == "P" else [_M("cudnn.SpatialConvolution"), _M("cudnn.ReLU")]
+    return _seq(*mods)   # 30 modules: convolutions at 1,3,6,8,11,13,15,18,20,22,25,27,29 (vgg.lua:18)
+
+
+def _resnet_block(shortcut):
+    path = _seq(_M("cudnn.SpatialConvolution"), _M("inn.ConstAffine"), _M("cudnn.ReLU"), _M("cudnn.SpatialConvolution"), _M("inn.ConstAffine"),
+                _M("cudnn.ReLU"), _M("cudnn.SpatialConvolution"), _M("inn.ConstAffine"))
+    sc = _seq(_M("cudnn.SpatialConvolution"), _M("inn.ConstAffine")) if shortcut else _M("nn.Identity")
+    return _seq(_M("nn.ConcatTable", path, sc, container=True), _M("nn.CAddTable"), _M("cudnn.ReLU"))
+
+
+def _resnet_layer(n):
+    return _seq(*[_resnet_block(i == 0) for i in range(n)])
+
+
+def test_lua_walkers_on_reference_shaped_trees():
+    import pytest
+    for n_gpu in (1, 2, 4):
+        # models/vgg.lua:14-31 ---------------------------------------------------------------------------------------------------------
+        def vgg():
+            f = _vgg_features()
+            _disable_feature_backprop(f, 10)
+            return f
+        wrapped = _make_data_parallel(vgg, n_gpu)                 # = model:get(1):get(1)
+        feats = _replica(wrapped)
+        assert feats.tn == "nn.Sequential" and feats.modules[0].tn == "nn.NoBackprop" and len(feats.modules) == 21
+        assert sum(_is_conv(m) for m in feats.list_modules()) == 13
+        if n_gpu > 1:   # what the un-unwrapped walk would have produced: every replica's convolutions
+            assert sum(_is_conv(m) for m in wrapped.list_modules()) == 13 * n_gpu
+        # models/resnet.lua:24-50 ------------------------------------------------------------------------------------------------------
+        def resnet_features():
+            f = _seq(_M("cudnn.SpatialConvolution"), _M("cudnn.SpatialBatchNormalization"), _M("cudnn.ReLU"), _M("nn.SpatialMaxPooling"),
+                     _resnet_layer(3), _resnet_layer(4), _resnet_layer(6))
+            _disable_feature_backprop(f, 5)
+            # inn.utils.foldBatchNorm on the NoBackprop part (resnet.lua:34): conv1's BatchNorm is gone
+            inner = f.modules[0].modules[0]
+            inner.modules = [m for m in inner.modules if m.tn != "cudnn.SpatialBatchNormalization"]
+            return f
+        wrapped = _make_data_parallel(resnet_features, n_gpu)
+        # the round-5 walker: findModules('nn.Sequential')[1] is the receiver / the wrapper, whose first module is not conv1
+        r5 = (wrapped.find_modules("nn.Sequential") or [wrapped])[0]
+        assert not _is_conv(r5.modules[0])
+        feats = _replica(wrapped)
+        stem = _conv_sequential(feats)
+        assert _is_conv(stem.modules[0]) and stem.modules[1].tn == "cudnn.ReLU" and len(stem.modules) == 4   # conv1, relu, maxpool, layer1
+        assert len(feats.find_modules("nn.ConcatTable")) == 3 + 4 + 6                                        # add_blocks(features): one replica
+        classifier = _replica(_make_data_parallel(lambda: _seq(_resnet_layer(3), _M("cudnn.SpatialAveragePooling"), _M("nn.View")), n_gpu))
+        assert len(classifier.find_modules("nn.ConcatTable")) == 3
+        # models/multipathnet.lua:30-62 ------------------------------------------------------------------------------------------------
+        def skip_features():
+            f = _vgg_features()
+            conv4, conv5 = _seq(*f.modules[16:23]), _seq(*f.modules[23:30])
+            s = _seq(*f.modules[:16])
+            s.modules.append(_M("nn.ConcatTable", conv4, _M("nn.Identity"), container=True))
+            s.modules.append(_M("nn.ParallelTable", _M("nn.ConcatTable", conv5, _M("nn.Identity"), container=True), _M("nn.Identity"), container=True))
+            s.modules.append(_M("nn.FlattenTable"))
+            return s
+        wrapped = _M("nn.NoBackprop", _make_data_parallel(skip_features, n_gpu), container=True)   # = model:get(1):get(1)
+        skip = _replica(wrapped)
+        top = _conv_sequential(skip)
+        assert top is skip and len(top.modules) == 19 and top.modules[16].tn == "nn.ConcatTable"
+        assert sum(_is_conv(m) for m in top.modules[:16]) == 7                                      # n3: conv1_1 .. conv3_3
+        assert sum(_is_conv(m) for m in top.modules[16].modules[0].list_modules()) == 3             # conv4_1 .. conv4_3
+        assert sum(_is_conv(m) for m in skip.list_modules()) == 13
+        if n_gpu == 1:   # round 5's `top`: the one-element makeDataParallel wrapper -> top:get(2..16) are nil
+            r5 = (wrapped.find_modules("nn.Sequential") or [wrapped])[0]
+            assert len(r5.modules) == 1
+    with pytest.raises(AssertionError):
+        _conv_sequential(_seq(_M("nn.Identity")))
+    # the Lua text carries the transcribed rules and every constructor uses them
+    lua = open(os.path.join(LUA, "mpn.lua")).read()
+    assert "findModules('nn.Sequential')" not in lua
+    assert "if tn == 'nn.DataParallelTable' or tn == 'nn.NoBackprop' then m = m.modules[1]" in lua
+    assert "elseif tn == 'nn.Sequential' and #m.modules == 1 and m.modules[1].modules then m = m.modules[1]" in lua
+    assert "if torch.typename(s) == 'nn.Sequential' and s.modules[1] and is_conv(s.modules[1]) then return s end" in lua
+    assert lua.count("replica(model:get(1):get(1))") == 4 and lua.count("replica(model:get(3))") == 2
+    assert "local stem = conv_sequential(features)" in lua and "local top = conv_sequential(skip)" in lua
