@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MPN_VERSION 400
+#define MPN_VERSION 600
 
 typedef enum mpn_status {
   MPN_OK = 0,
@@ -146,6 +146,23 @@ int mpn_project_im_rois(const float *d_boxes, int n, double scale, float *d_rois
 int mpn_roi_pool_forward(const float *d_feat, int B, int C, int H, int W, const float *d_rois, int N, int PH, int PW,
                          float scale, float coord_offset, int end_adjust, float *d_out, int32_t *d_argmax,
                          void *stream);
+/* The same module with an explicit BIN RULE (inn.ROIPooling is external and its source is not in the reference tree: both of its branches are
+ * restated, SURVEY §8a-6, parity unpinned):
+ *   MPN_ROI_BINS_CAFFE    — the CUDA branch (what mpn_roi_pool_forward computes): bins from the un-clipped window, each bin clipped to the map
+ *                           afterwards, a bin that falls outside the map is empty (0, argmax -1);
+ *   MPN_ROI_BINS_ADAPTIVE — the CPU branch ("CPU nn path", BASELINE configs[0]; call sites models/alexnet.lua:23, models/vgg.lua:28 with float
+ *                           tensors): corners = round((x - coord_offset) * scale + 1) in 1-based map coordinates, CLIPPED to the map first
+ *                           (the reference clips the upper side — cmin — and indexes the tensor with the lower side; we clip both), the crop
+ *                           goes through nn.SpatialAdaptiveMaxPooling(PW, PH): bin p = [floor(p * size / P), ceil((p + 1) * size / P)) of the
+ *                           clipped crop, never empty.  The two rules differ on windows whose rounded corners leave the map (Foveal's regions; border boxes whose
+ *                           round((x2 - 1) * scale) is W) and, about once in a thousand windows, by one cell where the fp32 bin size rounds
+ *                           (measured: tests/test_oracle_roipool_adaptive.py).
+ * d_argmax is h * W + w in the feature plane under both rules. */
+#define MPN_ROI_BINS_CAFFE 0
+#define MPN_ROI_BINS_ADAPTIVE 1
+int mpn_roi_pool_forward_rule(const float *d_feat, int B, int C, int H, int W, const float *d_rois, int N, int PH, int PW,
+                              float scale, float coord_offset, int end_adjust, int bin_rule, float *d_out, int32_t *d_argmax,
+                              void *stream);
 
 /* nn.Foveal:updateOutput (modules/Foveal.lua:15-44): [N,5] -> [4N,5], f64 arithmetic rounded to fp32. */
 int mpn_foveal_forward(const float *d_rois, int N, float *d_out, void *stream);
@@ -263,6 +280,8 @@ typedef struct mpn_frcnn_config {
   int use_rbox_scores;     /* opt.test_use_rbox_scores (Tester_FRCNN.lua:91-97): needs num_iter > 1; the scores of pass i+1 are
                               paired with the boxes of pass i (the first score table and the last box table are dropped), so
                               (num_iter - 1) * N rows reach the NMS */
+  int roi_bin_rule;        /* MPN_ROI_BINS_CAFFE (0, default: inn.ROIPooling's CUDA branch) | MPN_ROI_BINS_ADAPTIVE (its CPU branch): the
+                              rule of every ROI pooling of the pipeline — mpn_roi_pool_forward_rule.  (added in MPN_VERSION 600, at the END) */
 } mpn_frcnn_config;
 
 typedef struct mpn_frcnn mpn_frcnn; /* opaque */

@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void select_scored_kernel(const float *__restr
 // selection order inside a class (= the order keep_top_k preserves).
 __device__ __forceinline__ unsigned f2key(float f) {
   unsigned u = __float_as_uint(f);
+  if (u == 0x80000000u) u = 0u;  // -0.0f == +0.0f in utils.keep_top_k's `score >= thresh` (and in nms.c's order): one key for both
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 __device__ __forceinline__ float key2f(unsigned k) {

@@ -113,27 +113,25 @@ int linear_c8_rowscaled(const float *d_x_c8, int M, int K, const float *d_wpk, c
 // chunk q = cb*PH*PW + bin, row = roi.  argmax (optional) [N,C,PH,PW] int32 as the NCHW kernel.
 // roi_stride: floats between consecutive rois (5; 20 selects one Foveal region out of the [4N,5] table);
 // Mp: row pitch of the output matrix (0 = lin_mp(N)).
-int roi_pool_c8(Act feat, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset, int end_adjust,
+int roi_pool_c8(Act feat, const float *d_rois, int N, int PH, int PW, float scale, RoiRule rr,
                 float *d_x_c8, int32_t *d_argmax, hipStream_t s, int roi_stride = 5, int Mp = 0);
 // The same pooling from a pixel-major copy [y][x][Cb*8] of the map (one contiguous 1 KiB per pixel and 256 channels; bit-identical
 // output, no argmax): c8p_to_pixel_major once per image, then roi_pool_pm.
 size_t pixel_major_elems(Act feat);
 int c8p_to_pixel_major(Act feat, float *d_pm, hipStream_t s);
-int roi_pool_pm(Act feat, const float *d_pm, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset, int end_adjust,
+int roi_pool_pm(Act feat, const float *d_pm, const float *d_rois, int N, int PH, int PW, float scale, RoiRule rr,
                 float *d_x_c8, hipStream_t s, int roi_stride = 5, int Mp = 0);
 // vertical range-max tables of a C8P map (levels 1..vmax_levels_for(H), each feat.elems() floats) and the ROI max-pool that
 // reads them: identical output to roi_pool_c8 (no argmax), cost 2 x bin-width reads per bin instead of bin-height x bin-width
 int vmax_levels_for(int H);
 int build_vmax_tables(Act feat, float *d_tables, hipStream_t s);
-int roi_pool_c8_rmq(Act feat, const float *d_tables, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset,
-                    int end_adjust, float *d_x_c8, hipStream_t s, int roi_stride = 5, int Mp = 0);
+int roi_pool_c8_rmq(Act feat, const float *d_tables, const float *d_rois, int N, int PH, int PW, float scale, RoiRule rr, float *d_x_c8, hipStream_t s, int roi_stride = 5, int Mp = 0);
 // The same on PIXEL-MAJOR tables (levels 0 .. vmax_levels_for(H), pixel_major_elems(feat) floats each; level 0 = the map): coalesced
 // 1-KiB wave loads; `normalize` fuses nn.Normalize(2)'s sum of squares into the pooling launch and applies x * (mul / norm),
 // otherwise nn.MulConstant(mul).  Pooled values bit-identical to roi_pool_c8 / roi_pool_c8_rmq.
 int build_vmax_tables_pm(Act feat, float *d_tables, hipStream_t s);
 // d_scale_out (normalize only, [Mp]): write the per-ROI scale mul / norm there and leave the pooled matrix unscaled (the consumer applies it).
-int roi_pool_pm_rmq(Act feat, const float *d_tables_pm, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset,
-                    int end_adjust, float *d_x_c8, hipStream_t s, int roi_stride, int Mp, int normalize, float mul, float *d_scale_out = nullptr);
+int roi_pool_pm_rmq(Act feat, const float *d_tables_pm, const float *d_rois, int N, int PH, int PW, float scale, RoiRule rr, float *d_x_c8, hipStream_t s, int roi_stride, int Mp, int normalize, float mul, float *d_scale_out = nullptr);
 // in-place x * (mul / sqrt(sum x^2 + 1e-10)) per ROI over n_records 8-float records of a C8 matrix
 int l2norm_scale_c8(float *d_x_c8, int n_records, int Mp, int N, float mul, hipStream_t s);
 int mul_const_c8(float *d_x_c8, int n_records, int Mp, int N, float mul, hipStream_t s);  // nn.MulConstant on the same layout

@@ -1737,7 +1737,7 @@ __global__ void maxpool2x2_nchw_kernel(const float *__restrict__ in, size_t BC, 
 // (cb, bin, roi) half-record; roi fastest so a wave writes 1 KiB contiguous.
 __global__ __launch_bounds__(256) void roi_pool_c8_kernel(const float *__restrict__ feat, int C, int H, int W, int Hp, int Wp,
                                                           const float *__restrict__ rois, int roi_stride, int N, int PH, int PW,
-                                                          float scale, float coord_offset, int end_adjust, float *__restrict__ xc8,
+                                                          float scale, RoiRule rr, float *__restrict__ xc8,
                                                           int Mp, int32_t *__restrict__ argmax) {
   const int Cb = (C + 7) / 8, PP = PH * PW;
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1748,16 +1748,8 @@ __global__ __launch_bounds__(256) void roi_pool_c8_kernel(const float *__restric
   int bin = (int)(r % PP); int cb = (int)(r / PP);
   int ph = bin / PW, pw = bin - ph * PW;
   const float *ro = rois + (size_t)roi_stride * n;
-  int sw = (int)roundf((ro[1] - coord_offset) * scale);
-  int sh = (int)roundf((ro[2] - coord_offset) * scale);
-  int ew = (int)roundf((ro[3] - coord_offset) * scale) + end_adjust;
-  int eh = (int)roundf((ro[4] - coord_offset) * scale) + end_adjust;
-  int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
-  float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
-  int hs = (int)floorf((float)ph * bh) + sh, he = (int)ceilf((float)(ph + 1) * bh) + sh;
-  int ws = (int)floorf((float)pw * bw) + sw, we = (int)ceilf((float)(pw + 1) * bw) + sw;
-  hs = min(max(hs, 0), H); he = min(max(he, 0), H);
-  ws = min(max(ws, 0), W); we = min(max(we, 0), W);
+  int hs, he, ws, we;
+  roi_bin_bounds(ro, scale, rr, H, W, PH, PW, ph, pw, hs, he, ws, we);
   bool empty = (he <= hs) || (we <= ws);
   f32x4 m = empty ? f32x4{0, 0, 0, 0} : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
   int mi[4] = {-1, -1, -1, -1};
@@ -1905,8 +1897,7 @@ int build_vmax_tables(Act feat, float *d_tables, hipStream_t s) {
 
 __global__ __launch_bounds__(256) void roi_pool_c8_rmq_kernel(const float *__restrict__ feat, const float *__restrict__ tables, size_t level_elems,
                                                               int C, int H, int W, int Hp, int Wp, const float *__restrict__ rois,
-                                                              int roi_stride, int N, int PH, int PW, float scale, float coord_offset,
-                                                              int end_adjust, float *__restrict__ xc8, int Mp) {
+                                                              int roi_stride, int N, int PH, int PW, float scale, RoiRule rr, float *__restrict__ xc8, int Mp) {
   const int Cb = (C + 7) / 8, PP = PH * PW;
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)Cb * PP * N * 2;
@@ -1916,16 +1907,8 @@ __global__ __launch_bounds__(256) void roi_pool_c8_rmq_kernel(const float *__res
   int bin = (int)(r % PP); int cb = (int)(r / PP);
   int ph = bin / PW, pw = bin - ph * PW;
   const float *ro = rois + (size_t)roi_stride * n;
-  int sw = (int)roundf((ro[1] - coord_offset) * scale);
-  int sh = (int)roundf((ro[2] - coord_offset) * scale);
-  int ew = (int)roundf((ro[3] - coord_offset) * scale) + end_adjust;
-  int eh = (int)roundf((ro[4] - coord_offset) * scale) + end_adjust;
-  int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
-  float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
-  int hs = (int)floorf((float)ph * bh) + sh, he = (int)ceilf((float)(ph + 1) * bh) + sh;
-  int ws = (int)floorf((float)pw * bw) + sw, we = (int)ceilf((float)(pw + 1) * bw) + sw;
-  hs = min(max(hs, 0), H); he = min(max(he, 0), H);
-  ws = min(max(ws, 0), W); we = min(max(we, 0), W);
+  int hs, he, ws, we;
+  roi_bin_bounds(ro, scale, rr, H, W, PH, PW, ph, pw, hs, he, ws, we);
   const bool empty = (he <= hs) || (we <= ws);
   f32x4 m = empty ? f32x4{0, 0, 0, 0} : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
   if (!empty) {
@@ -1953,12 +1936,11 @@ __global__ __launch_bounds__(256) void roi_pool_c8_rmq_kernel(const float *__res
   *reinterpret_cast<f32x4 *>(xc8 + (((size_t)cb * PP + bin) * Mp + n) * 8 + h * 4) = m;
 }
 
-int roi_pool_c8_rmq(Act feat, const float *d_tables, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset,
-                    int end_adjust, float *d_x_c8, hipStream_t s, int roi_stride, int Mp) {
+int roi_pool_c8_rmq(Act feat, const float *d_tables, const float *d_rois, int N, int PH, int PW, float scale, RoiRule rr, float *d_x_c8, hipStream_t s, int roi_stride, int Mp) {
   MPN_CHECK_ARG(feat.p && d_tables && d_rois && d_x_c8 && N > 0 && PH > 0 && PW > 0);
   size_t total = (size_t)feat.Cb() * PH * PW * N * 2;
   hipLaunchKernelGGL(roi_pool_c8_rmq_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, feat.p, d_tables, feat.elems(), feat.C, feat.H,
-                     feat.W, feat.Hp, feat.Wp, d_rois, roi_stride, N, PH, PW, scale, coord_offset, end_adjust, d_x_c8, Mp > 0 ? Mp : lin_mp(N));
+                     feat.W, feat.Hp, feat.Wp, d_rois, roi_stride, N, PH, PW, scale, rr, d_x_c8, Mp > 0 ? Mp : lin_mp(N));
   MPN_CHECK_LAUNCH();
   return MPN_OK;
 }
@@ -1983,8 +1965,7 @@ __global__ void c8p_to_pixel_major_kernel(const float *__restrict__ in, int Cb, 
 
 template <int ABL>  // ABL: timing experiments (debug flavour): 1 no feature loads, 2 no stores, 4 no ROI decode (fixed 3x3 bin)
 __global__ __launch_bounds__(256) void roi_pool_pm_kernel(const float *__restrict__ pm, int Cb, int H, int W, const float *__restrict__ rois,
-                                                          int roi_stride, int N, int PH, int PW, float scale, float coord_offset,
-                                                          int end_adjust, float *__restrict__ xc8, int Mp) {
+                                                          int roi_stride, int N, int PH, int PW, float scale, RoiRule rr, float *__restrict__ xc8, int Mp) {
   __shared__ f32x4 stage[4][64];   // [roi of the quad][lane] = 4 channels
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1995,16 +1976,8 @@ __global__ __launch_bounds__(256) void roi_pool_pm_kernel(const float *__restric
   f32x4 m = f32x4{0, 0, 0, 0};
   if (n < N) {
     const float *ro = rois + (size_t)roi_stride * n;
-    const int sw = (int)roundf((ro[1] - coord_offset) * scale);
-    const int sh = (int)roundf((ro[2] - coord_offset) * scale);
-    const int ew = (int)roundf((ro[3] - coord_offset) * scale) + end_adjust;
-    const int eh = (int)roundf((ro[4] - coord_offset) * scale) + end_adjust;
-    const int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
-    const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
-    int hs = (int)floorf((float)ph * bh) + sh, he = (int)ceilf((float)(ph + 1) * bh) + sh;
-    int ws = (int)floorf((float)pw * bw) + sw, we = (int)ceilf((float)(pw + 1) * bw) + sw;
-    hs = min(max(hs, 0), H); he = min(max(he, 0), H);
-    ws = min(max(ws, 0), W); we = min(max(we, 0), W);
+    int hs, he, ws, we;
+    roi_bin_bounds(ro, scale, rr, H, W, PH, PW, ph, pw, hs, he, ws, we);
     hs = __builtin_amdgcn_readfirstlane(hs); he = __builtin_amdgcn_readfirstlane(he);
     ws = __builtin_amdgcn_readfirstlane(ws); we = __builtin_amdgcn_readfirstlane(we);
     if constexpr ((ABL & 4) != 0) { hs = (n * 7 + ph) % (H - 3); he = hs + 3; ws = (n * 13 + pw) % (W - 3); we = ws + 3; }
@@ -2044,7 +2017,7 @@ int c8p_to_pixel_major(Act feat, float *d_pm, hipStream_t s) {
   return MPN_OK;
 }
 
-int roi_pool_pm(Act feat, const float *d_pm, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset, int end_adjust,
+int roi_pool_pm(Act feat, const float *d_pm, const float *d_rois, int N, int PH, int PW, float scale, RoiRule rr,
                 float *d_x_c8, hipStream_t s, int roi_stride, int Mp) {
   MPN_CHECK_ARG(d_pm && d_rois && d_x_c8 && N > 0 && PH > 0 && PW > 0);
   auto kern = roi_pool_pm_kernel<0>;
@@ -2059,7 +2032,7 @@ int roi_pool_pm(Act feat, const float *d_pm, const float *d_rois, int N, int PH,
   }
 #endif
   hipLaunchKernelGGL(kern, dim3((unsigned)cdiv(N, 4), (unsigned)(PH * PW), (unsigned)cdiv(feat.Cb(), 32)), dim3(256), 0, s, d_pm,
-                     feat.Cb(), feat.H, feat.W, d_rois, roi_stride, N, PH, PW, scale, coord_offset, end_adjust, d_x_c8, Mp > 0 ? Mp : lin_mp(N));
+                     feat.Cb(), feat.H, feat.W, d_rois, roi_stride, N, PH, PW, scale, rr, d_x_c8, Mp > 0 ? Mp : lin_mp(N));
   MPN_CHECK_LAUNCH();
   return MPN_OK;
 }
@@ -2115,7 +2088,7 @@ __global__ __launch_bounds__(256) void l2norm_finish_rows_kernel(const float *__
 template <bool SS>
 __global__ __launch_bounds__(256) void roi_pool_pm_rmq_kernel(const float *__restrict__ tab, size_t level_elems, int Cb, int H, int W,
                                                               const float *__restrict__ rois, int roi_stride, int N, int PH, int PW, float scale,
-                                                              float coord_offset, int end_adjust, float *__restrict__ xc8, int Mp,
+                                                              RoiRule rr, float *__restrict__ xc8, int Mp,
                                                               float *__restrict__ ss_part) {
   __shared__ f32x4 stage[4][64];   // [roi of the quad][lane] = 4 channels
   const int lane = threadIdx.x & 63;
@@ -2127,16 +2100,8 @@ __global__ __launch_bounds__(256) void roi_pool_pm_rmq_kernel(const float *__res
   f32x4 m = f32x4{0, 0, 0, 0};
   if (n < N) {
     const float *ro = rois + (size_t)roi_stride * n;
-    const int sw = (int)roundf((ro[1] - coord_offset) * scale);
-    const int sh = (int)roundf((ro[2] - coord_offset) * scale);
-    const int ew = (int)roundf((ro[3] - coord_offset) * scale) + end_adjust;
-    const int eh = (int)roundf((ro[4] - coord_offset) * scale) + end_adjust;
-    const int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
-    const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
-    int hs = (int)floorf((float)ph * bh) + sh, he = (int)ceilf((float)(ph + 1) * bh) + sh;
-    int ws = (int)floorf((float)pw * bw) + sw, we = (int)ceilf((float)(pw + 1) * bw) + sw;
-    hs = min(max(hs, 0), H); he = min(max(he, 0), H);
-    ws = min(max(ws, 0), W); we = min(max(we, 0), W);
+    int hs, he, ws, we;
+    roi_bin_bounds(ro, scale, rr, H, W, PH, PW, ph, pw, hs, he, ws, we);
     hs = __builtin_amdgcn_readfirstlane(hs); he = __builtin_amdgcn_readfirstlane(he);
     ws = __builtin_amdgcn_readfirstlane(ws); we = __builtin_amdgcn_readfirstlane(we);
     const int ch = cq * 256 + lane * 4;
@@ -2193,14 +2158,13 @@ __global__ __launch_bounds__(256) void l2norm_scale_rows_kernel(const float *__r
   if (lane == 0) scale[n] = n < N ? mul / sqrtf(ss + 1e-10f) : 0.0f;
 }
 
-int roi_pool_pm_rmq(Act feat, const float *d_tables_pm, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset,
-                    int end_adjust, float *d_x_c8, hipStream_t s, int roi_stride, int Mp, int normalize, float mul, float *d_scale_out) {
+int roi_pool_pm_rmq(Act feat, const float *d_tables_pm, const float *d_rois, int N, int PH, int PW, float scale, RoiRule rr, float *d_x_c8, hipStream_t s, int roi_stride, int Mp, int normalize, float mul, float *d_scale_out) {
   MPN_CHECK_ARG(feat.p && d_tables_pm && d_rois && d_x_c8 && N > 0 && PH > 0 && PW > 0);
   const int mp = Mp > 0 ? Mp : lin_mp(N), Cq = cdiv(feat.Cb(), 32), PP = PH * PW;
   const dim3 grid((unsigned)cdiv(N, 4), (unsigned)PP, (unsigned)Cq);
   if (!normalize) {
     hipLaunchKernelGGL(roi_pool_pm_rmq_kernel<false>, grid, dim3(256), 0, s, d_tables_pm, pixel_major_elems(feat), feat.Cb(), feat.H, feat.W, d_rois,
-                       roi_stride, N, PH, PW, scale, coord_offset, end_adjust, d_x_c8, mp, (float *)nullptr);
+                       roi_stride, N, PH, PW, scale, rr, d_x_c8, mp, (float *)nullptr);
     MPN_CHECK_LAUNCH();
     return mul_const_c8(d_x_c8, feat.Cb() * PP, mp, N, mul, s);
   }
@@ -2209,7 +2173,7 @@ int roi_pool_pm_rmq(Act feat, const float *d_tables_pm, const float *d_rois, int
   { int rc_ws = scratch_get(SCR_L2NORM, ((size_t)G + 1) * N * sizeof(float), s, &ws); if (rc_ws) return rc_ws; }
   float *part = static_cast<float *>(ws), *nrm = part + (size_t)G * N;
   hipLaunchKernelGGL(roi_pool_pm_rmq_kernel<true>, grid, dim3(256), 0, s, d_tables_pm, pixel_major_elems(feat), feat.Cb(), feat.H, feat.W, d_rois,
-                     roi_stride, N, PH, PW, scale, coord_offset, end_adjust, d_x_c8, mp, part);
+                     roi_stride, N, PH, PW, scale, rr, d_x_c8, mp, part);
   MPN_CHECK_LAUNCH();
   if (d_scale_out) {  // the consumer GEMM applies the scale (linear_c8_rowscaled): the pooled matrix is left as pooled
     hipLaunchKernelGGL(l2norm_scale_rows_kernel, dim3(cdiv(mp, 4)), dim3(256), 0, s, part, G, N, mp, mul, d_scale_out);
@@ -2225,12 +2189,12 @@ int roi_pool_pm_rmq(Act feat, const float *d_tables_pm, const float *d_rois, int
 }
 
 
-int roi_pool_c8(Act feat, const float *d_rois, int N, int PH, int PW, float scale, float coord_offset, int end_adjust,
+int roi_pool_c8(Act feat, const float *d_rois, int N, int PH, int PW, float scale, RoiRule rr,
                 float *d_x_c8, int32_t *d_argmax, hipStream_t s, int roi_stride, int Mp) {
   MPN_CHECK_ARG(feat.p && d_rois && d_x_c8 && N > 0 && PH > 0 && PW > 0);
   size_t total = (size_t)feat.Cb() * PH * PW * N * 2;
   hipLaunchKernelGGL(roi_pool_c8_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, feat.p, feat.C, feat.H, feat.W, feat.Hp,
-                     feat.Wp, d_rois, roi_stride, N, PH, PW, scale, coord_offset, end_adjust, d_x_c8, Mp > 0 ? Mp : lin_mp(N), d_argmax);
+                     feat.Wp, d_rois, roi_stride, N, PH, PW, scale, rr, d_x_c8, Mp > 0 ? Mp : lin_mp(N), d_argmax);
   MPN_CHECK_LAUNCH();
   return MPN_OK;
 }
@@ -2329,10 +2293,10 @@ extern "C" int mpn_debug_bench_roipool(const float *h_rois, int N, int C, int H,
   hipEvent_t e0, e1;
   MPN_CHECK_HIP(hipEventCreate(&e0)); MPN_CHECK_HIP(hipEventCreate(&e1));
   int rc = MPN_OK;
-  for (int i = 0; i < 2 && rc == MPN_OK; ++i) rc = roi_pool_pm(feat, pm, rois, N, 7, 7, 1.0f / 16, 0.0f, 0, x, nullptr, 5, 0);
+  for (int i = 0; i < 2 && rc == MPN_OK; ++i) rc = roi_pool_pm(feat, pm, rois, N, 7, 7, 1.0f / 16, RoiRule{0.0f, 0, 0}, x, nullptr, 5, 0);
   MPN_CHECK_HIP(hipDeviceSynchronize());
   MPN_CHECK_HIP(hipEventRecord(e0, nullptr));
-  for (int i = 0; i < iters && rc == MPN_OK; ++i) rc = roi_pool_pm(feat, pm, rois, N, 7, 7, 1.0f / 16, 0.0f, 0, x, nullptr, 5, 0);
+  for (int i = 0; i < iters && rc == MPN_OK; ++i) rc = roi_pool_pm(feat, pm, rois, N, 7, 7, 1.0f / 16, RoiRule{0.0f, 0, 0}, x, nullptr, 5, 0);
   MPN_CHECK_HIP(hipEventRecord(e1, nullptr));
   MPN_CHECK_HIP(hipEventSynchronize(e1));
   float ms = 0.f;
@@ -2381,9 +2345,12 @@ __global__ void count_diff_kernel(const float *a, const float *b, size_t n, int 
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n && !(a[t] == b[t])) atomicAdd(cnt, 1);
 }
+static int g_dbg_roi_bins = 0;  // mpn_debug_set_roi_bins: the bin rule (MPN_ROI_BINS_*) of mpn_debug_roi_pool_rmq_mismatches
+extern "C" void mpn_debug_set_roi_bins(int v) { g_dbg_roi_bins = v; }
 extern "C" int mpn_debug_roi_pool_rmq_mismatches(const float *d_feat_nchw, int C, int H, int W, const float *d_rois, int roi_stride, int N,
                                                  int PH, int PW, float scale, int *n_mismatch) {
   MPN_CHECK_ARG(d_feat_nchw && d_rois && n_mismatch && C > 0 && H > 0 && W > 0 && N > 0);
+  const RoiRule rr{1.0f, 0, g_dbg_roi_bins};
   float *act = nullptr, *tab = nullptr, *o1 = nullptr, *o2 = nullptr;
   int *cnt = nullptr;
   const size_t ab = act_bytes(C, H, W);
@@ -2398,8 +2365,8 @@ extern "C" int mpn_debug_roi_pool_rmq_mismatches(const float *d_feat_nchw, int C
   Act a = make_act(act, C, H, W);
   int rc = nchw_to_c8p(d_feat_nchw, C, H, W, a, nullptr);
   if (rc == MPN_OK) rc = build_vmax_tables(a, tab, nullptr);
-  if (rc == MPN_OK) rc = roi_pool_c8(a, d_rois, N, PH, PW, scale, 1.0f, 0, o1, nullptr, nullptr, roi_stride, 0);
-  if (rc == MPN_OK) rc = roi_pool_c8_rmq(a, tab, d_rois, N, PH, PW, scale, 1.0f, 0, o2, nullptr, roi_stride, 0);
+  if (rc == MPN_OK) rc = roi_pool_c8(a, d_rois, N, PH, PW, scale, rr, o1, nullptr, nullptr, roi_stride, 0);
+  if (rc == MPN_OK) rc = roi_pool_c8_rmq(a, tab, d_rois, N, PH, PW, scale, rr, o2, nullptr, roi_stride, 0);
   if (rc == MPN_OK) {
     hipLaunchKernelGGL(count_diff_kernel, dim3((unsigned)cdiv_sz(oe, 256)), dim3(256), 0, nullptr, o1, o2, oe, cnt);
     MPN_CHECK_LAUNCH();
@@ -2410,7 +2377,7 @@ extern "C" int mpn_debug_roi_pool_rmq_mismatches(const float *d_feat_nchw, int C
     MPN_CHECK_HIP(hipMalloc(&tabpm, pixel_major_elems(a) * sizeof(float) * (L + 1)));
     MPN_CHECK_HIP(hipMemset(o2, 0, oe * 4));
     rc = build_vmax_tables_pm(a, tabpm, nullptr);
-    if (rc == MPN_OK) rc = roi_pool_pm_rmq(a, tabpm, d_rois, N, PH, PW, scale, 1.0f, 0, o2, nullptr, roi_stride, 0, 0, 1.0f, nullptr);
+    if (rc == MPN_OK) rc = roi_pool_pm_rmq(a, tabpm, d_rois, N, PH, PW, scale, rr, o2, nullptr, roi_stride, 0, 0, 1.0f, nullptr);
     if (rc == MPN_OK) {
       hipLaunchKernelGGL(count_diff_kernel, dim3((unsigned)cdiv_sz(oe, 256)), dim3(256), 0, nullptr, o1, o2, oe, cnt);
       MPN_CHECK_LAUNCH();

@@ -104,4 +104,38 @@ __device__ __forceinline__ float iou_plus1(float ax1, float ay1, float ax2, floa
   return (w <= 0.0f || h <= 0.0f) ? 0.0f : iou;
 }
 
+// ---- inn.ROIPooling's window and bins, both conventions (include/mpn.h: MPN_ROI_BINS_*; the oracle's orc_roi_pool) -------------------
+// bins = 0, the CUDA kernel's rule (Fast R-CNN):  start = round((x1 - off) * scale), end = round((x2 - off) * scale) + end_adjust, window forced
+//   >= 1 x 1, bin p = [floor(p * size / P), ceil((p + 1) * size / P)) with the fp32 bin size, offset by the start, THEN clipped to the map
+//   (a bin that falls outside is empty -> 0).
+// bins = 1, the module's CPU branch (crop + nn.SpatialAdaptiveMaxPooling; alexnet.lua:23 / vgg.lua:28 with float tensors): the window's
+//   corners are rounded in the Lua order (x - off) * scale + 1 (1-based map coordinates), CLIPPED to the map FIRST (the reference clips the
+//   upper side with cmin and indexes the tensor with the lower side, which must therefore be >= 1: we clip both), and the bins divide the
+//   clipped crop: [floor(p * size / P), ceil((p + 1) * size / P)) in integer products — never empty.  The two differ on windows whose
+//   rounded corners leave the map (the foveal regions, border boxes) and, once in a thousand, by one cell (fp32 bin size rounding).  All fp32, no contraction (-ffp-contract=off).
+struct RoiRule { float coord_offset; int end_adjust; int bins; };
+__device__ __forceinline__ void roi_bin_bounds(const float *__restrict__ ro, float scale, RoiRule rr, int H, int W, int PH, int PW, int ph, int pw,
+                                               int &hs, int &he, int &ws, int &we) {
+  if (rr.bins == 0) {
+    const int sw = (int)roundf((ro[1] - rr.coord_offset) * scale);
+    const int sh = (int)roundf((ro[2] - rr.coord_offset) * scale);
+    const int ew = (int)roundf((ro[3] - rr.coord_offset) * scale) + rr.end_adjust;
+    const int eh = (int)roundf((ro[4] - rr.coord_offset) * scale) + rr.end_adjust;
+    const int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
+    const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+    hs = (int)floorf((float)ph * bh) + sh; he = (int)ceilf((float)(ph + 1) * bh) + sh;
+    ws = (int)floorf((float)pw * bw) + sw; we = (int)ceilf((float)(pw + 1) * bw) + sw;
+    hs = min(max(hs, 0), H); he = min(max(he, 0), H);
+    ws = min(max(ws, 0), W); we = min(max(we, 0), W);
+  } else {
+    int x1 = (int)roundf((ro[1] - rr.coord_offset) * scale + 1.0f) - 1, y1 = (int)roundf((ro[2] - rr.coord_offset) * scale + 1.0f) - 1;
+    int x2 = (int)roundf((ro[3] - rr.coord_offset) * scale + 1.0f) - 1 + rr.end_adjust, y2 = (int)roundf((ro[4] - rr.coord_offset) * scale + 1.0f) - 1 + rr.end_adjust;
+    x1 = min(max(x1, 0), W - 1); x2 = min(max(x2, 0), W - 1);
+    y1 = min(max(y1, 0), H - 1); y2 = min(max(y2, 0), H - 1);
+    const int cw = max(x2 - x1 + 1, 1), ch = max(y2 - y1 + 1, 1);
+    hs = (int)floorf((float)(ph * ch) / (float)PH) + y1; he = (int)ceilf((float)((ph + 1) * ch) / (float)PH) + y1;
+    ws = (int)floorf((float)(pw * cw) / (float)PW) + x1; we = (int)ceilf((float)((pw + 1) * cw) / (float)PW) + x1;
+  }
+}
+
 }  // namespace mpn

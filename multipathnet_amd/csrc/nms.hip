@@ -1193,7 +1193,7 @@ __device__ __forceinline__ int fused_replay_select(const unsigned long long *LM,
 
 __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict__ scored, const int *__restrict__ counts, int m_stride, float thr,
                                                          float *__restrict__ keep, int *__restrict__ keep_idx, int *__restrict__ n_keep,
-                                                         unsigned long long *gmask, unsigned int *cnt, int lw, int mask_bytes, int replay_on) {
+                                                         unsigned long long *gmask, unsigned int *cnt, int lw, int mask_bytes, int replay_on, int fence) {
   // lw = log2 of the mask's row pitch in 64-bit words (a power of two >= ceil(m_stride / 64)), in HBM and in LDS; blockDim.x = the sort
   // width = the power of two >= max(64, m_stride)
   typedef unsigned long long u64;
@@ -1331,13 +1331,17 @@ __global__ __launch_bounds__(1024) void nms_fused_kernel(const float *__restrict
   }
   FUSED_STAMP(4);
   // ---- 3. the last block of the class to arrive runs the selection.  The mask words were stored and are loaded with device-scope
-  // (write-through / cache-bypassing) accesses; every wave waits for its stores to complete, the barrier collects the waves, thread 0
-  // counts the block in.  (A device-scope release fence instead — buffer_wbl2 — measured 20-35 us per block at 1000 rows, and queues
-  // behind the other blocks' write-backs.)
+  // (write-through / cache-bypassing) accesses; every wave waits for its stores to complete, the barrier collects the waves, and thread 0
+  // counts the block in with ONE acquire-release device-scope atomic: the barrier orders the other waves' completed stores
+  // before thread 0's release, the last block's acquire orders the counter's value before the barrier that lets its waves read the mask —
+  // a formally synchronised hand-off, not one that leans on gfx950's write-through behaviour.  The release costs one buffer_wbl2 per
+  // BLOCK (round 5 measured one per WAVE — a fence in every thread — at 20-35 us per block at 1000 rows, queueing behind the other
+  // blocks' write-backs; per block it is measured in profiles/r06_nms_fence.txt).  fence == 0 (debug flavour only): round 5's relaxed form.
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (tid == 0) {
-    const unsigned old = __hip_atomic_fetch_add(&cnt[cls], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned old = fence ? __hip_atomic_fetch_add(&cnt[cls], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+                               : __hip_atomic_fetch_add(&cnt[cls], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = old == (unsigned)(S - 1);
     if (last) __hip_atomic_store(&cnt[cls], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
     sh_last = last;
@@ -1533,12 +1537,14 @@ MPN_KNOB(unsigned long long *, g_nms_trace, nullptr);
 MPN_KNOB(int, g_nms_guard_limit, 0);  // test hook (mpn_debug_set_nms_guard_limit): bound of the replaying scan's progress loops (0 = the real one)
 MPN_KNOB(int, g_nms_fused_replay, 1);  // test hook: 0 = classes with a few tied pairs take the fused kernel's pick-by-pick path instead of the lazy replay; 2 = the replay gives up half way (its progress bounds cannot be reached otherwise) and the class is redone pick by pick
 MPN_KNOB(int, g_nms_fused_slices, 0);  // test / timing hook: mask slices per class of the fused kernel (0 = fill the GPU once)
+MPN_KNOB(int, g_nms_fused_fence, 1);  // timing hook (mpn_debug_set_nms_fused_fence): 0 = the fused kernel's block hand-off with relaxed atomics (round 5's form)
 MPN_KNOB(int, g_nms_fused, 1);  // test hook (mpn_debug_set_nms_fused): 0 = the launch chain at every size; 2 = the fused kernel for every table of <= kFusedMax rows
 #ifdef MPN_DEBUG_HOOKS
 extern "C" void mpn_debug_set_nms_force_exact(int v) { g_nms_force_exact = v; }
 extern "C" void mpn_debug_set_nms_trace(void *p) { g_nms_trace = static_cast<unsigned long long *>(p); }
 extern "C" void mpn_debug_set_nms_guard_limit(int v) { g_nms_guard_limit = v; }
 extern "C" void mpn_debug_set_nms_fused(int v) { g_nms_fused = v; }
+extern "C" void mpn_debug_set_nms_fused_fence(int v) { g_nms_fused_fence = v; }
 extern "C" void mpn_debug_set_nms_fused_slices(int v) { g_nms_fused_slices = v; }
 extern "C" void mpn_debug_set_nms_fused_replay(int v) { g_nms_fused_replay = v; }
 extern "C" int mpn_debug_get_nms_fused_wall(unsigned long long *h_out, int n_blocks) {  // [n_blocks][2]: entry, exit (10 ns ticks)
@@ -1617,8 +1623,14 @@ static int nms_batched_core(const float *d_scored, const int *d_counts, int n_cl
     if (rc_ws) return rc_ws;
     { int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(nms_fused_kernel), 160 * 1024 - 64); if (rc_attr) return rc_attr; }
     hipLaunchKernelGGL(nms_fused_kernel, dim3(S, n_cls), dim3(nt), lds, st, d_scored, d_counts, m_stride, thr, d_keep, d_keep_idx, d_n_keep,
-                       static_cast<unsigned long long *>(ws), static_cast<unsigned int *>(wc), lw, (int)mask_bytes, (int)g_nms_fused_replay);
-    MPN_CHECK_LAUNCH();
+                       static_cast<unsigned long long *>(ws), static_cast<unsigned int *>(wc), lw, (int)mask_bytes, (int)g_nms_fused_replay, (int)g_nms_fused_fence);
+    {
+      const hipError_t e_launch = hipGetLastError();
+      if (e_launch != hipSuccess) {  // the per-class arrival counters reset themselves only when a launch runs to its end: never leave them in doubt
+        (void)hipMemsetAsync(wc, 0, (size_t)n_cls * sizeof(unsigned), st);
+        MPN_CHECK_HIP(e_launch);
+      }
+    }
     return MPN_OK;
   }
   // ---- scratch for the fast path (library-owned, grown on demand, one stream at a time)
@@ -1825,14 +1837,33 @@ extern "C" int mpn_nms(const float *d_scored, int m, float thr, float *d_keep, i
 // host link (6 KB in, <= 7 KB out), so a call is memcpy + one launch + one stream sync + memcpy.  The buffer (45 KB) is allocated once per
 // host thread and deliberately never freed: the HIP runtime may already be gone when thread-local destructors run at process exit.
 namespace {
-struct HostNmsStage { void *pin = nullptr; void *dptr = nullptr; int device = -1; };
+struct HostNmsStage { void *pin = nullptr; void *dptr = nullptr; int device = -1; hipStream_t stream = nullptr; int stream_device = -1; };
 thread_local HostNmsStage t_host_nms;
 constexpr size_t kHostNmsBytes = (size_t)kFusedMax * (5 + 5 + 1) * 4 + 256;
 }  // namespace
 
+// The host entries run on a stream of the CALLING THREAD's own: library scratch is kept per (device, stream), so two host threads
+// on one device — the reference's worker threads all call utils.nms (Tester_FRCNN.lua:117) — no longer share the NULL stream's NMS scratch,
+// whose regrow (sync + free + malloc) by one thread could pull the buffer from under the other thread's launch.  Like the pinned stage, the
+// stream is created once per thread and device and never destroyed (the runtime may be gone when thread-local destructors run).
+static int host_nms_stream(hipStream_t *out) {
+  int dev = 0;
+  MPN_CHECK_HIP(hipGetDevice(&dev));
+  HostNmsStage &t = t_host_nms;
+  if (!t.stream || t.stream_device != dev) {
+    hipStream_t s = nullptr;
+    MPN_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    t.stream = s; t.stream_device = dev;
+  }
+  *out = t.stream;
+  return MPN_OK;
+}
+
 static int nms_host_small(const float *h_scored, int m, float thr, float *h_keep, int *h_keep_idx, int *n_keep) {
   int dev = 0;
   MPN_CHECK_HIP(hipGetDevice(&dev));
+  hipStream_t ts = nullptr;
+  { int rc_s = host_nms_stream(&ts); if (rc_s) return rc_s; }
   HostNmsStage &t = t_host_nms;
   if (!t.pin || t.device != dev) {  // (a thread that switches devices re-stages; the old buffer stays with its device)
     void *p = nullptr, *d = nullptr;
@@ -1846,9 +1877,9 @@ static int nms_host_small(const float *h_scored, int m, float thr, float *h_keep
   auto dp = [&](void *h) { return static_cast<void *>(static_cast<char *>(h) + delta); };
   memcpy(in, h_scored, sizeof(float) * 5 * (size_t)m);
   *n = 0;
-  int rc = mpn_nms_batched(static_cast<float *>(dp(in)), nullptr, 1, m, thr, static_cast<float *>(dp(out)), static_cast<int *>(dp(idx)), static_cast<int *>(dp(n)), nullptr);
+  int rc = mpn_nms_batched(static_cast<float *>(dp(in)), nullptr, 1, m, thr, static_cast<float *>(dp(out)), static_cast<int *>(dp(idx)), static_cast<int *>(dp(n)), ts);
   if (rc) return rc;
-  MPN_CHECK_HIP(hipStreamSynchronize(nullptr));
+  MPN_CHECK_HIP(hipStreamSynchronize(ts));
   const int k = *n;
   if (k < 0 || k > m) { set_error("mpn_nms_host: kept count %d out of range", k); return MPN_EHIP; }
   *n_keep = k;
@@ -1866,6 +1897,8 @@ extern "C" int mpn_nms_host(const float *h_scored, int m, float thr, float *h_ke
   float *d_in = nullptr, *d_keep = nullptr;
   int *d_idx = nullptr, *d_n = nullptr;
   size_t bytes = sizeof(float) * 5 * (size_t)m;
+  hipStream_t ts = nullptr;
+  { int rc_s = host_nms_stream(&ts); if (rc_s) return rc_s; }
   MPN_CHECK_HIP(hipMalloc(&d_in, bytes * 2 + sizeof(int) * ((size_t)m + 1)));
   d_keep = d_in + 5 * (size_t)m;
   d_idx = reinterpret_cast<int *>(d_keep + 5 * (size_t)m);
@@ -1873,8 +1906,9 @@ extern "C" int mpn_nms_host(const float *h_scored, int m, float thr, float *h_ke
   int rc = MPN_OK;
   hipError_t e = hipMemcpy(d_in, h_scored, bytes, hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    rc = mpn_nms(d_in, m, thr, d_keep, d_idx, d_n, nullptr);
-    if (rc == MPN_OK) e = hipMemcpy(n_keep, d_n, sizeof(int), hipMemcpyDeviceToHost);
+    rc = mpn_nms(d_in, m, thr, d_keep, d_idx, d_n, ts);   // (the blocking hipMemcpy above has completed; the thread's stream does not wait on the NULL stream)
+    if (rc == MPN_OK) e = hipStreamSynchronize(ts);
+    if (rc == MPN_OK && e == hipSuccess) e = hipMemcpy(n_keep, d_n, sizeof(int), hipMemcpyDeviceToHost);
     if (rc == MPN_OK && e == hipSuccess && *n_keep > 0) {
       e = hipMemcpy(h_keep, d_keep, sizeof(float) * 5 * (size_t)*n_keep, hipMemcpyDeviceToHost);
       if (e == hipSuccess && h_keep_idx) e = hipMemcpy(h_keep_idx, d_idx, sizeof(int) * (size_t)*n_keep, hipMemcpyDeviceToHost);

@@ -309,7 +309,7 @@ struct mpn_frcnn {
       return std::tie(kind, a, b, c, d, i0, i1, i2, i3) < std::tie(o.kind, o.a, o.b, o.c, o.d, o.i0, o.i1, o.i2, o.i3);
     }
   };
-  struct GraphEntry { hipGraphExec_t exec = nullptr; unsigned long long gen = 0, last_use = 0; bool failed = false; int seen = 0; };
+  struct GraphEntry { hipGraphExec_t exec = nullptr; unsigned long long gen = 0, last_use = 0; bool failed = false; int seen = 0; hipStream_t last_stream = nullptr; bool launched = false; };
   unsigned long long graph_clock = 0;
   std::map<GraphKey, GraphEntry> graphs;
   // the last few caller-pointer keys seen ONCE, per segment kind (a small ring: the pipelined forms alternate two output buffer sets, a host
@@ -447,6 +447,7 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
   p->cfg.pool_after = p->pool_after.data();
   int rc = MPN_OK;
 #define TRY(x) do { rc = (x); if (rc != MPN_OK) { mpn_frcnn_destroy(p); return rc; } } while (0)
+  TRY((cfg->roi_bin_rule == MPN_ROI_BINS_CAFFE || cfg->roi_bin_rule == MPN_ROI_BINS_ADAPTIVE) ? MPN_OK : (set_error("mpn_frcnn_config.roi_bin_rule: %d is not an MPN_ROI_BINS_* value", cfg->roi_bin_rule), MPN_EINVAL));
   // ---- trunk buffers + packed weights
   int h = cfg->max_h, w = cfg->max_w, cin = 3;
   size_t b = act_bytes(3, h, w);
@@ -488,6 +489,7 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
     if (rw) TRY(resnet_build(rw, cfg->max_h, cfg->max_w, cfg->max_rois, cfg->pooled_h, &p->rn));
     else TRY(graph_build(gw, cfg->max_h, cfg->max_w, cfg->max_rois, cfg->pooled_h, &p->rn));
     p->feat_c = resnet_feat_channels(p->rn);
+    resnet_set_roi_bins(p->rn, cfg->roi_bin_rule);
   }
   // ---- head
   const int PP = cfg->pooled_h * cfg->pooled_w, C = cfg->n_classes, F = graph_net ? resnet_out_channels(p->rn) : cfg->fc_dim;
@@ -762,7 +764,7 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
       { ProfScope ps(p, MPN_PROF_ROIPOOL, ps_stream);
         if (pm) {
           float *sc_out = fold_scale ? p->mix_scale + ((size_t)par * 3 + grs.n_seg) * p->Mp : nullptr;
-          rcl = roi_pool_pm_rmq(maps[m], p->vmax_tab[m], reg, N, c.pooled_h, c.pooled_w, scales[m], 1.0f, 0, dst, ps_stream, 20, Mp, p->conv345_norm ? 1 : 0,
+          rcl = roi_pool_pm_rmq(maps[m], p->vmax_tab[m], reg, N, c.pooled_h, c.pooled_w, scales[m], RoiRule{1.0f, 0, c.roi_bin_rule}, dst, ps_stream, 20, Mp, p->conv345_norm ? 1 : 0,
                                 p->conv345_norm ? 1000.0f : kConv345Factor[m], sc_out);
           if (fold_scale) {
             grs.scale[grs.n_seg] = sc_out;
@@ -770,7 +772,7 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
             ++grs.n_seg;
           }
         } else {
-          rcl = roi_pool_c8_rmq(maps[m], p->vmax_tab[m], reg, N, c.pooled_h, c.pooled_w, scales[m], 1.0f, 0, dst, ps_stream, 20, Mp);
+          rcl = roi_pool_c8_rmq(maps[m], p->vmax_tab[m], reg, N, c.pooled_h, c.pooled_w, scales[m], RoiRule{1.0f, 0, c.roi_bin_rule}, dst, ps_stream, 20, Mp);
           if (rcl == MPN_OK) rcl = p->conv345_norm ? l2norm_scale_c8(dst, maps[m].Cb() * PP, Mp, N, 1000.0f, ps_stream)
                                                    : mul_const_c8(dst, maps[m].Cb() * PP, Mp, N, kConv345Factor[m], ps_stream);
         } }
@@ -915,9 +917,9 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const 
   { ProfScope ps(p, MPN_PROF_ROIPOOL, s);
     if (p->feat_pm && g_roi_pool_pm) {
       if (!p->feat_pm_valid) { rc = c8p_to_pixel_major(feat, p->feat_pm, s); if (rc) return rc; p->feat_pm_valid = true; }  // once per trunk run
-      rc = roi_pool_pm(feat, p->feat_pm, p->rois, N, c.pooled_h, c.pooled_w, c.spatial_scale, 1.0f, 0, p->x6, s);
+      rc = roi_pool_pm(feat, p->feat_pm, p->rois, N, c.pooled_h, c.pooled_w, c.spatial_scale, RoiRule{1.0f, 0, c.roi_bin_rule}, p->x6, s);
     } else {
-      rc = roi_pool_c8(feat, p->rois, N, c.pooled_h, c.pooled_w, c.spatial_scale, 1.0f, 0, p->x6, nullptr, s);
+      rc = roi_pool_c8(feat, p->rois, N, c.pooled_h, c.pooled_w, c.spatial_scale, RoiRule{1.0f, 0, c.roi_bin_rule}, p->x6, nullptr, s);
     } }
   if (rc) return rc;
   { ProfScope ps(p, MPN_PROF_FC6, s); rc = linear_c8(p->x6, N, p->K6, p->w6, p->b6, F, 1, p->y6, nullptr, s, 0, nullptr, 1); }
@@ -1010,6 +1012,9 @@ static int run_segment(mpn_frcnn *p, int kind, const mpn_frcnn::GraphKey &key, c
       if (p->graphs.size() >= kMaxGraphs) {  // all live: evict the least recently used one
         auto lru = p->graphs.begin();
         for (auto j = p->graphs.begin(); j != p->graphs.end(); ++j) if (j->second.last_use < lru->second.last_use) lru = j;
+        // its last replay may still be in flight (the pipelined forms put no bound on how far the host runs ahead): wait for the stream it
+        // was launched on before the executable goes away.  Evictions are rare — a host must rotate > 64 live keys to get here.
+        if (lru->second.launched) (void)hipStreamSynchronize(lru->second.last_stream);
         (void)hipGraphExecDestroy(lru->second.exec);
         p->graphs.erase(lru);
       }
@@ -1019,9 +1024,13 @@ static int run_segment(mpn_frcnn *p, int kind, const mpn_frcnn::GraphKey &key, c
   }
   mpn_frcnn::GraphEntry &e = it->second;
   e.last_use = ++p->graph_clock;
-  if (e.exec && e.gen != alloc_generation()) { (void)hipGraphExecDestroy(e.exec); e.exec = nullptr; }  // a library buffer was replaced since
+  if (e.exec && e.gen != alloc_generation()) {  // a library buffer was replaced since (the regrow synchronised its stream; a replay on another stream may still run)
+    if (e.launched && e.last_stream != s) (void)hipStreamSynchronize(e.last_stream);
+    (void)hipGraphExecDestroy(e.exec); e.exec = nullptr;
+  }
   if (e.exec && same_shape) {
     MPN_CHECK_HIP(hipGraphLaunch(e.exec, s));
+    e.last_stream = s; e.launched = true;
     ++p->graph_replays;
     return MPN_OK;
   }
@@ -1039,6 +1048,7 @@ static int run_segment(mpn_frcnn *p, int kind, const mpn_frcnn::GraphKey &key, c
     ++p->graph_captures;
     memcpy(last, shape, sizeof(shape));
     MPN_CHECK_HIP(hipGraphLaunch(e.exec, s));
+    e.last_stream = s; e.launched = true;
     return MPN_OK;
   }
   if (g) (void)hipGraphDestroy(g);

@@ -21,6 +21,7 @@ int resnet_build(const mpn_resnet_weights *rw, int max_h, int max_w, int max_roi
 // the same object driven by two op lists (branching graphs: Inception-v3)
 int graph_build(const mpn_graph_weights *gw, int max_h, int max_w, int max_rois, int pooled, ResNetGraph **out);
 void resnet_free(ResNetGraph *g);
+void resnet_set_roi_bins(ResNetGraph *g, int bin_rule);  // MPN_ROI_BINS_* of every ROI pooling of the graph (default: the CUDA branch's rule)
 int resnet_feat_channels(const ResNetGraph *g);   // layer3 output channels (what the ROI pool reads)
 int resnet_out_channels(const ResNetGraph *g);    // layer4 output channels (what the cls / bbox heads read)
 // image [3,H,W] fp32 -> transformed -> conv1 -> pool -> layer1..3; the feature map is cached in the graph

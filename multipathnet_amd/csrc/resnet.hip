@@ -262,7 +262,7 @@ __global__ void image_transform_c8i_kernel(const float *__restrict__ in, int H, 
 // inn.ROIPooling on a one-map C8I feature -> [N][Cb][PH][PW][8] (the batch the per-ROI head convolves); the bin arithmetic
 // is the same as roi_pool_c8_kernel / the oracle's orc_roi_pool (coord_offset 1, end_adjust 0)
 __global__ void roi_pool_c8i_kernel(const float *__restrict__ feat, int Cb, int H, int W, size_t pitch_f, const float *__restrict__ rois, int roi_stride,
-                                    int N, int PH, int PW, float scale, float *__restrict__ out, size_t pitch_o) {
+                                    int N, int PH, int PW, float scale, float *__restrict__ out, size_t pitch_o, int roi_bins) {
   const int PP = PH * PW;
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)N * Cb * PP * 2;
@@ -272,14 +272,8 @@ __global__ void roi_pool_c8i_kernel(const float *__restrict__ feat, int Cb, int 
   const int cb = (int)(r % Cb); const int n = (int)(r / Cb);
   const int ph = bin / PW, pw = bin - ph * PW;
   const float *ro = rois + (size_t)roi_stride * n;
-  const int sw = (int)roundf((ro[1] - 1.0f) * scale), sh = (int)roundf((ro[2] - 1.0f) * scale);
-  const int ew = (int)roundf((ro[3] - 1.0f) * scale), eh = (int)roundf((ro[4] - 1.0f) * scale);
-  const int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
-  const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
-  int hs = (int)floorf((float)ph * bh) + sh, he = (int)ceilf((float)(ph + 1) * bh) + sh;
-  int ws = (int)floorf((float)pw * bw) + sw, we = (int)ceilf((float)(pw + 1) * bw) + sw;
-  hs = min(max(hs, 0), H); he = min(max(he, 0), H);
-  ws = min(max(ws, 0), W); we = min(max(we, 0), W);
+  int hs, he, ws, we;
+  roi_bin_bounds(ro, scale, RoiRule{1.0f, 0, roi_bins}, H, W, PH, PW, ph, pw, hs, he, ws, we);
   const bool empty = (he <= hs) || (we <= ws);
   f32x4 m = empty ? f32x4{0, 0, 0, 0} : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
   const float *fp = feat + (size_t)cb * pitch_f * 8 + h * 4;
@@ -298,21 +292,15 @@ __global__ void roi_pool_c8i_kernel(const float *__restrict__ feat, int Cb, int 
 template <int CBG>
 __global__ __launch_bounds__(256) void roi_pool_c8i_rows_kernel(const float *__restrict__ feat, int H, int W, size_t pitch_f, const float *__restrict__ rois,
                                                                  int roi_stride, int N, int PH, int PW, float scale, float *__restrict__ out, size_t pitch_o,
-                                                                 int fc_mp) {
+                                                                 int fc_mp, int roi_bins) {
   const int PP = PH * PW;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)N * PP) return;
   const int n = (int)(t / PP), bin = (int)(t - (size_t)n * PP);
   const int ph = bin / PW, pw = bin - ph * PW;
   const float *ro = rois + (size_t)roi_stride * n;
-  const int sw = (int)roundf((ro[1] - 1.0f) * scale), sh = (int)roundf((ro[2] - 1.0f) * scale);
-  const int ew = (int)roundf((ro[3] - 1.0f) * scale), eh = (int)roundf((ro[4] - 1.0f) * scale);
-  const int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
-  const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
-  int hs = (int)floorf((float)ph * bh) + sh, he = (int)ceilf((float)(ph + 1) * bh) + sh;
-  int ws = (int)floorf((float)pw * bw) + sw, we = (int)ceilf((float)(pw + 1) * bw) + sw;
-  hs = min(max(hs, 0), H); he = min(max(he, 0), H);
-  ws = min(max(ws, 0), W); we = min(max(we, 0), W);
+  int hs, he, ws, we;
+  roi_bin_bounds(ro, scale, RoiRule{1.0f, 0, roi_bins}, H, W, PH, PW, ph, pw, hs, he, ws, we);
   const bool empty = (he <= hs) || (we <= ws);
   const int cb0 = blockIdx.y * CBG;
   const float *fp = feat + (size_t)cb0 * pitch_f * 8;
@@ -2000,7 +1988,7 @@ __global__ void image_transform_c8i_bf16_kernel(const float *__restrict__ in, in
 }
 
 __global__ void roi_pool_c8i_bf16_kernel(const bf16_t *__restrict__ feat, int Cb, int H, int W, size_t pitch_f, const float *__restrict__ rois,
-                                         int roi_stride, int N, int PH, int PW, float scale, bf16_t *__restrict__ out, size_t pitch_o) {
+                                         int roi_stride, int N, int PH, int PW, float scale, bf16_t *__restrict__ out, size_t pitch_o, int roi_bins) {
   const int PP = PH * PW;
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)N * Cb * PP * 2;
@@ -2010,14 +1998,8 @@ __global__ void roi_pool_c8i_bf16_kernel(const bf16_t *__restrict__ feat, int Cb
   const int cb = (int)(r % Cb); const int n = (int)(r / Cb);
   const int ph = bin / PW, pw = bin - ph * PW;
   const float *ro = rois + (size_t)roi_stride * n;
-  const int sw = (int)roundf((ro[1] - 1.0f) * scale), sh = (int)roundf((ro[2] - 1.0f) * scale);
-  const int ew = (int)roundf((ro[3] - 1.0f) * scale), eh = (int)roundf((ro[4] - 1.0f) * scale);
-  const int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
-  const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
-  int hs = (int)floorf((float)ph * bh) + sh, he = (int)ceilf((float)(ph + 1) * bh) + sh;
-  int ws = (int)floorf((float)pw * bw) + sw, we = (int)ceilf((float)(pw + 1) * bw) + sw;
-  hs = min(max(hs, 0), H); he = min(max(he, 0), H);
-  ws = min(max(ws, 0), W); we = min(max(we, 0), W);
+  int hs, he, ws, we;
+  roi_bin_bounds(ro, scale, RoiRule{1.0f, 0, roi_bins}, H, W, PH, PW, ph, pw, hs, he, ws, we);
   const bool empty = (he <= hs) || (we <= ws);
   f32x4 m = empty ? f32x4{0, 0, 0, 0} : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
   const bf16_t *fp = feat + (size_t)cb * pitch_f * 8 + h * 4;
@@ -2074,21 +2056,15 @@ __global__ void vmax_level_sorted_kernel(const u32x4 *__restrict__ prev, u32x4 *
 template <int CBG>  // channel blocks per thread (grid.y = Cb / CBG)
 __global__ __launch_bounds__(256) void roi_pool_c8i_bf16_sorted_kernel(const u32x4 *__restrict__ feat, int H, int W, size_t pitch_f,
                                                                         const float *__restrict__ rois, int roi_stride, int N, int PH, int PW, float scale,
-                                                                        u32x4 *__restrict__ out, size_t pitch_o) {
+                                                                        u32x4 *__restrict__ out, size_t pitch_o, int roi_bins) {
   const int PP = PH * PW;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (roi, bin): the output row of the pooled batch
   if (t >= (size_t)N * PP) return;
   const int n = (int)(t / PP), bin = (int)(t - (size_t)n * PP);
   const int ph = bin / PW, pw = bin - ph * PW;
   const float *ro = rois + (size_t)roi_stride * n;
-  const int sw = (int)roundf((ro[1] - 1.0f) * scale), sh = (int)roundf((ro[2] - 1.0f) * scale);
-  const int ew = (int)roundf((ro[3] - 1.0f) * scale), eh = (int)roundf((ro[4] - 1.0f) * scale);
-  const int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
-  const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
-  int hs = (int)floorf((float)ph * bh) + sh, he = (int)ceilf((float)(ph + 1) * bh) + sh;
-  int ws = (int)floorf((float)pw * bw) + sw, we = (int)ceilf((float)(pw + 1) * bw) + sw;
-  hs = min(max(hs, 0), H); he = min(max(he, 0), H);
-  ws = min(max(ws, 0), W); we = min(max(we, 0), W);
+  int hs, he, ws, we;
+  roi_bin_bounds(ro, scale, RoiRule{1.0f, 0, roi_bins}, H, W, PH, PW, ph, pw, hs, he, ws, we);
   const bool empty = (he <= hs) || (we <= ws);
   const int cb0 = blockIdx.y * CBG;
   const u32x4 *fp = feat + (size_t)cb0 * pitch_f;
@@ -2559,6 +2535,7 @@ struct ResNetGraph {
   int feat_vmax_levels = 0;
   bool feat_vmax_valid = false;
   float *splitk_ws = nullptr;    // fp32 partial slabs of split-K convolutions (bf16 graph; one stream at a time, like tb / hb)
+  int roi_bins = 0;              // MPN_ROI_BINS_* (resnet_set_roi_bins)
   std::vector<void *> allocs;
 };
 constexpr size_t SPLITK_WS_BYTES = (size_t)96 << 20;
@@ -3063,6 +3040,7 @@ void resnet_free(ResNetGraph *g) {
   delete g;
 }
 
+void resnet_set_roi_bins(ResNetGraph *g, int bin_rule) { g->roi_bins = bin_rule; }
 int resnet_feat_channels(const ResNetGraph *g) { return g->feat_c; }
 int resnet_out_channels(const ResNetGraph *g) { return g->out_c; }
 int resnet_n_heads(const ResNetGraph *g) { return (int)g->heads.size(); }
@@ -3514,7 +3492,7 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
   MPN_CHECK_ARG(g && g->feat && d_rois && d_feat_c8 && N > 0 && N <= g->max_rois && head >= 0 && head < (int)g->heads.size());
   const int Cb = (g->feat_c + 7) / 8, PH = g->pooled;
   float *const pool_dst = g->is_graph ? g->t_head[0].buf : g->hb[0];
-  const bool fuse_mp = g->is_graph && g->bf16 && (g_bf16_fast_pool & 1) && Cb % 4 == 0 && (g_graph_fuse & 4);  // max-pools of the pooled input: from the map
+  const bool fuse_mp = g->is_graph && g->bf16 && (g_bf16_fast_pool & 1) && Cb % 4 == 0 && (g_graph_fuse & 4) && g->roi_bins == 0;  // max-pools of the pooled input: from the map (its kernel unions the CUDA branch's bins: the adaptive rule runs the max-pool as an ordinary op on the pooled batch)
   bool fc_gemm = false;  // the head starts with a fully-connected layer: pool straight into its GEMM operand
   if (g->is_graph && !g->bf16 && g->fc_x && (g_graph_fuse & 8) && (g_bf16_fast_pool & 1) && Cb % 4 == 0)
     for (const GOp &op : g->g_heads[head]) fc_gemm = fc_gemm || op.fc_w != nullptr;
@@ -3560,7 +3538,7 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
       }
       hipLaunchKernelGGL(roi_pool_c8i_bf16_sorted_kernel<4>, dim3((unsigned)cdiv_sz((size_t)N * PH * PH, 256), (unsigned)(Cb / 4)), dim3(256), 0, s,
                          reinterpret_cast<const u32x4 *>(g->feat_sorted), g->feat_h, g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale,
-                         reinterpret_cast<u32x4 *>(pool_dst), pa.pitch());
+                         reinterpret_cast<u32x4 *>(pool_dst), pa.pitch(), g->roi_bins);
       if (fuse_mp)
         for (const GOp &op : g->g_heads[head]) {
           if (!op.from_rois) continue;
@@ -3575,7 +3553,7 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
         }
     } else if (g->bf16)
       hipLaunchKernelGGL(roi_pool_c8i_bf16_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, reinterpret_cast<const bf16_t *>(g->feat), Cb, g->feat_h,
-                         g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale, reinterpret_cast<bf16_t *>(pool_dst), pa.pitch());
+                         g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale, reinterpret_cast<bf16_t *>(pool_dst), pa.pitch(), g->roi_bins);
     else if (fc_gemm && (g_graph_fuse & 256)) {
       // the fully-connected operand is the VGG pipeline's (bin, roi)-row matrix: its pooling kernel too (a wave = one (roi, bin) over 256
       // channels of a pixel-major copy of the map, four ROIs per block leaving as whole 128-byte lines) — 37 -> 12 us on AlexNet
@@ -3585,14 +3563,14 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
                          (size_t)g->feat_h * g->feat_w, fa.pitch(), static_cast<float *>(pm));
       MPN_CHECK_LAUNCH();
       const Act fdim{nullptr, g->feat_c, g->feat_h, g->feat_w, 0, 0};
-      int rcp = roi_pool_pm(fdim, static_cast<const float *>(pm), d_rois, N, PH, PH, spatial_scale, 1.0f, 0, g->fc_x, s, roi_stride, round_up(N, 128));
+      int rcp = roi_pool_pm(fdim, static_cast<const float *>(pm), d_rois, N, PH, PH, spatial_scale, RoiRule{1.0f, 0, g->roi_bins}, g->fc_x, s, roi_stride, round_up(N, 128));
       if (rcp) return rcp;
     } else if ((g_bf16_fast_pool & 1) && Cb % 4 == 0)
       hipLaunchKernelGGL(roi_pool_c8i_rows_kernel<4>, dim3((unsigned)cdiv_sz((size_t)N * PH * PH, 256), (unsigned)(Cb / 4)), dim3(256), 0, s, g->feat, g->feat_h,
-                         g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale, fc_gemm ? g->fc_x : pool_dst, pa.pitch(), fc_gemm ? round_up(N, 128) : 0);
+                         g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale, fc_gemm ? g->fc_x : pool_dst, pa.pitch(), fc_gemm ? round_up(N, 128) : 0, g->roi_bins);
     else
       hipLaunchKernelGGL(roi_pool_c8i_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, g->feat, Cb, g->feat_h, g->feat_w, fa.pitch(), d_rois, roi_stride,
-                         N, PH, PH, spatial_scale, pool_dst, pa.pitch());
+                         N, PH, PH, spatial_scale, pool_dst, pa.pitch(), g->roi_bins);
     MPN_CHECK_LAUNCH();
   }
   ActI cur{pool_dst, N, g->feat_c, PH, PH}, y;

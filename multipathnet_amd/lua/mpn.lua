@@ -41,9 +41,10 @@ end
 
 -- inn.ROIPooling(W, H, spatial_scale) ------------------------------------------------------------------------------------
 local ROIPooling, parent = torch.class('mpn.ROIPooling', 'nn.Module')
-function ROIPooling:__init(W, H, spatial_scale)
+-- bin_rule: 0 (default) = the module's CUDA branch, 1 = its CPU branch, crop + nn.SpatialAdaptiveMaxPooling (include/mpn.h MPN_ROI_BINS_*)
+function ROIPooling:__init(W, H, spatial_scale, bin_rule)
    parent.__init(self)
-   self.W, self.H, self.spatial_scale = W, H, spatial_scale or 1
+   self.W, self.H, self.spatial_scale, self.bin_rule = W, H, spatial_scale or 1, bin_rule or 0
    self.indices = torch.CudaIntTensor and torch.CudaIntTensor() or torch.CudaTensor()
 end
 function ROIPooling:setSpatialScale(s) self.spatial_scale = s; return self end
@@ -53,9 +54,9 @@ function ROIPooling:updateOutput(input)
    local N = rois:size(1)
    self.output:resize(N, feat:size(2), self.H, self.W)
    self.indices:resize(N, feat:size(2), self.H, self.W)
-   check(C.mpn_roi_pool_forward(feat:data(), feat:size(1), feat:size(2), feat:size(3), feat:size(4), rois:data(), N,
-                                self.H, self.W, self.spatial_scale, 1.0, 0, self.output:data(),
-                                ffi.cast('int32_t*', self.indices:data()), stream()), 'ROIPooling')
+   check(C.mpn_roi_pool_forward_rule(feat:data(), feat:size(1), feat:size(2), feat:size(3), feat:size(4), rois:data(), N,
+                                     self.H, self.W, self.spatial_scale, 1.0, 0, self.bin_rule or 0, self.output:data(),
+                                     ffi.cast('int32_t*', self.indices:data()), stream()), 'ROIPooling')
    return self.output
 end
 
@@ -133,6 +134,7 @@ local function common_config(cfg, opt, tf, bnorm)
    cfg.num_iter, cfg.bbox_voting = opt.test_num_iterative_loc or 1, opt.test_bbox_voting and 1 or 0
    cfg.bbox_vote_thresh, cfg.bbox_vote_score_pow = opt.test_bbox_voting_nms_threshold or 0.5, opt.test_bbox_voting_score_pow or 1
    cfg.use_rbox_scores = opt.test_use_rbox_scores and 1 or 0
+   cfg.roi_bin_rule = opt.roi_bin_rule or 0                        -- 1: inn.ROIPooling's CPU-branch bins (MPN_ROI_BINS_ADAPTIVE)
    cfg.scale_target, cfg.scale_max = opt.scale or 600, opt.max_size or 1000   -- getImages (ImageDetect.lua:34-43) on the device
 end
 -- classAndBBoxLinear (model_utils.lua:105-119) [+ utils.integral's K classifier clones, model_utils.lua:275-317] -> (cls weight, cls bias,

@@ -490,8 +490,9 @@ class FastRCNN(object):
 
     def __init__(self, params, cfg=VGG16_CFG, pooled=7, spatial_scale=1.0 / 16, transformer=None, max_h=600, max_w=1000,
                  max_rois=1000, nms_thresh=0.3, score_thresh=-1.5, top_k=100, num_iter=1, bbox_voting=False, bbox_vote_thresh=0.5,
-                 bbox_vote_score_pow=1.0, scale=None, max_size=None, bf16=False, use_rbox_scores=False):
+                 bbox_vote_score_pow=1.0, scale=None, max_size=None, bf16=False, use_rbox_scores=False, roi_bin_rule=0):
         """scale / max_size: getImages' rescaling (ImageDetect.lua:34-43) on the device; None feeds images as they are.
+        roi_bin_rule: 0 = inn.ROIPooling's CUDA-branch bins, 1 = its CPU branch (crop + SpatialAdaptiveMaxPooling), include/mpn.h MPN_ROI_BINS_*.
         num_iter / bbox_voting / use_rbox_scores: opt.test_num_iterative_loc / test_bbox_voting / test_use_rbox_scores
         (Tester_FRCNN.lua:82-99,118-124) inside the fused test_one."""
         _lib.require_gpu()
@@ -533,6 +534,7 @@ class FastRCNN(object):
         self.num_iter = num_iter
         c.scale_target, c.scale_max = float(scale or 0.0), float(max_size or 0.0)
         c.use_rbox_scores = int(bool(use_rbox_scores))
+        c.roi_bin_rule = int(roi_bin_rule)
         self.scale, self.max_size = scale, max_size
         self._cfg = c
         dev = torch.device("cuda", torch.cuda.current_device())

@@ -66,12 +66,14 @@ class ROIPooling(Module):
     """inn.ROIPooling(W, H, spatial_scale): input {features [B,C,h,w], rois [N,5]} -> [N,C,H,W].
 
     `coord_offset` / `end_adjust` parameterise the unpinned coordinate convention (SURVEY §8a-6);
-    defaults are the README.md:202-203 "v2" behaviour."""
+    defaults are the README.md:202-203 "v2" behaviour.  `bin_rule`: BINS_CAFFE = the module's CUDA branch (default),
+    BINS_ADAPTIVE = its CPU branch, crop + nn.SpatialAdaptiveMaxPooling (include/mpn.h MPN_ROI_BINS_*)."""
+    BINS_CAFFE, BINS_ADAPTIVE = 0, 1
 
-    def __init__(self, W, H, spatial_scale=1.0, coord_offset=1.0, end_adjust=0):
+    def __init__(self, W, H, spatial_scale=1.0, coord_offset=1.0, end_adjust=0, bin_rule=0):
         super().__init__()
         self.W, self.H, self.spatial_scale = int(W), int(H), float(spatial_scale)
-        self.coord_offset, self.end_adjust = float(coord_offset), int(end_adjust)
+        self.coord_offset, self.end_adjust, self.bin_rule = float(coord_offset), int(end_adjust), int(bin_rule)
         self.indices = None
 
     def setSpatialScale(self, scale):
@@ -86,9 +88,9 @@ class ROIPooling(Module):
         self.output = torch.empty((N, Cc, self.H, self.W), dtype=torch.float32, device=feat.device)
         self.indices = torch.empty((N, Cc, self.H, self.W), dtype=torch.int32, device=feat.device)
         if N:
-            check(_lib.load().mpn_roi_pool_forward(_f(feat, "features"), B, Cc, h, w, _f(rois, "rois"), N, self.H, self.W,
-                                                   C.c_float(self.spatial_scale), C.c_float(self.coord_offset),
-                                                   self.end_adjust, _f(self.output), _i(self.indices), _stream()),
+            check(_lib.load().mpn_roi_pool_forward_rule(_f(feat, "features"), B, Cc, h, w, _f(rois, "rois"), N, self.H, self.W,
+                                                        C.c_float(self.spatial_scale), C.c_float(self.coord_offset),
+                                                        self.end_adjust, self.bin_rule, _f(self.output), _i(self.indices), _stream()),
                   "ROIPooling")
         return self.output
 

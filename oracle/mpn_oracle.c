@@ -25,6 +25,7 @@
  * accumulate in fp32 in ascending-k order (k = cin*9 + ky*3 + kx for conv, k = input index for
  * linear), vectorised across *outputs* only, so no reassociation happens.
  */
+#include <float.h>
 #include <math.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -321,6 +322,62 @@ void orc_roi_pool(const float *feat, int B, int C, int H, int W, const float *ro
           out[o] = m;
           if (argmax) argmax[o] = mi;
         }
+    }
+  }
+}
+
+/* inn.ROIPooling's OTHER branch — the module's CPU path (the "CPU nn path" of BASELINE configs[0]; call sites
+ * models/alexnet.lua:23, models/vgg.lua:28 when the tensors are float): PARITY UNPINNED (external rock, source absent), restated as
+ *     rois[{{},{2,5}}]:add(-1):mul(spatial_scale):add(1):round()      -- corners in 1-based map coordinates, fp32 tensor ops in this order
+ *     x1, x2 clipped to the map width, y1, y2 to its height           -- the reference clips the upper side (cmin) and indexes the tensor
+ *                                                                        with the lower side, which must be >= 1; we clip both sides
+ *     im = data[{b, {}, {y1, y2}, {x1, x2}}]                          -- the inclusive crop
+ *     out[n] = nn.SpatialAdaptiveMaxPooling(PW, PH):forward(im)       -- bin i of a side of length L: [floor(i * L / P), ceil((i + 1) * L / P))
+ *                                                                        (THNN's START_IND / END_IND: (int)floor((float)(i * L) / P)),
+ *                                                                        max from -FLT_MAX upwards with `>`
+ * bin_rule 0 is orc_roi_pool (the CUDA branch: bins of the un-clipped window, clipped afterwards, empty bins -> 0); 1 is this one.  The two
+ * differ on windows whose rounded corners leave the map (Foveal's regions, border boxes) and, once in a thousand, by one cell.  argmax = h * W + w in the feature plane for both.
+ * Written as crop-then-pool, as the module does it — deliberately not sharing code with the CUDA-branch restatement above. */
+void orc_roi_pool_rule(const float *feat, int B, int C, int H, int W, const float *rois, int N, int PH, int PW, float scale,
+                       float coord_offset, int end_adjust, int bin_rule, float *out, int32_t *argmax) {
+  if (bin_rule == 0) { orc_roi_pool(feat, B, C, H, W, rois, N, PH, PW, scale, coord_offset, end_adjust, out, argmax); return; }
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int n = 0; n < N; ++n) {
+    const float *r = rois + 5 * n;
+    int b = (int)r[0] - 1;
+    if (b < 0) b = 0;
+    if (b >= B) b = B - 1;
+    float c1[4];
+    for (int k = 0; k < 4; ++k) {
+      float t = r[1 + k] - coord_offset;
+      t = t * scale;
+      t = t + 1.0f;
+      c1[k] = roundf(t);
+    }
+    int x1 = (int)c1[0], y1 = (int)c1[1], x2 = (int)c1[2] + end_adjust, y2 = (int)c1[3] + end_adjust;  /* 1-based, inclusive */
+    x1 = ORC_MIN(ORC_MAX(x1, 1), W); x2 = ORC_MIN(ORC_MAX(x2, 1), W);
+    y1 = ORC_MIN(ORC_MAX(y1, 1), H); y2 = ORC_MIN(ORC_MAX(y2, 1), H);
+    int iw = x2 - x1 + 1, ih = y2 - y1 + 1;
+    if (iw < 1) iw = 1;
+    if (ih < 1) ih = 1;
+    for (int c = 0; c < C; ++c) {
+      const float *crop = feat + ((size_t)b * C + c) * H * W + (size_t)(y1 - 1) * W + (x1 - 1);  /* crop(y, x) = crop[y * W + x] */
+      for (int i = 0; i < PH; ++i) {
+        int ys = (int)floorf((float)(i * ih) / (float)PH), ye = (int)ceilf((float)((i + 1) * ih) / (float)PH);
+        for (int j = 0; j < PW; ++j) {
+          int xs = (int)floorf((float)(j * iw) / (float)PW), xe = (int)ceilf((float)((j + 1) * iw) / (float)PW);
+          float m = -FLT_MAX;
+          int mi = -1;
+          for (int y = ys; y < ye; ++y)
+            for (int x = xs; x < xe; ++x) {
+              float v = crop[(size_t)y * W + x];
+              if (v > m) { m = v; mi = (y1 - 1 + y) * W + (x1 - 1 + x); }
+            }
+          size_t o = (((size_t)n * C + c) * PH + i) * PW + j;
+          out[o] = m;
+          if (argmax) argmax[o] = mi;
+        }
+      }
     }
   }
 }

@@ -251,7 +251,29 @@ def softmax(x):
     return y
 
 
-def roi_pool(feat, rois, PH, PW, scale, coord_offset=1.0, end_adjust=0):
+ROI_BINS_CAFFE, ROI_BINS_ADAPTIVE = 0, 1
+_roi_bin_rule = [ROI_BINS_CAFFE]   # what roi_pool() uses when its caller (the whole-model restatements below) does not say
+
+
+class roi_bin_rule:
+    """with O.roi_bin_rule(O.ROI_BINS_ADAPTIVE): ... — the whole-model restatements pool with inn.ROIPooling's CPU-branch rule inside."""
+
+    def __init__(self, rule):
+        self.rule = int(rule)
+
+    def __enter__(self):
+        _roi_bin_rule.append(self.rule)
+        return self
+
+    def __exit__(self, *a):
+        _roi_bin_rule.pop()
+
+
+def roi_pool(feat, rois, PH, PW, scale, coord_offset=1.0, end_adjust=0, bin_rule=None):
+    """inn.ROIPooling; bin_rule = ROI_BINS_CAFFE (the CUDA branch, orc_roi_pool) | ROI_BINS_ADAPTIVE (the CPU branch: crop +
+    SpatialAdaptiveMaxPooling, orc_roi_pool_rule)."""
+    if bin_rule is None:
+        bin_rule = _roi_bin_rule[-1]
     feat, rois = _f32(feat), _f32(rois).reshape(-1, 5)
     if feat.ndim == 3:
         feat = feat[None]
@@ -259,8 +281,8 @@ def roi_pool(feat, rois, PH, PW, scale, coord_offset=1.0, end_adjust=0):
     N = rois.shape[0]
     out = np.empty((N, Cc, PH, PW), np.float32)
     arg = np.empty((N, Cc, PH, PW), np.int32)
-    lib().orc_roi_pool(_p(feat), B, Cc, H, W, _p(rois), N, PH, PW, C.c_float(scale), C.c_float(coord_offset),
-                       int(end_adjust), _p(out), _p(arg, i32p))
+    lib().orc_roi_pool_rule(_p(feat), B, Cc, H, W, _p(rois), N, PH, PW, C.c_float(scale), C.c_float(coord_offset),
+                            int(end_adjust), int(bin_rule), _p(out), _p(arg, i32p))
     return out, arg
 
 

@@ -40,6 +40,33 @@ def test_alexnet_frcnn_vs_oracle(O, dev, H, W, N, width):
         assert nk[j - 1] == ref.shape[0] and np.array_equal(keep[j - 1, : nk[j - 1]], ref)
 
 
+@pytest.mark.parametrize("fuse", [511, 255, 7])
+def test_alexnet_cpu_branch_roi_pooling_vs_oracle(O, dev, fuse):
+    """BASELINE configs[0] says "CPU nn path": inn.ROIPooling's CPU branch crops the clipped window and runs nn.SpatialAdaptiveMaxPooling
+    (models/alexnet.lua:23 with float tensors).  roi_bin_rule = MPN_ROI_BINS_ADAPTIVE through the op-list pipeline — the pixel-major pooling
+    into the fully-connected operand (511), the row-per-thread C8I kernel writing that operand (255), the C8I batch of maps feeding the
+    fc-as-convolution form (7) — against the oracle's graph restatement pooling with the same rule; and it differs from the default rule."""
+    from conftest import hooks
+    from multipathnet_amd import models
+    H, W, N = 150, 250, 40
+    G = models.synthetic_alexnet_params(n_classes=6, width=0.25, fc_dim=128, seed=H)
+    Gn = models.graph_params_numpy(G)
+    im, boxes = _inputs(H, W, N, W)
+    boxes[:8, 2:] = [W, H]       # boxes that reach the right / bottom border: round((x2 - 1) / 16) lands on the column past the map
+    outs = {}
+    with hooks(graph_fuse=fuse):
+        for rule in (1, 0):
+            net = models.AlexNetFRCNN(G, max_h=H, max_w=W, max_rois=64, top_k=20, roi_bin_rule=rule)
+            s, b = net.detect(torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev))
+            with O.roi_bin_rule(rule):
+                so, bo, _, _ = O.graph_detect(im, boxes, Gn, O.ROSS, target=min(H, W), max_size=max(H, W), pooled=6, spatial_scale=1.0 / 16)
+            assert np.abs(s.cpu().numpy() - so).max() < 1e-4, (fuse, rule)
+            assert np.abs(b.cpu().numpy() - O.clamp_boxes(bo, W, H)).max() < 1e-4 * max(H, W)
+            outs[rule] = s.cpu().numpy().copy()
+            del net
+    assert np.abs(outs[0] - outs[1]).max() > 1e-5
+
+
 def test_alexnet_fc_layers_on_the_gemm_equal_the_convolution_form(dev):
     """graph_parse bit 3: fc6 (the 6x6 convolution over the whole pooled map) and fc7 (1x1 on 1x1 maps) run on the tuned GEMM — the
     ROI pooling writes (bin, roi) rows, K = (channel block, bin) — instead of the pixel-tile convolution kernels; bit 4: conv1 (3 input

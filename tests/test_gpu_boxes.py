@@ -145,7 +145,7 @@ def test_keep_top_k_sorted_equals_general(O, dev, n_cls, M, k):
     from multipathnet_amd import _lib, nn
     rng = np.random.default_rng(n_cls * 7 + M + k)
     lib = _lib.load()
-    for case in ("distinct", "quantised", "plateau", "empty"):
+    for case in ("distinct", "quantised", "plateau", "empty", "zeros"):
         counts = rng.integers(0, M + 1, n_cls)
         counts[rng.integers(0, n_cls)] = M
         if n_cls > 2:
@@ -159,6 +159,18 @@ def test_keep_top_k_sorted_equals_general(O, dev, n_cls, M, k):
                 sc = (np.round(sc * 50) / 50).astype(np.float32)
             if case == "plateau" and c == 0 and counts[c] > 3:
                 sc[: max(3, counts[c] * 2 // 3)] = np.float32(2.0)
+            if case == "zeros" and counts[c] > 0:
+                # -0.0f == +0.0f for NMS's order and for `score >= thresh`, but not for an order-preserving integer key unless it is
+                # canonicalised: a few positive scores, then a run of zeros of either sign (in float order: any arrangement is "non-increasing"),
+                # then negatives; the k-th largest score of the whole table is a zero
+                n = int(counts[c])
+                n_pos = min(n, max(0, k // (2 * n_cls)))
+                n_zero = min(n - n_pos, max(2, k))
+                sc = np.concatenate([np.sort(rng.random(n_pos).astype(np.float32) + np.float32(0.5))[::-1],
+                                     np.where(rng.random(n_zero) < 0.5, np.float32(-0.0), np.float32(0.0)).astype(np.float32),
+                                     np.sort(-rng.random(n - n_pos - n_zero).astype(np.float32) - np.float32(0.5))[::-1]]).astype(np.float32)
+                per.append(np.concatenate([rng.random((counts[c], 4)).astype(np.float32), sc[:, None]], 1).astype(np.float32))
+                continue
             sc = np.sort(sc)[::-1]
             per.append(np.concatenate([rng.random((counts[c], 4)).astype(np.float32), sc[:, None]], 1).astype(np.float32))
         d_keep = torch.zeros((n_cls, M, 5), device=dev)
