@@ -23,6 +23,7 @@ pytestmark = pytest.mark.gpu
 
 N_ORACLE = {"plain": 12, "towers": 6, "alexnet": 60}   # AlexNet's head is two GEMMs per ROI: the oracle affords 60
 N_TORCH = 64
+N_GATE = 256   # ROIs of the bf16 decision gate (plain-fp32 PyTorch-CPU rows of the same ROIs)
 
 
 def _inception_inputs(seed, N):
@@ -96,6 +97,8 @@ class Case(object):
         self.idx_t = rng.choice(N, N_TORCH, replace=False)
         self.idx_t[0] = N - 1   # the ragged end of the last tile
         self.idx_o = self.idx_t[: N_ORACLE["alexnet" if self.kind == "alexnet" else "towers" if self.towers else "plain"]]
+        rest = np.setdiff1d(np.arange(N), self.idx_t)
+        self.idx_g = np.concatenate([self.idx_t, rng.choice(rest, N_GATE - N_TORCH, replace=False)])
         self._oracle(O)
         self._torch(O)
 
@@ -134,13 +137,13 @@ class Case(object):
 
     # ---- PyTorch-CPU on 64 ROIs: oneDNN arithmetic; the ROI pooling's integer binning + max from the oracle
     def _torch(self, O):
-        self.lt, self.dt = self._torch_run(O, self.bf16)
-        # bf16 cases: also the SAME 64 ROIs in plain fp32 — the reference the decision-level report below counts against
-        self.lt32, self.dt32 = self._torch_run(O, False) if self.bf16 else (self.lt, self.dt)
+        self.lt, self.dt = self._torch_run(O, self.bf16, self.idx_t)
+        # bf16 cases: N_GATE ROIs (the 64 above first) in plain fp32 — the reference the decision-level gate below counts against
+        self.lt32, self.dt32 = self._torch_run(O, False, self.idx_g) if self.bf16 else (self.lt, self.dt)
 
-    def _torch_run(self, O, bf):
+    def _torch_run(self, O, bf, idx):
         from multipathnet_amd import models
-        rois = O.project_im_rois(self.boxes[self.idx_t], 1.0)
+        rois = O.project_im_rois(self.boxes[idx], 1.0)
         fov = O.foveal(rois).reshape(-1, 4, 5)
         with T.threads(32):
             if self.kind == "resnet":
@@ -254,16 +257,20 @@ def test_trained_scale_test_one_all_classes_vs_reference_nms(O, dev, case):
     assert nd == exp.shape[0] and np.array_equal(dets[:nd].cpu().numpy(), exp)
 
 
-def test_bf16_decision_report(O, dev, case):
-    """nothing bounded the DECISION error of the bf16 graphs.  Report (print; no gate — bf16 is a stated rounding scheme,
-    not a parity claim): on the 64-ROI sample, how many per-class NMS keep-sets and how many rows of the top-100 record differ between the
-    bf16 DEVICE rows and the plain-fp32 PyTorch-CPU rows of the same ROIs (scores = softmax / mean of K softmaxes of the logits, boxes =
-    utils.convertFrom + clamp of the deltas; NMS 0.3 per class by the oracle's nms == compiled nms.c; utils.keep_top_k(100))."""
+def test_bf16_decisions_gate(O, dev, case):
+    """VERDICT r5 missing #4 / task 4b: a GATE on the decisions of the bf16 graphs (/root/reference/Tester_FRCNN.lua:106-125 is what consumes the
+    scores: per-class select -> NMS 0.3 -> top-100).  On N_GATE = 256 ROIs the bf16 DEVICE rows are compared with the plain-fp32 PyTorch-CPU
+    rows of the same ROIs (scores = softmax / mean of K softmaxes of the logits, boxes = utils.convertFrom + clamp of the deltas; NMS per class
+    by the oracle's nms == compiled nms.c; utils.keep_top_k(100)):
+      * no arg-max class flip on any ROI whose fp32 top-1 / top-2 margin exceeds 0.02;
+      * the per-class NMS keep-SETS are equal in >= 90 % of the classes;
+      * >= 95 % of the fp32 top-100 record's rows are in the device's record (and vice versa).
+    bf16 is a stated rounding scheme, not a parity claim against fp32 — this bounds what the scheme does to the detections."""
     c = case
     if not c.bf16:
         pytest.skip("fp32 case: its decisions are compared bit for bit elsewhere")
     H, W = c.im.shape[1:]
-    bx = c.boxes[c.idx_t]
+    bx = c.boxes[c.idx_g]
 
     def decisions(logits, deltas):
         lg = np.ascontiguousarray(logits, np.float32).reshape(-1, c.K, c.C)
@@ -283,15 +290,25 @@ def test_bf16_decision_report(O, dev, case):
             top.update((j + 1, r) for r in ks[:thr_rows])   # NMS output is in descending score order: the survivors of the threshold are a prefix
         return sc, keeps, top
 
-    s_dev, k_dev, t_dev = decisions(c.logits[c.idx_t], c.raw[c.idx_t])
+    s_dev, k_dev, t_dev = decisions(c.logits[c.idx_g], c.raw[c.idx_g])
     s_ref, k_ref, t_ref = decisions(c.lt32, c.dt32)
+    n_cls = c.C - 1
     n_sets = sum(1 for a, b in zip(k_dev, k_ref) if set(a) != set(b))
     n_order = sum(1 for a, b in zip(k_dev, k_ref) if a != b)
-    flips = int((s_dev.argmax(1) != s_ref.argmax(1)).sum())
-    print("[%s] bf16 device vs plain fp32 (PyTorch-CPU) on %d ROIs x %d classes: max|dscore| = %.3g; argmax class differs on %d ROIs; per-class NMS keep-SETS differ "
-          "in %d of %d classes (kept ORDER in %d); top-100 record: %d rows, %d not in the fp32 record, %d fp32 rows missing"
-          % (c.name, N_TORCH, c.C - 1, np.abs(s_dev - s_ref).max(), flips, n_sets, c.C - 1, n_order, len(t_dev), len(t_dev - t_ref), len(t_ref - t_dev)))
-    assert len(t_dev) > 0 and len(t_ref) > 0
+    srt = np.sort(s_ref, 1)
+    margin = srt[:, -1] - srt[:, -2]
+    flip = s_dev.argmax(1) != s_ref.argmax(1)
+    flips, flips_m = int(flip.sum()), int((flip & (margin > 0.02)).sum())
+    shared = len(t_dev & t_ref)
+    print("[%s] bf16 device vs plain fp32 (PyTorch-CPU) on %d ROIs x %d classes: max|dscore| = %.3g; argmax class differs on %d ROIs (%d with fp32 margin > 0.02, "
+          "largest margin among the flips %.3g); per-class NMS keep-SETS differ in %d of %d classes (kept ORDER in %d); top-100 record: device %d rows, fp32 %d rows, "
+          "%d shared (%d device rows not in the fp32 record, %d fp32 rows missing)"
+          % (c.name, N_GATE, n_cls, np.abs(s_dev - s_ref).max(), flips, flips_m, float(margin[flip].max()) if flips else 0.0, n_sets, n_cls, n_order,
+             len(t_dev), len(t_ref), shared, len(t_dev - t_ref), len(t_ref - t_dev)))
+    assert len(t_dev) >= 100 and len(t_ref) >= 100
+    assert flips_m == 0
+    assert n_cls - n_sets >= 0.9 * n_cls
+    assert shared >= 0.95 * len(t_ref) and shared >= 0.95 * len(t_dev)
 
 
 def test_rows_do_not_depend_on_the_batch_they_are_scored_in(dev, case):

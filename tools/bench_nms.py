@@ -14,6 +14,7 @@ n_cls, M = 20, int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 only_regimes = sys.argv[2].split(",") if len(sys.argv) > 2 else None   # e.g. fewties
 only_modes = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else None   # e.g. 0,3
 from multipathnet_amd import _lib
+lib.mpn_debug_set_nms_fused_fence(int(os.environ.get("MPN_FUSED_FENCE", "1")))     # 0: round 5's relaxed block hand-off (no acquire-release counter)
 lib.mpn_debug_set_nms_fused_replay(int(os.environ.get("MPN_FUSED_REPLAY", "1")))   # 0: the fused kernel's per-round tie path for every tied class
 for regime in ("distinct", "fewties", "ties30", "ties100", "ties", "saturated"):
     if only_regimes and regime not in only_regimes:
@@ -49,3 +50,4 @@ for regime in ("distinct", "fewties", "ties30", "ties100", "ties", "saturated"):
 lib.mpn_debug_set_nms_force_exact(0)
 lib.mpn_debug_set_nms_fused(1)
 lib.mpn_debug_set_nms_fused_replay(1)
+lib.mpn_debug_set_nms_fused_fence(1)
