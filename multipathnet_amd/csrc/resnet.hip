@@ -2638,6 +2638,14 @@ MPN_KNOB(int, g_bf16_bdir, 1);  // mpn_debug_set_bf16_bdir: 1 = conv2d_c8i_bf16_
 MPN_KNOB(int, g_bf16_bdir_abl, 0);  // mpn_debug_set_bf16_bdir_abl: the B-direct kernel's ABL knock-outs (only in -DMPN_BF16_ABLATE builds)
 MPN_KNOB(int, g_bf16_bdir_ver, 1);  // mpn_debug_set_bf16_bdir_ver: 1 = compiler-counted form <3>, 2 / 3 = hand-counted form <3> / <4> (debug flavour only)
 #endif
+#ifdef MPN_DEBUG_HOOKS
+// mpn_debug_set_tower_knock (tools/tower_knockout.py; timing only, garbage results): the CEILING of a first per-ROI layer that never reads a
+// materialised pooled tensor (VERDICT r5 task 1, step 1).  bit 0: the ROI pooling launch of the bf16 heads is skipped; bit 1: the convolutions
+// that read the pooled tensor (Mixed_7a's fused 1x1 768 -> 384; layer4 block 1's conv1 and shortcut) run the B-direct kernel with every pixel
+// load hitting ONE resident 1-KiB window (ABL bit 5: nothing can fetch its operand cheaper than from the CU's own cache).
+static int g_tower_knock = 0;
+static int g_knock_arm = 0;  // the next `g_knock_arm` rn_conv calls are first-layer convolutions (armed by the caller)
+#endif
 MPN_KNOB(int, g_roi_invariant, 1);  // mpn_debug_set_roi_invariant: 0 = per-ROI layers pick kernel / split by batch size as round 3 did (tests, timing)
 // per_roi: the batch axis counts ROIs (the head of a graph model).  A ROI's result must not depend on which other ROIs share the
 // launch (memoryEfficientForward's chunked == full, ImageDetect.lua:126-133; the ROI-sharded mode == the unsharded one), so for
@@ -2669,11 +2677,22 @@ static int rn_conv(const RnConv &c, ActI in, float *out, const float *res, int r
     // (every second record of a row: half-used cache lines per fragment load, +26 %).  A rule of the layer alone, never of the batch.
     const bool pointwise = b.KH == 1 && b.KW == 1, strided = b.sh > 1 || b.sw > 1;
     const bool bdir_wins = pointwise ? (!strided && c.Cin >= 2 * c.Cout) : (!strided || c.Cin >= 512);
-    if (g_bf16_bdir && (g_bf16_bdir == 2 || bdir_wins) && g_bf16_dma && b.nch2 % 4 == 0 && b.P >= (g_bf16_dma == 2 ? 1 : 256 * 128) &&
+#ifdef MPN_DEBUG_HOOKS
+    const bool knock_first = g_knock_arm > 0 && (g_tower_knock & 2);
+#else
+    constexpr bool knock_first = false;
+#endif
+    if (g_bf16_bdir && (g_bf16_bdir == 2 || bdir_wins || knock_first) && g_bf16_dma && b.nch2 % 4 == 0 && b.P >= (g_bf16_dma == 2 ? 1 : 256 * 128) &&
         (size_t)b.nch2 * b.pitch_in * 16 < ((size_t)1 << 31) && (size_t)b.KH * b.KW * b.nch2 * b.CoutP * 16 < ((size_t)1 << 31)) {
       const int nx = (int)((b.P + 255) / 256), ny = b.CoutP / 128;
       const dim3 gridd((unsigned)(((nx + 7) / 8) * 8 * ny));
 #ifdef MPN_DEBUG_HOOKS
+      if (g_knock_arm > 0 && (g_tower_knock & 2)) {
+        --g_knock_arm;
+        hipLaunchKernelGGL((conv2d_c8i_bf16_bdir_kernel<3, 32 | 512>), gridd, dim3(256), 0, s, b, nx, ny);
+        MPN_CHECK_LAUNCH();
+        return MPN_OK;
+      }
       if (g_bf16_bdir_ver == 9) {
         const int nxq = (nx + 7) / 8;
         const dim3 gridp((unsigned)(8 * ((nxq * ny + 1) / 2)));
@@ -3404,7 +3423,13 @@ static int graph_run(ResNetGraph *g, const std::vector<GOp> &ops, std::vector<GT
       ActI o;
       // the GEMM writes whole 128-channel panels: only when this op owns them (no neighbouring branch inside the panel)
       const bool own = op.conv.Cout % 128 == 0 || (op.dst_c_off == 0 && op.conv.Cout == dst.C);
+#ifdef MPN_DEBUG_HOOKS
+      if (!trunk && op.src == 0 && g_tower_knock) g_knock_arm = 1;  // reads the pooled tensor
+#endif
       int rc = rn_conv(op.conv, in, reinterpret_cast<float *>(outp), nullptr, op.relu, s, &o, own, !trunk);
+#ifdef MPN_DEBUG_HOOKS
+      g_knock_arm = 0;
+#endif
       if (rc) return rc;
     } else {
       const size_t total = (size_t)in.Cb() * B * dst.H * dst.W * 2;
@@ -3536,6 +3561,9 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
         }
         g->feat_vmax_valid = true;
       }
+#ifdef MPN_DEBUG_HOOKS
+      if (!(g_tower_knock & 1))
+#endif
       hipLaunchKernelGGL(roi_pool_c8i_bf16_sorted_kernel<4>, dim3((unsigned)cdiv_sz((size_t)N * PH * PH, 256), (unsigned)(Cb / 4)), dim3(256), 0, s,
                          reinterpret_cast<const u32x4 *>(g->feat_sorted), g->feat_h, g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale,
                          reinterpret_cast<u32x4 *>(pool_dst), pa.pitch(), g->roi_bins);
@@ -3581,7 +3609,13 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
     cur = ActI{o.buf, N, o.C, o.H, o.W};
   } else
   for (auto &blk : g->heads[head]) {
+#ifdef MPN_DEBUG_HOOKS
+    if (g_tower_knock && &blk == &g->heads[head][0]) g_knock_arm = blk.has_sc ? 2 : 1;  // block 1's shortcut and conv1 read the pooled tensor
+#endif
     int rc = rn_block(blk, cur, g->hb, s, &y, true);
+#ifdef MPN_DEBUG_HOOKS
+    g_knock_arm = 0;
+#endif
     if (rc) return rc;
     cur = y;
   }
@@ -3672,6 +3706,7 @@ extern "C" int mpn_debug_bench_conv_bf16(int Cin, int Cout, int KH, int KW, int 
   resnet_free(g);
   return rc;
 }
+extern "C" void mpn_debug_set_tower_knock(int v) { mpn::g_tower_knock = v; }
 extern "C" void mpn_debug_set_bf16_dma(int v) { mpn::g_bf16_dma = v; }
 extern "C" void mpn_debug_set_roi_invariant(int v) { mpn::g_roi_invariant = v; }
 extern "C" void mpn_debug_set_bf16_exp(int v) { mpn::g_bf16_exp = v; }
