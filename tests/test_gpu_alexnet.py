@@ -52,7 +52,8 @@ def test_alexnet_cpu_branch_roi_pooling_vs_oracle(O, dev, fuse):
     G = models.synthetic_alexnet_params(n_classes=6, width=0.25, fc_dim=128, seed=H)
     Gn = models.graph_params_numpy(G)
     im, boxes = _inputs(H, W, N, W)
-    boxes[:8, 2:] = [W, H]       # boxes that reach the right / bottom border: round((x2 - 1) / 16) lands on the column past the map
+    boxes[:8, 2:] = [W + 40, H + 40]   # proposals that hang over the right / bottom border (CaffeNet's conv5 map of a 150 x 250 image is 11 x 17: its
+    boxes[8:12, :2] = [-30, -30]       # last column is 16 = round(249 / 16), so in-image boxes never leave it): the rounded window leaves the map
     outs = {}
     with hooks(graph_fuse=fuse):
         for rule in (1, 0):
