@@ -282,6 +282,13 @@ struct mpn_frcnn {
   float *tx2 = nullptr;                               // second pooled-operand buffer (towers alternate between tx and tx2)
   hipStream_t pool_stream = nullptr;
   hipEvent_t ev_pool_done[2] = {nullptr, nullptr}, ev_mix_done[2] = {nullptr, nullptr}, ev_pool_go = nullptr;
+  // two tower LANES (round 6): the towers of one image are independent until the concat (ModelParallelTable.lua:195-242 ran them on
+  // different GPUs), so towers 1, 3 run on the handle's second tower stream with their own mix / fc6 buffers beside towers 0, 2, 4 on the
+  // caller's stream: one lane's short-K mix GEMM (6.1 block rounds on 256 CUs, 40 stages per tile) and the prologue / epilogue of every
+  // launch run under the other lane's fc6 / fc7 instead of leaving the matrix pipe idle.  Pure scheduling: bit-identical results.
+  hipStream_t tower_stream = nullptr;
+  hipEvent_t ev_lane_go = nullptr, ev_lane_done = nullptr;
+  float *ty2 = nullptr, *tz6_2 = nullptr;
   std::vector<void *> allocs;
   Scratch scratch;  // split-K slabs, NMS masks, ... of THIS handle (bound to the calling thread by ScratchScope in every entry point)
   int device = 0;   // the handle lives on the device that was current at creation
@@ -353,6 +360,7 @@ MPN_KNOB(int, g_fuse_pool, 1);
 MPN_KNOB(int, g_first_k36, 1);  // 0: the first layer on the generic direct kernel
 MPN_KNOB(int, g_roi_pool_pm, 1);  // 0: ROI pooling straight from the C8P map (roi_pool_c8_kernel)
 MPN_KNOB(int, g_mix_fold, 1);     // 0: MultiPathNet's nn.Normalize scales applied in place (l2norm_apply) instead of inside the mix GEMM
+MPN_KNOB(int, g_tower_lanes, 1);  // 0: the towers of an image one after the other on the caller's stream (rounds 2-5) instead of two lanes (mpn_debug_set_tower_lanes)
 MPN_KNOB(int, g_pool_overlap, 1); // 0: MultiPathNet's skip pooling on the launch stream instead of its own stream under the previous tower's GEMMs
 MPN_KNOB(int, g_defer_heads, 1);  // 0: the pipelined forms keep heads / softmax / decode / select on the launch stream (rounds 1-5a); 2 (test): the
                                   // side stream is held back 1 ms before the heads, so that the launch stream runs far ahead of it
@@ -369,6 +377,7 @@ extern "C" void mpn_debug_set_first_k36(int v) { g_first_k36 = v; }
 extern "C" void mpn_debug_set_roi_pool_pm(int v) { g_roi_pool_pm = v; }
 extern "C" void mpn_debug_set_mix_fold(int v) { g_mix_fold = v; }
 extern "C" void mpn_debug_set_pool_overlap(int v) { g_pool_overlap = v; }
+extern "C" void mpn_debug_set_tower_lanes(int v) { g_tower_lanes = v; }
 extern "C" void mpn_debug_set_halo_memset(int v) { g_halo_memset = v; }
 extern "C" void mpn_debug_set_defer_heads(int v) { g_defer_heads = v; }
 #endif
@@ -399,6 +408,9 @@ extern "C" void mpn_frcnn_destroy(mpn_frcnn *p) {
   if (p->pool_stream) (void)hipStreamDestroy(p->pool_stream);
   for (int i = 0; i < 2; ++i) { if (p->ev_pool_done[i]) (void)hipEventDestroy(p->ev_pool_done[i]); if (p->ev_mix_done[i]) (void)hipEventDestroy(p->ev_mix_done[i]); }
   if (p->ev_pool_go) (void)hipEventDestroy(p->ev_pool_go);
+  if (p->tower_stream) (void)hipStreamDestroy(p->tower_stream);
+  if (p->ev_lane_go) (void)hipEventDestroy(p->ev_lane_go);
+  if (p->ev_lane_done) (void)hipEventDestroy(p->ev_lane_done);
   if (p->copy) (void)hipStreamDestroy(p->copy);
   for (int i = 0; i < mpn_frcnn::kStage; ++i) { if (p->ev_up[i]) (void)hipEventDestroy(p->ev_up[i]); if (p->ev_consumed[i]) (void)hipEventDestroy(p->ev_consumed[i]); }
   p->scratch.release();
@@ -548,6 +560,14 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
     TRY(dev_alloc(p, &p->tx, (size_t)(round_up(max_feat, 64) / 8) * rows * 8 * sizeof(float), true));
     TRY(dev_alloc(p, &p->ty, (size_t)(lin_np(c5) / 8) * rows * 8 * sizeof(float), true));
     TRY(dev_alloc(p, &p->tz6, (size_t)(lin_np(F) / 8) * p->Mp * 8 * sizeof(float), true));
+    if (mw->n_towers > 1) {  // the second tower lane
+      TRY(dev_alloc(p, &p->ty2, (size_t)(lin_np(c5) / 8) * rows * 8 * sizeof(float), true));
+      TRY(dev_alloc(p, &p->tz6_2, (size_t)(lin_np(F) / 8) * p->Mp * 8 * sizeof(float), true));
+      hipError_t e = hipStreamCreateWithFlags(&p->tower_stream, hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_lane_go, hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_lane_done, hipEventDisableTiming);
+      if (e != hipSuccess) { set_error("mpn_mpnet_create: tower stream / events: %s", hipGetErrorString(e)); mpn_frcnn_destroy(p); return MPN_EHIP; }
+    }
     TRY(dev_alloc(p, &p->cat, (size_t)mw->n_towers * (lin_np(F) / 8) * p->Mp * 8 * sizeof(float), true));
     TRY(dev_alloc(p, &p->cls_rm, M * K * C * sizeof(float), true));
     TRY(dev_alloc(p, &p->bbox_rm, M * 4 * C * sizeof(float), true));
@@ -566,6 +586,12 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
     TRY(dev_alloc(p, &p->cls_rm, M * K * C * sizeof(float), true));
     TRY(dev_alloc(p, &p->bbox_rm, M * 4 * C * sizeof(float), true));
     for (int t = 0; t < tower_heads; ++t) { MPN_CHECK_ARG(tower_region[t] >= 0 && tower_region[t] < 4); p->rn_region.push_back(tower_region[t]); }
+    {  // the second tower lane's stream (run_detect)
+      hipError_t e = hipStreamCreateWithFlags(&p->tower_stream, hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_lane_go, hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_lane_done, hipEventDisableTiming);
+      if (e != hipSuccess) { set_error("mpn_resnet_create / mpn_graph_create: tower stream / events: %s", hipGetErrorString(e)); mpn_frcnn_destroy(p); return MPN_EHIP; }
+    }
   } else {
   if (!graph_net) {
   TRY(dev_alloc(p, &p->w6, lin_wpk_elems(K6_32, F) * sizeof(float), false));
@@ -783,29 +809,48 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
     return MPN_OK;
   };
   MPN_CHECK_ARG(n_tow <= 8);
+  // Two tower lanes (mpn_frcnn::tower_stream): tower ti runs on lane ti & 1 — its own stream, its own mix-output / fc6-output buffers, the
+  // pooled operand of parity ti & 1 as before.  The pooling stream runs one tower ahead of EACH lane (towers 0 and 1 up front, tower
+  // ti + 2 as soon as tower ti's mix GEMM — the reader of that parity's operand — is enqueued).  The lanes join before the classifiers.
+  // (profiling keeps one lane: its per-group scopes time the launch stream)
+  const bool lanes = overlap && p->tower_stream && p->ty2 && p->tz6_2 && g_tower_lanes && n_tow > 1 && !p->prof;
+  hipStream_t lane_s[2] = {s, lanes ? p->tower_stream : s};
+  float *lane_ty[2] = {p->ty, lanes ? p->ty2 : p->ty}, *lane_tz6[2] = {p->tz6, lanes ? p->tz6_2 : p->tz6};
+  if (lanes) {  // everything the towers read (Foveal regions, tables, the previous image's use of the lane buffers) is ordered on `s`
+    MPN_CHECK_HIP(hipEventRecord(p->ev_lane_go, s));
+    MPN_CHECK_HIP(hipStreamWaitEvent(lane_s[1], p->ev_lane_go, 0));
+  }
   rc = pool_tower(0);
   if (rc) return rc;
+  if (lanes) { rc = pool_tower(1); if (rc) return rc; }
   for (int ti = 0; ti < n_tow; ++ti) {
     const mpn_frcnn::Tower &T = p->towers[ti];
     const int par = overlap ? (ti & 1) : 0;
+    const int ln = lanes ? (ti & 1) : 0;
+    hipStream_t ls = lane_s[ln];
     const float *txb = par ? p->tx2 : p->tx;
     if (overlap) {
-      MPN_CHECK_HIP(hipStreamWaitEvent(s, p->ev_pool_done[par], 0));
-      if (ti + 1 < n_tow) { rc = pool_tower(ti + 1); if (rc) return rc; }  // enqueued now: runs under this tower's GEMMs
+      MPN_CHECK_HIP(hipStreamWaitEvent(ls, p->ev_pool_done[par], 0));
+      if (!lanes && ti + 1 < n_tow) { rc = pool_tower(ti + 1); if (rc) return rc; }  // enqueued now: runs under this tower's GEMMs
     }
     const GemmRowScale &grs = grs_of[ti];
     // 1x1 conv mix: rows = (bin, roi), K = concat channels, N = feat_c; output layout == fc6 operand layout
-    { ProfScope ps(p, MPN_PROF_HEADS, s);
-      rc = fold_scale ? linear_c8_rowscaled(txb, PP * Mp, T.total_feat, T.mix_w, T.mix_b, p->feat_c, 0, p->ty, s, PP * Mp, grs)
-                      : linear_c8(txb, PP * Mp, T.total_feat, T.mix_w, T.mix_b, p->feat_c, 0, p->ty, nullptr, s, PP * Mp, nullptr, 2); }
+    { ProfScope ps(p, MPN_PROF_HEADS, ls);
+      rc = fold_scale ? linear_c8_rowscaled(txb, PP * Mp, T.total_feat, T.mix_w, T.mix_b, p->feat_c, 0, lane_ty[ln], ls, PP * Mp, grs)
+                      : linear_c8(txb, PP * Mp, T.total_feat, T.mix_w, T.mix_b, p->feat_c, 0, lane_ty[ln], nullptr, ls, PP * Mp, nullptr, 2); }
     if (rc) return rc;
-    if (overlap) MPN_CHECK_HIP(hipEventRecord(p->ev_mix_done[par], s));
-    { ProfScope ps(p, MPN_PROF_FC6, s); rc = linear_c8(p->ty, N, p->K6, T.w6, T.b6, F, 1, p->tz6, nullptr, s, Mp, nullptr, 1); }
+    if (overlap) MPN_CHECK_HIP(hipEventRecord(p->ev_mix_done[par], ls));
+    if (lanes && ti + 2 < n_tow) { rc = pool_tower(ti + 2); if (rc) return rc; }  // waits for the mix GEMM just enqueued; runs under this lane's fc6 and the other lane's tower
+    { ProfScope ps(p, MPN_PROF_FC6, ls); rc = linear_c8(lane_ty[ln], N, p->K6, T.w6, T.b6, F, 1, lane_tz6[ln], nullptr, ls, Mp, nullptr, 1); }
     if (rc) return rc;
-    { ProfScope ps(p, MPN_PROF_FC7, s);
-      rc = linear_c8(p->tz6, N, F, T.w7, T.b7, F, 1, p->cat + (size_t)ti * Fcb * Mp * 8, nullptr, s, Mp, nullptr, 1); }
+    { ProfScope ps(p, MPN_PROF_FC7, ls);
+      rc = linear_c8(lane_tz6[ln], N, F, T.w7, T.b7, F, 1, p->cat + (size_t)ti * Fcb * Mp * 8, nullptr, ls, Mp, nullptr, 1); }
     if (rc) return rc;
     if (!overlap && ti + 1 < n_tow) { rc = pool_tower(ti + 1); if (rc) return rc; }
+  }
+  if (lanes) {
+    MPN_CHECK_HIP(hipEventRecord(p->ev_lane_done, lane_s[1]));
+    MPN_CHECK_HIP(hipStreamWaitEvent(s, p->ev_lane_done, 0));
   }
   return run_integral_heads(p, d_boxes, N, H, W, (int)p->towers.size() - 1, s, clamp);
 }
@@ -895,10 +940,27 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const 
     rc = mpn_foveal_forward(p->rois, N, p->fov, s);
     if (rc) return rc;
     const int Fcb = lin_np(F) / 8, Mp = lin_mp(N);
-    for (size_t t = 0; t < p->rn_region.size(); ++t) {
-      ProfScope ps(p, MPN_PROF_FC6, s);
-      rc = resnet_head_forward(p->rn, (int)t, p->fov + 5 * p->rn_region[t], 20, N, c.spatial_scale, p->cat + t * (size_t)Fcb * Mp * 8, Mp, s);
+    // Two tower lanes (see mpn_frcnn::tower_stream): tower t on lane t & 1 — its own stream and activation buffers; the sorted / range-max
+    // images of the feature map every tower pools from are built before the fork.  Tower t + 1's ROI pooling (a store-bound launch with no
+    // matrix work), the ragged last block round and the launch gaps of each of a tower's ~20-80 convolutions then run under the other
+    // lane's convolutions.  Pure scheduling: bit-identical results (the towers meet only in `cat`, each writing its own slice).
+    const bool lanes = p->tower_stream && resnet_has_second_lane(p->rn) && g_tower_lanes && p->rn_region.size() > 1 && !p->prof;
+    if (lanes) {
+      rc = resnet_heads_prepare(p->rn, s);
       if (rc) return rc;
+      MPN_CHECK_HIP(hipEventRecord(p->ev_lane_go, s));
+      MPN_CHECK_HIP(hipStreamWaitEvent(p->tower_stream, p->ev_lane_go, 0));
+    }
+    for (size_t t = 0; t < p->rn_region.size(); ++t) {
+      const int ln = lanes ? (int)(t & 1) : 0;
+      hipStream_t ls = ln ? p->tower_stream : s;
+      ProfScope ps(p, MPN_PROF_FC6, ls);
+      rc = resnet_head_forward(p->rn, (int)t, p->fov + 5 * p->rn_region[t], 20, N, c.spatial_scale, p->cat + t * (size_t)Fcb * Mp * 8, Mp, ls, ln);
+      if (rc) return rc;
+    }
+    if (lanes) {
+      MPN_CHECK_HIP(hipEventRecord(p->ev_lane_done, p->tower_stream));
+      MPN_CHECK_HIP(hipStreamWaitEvent(s, p->ev_lane_done, 0));
     }
     rc = run_integral_heads(p, d_boxes, N, H, W, (int)p->rn_region.size() - 1, s, clamp);
     p->last_n = N;

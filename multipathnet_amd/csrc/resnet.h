@@ -31,7 +31,11 @@ bool resnet_has_features(const ResNetGraph *g, int H, int W);
 int resnet_n_heads(const ResNetGraph *g);
 // rois (roi_stride floats apart; 5 = a plain [N,5] table, 20 = one region of a Foveal [4N,5] table) -> ROI pool -> tower `head`'s
 // layer4 -> average pool -> C8 matrix [out_c/8][Mp][8] (row = roi)
+// lane: which set of per-ROI activation buffers the tower uses (0, or 1 where resnet_has_second_lane): towers on different lanes may run
+// concurrently on different streams once resnet_heads_prepare has run for the image on a stream both are ordered after
 int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_stride, int N, float spatial_scale, float *d_feat_c8, int Mp,
-                        hipStream_t s);
+                        hipStream_t s, int lane = 0);
+int resnet_heads_prepare(ResNetGraph *g, hipStream_t s);
+bool resnet_has_second_lane(const ResNetGraph *g);
 
 }  // namespace mpn

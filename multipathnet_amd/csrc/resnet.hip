@@ -2536,6 +2536,12 @@ struct ResNetGraph {
   bool feat_vmax_valid = false;
   float *splitk_ws = nullptr;    // fp32 partial slabs of split-K convolutions (bf16 graph; one stream at a time, like tb / hb)
   int roi_bins = 0;              // MPN_ROI_BINS_* (resnet_set_roi_bins)
+  // second tower LANE (graphs with more than one head): a second set of per-ROI activation buffers, so that towers 1, 3 can run on a
+  // second stream beside towers 0, 2, 4 (resnet_head_forward's `lane`; pipeline.hip run_detect).  Weights, the feature map and its sorted /
+  // range-max images are shared (read-only while the towers run: resnet_heads_prepare builds them before the lanes fork).
+  std::vector<GTensor> t_head2;
+  float *hb2[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool has_lane2 = false;
   std::vector<void *> allocs;
 };
 constexpr size_t SPLITK_WS_BYTES = (size_t)96 << 20;
@@ -3037,16 +3043,27 @@ int resnet_build(const mpn_resnet_weights *rw, int max_h, int max_w, int max_roi
     RTRY(rn_alloc(g, &mi, act_bytes(mos_cin, rows, cols)));
     RTRY(rn_alloc(g, &mo, act_bytes(mos_cout, rows, cols)));
     if (hipMemset(mi, 0, act_bytes(mos_cin, rows, cols)) != hipSuccess || hipMemset(mo, 0, act_bytes(mos_cout, rows, cols)) != hipSuccess) { resnet_free(g); return MPN_EHIP; }
-    for (auto &hd : g->heads)
-      for (auto &blk : hd)
+    float *mi2 = mi, *mo2 = mo;
+    if (g->heads.size() > 1) {  // towers 1, 3, .. run on the second lane (resnet_head_forward): their own mosaic images
+      mi2 = mo2 = nullptr;
+      RTRY(rn_alloc(g, &mi2, act_bytes(mos_cin, rows, cols)));
+      RTRY(rn_alloc(g, &mo2, act_bytes(mos_cout, rows, cols)));
+      if (hipMemset(mi2, 0, act_bytes(mos_cin, rows, cols)) != hipSuccess || hipMemset(mo2, 0, act_bytes(mos_cout, rows, cols)) != hipSuccess) { resnet_free(g); return MPN_EHIP; }
+    }
+    for (size_t hi = 0; hi < g->heads.size(); ++hi)
+      for (auto &blk : g->heads[hi])
         for (auto &cv : blk.convs)
-          if (cv.wino) { cv.mos_in = mi; cv.mos_out = mo; cv.mos_mx = mx; cv.mos_rows = rows; cv.mos_cols = cols; }
+          if (cv.wino) { cv.mos_in = (hi & 1) ? mi2 : mi; cv.mos_out = (hi & 1) ? mo2 : mo; cv.mos_mx = mx; cv.mos_rows = rows; cv.mos_cols = cols; }
   }
   const size_t esz = g->bf16 ? sizeof(bf16_t) : sizeof(float);
   RTRY(rn_alloc(g, &g->img, c8i_elems(1, 16, max_h, max_w) * esz));
   if (g->conv1.col_w) RTRY(rn_alloc(g, &g->img_planar, (size_t)3 * max_h * max_w * sizeof(float)));
   for (int i = 0; i < 4; ++i) { RTRY(rn_alloc(g, &g->tb[i], te * esz)); MPN_CHECK_HIP(hipMemset(g->tb[i], 0, te * esz)); }
   for (int i = 0; i < 4; ++i) { RTRY(rn_alloc(g, &g->hb[i], he * esz)); MPN_CHECK_HIP(hipMemset(g->hb[i], 0, he * esz)); }  // pad planes must hold finite values
+  if (g->heads.size() > 1) {  // the second lane's rotating buffers
+    for (int i = 0; i < 4; ++i) { RTRY(rn_alloc(g, &g->hb2[i], he * esz)); MPN_CHECK_HIP(hipMemset(g->hb2[i], 0, he * esz)); }
+    g->has_lane2 = true;
+  }
 #undef RTRY
   MPN_CHECK_HIP(hipDeviceSynchronize());
   *out = g;
@@ -3329,6 +3346,18 @@ int graph_build(const mpn_graph_weights *gw, int max_h, int max_w, int max_rois,
     rc = rn_alloc(g, &t.buf, bytes);
     if (rc == MPN_OK && hipMemset(t.buf, 0, bytes) != hipSuccess) rc = MPN_EHIP;
   }
+  if (rc == MPN_OK && n_heads > 1) {  // the second lane's activations
+    g->t_head2 = g->t_head;
+    for (size_t i = 0; rc == MPN_OK && i < g->t_head2.size(); ++i) {
+      GTensor &t = g->t_head2[i];
+      if (t.H == 0 || t.alias_of >= 0) continue;
+      const size_t bytes = c8i_elems(max_rois, t.C, t.H, t.W) * esz;
+      t.buf = nullptr;
+      rc = rn_alloc(g, &t.buf, bytes);
+      if (rc == MPN_OK && hipMemset(t.buf, 0, bytes) != hipSuccess) rc = MPN_EHIP;
+    }
+    g->has_lane2 = rc == MPN_OK;
+  }
   if (rc != MPN_OK) { resnet_free(g); return rc; }
   g->feat_c = g->t_trunk[g->feat_tensor].C;
   g->out_c = g->t_head[g->out_tensor].C;
@@ -3512,55 +3541,79 @@ int resnet_trunk_forward(ResNetGraph *g, const float *d_image, int H, int W, con
   return MPN_OK;
 }
 
+// The per-image preparation of the bf16 ROI pooling — the order-preserving int16 image of the feature map and, where a head fuses the
+// max-pool of its pooled input, its vertical range-max levels — for head `head` (-1: whatever ANY head needs).  Built once per trunk run
+// (the valid flags), on `s`.
+static int heads_prepare_impl(ResNetGraph *g, int head, hipStream_t s) {
+  const int Cb = (g->feat_c + 7) / 8;
+  if (!(g->bf16 && (g_bf16_fast_pool & 1) && Cb % 4 == 0)) return MPN_OK;
+  const bool fuse_mp = g->is_graph && (g_graph_fuse & 4) && g->roi_bins == 0;
+  const ActI fa{g->feat, 1, g->feat_c, g->feat_h, g->feat_w};
+  const size_t need = (size_t)Cb * fa.pitch() * 8;
+  if (g->feat_sorted_elems < need) {  // first use (or a larger image than any before): outside the steady state
+    float *q = reinterpret_cast<float *>(g->feat_sorted);
+    g->feat_sorted = nullptr; g->feat_sorted_elems = 0;
+    int rc = rn_regrow(g, &q, need * sizeof(bf16_t));
+    if (rc) return rc;
+    g->feat_sorted = reinterpret_cast<bf16_t *>(q); g->feat_sorted_elems = need; g->feat_sorted_valid = false;
+  }
+  bool any_mp = false;
+  if (fuse_mp)
+    for (int h = 0; h < (int)g->g_heads.size(); ++h)
+      if (head < 0 || h == head)
+        for (const GOp &op : g->g_heads[h]) any_mp = any_mp || op.from_rois;
+  const int want_levels = (any_mp && (g_graph_fuse & 64) && g->feat_h > 1) ? 31 - __builtin_clz((unsigned)g->feat_h) : 0;
+  if (want_levels > 0 && (g->feat_vmax_elems < need || g->feat_vmax_levels < want_levels)) {  // outside the steady state, as above
+    float *q = reinterpret_cast<float *>(g->feat_vmax);
+    g->feat_vmax = nullptr; g->feat_vmax_elems = 0; g->feat_vmax_levels = 0;
+    int rc = rn_regrow(g, &q, need * sizeof(bf16_t) * want_levels);
+    if (rc) return rc;
+    g->feat_vmax = reinterpret_cast<bf16_t *>(q); g->feat_vmax_elems = need; g->feat_vmax_levels = want_levels; g->feat_vmax_valid = false;
+  }
+  if (!g->feat_sorted_valid) {
+    hipLaunchKernelGGL(bf16_sortable_kernel, dim3((unsigned)cdiv_sz(need / 8, 256)), dim3(256), 0, s, reinterpret_cast<const u32x4 *>(g->feat), need / 8,
+                       reinterpret_cast<u32x4 *>(g->feat_sorted));
+    MPN_CHECK_LAUNCH();
+    g->feat_sorted_valid = true;
+    g->feat_vmax_valid = false;
+  }
+  if (want_levels > 0 && !g->feat_vmax_valid) {  // once per image: level l from level l - 1 (level 0 = the sortable map)
+    for (int l = 1; l <= want_levels; ++l) {
+      const u32x4 *prev = l == 1 ? reinterpret_cast<const u32x4 *>(g->feat_sorted)
+                                 : reinterpret_cast<const u32x4 *>(g->feat_vmax) + (size_t)(l - 2) * (g->feat_vmax_elems / 8);
+      hipLaunchKernelGGL(vmax_level_sorted_kernel, dim3((unsigned)cdiv_sz((size_t)g->feat_h * g->feat_w * Cb, 256)), dim3(256), 0, s, prev,
+                         reinterpret_cast<u32x4 *>(g->feat_vmax) + (size_t)(l - 1) * (g->feat_vmax_elems / 8), g->feat_h, g->feat_w, fa.pitch(), Cb, 1 << (l - 1));
+      MPN_CHECK_LAUNCH();
+    }
+    g->feat_vmax_valid = true;
+  }
+  return MPN_OK;
+}
+int resnet_heads_prepare(ResNetGraph *g, hipStream_t s) {
+  MPN_CHECK_ARG(g && g->feat);
+  return heads_prepare_impl(g, -1, s);
+}
+bool resnet_has_second_lane(const ResNetGraph *g) { return g->has_lane2 && g_roi_invariant != 0; }  // (per-ROI layers that may split K share one slab workspace: one lane)
+
 int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_stride, int N, float spatial_scale, float *d_feat_c8, int Mp,
-                        hipStream_t s) {
+                        hipStream_t s, int lane) {
   MPN_CHECK_ARG(g && g->feat && d_rois && d_feat_c8 && N > 0 && N <= g->max_rois && head >= 0 && head < (int)g->heads.size());
+  MPN_CHECK_ARG(lane == 0 || (lane == 1 && g->has_lane2));
   const int Cb = (g->feat_c + 7) / 8, PH = g->pooled;
-  float *const pool_dst = g->is_graph ? g->t_head[0].buf : g->hb[0];
+  std::vector<GTensor> &t_head = lane ? g->t_head2 : g->t_head;
+  float *const *const hb = lane ? g->hb2 : g->hb;
+  float *const pool_dst = g->is_graph ? t_head[0].buf : hb[0];
   const bool fuse_mp = g->is_graph && g->bf16 && (g_bf16_fast_pool & 1) && Cb % 4 == 0 && (g_graph_fuse & 4) && g->roi_bins == 0;  // max-pools of the pooled input: from the map (its kernel unions the CUDA branch's bins: the adaptive rule runs the max-pool as an ordinary op on the pooled batch)
   bool fc_gemm = false;  // the head starts with a fully-connected layer: pool straight into its GEMM operand
   if (g->is_graph && !g->bf16 && g->fc_x && (g_graph_fuse & 8) && (g_bf16_fast_pool & 1) && Cb % 4 == 0)
     for (const GOp &op : g->g_heads[head]) fc_gemm = fc_gemm || op.fc_w != nullptr;
-  if (g->is_graph) { int rc = graph_dims(g->g_heads[head], g->t_head, PH, PH); if (rc) return rc; }
+  if (g->is_graph) { int rc = graph_dims(g->g_heads[head], t_head, PH, PH); if (rc) return rc; }
   {
     const size_t total = (size_t)N * Cb * PH * PH * 2;
     const ActI fa{g->feat, 1, g->feat_c, g->feat_h, g->feat_w}, pa{pool_dst, N, g->feat_c, PH, PH};
     if (g->bf16 && (g_bf16_fast_pool & 1) && Cb % 4 == 0) {
-      const size_t need = (size_t)Cb * fa.pitch() * 8;
-      if (g->feat_sorted_elems < need) {  // first use (or a larger image than any before): outside the steady state
-        float *q = reinterpret_cast<float *>(g->feat_sorted);
-        g->feat_sorted = nullptr; g->feat_sorted_elems = 0;
-        int rc = rn_regrow(g, &q, need * sizeof(bf16_t));
-        if (rc) return rc;
-        g->feat_sorted = reinterpret_cast<bf16_t *>(q); g->feat_sorted_elems = need; g->feat_sorted_valid = false;
-      }
-      bool any_mp = false;
-      if (fuse_mp) for (const GOp &op : g->g_heads[head]) any_mp = any_mp || op.from_rois;
-      const int want_levels = (any_mp && (g_graph_fuse & 64) && g->feat_h > 1) ? 31 - __builtin_clz((unsigned)g->feat_h) : 0;
-      if (want_levels > 0 && (g->feat_vmax_elems < need || g->feat_vmax_levels < want_levels)) {  // outside the steady state, as above
-        float *q = reinterpret_cast<float *>(g->feat_vmax);
-        g->feat_vmax = nullptr; g->feat_vmax_elems = 0; g->feat_vmax_levels = 0;
-        int rc = rn_regrow(g, &q, need * sizeof(bf16_t) * want_levels);
-        if (rc) return rc;
-        g->feat_vmax = reinterpret_cast<bf16_t *>(q); g->feat_vmax_elems = need; g->feat_vmax_levels = want_levels; g->feat_vmax_valid = false;
-      }
-      if (!g->feat_sorted_valid) {
-        hipLaunchKernelGGL(bf16_sortable_kernel, dim3((unsigned)cdiv_sz(need / 8, 256)), dim3(256), 0, s, reinterpret_cast<const u32x4 *>(g->feat), need / 8,
-                           reinterpret_cast<u32x4 *>(g->feat_sorted));
-        MPN_CHECK_LAUNCH();
-        g->feat_sorted_valid = true;
-        g->feat_vmax_valid = false;
-      }
-      if (want_levels > 0 && !g->feat_vmax_valid) {  // once per image: level l from level l - 1 (level 0 = the sortable map)
-        for (int l = 1; l <= want_levels; ++l) {
-          const u32x4 *prev = l == 1 ? reinterpret_cast<const u32x4 *>(g->feat_sorted)
-                                     : reinterpret_cast<const u32x4 *>(g->feat_vmax) + (size_t)(l - 2) * (g->feat_vmax_elems / 8);
-          hipLaunchKernelGGL(vmax_level_sorted_kernel, dim3((unsigned)cdiv_sz((size_t)g->feat_h * g->feat_w * Cb, 256)), dim3(256), 0, s, prev,
-                             reinterpret_cast<u32x4 *>(g->feat_vmax) + (size_t)(l - 1) * (g->feat_vmax_elems / 8), g->feat_h, g->feat_w, fa.pitch(), Cb, 1 << (l - 1));
-          MPN_CHECK_LAUNCH();
-        }
-        g->feat_vmax_valid = true;
-      }
+      { int rc_prep = heads_prepare_impl(g, head, s); if (rc_prep) return rc_prep; }  // (a no-op when resnet_heads_prepare already ran for this image)
+      const int want_levels = g->feat_vmax_valid ? g->feat_vmax_levels : 0;
 #ifdef MPN_DEBUG_HOOKS
       if (!(g_tower_knock & 1))
 #endif
@@ -3571,7 +3624,7 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
         for (const GOp &op : g->g_heads[head]) {
           if (!op.from_rois) continue;
           MPN_CHECK_LAUNCH();
-          const GTensor &dst = g->t_head[op.dst];
+          const GTensor &dst = t_head[op.dst];
           const ActI od{dst.buf, N, dst.C, dst.H, dst.W};
           char *outp = reinterpret_cast<char *>(dst.buf) + (size_t)(op.dst_c_off / 8) * od.pitch() * 8 * sizeof(bf16_t);  // plane offset = the concat
           hipLaunchKernelGGL(roi_maxpool_c8i_bf16_sorted_kernel<4>, dim3((unsigned)cdiv_sz((size_t)N * dst.H * dst.W, 256), (unsigned)(Cb / 4)), dim3(256), 0, s,
@@ -3603,16 +3656,16 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
   }
   ActI cur{pool_dst, N, g->feat_c, PH, PH}, y;
   if (g->is_graph) {
-    int rc = graph_run(g, g->g_heads[head], g->t_head, N, s, fuse_mp, fc_gemm);
+    int rc = graph_run(g, g->g_heads[head], t_head, N, s, fuse_mp, fc_gemm);
     if (rc) return rc;
-    const GTensor &o = g->t_head[g->out_tensor];
+    const GTensor &o = t_head[g->out_tensor];
     cur = ActI{o.buf, N, o.C, o.H, o.W};
   } else
   for (auto &blk : g->heads[head]) {
 #ifdef MPN_DEBUG_HOOKS
     if (g_tower_knock && &blk == &g->heads[head][0]) g_knock_arm = blk.has_sc ? 2 : 1;  // block 1's shortcut and conv1 read the pooled tensor
 #endif
-    int rc = rn_block(blk, cur, g->hb, s, &y, true);
+    int rc = rn_block(blk, cur, hb, s, &y, true);
 #ifdef MPN_DEBUG_HOOKS
     g_knock_arm = 0;
 #endif

@@ -702,3 +702,54 @@ def test_deferred_heads_hazards(dev, small, defer):
         n = int(snap_n[t_].item())
         assert n == ref[t_ % 3].shape[0], t_
         assert torch.equal(snap_d[t_][:n], ref[t_ % 3]), t_
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["vggmpn", "rn_mpn_f32", "rn_mpn_bf16", "inc_mpn_bf16"])
+def test_two_tower_lanes_are_invisible(dev, model):
+    """Round 6: the towers of one image run on two LANES (towers 1, 3 on the handle's tower stream with their own activation buffers beside
+    towers 0, 2, 4 on the caller's stream; the reference ran them on different GPUs, ModelParallelTable.lua:195-242).  Pure scheduling:
+    scores, boxes and the detection record are bit-identical to the one-lane order (hook tower_lanes = 0), call after call, with different
+    proposal counts in a row (a missing event between the lanes, the pooling stream and the launch stream would show up as a mismatch or
+    as run-to-run noise), through detect(), the fused test_one and the pipelined form."""
+    from multipathnet_amd import models
+    rng = np.random.default_rng(5)
+    if model == "vggmpn":
+        cfg = [16, 32, "P", 32, 64, "P", 64, 96, "P", 128, "P", 384]
+        H, W, N = 150, 250, 300
+        P = models.synthetic_mpnet_params(cfg, pooled=7, fc_dim=256, n_classes=9, n_integral=3, seed=11)
+        mk = lambda: models.MultiPathNet(P, cfg=cfg, pooled=7, spatial_scale=1 / 16, max_h=H, max_w=W, max_rois=N)
+    elif model.startswith("rn"):
+        H, W, N = 150, 250, 200
+        R = models.synthetic_resnet_mpn_params(depth=0, n_classes=7, n_integral=3, base_width=16, blocks=[1, 1, 1, 2], block_type="bottleneck", seed=31)
+        mk = lambda: models.ResNetFRCNN(R, max_h=H, max_w=W, max_rois=N, top_k=20, bf16=model.endswith("bf16"))
+    else:
+        H, W, N = 170, 215, 120
+        G = models.synthetic_inception_mpn_params(n_classes=5, n_integral=2, width=0.25, seed=17)
+        mk = lambda: models.InceptionFRCNN(G, max_h=H, max_w=W, max_rois=N, top_k=10, bf16=True)
+    im = torch.from_numpy(rng.random((3, H, W), dtype=np.float32)).to(dev)
+    bx = torch.from_numpy(_boxes(rng, N, W, H, lo=12)).to(dev)
+    res = {}
+    for lanes in (0, 1):
+        with hooks(tower_lanes=lanes):
+            net = mk()
+            out = []
+            for n in (N, N // 3, N, 7, N):
+                s, b = net.detect(im, bx[:n].contiguous())
+                out.append((s.clone(), b.clone()))
+            for _ in range(3):
+                dets, nd = net.test_one_async(im, bx)
+                torch.cuda.synchronize()
+                out.append((dets[: int(nd.item())].clone(), nd.clone()))
+            bufs = [net.test_one_pipelined(im, bx) for _ in range(4)]
+            net.flush()
+            torch.cuda.synchronize()
+            for dets, nd in bufs[-2:]:       # the two output sets alternate: the last two calls' records are both still there
+                out.append((dets[: int(nd.item())].clone(), nd.clone()))
+            res[lanes] = out
+            del net
+    assert len(res[0]) == len(res[1])
+    for a, b in zip(res[0], res[1]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert torch.equal(res[1][0][0], res[1][2][0]) and torch.equal(res[1][0][0], res[1][4][0])   # the same call gives the same rows every time
