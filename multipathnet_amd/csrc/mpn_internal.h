@@ -42,7 +42,7 @@ constexpr int kWave = 64;
 // with a mutex.  Work on a stream is ordered, so one Scratch per stream of work is race-free; two handles, two host
 // threads or two devices never share a buffer (the reference host runs one worker thread per GPU in ONE process,
 // test_runner.lua:55-66).
-enum ScratchSlot { SCR_CONV_SPLITK = 0, SCR_GEMM_SPLITK, SCR_L2NORM, SCR_NMS, SCR_LINEAR_PACK, SCR_GRAPH_SPLITK, SCR_MISC, SCR_IM2COL, SCR_NMS_CNT, SCR_GEMM_SPLITK_SIDE, SCR_NSLOTS };
+enum ScratchSlot { SCR_CONV_SPLITK = 0, SCR_GEMM_SPLITK, SCR_L2NORM, SCR_NMS, SCR_LINEAR_PACK, SCR_GRAPH_SPLITK, SCR_MISC, SCR_IM2COL, SCR_NMS_CNT, SCR_GEMM_SPLITK_SIDE, SCR_GEMM_SPLITK_LANE, SCR_NSLOTS };
 struct Scratch {
   int device = -1;
   void *buf[SCR_NSLOTS] = {};

@@ -280,8 +280,13 @@ struct mpn_frcnn {
   float *mix_scale = nullptr;                         // [2 tower parities][3][Mp]: per-(map, ROI) nn.Normalize scales the mix GEMM applies
   // tower t + 1's skip pooling (L2 -> L1 bound, no matrix work) runs on its own stream under tower t's GEMMs (matrix-bound):
   float *tx2 = nullptr;                               // second pooled-operand buffer (towers alternate between tx and tx2)
+  // round 6: two towers that pool the SAME Foveal region, one's maps a prefix of the other's (models/multipathnet.lua:74-113: the "het"
+  // tower = region 2 with conv5 + conv4 + conv3, tower 2 = region 2 with conv5 + conv4), share ONE pooled operand: the wider one is pooled
+  // once into tx3, the narrower tower's mix GEMM reads its K prefix (the per-map nn.Normalize scales are per (map, region, ROI): the same)
+  float *tx3 = nullptr;
+  int share_provider = -1, share_consumer = -1;       // tower indices (-1: no such pair)
   hipStream_t pool_stream = nullptr;
-  hipEvent_t ev_pool_done[2] = {nullptr, nullptr}, ev_mix_done[2] = {nullptr, nullptr}, ev_pool_go = nullptr;
+  hipEvent_t ev_pool_done[3] = {nullptr, nullptr, nullptr}, ev_mix_done[3] = {nullptr, nullptr, nullptr}, ev_pool_go = nullptr;
   // two tower LANES (round 6): the towers of one image are independent until the concat (ModelParallelTable.lua:195-242 ran them on
   // different GPUs), so towers 1, 3 run on the handle's second tower stream with their own mix / fc6 buffers beside towers 0, 2, 4 on the
   // caller's stream: one lane's short-K mix GEMM (6.1 block rounds on 256 CUs, 40 stages per tile) and the prologue / epilogue of every
@@ -361,6 +366,7 @@ MPN_KNOB(int, g_first_k36, 1);  // 0: the first layer on the generic direct kern
 MPN_KNOB(int, g_roi_pool_pm, 1);  // 0: ROI pooling straight from the C8P map (roi_pool_c8_kernel)
 MPN_KNOB(int, g_mix_fold, 1);     // 0: MultiPathNet's nn.Normalize scales applied in place (l2norm_apply) instead of inside the mix GEMM
 MPN_KNOB(int, g_tower_lanes, 1);  // 0: the towers of an image one after the other on the caller's stream (rounds 2-5) instead of two lanes (mpn_debug_set_tower_lanes)
+MPN_KNOB(int, g_tower_share, 1);  // 0: every tower pools its own operand even where two of them pool the same region's maps (mpn_debug_set_tower_share)
 MPN_KNOB(int, g_pool_overlap, 1); // 0: MultiPathNet's skip pooling on the launch stream instead of its own stream under the previous tower's GEMMs
 MPN_KNOB(int, g_defer_heads, 1);  // 0: the pipelined forms keep heads / softmax / decode / select on the launch stream (rounds 1-5a); 2 (test): the
                                   // side stream is held back 1 ms before the heads, so that the launch stream runs far ahead of it
@@ -378,6 +384,7 @@ extern "C" void mpn_debug_set_roi_pool_pm(int v) { g_roi_pool_pm = v; }
 extern "C" void mpn_debug_set_mix_fold(int v) { g_mix_fold = v; }
 extern "C" void mpn_debug_set_pool_overlap(int v) { g_pool_overlap = v; }
 extern "C" void mpn_debug_set_tower_lanes(int v) { g_tower_lanes = v; }
+extern "C" void mpn_debug_set_tower_share(int v) { g_tower_share = v; }
 extern "C" void mpn_debug_set_halo_memset(int v) { g_halo_memset = v; }
 extern "C" void mpn_debug_set_defer_heads(int v) { g_defer_heads = v; }
 #endif
@@ -406,7 +413,7 @@ extern "C" void mpn_frcnn_destroy(mpn_frcnn *p) {
   if (p->ev_fc7) (void)hipEventDestroy(p->ev_fc7);
   if (p->side) (void)hipStreamDestroy(p->side);
   if (p->pool_stream) (void)hipStreamDestroy(p->pool_stream);
-  for (int i = 0; i < 2; ++i) { if (p->ev_pool_done[i]) (void)hipEventDestroy(p->ev_pool_done[i]); if (p->ev_mix_done[i]) (void)hipEventDestroy(p->ev_mix_done[i]); }
+  for (int i = 0; i < 3; ++i) { if (p->ev_pool_done[i]) (void)hipEventDestroy(p->ev_pool_done[i]); if (p->ev_mix_done[i]) (void)hipEventDestroy(p->ev_mix_done[i]); }
   if (p->ev_pool_go) (void)hipEventDestroy(p->ev_pool_go);
   if (p->tower_stream) (void)hipStreamDestroy(p->tower_stream);
   if (p->ev_lane_go) (void)hipEventDestroy(p->ev_lane_go);
@@ -546,11 +553,23 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
     TRY(pack_linear_weights(d_bbox_w, d_bbox_b, F, 4 * C, 1, p->wbbox, p->bbbox, nullptr));
     const size_t rows = (size_t)PP * p->Mp;
     TRY(dev_alloc(p, &p->fov, M * 20 * sizeof(float), true));
-    TRY(dev_alloc(p, &p->mix_scale, (size_t)2 * 3 * p->Mp * sizeof(float), true));
+    TRY(dev_alloc(p, &p->mix_scale, (size_t)3 * 3 * p->Mp * sizeof(float), true));
     TRY(dev_alloc(p, &p->tx2, (size_t)(round_up(max_feat, 64) / 8) * rows * 8 * sizeof(float), true));
+    for (int a = 0; a < (int)p->towers.size() && p->share_provider < 0; ++a)      // the first (provider, consumer) pair, if any
+      for (int b = 0; b < (int)p->towers.size() && p->share_provider < 0; ++b) {
+        const mpn_frcnn::Tower &A = p->towers[a], &B = p->towers[b];
+        if (a == b || A.region != B.region || A.total_feat <= B.total_feat) continue;
+        int la[3], lb[3], na = 0, nb = 0;   // the towers' map lists in concat order (conv345Combine: conv5, [conv4], [conv3])
+        la[na++] = 0; if (A.use4) la[na++] = 1; if (A.use3) la[na++] = 2;
+        lb[nb++] = 0; if (B.use4) lb[nb++] = 1; if (B.use3) lb[nb++] = 2;
+        bool prefix = nb <= na;
+        for (int i = 0; prefix && i < nb; ++i) prefix = la[i] == lb[i];
+        if (prefix) { p->share_provider = a; p->share_consumer = b; }
+      }
+    if (p->share_provider >= 0) TRY(dev_alloc(p, &p->tx3, (size_t)(round_up(max_feat, 64) / 8) * rows * 8 * sizeof(float), true));
     {
       hipError_t e = hipStreamCreateWithFlags(&p->pool_stream, hipStreamNonBlocking);
-      for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+      for (int i = 0; i < 3 && e == hipSuccess; ++i) {
         e = hipEventCreateWithFlags(&p->ev_pool_done[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_mix_done[i], hipEventDisableTiming);
       }
@@ -586,7 +605,7 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
     TRY(dev_alloc(p, &p->cls_rm, M * K * C * sizeof(float), true));
     TRY(dev_alloc(p, &p->bbox_rm, M * 4 * C * sizeof(float), true));
     for (int t = 0; t < tower_heads; ++t) { MPN_CHECK_ARG(tower_region[t] >= 0 && tower_region[t] < 4); p->rn_region.push_back(tower_region[t]); }
-    {  // the second tower lane's stream (run_detect)
+    if (resnet_has_second_lane(p->rn)) {  // the second tower lane's stream (run_detect; debug flavour only)
       hipError_t e = hipStreamCreateWithFlags(&p->tower_stream, hipStreamNonBlocking);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_lane_go, hipEventDisableTiming);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_lane_done, hipEventDisableTiming);
@@ -771,32 +790,65 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
     MPN_CHECK_HIP(hipStreamWaitEvent(ps_stream, p->ev_pool_go, 0));
   }
   const int n_tow = (int)p->towers.size();
+  MPN_CHECK_ARG(n_tow <= 8);
+  // ---- the operand plan of this image: which pooled-operand buffer each tower's mix GEMM reads, and which tower's arrival pools it.
+  // Plain towers alternate between tx and tx2 (buffers 0 / 1); the (provider, consumer) pair of mpn_frcnn::share_provider shares tx3
+  // (buffer 2): whichever of the two comes first pools the PROVIDER's maps there, the other one finds them.  prev_user = the tower whose
+  // mix GEMM read the buffer last (its ev_mix_done is what a re-pooling waits for; by construction it is at least two towers back, so
+  // its mix GEMM has been enqueued whenever the pooling is).
+  const bool share = overlap && p->tx3 && p->share_provider >= 0 && g_tower_share;
+  float *const tx_of[3] = {p->tx, p->tx2, p->tx3};
+  int buf_of[8], prev_user[8], pool_src[8];
+  bool pools[8];
+  {
+    int nplain = 0, last_user[3] = {-1, -1, -1};
+    bool shared_pooled = false;
+    for (int t = 0; t < n_tow; ++t) {
+      if (share && (t == p->share_provider || t == p->share_consumer)) {
+        buf_of[t] = 2; pools[t] = !shared_pooled; shared_pooled = true; pool_src[t] = p->share_provider;
+      } else {
+        buf_of[t] = overlap ? (nplain & 1) : 0; ++nplain; pools[t] = true; pool_src[t] = t;
+      }
+      prev_user[t] = pools[t] ? last_user[buf_of[t]] : -1;
+      last_user[buf_of[t]] = t;
+    }
+  }
   GemmRowScale grs_of[8];
-  auto pool_tower = [&](int t) -> int {  // pooling (+ normalisation scales) of tower t on the pooling stream
+  for (int t = 0; t < n_tow; ++t) {  // the per-(map, ROI) scale vectors tower t's mix GEMM applies: those of its buffer, its own K segments
     const mpn_frcnn::Tower &T = p->towers[t];
-    const int par = overlap ? (t & 1) : 0;
-    float *txb = par ? p->tx2 : p->tx;
-    const float *reg = p->fov + 5 * T.region;  // rows 4n + region of the Foveal table
-    if (overlap && t >= 2) MPN_CHECK_HIP(hipStreamWaitEvent(ps_stream, p->ev_mix_done[par], 0));  // tower t - 2's mix GEMM has read this buffer
-    int cb_off = 0;
-    const int used[3] = {1, T.use4, T.use3};
     GemmRowScale &grs = grs_of[t];
     grs = GemmRowScale{};
     grs.rs_mod = Mp;
+    if (!fold_scale) continue;
+    const int used[3] = {1, T.use4, T.use3};
+    int cb_off = 0;
+    for (int m = 0; m < 3; ++m) {
+      if (!used[m]) continue;
+      grs.scale[grs.n_seg] = p->mix_scale + ((size_t)buf_of[t] * 3 + grs.n_seg) * p->Mp;
+      if (grs.n_seg < 2) grs.k_end[grs.n_seg] = (cb_off + maps[m].Cb()) * 8;
+      ++grs.n_seg;
+      cb_off += maps[m].Cb();
+    }
+  }
+  auto pool_tower = [&](int t) -> int {  // pooling (+ normalisation scales) of tower t's operand on the pooling stream
+    if (!pools[t]) return MPN_OK;          // the other tower of the shared pair pooled it
+    const mpn_frcnn::Tower &T = p->towers[pool_src[t]];
+    const int b = buf_of[t];
+    float *txb = tx_of[b];
+    const float *reg = p->fov + 5 * T.region;  // rows 4n + region of the Foveal table
+    if (overlap && prev_user[t] >= 0) MPN_CHECK_HIP(hipStreamWaitEvent(ps_stream, p->ev_mix_done[b], 0));  // the buffer's last reader
+    int cb_off = 0, seg = 0;
+    const int used[3] = {1, T.use4, T.use3};
     int rcl = MPN_OK;
     for (int m = 0; m < 3; ++m) {
       if (!used[m]) continue;
       float *dst = txb + (size_t)cb_off * PP * Mp * 8;
       { ProfScope ps(p, MPN_PROF_ROIPOOL, ps_stream);
         if (pm) {
-          float *sc_out = fold_scale ? p->mix_scale + ((size_t)par * 3 + grs.n_seg) * p->Mp : nullptr;
+          float *sc_out = fold_scale ? p->mix_scale + ((size_t)b * 3 + seg) * p->Mp : nullptr;
           rcl = roi_pool_pm_rmq(maps[m], p->vmax_tab[m], reg, N, c.pooled_h, c.pooled_w, scales[m], RoiRule{1.0f, 0, c.roi_bin_rule}, dst, ps_stream, 20, Mp, p->conv345_norm ? 1 : 0,
                                 p->conv345_norm ? 1000.0f : kConv345Factor[m], sc_out);
-          if (fold_scale) {
-            grs.scale[grs.n_seg] = sc_out;
-            if (grs.n_seg < 2) grs.k_end[grs.n_seg] = (cb_off + maps[m].Cb()) * 8;
-            ++grs.n_seg;
-          }
+          ++seg;
         } else {
           rcl = roi_pool_c8_rmq(maps[m], p->vmax_tab[m], reg, N, c.pooled_h, c.pooled_w, scales[m], RoiRule{1.0f, 0, c.roi_bin_rule}, dst, ps_stream, 20, Mp);
           if (rcl == MPN_OK) rcl = p->conv345_norm ? l2norm_scale_c8(dst, maps[m].Cb() * PP, Mp, N, 1000.0f, ps_stream)
@@ -805,14 +857,12 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
       if (rcl) return rcl;
       cb_off += maps[m].Cb();
     }
-    if (overlap) MPN_CHECK_HIP(hipEventRecord(p->ev_pool_done[par], ps_stream));
+    if (overlap) MPN_CHECK_HIP(hipEventRecord(p->ev_pool_done[b], ps_stream));
     return MPN_OK;
   };
-  MPN_CHECK_ARG(n_tow <= 8);
-  // Two tower lanes (mpn_frcnn::tower_stream): tower ti runs on lane ti & 1 — its own stream, its own mix-output / fc6-output buffers, the
-  // pooled operand of parity ti & 1 as before.  The pooling stream runs one tower ahead of EACH lane (towers 0 and 1 up front, tower
-  // ti + 2 as soon as tower ti's mix GEMM — the reader of that parity's operand — is enqueued).  The lanes join before the classifiers.
-  // (profiling keeps one lane: its per-group scopes time the launch stream)
+  // Two tower lanes (mpn_frcnn::tower_stream): tower ti runs on lane ti & 1 — its own stream, its own mix-output / fc6-output buffers.
+  // The pooling stream runs one tower ahead of EACH lane (towers 0 and 1 up front, tower ti + 2 as soon as tower ti's mix GEMM is
+  // enqueued).  The lanes join before the classifiers.  (profiling keeps one lane: its per-group scopes time the launch stream)
   const bool lanes = overlap && p->tower_stream && p->ty2 && p->tz6_2 && g_tower_lanes && n_tow > 1 && !p->prof;
   hipStream_t lane_s[2] = {s, lanes ? p->tower_stream : s};
   float *lane_ty[2] = {p->ty, lanes ? p->ty2 : p->ty}, *lane_tz6[2] = {p->tz6, lanes ? p->tz6_2 : p->tz6};
@@ -825,12 +875,13 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
   if (lanes) { rc = pool_tower(1); if (rc) return rc; }
   for (int ti = 0; ti < n_tow; ++ti) {
     const mpn_frcnn::Tower &T = p->towers[ti];
-    const int par = overlap ? (ti & 1) : 0;
+    const int b = buf_of[ti];
     const int ln = lanes ? (ti & 1) : 0;
     hipStream_t ls = lane_s[ln];
-    const float *txb = par ? p->tx2 : p->tx;
+    SplitkSlotScope lane_slabs(ln ? SCR_GEMM_SPLITK_LANE : SCR_GEMM_SPLITK);  // a GEMM of few tiles (small ROI shards) runs split-K: each lane its own slabs
+    const float *txb = tx_of[b];
     if (overlap) {
-      MPN_CHECK_HIP(hipStreamWaitEvent(ls, p->ev_pool_done[par], 0));
+      MPN_CHECK_HIP(hipStreamWaitEvent(ls, p->ev_pool_done[b], 0));
       if (!lanes && ti + 1 < n_tow) { rc = pool_tower(ti + 1); if (rc) return rc; }  // enqueued now: runs under this tower's GEMMs
     }
     const GemmRowScale &grs = grs_of[ti];
@@ -839,8 +890,8 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
       rc = fold_scale ? linear_c8_rowscaled(txb, PP * Mp, T.total_feat, T.mix_w, T.mix_b, p->feat_c, 0, lane_ty[ln], ls, PP * Mp, grs)
                       : linear_c8(txb, PP * Mp, T.total_feat, T.mix_w, T.mix_b, p->feat_c, 0, lane_ty[ln], nullptr, ls, PP * Mp, nullptr, 2); }
     if (rc) return rc;
-    if (overlap) MPN_CHECK_HIP(hipEventRecord(p->ev_mix_done[par], ls));
-    if (lanes && ti + 2 < n_tow) { rc = pool_tower(ti + 2); if (rc) return rc; }  // waits for the mix GEMM just enqueued; runs under this lane's fc6 and the other lane's tower
+    if (overlap) MPN_CHECK_HIP(hipEventRecord(p->ev_mix_done[b], ls));
+    if (lanes && ti + 2 < n_tow) { rc = pool_tower(ti + 2); if (rc) return rc; }  // waits for its buffer's last reader; runs under this lane's fc6 and the other lane's tower
     { ProfScope ps(p, MPN_PROF_FC6, ls); rc = linear_c8(lane_ty[ln], N, p->K6, T.w6, T.b6, F, 1, lane_tz6[ln], nullptr, ls, Mp, nullptr, 1); }
     if (rc) return rc;
     { ProfScope ps(p, MPN_PROF_FC7, ls);
@@ -944,7 +995,10 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const 
     // images of the feature map every tower pools from are built before the fork.  Tower t + 1's ROI pooling (a store-bound launch with no
     // matrix work), the ragged last block round and the launch gaps of each of a tower's ~20-80 convolutions then run under the other
     // lane's convolutions.  Pure scheduling: bit-identical results (the towers meet only in `cat`, each writing its own slice).
-    const bool lanes = p->tower_stream && resnet_has_second_lane(p->rn) && g_tower_lanes && p->rn_region.size() > 1 && !p->prof;
+    // MEASURED (profiles/r06_tower_lanes_ab.txt): 10.86 -> 10.87 ms on configs[3] bf16, 23.61 -> 23.69 ms on configs[4] — nothing: two
+    // towers' convolutions contend for the same vector-memory path that bounds each of them alone (the VGG towers' matrix-bound GEMMs are
+    // a different story: 13.71 -> 13.43 ms, run_mpnet_head).  The graph lanes therefore exist in the debug flavour only (tower_lanes = 2).
+    const bool lanes = p->tower_stream && resnet_has_second_lane(p->rn) && g_tower_lanes == 2 && p->rn_region.size() > 1 && !p->prof;
     if (lanes) {
       rc = resnet_heads_prepare(p->rn, s);
       if (rc) return rc;
@@ -954,6 +1008,7 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const 
     for (size_t t = 0; t < p->rn_region.size(); ++t) {
       const int ln = lanes ? (int)(t & 1) : 0;
       hipStream_t ls = ln ? p->tower_stream : s;
+      SplitkSlotScope lane_slabs(ln ? SCR_GEMM_SPLITK_LANE : SCR_GEMM_SPLITK);  // (fp32 graphs: a pointwise layer of few tiles on the split-K GEMM)
       ProfScope ps(p, MPN_PROF_FC6, ls);
       rc = resnet_head_forward(p->rn, (int)t, p->fov + 5 * p->rn_region[t], 20, N, c.spatial_scale, p->cat + t * (size_t)Fcb * Mp * 8, Mp, ls, ln);
       if (rc) return rc;

@@ -3044,12 +3044,14 @@ int resnet_build(const mpn_resnet_weights *rw, int max_h, int max_w, int max_roi
     RTRY(rn_alloc(g, &mo, act_bytes(mos_cout, rows, cols)));
     if (hipMemset(mi, 0, act_bytes(mos_cin, rows, cols)) != hipSuccess || hipMemset(mo, 0, act_bytes(mos_cout, rows, cols)) != hipSuccess) { resnet_free(g); return MPN_EHIP; }
     float *mi2 = mi, *mo2 = mo;
+#ifdef MPN_DEBUG_HOOKS
     if (g->heads.size() > 1) {  // towers 1, 3, .. run on the second lane (resnet_head_forward): their own mosaic images
       mi2 = mo2 = nullptr;
       RTRY(rn_alloc(g, &mi2, act_bytes(mos_cin, rows, cols)));
       RTRY(rn_alloc(g, &mo2, act_bytes(mos_cout, rows, cols)));
       if (hipMemset(mi2, 0, act_bytes(mos_cin, rows, cols)) != hipSuccess || hipMemset(mo2, 0, act_bytes(mos_cout, rows, cols)) != hipSuccess) { resnet_free(g); return MPN_EHIP; }
     }
+#endif
     for (size_t hi = 0; hi < g->heads.size(); ++hi)
       for (auto &blk : g->heads[hi])
         for (auto &cv : blk.convs)
@@ -3060,10 +3062,12 @@ int resnet_build(const mpn_resnet_weights *rw, int max_h, int max_w, int max_roi
   if (g->conv1.col_w) RTRY(rn_alloc(g, &g->img_planar, (size_t)3 * max_h * max_w * sizeof(float)));
   for (int i = 0; i < 4; ++i) { RTRY(rn_alloc(g, &g->tb[i], te * esz)); MPN_CHECK_HIP(hipMemset(g->tb[i], 0, te * esz)); }
   for (int i = 0; i < 4; ++i) { RTRY(rn_alloc(g, &g->hb[i], he * esz)); MPN_CHECK_HIP(hipMemset(g->hb[i], 0, he * esz)); }  // pad planes must hold finite values
+#ifdef MPN_DEBUG_HOOKS
   if (g->heads.size() > 1) {  // the second lane's rotating buffers
     for (int i = 0; i < 4; ++i) { RTRY(rn_alloc(g, &g->hb2[i], he * esz)); MPN_CHECK_HIP(hipMemset(g->hb2[i], 0, he * esz)); }
     g->has_lane2 = true;
   }
+#endif
 #undef RTRY
   MPN_CHECK_HIP(hipDeviceSynchronize());
   *out = g;
@@ -3346,6 +3350,7 @@ int graph_build(const mpn_graph_weights *gw, int max_h, int max_w, int max_rois,
     rc = rn_alloc(g, &t.buf, bytes);
     if (rc == MPN_OK && hipMemset(t.buf, 0, bytes) != hipSuccess) rc = MPN_EHIP;
   }
+#ifdef MPN_DEBUG_HOOKS  // measured without a gain on the graph towers (pipeline.hip run_detect): the second lane is not built into the product library
   if (rc == MPN_OK && n_heads > 1) {  // the second lane's activations
     g->t_head2 = g->t_head;
     for (size_t i = 0; rc == MPN_OK && i < g->t_head2.size(); ++i) {
@@ -3358,6 +3363,7 @@ int graph_build(const mpn_graph_weights *gw, int max_h, int max_w, int max_rois,
     }
     g->has_lane2 = rc == MPN_OK;
   }
+#endif
   if (rc != MPN_OK) { resnet_free(g); return rc; }
   g->feat_c = g->t_trunk[g->feat_tensor].C;
   g->out_c = g->t_head[g->out_tensor].C;

@@ -730,8 +730,13 @@ def test_two_tower_lanes_are_invisible(dev, model):
     im = torch.from_numpy(rng.random((3, H, W), dtype=np.float32)).to(dev)
     bx = torch.from_numpy(_boxes(rng, N, W, H, lo=12)).to(dev)
     res = {}
-    for lanes in (0, 1):
-        with hooks(tower_lanes=lanes):
+    # (lanes, share): share = the "het" tower and the tower of the same Foveal region pool ONE operand (mpn_frcnn::tx3) — also pure scheduling /
+    # buffer planning: the narrower tower's mix GEMM reads the K prefix of the wider one's pooled matrix, the same values it would pool itself
+    variants = [(0, 0), (1, 0), (0, 1), (1, 1)] if model == "vggmpn" else [(0, 1), (1, 1)]
+    for lanes, share in variants:
+        # the graph towers' lanes are a debug-flavour experiment (tower_lanes = 2: measured without a gain, profiles/r06_tower_lanes_ab.txt);
+        # the VGG MultiPathNet's are what ships (1)
+        with hooks(tower_lanes=lanes * (1 if model == "vggmpn" else 2), tower_share=share):
             net = mk()
             out = []
             for n in (N, N // 3, N, 7, N):
@@ -746,10 +751,13 @@ def test_two_tower_lanes_are_invisible(dev, model):
             torch.cuda.synchronize()
             for dets, nd in bufs[-2:]:       # the two output sets alternate: the last two calls' records are both still there
                 out.append((dets[: int(nd.item())].clone(), nd.clone()))
-            res[lanes] = out
+            res[(lanes, share)] = out
             del net
-    assert len(res[0]) == len(res[1])
-    for a, b in zip(res[0], res[1]):
-        for x, y in zip(a, b):
-            assert torch.equal(x, y)
-    assert torch.equal(res[1][0][0], res[1][2][0]) and torch.equal(res[1][0][0], res[1][4][0])   # the same call gives the same rows every time
+    base = res[variants[0]]
+    for v in variants[1:]:
+        assert len(res[v]) == len(base)
+        for a, b in zip(base, res[v]):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y), v
+    last = res[variants[-1]]
+    assert torch.equal(last[0][0], last[2][0]) and torch.equal(last[0][0], last[4][0])   # the same call gives the same rows every time

@@ -34,7 +34,7 @@ for cfg in which:
     im, boxes = torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev)
 
     def leg(lanes):
-        lib.mpn_debug_set_tower_lanes(lanes)
+        lib.mpn_debug_set_tower_lanes(lanes * (1 if cfg == "c3" else 2))   # graph towers: the lanes are a debug-flavour experiment (2)
         for _ in range(3):
             net.test_one_pipelined(im, boxes)
         net.flush(); torch.cuda.synchronize()
@@ -45,14 +45,18 @@ for cfg in which:
         lib.mpn_debug_set_tower_lanes(1)
         return (time.perf_counter() - t0) / K * 1e3
 
-    res = {0: [], 1: []}
+    legs = [(0, 0, "towers one after the other, each pools its own operand (rounds 2-5)"), (1, 0, "two tower lanes"), (1, 1, "two tower lanes + shared operand (what ships)")] \
+        if cfg == "c3" else [(0, 0, "towers one after the other (what ships)"), (1, 0, "two tower lanes")]
+    res = {l[:2]: [] for l in legs}
     for rep in range(3):
-        for k in (0, 1):
-            res[k].append(leg(k))
-    base = min(res[0])
+        for ln, sh, _ in legs:
+            lib.mpn_debug_set_tower_share(sh)
+            res[(ln, sh)].append(leg(ln))
+    lib.mpn_debug_set_tower_share(1)
+    base = min(res[legs[0][:2]])
     print("%s  (%d images per leg, 3 interleaved repeats, best of)" % (name, K))
-    for k, what in ((0, "towers one after the other (rounds 2-5)"), (1, "two tower lanes")):
-        b = min(res[k])
-        print("  lanes %d  %-42s %7.3f ms / image  (%+.2f ms, %+.1f %%)   all: %s" % (k, what, b, b - base, (b - base) / base * 100, " ".join("%.3f" % x for x in res[k])))
+    for ln, sh, what in legs:
+        b = min(res[(ln, sh)])
+        print("  lanes %d share %d  %-72s %7.3f ms / image  (%+.2f ms, %+.1f %%)   all: %s" % (ln, sh, what, b, b - base, (b - base) / base * 100, " ".join("%.3f" % x for x in res[(ln, sh)])))
     del net
     torch.cuda.empty_cache()
