@@ -2053,7 +2053,7 @@ __global__ void vmax_level_sorted_kernel(const u32x4 *__restrict__ prev, u32x4 *
   out[(size_t)cb * pitch + px] = r;
 }
 
-template <int CBG>  // channel blocks per thread (grid.y = Cb / CBG)
+template <int CBG, bool NT = false>  // channel blocks per thread (grid.y = Cb / CBG); NT: non-temporal stores (timing experiment, debug flavour)
 __global__ __launch_bounds__(256) void roi_pool_c8i_bf16_sorted_kernel(const u32x4 *__restrict__ feat, int H, int W, size_t pitch_f,
                                                                         const float *__restrict__ rois, int roi_stride, int N, int PH, int PW, float scale,
                                                                         u32x4 *__restrict__ out, size_t pitch_o, int roi_bins) {
@@ -2092,7 +2092,8 @@ __global__ __launch_bounds__(256) void roi_pool_c8i_bf16_sorted_kernel(const u32
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = empty ? 0u : bf16x2_sortable(m[c][e]);
-    op[(size_t)c * pitch_o] = o;
+    if constexpr (NT) __builtin_nontemporal_store(o, &op[(size_t)c * pitch_o]);
+    else op[(size_t)c * pitch_o] = o;
   }
 }
 
@@ -2650,6 +2651,7 @@ MPN_KNOB(int, g_bf16_bdir_ver, 1);  // mpn_debug_set_bf16_bdir_ver: 1 = compiler
 // that read the pooled tensor (Mixed_7a's fused 1x1 768 -> 384; layer4 block 1's conv1 and shortcut) run the B-direct kernel with every pixel
 // load hitting ONE resident 1-KiB window (ABL bit 5: nothing can fetch its operand cheaper than from the CU's own cache).
 static int g_tower_knock = 0;
+static int g_pool_exp = 0;   // mpn_debug_set_pool_exp: timing experiments of the bf16 ROI pooling launch (resnet_head_forward)
 static int g_knock_arm = 0;  // the next `g_knock_arm` rn_conv calls are first-layer convolutions (armed by the caller)
 #endif
 MPN_KNOB(int, g_roi_invariant, 1);  // mpn_debug_set_roi_invariant: 0 = per-ROI layers pick kernel / split by batch size as round 3 did (tests, timing)
@@ -3621,7 +3623,15 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
       { int rc_prep = heads_prepare_impl(g, head, s); if (rc_prep) return rc_prep; }  // (a no-op when resnet_heads_prepare already ran for this image)
       const int want_levels = g->feat_vmax_valid ? g->feat_vmax_levels : 0;
 #ifdef MPN_DEBUG_HOOKS
-      if (!(g_tower_knock & 1))
+      if (g_tower_knock & 1) {}
+      else if ((g_pool_exp & 3) && Cb % 8 == 0) {  // mpn_debug_set_pool_exp (timing experiments): bit 0 = 8 channel blocks per thread, bit 1 = non-temporal stores
+        const dim3 g8((unsigned)cdiv_sz((size_t)N * PH * PH, 256), (unsigned)(Cb / 8)), g4((unsigned)cdiv_sz((size_t)N * PH * PH, 256), (unsigned)(Cb / 4));
+#define MPN_POOL_ARGS reinterpret_cast<const u32x4 *>(g->feat_sorted), g->feat_h, g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale, reinterpret_cast<u32x4 *>(pool_dst), pa.pitch(), g->roi_bins
+        if ((g_pool_exp & 3) == 1) hipLaunchKernelGGL((roi_pool_c8i_bf16_sorted_kernel<8, false>), g8, dim3(256), 0, s, MPN_POOL_ARGS);
+        else if ((g_pool_exp & 3) == 2) hipLaunchKernelGGL((roi_pool_c8i_bf16_sorted_kernel<4, true>), g4, dim3(256), 0, s, MPN_POOL_ARGS);
+        else hipLaunchKernelGGL((roi_pool_c8i_bf16_sorted_kernel<8, true>), g8, dim3(256), 0, s, MPN_POOL_ARGS);
+#undef MPN_POOL_ARGS
+      } else
 #endif
       hipLaunchKernelGGL(roi_pool_c8i_bf16_sorted_kernel<4>, dim3((unsigned)cdiv_sz((size_t)N * PH * PH, 256), (unsigned)(Cb / 4)), dim3(256), 0, s,
                          reinterpret_cast<const u32x4 *>(g->feat_sorted), g->feat_h, g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale,
@@ -3766,6 +3776,7 @@ extern "C" int mpn_debug_bench_conv_bf16(int Cin, int Cout, int KH, int KW, int 
   return rc;
 }
 extern "C" void mpn_debug_set_tower_knock(int v) { mpn::g_tower_knock = v; }
+extern "C" void mpn_debug_set_pool_exp(int v) { mpn::g_pool_exp = v; }
 extern "C" void mpn_debug_set_bf16_dma(int v) { mpn::g_bf16_dma = v; }
 extern "C" void mpn_debug_set_roi_invariant(int v) { mpn::g_roi_invariant = v; }
 extern "C" void mpn_debug_set_bf16_exp(int v) { mpn::g_bf16_exp = v; }
