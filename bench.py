@@ -360,8 +360,9 @@ def _cfg_alexnet(models, args):  # BASELINE configs[0]
 
 def _cfg_vgg_frcnn_n(models, args):  # the HEADLINE model at another proposal count: `--config c2 --rois 2000` (auxiliary line, never the headline)
     n = int(args.rois)
+    split3 = getattr(args, "fc_arith", "fp32") == "split3"
     P = models.synthetic_params(models.VGG16_CFG, pooled=7, fc_dim=4096, n_classes=N_CLASSES, seed=557)
-    net = models.FastRCNN(P, max_h=H, max_w=W, max_rois=n)
+    net = models.FastRCNN(P, max_h=H, max_w=W, max_rois=n, fc_arith=1 if split3 else 0)
     cf = conv_flops(models.VGG16_CFG, H, W)
     wino = sum(f for f, v in cf if v == "conv_wino")
     head = 2.0 * (25088 * 4096 + 4096 * 4096 + 4096 * 5 * N_CLASSES)
@@ -370,6 +371,12 @@ def _cfg_vgg_frcnn_n(models, args):  # the HEADLINE model at another proposal co
     # compulsory HBM bytes of one image, every layer reading its input and writing its output once (fp32), weights once
     trunk_b = _vgg_trunk_bytes(models.VGG16_CFG, H, W)
     head_b = 4.0 * (n * 25088 * 2 + 25088 * 4096 + n * 4096 * 2 + 4096 * 4096 + n * 4096 * 2 + 4096 * 5 * N_CLASSES + n * 5 * N_CLASSES)
+    if split3:  # VERDICT r5 task 2: an AUXILIARY line with its own metric string and dtype; the headline stays pure fp32 MFMA
+        return dict(params=P, net=net, n_rois=n, flops=sum(f for f, _ in cf) + n * head, dtype="f32 (fc6: 3-plane bf16 split, 6 products, fp32 accumulate)", groups=groups,
+                    key="c2_split3_n%d" % n, cpu_baseline=None, alg_bytes=trunk_b + head_b,
+                    metric="proposals/sec (%d ROIs, 600x1000 img) VGG-16 Fast R-CNN, fc6 on the bf16 matrix pipe as an exact three-plane split with fp32 accumulation "
+                           "[MPN_FC_SPLIT3; auxiliary line, not the headline metric: the headline is pure fp32 MFMA]" % n,
+                    workload="VGG-16 Fast R-CNN, 1 image 600x1000 x %d ROIs per GPU per step, 21 classes, NMS 0.3, top-100; fc6 = v_mfma_f32_32x32x16_bf16 x 6 plane products" % n)
     return dict(params=P, net=net, n_rois=n, flops=sum(f for f, _ in cf) + n * head, dtype="f32", groups=groups, key="c2_n%d" % n, cpu_baseline=None,
                 alg_bytes=trunk_b + head_b,
                 metric="proposals/sec (%d ROIs, 600x1000 img) VGG-16 Fast R-CNN [the headline model at the proposal count of scripts/eval_fastrcnn_voc2007.sh; "
@@ -915,6 +922,9 @@ def main():
                     help="c2 (default) = the headline line, BASELINE configs[1].  c1 / c3 / c4 / c5 = the other BASELINE configs, each with its "
                          "own metric string (never the headline): same timed loop, whole-path rates only")
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16"], help="c4 only (c5 is bf16, the rest fp32)")
+    ap.add_argument("--fc-arith", default="fp32", choices=["fp32", "split3"],
+                    help="c2 only.  split3 = fc6 on the bf16 matrix pipe (both operands as exact three-plane bf16 splits, six products, fp32 accumulate: "
+                         "include/mpn.h MPN_FC_SPLIT3) — an AUXILIARY line with its own metric string and dtype, never the headline")
     ap.add_argument("--rois", type=int, default=N_ROIS,
                     help="c2 only: another proposal count for the headline model (e.g. 2000, scripts/eval_fastrcnn_voc2007.sh) -> an AUXILIARY line with its "
                          "own metric string; the default (1000) is the headline")
@@ -1009,7 +1019,7 @@ def main():
     # the mixed-size leg's pinned host inputs are staged NOW, like the headline's: (diagnostic: MPN_BENCH_MIXED_PIN_LATE=1 stages them when the leg starts)
     mixed_pin = [(torch.from_numpy(i).pin_memory(), torch.from_numpy(b).pin_memory()) for i, b in mixed_size_inputs()] if args.mixed_sizes else None
     other = None
-    if args.config != "c2" or args.rois != N_ROIS:
+    if args.config != "c2" or args.rois != N_ROIS or args.fc_arith != "fp32":
         other = _cfg_vgg_frcnn_n(models, args) if args.config == "c2" else OTHER_CONFIGS[args.config](models, args)
         P, net, n_rois_cfg = other["params"], other["net"], other["n_rois"]
         im_np, boxes_np = synthetic_inputs()
@@ -1206,6 +1216,13 @@ def main():
                    "kernels": kernels}
             if world == 1 and not args.no_cpu_baseline and other.get("cpu_baseline"):
                 out["cpu_baseline"] = other["cpu_baseline"](im_np, boxes_np)
+            if other["key"].startswith("c2_split3") and "fc6" in kernels:
+                fc6_ms = kernels["fc6"]["ms_per_image"]
+                out["fc6_split3"] = {"ms_per_image": fc6_ms, "what": "operand split (split3_planes_kernel) + gemm_c8_split3_kernel + splitk_reduce_kernel",
+                                     "bf16_mfma_flops_per_image": 6 * 2.0 * n_rois_cfg * 25088 * 4096,
+                                     "frac_of_bf16_mfma_peak_2.5PF": round(6 * 2.0 * n_rois_cfg * 25088 * 4096 / (fc6_ms * 1e-3) / 2500e12, 4),
+                                     "note": "the group's executed_frac_of_fp32_mfma_peak above prices fp32-equivalent FLOPs against the fp32 pipe's peak and may exceed 1: "
+                                             "the six bf16 products run on the bf16 pipe (16x the fp32 MFMA rate)"}
             print(json.dumps(out))
             sys.stdout.flush()
         if comm is not None:

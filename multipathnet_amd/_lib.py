@@ -30,7 +30,7 @@ class FrcnnConfig(C.Structure):
         ("bbox_mean", C.c_float * 4), ("bbox_std", C.c_float * 4), ("nms_thresh", C.c_float),
         ("score_thresh", C.c_float), ("top_k", C.c_int),
         ("num_iter", C.c_int), ("bbox_voting", C.c_int), ("bbox_vote_thresh", C.c_float), ("bbox_vote_score_pow", C.c_float),
-        ("scale_target", C.c_double), ("scale_max", C.c_double), ("use_rbox_scores", C.c_int), ("roi_bin_rule", C.c_int),
+        ("scale_target", C.c_double), ("scale_max", C.c_double), ("use_rbox_scores", C.c_int), ("roi_bin_rule", C.c_int), ("fc_arith", C.c_int),
     ]
 
 

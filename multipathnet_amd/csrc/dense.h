@@ -109,6 +109,10 @@ struct SplitkSlotScope {
 struct GemmRowScale { int n_seg; int k_end[2]; const float *scale[3]; int rs_mod; };
 int linear_c8_rowscaled(const float *d_x_c8, int M, int K, const float *d_wpk, const float *d_bpk, int N, int relu, float *d_y_c8, hipStream_t s,
                         int Mp_override, const GemmRowScale &rs);
+// fc6 on the bf16 matrix pipe with fp32 results (dense.hip: gemm_c8_split3_kernel): operands as three bf16 planes [3][K64 / 8][rows↑256][8]
+size_t split3_plane_elems(int K, int rows);
+int split3_planes(const float *d_c8, int K, int rows_src, int rows_valid, unsigned short *d_planes, hipStream_t s);
+int linear_c8_split3(const unsigned short *d_x3, int M, int K, const unsigned short *d_w3, const float *d_bpk, int N, int relu, float *d_y_c8, hipStream_t s);
 // ROI max-pool reading a C8P feature map and writing the C8 matrix the fc6 GEMM consumes:
 // chunk q = cb*PH*PW + bin, row = roi.  argmax (optional) [N,C,PH,PW] int32 as the NCHW kernel.
 // roi_stride: floats between consecutive rois (5; 20 selects one Foveal region out of the [4N,5] table);

@@ -1438,6 +1438,256 @@ static int linear_c8_impl(const float *d_x_c8, int M, int K, const float *d_wpk,
 }
 
 // =================================================================================================
+// fc6 on the bf16 matrix pipe with fp32 results: the three-plane split (VERDICT r5 task 2; models/vgg.lua:16,30)
+// =================================================================================================
+// An fp32 value is the exact sum of three bf16 values h + m + l (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m): 8 + 8 + 8 significand
+// bits), so x . w = sum over the nine plane products; the six with weight >= 2^-16 (hh, hm, mh, hl, lh, mm) are kept, the three at or below
+// 2^-24 of the product (ml, lm, ll: the size of the fp32 rounding of the product itself) are dropped.  Each kept product is a
+// v_mfma_f32_32x32x16_bf16 — bf16 x bf16 is exact in fp32, the accumulation is the MFMA's fp32 — and the bf16 pipe runs 16x the fp32 MFMA rate:
+// six instructions of 32 cycles replace eight fp32 MFMAs of 64 (K = 16), 2.67x less matrix time for 1.5x the operand bytes.
+//
+// Kernel: block = 256 (N, weight rows) x 256 (M, ROI rows) x one k16 step per stage, four waves of 128 x 128 (16 accumulators = all 256 AGPRs, one
+// wave per SIMD); per stage 48 KiB of operands (3 planes x 2 chunks x 256 rows x 16 B, both sides) arrive by LDS-DMA into a two-slot ring (stage st + 2 goes
+// into stage st's slot as soon as stage st starts: its fragments are already in registers), the fragments of the next stage are read between
+// the 96 MFMAs of the current one (one LDS or DMA instruction per MFMA slot, no VALU in the loop), ONE barrier per stage.  15.6 B / clock / CU of DMA, 31 B / clock / CU of LDS reads.
+// Split-K over a FIXED number of K ranges (a function of K alone: a row's summation order does not depend on the rows it is batched with), partial
+// slabs reduced in split order by splitk_reduce_kernel, which also adds the bias and applies the ReLU.
+typedef __bf16 s3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 s3_hwbf16x2 __attribute__((ext_vector_type(2)));
+typedef float s3_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int s3_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned s3_pack2(float lo, float hi) {  // bits 0-15 = bf16(lo), 16-31 = bf16(hi), round to nearest even (hardware conversion)
+  const s3_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, s3_hwbf16x2));
+}
+__device__ __forceinline__ float s3_lo(unsigned pk) { return __uint_as_float(pk << 16); }
+__device__ __forceinline__ float s3_hi(unsigned pk) { return __uint_as_float(pk & 0xffff0000u); }
+
+// fp32 C8 matrix [Kc][rows_src][8] -> three bf16 planes [3][Kc][rows_dst][8] (rows beyond rows_valid are left untouched: the planes are
+// allocated zeroed).  One thread per 8-float record.
+__global__ __launch_bounds__(256) void split3_planes_kernel(const float *__restrict__ src, int Kc, int rows_src, int rows_valid, int rows_dst,
+                                                            unsigned short *__restrict__ dst) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)Kc * rows_valid) return;
+  const int r = (int)(t % rows_valid); const size_t kc = t / rows_valid;
+  const f32x4 a = *reinterpret_cast<const f32x4 *>(src + (kc * rows_src + r) * 8), b = *reinterpret_cast<const f32x4 *>(src + (kc * rows_src + r) * 8 + 4);
+  const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float x0 = v[2 * i], x1 = v[2 * i + 1];
+    h[i] = s3_pack2(x0, x1);
+    const float r0 = x0 - s3_lo(h[i]), r1 = x1 - s3_hi(h[i]);       // exact (Sterbenz-type cancellation: h is x rounded to 8 bits)
+    m[i] = s3_pack2(r0, r1);
+    l[i] = s3_pack2(r0 - s3_lo(m[i]), r1 - s3_hi(m[i]));
+  }
+  const size_t plane = (size_t)Kc * rows_dst * 8, rec = (kc * rows_dst + r) * 8;
+  *reinterpret_cast<s3_u32x4 *>(dst + rec) = s3_u32x4{h[0], h[1], h[2], h[3]};
+  *reinterpret_cast<s3_u32x4 *>(dst + plane + rec) = s3_u32x4{m[0], m[1], m[2], m[3]};
+  *reinterpret_cast<s3_u32x4 *>(dst + 2 * plane + rec) = s3_u32x4{l[0], l[1], l[2], l[3]};
+}
+
+struct Split3Args {
+  const unsigned short *xp; int Mp;   // [3][Kc][Mp][8] bf16, Mp % 128 == 0
+  const unsigned short *wp; int NP;   // [3][Kc][NP][8] bf16, NP % 256 == 0
+  float *part; int part_np, part_mp;  // partial slabs [S][part_np / 8][part_mp][8] fp32 (the fp32 GEMM's slab geometry: splitk_reduce_kernel reads them)
+  int Kc, steps, steps_per_split, n_mt, n_nt, M, N;
+};
+
+constexpr int S3_TN = 256, S3_TM = 128;                       // block tile: weight rows x ROI rows
+constexpr int S3_A_BYTES = 3 * 2 * S3_TN * 16;                // 24 KiB: [plane][chunk][row] 16-byte records
+constexpr int S3_B_BYTES = 3 * 2 * S3_TM * 16;                // 12 KiB
+constexpr int S3_STAGE_BYTES = S3_A_BYTES + S3_B_BYTES;       // 36 KiB per k16 stage
+constexpr int S3_RING = 2;
+
+__global__ __launch_bounds__(256, 2) void gemm_c8_split3_kernel(Split3Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wn = wave >> 1, wm = wave & 1;                          // wave tile: 128 weight rows x 64 ROI rows
+  int b = blockIdx.x;
+  const int nb = gridDim.x;
+  if ((nb & 7) == 0) b = (b & 7) * (nb >> 3) + (b >> 3);           // the blocks of one XCD walk neighbouring tiles
+  const int nt = b / a.n_mt, mt = b - nt * a.n_mt;                 // all row tiles of one weight tile back to back: the weights are the big operand
+  const int n0 = nt * S3_TN, m0 = mt * S3_TM;
+  const int split = blockIdx.y;
+  const int st0 = split * a.steps_per_split, st1 = min(a.steps, st0 + a.steps_per_split);
+  if (st0 >= st1) return;
+
+  // DMA: a stage is 24 + 12 one-KiB wave-loads (64 rows of one (operand, plane, chunk) each); wave w issues items w, w + 4, ...: 9 per stage
+  const unsigned dma_lane = (unsigned)(lane * 16);
+  const unsigned lds0 = lds_byte_addr(lds);
+  const size_t w_plane = (size_t)a.Kc * a.NP * 8, x_plane = (size_t)a.Kc * a.Mp * 8;   // in bf16 elements
+  const unsigned short *const w_tile = a.wp + (size_t)n0 * 8, *const x_tile = a.xp + (size_t)m0 * 8;
+  auto issue = [&](int st, int slot, int j) {  // j = 0 .. 8: this wave's j-th item of the stage = item 4 j + wave (j compile-time: no branch)
+    if (j < 6) {                               // weights: (plane, chunk) = j, row quarter = wave
+      const int pl = j >> 1, ch = j & 1;
+      const unsigned short *src = w_tile + pl * w_plane + (size_t)(2 * st + ch) * a.NP * 8 + (size_t)wave * 64 * 8;
+      glds16_saddr(reinterpret_cast<const float *>(src), dma_lane, lds0 + (unsigned)(slot * S3_STAGE_BYTES + (j * S3_TN + wave * 64) * 16));
+    } else {                                   // ROI rows: (plane, chunk) = 2 (j - 6) + wave / 2, row half = wave % 2
+      const int pc = 2 * (j - 6) + (wave >> 1), q = wave & 1, pl = pc >> 1, ch = pc & 1;
+      const unsigned short *src = x_tile + pl * x_plane + (size_t)(2 * st + ch) * a.Mp * 8 + (size_t)q * 64 * 8;
+      glds16_saddr(reinterpret_cast<const float *>(src), dma_lane, lds0 + (unsigned)(slot * S3_STAGE_BYTES + S3_A_BYTES + (pc * S3_TM + q * 64) * 16));
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+  // fragments: A (weights) fragment (plane, mi) = the record of row wn * 128 + mi * 32 + l31, chunk `half`; B (ROI rows) (plane, ni) = row
+  // wm * 64 + ni * 32 + l31.  The h-plane fragments are double-buffered (the next stage's first products need them while this stage's last
+  // product still reads the current ones), the m- and l-plane fragments are single-buffered and reloaded for the next stage as soon as their
+  // last product of this stage has been issued: 24 fragments = 96 VGPRs beside the 128 accumulator registers (two blocks per CU).
+  typedef const s3_bf16x8 __attribute__((address_space(3))) *lds_frag_ptr;
+  unsigned fbase[S3_RING][2];  // LDS byte addresses, opaque: every read is base + a 16-bit immediate (plane * 8 / 4 KiB + sub-tile * 512 B)
+#pragma unroll
+  for (int sl = 0; sl < S3_RING; ++sl) {
+    fbase[sl][0] = lds0 + (unsigned)(sl * S3_STAGE_BYTES + (half * S3_TN + wn * 128 + l31) * 16);
+    fbase[sl][1] = lds0 + (unsigned)(sl * S3_STAGE_BYTES + S3_A_BYTES + (half * S3_TM + wm * 64 + l31) * 16);
+    asm volatile("" : "+v"(fbase[sl][0]));
+    asm volatile("" : "+v"(fbase[sl][1]));
+  }
+  auto rda = [&](int slot, int pl, int i) -> s3_bf16x8 { return *(lds_frag_ptr)(size_t)(fbase[slot][0] + (unsigned)(pl * (2 * S3_TN * 16) + i * (32 * 16))); };
+  auto rdb = [&](int slot, int pl, int i) -> s3_bf16x8 { return *(lds_frag_ptr)(size_t)(fbase[slot][1] + (unsigned)(pl * (2 * S3_TM * 16) + i * (32 * 16))); };
+  s3_bf16x8 ha[2][4], hb[2][2], ma[4], mb[2], la[4], lb[2];
+
+  // prologue: stages st0 (slot 0) and st0 + 1 (slot 1) in flight, the fragments of st0 in registers (h planes in set 0)
+#pragma unroll
+  for (int j = 0; j < 9; ++j) issue(st0, 0, j);
+#pragma unroll
+  for (int j = 0; j < 9; ++j) issue(min(st0 + 1, st1 - 1), 1, j);
+  asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { ha[0][i] = rda(0, 0, i); ma[i] = rda(0, 1, i); la[i] = rda(0, 2, i); }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { hb[0][i] = rdb(0, 0, i); mb[i] = rdb(0, 1, i); lb[i] = rdb(0, 2, i); }
+
+  // One stage = the six kept plane products in the order l.h, h.l, m.m, m.h, h.m, h.h (small terms first; 8 MFMAs each).  Between the MFMAs,
+  // one LDS / DMA instruction per slot.  BRANCH-FREE: past the last stage the prefetches repeat the last stage (clamped index; nobody reads them).
+  const int st_last = st1 - 1;
+  auto body = [&](int st, auto slot_tag) {   // the h set of a stage is its slot's parity
+    constexpr int SLOT = decltype(slot_tag)::value, SET = SLOT;
+    constexpr int S1 = SLOT ^ 1;   // the slot of stage st + 1; stage st + 2 goes back into SLOT: stage st's fragments all went to registers during stage st - 1
+    const int st2 = min(st + 2, st_last);
+    dma_wait_all();        // stage st + 1 has landed (this wave's pieces); the barrier publishes everyone's, and says every wave has finished stage st - 1,
+    __syncthreads();       // i.e. has read the last fragments of stage st out of SLOT
+#define S3_MFMA(A, B, MI, NI)                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    acc[MI][NI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, acc[MI][NI], 0, 0, 0);                   \
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {  // l.h   (+ the DMA items of stage st + 2 first: they have the rest of this stage to land)
+      const int mi = t >> 1, ni = t & 1;
+      S3_MFMA(la[mi], hb[SET][ni], mi, ni)
+      issue(st2, SLOT, t);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {  // h.l
+      const int mi = t >> 1, ni = t & 1;
+      S3_MFMA(ha[SET][mi], lb[ni], mi, ni)
+      if (t == 0) issue(st2, SLOT, 8);
+      else if (t < 5) la[t - 1] = rda(S1, 2, t - 1);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {  // m.m
+      const int mi = t >> 1, ni = t & 1;
+      S3_MFMA(ma[mi], mb[ni], mi, ni)
+      if (t < 2) lb[t] = rdb(S1, 2, t);
+      else if (t < 6) ha[SET ^ 1][t - 2] = rda(S1, 0, t - 2);
+      else hb[SET ^ 1][t - 6] = rdb(S1, 0, t - 6);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {  // m.h
+      const int mi = t >> 1, ni = t & 1;
+      S3_MFMA(ma[mi], hb[SET][ni], mi, ni)
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {  // h.m
+      const int mi = t >> 1, ni = t & 1;
+      S3_MFMA(ha[SET][mi], mb[ni], mi, ni)
+      if (t < 4) ma[t] = rda(S1, 1, t);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {  // h.h
+      const int mi = t >> 1, ni = t & 1;
+      S3_MFMA(ha[SET][mi], hb[SET][ni], mi, ni)
+      if (t < 2) mb[t] = rdb(S1, 1, t);
+    }
+#undef S3_MFMA
+  };
+  using T0 = std::integral_constant<int, 0>;
+  using T1 = std::integral_constant<int, 1>;
+  int st = st0;
+  while (st < st1) {
+    body(st, T0{}); if (++st >= st1) break;
+    body(st, T1{}); ++st;
+  }
+  dma_wait_all();  // the clamped prefetches of the last two stages still write this block's LDS: they must have landed before the block ends
+
+  // epilogue: the partial slab of this split, in the fp32 GEMM's slab geometry
+  float *yb = a.part + (size_t)split * (a.part_np / 8) * a.part_mp * 8;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = n0 + wn * 128 + mi * 32 + g * 8;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int m = m0 + wm * 64 + ni * 32 + l31;
+        const f32x4 v = {acc[mi][ni][g * 4 + 0], acc[mi][ni][g * 4 + 1], acc[mi][ni][g * 4 + 2], acc[mi][ni][g * 4 + 3]};
+        if (n < a.part_np && m < a.part_mp) *reinterpret_cast<f32x4 *>(yb + ((size_t)(n / 8) * a.part_mp + m) * 8 + half * 4) = v;
+      }
+    }
+}
+
+size_t split3_plane_elems(int K, int rows) { return (size_t)3 * (round_up(K, 64) / 8) * round_up(rows, 256) * 8; }  // bf16 elements of a three-plane operand (rows padded to the 256-row weight tile)
+
+// fp32 C8 matrix (K64 / 8 chunks of `rows_src` rows; the packed weights [K/8][NP][8] or the activations [K/8][Mp][8]) -> its three bf16 planes
+int split3_planes(const float *d_c8, int K, int rows_src, int rows_valid, unsigned short *d_planes, hipStream_t s) {
+  MPN_CHECK_ARG(d_c8 && d_planes && K > 0 && rows_valid > 0 && rows_valid <= rows_src);
+  const int Kc = round_up(K, 64) / 8;
+  const size_t total = (size_t)Kc * rows_valid;
+  hipLaunchKernelGGL(split3_planes_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, d_c8, Kc, rows_src, rows_valid, round_up(rows_src, 256), d_planes);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+// y = relu?(x . w^T + b) with both operands given as three-plane splits; y in the fp32 C8 layout [NP / 8][Mp][8] (Mp = lin_mp(M))
+int linear_c8_split3(const unsigned short *d_x3, int M, int K, const unsigned short *d_w3, const float *d_bpk, int N, int relu, float *d_y_c8, hipStream_t s) {
+  MPN_CHECK_ARG(d_x3 && d_w3 && d_bpk && d_y_c8 && M > 0 && K > 0 && N > 0);
+  Split3Args a{};
+  const int Mp = lin_mp(M), NP = lin_np(N);
+  a.xp = d_x3; a.Mp = round_up(Mp, 256); a.wp = d_w3; a.NP = round_up(NP, 256);   // (the planes' row pitch: split3_plane_elems)
+  a.part_np = NP; a.part_mp = Mp;
+  a.Kc = round_up(K, 64) / 8; a.steps = a.Kc / 2;
+  a.n_mt = Mp / S3_TM; a.n_nt = a.NP / S3_TN; a.M = M; a.N = N;
+  // K ranges from K alone (>= 256 k16 steps each, at most 8): 25088 -> 4 ranges of 392 steps — with fc6's 16 weight tiles x 8 row tiles 512 blocks, two per CU
+  int S = a.steps / 256;
+  if (S > 8) S = 8;
+  if (S < 1) S = 1;
+  a.steps_per_split = cdiv(a.steps, S);
+  S = cdiv(a.steps, a.steps_per_split);
+  const size_t need = (size_t)S * (NP / 8) * Mp * 8 * sizeof(float);
+  void *ws = nullptr;
+  { int rc_ws = scratch_get(t_gemm_splitk_slot, need, s, &ws); if (rc_ws) return rc_ws; }
+  a.part = static_cast<float *>(ws);
+  { int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(gemm_c8_split3_kernel), S3_RING * S3_STAGE_BYTES); if (rc_attr) return rc_attr; }
+  hipLaunchKernelGGL(gemm_c8_split3_kernel, dim3((unsigned)(a.n_mt * a.n_nt), (unsigned)S), dim3(256), (size_t)S3_RING * S3_STAGE_BYTES, s, a);
+  MPN_CHECK_LAUNCH();
+  const size_t total = (size_t)(NP / 8) * M;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, a.part, S, NP, Mp, M, N, d_bpk, relu, d_y_c8, (float *)nullptr);
+  MPN_CHECK_LAUNCH();
+  return MPN_OK;
+}
+
+// =================================================================================================
 // packers / converters / pooling
 // =================================================================================================
 __global__ void pack_conv_w_kernel(const float *__restrict__ w, const float *__restrict__ b, int Cin, int Cout, int CoutP,

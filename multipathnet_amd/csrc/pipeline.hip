@@ -291,6 +291,7 @@ struct mpn_frcnn {
   // different GPUs), so towers 1, 3 run on the handle's second tower stream with their own mix / fc6 buffers beside towers 0, 2, 4 on the
   // caller's stream: one lane's short-K mix GEMM (6.1 block rounds on 256 CUs, 40 stages per tile) and the prologue / epilogue of every
   // launch run under the other lane's fc6 / fc7 instead of leaving the matrix pipe idle.  Pure scheduling: bit-identical results.
+  unsigned short *w6_s3 = nullptr, *x6_s3 = nullptr;  // MPN_FC_SPLIT3: fc6's weights (packed once) and operand (per image) as three bf16 planes
   hipStream_t tower_stream = nullptr;
   hipEvent_t ev_lane_go = nullptr, ev_lane_done = nullptr;
   float *ty2 = nullptr, *tz6_2 = nullptr;
@@ -466,6 +467,7 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
   p->cfg.pool_after = p->pool_after.data();
   int rc = MPN_OK;
 #define TRY(x) do { rc = (x); if (rc != MPN_OK) { mpn_frcnn_destroy(p); return rc; } } while (0)
+  TRY((cfg->fc_arith == MPN_FC_FP32 || (cfg->fc_arith == MPN_FC_SPLIT3 && !graph_net && !mw)) ? MPN_OK : (set_error("mpn_frcnn_config.fc_arith: %d (MPN_FC_SPLIT3 is for mpn_frcnn_create pipelines)", cfg->fc_arith), MPN_EINVAL));
   TRY((cfg->roi_bin_rule == MPN_ROI_BINS_CAFFE || cfg->roi_bin_rule == MPN_ROI_BINS_ADAPTIVE) ? MPN_OK : (set_error("mpn_frcnn_config.roi_bin_rule: %d is not an MPN_ROI_BINS_* value", cfg->roi_bin_rule), MPN_EINVAL));
   // ---- trunk buffers + packed weights
   int h = cfg->max_h, w = cfg->max_w, cin = 3;
@@ -616,6 +618,15 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
   TRY(dev_alloc(p, &p->w6, lin_wpk_elems(K6_32, F) * sizeof(float), false));
   TRY(dev_alloc(p, &p->b6, (size_t)lin_np(F) * sizeof(float), false));
   TRY(pack_linear_weights(d_fc6_w, d_fc6_b, p->K6, F, PP, p->w6, p->b6, nullptr));
+  if (cfg->fc_arith == MPN_FC_SPLIT3) {  // the packed fp32 weights [K/8][NP][8] split once into three bf16 planes [3][K/8][NP↑256][8]; the operand's planes per image
+    TRY((p->K6 % 64 == 0) ? MPN_OK : (set_error("MPN_FC_SPLIT3 needs fc6's K (%d) to be a multiple of 64", p->K6), MPN_EINVAL));
+    float *tmp = nullptr;
+    TRY(dev_alloc(p, &tmp, split3_plane_elems(p->K6, lin_np(F)) * sizeof(unsigned short), true));
+    p->w6_s3 = reinterpret_cast<unsigned short *>(tmp);
+    TRY(split3_planes(p->w6, p->K6, lin_np(F), lin_np(F), p->w6_s3, nullptr));
+    TRY(dev_alloc(p, &tmp, split3_plane_elems(p->K6, p->Mp) * sizeof(unsigned short), true));
+    p->x6_s3 = reinterpret_cast<unsigned short *>(tmp);
+  }
   TRY(dev_alloc(p, &p->w7, lin_wpk_elems(F32, F) * sizeof(float), false));
   TRY(dev_alloc(p, &p->b7, (size_t)lin_np(F) * sizeof(float), false));
   TRY(pack_linear_weights(d_fc7_w, d_fc7_b, F, F, 1, p->w7, p->b7, nullptr));
@@ -1039,7 +1050,12 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const 
       rc = roi_pool_c8(feat, p->rois, N, c.pooled_h, c.pooled_w, c.spatial_scale, RoiRule{1.0f, 0, c.roi_bin_rule}, p->x6, nullptr, s);
     } }
   if (rc) return rc;
-  { ProfScope ps(p, MPN_PROF_FC6, s); rc = linear_c8(p->x6, N, p->K6, p->w6, p->b6, F, 1, p->y6, nullptr, s, 0, nullptr, 1); }
+  { ProfScope ps(p, MPN_PROF_FC6, s);
+    if (p->w6_s3) {  // MPN_FC_SPLIT3: the pooled operand -> three bf16 planes, six bf16 products per k-step with fp32 accumulation, fixed K ranges
+      rc = split3_planes(p->x6, p->K6, lin_mp(N), lin_mp(N), p->x6_s3, s);
+      if (rc == MPN_OK) rc = linear_c8_split3(p->x6_s3, N, p->K6, p->w6_s3, p->b6, F, 1, p->y6, s);
+    } else
+      rc = linear_c8(p->x6, N, p->K6, p->w6, p->b6, F, 1, p->y6, nullptr, s, 0, nullptr, 1); }
   if (rc) return rc;
   { ProfScope ps(p, MPN_PROF_FC7, s); rc = linear_c8(p->y6, N, F, p->w7, p->b7, F, 1, y7, nullptr, s, 0, nullptr, 1); }
   if (rc) return rc;

@@ -3624,16 +3624,18 @@ int resnet_head_forward(ResNetGraph *g, int head, const float *d_rois, int roi_s
       const int want_levels = g->feat_vmax_valid ? g->feat_vmax_levels : 0;
 #ifdef MPN_DEBUG_HOOKS
       if (g_tower_knock & 1) {}
-      else if ((g_pool_exp & 3) && Cb % 8 == 0) {  // mpn_debug_set_pool_exp (timing experiments): bit 0 = 8 channel blocks per thread, bit 1 = non-temporal stores
+      else if ((g_pool_exp & 3) && Cb % 8 == 0) {  // mpn_debug_set_pool_exp (timing experiments): 1 = 8 channel blocks per thread / ordinary stores, 2 = 4 blocks / ordinary stores (rounds 3-5), 3 = 8 blocks / non-temporal
         const dim3 g8((unsigned)cdiv_sz((size_t)N * PH * PH, 256), (unsigned)(Cb / 8)), g4((unsigned)cdiv_sz((size_t)N * PH * PH, 256), (unsigned)(Cb / 4));
 #define MPN_POOL_ARGS reinterpret_cast<const u32x4 *>(g->feat_sorted), g->feat_h, g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale, reinterpret_cast<u32x4 *>(pool_dst), pa.pitch(), g->roi_bins
         if ((g_pool_exp & 3) == 1) hipLaunchKernelGGL((roi_pool_c8i_bf16_sorted_kernel<8, false>), g8, dim3(256), 0, s, MPN_POOL_ARGS);
-        else if ((g_pool_exp & 3) == 2) hipLaunchKernelGGL((roi_pool_c8i_bf16_sorted_kernel<4, true>), g4, dim3(256), 0, s, MPN_POOL_ARGS);
+        else if ((g_pool_exp & 3) == 2) hipLaunchKernelGGL((roi_pool_c8i_bf16_sorted_kernel<4, false>), g4, dim3(256), 0, s, MPN_POOL_ARGS);   // rounds 3-5: ordinary stores
         else hipLaunchKernelGGL((roi_pool_c8i_bf16_sorted_kernel<8, true>), g8, dim3(256), 0, s, MPN_POOL_ARGS);
 #undef MPN_POOL_ARGS
       } else
 #endif
-      hipLaunchKernelGGL(roi_pool_c8i_bf16_sorted_kernel<4>, dim3((unsigned)cdiv_sz((size_t)N * PH * PH, 256), (unsigned)(Cb / 4)), dim3(256), 0, s,
+      // non-temporal stores: the 0.4-0.9 GB pooled tensor streams past the L2 instead of evicting the sorted map the launch gathers from
+      // (measured, profiles/r06_pool_exp.txt: configs[4] 24.28 -> 24.10 ms, configs[3] bf16 11.06 -> 10.99; 8 channel blocks per thread: slower)
+      hipLaunchKernelGGL((roi_pool_c8i_bf16_sorted_kernel<4, true>), dim3((unsigned)cdiv_sz((size_t)N * PH * PH, 256), (unsigned)(Cb / 4)), dim3(256), 0, s,
                          reinterpret_cast<const u32x4 *>(g->feat_sorted), g->feat_h, g->feat_w, fa.pitch(), d_rois, roi_stride, N, PH, PH, spatial_scale,
                          reinterpret_cast<u32x4 *>(pool_dst), pa.pitch(), g->roi_bins);
       if (fuse_mp)

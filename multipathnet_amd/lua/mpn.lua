@@ -135,6 +135,7 @@ local function common_config(cfg, opt, tf, bnorm)
    cfg.bbox_vote_thresh, cfg.bbox_vote_score_pow = opt.test_bbox_voting_nms_threshold or 0.5, opt.test_bbox_voting_score_pow or 1
    cfg.use_rbox_scores = opt.test_use_rbox_scores and 1 or 0
    cfg.roi_bin_rule = opt.roi_bin_rule or 0                        -- 1: inn.ROIPooling's CPU-branch bins (MPN_ROI_BINS_ADAPTIVE)
+   cfg.fc_arith = opt.fc_arith or 0                                -- 1: fc6 as the three-plane bf16 split (MPN_FC_SPLIT3; auxiliary arithmetic)
    cfg.scale_target, cfg.scale_max = opt.scale or 600, opt.max_size or 1000   -- getImages (ImageDetect.lua:34-43) on the device
 end
 -- classAndBBoxLinear (model_utils.lua:105-119) [+ utils.integral's K classifier clones, model_utils.lua:275-317] -> (cls weight, cls bias,

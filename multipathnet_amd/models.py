@@ -6,6 +6,7 @@ given in Torch layout (conv [Cout,Cin,3,3], linear [out,in]) and re-packed once 
 MFMA-fragment order.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -490,7 +491,7 @@ class FastRCNN(object):
 
     def __init__(self, params, cfg=VGG16_CFG, pooled=7, spatial_scale=1.0 / 16, transformer=None, max_h=600, max_w=1000,
                  max_rois=1000, nms_thresh=0.3, score_thresh=-1.5, top_k=100, num_iter=1, bbox_voting=False, bbox_vote_thresh=0.5,
-                 bbox_vote_score_pow=1.0, scale=None, max_size=None, bf16=False, use_rbox_scores=False, roi_bin_rule=0):
+                 bbox_vote_score_pow=1.0, scale=None, max_size=None, bf16=False, use_rbox_scores=False, roi_bin_rule=0, fc_arith=None):
         """scale / max_size: getImages' rescaling (ImageDetect.lua:34-43) on the device; None feeds images as they are.
         roi_bin_rule: 0 = inn.ROIPooling's CUDA-branch bins, 1 = its CPU branch (crop + SpatialAdaptiveMaxPooling), include/mpn.h MPN_ROI_BINS_*.
         num_iter / bbox_voting / use_rbox_scores: opt.test_num_iterative_loc / test_bbox_voting / test_use_rbox_scores
@@ -535,6 +536,15 @@ class FastRCNN(object):
         c.scale_target, c.scale_max = float(scale or 0.0), float(max_size or 0.0)
         c.use_rbox_scores = int(bool(use_rbox_scores))
         c.roi_bin_rule = int(roi_bin_rule)
+        # fc_arith: 0 = fc6 on the fp32 matrix pipe (default), 1 / "split3" = the three-plane bf16 split with fp32 accumulation (include/mpn.h
+        # MPN_FC_SPLIT3; plain VGG / AlexNet-free pipelines only).  MPN_FC_ARITH=split3 in the environment forces it on for every plain VGG
+        # pipeline a process builds (how the fp32 parity suite is run against it: tools/r06_split3_gate.sh).
+        if fc_arith is None:
+            fc_arith = os.environ.get("MPN_FC_ARITH", "0")
+        fc_arith = {"0": 0, "fp32": 0, "1": 1, "split3": 1}[str(fc_arith)]
+        plain_vgg = not (self.is_resnet or self.is_graph or self.is_mpnet)
+        c.fc_arith = fc_arith if plain_vgg else 0
+        self.fc_arith = c.fc_arith
         self.scale, self.max_size = scale, max_size
         self._cfg = c
         dev = torch.device("cuda", torch.cuda.current_device())

@@ -761,3 +761,40 @@ def test_two_tower_lanes_are_invisible(dev, model):
                 assert torch.equal(x, y), v
     last = res[variants[-1]]
     assert torch.equal(last[0][0], last[2][0]) and torch.equal(last[0][0], last[4][0])   # the same call gives the same rows every time
+
+
+@pytest.mark.gpu
+def test_fc6_three_plane_split_vs_oracle_and_fp32_pipeline(O, dev, small):
+    """MPN_FC_SPLIT3 (VERDICT r5 task 2; models/vgg.lua:16,30): fc6 on the bf16 matrix pipe — both operands split exactly into three bf16 planes,
+    the six plane products of weight >= 2^-16 accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Held to the gate of the fp32 path: logits and
+    deltas within 1e-4 of the oracle, scores within 1e-4, and no further from a float64 head than the fp32-MFMA pipeline is (x 1.5).  Rows do
+    not depend on the batch they are scored in (fixed K ranges)."""
+    from multipathnet_amd import models
+    s = SMALL
+    net = models.FastRCNN(small["P_torch"], cfg=s["cfg"], pooled=7, spatial_scale=s["scale"], max_h=s["H"], max_w=s["W"], max_rois=s["N"], fc_arith="split3")
+    assert net.fc_arith == 1
+    im, bx = torch.from_numpy(small["im"]).to(dev), torch.from_numpy(small["boxes"]).to(dev)
+    scores, bbox = net.detect(im, bx)
+    torch.cuda.synchronize()
+    cls = net.debug_tensor("cls", small["logits"].shape).cpu().numpy()
+    raw = net.debug_tensor("bbox_raw", small["deltas"].shape).cpu().numpy()
+    assert np.abs(cls - small["logits"]).max() < 1e-4 and np.abs(raw - small["deltas"]).max() < 1e-4
+    assert np.abs(scores.cpu().numpy() - O.softmax(small["logits"])).max() < 1e-4
+    # against a float64 head on the device's own pooled operand: the split's error beside the fp32 MFMA path's
+    ref = small["net"]
+    ref.detect(im, bx)
+    torch.cuda.synchronize()
+    pooled = net.debug_tensor("pooled", small["pooled"].shape).cpu().numpy().reshape(s["N"], -1).astype(np.float64)
+    P = small["P"]
+    h6 = np.maximum(pooled @ P["fc6_w"].astype(np.float64).T + P["fc6_b"], 0)
+    h7 = np.maximum(h6 @ P["fc7_w"].astype(np.float64).T + P["fc7_b"], 0)
+    l64 = h7 @ P["cls_w"].astype(np.float64).T + P["cls_b"]
+    e_split = np.abs(cls - l64).max()
+    e_fp32 = np.abs(ref.debug_tensor("cls", small["logits"].shape).cpu().numpy() - l64).max()
+    print("logits vs a float64 head on the same pooled operand: three-plane split %.3g, fp32 MFMA %.3g" % (e_split, e_fp32))
+    assert e_split < max(1.5 * e_fp32, 2e-6)
+    # batch invariance + determinism
+    s2, b2 = net.detect(im, bx[:37].contiguous(), recompute_features=False)
+    assert torch.equal(s2, scores[:37]) and torch.equal(b2, bbox[:37])
+    s3, b3 = net.detect(im, bx)
+    assert torch.equal(s3, scores) and torch.equal(b3, bbox)
