@@ -1098,8 +1098,14 @@ struct GemmArgs {
 // FOLD: the launch folds its accumulator into a running total at K-segment boundaries (row-invariant summation / per-row-scaled segments).
 // A separate instantiation because the total costs 64 more registers (264 > 256: one block per CU instead of two); launches that never
 // fold — split-K pieces, ResNet's pointwise convolutions, the un-scaled mix — keep the two-blocks-per-CU form.
-template <int KCH, bool FOLD>
+// RSI (round 6; with FOLD = false): per-row-scaled K segments WITHOUT the running total — y = s_last * (P_last + (s_k / s_last) * (... )): at a segment
+// boundary the accumulator is multiplied by the ratio of the two segments' row scales and keeps accumulating, at the end by the last segment's
+// scale.  Mathematically the FOLD form's sum_k s_k P_k with two or three more roundings per element (2^-24 each, far inside the 1e-4 of the
+// path's parity gate), for 64 fewer registers: 196 + 8 instead of 264 — two blocks per CU, and, what matters more on the MultiPathNet path, a
+// mix-GEMM block can share a CU with a block of the other tower lane's fc6 / fc7 (264 registers per lane: 264 + 264 > 512, 204 + 264 fits).
+template <int KCH, bool FOLD, bool RSI = false>
 __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
+  static_assert(!(FOLD && RSI), "row scales are applied either through the running total or in place");
   constexpr int OP_FLOATS = KCH * 128 * 8;
   constexpr int STAGE = 2 * OP_FLOATS;
   constexpr int IT = OP_FLOATS / 256 / 4;
@@ -1142,13 +1148,23 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
   float rsc[3][2];  // this lane's two rows' scales per K segment (fetched now: a load at a fold boundary would be an exposed round trip)
 #pragma unroll
   for (int sg = 0; sg < 3; ++sg) { rsc[sg][0] = 1.0f; rsc[sg][1] = 1.0f; }
-  if (FOLD && a.rs0) {
+  if ((FOLD || RSI) && a.rs0) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
       const int row = (m0 + wn * 64 + ni * 32 + l31) % a.rs_mod;
       rsc[0][ni] = a.rs0[row];
       if (a.rs1) rsc[1][ni] = a.rs1[row];
       if (a.rs2) rsc[2][ni] = a.rs2[row];
+    }
+    if constexpr (RSI) {  // rsc[k] <- s_k / s_(k+1) for the interior boundaries, the last segment's scale stays: applied at the end
+      const int nseg = a.nsb + 1;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const float s0 = rsc[0][ni], s1 = rsc[1][ni], s2 = rsc[2][ni];
+        if (nseg == 2) { rsc[0][ni] = s0 / s1; rsc[2][ni] = s1; }
+        else if (nseg == 3) { rsc[0][ni] = s0 / s1; rsc[1][ni] = s1 / s2; rsc[2][ni] = s2; }
+        else rsc[2][ni] = s0;
+      }
     }
   }
   const int lane_off = l31 * 8 + half * 4;
@@ -1211,6 +1227,15 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
   }
   int fseg = 0;  // index of the segment being accumulated
   auto fold = [&]() {
+    if constexpr (RSI) {  // boundary fseg -> fseg + 1: the accumulator moves to the next segment's scale
+      const float q0 = fseg == 0 ? rsc[0][0] : rsc[1][0], q1 = fseg == 0 ? rsc[0][1] : rsc[1][1];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[mi][0][r] *= q0; acc[mi][1][r] *= q1; }
+      ++fseg;
+      return;
+    }
     if constexpr (!FOLD) return;
     if (a.rs0) {  // (wave-uniform) the segment's per-row scale: tot += scale * acc
       const float s0 = fseg == 0 ? rsc[0][0] : (fseg == 1 ? rsc[1][0] : rsc[2][0]), s1 = fseg == 0 ? rsc[0][1] : (fseg == 1 ? rsc[1][1] : rsc[2][1]);
@@ -1232,7 +1257,7 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
     ++fseg;
   };
   // fold points: explicit boundaries (sb0, sb1) or every seg_stages stages
-  int next_fold = !FOLD ? 0x7fffffff : (a.nsb > 0 ? a.sb0 : (a.seg_stages > 0 ? st0 + a.seg_stages : 0x7fffffff));
+  int next_fold = !(FOLD || RSI) ? 0x7fffffff : (a.nsb > 0 ? a.sb0 : (a.seg_stages > 0 ? st0 + a.seg_stages : 0x7fffffff));
   auto advance = [&]() { next_fold = a.nsb > 0 ? (fseg < a.nsb ? a.sb1 : 0x7fffffff) : next_fold + a.seg_stages; };
   int st = st0;
   if (n_more & 1) { body(st, std::true_type{}, P1{}); ++st; if (st == next_fold) { fold(); advance(); } }
@@ -1243,6 +1268,14 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
     if (st + 2 == next_fold) { fold(); advance(); }
   }
   body(st1 - 1, std::false_type{}, P0{});
+  if constexpr (RSI) {  // the last segment's scale
+    if (a.rs0) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[mi][0][r] *= rsc[2][0]; acc[mi][1][r] *= rsc[2][1]; }
+    }
+  } else
   fold();  // tot = 0 + acc when nothing was folded before: exact
 
   // Epilogue: every bias / residual load is issued before the first store (the empty asm is a compiler barrier for memory
@@ -1326,6 +1359,7 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ part, int S, int 
 MPN_KNOB(int, g_gemm_kch, 0);       // test/bench hook: force 4 or 8 K chunks per stage
 MPN_KNOB(int, g_gemm_split, 0);  // test/bench hook: force a split-K factor
 
+MPN_KNOB(int, g_gemm_rsi, 1);  // mpn_debug_set_gemm_rsi: 0 = per-row-scaled K segments through the running total (the FOLD kernel, rounds 3-5)
 static thread_local ScratchSlot t_gemm_splitk_slot = SCR_GEMM_SPLITK;
 SplitkSlotScope::SplitkSlotScope(ScratchSlot slot) : prev(t_gemm_splitk_slot) { t_gemm_splitk_slot = slot; }
 SplitkSlotScope::~SplitkSlotScope() { t_gemm_splitk_slot = prev; }
@@ -1418,13 +1452,18 @@ static int linear_c8_impl(const float *d_x_c8, int M, int K, const float *d_wpk,
     a.y = static_cast<float *>(ws);
   }
   dim3 grid((unsigned)tiles, (unsigned)S);
-  const bool folds = a.seg_stages > 0 || a.nsb > 0 || a.rs0 != nullptr;
+  const bool rsi = rs != nullptr && g_gemm_rsi && kch == 4;   // per-row-scaled segments applied in place (no running total)
+  const bool folds = !rsi && (a.seg_stages > 0 || a.nsb > 0 || a.rs0 != nullptr);
   if (folds && a.res) { set_error("linear_c8: a residual cannot be combined with a folding (row-invariant / row-scaled) launch"); return MPN_EINVAL; }
   if (kch == 8) {
     if (folds) hipLaunchKernelGGL((gemm_c8_pf_kernel<8, true>), grid, dim3(256), (size_t)2 * 2 * 8 * 128 * 8 * 4, s, a);
     else hipLaunchKernelGGL((gemm_c8_pf_kernel<8, false>), grid, dim3(256), (size_t)2 * 2 * 8 * 128 * 8 * 4, s, a);
   } else {
-    if (folds) hipLaunchKernelGGL((gemm_c8_pf_kernel<4, true>), grid, dim3(256), (size_t)2 * 2 * 4 * 128 * 8 * 4, s, a);
+    if (rsi) {
+      int rc_attr = set_max_dyn_lds(reinterpret_cast<const void *>(gemm_c8_pf_kernel<4, false, true>), 2 * 2 * 4 * 128 * 8 * 4);
+      if (rc_attr) return rc_attr;
+      hipLaunchKernelGGL((gemm_c8_pf_kernel<4, false, true>), grid, dim3(256), (size_t)2 * 2 * 4 * 128 * 8 * 4, s, a);
+    } else if (folds) hipLaunchKernelGGL((gemm_c8_pf_kernel<4, true>), grid, dim3(256), (size_t)2 * 2 * 4 * 128 * 8 * 4, s, a);
     else hipLaunchKernelGGL((gemm_c8_pf_kernel<4, false>), grid, dim3(256), (size_t)2 * 2 * 4 * 128 * 8 * 4, s, a);
   }
   MPN_CHECK_LAUNCH();
@@ -2460,6 +2499,7 @@ extern "C" void mpn_debug_set_conv_variant(int v) { g_conv_variant = v; }
 extern "C" void mpn_debug_set_wino_tc(int v) { g_wino_tc = v; }
 extern "C" void mpn_debug_set_conv_split(int v) { g_conv_split = v; }
 extern "C" void mpn_debug_set_gemm_split(int v) { g_gemm_split = v; }
+extern "C" void mpn_debug_set_gemm_rsi(int v) { g_gemm_rsi = v; }
 extern "C" void mpn_debug_set_gemm_kch(int v) { g_gemm_kch = (v == 4 || v == 8) ? v : 0; }
 extern "C" void mpn_debug_set_gemm_ablate(int v) { g_gemm_ablate = v; }
 

@@ -798,3 +798,37 @@ def test_fc6_three_plane_split_vs_oracle_and_fp32_pipeline(O, dev, small):
     assert torch.equal(s2, scores[:37]) and torch.equal(b2, bbox[:37])
     s3, b3 = net.detect(im, bx)
     assert torch.equal(s3, scores) and torch.equal(b3, bbox)
+
+
+@pytest.mark.gpu
+def test_mix_gemm_row_scales_in_place_equal_the_running_total_form(O, dev):
+    """Round 6: MultiPathNet's mix GEMM applies nn.Normalize's per-(map, ROI) scales by moving the accumulator from one K segment's scale to the
+    next (gemm_c8_pf_kernel<4, false, true>: 64 fewer registers than the running-total form, so its blocks share a CU with the other tower lane's
+    fc6) instead of folding scaled segments into a running total (hook gemm_rsi = 0: rounds 3-5).  Same sum with two or three more roundings per
+    element: scores agree to fp32 rounding, both forms are deterministic, and both are within the path's 1e-4 of the oracle."""
+    from multipathnet_amd import models
+    cfg = [16, 32, "P", 32, 64, "P", 64, 96, "P", 128, "P", 384]
+    H, W, N, Cn, K = 150, 250, 150, 9, 3
+    P = models.synthetic_mpnet_params(cfg, pooled=7, fc_dim=256, n_classes=Cn, n_integral=K, seed=11)
+    rng = np.random.default_rng(21)
+    im_np = rng.random((3, H, W), dtype=np.float32)
+    bx_np = _boxes(rng, N, W, H, lo=12)
+    im, bx = torch.from_numpy(im_np).to(dev), torch.from_numpy(bx_np).to(dev)
+    outs = []
+    for rsi in (1, 0):
+        with hooks(gemm_rsi=rsi):
+            net = models.MultiPathNet(P, cfg=cfg, pooled=7, spatial_scale=1 / 16, max_h=H, max_w=W, max_rois=N)
+            s1, b1 = net.detect(im, bx)
+            s2, b2 = net.detect(im, bx)
+            torch.cuda.synchronize()
+            assert torch.equal(s1, s2) and torch.equal(b1, b2)
+            outs.append((s1.clone(), b1.clone()))
+            del net
+    d = float((outs[0][0] - outs[1][0]).abs().max())
+    print("scores, in-place row scales vs running total: max |d| = %.3g" % d)
+    assert d < 2e-6 and float((outs[0][1] - outs[1][1]).abs().max()) < 1e-3
+    Pn = _np_tree(P)
+    taps = {}
+    O.vgg_trunk(O.image_transform(im_np, **O.ROSS), Pn["conv_w"], Pn["conv_b"], cfg, taps=taps)
+    ref_scores, _ = O.mpnet_head([taps["conv5"], taps["conv4"], taps["conv3"]], O.project_im_rois(bx_np, 1.0), Pn)
+    assert np.abs(outs[0][0].cpu().numpy() - ref_scores).max() < 1e-4
