@@ -1504,10 +1504,10 @@ __device__ __forceinline__ float s3_hi(unsigned pk) { return __uint_as_float(pk 
 
 // fp32 C8 matrix [Kc][rows_src][8] -> three bf16 planes [3][Kc][rows_dst][8] (rows beyond rows_valid are left untouched: the planes are
 // allocated zeroed).  One thread per 8-float record.
-__global__ __launch_bounds__(256) void split3_planes_kernel(const float *__restrict__ src, int Kc, int rows_src, int rows_valid, int rows_dst,
+__global__ __launch_bounds__(256) void split3_planes_kernel(const float *__restrict__ src, int Kc, int Kc_valid, int rows_src, int rows_valid, int rows_dst,
                                                             unsigned short *__restrict__ dst) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (size_t)Kc * rows_valid) return;
+  if (t >= (size_t)Kc_valid * rows_valid) return;
   const int r = (int)(t % rows_valid); const size_t kc = t / rows_valid;
   const f32x4 a = *reinterpret_cast<const f32x4 *>(src + (kc * rows_src + r) * 8), b = *reinterpret_cast<const f32x4 *>(src + (kc * rows_src + r) * 8 + 4);
   const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -1691,9 +1691,9 @@ size_t split3_plane_elems(int K, int rows) { return (size_t)3 * (round_up(K, 64)
 // fp32 C8 matrix (K64 / 8 chunks of `rows_src` rows; the packed weights [K/8][NP][8] or the activations [K/8][Mp][8]) -> its three bf16 planes
 int split3_planes(const float *d_c8, int K, int rows_src, int rows_valid, unsigned short *d_planes, hipStream_t s) {
   MPN_CHECK_ARG(d_c8 && d_planes && K > 0 && rows_valid > 0 && rows_valid <= rows_src);
-  const int Kc = round_up(K, 64) / 8;
-  const size_t total = (size_t)Kc * rows_valid;
-  hipLaunchKernelGGL(split3_planes_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, d_c8, Kc, rows_src, rows_valid, round_up(rows_src, 256), d_planes);
+  const int Kc = round_up(K, 64) / 8, Kc_valid = (K + 7) / 8;   // the chunks past K (up to the k16-step granularity) stay zero: the planes are allocated zeroed
+  const size_t total = (size_t)Kc_valid * rows_valid;
+  hipLaunchKernelGGL(split3_planes_kernel, dim3((unsigned)cdiv_sz(total, 256)), dim3(256), 0, s, d_c8, Kc, Kc_valid, rows_src, rows_valid, round_up(rows_src, 256), d_planes);
   MPN_CHECK_LAUNCH();
   return MPN_OK;
 }
@@ -1707,9 +1707,11 @@ int linear_c8_split3(const unsigned short *d_x3, int M, int K, const unsigned sh
   a.part_np = NP; a.part_mp = Mp;
   a.Kc = round_up(K, 64) / 8; a.steps = a.Kc / 2;
   a.n_mt = Mp / S3_TM; a.n_nt = a.NP / S3_TN; a.M = M; a.N = N;
-  // K ranges from K alone (>= 256 k16 steps each, at most 8): 25088 -> 4 ranges of 392 steps — with fc6's 16 weight tiles x 8 row tiles 512 blocks, two per CU
-  int S = a.steps / 256;
+  // K ranges from (K, N) alone — never from M: a row's summation order must not depend on the rows it is batched with.  As many as make 512 blocks
+  // (two per CU) at the usual 8 row tiles (1000 ROIs), at most 8, each >= 32 k16 steps: fc6 (16 weight tiles, 1568 steps) 4 ranges of 392, fc7 (256 steps) 4 of 64
+  int S = 512 / (a.n_nt * 8);
   if (S > 8) S = 8;
+  if (S > a.steps / 32) S = a.steps / 32;
   if (S < 1) S = 1;
   a.steps_per_split = cdiv(a.steps, S);
   S = cdiv(a.steps, a.steps_per_split);

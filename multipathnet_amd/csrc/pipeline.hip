@@ -292,6 +292,7 @@ struct mpn_frcnn {
   // caller's stream: one lane's short-K mix GEMM (6.1 block rounds on 256 CUs, 40 stages per tile) and the prologue / epilogue of every
   // launch run under the other lane's fc6 / fc7 instead of leaving the matrix pipe idle.  Pure scheduling: bit-identical results.
   unsigned short *w6_s3 = nullptr, *x6_s3 = nullptr;  // MPN_FC_SPLIT3: fc6's weights (packed once) and operand (per image) as three bf16 planes
+  unsigned short *w7_s3 = nullptr, *y6_s3 = nullptr;  // ... and fc7's
   hipStream_t tower_stream = nullptr;
   hipEvent_t ev_lane_go = nullptr, ev_lane_done = nullptr;
   float *ty2 = nullptr, *tz6_2 = nullptr;
@@ -619,7 +620,6 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
   TRY(dev_alloc(p, &p->b6, (size_t)lin_np(F) * sizeof(float), false));
   TRY(pack_linear_weights(d_fc6_w, d_fc6_b, p->K6, F, PP, p->w6, p->b6, nullptr));
   if (cfg->fc_arith == MPN_FC_SPLIT3) {  // the packed fp32 weights [K/8][NP][8] split once into three bf16 planes [3][K/8][NP↑256][8]; the operand's planes per image
-    TRY((p->K6 % 64 == 0) ? MPN_OK : (set_error("MPN_FC_SPLIT3 needs fc6's K (%d) to be a multiple of 64", p->K6), MPN_EINVAL));
     float *tmp = nullptr;
     TRY(dev_alloc(p, &tmp, split3_plane_elems(p->K6, lin_np(F)) * sizeof(unsigned short), true));
     p->w6_s3 = reinterpret_cast<unsigned short *>(tmp);
@@ -630,6 +630,14 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
   TRY(dev_alloc(p, &p->w7, lin_wpk_elems(F32, F) * sizeof(float), false));
   TRY(dev_alloc(p, &p->b7, (size_t)lin_np(F) * sizeof(float), false));
   TRY(pack_linear_weights(d_fc7_w, d_fc7_b, F, F, 1, p->w7, p->b7, nullptr));
+  if (cfg->fc_arith == MPN_FC_SPLIT3) {
+    float *tmp = nullptr;
+    TRY(dev_alloc(p, &tmp, split3_plane_elems(F, lin_np(F)) * sizeof(unsigned short), true));
+    p->w7_s3 = reinterpret_cast<unsigned short *>(tmp);
+    TRY(split3_planes(p->w7, F, lin_np(F), lin_np(F), p->w7_s3, nullptr));
+    TRY(dev_alloc(p, &tmp, split3_plane_elems(F, p->Mp) * sizeof(unsigned short), true));
+    p->y6_s3 = reinterpret_cast<unsigned short *>(tmp);
+  }
   }
   {  // cls and bbox heads share their input -> one [5C, F] GEMM (model_utils.lua:105-119 ConcatTable)
     float *tmp_w = nullptr, *tmp_b = nullptr;
@@ -1057,7 +1065,12 @@ static int run_detect(mpn_frcnn *p, const float *d_image, int H0, int W0, const 
     } else
       rc = linear_c8(p->x6, N, p->K6, p->w6, p->b6, F, 1, p->y6, nullptr, s, 0, nullptr, 1); }
   if (rc) return rc;
-  { ProfScope ps(p, MPN_PROF_FC7, s); rc = linear_c8(p->y6, N, F, p->w7, p->b7, F, 1, y7, nullptr, s, 0, nullptr, 1); }
+  { ProfScope ps(p, MPN_PROF_FC7, s);
+    if (p->w7_s3) {
+      rc = split3_planes(p->y6, F, lin_mp(N), lin_mp(N), p->y6_s3, s);
+      if (rc == MPN_OK) rc = linear_c8_split3(p->y6_s3, N, F, p->w7_s3, p->b7, F, 1, y7, s);
+    } else
+      rc = linear_c8(p->y6, N, F, p->w7, p->b7, F, 1, y7, nullptr, s, 0, nullptr, 1); }
   if (rc) return rc;
   }
   if (hs != s) {  // hand over: the side stream continues from here (its work on this buffer set is ordered by ev_tail[set])
