@@ -1359,6 +1359,7 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ part, int S, int 
 MPN_KNOB(int, g_gemm_kch, 0);       // test/bench hook: force 4 or 8 K chunks per stage
 MPN_KNOB(int, g_gemm_split, 0);  // test/bench hook: force a split-K factor
 
+MPN_KNOB(int, g_split3_ranges, 0);  // mpn_debug_set_split3_ranges: forced number of K ranges of linear_c8_split3 (0 = its own rule)
 MPN_KNOB(int, g_gemm_rsi, 1);  // mpn_debug_set_gemm_rsi: 0 = per-row-scaled K segments through the running total (the FOLD kernel, rounds 3-5)
 static thread_local ScratchSlot t_gemm_splitk_slot = SCR_GEMM_SPLITK;
 SplitkSlotScope::SplitkSlotScope(ScratchSlot slot) : prev(t_gemm_splitk_slot) { t_gemm_splitk_slot = slot; }
@@ -1710,6 +1711,7 @@ int linear_c8_split3(const unsigned short *d_x3, int M, int K, const unsigned sh
   // K ranges from (K, N) alone — never from M: a row's summation order must not depend on the rows it is batched with.  As many as make 512 blocks
   // (two per CU) at the usual 8 row tiles (1000 ROIs), at most 8, each >= 32 k16 steps: fc6 (16 weight tiles, 1568 steps) 4 ranges of 392, fc7 (256 steps) 4 of 64
   int S = 512 / (a.n_nt * 8);
+  if (g_split3_ranges > 0) S = g_split3_ranges;   // (mpn_debug_set_split3_ranges: accuracy / timing experiments)
   if (S > 8) S = 8;
   if (S > a.steps / 32) S = a.steps / 32;
   if (S < 1) S = 1;
@@ -2502,6 +2504,7 @@ extern "C" void mpn_debug_set_wino_tc(int v) { g_wino_tc = v; }
 extern "C" void mpn_debug_set_conv_split(int v) { g_conv_split = v; }
 extern "C" void mpn_debug_set_gemm_split(int v) { g_gemm_split = v; }
 extern "C" void mpn_debug_set_gemm_rsi(int v) { g_gemm_rsi = v; }
+extern "C" void mpn_debug_set_split3_ranges(int v) { g_split3_ranges = v; }
 extern "C" void mpn_debug_set_gemm_kch(int v) { g_gemm_kch = (v == 4 || v == 8) ? v : 0; }
 extern "C" void mpn_debug_set_gemm_ablate(int v) { g_gemm_ablate = v; }
 

@@ -553,3 +553,40 @@ def test_multipathnet_fullsize_scores_vs_oracle_on_roi_sample(O, dev):
     ref_bbox = O.clamp_boxes(O.bbox_decode(boxes[idx], deltas), im.shape[2], im.shape[1])
     assert np.abs(scores[idx] - ref_scores).max() < 1e-4
     assert np.abs(bbox[idx] - ref_bbox).max() < 1e-4 * im.shape[2]
+
+
+@pytest.mark.parametrize("n", [1000, 2000])
+def test_fullsize_fc_three_plane_split_beside_the_fp32_pipeline(O, dev, full, n):
+    """MPN_FC_SPLIT3 (fc6 / fc7 as exact three-plane bf16 splits, six bf16 MFMA products per k-step, fp32 accumulate) at FULL size with trained-scale
+    heads, isolated from the trunk: both pipelines pool the same device conv5 map, so the difference of their logits / deltas is the fc
+    arithmetic alone.  Reported against a float64 head (fc6 -> fc7 -> cls / bbox in float64 on the device's own pooled operand of a 100-ROI
+    sample): the split must be no further from it than 1.5x the fp32 MFMA pipeline is, and the two pipelines within 3e-5 of each other on
+    logits of magnitude ~16 (the 1e-4 budget of the path's parity gate is spent on the trunk: tests above)."""
+    import bench
+    from multipathnet_amd import models
+    from conftest import hooks
+    Q = models.synthetic_params(models.VGG16_CFG, pooled=7, fc_dim=4096, n_classes=bench.N_CLASSES, seed=557, head_scale="trained")
+    boxes = bench.more_boxes(full["boxes"], n)
+    bd = torch.from_numpy(boxes).to(dev)
+    C = bench.N_CLASSES
+    out = {}
+    for arith in ("fp32", "split3"):
+        net = models.FastRCNN(Q, max_h=bench.H, max_w=bench.W, max_rois=n, fc_arith=arith)
+        net.detect(full["imd"], bd)
+        out[arith] = (net.debug_tensor("cls", (n, C)).cpu().numpy(), net.debug_tensor("bbox_raw", (n, 4 * C)).cpu().numpy())
+        if arith == "fp32":
+            idx = np.random.default_rng(3).choice(n, N_SAMPLE, replace=False)
+            pooled = net.debug_tensor("pooled", (n, 512, 7, 7))[torch.from_numpy(idx).to(dev)].cpu().numpy().reshape(N_SAMPLE, -1).astype(np.float64)
+        del net
+        torch.cuda.empty_cache()
+    Qn = _np_tree(Q)
+    h6 = np.maximum(pooled @ Qn["fc6_w"].astype(np.float64).T + Qn["fc6_b"], 0)
+    h7 = np.maximum(h6 @ Qn["fc7_w"].astype(np.float64).T + Qn["fc7_b"], 0)
+    l64 = h7 @ Qn["cls_w"].astype(np.float64).T + Qn["cls_b"]
+    e32, e3 = np.abs(out["fp32"][0][idx] - l64).max(), np.abs(out["split3"][0][idx] - l64).max()
+    d_l, d_d = np.abs(out["fp32"][0] - out["split3"][0]).max(), np.abs(out["fp32"][1] - out["split3"][1]).max()
+    bias = float((out["split3"][0].astype(np.float64) - out["fp32"][0]).mean())
+    print("N = %d, logits up to %.3g: vs a float64 head on the same pooled operand (%d ROIs): fp32 MFMA %.3g, three-plane split %.3g; split - fp32 pipeline: "
+          "max |dlogit| %.3g (mean signed %.2g), max |ddelta| %.3g" % (n, np.abs(out["fp32"][0]).max(), N_SAMPLE, e32, e3, d_l, bias, d_d))
+    assert e3 < max(1.5 * e32, 1e-5)
+    assert d_l < 3e-5 and d_d < 3e-6
