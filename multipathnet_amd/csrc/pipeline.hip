@@ -10,6 +10,7 @@
 // fc weights stream from HBM once per image instead of twice.
 #include <cstdlib>
 #include <iterator>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <tuple>
@@ -368,6 +369,7 @@ MPN_KNOB(int, g_first_k36, 1);  // 0: the first layer on the generic direct kern
 MPN_KNOB(int, g_roi_pool_pm, 1);  // 0: ROI pooling straight from the C8P map (roi_pool_c8_kernel)
 MPN_KNOB(int, g_mix_fold, 1);     // 0: MultiPathNet's nn.Normalize scales applied in place (l2norm_apply) instead of inside the mix GEMM
 MPN_KNOB(int, g_tower_lanes, 1);  // 0: the towers of an image one after the other on the caller's stream (rounds 2-5) instead of two lanes (mpn_debug_set_tower_lanes)
+MPN_KNOB(int, g_tower_order, 1);  // 0: the towers in index order instead of cheapest pooling first (mpn_debug_set_tower_order)
 MPN_KNOB(int, g_tower_share, 1);  // 0: every tower pools its own operand even where two of them pool the same region's maps (mpn_debug_set_tower_share)
 MPN_KNOB(int, g_pool_overlap, 1); // 0: MultiPathNet's skip pooling on the launch stream instead of its own stream under the previous tower's GEMMs
 MPN_KNOB(int, g_defer_heads, 1);  // 0: the pipelined forms keep heads / softmax / decode / select on the launch stream (rounds 1-5a); 2 (test): the
@@ -387,6 +389,7 @@ extern "C" void mpn_debug_set_mix_fold(int v) { g_mix_fold = v; }
 extern "C" void mpn_debug_set_pool_overlap(int v) { g_pool_overlap = v; }
 extern "C" void mpn_debug_set_tower_lanes(int v) { g_tower_lanes = v; }
 extern "C" void mpn_debug_set_tower_share(int v) { g_tower_share = v; }
+extern "C" void mpn_debug_set_tower_order(int v) { g_tower_order = v; }
 extern "C" void mpn_debug_set_halo_memset(int v) { g_halo_memset = v; }
 extern "C" void mpn_debug_set_defer_heads(int v) { g_defer_heads = v; }
 #endif
@@ -817,12 +820,20 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
   // its mix GEMM has been enqueued whenever the pooling is).
   const bool share = overlap && p->tx3 && p->share_provider >= 0 && g_tower_share;
   float *const tx_of[3] = {p->tx, p->tx2, p->tx3};
-  int buf_of[8], prev_user[8], pool_src[8];
+  int buf_of[8], prev_user[8], pool_src[8], order[8];
   bool pools[8];
+  // Execution order: the towers meet only in `cat` (each writes its own slice), so the order is free — cheapest pooling first.  The first
+  // tower's pooling has nothing to hide behind (it follows the trunk directly): 512 channels (the conv5-only tower) instead of 1280.
+  for (int t = 0; t < n_tow; ++t) order[t] = t;
+  if (overlap && g_tower_order) {
+    auto cost = [&](int t) { return (share && (t == p->share_provider || t == p->share_consumer)) ? p->towers[p->share_provider].total_feat : p->towers[t].total_feat; };
+    std::stable_sort(order, order + n_tow, [&](int x, int y) { return cost(x) < cost(y); });
+  }
   {
     int nplain = 0, last_user[3] = {-1, -1, -1};
     bool shared_pooled = false;
-    for (int t = 0; t < n_tow; ++t) {
+    for (int k = 0; k < n_tow; ++k) {
+      const int t = order[k];
       if (share && (t == p->share_provider || t == p->share_consumer)) {
         buf_of[t] = 2; pools[t] = !shared_pooled; shared_pooled = true; pool_src[t] = p->share_provider;
       } else {
@@ -889,19 +900,20 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
     MPN_CHECK_HIP(hipEventRecord(p->ev_lane_go, s));
     MPN_CHECK_HIP(hipStreamWaitEvent(lane_s[1], p->ev_lane_go, 0));
   }
-  rc = pool_tower(0);
+  rc = pool_tower(order[0]);
   if (rc) return rc;
-  if (lanes) { rc = pool_tower(1); if (rc) return rc; }
-  for (int ti = 0; ti < n_tow; ++ti) {
+  if (lanes) { rc = pool_tower(order[1]); if (rc) return rc; }
+  for (int k = 0; k < n_tow; ++k) {
+    const int ti = order[k];
     const mpn_frcnn::Tower &T = p->towers[ti];
     const int b = buf_of[ti];
-    const int ln = lanes ? (ti & 1) : 0;
+    const int ln = lanes ? (k & 1) : 0;
     hipStream_t ls = lane_s[ln];
     SplitkSlotScope lane_slabs(ln ? SCR_GEMM_SPLITK_LANE : SCR_GEMM_SPLITK);  // a GEMM of few tiles (small ROI shards) runs split-K: each lane its own slabs
     const float *txb = tx_of[b];
     if (overlap) {
       MPN_CHECK_HIP(hipStreamWaitEvent(ls, p->ev_pool_done[b], 0));
-      if (!lanes && ti + 1 < n_tow) { rc = pool_tower(ti + 1); if (rc) return rc; }  // enqueued now: runs under this tower's GEMMs
+      if (!lanes && k + 1 < n_tow) { rc = pool_tower(order[k + 1]); if (rc) return rc; }  // enqueued now: runs under this tower's GEMMs
     }
     const GemmRowScale &grs = grs_of[ti];
     // 1x1 conv mix: rows = (bin, roi), K = concat channels, N = feat_c; output layout == fc6 operand layout
@@ -910,13 +922,13 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
                       : linear_c8(txb, PP * Mp, T.total_feat, T.mix_w, T.mix_b, p->feat_c, 0, lane_ty[ln], nullptr, ls, PP * Mp, nullptr, 2); }
     if (rc) return rc;
     if (overlap) MPN_CHECK_HIP(hipEventRecord(p->ev_mix_done[b], ls));
-    if (lanes && ti + 2 < n_tow) { rc = pool_tower(ti + 2); if (rc) return rc; }  // waits for its buffer's last reader; runs under this lane's fc6 and the other lane's tower
+    if (lanes && k + 2 < n_tow) { rc = pool_tower(order[k + 2]); if (rc) return rc; }  // waits for its buffer's last reader; runs under this lane's fc6 and the other lane's tower
     { ProfScope ps(p, MPN_PROF_FC6, ls); rc = linear_c8(lane_ty[ln], N, p->K6, T.w6, T.b6, F, 1, lane_tz6[ln], nullptr, ls, Mp, nullptr, 1); }
     if (rc) return rc;
     { ProfScope ps(p, MPN_PROF_FC7, ls);
       rc = linear_c8(lane_tz6[ln], N, F, T.w7, T.b7, F, 1, p->cat + (size_t)ti * Fcb * Mp * 8, nullptr, ls, Mp, nullptr, 1); }
     if (rc) return rc;
-    if (!overlap && ti + 1 < n_tow) { rc = pool_tower(ti + 1); if (rc) return rc; }
+    if (!overlap && k + 1 < n_tow) { rc = pool_tower(order[k + 1]); if (rc) return rc; }
   }
   if (lanes) {
     MPN_CHECK_HIP(hipEventRecord(p->ev_lane_done, lane_s[1]));

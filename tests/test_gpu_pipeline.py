@@ -732,11 +732,12 @@ def test_two_tower_lanes_are_invisible(dev, model):
     res = {}
     # (lanes, share): share = the "het" tower and the tower of the same Foveal region pool ONE operand (mpn_frcnn::tx3) — also pure scheduling /
     # buffer planning: the narrower tower's mix GEMM reads the K prefix of the wider one's pooled matrix, the same values it would pool itself
-    variants = [(0, 0), (1, 0), (0, 1), (1, 1)] if model == "vggmpn" else [(0, 1), (1, 1)]
-    for lanes, share in variants:
+    # order = the towers run cheapest pooling first instead of in index order (each writes its own slice of the concat: the order is free)
+    variants = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 0), (1, 1, 1), (0, 1, 1), (0, 0, 1)] if model == "vggmpn" else [(0, 1, 1), (1, 1, 1)]
+    for lanes, share, order in variants:
         # the graph towers' lanes are a debug-flavour experiment (tower_lanes = 2: measured without a gain, profiles/r06_tower_lanes_ab.txt);
         # the VGG MultiPathNet's are what ships (1)
-        with hooks(tower_lanes=lanes * (1 if model == "vggmpn" else 2), tower_share=share):
+        with hooks(tower_lanes=lanes * (1 if model == "vggmpn" else 2), tower_share=share, tower_order=order):
             net = mk()
             out = []
             for n in (N, N // 3, N, 7, N):
@@ -751,7 +752,7 @@ def test_two_tower_lanes_are_invisible(dev, model):
             torch.cuda.synchronize()
             for dets, nd in bufs[-2:]:       # the two output sets alternate: the last two calls' records are both still there
                 out.append((dets[: int(nd.item())].clone(), nd.clone()))
-            res[(lanes, share)] = out
+            res[(lanes, share, order)] = out
             del net
     base = res[variants[0]]
     for v in variants[1:]:
