@@ -1538,9 +1538,15 @@ constexpr int S3_TN = 256, S3_TM = 128;                       // block tile: wei
 constexpr int S3_A_BYTES = 3 * 2 * S3_TN * 16;                // 24 KiB: [plane][chunk][row] 16-byte records
 constexpr int S3_B_BYTES = 3 * 2 * S3_TM * 16;                // 12 KiB
 constexpr int S3_STAGE_BYTES = S3_A_BYTES + S3_B_BYTES;       // 36 KiB per k16 stage
-constexpr int S3_RING = 2;
+constexpr int S3_RING = 3;                                    // 108 KiB: stage st + 2 lands while st and st + 1 are being read
 
-__global__ __launch_bounds__(256, 2) void gemm_c8_split3_kernel(Split3Args a) {
+// TWO accumulator sets.  acc (AGPRs) takes the h.h products — the sum to 16 bits of each factor —, acc2 (VGPRs) the five correction products, 2^-8 and
+// 2^-16 of it.  Added into ONE running sum (the first form of this kernel), each of the six products of a k16 step is rounded at the ulp of the big
+// sum: measured at full size against a float64 head, 3.4-3.7e-5 on logits of 16 where the fp32 MFMA pipeline has 2.0e-5, and one full-size parity
+// test at 1.03e-4 of its 1e-4.  Kept apart, the corrections round at 2^-8 of that and the main sum takes one addition per k16 step.  acc + acc2
+// in the epilogue.  Cost: one block per CU (one wave per SIMD) instead of two; the fragments are single-buffered to make room, each plane's
+// registers reloaded for the next stage right after its last product of this one (order h.h, h.l, l.h, h.m, m.h, m.m).
+__global__ __launch_bounds__(256, 1) void gemm_c8_split3_kernel(Split3Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1572,18 +1578,16 @@ __global__ __launch_bounds__(256, 2) void gemm_c8_split3_kernel(Split3Args a) {
     }
   };
 
-  f32x16 acc[4][2];
+  f32x16 acc[4][2], acc2[4][2];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) { acc[mi][ni][r] = 0.0f; acc2[mi][ni][r] = 0.0f; }
 
   // fragments: A (weights) fragment (plane, mi) = the record of row wn * 128 + mi * 32 + l31, chunk `half`; B (ROI rows) (plane, ni) = row
-  // wm * 64 + ni * 32 + l31.  The h-plane fragments are double-buffered (the next stage's first products need them while this stage's last
-  // product still reads the current ones), the m- and l-plane fragments are single-buffered and reloaded for the next stage as soon as their
-  // last product of this stage has been issued: 24 fragments = 96 VGPRs beside the 128 accumulator registers (two blocks per CU).
+  // wm * 64 + ni * 32 + l31: 18 fragments = 72 VGPRs beside the 128 + 128 accumulator registers.
   typedef const s3_bf16x8 __attribute__((address_space(3))) *lds_frag_ptr;
   unsigned fbase[S3_RING][2];  // LDS byte addresses, opaque: every read is base + a 16-bit immediate (plane * 8 / 4 KiB + sub-tile * 512 B)
 #pragma unroll
@@ -1595,9 +1599,9 @@ __global__ __launch_bounds__(256, 2) void gemm_c8_split3_kernel(Split3Args a) {
   }
   auto rda = [&](int slot, int pl, int i) -> s3_bf16x8 { return *(lds_frag_ptr)(size_t)(fbase[slot][0] + (unsigned)(pl * (2 * S3_TN * 16) + i * (32 * 16))); };
   auto rdb = [&](int slot, int pl, int i) -> s3_bf16x8 { return *(lds_frag_ptr)(size_t)(fbase[slot][1] + (unsigned)(pl * (2 * S3_TM * 16) + i * (32 * 16))); };
-  s3_bf16x8 ha[2][4], hb[2][2], ma[4], mb[2], la[4], lb[2];
+  s3_bf16x8 ha[4], hb[2], ma[4], mb[2], la[4], lb[2];
 
-  // prologue: stages st0 (slot 0) and st0 + 1 (slot 1) in flight, the fragments of st0 in registers (h planes in set 0)
+  // prologue: stages st0 (slot 0) and st0 + 1 (slot 1) in flight, the fragments of st0 in registers
 #pragma unroll
   for (int j = 0; j < 9; ++j) issue(st0, 0, j);
 #pragma unroll
@@ -1605,69 +1609,75 @@ __global__ __launch_bounds__(256, 2) void gemm_c8_split3_kernel(Split3Args a) {
   asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { ha[0][i] = rda(0, 0, i); ma[i] = rda(0, 1, i); la[i] = rda(0, 2, i); }
+  for (int i = 0; i < 4; ++i) { ha[i] = rda(0, 0, i); ma[i] = rda(0, 1, i); la[i] = rda(0, 2, i); }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) { hb[0][i] = rdb(0, 0, i); mb[i] = rdb(0, 1, i); lb[i] = rdb(0, 2, i); }
+  for (int i = 0; i < 2; ++i) { hb[i] = rdb(0, 0, i); mb[i] = rdb(0, 1, i); lb[i] = rdb(0, 2, i); }
 
-  // One stage = the six kept plane products in the order l.h, h.l, m.m, m.h, h.m, h.h (small terms first; 8 MFMAs each).  Between the MFMAs,
-  // one LDS / DMA instruction per slot.  BRANCH-FREE: past the last stage the prefetches repeat the last stage (clamped index; nobody reads them).
+  // One stage = six products of 8 MFMAs: h.h -> acc; h.l, l.h, h.m, m.h, m.m -> acc2.  Between the MFMAs one LDS / DMA instruction per slot:
+  // the 9 DMA items of stage st + 2 (ring slot S2: read out two stages ago) during h.h / h.l; the next stage's fragments (slot S1: its DMA was
+  // waited for and published by the barrier at the top) into each plane's registers right after the plane's last product: lb after h.l, la after
+  // l.h, ha after h.m, hb after m.h, ma / mb during the next stage's h.h (they are first needed by its fourth product).
+  // BRANCH-FREE: past the last stage the prefetches repeat the last stage (clamped index; nobody reads them).
   const int st_last = st1 - 1;
-  auto body = [&](int st, auto slot_tag) {   // the h set of a stage is its slot's parity
-    constexpr int SLOT = decltype(slot_tag)::value, SET = SLOT;
-    constexpr int S1 = SLOT ^ 1;   // the slot of stage st + 1; stage st + 2 goes back into SLOT: stage st's fragments all went to registers during stage st - 1
+  auto body = [&](int st, auto slot_tag, bool first) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    constexpr int S1 = (SLOT + 1) % S3_RING, S2 = (SLOT + 2) % S3_RING;
     const int st2 = min(st + 2, st_last);
-    dma_wait_all();        // stage st + 1 has landed (this wave's pieces); the barrier publishes everyone's, and says every wave has finished stage st - 1,
-    __syncthreads();       // i.e. has read the last fragments of stage st out of SLOT
-#define S3_MFMA(A, B, MI, NI)                                                                            \
+    dma_wait_all();        // stage st + 1 has landed (this wave's pieces; issued a whole stage ago) ...
+    __syncthreads();       // ... and everyone's; every wave has also finished stage st - 1, whose fragments were the last reads of slot S2's old tenant
+#define S3_MFMA_INTO(ACC, A, B, MI, NI)                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                   \
-    acc[MI][NI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, acc[MI][NI], 0, 0, 0);                   \
+    ACC[MI][NI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, ACC[MI][NI], 0, 0, 0);                   \
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {  // l.h   (+ the DMA items of stage st + 2 first: they have the rest of this stage to land)
+    for (int t = 0; t < 8; ++t) {  // h.h -> the main sum   (+ this stage's m fragments, which the previous stage's m.m was still using; not in the first stage: the prologue loaded them)
       const int mi = t >> 1, ni = t & 1;
-      S3_MFMA(la[mi], hb[SET][ni], mi, ni)
-      issue(st2, SLOT, t);
+      S3_MFMA_INTO(acc, ha[mi], hb[ni], mi, ni)
+      if (!first) { if (t < 4) ma[t] = rda(SLOT, 1, t); else if (t < 6) mb[t - 4] = rdb(SLOT, 1, t - 4); }
+      if (t >= 6) issue(st2, S2, t - 6);
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {  // h.l
       const int mi = t >> 1, ni = t & 1;
-      S3_MFMA(ha[SET][mi], lb[ni], mi, ni)
-      if (t == 0) issue(st2, SLOT, 8);
-      else if (t < 5) la[t - 1] = rda(S1, 2, t - 1);
+      S3_MFMA_INTO(acc2, ha[mi], lb[ni], mi, ni)
+      if (t < 7) issue(st2, S2, 2 + t);
     }
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {  // m.m
+    for (int t = 0; t < 8; ++t) {  // l.h
       const int mi = t >> 1, ni = t & 1;
-      S3_MFMA(ma[mi], mb[ni], mi, ni)
+      S3_MFMA_INTO(acc2, la[mi], hb[ni], mi, ni)
       if (t < 2) lb[t] = rdb(S1, 2, t);
-      else if (t < 6) ha[SET ^ 1][t - 2] = rda(S1, 0, t - 2);
-      else hb[SET ^ 1][t - 6] = rdb(S1, 0, t - 6);
-    }
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {  // m.h
-      const int mi = t >> 1, ni = t & 1;
-      S3_MFMA(ma[mi], hb[SET][ni], mi, ni)
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {  // h.m
       const int mi = t >> 1, ni = t & 1;
-      S3_MFMA(ha[SET][mi], mb[ni], mi, ni)
-      if (t < 4) ma[t] = rda(S1, 1, t);
+      S3_MFMA_INTO(acc2, ha[mi], mb[ni], mi, ni)
+      if (t < 4) la[t] = rda(S1, 2, t);
     }
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {  // h.h
+    for (int t = 0; t < 8; ++t) {  // m.h
       const int mi = t >> 1, ni = t & 1;
-      S3_MFMA(ha[SET][mi], hb[SET][ni], mi, ni)
-      if (t < 2) mb[t] = rdb(S1, 1, t);
+      S3_MFMA_INTO(acc2, ma[mi], hb[ni], mi, ni)
+      if (t < 4) ha[t] = rda(S1, 0, t);
     }
-#undef S3_MFMA
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {  // m.m
+      const int mi = t >> 1, ni = t & 1;
+      S3_MFMA_INTO(acc2, ma[mi], mb[ni], mi, ni)
+      if (t < 2) hb[t] = rdb(S1, 0, t);
+    }
+#undef S3_MFMA_INTO
   };
   using T0 = std::integral_constant<int, 0>;
   using T1 = std::integral_constant<int, 1>;
+  using T2 = std::integral_constant<int, 2>;
   int st = st0;
+  body(st, T0{}, true);
+  ++st;
   while (st < st1) {
-    body(st, T0{}); if (++st >= st1) break;
-    body(st, T1{}); ++st;
+    body(st, T1{}, false); if (++st >= st1) break;
+    body(st, T2{}, false); if (++st >= st1) break;
+    body(st, T0{}, false); ++st;
   }
   dma_wait_all();  // the clamped prefetches of the last two stages still write this block's LDS: they must have landed before the block ends
 
@@ -1681,7 +1691,8 @@ __global__ __launch_bounds__(256, 2) void gemm_c8_split3_kernel(Split3Args a) {
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
         const int m = m0 + wm * 64 + ni * 32 + l31;
-        const f32x4 v = {acc[mi][ni][g * 4 + 0], acc[mi][ni][g * 4 + 1], acc[mi][ni][g * 4 + 2], acc[mi][ni][g * 4 + 3]};
+        const f32x4 v = {acc[mi][ni][g * 4 + 0] + acc2[mi][ni][g * 4 + 0], acc[mi][ni][g * 4 + 1] + acc2[mi][ni][g * 4 + 1],
+                         acc[mi][ni][g * 4 + 2] + acc2[mi][ni][g * 4 + 2], acc[mi][ni][g * 4 + 3] + acc2[mi][ni][g * 4 + 3]};
         if (n < a.part_np && m < a.part_mp) *reinterpret_cast<f32x4 *>(yb + ((size_t)(n / 8) * a.part_mp + m) * 8 + half * 4) = v;
       }
     }
