@@ -560,7 +560,7 @@ def test_fullsize_fc_three_plane_split_beside_the_fp32_pipeline(O, dev, full, n)
     """MPN_FC_SPLIT3 (fc6 / fc7 as exact three-plane bf16 splits, six bf16 MFMA products per k-step, fp32 accumulate) at FULL size with trained-scale
     heads, isolated from the trunk: both pipelines pool the same device conv5 map, so the difference of their logits / deltas is the fc
     arithmetic alone.  Reported against a float64 head (fc6 -> fc7 -> cls / bbox in float64 on the device's own pooled operand of a 100-ROI
-    sample): the split must be no further from it than 1.5x the fp32 MFMA pipeline is, and the two pipelines within 3e-5 of each other on
+    sample): the split must be no further from it than the fp32 MFMA pipeline is (x 1.2), and the two pipelines within 5e-5 of each other on
     logits of magnitude ~16 (the 1e-4 budget of the path's parity gate is spent on the trunk: tests above)."""
     import bench
     from multipathnet_amd import models
@@ -588,5 +588,5 @@ def test_fullsize_fc_three_plane_split_beside_the_fp32_pipeline(O, dev, full, n)
     bias = float((out["split3"][0].astype(np.float64) - out["fp32"][0]).mean())
     print("N = %d, logits up to %.3g: vs a float64 head on the same pooled operand (%d ROIs): fp32 MFMA %.3g, three-plane split %.3g; split - fp32 pipeline: "
           "max |dlogit| %.3g (mean signed %.2g), max |ddelta| %.3g" % (n, np.abs(out["fp32"][0]).max(), N_SAMPLE, e32, e3, d_l, bias, d_d))
-    assert e3 < max(1.5 * e32, 1e-5)
-    assert d_l < 3e-5 and d_d < 3e-6
+    assert e3 < max(1.2 * e32, 1e-5)          # measured: 1.3-1.4e-5 against the fp32 MFMA pipeline's 2.0-2.1e-5 (two accumulator sets: dense.hip)
+    assert d_l < 5e-5 and d_d < 3e-6          # the two pipelines differ by no more than their two distances to the float64 head add up to

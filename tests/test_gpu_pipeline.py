@@ -768,7 +768,7 @@ def test_two_tower_lanes_are_invisible(dev, model):
 def test_fc6_three_plane_split_vs_oracle_and_fp32_pipeline(O, dev, small):
     """MPN_FC_SPLIT3 (VERDICT r5 task 2; models/vgg.lua:16,30): fc6 on the bf16 matrix pipe — both operands split exactly into three bf16 planes,
     the six plane products of weight >= 2^-16 accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Held to the gate of the fp32 path: logits and
-    deltas within 1e-4 of the oracle, scores within 1e-4, and no further from a float64 head than the fp32-MFMA pipeline is (x 1.5).  Rows do
+    deltas within 1e-4 of the oracle, scores within 1e-4, and no further from a float64 head than the fp32-MFMA pipeline is (x 1.2).  Rows do
     not depend on the batch they are scored in (fixed K ranges)."""
     from multipathnet_amd import models
     s = SMALL
@@ -793,7 +793,7 @@ def test_fc6_three_plane_split_vs_oracle_and_fp32_pipeline(O, dev, small):
     e_split = np.abs(cls - l64).max()
     e_fp32 = np.abs(ref.debug_tensor("cls", small["logits"].shape).cpu().numpy() - l64).max()
     print("logits vs a float64 head on the same pooled operand: three-plane split %.3g, fp32 MFMA %.3g" % (e_split, e_fp32))
-    assert e_split < max(1.5 * e_fp32, 2e-6)
+    assert e_split < max(1.2 * e_fp32, 1e-6)
     # batch invariance + determinism
     s2, b2 = net.detect(im, bx[:37].contiguous(), recompute_features=False)
     assert torch.equal(s2, scores[:37]) and torch.equal(b2, bbox[:37])
