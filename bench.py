@@ -444,7 +444,8 @@ def _oplist_bytes(ops, h, w, batch, esz, tensor_c=None):
 def _cfg_vgg_mpn(models, args):  # BASELINE configs[2]
     n = 1000
     P = models.synthetic_mpnet_params(models.VGG16_CFG, pooled=7, fc_dim=4096, n_classes=81, n_integral=6, seed=557)
-    net = models.MultiPathNet(P, max_h=H, max_w=W, max_rois=n)
+    split3 = getattr(args, "fc_arith", "fp32") == "split3"
+    net = models.MultiPathNet(P, max_h=H, max_w=W, max_rois=n, fc_arith=1 if split3 else 0)
     flops = (367.74e9 + 5 * n * 2.0 * (25088 * 4096 + 4096 * 4096) + 49 * n * 2.0 * 512 * (1280 + 1024 + 1024 + 512 + 1280)
              + n * 2.0 * (16384 * 486 + 4096 * 324))
     cf = conv_flops(models.VGG16_CFG, H, W)
@@ -459,6 +460,12 @@ def _cfg_vgg_mpn(models, args):  # BASELINE configs[2]
     alg_bytes = (_vgg_trunk_bytes(models.VGG16_CFG, H, W)
                  + sum(4.0 * (n * 49 * c * 2 + c * 512 + n * 25088 * 2 + 25088 * 4096 + n * 4096 * 2 + 4096 * 4096 + n * 4096) for c in tow_c)
                  + 4.0 * (16384 * 486 + 4096 * 324 + n * 20480 + n * (486 + 324)))
+    if split3:
+        return dict(params=P, net=net, n_rois=n, flops=flops, dtype="f32 (fc6 / fc7: 3-plane bf16 split, 6 products, fp32 accumulate)", groups=groups, key="c3_split3",
+                    cpu_baseline=None, alg_bytes=alg_bytes,
+                    metric="proposals/sec (1000 ROIs, 600x1000 img) VGG-16 MultiPathNet, the towers' fc6 / fc7 on the bf16 matrix pipe as exact three-plane splits "
+                           "with fp32 accumulation [MPN_FC_SPLIT3; auxiliary line: BASELINE configs[2] in plain fp32 is the --config c3 line]",
+                    workload="VGG-16 MultiPathNet (4 foveal towers + box tower, conv3/4/5 skip pooling, K = 6 integral classifiers, 81 classes), 1000 ROIs; fc6 / fc7 = 6 bf16 plane products")
     return dict(params=P, net=net, n_rois=n, flops=flops, dtype="f32", groups=groups, key="c3", cpu_baseline=cpu, alg_bytes=alg_bytes,
                 metric="proposals/sec (1000 ROIs, 600x1000 img) VGG-16 MultiPathNet [BASELINE configs[2]; not the headline metric]",
                 workload="VGG-16 MultiPathNet (4 foveal towers + box tower, conv3/4/5 skip pooling, K = 6 integral classifiers, 81 classes), 1000 ROIs")
@@ -923,7 +930,7 @@ def main():
                          "own metric string (never the headline): same timed loop, whole-path rates only")
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16"], help="c4 only (c5 is bf16, the rest fp32)")
     ap.add_argument("--fc-arith", default="fp32", choices=["fp32", "split3"],
-                    help="c2 only.  split3 = fc6 on the bf16 matrix pipe (both operands as exact three-plane bf16 splits, six products, fp32 accumulate: "
+                    help="c2 / c3 only.  split3 = fc6 / fc7 on the bf16 matrix pipe (both operands as exact three-plane bf16 splits, six products, fp32 accumulate: "
                          "include/mpn.h MPN_FC_SPLIT3) — an AUXILIARY line with its own metric string and dtype, never the headline")
     ap.add_argument("--rois", type=int, default=N_ROIS,
                     help="c2 only: another proposal count for the headline model (e.g. 2000, scripts/eval_fastrcnn_voc2007.sh) -> an AUXILIARY line with its "
@@ -1216,11 +1223,11 @@ def main():
                    "kernels": kernels}
             if world == 1 and not args.no_cpu_baseline and other.get("cpu_baseline"):
                 out["cpu_baseline"] = other["cpu_baseline"](im_np, boxes_np)
-            if other["key"].startswith("c2_split3") and "fc6" in kernels:
+            if "split3" in other["key"] and "fc6" in kernels:
                 fc6_ms = kernels["fc6"]["ms_per_image"]
                 out["fc6_split3"] = {"ms_per_image": fc6_ms, "what": "operand split (split3_planes_kernel) + gemm_c8_split3_kernel + splitk_reduce_kernel",
-                                     "bf16_mfma_flops_per_image": 6 * 2.0 * n_rois_cfg * 25088 * 4096,
-                                     "frac_of_bf16_mfma_peak_2.5PF": round(6 * 2.0 * n_rois_cfg * 25088 * 4096 / (fc6_ms * 1e-3) / 2500e12, 4),
+                                     "bf16_mfma_flops_per_image": 6 * groups["fc6"]["alg"],
+                                     "frac_of_bf16_mfma_peak_2.5PF": round(6 * groups["fc6"]["alg"] / (fc6_ms * 1e-3) / 2500e12, 4),
                                      "note": "the group's executed_frac_of_fp32_mfma_peak above prices fp32-equivalent FLOPs against the fp32 pipe's peak and may exceed 1: "
                                              "the six bf16 products run on the bf16 pipe (16x the fp32 MFMA rate)"}
             print(json.dumps(out))

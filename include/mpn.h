@@ -282,7 +282,7 @@ typedef struct mpn_frcnn_config {
                               (num_iter - 1) * N rows reach the NMS */
   int roi_bin_rule;        /* MPN_ROI_BINS_CAFFE (0, default: inn.ROIPooling's CUDA branch) | MPN_ROI_BINS_ADAPTIVE (its CPU branch): the
                               rule of every ROI pooling of the pipeline — mpn_roi_pool_forward_rule.  (added in MPN_VERSION 600, at the END) */
-  int fc_arith;            /* MPN_FC_FP32 (0, default): fc6 on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32).  MPN_FC_SPLIT3 (1; mpn_frcnn_create only): fc6 and fc7
+  int fc_arith;            /* MPN_FC_FP32 (0, default): fc6 on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32).  MPN_FC_SPLIT3 (1; mpn_frcnn_create / mpn_mpnet_create): fc6 and fc7
                               on the bf16 pipe with fp32-level results — both operands split exactly into three bf16 planes (h + m + l = the fp32 value),
                               the six plane products of weight >= 2^-16 accumulated in fp32, the three <= 2^-24 ones (the size of an fp32 product's own
                               rounding) dropped.  An AUXILIARY arithmetic: the headline and every parity claim are MPN_FC_FP32.  (MPN_VERSION 600) */

@@ -265,7 +265,7 @@ struct mpn_frcnn {
   int last_n = 0, last_rows = 0;
   int fuse_pool = 1;
   // ---- MultiPathNet head (models/multipathnet.lua:64-120); empty for plain Fast R-CNN
-  struct Tower { int region, use4, use3, total_feat; float *mix_w, *mix_b, *w6, *b6, *w7, *b7; };
+  struct Tower { int region, use4, use3, total_feat; float *mix_w, *mix_b, *w6, *b6, *w7, *b7; unsigned short *w6_s3 = nullptr, *w7_s3 = nullptr; };
   bool is_mpnet = false;
   std::vector<int> rn_region;   // ResNet towers: Foveal region per tower (empty = plain resnet.lua)
   ResNetGraph *rn = nullptr;  // ResNet Fast R-CNN (mpn_resnet_create): trunk + per-ROI layer4 replace the VGG convs / fc6 / fc7
@@ -294,6 +294,7 @@ struct mpn_frcnn {
   // launch run under the other lane's fc6 / fc7 instead of leaving the matrix pipe idle.  Pure scheduling: bit-identical results.
   unsigned short *w6_s3 = nullptr, *x6_s3 = nullptr;  // MPN_FC_SPLIT3: fc6's weights (packed once) and operand (per image) as three bf16 planes
   unsigned short *w7_s3 = nullptr, *y6_s3 = nullptr;  // ... and fc7's
+  unsigned short *ty_s3[2] = {nullptr, nullptr}, *tz6_s3[2] = {nullptr, nullptr};  // MultiPathNet towers: the per-lane fc6 / fc7 operands as planes
   hipStream_t tower_stream = nullptr;
   hipEvent_t ev_lane_go = nullptr, ev_lane_done = nullptr;
   float *ty2 = nullptr, *tz6_2 = nullptr;
@@ -471,7 +472,7 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
   p->cfg.pool_after = p->pool_after.data();
   int rc = MPN_OK;
 #define TRY(x) do { rc = (x); if (rc != MPN_OK) { mpn_frcnn_destroy(p); return rc; } } while (0)
-  TRY((cfg->fc_arith == MPN_FC_FP32 || (cfg->fc_arith == MPN_FC_SPLIT3 && !graph_net && !mw)) ? MPN_OK : (set_error("mpn_frcnn_config.fc_arith: %d (MPN_FC_SPLIT3 is for mpn_frcnn_create pipelines)", cfg->fc_arith), MPN_EINVAL));
+  TRY((cfg->fc_arith == MPN_FC_FP32 || (cfg->fc_arith == MPN_FC_SPLIT3 && !graph_net)) ? MPN_OK : (set_error("mpn_frcnn_config.fc_arith: %d (MPN_FC_SPLIT3 is for mpn_frcnn_create / mpn_mpnet_create pipelines)", cfg->fc_arith), MPN_EINVAL));
   TRY((cfg->roi_bin_rule == MPN_ROI_BINS_CAFFE || cfg->roi_bin_rule == MPN_ROI_BINS_ADAPTIVE) ? MPN_OK : (set_error("mpn_frcnn_config.roi_bin_rule: %d is not an MPN_ROI_BINS_* value", cfg->roi_bin_rule), MPN_EINVAL));
   // ---- trunk buffers + packed weights
   int h = cfg->max_h, w = cfg->max_w, cin = 3;
@@ -547,6 +548,15 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
       TRY(dev_alloc(p, &T.w7, lin_wpk_elems(F32, F) * sizeof(float), false));
       TRY(dev_alloc(p, &T.b7, (size_t)lin_np(F) * sizeof(float), false));
       TRY(pack_linear_weights(mw->fc7_w[t], mw->fc7_b[t], F, F, 1, T.w7, T.b7, nullptr));
+      if (cfg->fc_arith == MPN_FC_SPLIT3) {  // the towers' fc6 / fc7 weights as three bf16 planes (include/mpn.h)
+        float *tmp = nullptr;
+        TRY(dev_alloc(p, &tmp, split3_plane_elems(p->K6, lin_np(F)) * sizeof(unsigned short), true));
+        T.w6_s3 = reinterpret_cast<unsigned short *>(tmp);
+        TRY(split3_planes(T.w6, p->K6, lin_np(F), lin_np(F), T.w6_s3, nullptr));
+        TRY(dev_alloc(p, &tmp, split3_plane_elems(F, lin_np(F)) * sizeof(unsigned short), true));
+        T.w7_s3 = reinterpret_cast<unsigned short *>(tmp);
+        TRY(split3_planes(T.w7, F, lin_np(F), lin_np(F), T.w7_s3, nullptr));
+      }
       p->towers.push_back(T);
     }
     const int n_fov = mw->n_towers - 1, K = p->n_integral;
@@ -585,6 +595,14 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
     TRY(dev_alloc(p, &p->tx, (size_t)(round_up(max_feat, 64) / 8) * rows * 8 * sizeof(float), true));
     TRY(dev_alloc(p, &p->ty, (size_t)(lin_np(c5) / 8) * rows * 8 * sizeof(float), true));
     TRY(dev_alloc(p, &p->tz6, (size_t)(lin_np(F) / 8) * p->Mp * 8 * sizeof(float), true));
+    if (cfg->fc_arith == MPN_FC_SPLIT3)
+      for (int ln = 0; ln < (mw->n_towers > 1 ? 2 : 1); ++ln) {
+        float *tmp = nullptr;
+        TRY(dev_alloc(p, &tmp, split3_plane_elems(p->K6, p->Mp) * sizeof(unsigned short), true));
+        p->ty_s3[ln] = reinterpret_cast<unsigned short *>(tmp);
+        TRY(dev_alloc(p, &tmp, split3_plane_elems(F, p->Mp) * sizeof(unsigned short), true));
+        p->tz6_s3[ln] = reinterpret_cast<unsigned short *>(tmp);
+      }
     if (mw->n_towers > 1) {  // the second tower lane
       TRY(dev_alloc(p, &p->ty2, (size_t)(lin_np(c5) / 8) * rows * 8 * sizeof(float), true));
       TRY(dev_alloc(p, &p->tz6_2, (size_t)(lin_np(F) / 8) * p->Mp * 8 * sizeof(float), true));
@@ -923,10 +941,19 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
     if (rc) return rc;
     if (overlap) MPN_CHECK_HIP(hipEventRecord(p->ev_mix_done[b], ls));
     if (lanes && k + 2 < n_tow) { rc = pool_tower(order[k + 2]); if (rc) return rc; }  // waits for its buffer's last reader; runs under this lane's fc6 and the other lane's tower
-    { ProfScope ps(p, MPN_PROF_FC6, ls); rc = linear_c8(lane_ty[ln], N, p->K6, T.w6, T.b6, F, 1, lane_tz6[ln], nullptr, ls, Mp, nullptr, 1); }
+    { ProfScope ps(p, MPN_PROF_FC6, ls);
+      if (T.w6_s3) {  // MPN_FC_SPLIT3 (auxiliary arithmetic)
+        rc = split3_planes(lane_ty[ln], p->K6, Mp, Mp, p->ty_s3[ln], ls);
+        if (rc == MPN_OK) rc = linear_c8_split3(p->ty_s3[ln], N, p->K6, T.w6_s3, T.b6, F, 1, lane_tz6[ln], ls);
+      } else
+        rc = linear_c8(lane_ty[ln], N, p->K6, T.w6, T.b6, F, 1, lane_tz6[ln], nullptr, ls, Mp, nullptr, 1); }
     if (rc) return rc;
     { ProfScope ps(p, MPN_PROF_FC7, ls);
-      rc = linear_c8(lane_tz6[ln], N, F, T.w7, T.b7, F, 1, p->cat + (size_t)ti * Fcb * Mp * 8, nullptr, ls, Mp, nullptr, 1); }
+      if (T.w7_s3) {
+        rc = split3_planes(lane_tz6[ln], F, Mp, Mp, p->tz6_s3[ln], ls);
+        if (rc == MPN_OK) rc = linear_c8_split3(p->tz6_s3[ln], N, F, T.w7_s3, T.b7, F, 1, p->cat + (size_t)ti * Fcb * Mp * 8, ls);
+      } else
+        rc = linear_c8(lane_tz6[ln], N, F, T.w7, T.b7, F, 1, p->cat + (size_t)ti * Fcb * Mp * 8, nullptr, ls, Mp, nullptr, 1); }
     if (rc) return rc;
     if (!overlap && k + 1 < n_tow) { rc = pool_tower(order[k + 1]); if (rc) return rc; }
   }

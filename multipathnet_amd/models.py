@@ -542,8 +542,7 @@ class FastRCNN(object):
         if fc_arith is None:
             fc_arith = os.environ.get("MPN_FC_ARITH", "0")
         fc_arith = {"0": 0, "fp32": 0, "1": 1, "split3": 1}[str(fc_arith)]
-        plain_vgg = not (self.is_resnet or self.is_graph or self.is_mpnet)
-        c.fc_arith = fc_arith if plain_vgg else 0
+        c.fc_arith = 0 if (self.is_resnet or self.is_graph) else fc_arith   # the VGG pipelines (Fast R-CNN, MultiPathNet towers) have fc6 / fc7
         self.fc_arith = c.fc_arith
         self.scale, self.max_size = scale, max_size
         self._cfg = c
