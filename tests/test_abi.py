@@ -78,6 +78,11 @@ def test_arg_errors_do_not_need_a_gpu():
     assert rc == -1 and b"invalid argument" in lib.mpn_last_error()
     rc = lib.mpn_nms_batched(None, None, 1, 1 << 20, ctypes.c_float(0.3), None, None, None, None)
     assert rc == -1
+    # round 6: the ROI-pooling bin rule is validated before anything touches the device (N = 0 with a valid rule is a no-op)
+    assert lib.mpn_roi_pool_forward_rule(None, 1, 8, 4, 4, None, 0, 7, 7, ctypes.c_float(1.0), ctypes.c_float(1.0), 0, 5, None, None, None) == -1
+    assert b"invalid argument" in lib.mpn_last_error()
+    assert lib.mpn_roi_pool_forward_rule(None, 1, 8, 4, 4, None, 0, 7, 7, ctypes.c_float(1.0), ctypes.c_float(1.0), 0, 1, None, None, None) == 0
+    assert lib.mpn_version() == 600
     # the three pipeline constructors reject missing descriptors before touching the device
     h = ctypes.c_void_p()
     assert lib.mpn_frcnn_create(None, None, None, None, None, None, None, None, None, None, None, ctypes.byref(h)) == -1
