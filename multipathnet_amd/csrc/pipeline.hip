@@ -370,6 +370,10 @@ MPN_KNOB(int, g_first_k36, 1);  // 0: the first layer on the generic direct kern
 MPN_KNOB(int, g_roi_pool_pm, 1);  // 0: ROI pooling straight from the C8P map (roi_pool_c8_kernel)
 MPN_KNOB(int, g_mix_fold, 1);     // 0: MultiPathNet's nn.Normalize scales applied in place (l2norm_apply) instead of inside the mix GEMM
 MPN_KNOB(int, g_tower_lanes, 1);  // 0: the towers of an image one after the other on the caller's stream (rounds 2-5) instead of two lanes (mpn_debug_set_tower_lanes)
+#ifdef MPN_DEBUG_HOOKS
+static int g_mpn_pool_knock = 0;
+extern "C" void mpn_debug_set_mpn_pool_knock(int v) { g_mpn_pool_knock = v; }
+#endif
 MPN_KNOB(int, g_tower_order, 1);  // 0: the towers in index order instead of cheapest pooling first (mpn_debug_set_tower_order)
 MPN_KNOB(int, g_tower_share, 1);  // 0: every tower pools its own operand even where two of them pool the same region's maps (mpn_debug_set_tower_share)
 MPN_KNOB(int, g_pool_overlap, 1); // 0: MultiPathNet's skip pooling on the launch stream instead of its own stream under the previous tower's GEMMs
@@ -880,6 +884,12 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
   }
   auto pool_tower = [&](int t) -> int {  // pooling (+ normalisation scales) of tower t's operand on the pooling stream
     if (!pools[t]) return MPN_OK;          // the other tower of the shared pair pooled it
+#ifdef MPN_DEBUG_HOOKS
+    if (g_mpn_pool_knock) {                // mpn_debug_set_mpn_pool_knock (timing only, stale operands): what the skip pooling costs the towers' GEMMs
+      if (overlap) MPN_CHECK_HIP(hipEventRecord(p->ev_pool_done[buf_of[t]], ps_stream));
+      return MPN_OK;
+    }
+#endif
     const mpn_frcnn::Tower &T = p->towers[pool_src[t]];
     const int b = buf_of[t];
     float *txb = tx_of[b];

@@ -37,7 +37,7 @@ boxes = np.clip(boxes[:N], 1, [1000, 600, 1000, 600]).astype(np.float32)
 im, boxes = torch.from_numpy(im).to(dev), torch.from_numpy(boxes).to(dev)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from conftest import HOOK_DEFAULTS
-DEFAULTS = dict(HOOK_DEFAULTS, pool_exp=0, tower_knock=0)
+DEFAULTS = dict(HOOK_DEFAULTS, pool_exp=0, tower_knock=0, mpn_pool_knock=0)
 
 
 def run(leg):

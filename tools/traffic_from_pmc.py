@@ -3,6 +3,9 @@ dominant kernel groups (FETCH_SIZE / WRITE_SIZE are in KB; gfx950 correction fro
 counts the 128-byte requests of wide coalesced reads as 64 B, so it is doubled)."""
 import json, os, re, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+# --commit <hash>: the commit whose binary the PMC passes were collected on (VERDICT r5 task 5: roofline.traffic_source names it)
+commit = sys.argv[sys.argv.index("--commit") + 1] if "--commit" in sys.argv else None
+COMMIT_NOTE = ("; collected on the binary of commit %s" % commit) if commit else ""
 if "--config" in sys.argv:  # the other BASELINE configs: the DOMINANT kernel (by total duration) of `bench.py --config <key>` under the two PMC passes
     key = sys.argv[sys.argv.index("--config") + 1]
     images_arg = sys.argv[sys.argv.index("--images") + 1] if "--images" in sys.argv else "auto"
@@ -26,7 +29,7 @@ if "--config" in sys.argv:  # the other BASELINE configs: the DOMINANT kernel (b
                             "bytes_per_image": round((fb + wb) / images), "fetch_bytes_per_image": round(fb / images), "write_bytes_per_image": round(wb / images)},
                "all_kernels_bytes_per_image": round(tot / images), "images_sampled": images,
                "_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --config ... --steps 2 --warmup 1 "
-                          "--no-cpu-baseline --sustained-seconds 0; summaries in profiles/%s_%s_pmc_fetch.summary.txt and _write; FETCH_SIZE doubled (gfx950 128-B request correction)" % (tag, key)}
+                          "--no-cpu-baseline --sustained-seconds 0; summaries in profiles/%s_%s_pmc_fetch.summary.txt and _write; FETCH_SIZE doubled (gfx950 128-B request correction)" % (tag, key) + COMMIT_NOTE}
     json.dump(tj, open("profiles/traffic.json", "w"), indent=1)
     print(json.dumps(tj[key], indent=1))
     sys.exit(0)
@@ -52,7 +55,7 @@ for g in groups:
         res[g] = {"fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write), "bytes_per_launch": round(fetch + write),
                   "launches_sampled": f[g][0]}
 res["_source"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 3 --warmup 1 "
-                  "--no-cpu-baseline; summaries in profiles/%s_pmc_fetch.summary.txt and _write; FETCH_SIZE doubled (gfx950 128-B request correction)" % tag)
+                  "--no-cpu-baseline; summaries in profiles/%s_pmc_fetch.summary.txt and _write; FETCH_SIZE doubled (gfx950 128-B request correction)" % tag) + COMMIT_NOTE
 old = json.load(open("profiles/traffic.json")) if os.path.exists("profiles/traffic.json") else {}
 for k_, v_ in old.items():   # keep the per-config entries (c1 / c3 / c4 / c5) written by --config
     if isinstance(v_, dict) and "dominant" in v_:
