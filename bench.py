@@ -929,6 +929,7 @@ def main():
                     help="c2 (default) = the headline line, BASELINE configs[1].  c1 / c3 / c4 / c5 = the other BASELINE configs, each with its "
                          "own metric string (never the headline): same timed loop, whole-path rates only")
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16"], help="c4 only (c5 is bf16, the rest fp32)")
+    ap.add_argument("--no-fc-split3-leg", action="store_true", help="c2 only: skip the auxiliary `fc_split3_aux` leg (the same model with MPN_FC_SPLIT3)")
     ap.add_argument("--fc-arith", default="fp32", choices=["fp32", "split3"],
                     help="c2 / c3 only.  split3 = fc6 / fc7 on the bf16 matrix pipe (both operands as exact three-plane bf16 splits, six products, fp32 accumulate: "
                          "include/mpn.h MPN_FC_SPLIT3) — an AUXILIARY line with its own metric string and dtype, never the headline")
@@ -1252,6 +1253,31 @@ def main():
     power_sens = None
     if world == 1 and not args.no_power_sensitivity:
         power_sens = power_sensitivity(torch, models, P, im_dev, boxes_dev, dev_index, prof)
+    # Auxiliary leg (round 6; never the metric): the SAME model and inputs with fc6 / fc7 on the bf16 matrix pipe as exact three-plane splits with fp32
+    # accumulation (include/mpn.h MPN_FC_SPLIT3) — so that the driver's own record carries this figure measured on the driver's box.  Inputs resident
+    # in HBM, the pipelined form, --steps steps after --warmup; a failure here never touches the headline.  `bench.py --fc-arith split3` is the full line.
+    fc_split3_aux = None
+    if world == 1 and not args.no_fc_split3_leg:
+        try:
+            net3 = models.FastRCNN(P, max_h=H, max_w=W, max_rois=N_ROIS, fc_arith=1)
+            for _ in range(args.warmup):
+                net3.test_one_pipelined(im_dev, boxes_dev)
+            net3.flush(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                net3.test_one_pipelined(im_dev, boxes_dev)
+            net3.flush(); torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t0
+            s3, _ = net3.detect(im_dev, boxes_dev)
+            s1, _ = net.detect(im_dev, boxes_dev)
+            fc_split3_aux = {"value": round(args.steps * N_ROIS / dt3, 1), "unit": "proposals/s", "ms_per_step": round(dt3 / args.steps * 1e3, 4),
+                             "dtype": "f32 (fc6 / fc7: 3-plane bf16 split, 6 products, fp32 accumulate)", "inputs": "resident in HBM",
+                             "max_abs_score_difference_to_the_fp32_mfma_pipeline": float((s3 - s1).abs().max().item()),
+                             "note": "AUXILIARY, never the metric: the headline above is pure fp32 MFMA.  Gate and accuracy: DESIGN.md 4.2b, tools/r06_split3_gate.sh"}
+            del net3
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            fc_split3_aux = {"error": "%s: %s" % (type(e).__name__, e)}
     mixed = None
     if args.mixed_sizes:
         mixed = mixed_sizes_leg(torch, dist, models, P, dev, dev_index, world, rank, max(args.sustained_seconds, 1.0),
@@ -1322,6 +1348,8 @@ def main():
                 out["roofline"]["traffic_source"] = tj.get("_source")
         if power_sens is not None:
             out["power_sensitivity"] = power_sens
+        if fc_split3_aux is not None:
+            out["fc_split3_aux"] = fc_split3_aux
         if mixed is not None:
             out["mixed_sizes"] = mixed
         if world == 1 and not args.no_cpu_baseline:
