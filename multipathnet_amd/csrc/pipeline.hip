@@ -276,7 +276,7 @@ struct mpn_frcnn {
   float *wcls = nullptr, *bcls = nullptr, *wbbox = nullptr, *bbbox = nullptr;
   Act tap_act[3];  // conv5, conv4, conv3 of the last trunk run
   float *vmax_tab[3] = {nullptr, nullptr, nullptr};  // vertical range-max tables of the three maps (MultiPathNet ROI pools)
-  bool vmax_valid = false;                            // built for the current tap_act maps
+  bool vmax_built[3] = {false, false, false};         // built for the current tap_act maps (per map: the pooling stream builds a map's tables where its first pooling is enqueued)
   bool vmax_pm = false;                               // ... in the pixel-major form
   float *mix_scale = nullptr;                         // [2 tower parities][3][Mp]: per-(map, ROI) nn.Normalize scales the mix GEMM applies
   // tower t + 1's skip pooling (L2 -> L1 bound, no matrix work) runs on its own stream under tower t's GEMMs (matrix-bound):
@@ -374,6 +374,7 @@ MPN_KNOB(int, g_tower_lanes, 1);  // 0: the towers of an image one after the oth
 static int g_mpn_pool_knock = 0;
 extern "C" void mpn_debug_set_mpn_pool_knock(int v) { g_mpn_pool_knock = v; }
 #endif
+MPN_KNOB(int, g_tables_lazy, 1);  // 0: all range-max tables on the launch stream in front of the head (rounds 3-5) instead of per map on the pooling stream (mpn_debug_set_tables_lazy)
 MPN_KNOB(int, g_tower_order, 1);  // 0: the towers in index order instead of cheapest pooling first (mpn_debug_set_tower_order)
 MPN_KNOB(int, g_tower_share, 1);  // 0: every tower pools its own operand even where two of them pool the same region's maps (mpn_debug_set_tower_share)
 MPN_KNOB(int, g_pool_overlap, 1); // 0: MultiPathNet's skip pooling on the launch stream instead of its own stream under the previous tower's GEMMs
@@ -395,6 +396,7 @@ extern "C" void mpn_debug_set_pool_overlap(int v) { g_pool_overlap = v; }
 extern "C" void mpn_debug_set_tower_lanes(int v) { g_tower_lanes = v; }
 extern "C" void mpn_debug_set_tower_share(int v) { g_tower_share = v; }
 extern "C" void mpn_debug_set_tower_order(int v) { g_tower_order = v; }
+extern "C" void mpn_debug_set_tables_lazy(int v) { g_tables_lazy = v; }
 extern "C" void mpn_debug_set_halo_memset(int v) { g_halo_memset = v; }
 extern "C" void mpn_debug_set_defer_heads(int v) { g_defer_heads = v; }
 #endif
@@ -756,7 +758,7 @@ static int run_trunk(mpn_frcnn *p, const float *d_image, int H, int W, hipStream
     p->last_h = H; p->last_w = W;
   }
   Act cur = make_act(p->img_c8p, 3, H, W);
-  p->vmax_valid = false;
+  p->vmax_built[0] = p->vmax_built[1] = p->vmax_built[2] = false;
   p->feat_pm_valid = false;
   int rc;
   { ProfScope ps(p, MPN_PROF_TRANSFORM, s);
@@ -809,13 +811,18 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
   const float kConv345Factor[3] = {1.0f, (float)(1.0 / 30), (float)(1.0 / 200)};  // model_utils.lua:231-237 normFactor (Lua doubles -> float)
   const int Fcb = lin_np(F) / 8;
   const bool pm = g_roi_pool_pm != 0;  // pixel-major range-max tables + fused sum of squares (round 3); 0 = the C8P form (test hook)
-  if (!p->vmax_valid || p->vmax_pm != pm) {  // once per trunk run; iterative localisation on the cached maps reuses them
-    ProfScope ps(p, MPN_PROF_ROIPOOL, s);
-    for (int m = 0; m < 3 && rc == MPN_OK; ++m) rc = pm ? build_vmax_tables_pm(maps[m], p->vmax_tab[m], s) : build_vmax_tables(maps[m], p->vmax_tab[m], s);
-    if (rc) return rc;
-    p->vmax_valid = true;
-    p->vmax_pm = pm;
-  }
+  // The range-max tables: once per trunk run and map (iterative localisation on the cached maps reuses them).  Round 6: with the pooling
+  // stream, a map's tables are built THERE, where the first pooling that reads them is enqueued — the first tower in execution order pools
+  // conv5 alone (cheapest first), so only conv5's small tables (1/7 of the bytes) stand between the trunk and the first GEMM; conv4's and
+  // conv3's levels (HBM-bound writes) are built under that tower's GEMMs instead of in front of everything.
+  if (p->vmax_pm != pm) { p->vmax_built[0] = p->vmax_built[1] = p->vmax_built[2] = false; p->vmax_pm = pm; }
+  auto build_tables = [&](int m, hipStream_t st) -> int {
+    if (p->vmax_built[m]) return MPN_OK;
+    ProfScope ps(p, MPN_PROF_ROIPOOL, st);
+    const int rcb = pm ? build_vmax_tables_pm(maps[m], p->vmax_tab[m], st) : build_vmax_tables(maps[m], p->vmax_tab[m], st);
+    if (rcb == MPN_OK) p->vmax_built[m] = true;
+    return rcb;
+  };
   // nn.Normalize's per-(ROI, map) scale folded into the mix GEMM (linear_c8_rowscaled).  Fold or in-place l2norm_apply is decided by
   // the network alone (channel counts), never by the ROI count, and the mix GEMM — K = the channel concat, >= 49 row tiles for any N —
   // always runs as ONE un-split accumulation chain, so a ROI's mix output does not depend on the rows it is batched with (ADVICE r3:
@@ -829,6 +836,8 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
   // ordered on `s`.  (Profiling scopes time each stream's own work; with overlap their sum exceeds the wall time.)
   const bool overlap = pm && p->pool_stream && p->tx2 && g_pool_overlap;
   hipStream_t ps_stream = overlap ? p->pool_stream : s;
+  if (!(overlap && g_tables_lazy))   // one stream (or the round-3..5 order, hook tables_lazy = 0): all tables up front
+    for (int m = 0; m < 3; ++m) if ((rc = build_tables(m, s)) != MPN_OK) return rc;
   if (overlap) {  // the tables, the Foveal regions and everything before them on `s`
     MPN_CHECK_HIP(hipEventRecord(p->ev_pool_go, s));
     MPN_CHECK_HIP(hipStreamWaitEvent(ps_stream, p->ev_pool_go, 0));
@@ -901,6 +910,7 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
     for (int m = 0; m < 3; ++m) {
       if (!used[m]) continue;
       float *dst = txb + (size_t)cb_off * PP * Mp * 8;
+      if ((rcl = build_tables(m, ps_stream)) != MPN_OK) return rcl;   // (first reader of the map's tables this trunk run)
       { ProfScope ps(p, MPN_PROF_ROIPOOL, ps_stream);
         if (pm) {
           float *sc_out = fold_scale ? p->mix_scale + ((size_t)b * 3 + seg) * p->Mp : nullptr;

@@ -765,6 +765,48 @@ def test_two_tower_lanes_are_invisible(dev, model):
 
 
 @pytest.mark.gpu
+def test_range_max_tables_built_on_the_pooling_stream_are_invisible(dev):
+    """Round 6: a map's range-max tables are built on the pooling stream where its first pooling is enqueued (conv5's in front of the first
+    tower, conv4's / conv3's under that tower's GEMMs) instead of all of them on the launch stream in front of the head.  Pure scheduling:
+    scores, boxes and detections are bit-identical to the up-front order (hook tables_lazy = 0), with and without the shared operand, with a
+    three-map tower first (tower_order = 0), for ROI counts in a row and on the cached maps + tables of the iterative-localisation path."""
+    from multipathnet_amd import models
+    rng = np.random.default_rng(6)
+    cfg = [16, 32, "P", 32, 64, "P", 64, 96, "P", 128, "P", 384]
+    H, W, N = 180, 290, 300
+    P = models.synthetic_mpnet_params(cfg, pooled=7, fc_dim=256, n_classes=9, n_integral=3, seed=12)
+    im = torch.from_numpy(rng.random((3, H, W), dtype=np.float32)).to(dev)
+    bx = torch.from_numpy(_boxes(rng, N, W, H, lo=4)).to(dev)
+    res = {}
+    for lazy, share, order in [(0, 1, 1), (1, 1, 1), (1, 0, 1), (1, 1, 0), (1, 0, 0)]:
+        with hooks(tables_lazy=lazy, tower_share=share, tower_order=order):
+            net = models.MultiPathNet(P, cfg=cfg, pooled=7, spatial_scale=1 / 16, max_h=H, max_w=W, max_rois=N)
+            out = []
+            for n in (N, 40, N // 2, 3):
+                s, b = net.detect(im, bx[:n].contiguous())
+                out.append((s.clone(), b.clone()))
+                s, b = net.detect(im, bx[n // 2:n // 2 + 50].contiguous(), recompute_features=False)   # the cached maps AND their tables (ImageDetect.lua:107-111)
+                out.append((s.clone(), b.clone()))
+            for _ in range(2):
+                dets, nd = net.test_one_async(im, bx)
+                torch.cuda.synchronize()
+                out.append((dets[: int(nd.item())].clone(), nd.clone()))
+            bufs = [net.test_one_pipelined(im, bx) for _ in range(4)]
+            net.flush()
+            torch.cuda.synchronize()
+            for dets, nd in bufs[-2:]:
+                out.append((dets[: int(nd.item())].clone(), nd.clone()))
+            res[(lazy, share, order)] = out
+            del net
+    base = res[(0, 1, 1)]
+    for v, r in res.items():
+        assert len(r) == len(base)
+        for a, b in zip(base, r):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y), v
+
+
+@pytest.mark.gpu
 def test_fc6_three_plane_split_vs_oracle_and_fp32_pipeline(O, dev, small):
     """MPN_FC_SPLIT3 (VERDICT r5 task 2; models/vgg.lua:16,30): fc6 on the bf16 matrix pipe — both operands split exactly into three bf16 planes,
     the six plane products of weight >= 2^-16 accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Held to the gate of the fp32 path: logits and
