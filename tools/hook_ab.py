@@ -1,5 +1,5 @@
 """Generic A/B of debug-flavour hooks on the pipelined loop of one BASELINE config: interleaved legs, best of 3.
-Usage: MPN_FLAVOUR=debug python tools/hook_ab.py <c3|c4|c5> [images per leg] leg [leg ...]     leg = name=value[,name=value...] | base
+Usage: MPN_FLAVOUR=debug python tools/hook_ab.py <c2|c3|c4|c5> [images per leg] leg [leg ...]     leg = name=value[,name=value...] | base
   e.g. tools/hook_ab.py c5 12 base pool_exp=1 pool_exp=2 pool_exp=3"""
 import os, sys, time
 os.environ.setdefault("MPN_FLAVOUR", "debug")
@@ -25,6 +25,10 @@ elif cfg == "c4":
     N = 1000
     net = models.ResNetFRCNN(models.synthetic_resnet_mpn_params(depth=50, n_classes=81, n_integral=6, seed=557), max_h=600, max_w=1000, max_rois=N, bf16=True)
     name = "configs[3] ResNet-50 MultiPathNet bf16, 1000 ROIs"
+elif cfg == "c2":
+    N = 1000
+    net = models.FastRCNN(models.synthetic_params(models.VGG16_CFG, pooled=7, fc_dim=4096, n_classes=21, seed=557), max_h=600, max_w=1000, max_rois=N)
+    name = "configs[1] VGG-16 Fast R-CNN fp32, 1000 ROIs (the headline)"
 else:
     N = 1000
     net = models.MultiPathNet(models.synthetic_mpnet_params(models.VGG16_CFG, pooled=7, fc_dim=4096, n_classes=81, n_integral=6, seed=557), max_h=600, max_w=1000, max_rois=N)
