@@ -106,7 +106,9 @@ struct SplitkSlotScope {
 // y = sum over up to three K segments of scale_seg[row % rs_mod] * (x_seg . w_seg) (+ b, ReLU): MultiPathNet's mix GEMM with nn.Normalize
 // of its three pooled maps applied where the accumulator is folded, instead of a read-modify-write pass over the pooled matrix.
 // Always launched un-split (like row_invariant = 2, so a row's result does not depend on the row count); k_end = the K index (multiple of 32) at which segment i ends.
-struct GemmRowScale { int n_seg; int k_end[2]; const float *scale[3]; int rs_mod; };
+// bin_rows > 0 (round 6): the rows are packed (bin, roi) pairs, bin_rows per bin, x_pitch rows between the operand's K chunks, and the output is
+// scattered into [N / 8][M / bin_rows][out_Mp][8] — the fc6 operand of the MultiPathNet towers (GemmArgs in dense.hip)
+struct GemmRowScale { int n_seg; int k_end[2]; const float *scale[3]; int rs_mod; int bin_rows, out_Mp, x_pitch; };
 int linear_c8_rowscaled(const float *d_x_c8, int M, int K, const float *d_wpk, const float *d_bpk, int N, int relu, float *d_y_c8, hipStream_t s,
                         int Mp_override, const GemmRowScale &rs);
 // fc6 on the bf16 matrix pipe with fp32 results (dense.hip: gemm_c8_split3_kernel): operands as three bf16 planes [3][K64 / 8][rows↑256][8]

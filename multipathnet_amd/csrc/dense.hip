@@ -1087,6 +1087,13 @@ struct GemmArgs {
   int nsb, sb0, sb1;             // interior segment boundaries (stage indices), nsb = 0: none (seg_stages applies)
   const float *rs0, *rs1, *rs2;  // scale vector of segment 0 / 1 / 2 (rs0 == nullptr: no scaling)
   int rs_mod;
+  // Round 6, MultiPathNet's mix GEMM: its rows are (bin, roi) pairs and its output IS fc6's operand [cout block][bin][Mp6][8].  Until round 5
+  // every bin carried Mp6 = N rounded up to 128 rows (49 x 1024 for 1000 proposals: 392 row tiles, 1568 blocks = 3.06 rounds of 512 resident
+  // blocks — a whole extra round for 32 blocks).  Now the operand's rows are packed, bin_rows = N rounded up to 8 per bin (49 x 1000 rows: 383
+  // row tiles, 1532 blocks = 2.99 rounds), a row tile may straddle bins, and the epilogue scatters row m to (bin m / bin_rows, roi m % bin_rows).
+  int xp;                        // row pitch of x between K chunks (Mp unless the rows are packed: the last row tile then reads past the
+                                 // chunk's rows — into the next chunk or the buffer's slack — and never stores them)
+  int bin_rows, out_Mp;          // bin_rows > 0: the scatter above into [NP/8][M / bin_rows][out_Mp][8]
 };
 
 // C8 GEMM  y[NP/8][Mp][8] = x[K/8][Mp][8] . wpk[K/8][NP][8]: 128 x 128 tile per block, KCH 8-wide K chunks per LDS stage (4 -> 32 k, 32 KiB per
@@ -1127,14 +1134,14 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
   // no VALU address arithmetic in the loop (see glds16_saddr)
   static_assert(IT == KCH, "one 1-KiB wave-load per wave per K chunk per operand");
   const unsigned dma_lane = (unsigned)((wave * 64 + lane) * 16);
-  const size_t a_stage = (size_t)KCH * a.NP * 8, b_stage = (size_t)KCH * a.Mp * 8;
+  const size_t a_stage = (size_t)KCH * a.NP * 8, b_stage = (size_t)KCH * a.xp * 8;
   const float *const a_tile = a.wpk + (size_t)n0 * 8, *const b_tile = a.x + (size_t)m0 * 8;
   const unsigned lds0 = lds_byte_addr(lds) + (unsigned)(wave * 256) * 4;
   auto issue_a = [&](int st, int s, int i) {
     glds16_saddr(a_tile + (size_t)st * a_stage + (size_t)i * a.NP * 8, dma_lane, lds0 + (unsigned)(s * STAGE + i * 1024) * 4);
   };
   auto issue_b = [&](int st, int s, int i) {
-    glds16_saddr(b_tile + (size_t)st * b_stage + (size_t)i * a.Mp * 8, dma_lane, lds0 + (unsigned)(s * STAGE + OP_FLOATS + i * 1024) * 4);
+    glds16_saddr(b_tile + (size_t)st * b_stage + (size_t)i * a.xp * 8, dma_lane, lds0 + (unsigned)(s * STAGE + OP_FLOATS + i * 1024) * 4);
   };
 
   f32x16 acc[2][2];
@@ -1301,6 +1308,15 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
         }
       }
     }
+  // where this lane's two rows go: row m of channel block nb8 at (nb8 * cb_rows + row_off) records of 8 — rows as they are, or (bin, roi) scattered
+  size_t row_off[2], cb_rows = (size_t)a.Mp;
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int m = m0 + wn * 64 + ni * 32 + l31;
+    row_off[ni] = (size_t)m;
+    if (a.bin_rows > 0) { const int bin = m / a.bin_rows; row_off[ni] = (size_t)bin * a.out_Mp + (m - bin * a.bin_rows); }
+  }
+  if (a.bin_rows > 0) cb_rows = (size_t)(a.M / a.bin_rows) * a.out_Mp;
   asm volatile("" ::: "memory");
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
@@ -1317,7 +1333,7 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
           if (a.direct && a.relu) t = t < 0.0f ? 0.0f : t;
           v[e] = t;
         }
-        if (m < a.M) *reinterpret_cast<f32x4 *>(yb + ((size_t)nb8 * a.Mp + m) * 8 + half * 4) = v;
+        if (m < a.M) *reinterpret_cast<f32x4 *>(yb + ((size_t)nb8 * cb_rows + row_off[ni]) * 8 + half * 4) = v;
       }
     }
 }
@@ -1392,6 +1408,11 @@ static int linear_c8_impl(const float *d_x_c8, int M, int K, const float *d_wpk,
   GemmArgs a{};
   a.x = d_x_c8; a.Mp = Mp_override ? Mp_override : lin_mp(M); a.wpk = d_wpk; a.NP = lin_np(N); a.bpk = d_bpk;
   a.M = M; a.relu = relu;
+  a.xp = a.Mp;
+  if (rs && rs->bin_rows > 0) {  // packed (bin, roi) rows scattered into the consumer's [cout block][bin][out_Mp][8] operand
+    MPN_CHECK_ARG(rs->bin_rows % 4 == 0 && M % rs->bin_rows == 0 && rs->out_Mp >= rs->bin_rows && rs->x_pitch >= M);
+    a.xp = rs->x_pitch; a.bin_rows = rs->bin_rows; a.out_Mp = rs->out_Mp;
+  }
   const int K64 = round_up(K, 64);
   a.n_mt = a.Mp / 128; a.n_nt = a.NP / 128;
   a.n_fast = a.n_mt > a.n_nt ? 1 : 0;

@@ -374,6 +374,7 @@ MPN_KNOB(int, g_tower_lanes, 1);  // 0: the towers of an image one after the oth
 static int g_mpn_pool_knock = 0;
 extern "C" void mpn_debug_set_mpn_pool_knock(int v) { g_mpn_pool_knock = v; }
 #endif
+MPN_KNOB(int, g_mix_packed, 1);   // 0: the mix GEMM's rows padded to 128 per bin as the fc operands are (rounds 2-5; mpn_debug_set_mix_packed)
 MPN_KNOB(int, g_tables_lazy, 1);  // 0: all range-max tables on the launch stream in front of the head (rounds 3-5) instead of per map on the pooling stream (mpn_debug_set_tables_lazy)
 MPN_KNOB(int, g_tower_order, 1);  // 0: the towers in index order instead of cheapest pooling first (mpn_debug_set_tower_order)
 MPN_KNOB(int, g_tower_share, 1);  // 0: every tower pools its own operand even where two of them pool the same region's maps (mpn_debug_set_tower_share)
@@ -397,6 +398,7 @@ extern "C" void mpn_debug_set_tower_lanes(int v) { g_tower_lanes = v; }
 extern "C" void mpn_debug_set_tower_share(int v) { g_tower_share = v; }
 extern "C" void mpn_debug_set_tower_order(int v) { g_tower_order = v; }
 extern "C" void mpn_debug_set_tables_lazy(int v) { g_tables_lazy = v; }
+extern "C" void mpn_debug_set_mix_packed(int v) { g_mix_packed = v; }
 extern "C" void mpn_debug_set_halo_memset(int v) { g_halo_memset = v; }
 extern "C" void mpn_debug_set_defer_heads(int v) { g_defer_heads = v; }
 #endif
@@ -834,6 +836,12 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
   // operand buffer / scale set of parity t & 1, under tower t - 1's GEMMs on `s`; `s` waits for the pooling only where the mix GEMM
   // starts, the pooling stream waits for the mix GEMM of tower t - 2 (the previous user of its buffers).  Every result is still
   // ordered on `s`.  (Profiling scopes time each stream's own work; with overlap their sum exceeds the wall time.)
+  // Rows of the pooled operand = the mix GEMM's rows = (bin, roi).  With the scale fold (the product path) they are PACKED: Nr = N rounded up to 8
+  // rows per bin instead of the Mp = N rounded up to 128 the fc GEMMs' operands carry, and the mix GEMM scatters its output rows into fc6's
+  // [cout block][bin][Mp][8] operand (GemmArgs::bin_rows).  1000 proposals: 49 x 1000 = 383 row tiles instead of 49 x 1024 = 392 — 1532 blocks
+  // instead of 1568 on 512 resident slots, i.e. 2.99 rounds instead of 3.06 (a whole block time per mix GEMM); 300 proposals: 115 instead of 147.
+  const int Nr = (fold_scale && g_mix_packed) ? round_up(N, 8) : Mp;
+  const int R = PP * Nr, Rp = round_up(R, 128);
   const bool overlap = pm && p->pool_stream && p->tx2 && g_pool_overlap;
   hipStream_t ps_stream = overlap ? p->pool_stream : s;
   if (!(overlap && g_tables_lazy))   // one stream (or the round-3..5 order, hook tables_lazy = 0): all tables up front
@@ -879,8 +887,9 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
     const mpn_frcnn::Tower &T = p->towers[t];
     GemmRowScale &grs = grs_of[t];
     grs = GemmRowScale{};
-    grs.rs_mod = Mp;
+    grs.rs_mod = Nr;
     if (!fold_scale) continue;
+    if (Nr != Mp) { grs.bin_rows = Nr; grs.out_Mp = Mp; grs.x_pitch = R; }
     const int used[3] = {1, T.use4, T.use3};
     int cb_off = 0;
     for (int m = 0; m < 3; ++m) {
@@ -909,18 +918,18 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
     int rcl = MPN_OK;
     for (int m = 0; m < 3; ++m) {
       if (!used[m]) continue;
-      float *dst = txb + (size_t)cb_off * PP * Mp * 8;
+      float *dst = txb + (size_t)cb_off * R * 8;
       if ((rcl = build_tables(m, ps_stream)) != MPN_OK) return rcl;   // (first reader of the map's tables this trunk run)
       { ProfScope ps(p, MPN_PROF_ROIPOOL, ps_stream);
         if (pm) {
           float *sc_out = fold_scale ? p->mix_scale + ((size_t)b * 3 + seg) * p->Mp : nullptr;
-          rcl = roi_pool_pm_rmq(maps[m], p->vmax_tab[m], reg, N, c.pooled_h, c.pooled_w, scales[m], RoiRule{1.0f, 0, c.roi_bin_rule}, dst, ps_stream, 20, Mp, p->conv345_norm ? 1 : 0,
+          rcl = roi_pool_pm_rmq(maps[m], p->vmax_tab[m], reg, N, c.pooled_h, c.pooled_w, scales[m], RoiRule{1.0f, 0, c.roi_bin_rule}, dst, ps_stream, 20, Nr, p->conv345_norm ? 1 : 0,
                                 p->conv345_norm ? 1000.0f : kConv345Factor[m], sc_out);
           ++seg;
         } else {
-          rcl = roi_pool_c8_rmq(maps[m], p->vmax_tab[m], reg, N, c.pooled_h, c.pooled_w, scales[m], RoiRule{1.0f, 0, c.roi_bin_rule}, dst, ps_stream, 20, Mp);
-          if (rcl == MPN_OK) rcl = p->conv345_norm ? l2norm_scale_c8(dst, maps[m].Cb() * PP, Mp, N, 1000.0f, ps_stream)
-                                                   : mul_const_c8(dst, maps[m].Cb() * PP, Mp, N, kConv345Factor[m], ps_stream);
+          rcl = roi_pool_c8_rmq(maps[m], p->vmax_tab[m], reg, N, c.pooled_h, c.pooled_w, scales[m], RoiRule{1.0f, 0, c.roi_bin_rule}, dst, ps_stream, 20, Nr);
+          if (rcl == MPN_OK) rcl = p->conv345_norm ? l2norm_scale_c8(dst, maps[m].Cb() * PP, Nr, N, 1000.0f, ps_stream)
+                                                   : mul_const_c8(dst, maps[m].Cb() * PP, Nr, N, kConv345Factor[m], ps_stream);
         } }
       if (rcl) return rcl;
       cb_off += maps[m].Cb();
@@ -956,7 +965,7 @@ static int run_mpnet_head(mpn_frcnn *p, const float *d_boxes, int N, int H, int 
     const GemmRowScale &grs = grs_of[ti];
     // 1x1 conv mix: rows = (bin, roi), K = concat channels, N = feat_c; output layout == fc6 operand layout
     { ProfScope ps(p, MPN_PROF_HEADS, ls);
-      rc = fold_scale ? linear_c8_rowscaled(txb, PP * Mp, T.total_feat, T.mix_w, T.mix_b, p->feat_c, 0, lane_ty[ln], ls, PP * Mp, grs)
+      rc = fold_scale ? linear_c8_rowscaled(txb, R, T.total_feat, T.mix_w, T.mix_b, p->feat_c, 0, lane_ty[ln], ls, Rp, grs)
                       : linear_c8(txb, PP * Mp, T.total_feat, T.mix_w, T.mix_b, p->feat_c, 0, lane_ty[ln], nullptr, ls, PP * Mp, nullptr, 2); }
     if (rc) return rc;
     if (overlap) MPN_CHECK_HIP(hipEventRecord(p->ev_mix_done[b], ls));

@@ -33,7 +33,7 @@ def dev():
 
 
 HOOK_DEFAULTS = dict(conv_variant=0, conv_split=0, gemm_split=0, fuse_pool=1, nms_force_exact=0, fp32_pf=1, bf16_dma=1, bf16_dma_tn=0,
-                     bf16_fast_pool=3, graph_fuse=511, first_k36=1, wino_tc=0, roi_pool_pm=1, mix_fold=1, pool_overlap=1, roi_invariant=1, nms_dense_sweep=0, nms_guard_limit=0, bf16_bdir=1, bf16_exp=0, bf16_nch=4, bf16_bdir_ver=1, bf16_bdir_abl=0, nms_fused=1, nms_fused_replay=1, nms_fused_fence=1, tower_lanes=1, tower_share=1, tower_order=1, gemm_rsi=1, split3_ranges=0, tables_lazy=1, halo_memset=0, defer_heads=1)
+                     bf16_fast_pool=3, graph_fuse=511, first_k36=1, wino_tc=0, roi_pool_pm=1, mix_fold=1, pool_overlap=1, roi_invariant=1, nms_dense_sweep=0, nms_guard_limit=0, bf16_bdir=1, bf16_exp=0, bf16_nch=4, bf16_bdir_ver=1, bf16_bdir_abl=0, nms_fused=1, nms_fused_replay=1, nms_fused_fence=1, tower_lanes=1, tower_share=1, tower_order=1, gemm_rsi=1, split3_ranges=0, tables_lazy=1, mix_packed=1, halo_memset=0, defer_heads=1)
 
 
 @contextlib.contextmanager

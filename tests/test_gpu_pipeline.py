@@ -765,6 +765,51 @@ def test_two_tower_lanes_are_invisible(dev, model):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rsi", [1, 0])
+def test_packed_mix_rows_are_invisible(dev, rsi):
+    """Round 6: the MultiPathNet mix GEMM's rows — (bin, roi) pairs — are packed, N rounded up to 8 per bin instead of to the fc operands' 128, and
+    its epilogue scatters them into fc6's [cout block][bin][Mp][8] operand (1000 proposals: 383 row tiles instead of 392).  A row's sum does
+    not depend on the tile it sits in: scores, boxes and detections are bit-identical to the padded layout (hook mix_packed = 0) for ROI counts
+    that end inside a row tile, inside a group of 8, on a multiple of 128 and within 8 of one (where the two layouts coincide), in a row on one
+    handle (the operand's pitch changes with the count), on the cached maps, with the in-place and the running-total row scales (gemm_rsi)."""
+    from multipathnet_amd import models
+    rng = np.random.default_rng(8)
+    cfg = [16, 32, "P", 32, 64, "P", 64, 96, "P", 128, "P", 384]
+    H, W, N = 150, 250, 300
+    P = models.synthetic_mpnet_params(cfg, pooled=7, fc_dim=256, n_classes=9, n_integral=3, seed=13)
+    im = torch.from_numpy(rng.random((3, H, W), dtype=np.float32)).to(dev)
+    bx = torch.from_numpy(_boxes(rng, N, W, H, lo=6)).to(dev)
+    res = {}
+    for packed, share, lanes in [(0, 1, 1), (1, 1, 1), (1, 0, 1), (1, 1, 0)]:
+        with hooks(mix_packed=packed, tower_share=share, tower_lanes=lanes, gemm_rsi=rsi):
+            net = models.MultiPathNet(P, cfg=cfg, pooled=7, spatial_scale=1 / 16, max_h=H, max_w=W, max_rois=N)
+            out = []
+            for n in (N, 100, 7, 128, 125, 297, 1, 256, 250):
+                s, b = net.detect(im, bx[:n].contiguous())
+                out.append((s.clone(), b.clone()))
+            s, b = net.detect(im, bx[40:141].contiguous(), recompute_features=False)
+            out.append((s.clone(), b.clone()))
+            for _ in range(2):
+                dets, nd = net.test_one_async(im, bx)
+                torch.cuda.synchronize()
+                out.append((dets[: int(nd.item())].clone(), nd.clone()))
+            bufs = [net.test_one_pipelined(im, bx[: (N if i % 2 else 203)].contiguous()) for i in range(4)]
+            net.flush()
+            torch.cuda.synchronize()
+            for dets, nd in bufs[-2:]:
+                out.append((dets[: int(nd.item())].clone(), nd.clone()))
+            res[(packed, share, lanes)] = out
+            del net
+    base = res[(0, 1, 1)]
+    for v, r in res.items():
+        assert len(r) == len(base)
+        for i, (a, b) in enumerate(zip(base, r)):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y), (v, i)
+    assert torch.equal(base[1][0], base[0][0][:100])          # and rows do not depend on the batch they are scored in
+
+
+@pytest.mark.gpu
 def test_range_max_tables_built_on_the_pooling_stream_are_invisible(dev):
     """Round 6: a map's range-max tables are built on the pooling stream where its first pooling is enqueued (conv5's in front of the first
     tower, conv4's / conv3's under that tower's GEMMs) instead of all of them on the launch stream in front of the head.  Pure scheduling:
