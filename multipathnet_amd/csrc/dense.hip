@@ -1122,7 +1122,11 @@ __global__ __launch_bounds__(256) void gemm_c8_pf_kernel(GemmArgs a) {
   const int half = lane >> 5, l31 = lane & 31;
   int b = blockIdx.x;
   const int nb = gridDim.x;
-  if ((nb & 7) == 0) b = (b & 7) * (nb >> 3) + (b >> 3);
+  {  // the blocks of one XCD (b mod 8, round-robin dispatch) walk neighbouring tiles: XCD x owns nb / 8 (+ 1 for x < nb mod 8) consecutive ones.
+     // (Until round 6 only launches of a multiple of 8 blocks were remapped — the packed mix GEMM's 1532 blocks fetched every row tile into four L2s.)
+    const int per = nb >> 3, rem = nb & 7, xcd = b & 7, idx = b >> 3;
+    b = xcd < rem ? xcd * (per + 1) + idx : rem * (per + 1) + (xcd - rem) * per + idx;
+  }
   const int nt = a.n_fast ? b % a.n_nt : b / a.n_mt, mt = a.n_fast ? b / a.n_nt : b - nt * a.n_mt;
   const int n0 = nt * 128, m0 = mt * 128;
   const int split = blockIdx.y;

@@ -22,6 +22,7 @@ done
 timeout 600 python $R/bench.py --config c2 --rois 2000 --steps 10 --warmup 3 > $OUT/${TAG}_bench_c2_n2000.json 2> /tmp/bench_n2000.err
 timeout 600 python $R/bench.py --fc-arith split3 --steps 20 --warmup 5 > $OUT/${TAG}_bench_split3.json 2> /tmp/bench_split3.err
 timeout 600 python $R/bench.py --fc-arith split3 --rois 2000 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_split3_n2000.json 2> /tmp/bench_split3b.err
+timeout 600 python $R/bench.py --config c3 --fc-arith split3 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_c3_split3.json 2> /tmp/bench_split3c.err
 for cfg in "c1:--config c1 --steps 50 --warmup 6" "c3:--config c3 --steps 20 --warmup 5" "c4:--config c4 --steps 6 --warmup 2" "c4_bf16:--config c4 --dtype bf16 --steps 6 --warmup 2" "c5:--config c5 --steps 6 --warmup 2"; do
   key=${cfg%%:*}; args=${cfg#*:}
   timeout 900 python $R/bench.py $args > $OUT/${TAG}_bench_$key.json 2> /tmp/bench_$key.err
