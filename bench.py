@@ -54,6 +54,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# A handle drives up to five streams (launch, NMS tail, skip pooling, second tower lane, upload) and ROCm maps a process's streams onto FOUR
+# hardware queues by default: two streams that share a queue serialise behind each other's waits (the upload stream's wait for its DMA copy
+# blocked a tower lane for the copy's 0.2 ms per image).  Measured, interleaved (profiles/r06_hw_queues.txt): configs[2] host-fed 13.19 -> 13.12 ms,
+# the headline 3.433 -> 3.426 ms, the bf16 tower configs unchanged.  A deployment setting; must be in the environment before HIP starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 H, W, N_ROIS, N_CLASSES = 600, 1000, 1000, 21
 FP32_MFMA_PEAK = 157.3e12  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
