@@ -59,6 +59,7 @@ sys.path.insert(0, ROOT)
 # blocked a tower lane for the copy's 0.2 ms per image).  Measured, interleaved (profiles/r06_hw_queues.txt): configs[2] host-fed 13.19 -> 13.12 ms,
 # the headline 3.433 -> 3.426 ms, the bf16 tower configs unchanged.  A deployment setting; must be in the environment before HIP starts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (already exported on the GPU boxes: RCCL between processes needs the dmabuf IPC path)
 
 H, W, N_ROIS, N_CLASSES = 600, 1000, 1000, 21
 FP32_MFMA_PEAK = 157.3e12  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
