@@ -54,11 +54,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# A handle drives up to five streams (launch, NMS tail, skip pooling, second tower lane, upload) and ROCm maps a process's streams onto FOUR
-# hardware queues by default: two streams that share a queue serialise behind each other's waits (the upload stream's wait for its DMA copy
-# blocked a tower lane for the copy's 0.2 ms per image).  Measured, interleaved (profiles/r06_hw_queues.txt): configs[2] host-fed 13.19 -> 13.12 ms,
-# the headline 3.433 -> 3.426 ms, the bf16 tower configs unchanged.  A deployment setting; must be in the environment before HIP starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (GPU_MAX_HW_QUEUES is deliberately NOT set here.  A handle drives up to five streams and ROCm maps a process's streams onto four hardware queues;
+# 8 queues take 0.07 ms off the host-fed configs[2] line — and cost a SECOND handle in the same process 20-25 %: the default line's auxiliary
+# split3 leg 2.90 -> 3.54-3.71 ms.  profiles/r06_hw_queues.txt)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (already exported on the GPU boxes: RCCL between processes needs the dmabuf IPC path)
 
 H, W, N_ROIS, N_CLASSES = 600, 1000, 1000, 21
