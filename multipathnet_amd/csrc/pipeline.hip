@@ -286,7 +286,12 @@ struct mpn_frcnn {
   // once into tx3, the narrower tower's mix GEMM reads its K prefix (the per-map nn.Normalize scales are per (map, region, ROI): the same)
   float *tx3 = nullptr;
   int share_provider = -1, share_consumer = -1;       // tower indices (-1: no such pair)
-  hipStream_t pool_stream = nullptr;
+  // The pooling stream IS the side stream (the NMS / top-k tail's) since the end of round 6: the tail of image i - 1 runs under image i's
+  // trunk and is long over when image i's first pooling is enqueued behind it, and the handle needs one stream fewer.  With a stream of its own
+  // the host-fed form drove five streams on ROCm's four hardware queues, and whichever stream shared a queue with the upload stream waited
+  // behind the upload's completion marker: 0.2 ms per image (configs[2] host-fed 13.26-13.31 -> 13.07-13.13 ms, profiles/r06_hw_queues.txt).
+  hipStream_t pool_stream = nullptr;   // alias of `side` (never destroyed on its own); nullptr = no overlapped pooling (plain Fast R-CNN handles)
+  bool pool_on_side = false;
   hipEvent_t ev_pool_done[3] = {nullptr, nullptr, nullptr}, ev_mix_done[3] = {nullptr, nullptr, nullptr}, ev_pool_go = nullptr;
   // two tower LANES (round 6): the towers of one image are independent until the concat (ModelParallelTable.lua:195-242 ran them on
   // different GPUs), so towers 1, 3 run on the handle's second tower stream with their own mix / fc6 buffers beside towers 0, 2, 4 on the
@@ -426,7 +431,6 @@ extern "C" void mpn_frcnn_destroy(mpn_frcnn *p) {
   for (int i = 0; i < 2; ++i) { if (p->ev_head[i]) (void)hipEventDestroy(p->ev_head[i]); if (p->ev_tail[i]) (void)hipEventDestroy(p->ev_tail[i]); }
   if (p->ev_fc7) (void)hipEventDestroy(p->ev_fc7);
   if (p->side) (void)hipStreamDestroy(p->side);
-  if (p->pool_stream) (void)hipStreamDestroy(p->pool_stream);
   for (int i = 0; i < 3; ++i) { if (p->ev_pool_done[i]) (void)hipEventDestroy(p->ev_pool_done[i]); if (p->ev_mix_done[i]) (void)hipEventDestroy(p->ev_mix_done[i]); }
   if (p->ev_pool_go) (void)hipEventDestroy(p->ev_pool_go);
   if (p->tower_stream) (void)hipStreamDestroy(p->tower_stream);
@@ -592,13 +596,14 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
       }
     if (p->share_provider >= 0) TRY(dev_alloc(p, &p->tx3, (size_t)(round_up(max_feat, 64) / 8) * rows * 8 * sizeof(float), true));
     {
-      hipError_t e = hipStreamCreateWithFlags(&p->pool_stream, hipStreamNonBlocking);
+      hipError_t e = hipSuccess;
+      p->pool_on_side = true;   // (p->side is created below)
       for (int i = 0; i < 3 && e == hipSuccess; ++i) {
         e = hipEventCreateWithFlags(&p->ev_pool_done[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_mix_done[i], hipEventDisableTiming);
       }
       if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_pool_go, hipEventDisableTiming);
-      if (e != hipSuccess) { set_error("mpn_mpnet_create: pooling stream / events: %s", hipGetErrorString(e)); mpn_frcnn_destroy(p); return MPN_EHIP; }
+      if (e != hipSuccess) { set_error("mpn_mpnet_create: pooling events: %s", hipGetErrorString(e)); mpn_frcnn_destroy(p); return MPN_EHIP; }
     }
     TRY(dev_alloc(p, &p->tx, (size_t)(round_up(max_feat, 64) / 8) * rows * 8 * sizeof(float), true));
     TRY(dev_alloc(p, &p->ty, (size_t)(lin_np(c5) / 8) * rows * 8 * sizeof(float), true));
@@ -733,6 +738,7 @@ static int create_impl(const mpn_frcnn_config *cfg, const float *const *d_conv_w
       if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_tail[i], hipEventDisableTiming);
     }
     if (e != hipSuccess) { set_error("mpn_frcnn_create: side stream/events: %s", hipGetErrorString(e)); mpn_frcnn_destroy(p); return MPN_EHIP; }
+    if (p->pool_on_side) p->pool_stream = p->side;
   }
 #undef TRY
   hipError_t e = hipDeviceSynchronize();
